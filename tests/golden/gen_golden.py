@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the upstream reference (this container only).
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.json
+
+The reference modules are imported from /root/reference through ``refstub`` (see its docstring);
+inputs come from the seeded generator ``nanomotif_amd.synth`` and are identified in every fixture
+by a sha1 digest so drift of the generator is detected.  Fixtures hold data only (inputs or their
+seeds + digests, and the reference's outputs) — no reference source text.
+
+Vectors:
+  G1  utils.subseq_indices hit lists                          -> g1_subseq_indices.json
+  G2  find_motifs_bin.motif_model_contig counts + hit arrays   -> g2_motif_model_contig.json
+  G3  model / predictive_evaluation_score grid                 -> g3_scores.json
+  G4  MotifSearcher / find_best_candidates traces              -> g4_search.json
+  G5  Motif algebra                                            -> g5_motif_algebra.json
+  G6  background window starts (random.sample, seed 1)         -> g6_background.json
+  G7  get_parent_scores / merge_motifs                         -> g7_parents_merge.json
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import random
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import refstub  # noqa: E402
+from nanomotif_amd import synth  # noqa: E402
+
+
+def sha1(arr) -> str:
+    return hashlib.sha1(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, sort_keys=True, separators=(",", ":"))
+        f.write("\n")
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ---------------------------------------------------------------------------------------------
+# motif zoo shared by G1/G2 (regex-style strings as the reference uses them)
+# ---------------------------------------------------------------------------------------------
+def motif_zoo():
+    zoo = [
+        # literals / palindromes
+        ("A", 0), ("C", 0), ("AA", 0), ("AA", 1), ("AAAA", 2), ("GATC", 1), ("GATC", 3), ("CCGG", 1),
+        ("GAATTC", 2), ("CTGCAG", 4), ("ACCCA", 4), ("CCAAAT", 4), ("TTCGAA", 5), ("GTAC", 2),
+        ("ACGT", 0), ("ACGT", 1), ("ACGT", 2), ("ACGT", 3), ("TTTT", 0), ("CAGAG", 3),
+        # gaps and bipartite
+        ("GA.TC", 1), ("A.A", 0), ("A.A", 2), ("C..G", 0), ("GCAC......GTT", 2), ("AAC......GTGC", 1),
+        ("CAC.....TGG", 1), ("A..........T", 0), ("A...................C", 0),
+        ("C....................A....................G", 21),
+        # IUPAC sets
+        ("CC[AT]GG", 1), ("G[AG].GAAG[CT]", 5), ("[AG]GC[CT]", 2), ("GC.GC", 1), ("[ACG]A[CGT]", 1),
+        ("[AC][AC][AC]", 1), ("[CGT]A", 1), ("A[ACT]", 0), ("[AG][CT][AG][CT]", 0), ("[GT]A[AC]..[ACG]C", 1),
+        # modified base not canonical / at a bracket (generic API use)
+        ("GATC", 0), ("GATC", 2), ("CC[AT]GG", 2), ("TTAA", 0), ("TTAA", 1),
+        # flanking dots (search-window form, pad 20)
+        ("." * 19 + "GATC" + "." * 18, 20), ("." * 20 + "A" + "." * 20, 20), ("." * 20 + "C" + "." * 20, 20),
+        ("." * 18 + "CCAGG" + "." * 18, 19), ("." * 14 + "GCAC......GTT" + "." * 14, 16),
+        ("." * 20 + "AATT" + "." * 17, 20), ("..GA.TC..", 3), (".A", 1), ("A.", 0),
+    ]
+    # seeded extras: random stripped motifs incl. long ones
+    for s, p, _ in synth.random_candidates(40, seed=11, mod_types=("a", "m")):
+        zoo.append((s, p))
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(20):
+        L = int(rng.integers(20, 42))
+        chars = ["."] * L
+        for q in rng.choice(L, size=int(rng.integers(3, 9)), replace=False):
+            chars[int(q)] = "ACGT"[int(rng.integers(4))]
+        if chars[0] == "." and chars[-1] == ".":
+            chars[0] = "G"
+        pos = int(rng.integers(0, L))
+        chars[pos] = "AC"[int(rng.integers(2))]
+        zoo.append(("".join(chars), pos))
+    return zoo
+
+
+def g1(nm):
+    from nanomotif.utils import subseq_indices
+    spec = synth.SynthSpec(n_contigs=3, total_bp=150_000, n_bins=1, mod_types=("a",), seed=21,
+                           min_contig_bp=40_000, n_fraction=0.002)
+    mg = synth.make_metagenome(spec)
+    seqs = [mg.contig_str(i) for i in range(3)]
+    # contig 2: add a few other IUPAC letters (match only '.')
+    s2 = list(seqs[2])
+    for k, ch in zip(range(100, 20000, 997), "RYSWKMBDHV" * 3):
+        s2[k] = ch
+    seqs[2] = "".join(s2)
+    out = {"spec": dict(n_contigs=3, total_bp=150_000, n_bins=1, seed=21, min_contig_bp=40_000, n_fraction=0.002),
+           "iupac_edits": [[k, ch] for k, ch in zip(range(100, 20000, 997), "RYSWKMBDHV" * 3)],
+           "seq_sha1": [hashlib.sha1(s.encode()).hexdigest() for s in seqs],
+           "kat": {"seq": "AATTAAATTAAGTAAAT", "AATT": [0, 5], "AA.T": [0, 4, 5, 9, 13]},  # tests/test_fasta.py:95-109
+           "cases": []}
+    from nanomotif.motif import Motif
+    for motif, pos in motif_zoo():
+        stripped = Motif(motif, pos).new_stripped_motif().string
+        for ci, s in enumerate(seqs):
+            idx = subseq_indices(stripped, s)
+            out["cases"].append({"motif": stripped, "contig": ci, "n": int(len(idx)), "sha1": sha1(idx.astype(np.int64)),
+                                 "head": idx[:4].tolist(), "tail": idx[-2:].tolist()})
+    dump("g1_subseq_indices.json", out)
+
+
+def _g2_inputs():
+    spec = synth.SynthSpec(n_contigs=1, total_bp=200_000, n_bins=1, mod_types=("a", "m"), seed=31,
+                           fixed_motifs=(("GATC", 1, "a"), ("GCACNNNNNNGTT", 2, "a"), ("AACNNNNNNGTGC", 1, "a"),
+                                         ("CCWGG", 1, "m")), n_fraction=0.001)
+    mg = synth.make_metagenome(spec)
+    return spec, mg
+
+
+def g2(nm):
+    from nanomotif.motif import Motif
+    from nanomotif.model import BetaBernoulliModel
+    fmb = nm.find_motifs_bin
+    spec, mg = _g2_inputs()
+    seq = mg.contig_str(0)
+    out = {"spec": {"n_contigs": 1, "total_bp": 200_000, "n_bins": 1, "mod_types": ["a", "m"], "seed": 31,
+                    "fixed_motifs": [list(m) for m in spec.fixed_motifs], "n_fraction": 0.001},
+           "seq_sha1": hashlib.sha1(seq.encode()).hexdigest(), "pileup_sha1": {}, "cases": []}
+    for mt in ("a", "m"):
+        p = mg.contig_pileup(0, mt)
+        frac = synth.pct_to_fraction(p["pct_hundredths"])
+        out["pileup_sha1"][mt] = {"position": sha1(p["position"]), "strand": sha1(p["strand"]),
+                                  "fraction_mod": sha1(frac), "n": int(len(frac))}
+        pile = refstub.make_pileup(["c0"] * len(frac), p["position"],
+                                   [chr(c) for c in p["strand"].tolist()], frac)
+        for (low, high) in ((0.3, 0.7), (0.1, 0.9)):
+            for zi, (motif, pos) in enumerate(motif_zoo()):
+                if (low, high) != (0.3, 0.7) and zi % 3:
+                    continue  # thin the second threshold pair
+                model, d = fmb.motif_model_contig(pile, seq, BetaBernoulliModel(), Motif(motif, pos),
+                                                  low_meth_threshold=low, high_meth_threshold=high,
+                                                  save_motif_positions=True)
+                n_mod, n_nomod = model.get_raw_counts()
+                case = {"mod_type": mt, "low": low, "high": high, "motif": motif, "pos": pos,
+                        "n_mod": int(n_mod), "n_nomod": int(n_nomod)}
+                for k, v in d.items():
+                    v = np.asarray(v, dtype=np.int64)
+                    case[k] = {"n": int(len(v)), "sha1": sha1(v), "head": v[:3].tolist()}
+                out["cases"].append(case)
+    dump("g2_motif_model_contig.json", out)
+
+
+def g3(nm):
+    from nanomotif.model import BetaBernoulliModel
+    fmb = nm.find_motifs_bin
+    out = {"cases": [], "kat": {}}
+    m = BetaBernoulliModel()
+    m.update(100, 3)
+    out["kat"] = {"update": [100, 3], "mean": m.mean(), "ppo_self": m.posterior_predictive_per_obs(m._alpha, m._beta)}
+    grid = [(0, 0), (1, 0), (0, 1), (3, 7), (10, 0), (100, 3), (1545 - 5, 0), (75, 17), (679, 74), (38207, 42),
+            (5, 100), (50, 50), (1000, 1000), (12, 900), (250000, 1200)]
+    for (a1, b1) in grid:
+        for (a2, b2) in grid:
+            nxt, cur = BetaBernoulliModel(), BetaBernoulliModel()
+            nxt.update(a1, b1)
+            cur.update(a2, b2)
+            s = fmb.predictive_evaluation_score(nxt, cur)
+            out["cases"].append({"next": [a1, b1], "cur": [a2, b2], "score": float(s),
+                                 "ppo_next": float(nxt.posterior_predictive_per_obs(nxt._alpha, nxt._beta)),
+                                 "mean_next": float(nxt.mean())})
+    dump("g3_scores.json", out)
+
+
+def _bin_inputs(spec):
+    mg = synth.make_metagenome(spec)
+    return mg
+
+
+SEARCH_BINS = {
+    # name -> (spec kwargs, mod_type)
+    "gatc_single": (dict(n_contigs=1, total_bp=200_000, n_bins=1, mod_types=("a",), seed=41,
+                         fixed_motifs=(("GATC", 1, "a"),)), "a"),
+    "ecoli_like_a": (dict(n_contigs=3, total_bp=600_000, n_bins=1, mod_types=("a", "m"), seed=42, min_contig_bp=100_000,
+                          fixed_motifs=(("GATC", 1, "a"), ("GCACNNNNNNGTT", 2, "a"), ("AACNNNNNNGTGC", 1, "a"),
+                                        ("CCWGG", 1, "m"))), "a"),
+    "ecoli_like_m": (dict(n_contigs=3, total_bp=600_000, n_bins=1, mod_types=("a", "m"), seed=42, min_contig_bp=100_000,
+                          fixed_motifs=(("GATC", 1, "a"), ("GCACNNNNNNGTT", 2, "a"), ("AACNNNNNNGTGC", 1, "a"),
+                                        ("CCWGG", 1, "m"))), "m"),
+    "geobacillus_like": (dict(n_contigs=2, total_bp=400_000, n_bins=1, mod_types=("a",), seed=43, min_contig_bp=150_000,
+                              fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCAAAT", 4, "a"),
+                                            ("GRNGAAGY", 5, "a"))), "a"),
+    "no_motif": (dict(n_contigs=1, total_bp=120_000, n_bins=1, mod_types=("a",), seed=44, fixed_motifs=()), "a"),
+}
+
+
+def model_counts(model):
+    a, b = model.get_raw_counts()
+    return [int(a), int(b)]
+
+
+def filtered_bin_pileup(mg, mod_type):
+    """Bin pileup as the reference sees it after the three pre-filters — restated minimally here
+    (coverage > 5 only; the adjacency / frequency filters are pinned separately) so the trace
+    inputs are exactly reproducible from the synth spec."""
+    cols = mg.pileup_columns(mod_type)
+    keep = cols["nvalid"] > 5
+    return {k: v[keep] for k, v in cols.items()}
+
+
+def g4(nm):
+    from nanomotif.seq import DNAsequence
+    fmb = nm.find_motifs_bin
+    out = {}
+    for name, (kw, mt) in SEARCH_BINS.items():
+        spec = synth.SynthSpec(**kw)
+        mg = synth.make_metagenome(spec)
+        cols = filtered_bin_pileup(mg, mt)
+        names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+        pile = refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()],
+                                   cols["fraction_mod"], mod_type=[mt] * len(names))
+        seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+        tmp = tempfile.mkdtemp()
+        random.seed(1)  # worker_function: set_seed(seed) -> random.seed (seed.py:5-9), default --seed 1
+        res = fmb.find_best_candidates(pile, seqs, mt, "bin0", tmp, low_meth_threshold=0.3,
+                                       high_meth_threshold=0.7, padding=20, min_kl=0.05,
+                                       max_dead_ends=25, max_rounds_since_new_best=30, score_threshold=1.5)
+        rec = {"spec": {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v))
+                        for k, v in kw.items()},
+               "mod_type": mt, "n_rows": int(len(names)), "pileup_sha1": sha1(cols["fraction_mod"]),
+               "params": dict(low=0.3, high=0.7, padding=20, min_kl=0.05, score_threshold=1.5, seed=1)}
+        bg = np.loadtxt(os.path.join(tmp, "temp", "bin0", "background_pssm.txt"))
+        rec["bin_pssm_4dp"] = bg.tolist()
+        if res is None:
+            rec["result"] = None
+        else:
+            graph, best = res
+            rec["best"] = [[m.string, int(m.mod_position)] for m in best]
+            rec["nodes"] = [{"motif": n.string, "pos": int(n.mod_position), "counts": model_counts(d["model"]),
+                             "score": float(d["score"]), "priority": float(d["priority"]), "depth": int(d["depth"]),
+                             "visited": bool(d["visited"])} for n, d in graph.nodes(data=True)]
+            rec["edges"] = [[u.string, v.string] for u, v in graph.edges()]
+        out[name] = rec
+        print(name, "best:", rec.get("best"), "nodes:", len(rec.get("nodes", [])))
+    dump("g4_search.json", out)
+
+
+def g5(nm):
+    from nanomotif.motif import Motif, align_motifs, merge_and_find_new_variants
+    from nanomotif.seq import regex_to_iupac, iupac_to_regex
+    from nanomotif.utils import motif_type
+    motifs = [("ATCG", 0), ("ATCG", 2), ("AT", 0), ("A[TCG]CG", 0), ("A.C", 0), ("CG", 0), ("CG", 1), ("CG", 2),
+              ("AGCG", 2), ("ACC", 0), ("A[CG]C", 2), ("AT.G", 2), ("....ATCG", 4), ("ATCG....", 0),
+              ("....AT..CG", 4), ("....AT..CG..", 4), ("AT[CG]G", 0), ("ATC.G.", 0), ("ATAC.G.", 2),
+              ("GATC", 1), ("G[AG].GAAG[CT]", 5), ("CC[AT]GG", 1), ("GCAC......GTT", 2), ("AAC......GTGC", 1),
+              ("." * 19 + "GATC" + "." * 18, 20), ("." * 20 + "A" + "." * 20, 20), ("A...T", 0), ("A....T", 0),
+              ("GA..A.C", 4), ("T.A", 2), ("GGCA[AT]", 2), ("GGCAAT", 2), ("GGCAAT", 4), ("AATTT", 0), ("AATTT", 1),
+              ("AATTTT", 0), ("TTAAGGAG", 6), ("TTAA", 3), ("ACGT", 0), ("ACG", 0), ("CGT", 1), ("ACGTG", 0),
+              ("TGCA", 1), ("C.A.G", 2), ("..C.A.G..", 4), ("[AC]A[GT]", 1)]
+    out = {"unary": [], "binary": [], "iupac": [], "align": [], "merge_variants": []}
+    for s, p in motifs:
+        m = Motif(s, p)
+        st = m.new_stripped_motif()
+        rc = st.reverse_compliment()
+        out["unary"].append({
+            "motif": s, "pos": p, "split": m.split(), "length": m.length(), "trimmed_length": m.trimmed_length(),
+            "stripped": [st.string, int(st.mod_position)], "revcomp_of_stripped": [rc.string, int(rc.mod_position)],
+            "one_hot": m.one_hot().tolist(), "iupac": st.iupac(),
+            "isolated": {str(k): [bool(m.have_isolated_bases(isolation_size=k)),
+                                  int(m.count_isolated_bases(isolation_size=k))] for k in (1, 2, 3)},
+            "motif_type_of_iupac": motif_type(st.iupac()),
+        })
+    for s1, p1 in motifs:
+        for s2, p2 in motifs:
+            a, b = Motif(s1, p1), Motif(s2, p2)
+            rec = {"a": [s1, p1], "b": [s2, p2], "sub_motif_of": bool(a.sub_motif_of(b)),
+                   "sub_string_of": bool(a.sub_string_of(b)), "distance": int(a.distance(b)), "eq": bool(a == b)}
+            try:
+                mg = a.merge(b)
+                rec["merge"] = [mg.string, int(mg.mod_position)]
+            except Exception as e:  # noqa: BLE001
+                rec["merge"] = None
+            try:
+                mg = a.merge_no_strip(b)
+                rec["merge_no_strip"] = [mg.string, int(mg.mod_position)]
+            except Exception as e:  # noqa: BLE001
+                rec["merge_no_strip"] = None
+            out["binary"].append(rec)
+    for s in ["GATC", "GRNGAAGY", "CCWGG", "GCACNNNNNNGTT", "NNANN", "BDHV", "KMSWRY", "ACGTN"]:
+        out["iupac"].append({"iupac": s, "regex": iupac_to_regex(s), "roundtrip": regex_to_iupac(iupac_to_regex(s)),
+                             "type": motif_type(s)})
+    for s in ["NNANNNNNNNNTNN", "ANNNT", "ANNT", "GATC", "GAATTC", "ANNTNNC", "ANNNNNNT"]:
+        out["iupac"].append({"iupac": s, "regex": iupac_to_regex(s), "roundtrip": s, "type": motif_type(s)})
+    groups = [[("GATC", 1), ("GATG", 1)], [("A.C", 0), ("CA.C", 1), ("A.CT", 0)],
+              [("GGCAAT", 2), ("GGCATT", 2)], [("TCAGG", 2), ("CCAGG", 2), ("CCTGG", 2)],
+              [("AGAAG[CT]", 3), ("GGAAG[CT]", 3)], [("GA.GAAGC", 5), ("GG.GAAGT", 5), ("GA.GAAGT", 5)],
+              [("." * 18 + "ACAGG" + "." * 18, 20), ("." * 18 + "CCAGG" + "." * 18, 20)]]
+    for g in groups:
+        ms = [Motif(s, p) for s, p in g]
+        al = align_motifs(ms)
+        out["align"].append({"in": g, "out": [[m.string, int(m.mod_position)] for m in al]})
+        merged, pre, new = merge_and_find_new_variants(ms)
+        out["merge_variants"].append({"in": g, "merged": [merged.string, int(merged.mod_position)],
+                                      "pre": sorted([m.string, int(m.mod_position)] for m in pre),
+                                      "new": sorted([m.string, int(m.mod_position)] for m in new)})
+    dump("g5_motif_algebra.json", out)
+
+
+def g6(nm):
+    from nanomotif.seq import DNAsequence
+    spec = synth.SynthSpec(n_contigs=2, total_bp=60_000, n_bins=1, mod_types=("a",), seed=51, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    out = {"spec": dict(n_contigs=2, total_bp=60_000, n_bins=1, seed=51, min_contig_bp=20_000), "cases": []}
+    random.seed(1)
+    for i in range(2):
+        s = mg.contig_str(i)
+        for base in ("A", "C"):
+            n = max(int(np.ceil(len(s) * 0.01)), 50)
+            st = DNAsequence(s).sample_n_subsequences_unique(41, n, base)
+            seqs = [x.sequence for x in st.sequences]
+            out["cases"].append({"contig": i, "base": base, "n": n,
+                                 "windows_sha1": hashlib.sha1("".join(seqs).encode()).hexdigest(),
+                                 "first": seqs[:2], "pssm": st.pssm().tolist()})
+    dump("g6_background.json", out)
+
+
+def g7(nm):
+    from nanomotif.motif import Motif, merge_motifs
+    from nanomotif.seq import DNAsequence
+    fmb = nm.find_motifs_bin
+    kw, mt = SEARCH_BINS["geobacillus_like"]
+    mg = synth.make_metagenome(synth.SynthSpec(**kw))
+    cols = filtered_bin_pileup(mg, mt)
+    names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+    pile = refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()],
+                               cols["fraction_mod"], mod_type=[mt] * len(names))
+    seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+    out = {"bin": "geobacillus_like", "parents": [], "merge": []}
+    pad = 20
+    def W(core, pos):  # 41-wide search-window form
+        left = pad - pos
+        return Motif("." * left + core + "." * (41 - left - len(core)), pad)
+    for core, pos in [("GATC", 1), ("GA.GAAG", 5), ("G[AG].GAAG[CT]", 5), ("ACCCA", 4), ("CCAAAT", 4), ("TGATCA", 2),
+                      ("GATCG.T", 1), ("A", 0), ("CA", 1)]:
+        m = W(core, pos)
+        ps = fmb.get_parent_scores(m, pile, seqs, 0.3, 0.7)
+        out["parents"].append({"motif": [m.string, pad],
+                               "parents": [{"motif": k.string, "motif_position": int(v["motif_position"]),
+                                            "parent_counts": model_counts(v["parent_model"]),
+                                            "child_counts": model_counts(v["child_model"]),
+                                            "score": float(v["score"])} for k, v in ps.items()]})
+    sets = [[W("GAAGAAGC", 5), W("GGAGAAGT", 5), W("GAGGAAGT", 5), W("GATC", 1)],
+            [W("ACCCA", 4), W("ACCCAT", 4), W("CCAAAT", 4)],
+            [W("CCAGG", 1), W("CCTGG", 1), W("GATCA", 1), W("GATCT", 1)]]
+    for ms in sets:
+        res = merge_motifs(ms)
+        recs = []
+        for _, (merged, cluster, pre, new) in res.items():
+            recs.append({"merged": [merged.string, int(merged.mod_position)],
+                         "cluster": sorted([m.string, int(m.mod_position)] for m in cluster),
+                         "pre": sorted([m.string, int(m.mod_position)] for m in pre),
+                         "new": sorted([m.string, int(m.mod_position)] for m in new)})
+        out["merge"].append({"in": [[m.string, int(m.mod_position)] for m in ms],
+                             "out": sorted(recs, key=lambda r: r["merged"])})
+    dump("g7_parents_merge.json", out)
+
+
+if __name__ == "__main__":
+    nm = refstub.load_reference()
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for w in which:
+        globals()[w](nm)
