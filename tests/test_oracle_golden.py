@@ -1,0 +1,284 @@
+"""Pin the CPU oracle against vectors recorded from the real reference (tests/golden/gen_golden.py)
+and against the literal known-answer values of the reference's own tests."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, oracle_bin_inputs, sha1, spec_from_json
+from nanomotif_amd import synth
+from oracle import motif as om
+from oracle import pileup as op
+from oracle import postprocess as opp
+from oracle import scan as osc
+from oracle import search as ose
+from oracle.model import BetaBernoulliModel, predictive_evaluation_score
+from oracle.motif import Motif
+
+
+# ------------------------------------------------------------------ G1: subseq_indices
+def _g1_seqs(g):
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    seqs = [mg.contig_str(i) for i in range(3)]
+    s2 = list(seqs[2])
+    for k, ch in g["iupac_edits"]:
+        s2[k] = ch
+    seqs[2] = "".join(s2)
+    import hashlib
+    assert [hashlib.sha1(s.encode()).hexdigest() for s in seqs] == g["seq_sha1"], "synthetic generator drifted"
+    return seqs
+
+
+def test_g1_subseq_indices():
+    g = load_golden("g1_subseq_indices.json")
+    assert osc.subseq_indices("AATT", g["kat"]["seq"]).tolist() == g["kat"]["AATT"]      # tests/test_fasta.py:95-109
+    assert osc.subseq_indices("AA.T", g["kat"]["seq"]).tolist() == g["kat"]["AA.T"]
+    seqs = _g1_seqs(g)
+    for c in g["cases"]:
+        idx = osc.subseq_indices(c["motif"], seqs[c["contig"]])
+        assert len(idx) == c["n"] and sha1(idx.astype(np.int64)) == c["sha1"], c["motif"]
+
+
+# ------------------------------------------------------------------ G2: motif_model_contig
+def test_reference_kat_methylated_motif_occurrences():
+    # tests/test_motif_find.py:14-39
+    m = Motif("ACG", 0)
+    a, b = osc.methylated_motif_occourances(m, "TACGGACGCCACG", np.array([1, 5]), np.array([10]))
+    assert a.tolist() == [1, 5] and b.tolist() == [10]
+    a, b = osc.methylated_motif_occourances(m, "TACGGACGCCACG", np.array([]), np.array([1, 10]))
+    assert a.tolist() == [] and b.tolist() == [1, 10]
+
+
+def test_g2_motif_model_contig():
+    g = load_golden("g2_motif_model_contig.json")
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    seq = mg.contig_str(0)
+    import hashlib
+    assert hashlib.sha1(seq.encode()).hexdigest() == g["seq_sha1"]
+    piles = {}
+    for mt in ("a", "m"):
+        p = mg.contig_pileup(0, mt)
+        frac = synth.pct_to_fraction(p["pct_hundredths"])
+        assert sha1(frac) == g["pileup_sha1"][mt]["fraction_mod"] and sha1(p["position"]) == g["pileup_sha1"][mt]["position"]
+        piles[mt] = osc.ContigPileup(p["position"], p["strand"], frac)
+    for c in g["cases"]:
+        model, d = osc.motif_model_contig(piles[c["mod_type"]], seq, BetaBernoulliModel(), Motif(c["motif"], c["pos"]),
+                                          c["low"], c["high"], save_motif_positions=True)
+        assert list(model.get_raw_counts()) == [c["n_mod"], c["n_nomod"]], c
+        for k in ("index_meth_fwd", "index_nonmeth_fwd", "index_meth_rev", "index_nonmeth_rev"):
+            assert len(d[k]) == c[k]["n"] and sha1(d[k].astype(np.int64)) == c[k]["sha1"], (c["motif"], k)
+
+
+# ------------------------------------------------------------------ G3: scores
+def test_g3_scores():
+    g = load_golden("g3_scores.json")
+    m = BetaBernoulliModel()
+    m.update(*g["kat"]["update"])
+    assert m.mean() == g["kat"]["mean"]
+    assert abs(m.posterior_predictive_per_obs(m._alpha, m._beta) - g["kat"]["ppo_self"]) < 1e-12
+    for c in g["cases"]:
+        nxt, cur = BetaBernoulliModel(), BetaBernoulliModel()
+        nxt.update(*c["next"])
+        cur.update(*c["cur"])
+        s = predictive_evaluation_score(nxt, cur)
+        assert s == pytest.approx(c["score"], rel=1e-12, abs=1e-12)
+        assert nxt.mean() == c["mean_next"]
+
+
+# ------------------------------------------------------------------ G5: motif algebra
+def test_g5_motif_algebra():
+    g = load_golden("g5_motif_algebra.json")
+    for u in g["unary"]:
+        m = Motif(u["motif"], u["pos"])
+        st = m.new_stripped_motif()
+        rc = st.reverse_compliment()
+        assert m.split() == u["split"] and m.length() == u["length"] and m.trimmed_length() == u["trimmed_length"]
+        assert [st.string, st.mod_position] == u["stripped"]
+        assert [rc.string, rc.mod_position] == u["revcomp_of_stripped"]
+        assert m.one_hot().tolist() == u["one_hot"] and st.iupac() == u["iupac"]
+        for k, (h, n) in u["isolated"].items():
+            assert m.have_isolated_bases(isolation_size=int(k)) == h and m.count_isolated_bases(isolation_size=int(k)) == n
+        assert om.motif_type(st.iupac()) == u["motif_type_of_iupac"]
+    for b in g["binary"]:
+        x, y = Motif(*b["a"]), Motif(*b["b"])
+        assert x.sub_motif_of(y) == b["sub_motif_of"], b
+        assert x.sub_string_of(y) == b["sub_string_of"], b
+        assert x.distance(y) == b["distance"], b
+        assert (x == y) == b["eq"]
+        if b["merge"] is not None:
+            mg = x.merge(y)
+            assert [mg.string, mg.mod_position] == b["merge"], b
+        if b["merge_no_strip"] is not None:
+            mg = x.merge_no_strip(y)
+            assert [mg.string, mg.mod_position] == b["merge_no_strip"], b
+    for c in g["iupac"]:
+        assert om.iupac_to_regex(c["iupac"]) == c["regex"] and om.regex_to_iupac(c["regex"]) == c["roundtrip"]
+        assert om.motif_type(c["iupac"]) == c["type"]
+    for c in g["align"]:
+        al = om.align_motifs([Motif(s, p) for s, p in c["in"]])
+        assert [[m.string, m.mod_position] for m in al] == c["out"]
+    for c in g["merge_variants"]:
+        merged, pre, new = om.merge_and_find_new_variants([Motif(s, p) for s, p in c["in"]])
+        assert [merged.string, merged.mod_position] == c["merged"]
+        assert sorted([m.string, m.mod_position] for m in pre) == c["pre"]
+        assert sorted([m.string, m.mod_position] for m in new) == c["new"]
+
+
+def test_reference_kat_motif():
+    # literal values of tests/test_candidate.py:42-64 and tests/test_motif_find.py:42-84
+    assert Motif("ATCG", 0).reverse_compliment() == Motif("CGAT", 3)
+    assert Motif("AT[CG]G", 0).reverse_compliment() == Motif("C[CG]AT", 3)
+    assert Motif("ATAC.G.", 2).reverse_compliment() == Motif(".C.GTAT", 4)
+    assert Motif("....AT..CG..", 4).new_stripped_motif().reverse_compliment() == Motif("CG..AT", 5)
+    m = [Motif("ACGT", 0), Motif("ACG", 0), Motif("CGT", 1), Motif("ACGTG", 0), Motif("TGCA", 1)]
+    rel = set(opp.get_motif_parental_relationship(m))
+    assert rel == {(m[1], m[0]), (m[1], m[3]), (m[2], m[0]), (m[2], m[3]), (m[0], m[3])}
+    m = [Motif("GGCA[AT]", 2), Motif("GGCAAT", 2), Motif("GGCAAT", 4), Motif("AATTT", 0), Motif("AATTT", 1), Motif("AATTTT", 0)]
+    rel = set(opp.get_motif_parental_relationship(m))
+    assert rel == {(m[0], m[1]), (m[0], m[2]), (m[3], m[5]), (m[4], m[5])}
+    m = [Motif("TTAAGGAG", 6), Motif("TTAA", 3)]
+    assert set(opp.get_motif_parental_relationship(m)) == {(m[1], m[0])}
+
+
+# ------------------------------------------------------------------ G6: background sampling
+def test_g6_background_windows():
+    import hashlib
+    g = load_golden("g6_background.json")
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    random.seed(1)
+    for c in g["cases"]:
+        s = mg.contig_str(c["contig"])
+        w = ose.sample_n_subsequences_unique(s, 41, c["n"], c["base"])
+        assert hashlib.sha1("".join(w).encode()).hexdigest() == c["windows_sha1"] and w[:2] == c["first"]
+        assert np.array_equal(ose.letter_pssm(w), np.array(c["pssm"]))
+
+
+# ------------------------------------------------------------------ G4: search traces
+@pytest.mark.parametrize("name", ["gatc_single", "ecoli_like_a", "ecoli_like_m", "geobacillus_like", "no_motif"])
+def test_g4_search_trace(name):
+    g = load_golden("g4_search.json")[name]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    pile, seqs = oracle_bin_inputs(mg, g["mod_type"])
+    assert sum(len(p) for p in pile.values()) == g["n_rows"]
+    P = g["params"]
+    random.seed(P["seed"])
+    res = ose.find_best_candidates(pile, seqs, g["mod_type"], P["low"], P["high"], P["padding"], min_kl=P["min_kl"],
+                                   max_dead_ends=25, max_rounds_since_new_best=30, score_threshold=P["score_threshold"])
+    assert res is not None
+    graph, best, bin_pssm = res
+    assert np.allclose(bin_pssm, np.array(g["bin_pssm_4dp"]), atol=5.1e-5, rtol=0)  # fixture is the %.4f text dump
+    got_nodes = {(n.string, n.mod_position): d for n, d in graph.nodes.items()}
+    assert len(got_nodes) == len(g["nodes"])
+    assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
+    for r in g["nodes"]:
+        d = got_nodes[(r["motif"], r["pos"])]
+        assert list(d["model"].get_raw_counts()) == r["counts"], r["motif"]
+        assert d["score"] == pytest.approx(r["score"], abs=1e-9, rel=1e-9), r["motif"]
+        assert d["priority"] == pytest.approx(r["priority"], abs=1e-12, rel=1e-12)
+        assert d["depth"] == r["depth"] and d["visited"] == r["visited"]
+    assert sorted((u.string, v.string) for u, v in graph.edges()) == sorted(map(tuple, g["edges"]))
+    assert sorted((m.string, m.mod_position) for m in best) == sorted(map(tuple, g["best"]))
+    assert [(m.string, m.mod_position) for m in best][:1] == [tuple(x) for x in g["best"]][:1]
+
+
+# ------------------------------------------------------------------ G7: parents + merge
+def test_g7_parents_and_merge():
+    g = load_golden("g7_parents_merge.json")
+    gs = load_golden("g4_search.json")[g["bin"]]
+    mg = synth.make_metagenome(spec_from_json(gs["spec"]))
+    pile, seqs = oracle_bin_inputs(mg, gs["mod_type"])
+    for c in g["parents"]:
+        ps = ose.get_parent_scores(Motif(*c["motif"]), pile, seqs, 0.3, 0.7)
+        assert [k.string for k in ps] == [p["motif"] for p in c["parents"]]
+        for (k, v), p in zip(ps.items(), c["parents"]):
+            assert v["motif_position"] == p["motif_position"]
+            assert list(v["parent_model"].get_raw_counts()) == p["parent_counts"]
+            assert list(v["child_model"].get_raw_counts()) == p["child_counts"]
+            assert v["score"] == pytest.approx(p["score"], abs=1e-9, rel=1e-9)
+    for c in g["merge"]:
+        res = om.merge_motifs([Motif(s, p) for s, p in c["in"]])
+        got = sorted(({"merged": [m.string, m.mod_position],
+                       "cluster": sorted([x.string, x.mod_position] for x in cl),
+                       "pre": sorted([x.string, x.mod_position] for x in pre),
+                       "new": sorted([x.string, x.mod_position] for x in new)} for m, cl, pre, new in res),
+                     key=lambda r: r["merged"])
+        assert got == c["out"]
+
+
+# ------------------------------------------------------------------ pileup filters (reference KATs)
+def test_adjacency_filter_kat():
+    # tests/test_dataload.py:37-69
+    t = dict(contig=np.array(["contig1"] * 10, dtype=object), position=np.arange(10, dtype=np.int64),
+             mod_type=np.array(["m6A"] * 10, dtype=object), strand=np.array(["+"] * 10, dtype=object),
+             fraction_mod=np.array([0.8, 0.9, 0.1, 0.95, 0.85, 0.2, 0.75, 0.9, 0.05, 0.8]),
+             Nvalid_cov=np.full(10, 10))
+    f = op.filter_pileup_adjacency_filter(t, methylation_threshold=0.7, adjacency_distance=1)
+    assert f["position"].tolist() == [1, 2, 3, 5, 7, 8, 9]
+    t = dict(contig=np.array(["contig1"] * 5 + ["contig2"] * 5, dtype=object),
+             position=np.array(list(range(5)) + list(range(5)), dtype=np.int64),
+             mod_type=np.array(["m6A", "5mC"] * 5, dtype=object), strand=np.array(["+"] * 5 + ["-"] * 5, dtype=object),
+             fraction_mod=np.array([0.8, 0.9, 0.1, 0.95, 0.85, 0.2, 0.75, 0.9, 0.05, 0.8]), Nvalid_cov=np.full(10, 10))
+    f = op.filter_pileup_adjacency_filter(t, methylation_threshold=0.7, adjacency_distance=1)
+    assert f["position"][f["contig"] == "contig1"].tolist() == [1, 2, 3]
+    assert f["position"][f["contig"] == "contig2"].tolist() == [0, 2, 3, 4]
+
+
+def test_frequency_and_coverage_filters():
+    n = 200_000
+    t = dict(contig=np.array(["c1"] * n + ["c2"] * 100, dtype=object), position=np.arange(n + 100, dtype=np.int64),
+             mod_type=np.array(["a"] * (n + 100), dtype=object), strand=np.array(["+"] * (n + 100), dtype=object),
+             fraction_mod=np.zeros(n + 100), Nvalid_cov=np.full(n + 100, 6))
+    t["fraction_mod"][:51] = 0.71       # c1: 51 > 50 and 51/200000 > 1e-4
+    t["fraction_mod"][n:n + 50] = 0.9    # c2: 50 is not > 50
+    t["Nvalid_cov"][60] = 5             # strict > 5
+    f = op.filter_pileup_minimummod_frequency(op.filter_pileup(t))
+    assert set(f["contig"].tolist()) == {"c1"} and len(f["position"]) == n - 1
+    t["fraction_mod"][50] = 0.7          # not > 0.7 -> only 50 modified rows left
+    assert len(op.filter_pileup_minimummod_frequency(t)["position"]) == 0
+
+
+# ------------------------------------------------------------------ postprocess (reference KATs)
+def _rows(motifs, pos, mod="m", models=None, scores=None):
+    models = models or [BetaBernoulliModel() for _ in motifs]
+    scores = scores or [1.0] * len(motifs)
+    return [opp.derive(dict(reference="ref1", motif=m, mod_type=mod, mod_position=p, model=mo, score=s))
+            for m, p, mo, s in zip(motifs, pos, models, scores)]
+
+
+def test_join_motif_complements_kats():
+    # tests/test_postprocess.py:17-146
+    r = opp.join_motif_complements(_rows(["AAGGTT", "AACCTT"], [0, 0]))
+    assert [x["motif"] for x in r] == ["AAGGTT"] and [x["motif_complement"] for x in r] == ["AACCTT"]
+    r = opp.join_motif_complements(_rows(["GATCC", "GATCG"], [0, 0]))
+    assert {x["motif"] for x in r} == {"GATCC", "GATCG"} and [x["motif_complement"] for x in r] == [None, None]
+    r = opp.join_motif_complements(_rows(["GCGC", "GATC"], [1, 2]))
+    assert {x["motif"] for x in r} == {"GCGC", "GATC"} and {x["motif_complement"] for x in r} == {"GCGC", "GATC"}
+    r = opp.join_motif_complements(_rows(["GCGC", "GCGC"], [1, 3]))
+    assert [x["motif"] for x in r] == ["GCGC"] * 4 and [x["motif_complement"] for x in r] == ["GCGC"] * 4
+    motifs = ["AATT", "GATC", "CCA......TGCC", "CAGACG..G", "GGCA......TGG", "GGGAGC", "TTAA", "CTCGAG", "GCAGATG"]
+    r = opp.join_motif_complements(_rows(motifs, [1, 1, 2, 3, 3, 3, 3, 4, 4], mod="a"))
+    assert [x["motif"] for x in r] == ["AATT", "GATC", "CAGACG..G", "GGCA......TGG", "GGGAGC", "TTAA", "CTCGAG", "GCAGATG"]
+    assert [x["motif_complement"] for x in r] == ["AATT", "GATC", None, "CCA......TGCC", None, "TTAA", "CTCGAG", None]
+
+
+def test_remove_noisy_motifs_kat():
+    rows = _rows(["AAGGTT", "AACCTT", "GATCC"], [0, 0, 0])
+    assert len(opp.remove_noisy_motifs(rows)) == 3         # tests/test_postprocess.py:147-162
+    rows = _rows(["A....T", "GATC"], [0, 1])
+    assert [r["motif"] for r in opp.remove_noisy_motifs(rows)] == ["GATC"]
+    rows = _rows(["A....T"], [0])
+    assert len(opp.remove_noisy_motifs(rows)) == 1         # all noisy -> unchanged (postprocess.py:21-22)
+
+
+def test_full_chain_runs_and_formats():
+    g = load_golden("g4_search.json")["geobacillus_like"]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    pile, seqs = oracle_bin_inputs(mg, "a")
+    random.seed(1)
+    graph, best, _ = ose.find_best_candidates(pile, seqs, "a", 0.3, 0.7, 20, min_kl=0.05, score_threshold=1.5)
+    rows = opp.process_bin(pile, seqs, "bin0", "a", graph, best, 20)
+    text = opp.format_bin_motifs(rows)
+    lines = text.strip().split("\n")
+    assert lines[0].split("\t") == opp.HEADER
+    found = {l.split("\t")[1] for l in lines[1:]}
+    assert {"GATC", "ACCCA", "CCAAAT"} <= found and any(m.startswith("G") and m.endswith("GAAGY") for m in found), found
