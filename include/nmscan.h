@@ -1,0 +1,127 @@
+/*
+ * nmscan.h — C ABI of libnmscan.so, the MI355X (gfx950) motif-scan / methylation-count engine.
+ *
+ * Drop-in boundary.  The reference (MicrobialDarkMatter/nanomotif, pure Python) has no FFI; the seam this
+ * library replaces is the Python call
+ *
+ *     motif_model_bin(pileup, contigs, motif, model, low, high) -> BetaBernoulliModel
+ *         nanomotif/find_motifs_bin.py:1265-1283  (per contig: motif_model_contig, :1285-1331;
+ *         scan = utils.subseq_indices, utils.py:44-67; count = methylated_motif_occourances, :1234-1263)
+ *
+ * which is called once per candidate from MotifSearcher.run (:1035, :1128), get_parent_scores (:1400, :1418)
+ * and merge_motifs_in_df (:1462, :1473, :1503).  Each entry point below names the reference lines whose
+ * work it takes over.  The Python host (nanomotif_amd/engine.py) binds these with ctypes; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative nm_status; nm_last_error() gives the text
+ * for the calling thread.  The caller owns all host buffers (they may be freed when the call returns);
+ * the library owns all device memory inside the opaque nm_ctx.  One ctx per GPU / process; calls on one ctx
+ * are not re-entrant.  No torch / C++ types cross this boundary.
+ */
+#ifndef NMSCAN_H
+#define NMSCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nm_ctx nm_ctx;
+
+typedef enum nm_status {
+    NM_OK = 0,
+    NM_EINVAL = -1,      /* bad argument (message says which) */
+    NM_EHIP = -2,        /* HIP runtime error */
+    NM_ESTATE = -3,      /* call order (e.g. scoring before contigs / pileup were uploaded) */
+    NM_ENOMEM = -4,
+    NM_ERANGE = -5       /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
+} nm_status;
+
+#define NM_MAX_MOTIF_LEN 64   /* stripped motif length; offsets relative to the modified base in [-64, 63] */
+#define NM_MAX_MOD_SLOTS 4    /* modification types resident at once (reference: m, a, 21839 — constants.py:29-33) */
+
+/* motif position sets are 4-bit masks: bit0 = A, bit1 = C, bit2 = G, bit3 = T; 15 = '.'/N (any character,
+ * including non-ACGT assembly letters — regex '.' semantics of utils.py:61-66). */
+#define NM_BASE_A 1
+#define NM_BASE_C 2
+#define NM_BASE_G 4
+#define NM_BASE_T 8
+
+int nm_abi_version(void);
+const char *nm_last_error(void);
+
+/* Create / destroy an engine bound to HIP device `device`. */
+int nm_ctx_create(int device, nm_ctx **out);
+int nm_ctx_destroy(nm_ctx *ctx);
+
+/* Run all subsequent work of this ctx on `hip_stream` (a hipStream_t, e.g. torch's current stream);
+ * NULL restores the ctx's own stream. */
+int nm_set_stream(nm_ctx *ctx, void *hip_stream);
+
+/*
+ * Assembly upload — replaces the per-call `contig_sequence.sequence` strings handed to motif_model_contig
+ * (find_motifs_bin.py:1273-1277; loaded and upper-cased by fasta.py:35-49 / seq.py:53-56).
+ *   offsets[n_contigs+1]  byte offsets of each contig inside seq_ascii (offsets[0] = 0)
+ *   bin_id[n_contigs]     bin of each contig, 0 <= bin_id < n_bins
+ *   seq_ascii             concatenated sequences, any case; non-ACGT letters are kept as "matches only '.'"
+ * Packs on the device into bit-sliced planes (2 bits/bp + validity plane), contigs grouped by bin.
+ */
+int nm_upload_contigs(nm_ctx *ctx, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
+                      uint32_t n_bins, const uint8_t *seq_ascii);
+
+/*
+ * Pileup upload for one modification type — replaces the six polars filters executed per candidate per contig
+ * (find_motifs_bin.py:1274, 1308-1314): rows are classified ONCE, methylated <=> fraction_mod >= high,
+ * unmethylated <=> fraction_mod <= low (float64 compares, same expression as the reference).
+ *   mod_slot        0..NM_MAX_MOD_SLOTS-1, chosen by the caller
+ *   canonical_base  'A' or 'C' (constants.py MOD_TYPE_TO_CANONICAL)
+ *   rows (SoA, post pre-filter): contig_id (index into the uploaded contigs), position (0-based), strand
+ *   ('+' / '-'), fraction_mod (= percent / 100, dataload.py:85).  (contig, position, strand) must be unique.
+ *   append != 0 adds rows to the slot (streaming in chunks); append == 0 clears the slot first.
+ */
+int nm_upload_pileup(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_base, double low, double high,
+                     uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                     const uint8_t *strand, const double *fraction_mod, int append);
+
+/*
+ * Score a batch of candidate motifs — replaces n_cand calls of motif_model_bin(..., BetaBernoulliModel())
+ * (find_motifs_bin.py:1265-1283).  Candidate k is the STRIPPED motif (motif.py:213-224) given as
+ * cand_len[k] position masks starting at cand_masks[cand_mask_offset[k]], with the modified base at index
+ * cand_modpos[k]; it is scored against every contig of bin cand_bin[k] on both strands (forward motif vs
+ * '+' rows, reverse complement vs '-' rows, find_motifs_bin.py:1316-1317).
+ *   out_counts[2k] = n_mod, out_counts[2k+1] = n_nomod  (what model.update receives, :1320)
+ * nm_score_batch writes host memory and returns when done; nm_score_batch_device writes device memory
+ * (e.g. a torch int64 tensor's data_ptr) asynchronously on the ctx stream so the caller can all-reduce it
+ * with RCCL before reading.
+ */
+int nm_score_batch(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                   const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                   const uint8_t *cand_masks, int64_t *out_counts);
+int nm_score_batch_device(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                          const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                          const uint8_t *cand_masks, int64_t *d_out_counts);
+
+/*
+ * Hit positions of one candidate on one contig — the four arrays motif_model_contig returns with
+ * save_motif_positions=True (find_motifs_bin.py:1322-1329), ascending.  which: 0 = index_meth_fwd,
+ * 1 = index_nonmeth_fwd, 2 = index_meth_rev, 3 = index_nonmeth_rev.  Writes at most `capacity` positions to
+ * `out`, always stores the full count in *n_out.
+ */
+int nm_hit_positions(nm_ctx *ctx, uint32_t contig_id, uint32_t mod_slot, uint8_t len, uint8_t modpos,
+                     const uint8_t *masks, int which, int64_t *out, uint64_t capacity, uint64_t *n_out);
+
+/* Engine facts for measurement: what[0] = total bp uploaded, [1] = padded bp resident, [2] = bytes of the
+ * sequence planes, [3] = bytes of one mod slot's compact state planes, [4] = kernel launches so far,
+ * [5] = workgroups of the last scoring launch, [6] = candidates of the last launch scored on the
+ * strand-implied ("compact") state, [7] = on the general 4-plane state. */
+int nm_stats(nm_ctx *ctx, uint64_t what[8]);
+
+/* Device time of the last scoring launch(es) in milliseconds, measured with HIP events on the ctx stream
+ * (kernels only, no copies).  Blocks until the launch finished. */
+int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMSCAN_H */

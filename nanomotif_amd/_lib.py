@@ -1,0 +1,66 @@
+"""ctypes binding of libnmscan.so (C ABI: include/nmscan.h).
+
+The library is built in-tree by ``nanomotif_amd.build.build()`` (hipcc, gfx950) and must be present:
+there is NO CPU fallback — importing the product path without it raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnmscan.so")
+
+SYMBOLS = [
+    "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
+    "nm_upload_pileup", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
+    "nm_last_kernel_ms",
+]
+
+_lib = None
+
+
+class NmScanError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libnmscan.so (after torch, so both share one HIP runtime) and declare prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NmScanError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  nanomotif_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  — loads torch's bundled libamdhip64 first; SONAME matches ours
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    p = C.c_void_p
+    u8p, u32p, u64p, i64p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int64, C.c_double))
+    lib.nm_abi_version.restype = C.c_int
+    lib.nm_last_error.restype = C.c_char_p
+    lib.nm_ctx_create.argtypes = [C.c_int, C.POINTER(p)]
+    lib.nm_ctx_destroy.argtypes = [p]
+    lib.nm_set_stream.argtypes = [p, p]
+    lib.nm_upload_contigs.argtypes = [p, C.c_uint32, u64p, u32p, C.c_uint32, u8p]
+    lib.nm_upload_pileup.argtypes = [p, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.c_uint64, u32p, u32p, u8p,
+                                     f64p, C.c_int]
+    for name in ("nm_score_batch", "nm_score_batch_device"):
+        getattr(lib, name).argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p, p]
+    lib.nm_hit_positions.argtypes = [p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, u8p, C.c_int, i64p, C.c_uint64,
+                                     u64p]
+    lib.nm_stats.argtypes = [p, u64p]
+    lib.nm_last_kernel_ms.argtypes = [p, C.POINTER(C.c_float)]
+    for s in SYMBOLS:
+        if s != "nm_last_error":
+            getattr(lib, s).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise NmScanError(f"libnmscan error {rc}: {load().nm_last_error().decode()}")

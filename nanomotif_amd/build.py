@@ -1,0 +1,22 @@
+"""In-tree build of the HIP library (hipcc cross-compiles gfx950 without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "csrc", "nmscan.hip")
+OUT = os.path.join(_HERE, "libnmscan.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    deps = [SRC, HEADER]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT

@@ -1,0 +1,901 @@
+// libnmscan — MI355X (gfx950 / CDNA4) motif scan + methylation count engine.  C ABI: include/nmscan.h.
+//
+// Design (DESIGN.md has the long form):
+//   * Assembly resident in HBM as three bit planes over one padded coordinate space: H, L (the two bits of
+//     the base code, "bit-sliced 2-bit") and V (1 = A/C/G/T inside a contig).  Contigs are grouped by bin and
+//     start on 8192-bp chunk boundaries with >= 64 invalid positions after each one, so a match can never
+//     straddle two contigs and a chunk never straddles two bins.
+//   * Per modification type two state planes M / U (methylated, unmethylated; the strand of a row is implied by
+//     the base under it: '+' rows sit on the canonical base, '-' rows on its complement) — 0.5 byte per bp per
+//     scoring step in total with H and L.  Four per-strand planes (MP, UP, MM, UM) back the general case
+//     (motifs whose modified position is not the canonical literal).
+//   * Scoring kernel: one wavefront owns one chunk (64 lanes x 4 consecutive 32-bit words = 8192 bp) held in
+//     VGPRs as eight derived planes (is-A/C/G/T and valid-not-A/C/G/T) with one halo word each side.  A
+//     candidate motif is a set of wave-uniform constraints "plane p must be set at offset d from the modified
+//     base"; each costs one v_alignbit + one v_and per word, driven from SGPR bit masks (s_ff1 loop), no LDS
+//     traffic and no divergent control flow.  Forward and reverse-complement sites are disjoint (canonical vs
+//     complement base), so they are OR-ed and counted with two popcounts against M and U.
+//   * Per-lane counts go to LDS with ds_add, are reduced once per workgroup segment and leave the CU as one
+//     64-bit atomic per counter.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/nmscan.h"
+
+namespace {
+
+constexpr int T_WORDS = 4;                              // 32-bit words per lane
+constexpr int CHUNK_WORDS = 64 * T_WORDS;               // 256 words
+constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wave-chunk
+constexpr int GAP_BP = 64;                              // invalid positions guaranteed after every contig
+constexpr int SEG_CHUNKS = 16;                          // chunks per workgroup segment (128 Kbp)
+constexpr int BMAX = 32;                                // candidates per LDS accumulation pass
+constexpr int PROG_DW = 72;                             // dwords per candidate program
+constexpr int PROG_META = 64;                           // meta dwords start
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(NM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------
+// device code
+// ------------------------------------------------------------------------------------------------------
+struct Planes {
+    const uint32_t *H, *L, *V;
+    const uint8_t *needs_v;   // per chunk: 1 => V (and halo) must be consulted
+};
+
+struct StatePlanes {
+    const uint32_t *M, *U;               // compact (strand implied by base)
+    const uint32_t *MP, *UP, *MM, *UM;   // general
+};
+
+struct ScoreArgs {
+    Planes seq;
+    StatePlanes st[NM_MAX_MOD_SLOTS];
+    const uint4 *segments;      // {first chunk, n chunks, bin, 0}
+    uint32_t n_segments;
+    uint32_t n_bins;
+    const uint2 *cand_range;    // [active_slot_index][bin] -> {begin, count} into programs
+    const uint32_t *programs;   // [n_cand][PROG_DW], sorted by (slot, bin)
+    const uint32_t *orig_index; // [n_cand] sorted -> caller order
+    unsigned long long *out;    // [n_cand][2]
+    uint32_t active_slot[NM_MAX_MOD_SLOTS];
+};
+
+// Pack: one workgroup per chunk, 64 positions per wave per step, wave ballot builds the plane words.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
+                                                   const uint64_t *__restrict__ contig_off,
+                                                   const uint32_t *__restrict__ chunk_contig,
+                                                   const uint32_t *__restrict__ chunk_first,
+                                                   uint32_t *__restrict__ H, uint32_t *__restrict__ L,
+                                                   uint32_t *__restrict__ V) {
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t contig = chunk_contig[chunk];
+    if (contig == 0xFFFFFFFFu) return;                               // pad chunk, planes already zero
+    const uint64_t beg = contig_off[contig], len = contig_off[contig + 1] - beg;
+    const uint64_t local0 = (uint64_t)(chunk - chunk_first[contig]) * CHUNK_BP;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int it = wave; it < CHUNK_BP / 64; it += 4) {
+        const uint64_t p = local0 + (uint64_t)it * 64 + lane;
+        uint8_t c = 0;
+        if (p < len) c = ascii[beg + p] & 0xDF;                      // upper-case (seq.py:55)
+        const bool valid = (c == 'A') | (c == 'C') | (c == 'G') | (c == 'T');
+        const unsigned long long bv = __ballot(valid);
+        const unsigned long long bh = __ballot(valid && (c & 4));    // A=00 C=01 G=11 T=10 as (H,L) = bits 2,1
+        const unsigned long long bl = __ballot(valid && (c & 2));
+        if (lane < 2) {
+            const size_t w = (size_t)chunk * CHUNK_WORDS + (size_t)it * 2 + lane;
+            H[w] = (uint32_t)(bh >> (32 * lane));
+            L[w] = (uint32_t)(bl >> (32 * lane));
+            V[w] = (uint32_t)(bv >> (32 * lane));
+        }
+    }
+}
+
+// needs_v[c] = 0 iff chunk c is entirely valid and so are the two words either side of it.
+__global__ void needs_v_kernel(const uint32_t *__restrict__ V, uint8_t *__restrict__ needs_v, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x;
+    __shared__ uint32_t all_and;
+    if (threadIdx.x == 0) all_and = 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t v = V[(size_t)c * CHUNK_WORDS + threadIdx.x];
+    if (threadIdx.x < 2) {
+        if (c > 0) v &= V[(size_t)c * CHUNK_WORDS - 1 - threadIdx.x];
+        else v = 0;
+        if (c + 1 < n_chunks) v &= V[(size_t)(c + 1) * CHUNK_WORDS + threadIdx.x];
+        else v = 0;
+    }
+    if (v != 0xFFFFFFFFu) atomicAnd(&all_and, v);
+    __syncthreads();
+    if (threadIdx.x == 0) needs_v[c] = all_and != 0xFFFFFFFFu;
+}
+
+// State build: one thread per pileup row; classification is the reference's float64 compare.
+__global__ void state_kernel(uint64_t n_rows, const uint32_t *__restrict__ contig_id,
+                             const uint32_t *__restrict__ position, const uint8_t *__restrict__ strand,
+                             const double *__restrict__ frac, double low, double high,
+                             const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ contig_len,
+                             uint32_t n_contigs, uint32_t can_h, uint32_t can_l,
+                             const uint32_t *__restrict__ H, const uint32_t *__restrict__ L,
+                             const uint32_t *__restrict__ V, uint32_t *M, uint32_t *U, uint32_t *MP, uint32_t *UP,
+                             uint32_t *MM, uint32_t *UM, unsigned int *err) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const uint32_t cid = contig_id[i];
+    const uint32_t pos = position[i];
+    if (cid >= n_contigs || pos >= contig_len[cid]) { atomicOr(err, 1u); return; }
+    const double f = frac[i];
+    const bool meth = f >= high, non = f <= low;
+    if (!meth && !non) return;
+    const uint64_t g = (uint64_t)contig_chunk[cid] * CHUNK_BP + pos;
+    const size_t w = g >> 5;
+    const uint32_t bit = 1u << (g & 31);
+    const bool plus = strand[i] == '+';
+    if (!plus && strand[i] != '-') { atomicOr(err, 2u); return; }
+    uint32_t *gen = plus ? (meth ? MP : UP) : (meth ? MM : UM);
+    const uint32_t old = atomicOr(gen + w, bit);
+    if (old & bit) atomicOr(err, 4u);                                // duplicate (contig, position, strand)
+    // compact planes: keep the row only when the base under it is the one its strand implies
+    const uint32_t h = (H[w] & bit) != 0, l = (L[w] & bit) != 0, v = (V[w] & bit) != 0;
+    // complement in the (H,L) code: A(00)<->T(10), C(01)<->G(11) — H flips, L stays
+    const uint32_t want_h = plus ? can_h : (can_h ^ 1u);
+    if (v && h == want_h && l == can_l) atomicOr((meth ? M : U) + w, bit);
+}
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// Read-only tables are addressed through the constant address space so that wave-uniform reads become scalar
+// loads (s_load_dwordx16 straight into SGPRs) instead of vector loads + v_readfirstlane.
+typedef const uint32_t __attribute__((address_space(4))) *cu32p;
+typedef const uint8_t __attribute__((address_space(4))) *cu8p;
+
+// Eight derived planes for the T main words of this lane plus GN halo words left and GP right.
+template <int GN, int GP>
+struct Tile {
+    static constexpr int NW = T_WORDS + GN + GP;
+    uint32_t w[8][NW];
+
+    __device__ __forceinline__ void load(const Planes &s, uint32_t chunk, int lane) {
+        const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
+        uint32_t h[NW], l[NW], v[NW];
+        const uint4 h4 = *reinterpret_cast<const uint4 *>(s.H + base);
+        const uint4 l4 = *reinterpret_cast<const uint4 *>(s.L + base);
+        h[GN + 0] = h4.x; h[GN + 1] = h4.y; h[GN + 2] = h4.z; h[GN + 3] = h4.w;
+        l[GN + 0] = l4.x; l[GN + 1] = l4.y; l[GN + 2] = l4.z; l[GN + 3] = l4.w;
+#pragma unroll
+        for (int j = 0; j < GN; ++j) { h[j] = s.H[base - GN + j]; l[j] = s.L[base - GN + j]; }
+#pragma unroll
+        for (int j = 0; j < GP; ++j) { h[GN + T_WORDS + j] = s.H[base + T_WORDS + j]; l[GN + T_WORDS + j] = s.L[base + T_WORDS + j]; }
+        if (((cu8p)s.needs_v)[chunk]) {                              // wave-uniform, scalar load
+            const uint4 v4 = *reinterpret_cast<const uint4 *>(s.V + base);
+            v[GN + 0] = v4.x; v[GN + 1] = v4.y; v[GN + 2] = v4.z; v[GN + 3] = v4.w;
+#pragma unroll
+            for (int j = 0; j < GN; ++j) v[j] = s.V[base - GN + j];
+#pragma unroll
+            for (int j = 0; j < GP; ++j) v[GN + T_WORDS + j] = s.V[base + T_WORDS + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NW; ++j) v[j] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const uint32_t hh = h[j], ll = l[j], vv = v[j];
+            w[0][j] = vv & ~hh & ~ll;          // A = 00
+            w[1][j] = vv & ~hh & ll;           // C = 01
+            w[2][j] = vv & hh & ll;            // G = 11
+            w[3][j] = vv & hh & ~ll;           // T = 10
+            w[4][j] = vv & (hh | ll);          // valid, not A
+            w[5][j] = vv & (hh | ~ll);         // valid, not C
+            w[6][j] = vv & ~(hh & ll);         // valid, not G
+            w[7][j] = vv & (~hh | ll);         // valid, not T
+        }
+    }
+};
+
+// One strand's constraint masks for the offset groups this kernel variant supports: m[(gi - (2 - GN)) * 8 + p].
+template <int GN, int GP>
+struct StrandMasks {
+    static constexpr int N = (GN + GP) * 8;
+    uint32_t m[N];
+    __device__ __forceinline__ void load(cu32p prog_strand) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) m[i] = prog_strand[(2 - GN) * 8 + i];
+    }
+};
+
+// acc[t] &= plane p at offset d (d = 32 g + r) for every constraint bit of one strand's program.
+template <int GN, int GP>
+__device__ __forceinline__ void eval_strand(const StrandMasks<GN, GP> &sm, const Tile<GN, GP> &tile,
+                                            uint32_t (&acc)[T_WORDS]) {
+#pragma unroll
+    for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int g = 0; g < GN + GP; ++g) {            // g = gi - (2 - GN): word pair (t + g, t + g + 1)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            uint32_t m = sm.m[g * 8 + p];
+            while (m) {
+                const uint32_t r = __builtin_ctz(m);
+                m &= m - 1;
+#pragma unroll
+                for (int t = 0; t < T_WORDS; ++t) acc[t] &= alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
+            }
+        }
+    }
+}
+
+template <int GN, int GP, bool COMPACT>
+__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
+    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
+    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
+    // of segments so candidate programs and counters of one bin stay in one L2.
+    const uint32_t nb = gridDim.x;
+    const uint32_t per = (nb + 7) / 8;
+    uint32_t seg = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (seg >= a.n_segments) return;
+    uint4 sg = a.segments[seg];
+    sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
+    sg.y = __builtin_amdgcn_readfirstlane(sg.y);
+    sg.z = __builtin_amdgcn_readfirstlane(sg.z);
+    const uint32_t slot_i = blockIdx.y;
+    const uint32_t slot = a.active_slot[slot_i];
+    uint2 range = a.cand_range[(size_t)slot_i * a.n_bins + sg.z];
+    range.x = __builtin_amdgcn_readfirstlane(range.x);
+    range.y = __builtin_amdgcn_readfirstlane(range.y);
+    if (range.y == 0) return;
+    const StatePlanes st = a.st[slot];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (uint32_t pass0 = 0; pass0 < range.y; pass0 += BMAX) {
+        const uint32_t nbatch = min((uint32_t)BMAX, range.y - pass0);
+        for (uint32_t i = threadIdx.x; i < nbatch * 128; i += 256) lds_acc[i] = 0;
+        __syncthreads();
+        for (uint32_t ck = wave; ck < sg.y; ck += 4) {
+            const uint32_t chunk = sg.x + ck;
+            Tile<GN, GP> tile;
+            tile.load(a.seq, chunk, lane);
+            const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
+            uint32_t s0[T_WORDS], s1[T_WORDS], s2[T_WORDS], s3[T_WORDS];
+            if (COMPACT) {
+                const uint4 m4 = *reinterpret_cast<const uint4 *>(st.M + base);
+                const uint4 u4 = *reinterpret_cast<const uint4 *>(st.U + base);
+                s0[0] = m4.x; s0[1] = m4.y; s0[2] = m4.z; s0[3] = m4.w;
+                s1[0] = u4.x; s1[1] = u4.y; s1[2] = u4.z; s1[3] = u4.w;
+            } else {
+                const uint4 a4 = *reinterpret_cast<const uint4 *>(st.MP + base);
+                const uint4 b4 = *reinterpret_cast<const uint4 *>(st.UP + base);
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(st.MM + base);
+                const uint4 d4 = *reinterpret_cast<const uint4 *>(st.UM + base);
+                s0[0] = a4.x; s0[1] = a4.y; s0[2] = a4.z; s0[3] = a4.w;
+                s1[0] = b4.x; s1[1] = b4.y; s1[2] = b4.z; s1[3] = b4.w;
+                s2[0] = c4.x; s2[1] = c4.y; s2[2] = c4.z; s2[3] = c4.w;
+                s3[0] = d4.x; s3[1] = d4.y; s3[2] = d4.z; s3[3] = d4.w;
+            }
+            for (uint32_t k = 0; k < nbatch; ++k) {
+                cu32p prog = (cu32p)(a.programs + (size_t)(range.x + pass0 + k) * PROG_DW);
+                StrandMasks<GN, GP> mf, mr;
+                mf.load(prog);
+                mr.load(prog + 32);
+                uint32_t accf[T_WORDS], accr[T_WORDS];
+                eval_strand<GN, GP>(mf, tile, accf);
+                eval_strand<GN, GP>(mr, tile, accr);
+                uint32_t n_mod = 0, n_non = 0;
+#pragma unroll
+                for (int t = 0; t < T_WORDS; ++t) {
+                    if (COMPACT) {
+                        const uint32_t sites = accf[t] | accr[t];
+                        n_mod += __popc(sites & s0[t]);
+                        n_non += __popc(sites & s1[t]);
+                    } else {
+                        n_mod += __popc(accf[t] & s0[t]) + __popc(accr[t] & s2[t]);
+                        n_non += __popc(accf[t] & s1[t]) + __popc(accr[t] & s3[t]);
+                    }
+                }
+                atomicAdd(&lds_acc[(k * 2 + 0) * 64 + lane], n_mod);
+                atomicAdd(&lds_acc[(k * 2 + 1) * 64 + lane], n_non);
+            }
+        }
+        __syncthreads();
+        // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
+        for (uint32_t idx = threadIdx.x; idx < nbatch * 8; idx += 256) {
+            const uint32_t i = idx >> 2, q = idx & 3;
+            uint32_t s = 0;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) s += lds_acc[i * 64 + q * 16 + j];
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (q == 0 && s) {
+                const uint32_t orig = a.orig_index[range.x + pass0 + (i >> 1)];
+                atomicAdd(a.out + (size_t)orig * 2 + (i & 1), (unsigned long long)s);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
+template <int GN, int GP>
+__global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, uint32_t chunk0, uint32_t n_chunks,
+                                                   const uint32_t *__restrict__ prog, int which,
+                                                   uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ck = blockIdx.x * 4 + wave;
+    if (ck >= n_chunks) return;
+    const uint32_t chunk = chunk0 + ck;
+    Tile<GN, GP> tile;
+    tile.load(seq, chunk, lane);
+    uint32_t acc[T_WORDS];
+    StrandMasks<GN, GP> sm;
+    sm.load((cu32p)(prog + (which >= 2 ? 32 : 0)));
+    eval_strand<GN, GP>(sm, tile, acc);
+    const uint32_t *plane = which == 0 ? st.MP : which == 1 ? st.UP : which == 2 ? st.MM : st.UM;
+    const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
+#pragma unroll
+    for (int t = 0; t < T_WORDS; ++t) out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & plane[base + t];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+struct ModSlot {
+    bool present = false;
+    uint8_t canonical = 0;          // 'A' or 'C'
+    double low = 0.3, high = 0.7;
+    uint32_t *planes[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // M U MP UP MM UM
+    uint64_t n_rows = 0;
+};
+
+struct nm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // assembly
+    uint32_t n_contigs = 0, n_bins = 0, n_chunks = 0;
+    uint64_t total_bp = 0;
+    std::vector<uint64_t> contig_len;
+    std::vector<uint32_t> contig_chunk, contig_bin, contig_nchunks;
+    std::vector<uint32_t> bin_chunk0, bin_nchunks;
+    uint32_t *dH = nullptr, *dL = nullptr, *dV = nullptr;
+    uint8_t *d_needs_v = nullptr;
+    uint32_t *d_contig_chunk = nullptr;
+    uint64_t *d_contig_len = nullptr;
+    uint4 *d_segments = nullptr;
+    uint32_t n_segments = 0;
+    ModSlot slots[NM_MAX_MOD_SLOTS];
+    // per-call staging: ring of two (device, pinned host) buffer pairs so that compiling the next batch on the
+    // host overlaps the previous launch; `busy` marks the last device work that read the pair.
+    struct Stage {
+        void *d = nullptr, *h = nullptr;
+        size_t bytes = 0;
+        hipEvent_t busy = nullptr;
+        bool pending = false;
+    } stage[2];
+    int stage_next = 0;
+    void *d_stage = nullptr, *h_stage = nullptr;   // the pair acquired by the current call
+    Stage *cur_stage = nullptr;
+    unsigned long long *d_counts = nullptr;
+    size_t counts_cap = 0;
+    unsigned int *d_err = nullptr;
+    uint64_t launches = 0, last_wgs = 0, last_compact = 0, last_general = 0;
+};
+
+namespace {
+
+size_t plane_words(const nm_ctx *c) { return (size_t)c->n_chunks * CHUNK_WORDS; }
+
+int ensure_stage(nm_ctx *c, size_t bytes) {
+    nm_ctx::Stage &st = c->stage[c->stage_next];
+    c->stage_next ^= 1;
+    if (!st.busy) HIP_TRY(hipEventCreateWithFlags(&st.busy, hipEventDisableTiming));
+    if (st.pending) {
+        HIP_TRY(hipEventSynchronize(st.busy));
+        st.pending = false;
+    }
+    if (bytes > st.bytes) {
+        const size_t nb = std::max(bytes, st.bytes * 2);
+        if (st.d) (void)hipFree(st.d);
+        if (st.h) (void)hipHostFree(st.h);
+        st.d = st.h = nullptr;
+        st.bytes = 0;
+        HIP_TRY(hipMalloc(&st.d, nb));
+        HIP_TRY(hipHostMalloc(&st.h, nb, hipHostMallocDefault));
+        st.bytes = nb;
+    }
+    c->d_stage = st.d;
+    c->h_stage = st.h;
+    c->cur_stage = &st;
+    return NM_OK;
+}
+
+int release_stage(nm_ctx *c) {   // call after the last device work that reads the acquired pair was enqueued
+    HIP_TRY(hipEventRecord(c->cur_stage->busy, c->stream));
+    c->cur_stage->pending = true;
+    return NM_OK;
+}
+
+inline uint32_t comp_mask(uint32_t m) { return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3); }
+
+// Compile one stripped motif into the per-strand constraint masks.  Layout: prog[strand*32 + gi*8 + plane],
+// gi = floor(d/32) + 2, bit r = d mod 32; meta at PROG_META: [0] flags (1 = wide offsets used).
+int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_t *prog, bool *wide,
+                    uint32_t *modpos_mask) {
+    if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "motif length %u outside 1..%d", len, NM_MAX_MOTIF_LEN);
+    if (modpos >= len) return fail(NM_EINVAL, "mod_position %u outside motif of length %u", modpos, len);
+    memset(prog, 0, PROG_DW * sizeof(uint32_t));
+    bool any = false;
+    *wide = false;
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint32_t m = masks[j] & 15u;
+        if (m == 0) return fail(NM_EINVAL, "empty base set at motif position %u", j);
+        if (m == 15u) continue;
+        any = true;
+        for (int strand = 0; strand < 2; ++strand) {
+            const int d = strand == 0 ? (int)j - (int)modpos : (int)modpos - (int)j;
+            const uint32_t set = strand == 0 ? m : comp_mask(m);
+            const int gi = (d >> 5) + 2;                            // arithmetic shift = floor
+            const uint32_t r = (uint32_t)d & 31u;
+            if (gi < 0 || gi > 3) return fail(NM_ERANGE, "offset %d from the modified base is outside [-64, 63]", d);
+            if (gi == 0 || gi == 3) *wide = true;
+            uint32_t *row = prog + strand * 32 + gi * 8;
+            const int nbits = __builtin_popcount(set);
+            if (nbits == 1) {
+                row[__builtin_ctz(set)] |= 1u << r;                 // literal: plane of that base
+            } else {
+                uint32_t missing = (~set) & 15u;                    // 3-set: one "valid and not x"; 2-set: two of them
+                while (missing) {
+                    row[4 + __builtin_ctz(missing)] |= 1u << r;
+                    missing &= missing - 1;
+                }
+            }
+        }
+    }
+    if (!any) return fail(NM_EINVAL, "motif has no specified position");
+    prog[PROG_META] = *wide ? 1u : 0u;
+    *modpos_mask = masks[modpos] & 15u;
+    return NM_OK;
+}
+
+template <int GN, int GP, bool COMPACT>
+void launch_score(const ScoreArgs &a, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT>), grid, dim3(256), 0, s, a);
+}
+
+int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+               const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+               const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    if (n_cand == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // ---- sort candidates by (slot, bin)
+    std::vector<uint32_t> order(n_cand);
+    std::iota(order.begin(), order.end(), 0u);
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        if (cand_mod_slot[k] >= NM_MAX_MOD_SLOTS || !c->slots[cand_mod_slot[k]].present)
+            return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, cand_mod_slot[k]);
+        if (cand_bin[k] >= c->n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, cand_bin[k], c->n_bins);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (cand_mod_slot[x] != cand_mod_slot[y]) return cand_mod_slot[x] < cand_mod_slot[y];
+        return cand_bin[x] < cand_bin[y];
+    });
+    uint32_t active[NM_MAX_MOD_SLOTS], n_active = 0;
+    int slot_to_active[NM_MAX_MOD_SLOTS];
+    for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) slot_to_active[s] = -1;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const int s = cand_mod_slot[order[k]];
+        if (slot_to_active[s] < 0) { slot_to_active[s] = (int)n_active; active[n_active++] = (uint32_t)s; }
+    }
+    // ---- staging layout: programs | orig_index | cand_range
+    const size_t prog_bytes = (size_t)n_cand * PROG_DW * 4;
+    const size_t orig_bytes = (size_t)n_cand * 4;
+    const size_t range_bytes = (size_t)n_active * c->n_bins * sizeof(uint2);
+    const size_t off_orig = (prog_bytes + 15) & ~(size_t)15, off_range = (off_orig + orig_bytes + 15) & ~(size_t)15;
+    const size_t total = off_range + range_bytes;
+    int rc = ensure_stage(c, total);
+    if (rc) return rc;
+    uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
+    uint32_t *h_prog = reinterpret_cast<uint32_t *>(hs);
+    uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
+    uint2 *h_range = reinterpret_cast<uint2 *>(hs + off_range);
+    memset(h_range, 0, range_bytes);
+    bool any_wide = false, all_compact = true;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const uint32_t o = order[k];
+        bool wide = false;
+        uint32_t mp_mask = 0;
+        rc = compile_program(cand_masks + cand_mask_offset[o], cand_len[o], cand_modpos[o], h_prog + (size_t)k * PROG_DW,
+                             &wide, &mp_mask);
+        if (rc) return rc;
+        any_wide |= wide;
+        const ModSlot &ms = c->slots[cand_mod_slot[o]];
+        const uint32_t can_mask = ms.canonical == 'A' ? NM_BASE_A : NM_BASE_C;
+        if (mp_mask != can_mask) all_compact = false;
+        h_orig[k] = o;
+        uint2 &r = h_range[(size_t)slot_to_active[cand_mod_slot[o]] * c->n_bins + cand_bin[o]];
+        if (r.y == 0) r.x = k;
+        r.y += 1;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, c->stream));
+    // ---- output counters
+    unsigned long long *out = d_out;
+    if (!out) {
+        if (c->counts_cap < n_cand) {
+            if (c->d_counts) (void)hipFree(c->d_counts);
+            c->d_counts = nullptr;
+            c->counts_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_counts, (size_t)n_cand * 2 * sizeof(unsigned long long) * 2));
+            c->counts_cap = (size_t)n_cand * 2;
+        }
+        out = c->d_counts;
+    }
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_cand * 2 * sizeof(unsigned long long), c->stream));
+    // ---- launch
+    ScoreArgs a{};
+    a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
+    for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) {
+        const ModSlot &ms = c->slots[s];
+        a.st[s] = StatePlanes{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
+    }
+    a.segments = c->d_segments;
+    a.n_segments = c->n_segments;
+    a.n_bins = c->n_bins;
+    uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
+    a.programs = reinterpret_cast<uint32_t *>(ds);
+    a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
+    a.cand_range = reinterpret_cast<uint2 *>(ds + off_range);
+    a.out = out;
+    for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
+    const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
+    dim3 grid(gx, n_active);
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (!any_wide && all_compact) launch_score<1, 1, true>(a, grid, c->stream);
+    else if (!any_wide) launch_score<1, 1, false>(a, grid, c->stream);
+    else if (all_compact) launch_score<2, 2, true>(a, grid, c->stream);
+    else launch_score<2, 2, false>(a, grid, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    rc = release_stage(c);
+    if (rc) return rc;
+    c->timed = true;
+    c->launches += 1;
+    c->last_wgs = (uint64_t)gx * n_active;
+    c->last_compact = all_compact ? n_cand : 0;
+    c->last_general = all_compact ? 0 : n_cand;
+    if (h_out) {
+        HIP_TRY(hipMemcpyAsync(h_out, out, (size_t)n_cand * 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return NM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_abi_version(void) { return 1; }
+
+const char *nm_last_error(void) { return g_err.c_str(); }
+
+int nm_ctx_create(int device, nm_ctx **out) {
+    if (!out) return fail(NM_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(NM_EINVAL, "device %d not in 0..%d", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    nm_ctx *c = new (std::nothrow) nm_ctx();
+    if (!c) return fail(NM_ENOMEM, "out of host memory");
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipMalloc(&c->d_err, sizeof(unsigned int)));
+    *out = c;
+    return NM_OK;
+}
+
+static void free_assembly(nm_ctx *c) {
+    void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c->dH = c->dL = c->dV = nullptr;
+    c->d_needs_v = nullptr;
+    c->d_contig_chunk = nullptr;
+    c->d_contig_len = nullptr;
+    c->d_segments = nullptr;
+    for (auto &s : c->slots) {
+        for (auto &p : s.planes) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        s.present = false;
+        s.n_rows = 0;
+    }
+}
+
+int nm_ctx_destroy(nm_ctx *c) {
+    if (!c) return NM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_assembly(c);
+    for (auto &st : c->stage) {
+        if (st.d) (void)hipFree(st.d);
+        if (st.h) (void)hipHostFree(st.h);
+        if (st.busy) (void)hipEventDestroy(st.busy);
+    }
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return NM_OK;
+}
+
+int nm_set_stream(nm_ctx *c, void *hip_stream) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->timed = false;
+    return NM_OK;
+}
+
+int nm_upload_contigs(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
+                      uint32_t n_bins, const uint8_t *seq_ascii) {
+    if (!c || !offsets || !bin_id || !seq_ascii) return fail(NM_EINVAL, "NULL argument");
+    if (n_contigs == 0 || n_bins == 0) return fail(NM_EINVAL, "need at least one contig and one bin");
+    if (offsets[0] != 0) return fail(NM_EINVAL, "offsets[0] must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_assembly(c);
+    c->n_contigs = n_contigs;
+    c->n_bins = n_bins;
+    c->contig_len.assign(n_contigs, 0);
+    c->contig_bin.assign(bin_id, bin_id + n_contigs);
+    c->contig_chunk.assign(n_contigs, 0);
+    c->contig_nchunks.assign(n_contigs, 0);
+    c->total_bp = offsets[n_contigs];
+    for (uint32_t i = 0; i < n_contigs; ++i) {
+        if (offsets[i + 1] <= offsets[i]) return fail(NM_EINVAL, "contig %u is empty (seq.py:70 asserts non-empty)", i);
+        if (bin_id[i] >= n_bins) return fail(NM_EINVAL, "contig %u: bin %u >= n_bins %u", i, bin_id[i], n_bins);
+        c->contig_len[i] = offsets[i + 1] - offsets[i];
+        if (c->contig_len[i] >= 0xFFFFFFFFull - CHUNK_BP) return fail(NM_ERANGE, "contig %u longer than 4 Gbp", i);
+    }
+    // group contigs by bin; chunk 0 and the last chunk are zero pads for the halo reads
+    std::vector<uint32_t> order(n_contigs);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bin_id[x] < bin_id[y]; });
+    c->bin_chunk0.assign(n_bins, 0);
+    c->bin_nchunks.assign(n_bins, 0);
+    uint64_t next = 1;
+    std::vector<uint32_t> chunk_contig(1, 0xFFFFFFFFu);
+    for (uint32_t oi = 0; oi < n_contigs; ++oi) {
+        const uint32_t i = order[oi];
+        const uint64_t nch = (c->contig_len[i] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP;
+        if (next + nch + 1 >= 0xFFFFFFFFull / CHUNK_WORDS * 8) return fail(NM_ERANGE, "assembly too large for one device context");
+        c->contig_chunk[i] = (uint32_t)next;
+        c->contig_nchunks[i] = (uint32_t)nch;
+        const uint32_t b = bin_id[i];
+        if (c->bin_nchunks[b] == 0) c->bin_chunk0[b] = (uint32_t)next;
+        c->bin_nchunks[b] += (uint32_t)nch;
+        chunk_contig.insert(chunk_contig.end(), nch, i);
+        next += nch;
+    }
+    chunk_contig.push_back(0xFFFFFFFFu);
+    c->n_chunks = (uint32_t)(next + 1);
+    const size_t words = plane_words(c);
+    HIP_TRY(hipMalloc(&c->dH, words * 4));
+    HIP_TRY(hipMalloc(&c->dL, words * 4));
+    HIP_TRY(hipMalloc(&c->dV, words * 4));
+    HIP_TRY(hipMalloc(&c->d_needs_v, c->n_chunks));
+    HIP_TRY(hipMemsetAsync(c->dH, 0, words * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dL, 0, words * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->dV, 0, words * 4, c->stream));
+    HIP_TRY(hipMalloc(&c->d_contig_chunk, (size_t)n_contigs * 4));
+    HIP_TRY(hipMalloc(&c->d_contig_len, (size_t)n_contigs * 8));
+    HIP_TRY(hipMemcpyAsync(c->d_contig_chunk, c->contig_chunk.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_contig_len, c->contig_len.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, c->stream));
+    // temporaries for the pack pass
+    uint8_t *d_ascii = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_chunk_contig = nullptr;
+    HIP_TRY(hipMalloc(&d_ascii, c->total_bp));
+    HIP_TRY(hipMalloc(&d_off, (size_t)(n_contigs + 1) * 8));
+    HIP_TRY(hipMalloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
+    HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, d_chunk_contig,
+                       c->d_contig_chunk, c->dH, c->dL, c->dV);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(needs_v_kernel, dim3(c->n_chunks), dim3(CHUNK_WORDS), 0, c->stream, c->dV, c->d_needs_v, c->n_chunks);
+    HIP_TRY(hipGetLastError());
+    // static segment table: every bin's chunk range cut into pieces of SEG_CHUNKS
+    std::vector<uint4> segs;
+    for (uint32_t b = 0; b < n_bins; ++b)
+        for (uint32_t k = 0; k < c->bin_nchunks[b]; k += SEG_CHUNKS)
+            segs.push_back(make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(SEG_CHUNKS, c->bin_nchunks[b] - k), b, 0));
+    c->n_segments = (uint32_t)segs.size();
+    HIP_TRY(hipMalloc(&c->d_segments, segs.size() * sizeof(uint4)));
+    HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_ascii);
+    (void)hipFree(d_off);
+    (void)hipFree(d_chunk_contig);
+    return NM_OK;
+}
+
+int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high, uint64_t n_rows,
+                     const uint32_t *contig_id, const uint32_t *position, const uint8_t *strand,
+                     const double *fraction_mod, int append) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (mod_slot >= NM_MAX_MOD_SLOTS) return fail(NM_EINVAL, "mod_slot %u >= %d", mod_slot, NM_MAX_MOD_SLOTS);
+    if (canonical_base != 'A' && canonical_base != 'C') return fail(NM_EINVAL, "canonical base must be 'A' or 'C'");
+    if (!(high > low)) return fail(NM_EINVAL, "high threshold must exceed low (find_motifs_bin.py:117-118)");
+    if (n_rows && (!contig_id || !position || !strand || !fraction_mod)) return fail(NM_EINVAL, "NULL column");
+    HIP_TRY(hipSetDevice(c->device));
+    ModSlot &ms = c->slots[mod_slot];
+    const size_t words = plane_words(c);
+    if (!ms.present || !append) {
+        for (auto &p : ms.planes) {
+            if (!p) HIP_TRY(hipMalloc(&p, words * 4));
+            HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
+        }
+        ms.n_rows = 0;
+    } else if (ms.canonical != canonical_base || ms.low != low || ms.high != high) {
+        return fail(NM_EINVAL, "append with different canonical base / thresholds than the slot holds");
+    }
+    ms.present = true;
+    ms.canonical = canonical_base;
+    ms.low = low;
+    ms.high = high;
+    if (n_rows == 0) return NM_OK;
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
+    // stream the SoA columns through the staging buffer in slabs
+    const uint64_t slab = 8ull << 20;  // rows per slab (17 B each)
+    for (uint64_t r0 = 0; r0 < n_rows; r0 += slab) {
+        const uint64_t n = std::min(slab, n_rows - r0);
+        const size_t o_pos = n * 4, o_frac = ((o_pos + n * 4) + 7) & ~(size_t)7, o_str = o_frac + n * 8;
+        int rc = ensure_stage(c, o_str + n);
+        if (rc) return rc;
+        uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+        memcpy(hs, contig_id + r0, n * 4);
+        memcpy(hs + o_pos, position + r0, n * 4);
+        memcpy(hs + o_frac, fraction_mod + r0, n * 8);
+        memcpy(hs + o_str, strand + r0, n);
+        HIP_TRY(hipMemcpyAsync(ds, hs, o_str + n, hipMemcpyHostToDevice, c->stream));
+        const uint32_t can_h = 0, can_l = canonical_base == 'C' ? 1u : 0u;   // A = 00, C = 01
+        hipLaunchKernelGGL(state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
+                           reinterpret_cast<uint32_t *>(ds), reinterpret_cast<uint32_t *>(ds + o_pos), ds + o_str,
+                           reinterpret_cast<double *>(ds + o_frac), low, high, c->d_contig_chunk, c->d_contig_len,
+                           c->n_contigs, can_h, can_l, c->dH, c->dL, c->dV, ms.planes[0], ms.planes[1], ms.planes[2],
+                           ms.planes[3], ms.planes[4], ms.planes[5], c->d_err);
+        HIP_TRY(hipGetLastError());
+        rc = release_stage(c);
+        if (rc) return rc;
+    }
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ms.n_rows += n_rows;
+    if (err & 1u) return fail(NM_EINVAL, "pileup row with contig_id / position outside the uploaded assembly");
+    if (err & 2u) return fail(NM_EINVAL, "pileup strand must be '+' or '-'");
+    if (err & 4u) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
+    return NM_OK;
+}
+
+int nm_score_batch(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                   const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                   const uint8_t *cand_masks, int64_t *out_counts) {
+    if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !out_counts))
+        return fail(NM_EINVAL, "NULL argument");
+    return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, out_counts);
+}
+
+int nm_score_batch_device(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                          const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                          const uint8_t *cand_masks, int64_t *d_out_counts) {
+    if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !d_out_counts))
+        return fail(NM_EINVAL, "NULL argument");
+    return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks,
+                      reinterpret_cast<unsigned long long *>(d_out_counts), nullptr);
+}
+
+int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t len, uint8_t modpos, const uint8_t *masks,
+                     int which, int64_t *out, uint64_t capacity, uint64_t *n_out) {
+    if (!c || !masks || !n_out) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    if (contig_id >= c->n_contigs) return fail(NM_EINVAL, "contig_id %u >= %u", contig_id, c->n_contigs);
+    if (mod_slot >= NM_MAX_MOD_SLOTS || !c->slots[mod_slot].present) return fail(NM_ESTATE, "mod slot %u has no pileup", mod_slot);
+    if (which < 0 || which > 3) return fail(NM_EINVAL, "which must be 0..3");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t prog[PROG_DW];
+    bool wide = false;
+    uint32_t mpm = 0;
+    int rc = compile_program(masks, len, modpos, prog, &wide, &mpm);
+    if (rc) return rc;
+    const uint32_t nch = c->contig_nchunks[contig_id];
+    const size_t out_words = (size_t)nch * CHUNK_WORDS;
+    rc = ensure_stage(c, sizeof prog + out_words * 4);
+    if (rc) return rc;
+    memcpy(c->h_stage, prog, sizeof prog);
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof prog, hipMemcpyHostToDevice, c->stream));
+    uint32_t *d_prog = static_cast<uint32_t *>(c->d_stage);
+    uint32_t *d_out = d_prog + PROG_DW;
+    const ModSlot &ms = c->slots[mod_slot];
+    Planes seq{c->dH, c->dL, c->dV, c->d_needs_v};
+    StatePlanes st{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
+    dim3 grid((nch + 3) / 4);
+    if (wide) hipLaunchKernelGGL((hits_kernel<2, 2>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_out);
+    else hipLaunchKernelGGL((hits_kernel<1, 1>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_out);
+    HIP_TRY(hipGetLastError());
+    uint32_t *h_out = static_cast<uint32_t *>(c->h_stage) + PROG_DW;
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_words * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint64_t n = 0;
+    for (size_t w = 0; w < out_words; ++w) {
+        uint32_t m = h_out[w];
+        while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            if (out && n < capacity) out[n] = (int64_t)(w * 32 + b);
+            ++n;
+        }
+    }
+    *n_out = n;
+    return NM_OK;
+}
+
+int nm_stats(nm_ctx *c, uint64_t what[8]) {
+    if (!c || !what) return fail(NM_EINVAL, "NULL argument");
+    what[0] = c->total_bp;
+    what[1] = (uint64_t)c->n_chunks * CHUNK_BP;
+    what[2] = (uint64_t)plane_words(c) * 4 * 3;
+    what[3] = (uint64_t)plane_words(c) * 4 * 2;
+    what[4] = c->launches;
+    what[5] = c->last_wgs;
+    what[6] = c->last_compact;
+    what[7] = c->last_general;
+    return NM_OK;
+}
+
+int nm_last_kernel_ms(nm_ctx *c, float *ms) {
+    if (!c || !ms) return fail(NM_EINVAL, "NULL argument");
+    if (!c->timed) return fail(NM_ESTATE, "no scoring launch recorded on this stream");
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return NM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""Python host of the HIP scan engine: owns an ``nm_ctx`` and speaks in the reference's vocabulary
+(contigs, bins, pileup rows, motifs).  Thin by design — packing, classification, scanning and counting all
+happen on the GPU inside libnmscan.so; this file only marshals numpy buffers through ctypes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .motif import MOD_TYPE_TO_CANONICAL, Motif
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class CandidateBatch:
+    """Flat SoA form of a list of candidates (include/nmscan.h: nm_score_batch arguments)."""
+
+    def __init__(self, bins, slots, lens, modpos, offsets, masks):
+        self.bins, self.slots, self.lens, self.modpos, self.offsets, self.masks = bins, slots, lens, modpos, offsets, masks
+
+    def __len__(self):
+        return len(self.bins)
+
+
+class ScanEngine:
+    """One engine per GPU / process.  Mirrors what ``motif_model_bin`` needs (find_motifs_bin.py:1265-1283):
+    the bin's contig sequences and the (bin, mod_type) pileup, but resident in HBM across calls."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        self.ctx = C.c_void_p()
+        _lib.check(self.lib.nm_ctx_create(int(device), C.byref(self.ctx)))
+        self.device = int(device)
+        self.contig_index = {}
+        self.contig_names = []
+        self.contig_lengths = None
+        self.contig_bin = None
+        self.bin_index = {}
+        self.bin_names = []
+        self.slot_of_mod = {}
+        self._cand_cache = {}
+
+    def close(self):
+        if self.ctx:
+            self.lib.nm_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, hip_stream_handle: int | None):
+        """Run engine work on another HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _lib.check(self.lib.nm_set_stream(self.ctx, C.c_void_p(hip_stream_handle or 0)))
+
+    # ------------------------------------------------------------------ assembly
+    def upload_assembly(self, names, sequences, bin_of_contig):
+        """names: contig names; sequences: str / bytes / uint8 arrays (any case, IUPAC letters);
+        bin_of_contig: bin name per contig.  Bin ids are assigned in sorted bin-name order."""
+        names = list(names)
+        if not names:
+            raise ValueError("assembly is empty")
+        bufs = []
+        for s in sequences:
+            if isinstance(s, str):
+                s = s.encode("ascii")
+            bufs.append(np.frombuffer(s, dtype=np.uint8) if not isinstance(s, np.ndarray) else s.astype(np.uint8, copy=False))
+        lengths = np.array([len(b) for b in bufs], dtype=np.uint64)
+        offsets = np.zeros(len(bufs) + 1, dtype=np.uint64)
+        np.cumsum(lengths, out=offsets[1:])
+        ascii_all = np.concatenate(bufs) if len(bufs) > 1 else np.ascontiguousarray(bufs[0])
+        self.bin_names = sorted(set(bin_of_contig))
+        self.bin_index = {b: i for i, b in enumerate(self.bin_names)}
+        bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
+        _lib.check(self.lib.nm_upload_contigs(self.ctx, len(names), _ptr(offsets, C.c_uint64), _ptr(bin_ids, C.c_uint32),
+                                              len(self.bin_names), _ptr(ascii_all, C.c_uint8)))
+        self.contig_names = names
+        self.contig_index = {n: i for i, n in enumerate(names)}
+        self.contig_lengths = lengths.astype(np.int64)
+        self.contig_bin = bin_ids
+        self.slot_of_mod = {}
+
+    # ------------------------------------------------------------------ pileup
+    def upload_pileup(self, mod_type: str, contig_id, position, strand, fraction_mod, low=0.3, high=0.7, append=False):
+        """Rows of one mod type after the pre-filters (SoA).  strand: uint8 ASCII '+'/'-'."""
+        if mod_type not in self.slot_of_mod:
+            if len(self.slot_of_mod) >= 4:
+                raise ValueError("at most 4 modification types resident")
+            self.slot_of_mod[mod_type] = len(self.slot_of_mod)
+        slot = self.slot_of_mod[mod_type]
+        cid = np.ascontiguousarray(contig_id, dtype=np.uint32)
+        pos = np.ascontiguousarray(position, dtype=np.uint32)
+        st = np.ascontiguousarray(strand, dtype=np.uint8)
+        fr = np.ascontiguousarray(fraction_mod, dtype=np.float64)
+        if not (len(cid) == len(pos) == len(st) == len(fr)):
+            raise ValueError("pileup columns differ in length")
+        _lib.check(self.lib.nm_upload_pileup(self.ctx, slot, ord(MOD_TYPE_TO_CANONICAL[mod_type]), float(low), float(high),
+                                             len(cid), _ptr(cid, C.c_uint32), _ptr(pos, C.c_uint32), _ptr(st, C.c_uint8),
+                                             _ptr(fr, C.c_double), 1 if append else 0))
+
+    # ------------------------------------------------------------------ scoring
+    def _encode(self, motif: Motif):
+        key = (motif.string, motif.mod_position)
+        hit = self._cand_cache.get(key)
+        if hit is None:
+            sets, pos = motif.stripped_sets()
+            hit = (sets.tobytes(), int(pos))
+            if len(self._cand_cache) < 1 << 18:
+                self._cand_cache[key] = hit
+        return hit
+
+    def make_batch(self, candidates) -> CandidateBatch:
+        """candidates: iterable of (Motif, mod_type, bin name or id)."""
+        n = len(candidates)
+        bins = np.empty(n, dtype=np.uint32)
+        slots = np.empty(n, dtype=np.uint8)
+        lens = np.empty(n, dtype=np.uint8)
+        modpos = np.empty(n, dtype=np.uint8)
+        offsets = np.empty(n, dtype=np.uint32)
+        chunks = []
+        off = 0
+        for k, (motif, mod_type, b) in enumerate(candidates):
+            raw, pos = self._encode(motif)
+            if len(raw) > 64 or not 0 <= pos < len(raw):
+                raise ValueError(f"motif {motif!r}: stripped length {len(raw)} / mod_position {pos} unsupported")
+            bins[k] = self.bin_index[b] if isinstance(b, str) else int(b)
+            slots[k] = self.slot_of_mod[mod_type]
+            lens[k] = len(raw)
+            modpos[k] = pos
+            offsets[k] = off
+            chunks.append(raw)
+            off += len(raw)
+        masks = np.frombuffer(b"".join(chunks), dtype=np.uint8) if chunks else np.zeros(0, np.uint8)
+        return CandidateBatch(bins, slots, lens, modpos, offsets, masks)
+
+    def _batch_args(self, b: CandidateBatch):
+        return (len(b), _ptr(b.bins, C.c_uint32), _ptr(b.slots, C.c_uint8), _ptr(b.lens, C.c_uint8),
+                _ptr(b.modpos, C.c_uint8), _ptr(b.offsets, C.c_uint32), _ptr(b.masks, C.c_uint8))
+
+    def score(self, candidates) -> np.ndarray:
+        """int64[n, 2] = (n_mod, n_nomod) per candidate — what ``model.update`` receives (find_motifs_bin.py:1320)."""
+        b = candidates if isinstance(candidates, CandidateBatch) else self.make_batch(candidates)
+        out = np.zeros((len(b), 2), dtype=np.int64)
+        if len(b):
+            _lib.check(self.lib.nm_score_batch(self.ctx, *self._batch_args(b), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def score_into_device(self, batch: CandidateBatch, device_ptr: int):
+        """Asynchronous variant: counts land in device memory (e.g. a torch int64 tensor) on the engine stream."""
+        _lib.check(self.lib.nm_score_batch_device(self.ctx, *self._batch_args(batch), C.c_void_p(device_ptr)))
+
+    def hit_positions(self, contig, mod_type, motif: Motif, which: int) -> np.ndarray:
+        """Ascending contig-local positions; which = 0 meth fwd, 1 nonmeth fwd, 2 meth rev, 3 nonmeth rev
+        (motif_model_contig(save_motif_positions=True), find_motifs_bin.py:1322-1329)."""
+        cid = self.contig_index[contig] if isinstance(contig, str) else int(contig)
+        raw, pos = self._encode(motif)
+        masks = np.frombuffer(raw, dtype=np.uint8)
+        n = C.c_uint64(0)
+        cap = 1 << 16
+        while True:
+            out = np.empty(cap, dtype=np.int64)
+            _lib.check(self.lib.nm_hit_positions(self.ctx, cid, self.slot_of_mod[mod_type], len(raw), pos,
+                                                 _ptr(masks, C.c_uint8), which, _ptr(out, C.c_int64), cap, C.byref(n)))
+            if n.value <= cap:
+                return out[:n.value].copy()
+            cap = int(n.value)
+
+    # ------------------------------------------------------------------ measurement
+    def stats(self) -> dict:
+        w = (C.c_uint64 * 8)()
+        _lib.check(self.lib.nm_stats(self.ctx, w))
+        keys = ["total_bp", "padded_bp", "seq_plane_bytes", "state_plane_bytes", "launches", "last_workgroups",
+                "last_compact", "last_general"]
+        return dict(zip(keys, [int(x) for x in w]))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        _lib.check(self.lib.nm_last_kernel_ms(self.ctx, C.byref(ms)))
+        return float(ms.value)

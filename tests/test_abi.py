@@ -1,0 +1,33 @@
+"""CPU-side checks of the C-ABI library: it loads and exports every symbol include/nmscan.h declares
+(no compute calls — there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+from nanomotif_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nmscan.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nm_[a-z_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    path = build.build()
+    lib = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 12 and set(syms) == set(_lib.SYMBOLS)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in nmscan.h but not exported"
+    lib.nm_abi_version.restype = ctypes.c_int
+    assert lib.nm_abi_version() == 1
+
+
+def test_bad_arguments_fail_loudly_without_gpu():
+    lib = _lib.load()
+    assert lib.nm_ctx_create(0, None) == -1          # NM_EINVAL, no HIP call made
+    assert b"NULL" in lib.nm_last_error()
+    assert lib.nm_score_batch(None, 0, None, None, None, None, None, None, None) == -1

@@ -1,0 +1,162 @@
+"""GPU parity: the HIP engine (through the C ABI) against the reference-recorded vectors and the CPU oracle.
+Integer counts and hit positions must be bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, oracle_bin_inputs, sha1, spec_from_json
+from nanomotif_amd import synth
+from nanomotif_amd.motif import Motif
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine_cls():
+    from nanomotif_amd.engine import ScanEngine
+    return ScanEngine
+
+
+def _upload_metagenome(eng, mg, mod_types, low=0.3, high=0.7, min_cov=5, contigs=None):
+    idx = list(range(len(mg.names))) if contigs is None else list(contigs)
+    eng.upload_assembly([mg.names[i] for i in idx], [mg.contig_ascii(i) for i in idx], [mg.bin_names[i] for i in idx])
+    for mt in mod_types:
+        first = True
+        for local, i in enumerate(idx):
+            p = mg.contig_pileup(i, mt)
+            keep = p["nvalid"] > min_cov
+            eng.upload_pileup(mt, np.full(int(keep.sum()), local, np.uint32), p["position"][keep], p["strand"][keep],
+                              synth.pct_to_fraction(p["pct_hundredths"][keep]), low=low, high=high, append=not first)
+            first = False
+
+
+def test_reference_kat_tiny_sequence(engine_cls):
+    # tests/test_motif_find.py:14-39 expressed through the engine: motif ACG@0 in TACGGACGCCACG
+    eng = engine_cls()
+    eng.upload_assembly(["c"], ["TACGGACGCCACG"], ["b"])
+    eng.upload_pileup("a", [0, 0, 0], [1, 5, 10], np.frombuffer(b"+++", np.uint8), [0.9, 0.95, 0.1])
+    out = eng.score([(Motif("ACG", 0), "a", "b")])
+    assert out.tolist() == [[2, 1]]
+    assert eng.hit_positions("c", "a", Motif("ACG", 0), 0).tolist() == [1, 5]
+    assert eng.hit_positions("c", "a", Motif("ACG", 0), 1).tolist() == [10]
+    # subseq_indices KAT (tests/test_fasta.py:95-109): AA.T in AATTAAATTAAGTAAAT -> starts [0,4,5,9,13]
+    seq = "AATTAAATTAAGTAAAT"
+    eng.upload_assembly(["c"], [seq], ["b"])
+    eng.upload_pileup("a", np.zeros(len(seq), np.uint32), np.arange(len(seq)), np.full(len(seq), ord("+"), np.uint8),
+                      np.ones(len(seq)))
+    assert eng.hit_positions("c", "a", Motif("AA.T", 0), 0).tolist() == [0, 4, 5, 9, 13]
+    assert eng.hit_positions("c", "a", Motif("AATT", 0), 0).tolist() == [0, 5]
+    eng.close()
+
+
+def test_g2_counts_and_hit_positions_match_reference(engine_cls):
+    g = load_golden("g2_motif_model_contig.json")
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    assert hashlib.sha1(mg.contig_str(0).encode()).hexdigest() == g["seq_sha1"]
+    for (low, high) in ((0.3, 0.7), (0.1, 0.9)):
+        eng = engine_cls()
+        _upload_metagenome(eng, mg, ("a", "m"), low=low, high=high, min_cov=-1)
+        cases = [c for c in g["cases"] if (c["low"], c["high"]) == (low, high)]
+        cands = [(Motif(c["motif"], c["pos"]), c["mod_type"], mg.bin_names[0]) for c in cases]
+        out = eng.score(cands)                       # mixed canonical / non-canonical -> general planes
+        assert out.tolist() == [[c["n_mod"], c["n_nomod"]] for c in cases]
+        # canonical-only sub-batch takes the compact (strand-implied) path: must agree
+        can = [k for k, c in enumerate(cases)
+               if Motif(c["motif"], c["pos"]).split()[c["pos"]] == {"a": "A", "m": "C"}[c["mod_type"]]]
+        out2 = eng.score([cands[k] for k in can])
+        assert eng.stats()["last_compact"] == len(can) and len(can) > 50
+        assert out2.tolist() == [[cases[k]["n_mod"], cases[k]["n_nomod"]] for k in can]
+        keys = ("index_meth_fwd", "index_nonmeth_fwd", "index_meth_rev", "index_nonmeth_rev")
+        for c in cases[::3]:
+            for which, k in enumerate(keys):
+                pos = eng.hit_positions(0, c["mod_type"], Motif(c["motif"], c["pos"]), which)
+                assert len(pos) == c[k]["n"] and sha1(pos) == c[k]["sha1"], (c["motif"], k)
+        eng.close()
+
+
+def _oracle_counts(mg, mt, contigs, cands, low=0.3, high=0.7):
+    from oracle.scan import score_candidates
+    pile, seqs = oracle_bin_inputs(mg, mt, contigs=contigs)
+    return score_candidates(pile, seqs, cands, low, high)
+
+
+def test_multi_bin_metagenome_matches_oracle(engine_cls):
+    spec = synth.SynthSpec(n_contigs=12, total_bp=900_000, n_bins=3, mod_types=("a", "m"), seed=77,
+                           min_contig_bp=9_000, n_fraction=0.003)
+    mg = synth.make_metagenome(spec)
+    eng = engine_cls()
+    _upload_metagenome(eng, mg, ("a", "m"))
+    zoo = synth.random_candidates(120, seed=5)
+    zoo += [("." * 19 + "GATC" + "." * 18, 20, "a"), ("." * 19 + "CC[AT]GG" + "." * 15, 20, "m"), ("A", 0, "a"), ("C", 0, "m")]
+    cands, expect = [], []
+    for b in sorted(set(mg.bin_names)):
+        contigs = [i for i, x in enumerate(mg.bin_names) if x == b]
+        for mt in ("a", "m"):
+            these = [(s, p) for s, p, t in zoo if t == mt]
+            expect.append(_oracle_counts(mg, mt, contigs, these))
+            cands += [(Motif(s, p), mt, b) for s, p in these]
+    out = eng.score(cands)
+    assert np.array_equal(out, np.concatenate(expect))
+    assert eng.stats()["last_compact"] == len(cands)
+    # scoring the same batch in a shuffled order gives the same rows
+    perm = np.random.default_rng(0).permutation(len(cands))
+    assert np.array_equal(eng.score([cands[i] for i in perm]), out[perm])
+    eng.close()
+
+
+def test_edge_cases(engine_cls):
+    eng = engine_cls()
+    # contigs of awkward lengths around the 8192-bp chunk and 32-bit word edges, sites at both ends
+    rng = np.random.default_rng(3)
+    lens = [1, 5, 31, 32, 33, 64, 8191, 8192, 8193, 16384 - 64, 16384 - 63, 16385, 40_000]
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in lens]
+    seqs[3] = "GATC" * 8
+    seqs[5] = "N" * 10 + "GATC" + "R" * 10 + "GATCGATC" + "n" * 32
+    names = [f"c{i}" for i in range(len(lens))]
+    eng.upload_assembly(names, seqs, ["b"] * len(lens))
+    from oracle.scan import ContigPileup, score_candidates
+    pile, cid, pos, st, fr = {}, [], [], [], []
+    for i, s in enumerate(seqs):
+        p = np.array([k for k, ch in enumerate(s.upper()) if ch in "AT"], dtype=np.int64)
+        strand = np.array([ord("+") if s.upper()[k] == "A" else ord("-") for k in p], dtype=np.uint8)
+        f = rng.choice([0.0, 0.3, 0.30000000000000004, 0.5, 0.7, 0.6999999999999999, 1.0], size=len(p))
+        pile[names[i]] = ContigPileup(p, strand, f)
+        cid += [i] * len(p); pos += p.tolist(); st += strand.tolist(); fr += f.tolist()
+    eng.upload_pileup("a", cid, pos, np.array(st, np.uint8), fr)
+    motifs = [("GATC", 1), ("A", 0), ("A.", 0), (".A", 1), ("A" + "." * 30 + "T", 0), ("T" + "." * 39 + "A", 40),
+              ("A" + "." * 62 + "C", 0), ("G" + "." * 62 + "A", 63), ("[ACG]A[CGT]", 1), ("AA", 0), ("AA", 1),
+              ("TA", 1), ("G.TC....A", 8), ("....A....", 4)]
+    out = eng.score([(Motif(s, p), "a", "b") for s, p in motifs])
+    exp = score_candidates(pile, dict(zip(names, [s.upper() for s in seqs])), motifs)
+    assert np.array_equal(out, exp), (out.tolist(), exp.tolist())
+    # errors are loud
+    from nanomotif_amd._lib import NmScanError
+    with pytest.raises(NmScanError):
+        eng.score([(Motif("....", 1), "a", "b")])                       # no specified position
+    with pytest.raises(NmScanError):
+        eng.upload_pileup("a", [0, 0], [0, 0], np.frombuffer(b"++", np.uint8), [1.0, 1.0])   # duplicate row
+    with pytest.raises(NmScanError):
+        eng.upload_pileup("a", [0], [5], np.frombuffer(b"+", np.uint8), [1.0])                # beyond contig 0 (len 1)
+    assert eng.score([]).shape == (0, 2)
+    eng.close()
+
+
+def test_large_contig_properties(engine_cls):
+    """cfg 2 size (5 Mbp): size-independent properties + oracle spot checks."""
+    mg = synth.make_metagenome(synth.config("cfg2"))
+    eng = engine_cls()
+    _upload_metagenome(eng, mg, ("a",))
+    M = lambda s, p: (Motif(s, p), "a", mg.bin_names[0])
+    out = eng.score([M("GATC", 1), M("A", 0), M("AA", 1), M("CA", 1), M("GA", 1), M("TA", 1), M(".A", 1), M("GATC", 1)])
+    # linearity: sites of 'A' = sum over the four possible left neighbours, except the (at most one per strand)
+    # site that has no neighbour because it sits on a contig end
+    a, parts = out[1], out[2] + out[3] + out[4] + out[5]
+    assert np.all(a - parts >= 0) and np.all(a - parts <= 2)
+    assert np.array_equal(out[0], out[7])            # idempotent
+    assert np.array_equal(out[6], out[1])            # leading '.' is stripped
+    assert a.sum() > 2_000_000                       # every A / T row with a confident call is counted
+    exp = _oracle_counts(mg, "a", None, [("GATC", 1), ("GCAC......GTT", 2), ("A", 0), ("G[AG].GAAG[CT]", 5)])
+    got = eng.score([M("GATC", 1), M("GCAC......GTT", 2), M("A", 0), M("G[AG].GAAG[CT]", 5)])
+    assert np.array_equal(got, exp)
+    eng.close()
