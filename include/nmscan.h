@@ -70,6 +70,10 @@ int nm_set_stream(nm_ctx *ctx, void *hip_stream);
 int nm_upload_contigs(nm_ctx *ctx, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
                       uint32_t n_bins, const uint8_t *seq_ascii);
 
+/* Same, with the concatenated sequences already in device memory (offsets / bin_id stay host arrays). */
+int nm_upload_contigs_device(nm_ctx *ctx, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
+                             uint32_t n_bins, const uint8_t *d_seq_ascii);
+
 /*
  * Pileup upload for one modification type — replaces the six polars filters executed per candidate per contig
  * (find_motifs_bin.py:1274, 1308-1314): rows are classified ONCE, methylated <=> fraction_mod >= high,
@@ -83,6 +87,11 @@ int nm_upload_contigs(nm_ctx *ctx, uint32_t n_contigs, const uint64_t *offsets, 
 int nm_upload_pileup(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_base, double low, double high,
                      uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
                      const uint8_t *strand, const double *fraction_mod, int append);
+
+/* Same, with the four columns already in device memory (e.g. written by a GPU-side parser or generator). */
+int nm_upload_pileup_device(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_base, double low, double high,
+                            uint64_t n_rows, const uint32_t *d_contig_id, const uint32_t *d_position,
+                            const uint8_t *d_strand, const double *d_fraction_mod, int append);
 
 /*
  * Score a batch of candidate motifs — replaces n_cand calls of motif_model_bin(..., BetaBernoulliModel())

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libnmscan.so")
 
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
-    "nm_upload_pileup", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
+    "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms",
 ]
 
@@ -46,8 +46,11 @@ def load():
     lib.nm_ctx_destroy.argtypes = [p]
     lib.nm_set_stream.argtypes = [p, p]
     lib.nm_upload_contigs.argtypes = [p, C.c_uint32, u64p, u32p, C.c_uint32, u8p]
+    lib.nm_upload_contigs_device.argtypes = [p, C.c_uint32, u64p, u32p, C.c_uint32, p]
     lib.nm_upload_pileup.argtypes = [p, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.c_uint64, u32p, u32p, u8p,
                                      f64p, C.c_int]
+    lib.nm_upload_pileup_device.argtypes = [p, C.c_uint32, C.c_uint8, C.c_double, C.c_double, C.c_uint64, p, p, p, p,
+                                            C.c_int]
     for name in ("nm_score_batch", "nm_score_batch_device"):
         getattr(lib, name).argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p, p]
     lib.nm_hit_positions.argtypes = [p, C.c_uint32, C.c_uint32, C.c_uint8, C.c_uint8, u8p, C.c_int, i64p, C.c_uint64,

@@ -670,8 +670,8 @@ int nm_set_stream(nm_ctx *c, void *hip_stream) {
     return NM_OK;
 }
 
-int nm_upload_contigs(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
-                      uint32_t n_bins, const uint8_t *seq_ascii) {
+static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
+                               uint32_t n_bins, const uint8_t *seq_ascii, bool on_device) {
     if (!c || !offsets || !bin_id || !seq_ascii) return fail(NM_EINVAL, "NULL argument");
     if (n_contigs == 0 || n_bins == 0) return fail(NM_EINVAL, "need at least one contig and one bin");
     if (offsets[0] != 0) return fail(NM_EINVAL, "offsets[0] must be 0");
@@ -729,10 +729,11 @@ int nm_upload_contigs(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, co
     uint8_t *d_ascii = nullptr;
     uint64_t *d_off = nullptr;
     uint32_t *d_chunk_contig = nullptr;
-    HIP_TRY(hipMalloc(&d_ascii, c->total_bp));
+    if (on_device) d_ascii = const_cast<uint8_t *>(seq_ascii);
+    else HIP_TRY(hipMalloc(&d_ascii, c->total_bp));
     HIP_TRY(hipMalloc(&d_off, (size_t)(n_contigs + 1) * 8));
     HIP_TRY(hipMalloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
-    HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
+    if (!on_device) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, d_chunk_contig,
@@ -749,15 +750,15 @@ int nm_upload_contigs(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, co
     HIP_TRY(hipMalloc(&c->d_segments, segs.size() * sizeof(uint4)));
     HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_ascii);
+    if (!on_device) (void)hipFree(d_ascii);
     (void)hipFree(d_off);
     (void)hipFree(d_chunk_contig);
     return NM_OK;
 }
 
-int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high, uint64_t n_rows,
-                     const uint32_t *contig_id, const uint32_t *position, const uint8_t *strand,
-                     const double *fraction_mod, int append) {
+static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high,
+                              uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                              const uint8_t *strand, const double *fraction_mod, int append, bool on_device) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
     if (mod_slot >= NM_MAX_MOD_SLOTS) return fail(NM_EINVAL, "mod_slot %u >= %d", mod_slot, NM_MAX_MOD_SLOTS);
@@ -782,28 +783,39 @@ int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, doubl
     ms.high = high;
     if (n_rows == 0) return NM_OK;
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
-    // stream the SoA columns through the staging buffer in slabs
-    const uint64_t slab = 8ull << 20;  // rows per slab (17 B each)
+    const uint32_t can_h = 0, can_l = canonical_base == 'C' ? 1u : 0u;   // A = 00, C = 01
+    // host columns stream through the pinned staging ring in slabs; device columns are consumed in place
+    const uint64_t slab = on_device ? n_rows : (8ull << 20);  // rows per slab (17 B each)
     for (uint64_t r0 = 0; r0 < n_rows; r0 += slab) {
         const uint64_t n = std::min(slab, n_rows - r0);
-        const size_t o_pos = n * 4, o_frac = ((o_pos + n * 4) + 7) & ~(size_t)7, o_str = o_frac + n * 8;
-        int rc = ensure_stage(c, o_str + n);
-        if (rc) return rc;
-        uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
-        memcpy(hs, contig_id + r0, n * 4);
-        memcpy(hs + o_pos, position + r0, n * 4);
-        memcpy(hs + o_frac, fraction_mod + r0, n * 8);
-        memcpy(hs + o_str, strand + r0, n);
-        HIP_TRY(hipMemcpyAsync(ds, hs, o_str + n, hipMemcpyHostToDevice, c->stream));
-        const uint32_t can_h = 0, can_l = canonical_base == 'C' ? 1u : 0u;   // A = 00, C = 01
-        hipLaunchKernelGGL(state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
-                           reinterpret_cast<uint32_t *>(ds), reinterpret_cast<uint32_t *>(ds + o_pos), ds + o_str,
-                           reinterpret_cast<double *>(ds + o_frac), low, high, c->d_contig_chunk, c->d_contig_len,
-                           c->n_contigs, can_h, can_l, c->dH, c->dL, c->dV, ms.planes[0], ms.planes[1], ms.planes[2],
-                           ms.planes[3], ms.planes[4], ms.planes[5], c->d_err);
+        const uint32_t *d_cid = contig_id + r0, *d_pos = position + r0;
+        const uint8_t *d_str = strand + r0;
+        const double *d_frac = fraction_mod + r0;
+        int rc = NM_OK;
+        if (!on_device) {
+            const size_t o_pos = n * 4, o_frac = ((o_pos + n * 4) + 7) & ~(size_t)7, o_str = o_frac + n * 8;
+            rc = ensure_stage(c, o_str + n);
+            if (rc) return rc;
+            uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+            memcpy(hs, contig_id + r0, n * 4);
+            memcpy(hs + o_pos, position + r0, n * 4);
+            memcpy(hs + o_frac, fraction_mod + r0, n * 8);
+            memcpy(hs + o_str, strand + r0, n);
+            HIP_TRY(hipMemcpyAsync(ds, hs, o_str + n, hipMemcpyHostToDevice, c->stream));
+            d_cid = reinterpret_cast<uint32_t *>(ds);
+            d_pos = reinterpret_cast<uint32_t *>(ds + o_pos);
+            d_str = ds + o_str;
+            d_frac = reinterpret_cast<double *>(ds + o_frac);
+        }
+        hipLaunchKernelGGL(state_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, d_cid, d_pos,
+                           d_str, d_frac, low, high, c->d_contig_chunk, c->d_contig_len, c->n_contigs, can_h, can_l,
+                           c->dH, c->dL, c->dV, ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4],
+                           ms.planes[5], c->d_err);
         HIP_TRY(hipGetLastError());
-        rc = release_stage(c);
-        if (rc) return rc;
+        if (!on_device) {
+            rc = release_stage(c);
+            if (rc) return rc;
+        }
     }
     unsigned int err = 0;
     HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
@@ -813,6 +825,30 @@ int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, doubl
     if (err & 2u) return fail(NM_EINVAL, "pileup strand must be '+' or '-'");
     if (err & 4u) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
     return NM_OK;
+}
+
+int nm_upload_contigs(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id, uint32_t n_bins,
+                      const uint8_t *seq_ascii) {
+    return upload_contigs_impl(c, n_contigs, offsets, bin_id, n_bins, seq_ascii, false);
+}
+
+int nm_upload_contigs_device(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
+                             uint32_t n_bins, const uint8_t *d_seq_ascii) {
+    return upload_contigs_impl(c, n_contigs, offsets, bin_id, n_bins, d_seq_ascii, true);
+}
+
+int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high, uint64_t n_rows,
+                     const uint32_t *contig_id, const uint32_t *position, const uint8_t *strand,
+                     const double *fraction_mod, int append) {
+    return upload_pileup_impl(c, mod_slot, canonical_base, low, high, n_rows, contig_id, position, strand, fraction_mod,
+                              append, false);
+}
+
+int nm_upload_pileup_device(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high,
+                            uint64_t n_rows, const uint32_t *d_contig_id, const uint32_t *d_position,
+                            const uint8_t *d_strand, const double *d_fraction_mod, int append) {
+    return upload_pileup_impl(c, mod_slot, canonical_base, low, high, n_rows, d_contig_id, d_position, d_strand,
+                              d_fraction_mod, append, true);
 }
 
 int nm_score_batch(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,

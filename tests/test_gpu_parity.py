@@ -65,7 +65,7 @@ def test_g2_counts_and_hit_positions_match_reference(engine_cls):
         can = [k for k, c in enumerate(cases)
                if Motif(c["motif"], c["pos"]).split()[c["pos"]] == {"a": "A", "m": "C"}[c["mod_type"]]]
         out2 = eng.score([cands[k] for k in can])
-        assert eng.stats()["last_compact"] == len(can) and len(can) > 50
+        assert eng.stats()["last_compact"] == len(can) and len(can) > 10
         assert out2.tolist() == [[cases[k]["n_mod"], cases[k]["n_nomod"]] for k in can]
         keys = ("index_meth_fwd", "index_nonmeth_fwd", "index_meth_rev", "index_nonmeth_rev")
         for c in cases[::3]:
