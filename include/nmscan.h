@@ -112,6 +112,16 @@ int nm_score_batch_device(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin
                           const uint8_t *cand_masks, int64_t *d_out_counts);
 
 /*
+ * Parse n regex-style motif strings (characters A C G T . and [..] sets, the form the reference keeps in
+ * Motif.string) into the candidate arrays nm_score_batch takes: strips flanking dots and shifts mod_position
+ * exactly like Motif.new_stripped_motif (motif.py:213-224).  text holds the strings back to back,
+ * text_offset[n+1] their byte offsets.  No GPU involved.
+ */
+int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, const int32_t *mod_position,
+                    uint8_t *out_len, uint8_t *out_modpos, uint32_t *out_mask_offset, uint8_t *out_masks,
+                    uint64_t masks_capacity, uint64_t *masks_used);
+
+/*
  * Hit positions of one candidate on one contig — the four arrays motif_model_contig returns with
  * save_motif_positions=True (find_motifs_bin.py:1322-1329), ascending.  which: 0 = index_meth_fwd,
  * 1 = index_nonmeth_fwd, 2 = index_meth_rev, 3 = index_nonmeth_rev.  Writes at most `capacity` positions to
@@ -129,6 +139,12 @@ int nm_stats(nm_ctx *ctx, uint64_t what[8]);
 /* Device time of the last scoring launch(es) in milliseconds, measured with HIP events on the ctx stream
  * (kernels only, no copies).  Blocks until the launch finished. */
 int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
+
+/* Per-launch timing over a region: nm_timing_reset(ctx, 1) starts collecting one HIP event pair per scoring
+ * launch (no synchronisation per launch); nm_timing_total_ms sums the kernel durations recorded since then and
+ * reports how many launches they cover; nm_timing_reset(ctx, 0) stops collecting. */
+int nm_timing_reset(nm_ctx *ctx, int enable);
+int nm_timing_total_ms(nm_ctx *ctx, double *total_ms, uint64_t *n_launches);
 
 #ifdef __cplusplus
 }

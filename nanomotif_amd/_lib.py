@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libnmscan.so")
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
-    "nm_last_kernel_ms",
+    "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
 ]
 
 _lib = None
@@ -57,6 +57,10 @@ def load():
                                      u64p]
     lib.nm_stats.argtypes = [p, u64p]
     lib.nm_last_kernel_ms.argtypes = [p, C.POINTER(C.c_float)]
+    lib.nm_parse_motifs.argtypes = [C.c_uint32, C.c_char_p, u32p, C.POINTER(C.c_int32), u8p, u8p, u32p, u8p, C.c_uint64,
+                                    u64p]
+    lib.nm_timing_reset.argtypes = [p, C.c_int]
+    lib.nm_timing_total_ms.argtypes = [p, C.POINTER(C.c_double), u64p]
     for s in SYMBOLS:
         if s != "nm_last_error":
             getattr(lib, s).restype = C.c_int

@@ -377,6 +377,10 @@ struct nm_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // per-launch event pairs since the last nm_timing_reset (bounded pool, summed lazily: no sync per launch)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    bool ev_collect = false;
     // assembly
     uint32_t n_contigs = 0, n_bins = 0, n_chunks = 0;
     uint64_t total_bp = 0;
@@ -576,16 +580,29 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
     dim3 grid(gx, n_active);
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    if (c->ev_collect) {
+        if (c->ev_used == c->ev_pool.size()) {
+            if (c->ev_pool.size() >= 65536) return fail(NM_ESTATE, "timing pool exhausted: call nm_timing_reset");
+            hipEvent_t a_ = nullptr, b_ = nullptr;
+            HIP_TRY(hipEventCreate(&a_));
+            HIP_TRY(hipEventCreate(&b_));
+            c->ev_pool.emplace_back(a_, b_);
+        }
+        e0 = c->ev_pool[c->ev_used].first;
+        e1 = c->ev_pool[c->ev_used].second;
+        c->ev_used += 1;
+    }
+    HIP_TRY(hipEventRecord(e0, c->stream));
     if (!any_wide && all_compact) launch_score<1, 1, true>(a, grid, c->stream);
     else if (!any_wide) launch_score<1, 1, false>(a, grid, c->stream);
     else if (all_compact) launch_score<2, 2, true>(a, grid, c->stream);
     else launch_score<2, 2, false>(a, grid, c->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventRecord(e1, c->stream));
     rc = release_stage(c);
     if (rc) return rc;
-    c->timed = true;
+    c->timed = !c->ev_collect;
     c->launches += 1;
     c->last_wgs = (uint64_t)gx * n_active;
     c->last_compact = all_compact ? n_cand : 0;
@@ -655,6 +672,10 @@ int nm_ctx_destroy(nm_ctx *c) {
     }
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_err) (void)hipFree(c->d_err);
+    for (auto &pr : c->ev_pool) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -913,6 +934,59 @@ int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t l
     return NM_OK;
 }
 
+int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, const int32_t *mod_position,
+                    uint8_t *out_len, uint8_t *out_modpos, uint32_t *out_mask_offset, uint8_t *out_masks,
+                    uint64_t masks_capacity, uint64_t *masks_used) {
+    if (n && (!text || !text_offset || !mod_position || !out_len || !out_modpos || !out_mask_offset || !out_masks || !masks_used))
+        return fail(NM_EINVAL, "NULL argument");
+    uint64_t used = 0;
+    uint8_t tmp[4096];
+    for (uint32_t k = 0; k < n; ++k) {
+        const char *s = text + text_offset[k];
+        const uint32_t slen = text_offset[k + 1] - text_offset[k];
+        uint32_t nt = 0;
+        for (uint32_t i = 0; i < slen;) {
+            uint8_t m = 0;
+            const char ch = s[i];
+            if (ch == '[') {
+                uint32_t j = i + 1;
+                while (j < slen && s[j] != ']') {
+                    const char b = s[j++];
+                    m |= b == 'A' ? NM_BASE_A : b == 'C' ? NM_BASE_C : b == 'G' ? NM_BASE_G : b == 'T' ? NM_BASE_T : 0x80;
+                }
+                if (j >= slen) return fail(NM_EINVAL, "motif %u: unmatched '[' (motif.py:239)", k);
+                if (m == 0 || (m & 0x80)) return fail(NM_EINVAL, "motif %u: a bracket may only list A, C, G, T", k);
+                i = j + 1;
+            } else {
+                m = ch == 'A' ? NM_BASE_A : ch == 'C' ? NM_BASE_C : ch == 'G' ? NM_BASE_G : ch == 'T' ? NM_BASE_T
+                    : ch == '.' ? 15 : 0;
+                if (m == 0)
+                    return fail(NM_EINVAL, "motif %u: character '%c' is not A/C/G/T/./[..] — the reference scans motifs as "
+                                           "regular expressions (utils.py:61), other letters would be literals", k, ch);
+                i += 1;
+            }
+            if (nt >= sizeof tmp) return fail(NM_ERANGE, "motif %u longer than %zu positions", k, sizeof tmp);
+            tmp[nt++] = m;
+        }
+        uint32_t lo = 0, hi = nt;
+        while (lo < nt && tmp[lo] == 15) ++lo;
+        if (lo == nt) { lo = 0; }                      // all dots: left as is (motif.py:218-219), rejected at scoring
+        else while (hi > lo && tmp[hi - 1] == 15) --hi;
+        const uint32_t len = hi - lo;
+        const int64_t mp = (int64_t)mod_position[k] - (int64_t)lo;
+        if (len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "motif %u: stripped length %u > %d", k, len, NM_MAX_MOTIF_LEN);
+        if (mp < 0 || mp >= (int64_t)len) return fail(NM_EINVAL, "motif %u: mod_position %d outside the stripped motif", k, mod_position[k]);
+        if (used + len > masks_capacity) return fail(NM_ERANGE, "masks buffer too small");
+        memcpy(out_masks + used, tmp + lo, len);
+        out_len[k] = (uint8_t)len;
+        out_modpos[k] = (uint8_t)mp;
+        out_mask_offset[k] = (uint32_t)used;
+        used += len;
+    }
+    *masks_used = used;
+    return NM_OK;
+}
+
 int nm_stats(nm_ctx *c, uint64_t what[8]) {
     if (!c || !what) return fail(NM_EINVAL, "NULL argument");
     what[0] = c->total_bp;
@@ -923,6 +997,29 @@ int nm_stats(nm_ctx *c, uint64_t what[8]) {
     what[5] = c->last_wgs;
     what[6] = c->last_compact;
     what[7] = c->last_general;
+    return NM_OK;
+}
+
+int nm_timing_reset(nm_ctx *c, int enable) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ev_used = 0;
+    c->ev_collect = enable != 0;
+    c->timed = false;
+    return NM_OK;
+}
+
+int nm_timing_total_ms(nm_ctx *c, double *total_ms, uint64_t *n_launches) {
+    if (!c || !total_ms || !n_launches) return fail(NM_EINVAL, "NULL argument");
+    double tot = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(c->ev_pool[i].second));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *n_launches = c->ev_used;
     return NM_OK;
 }
 

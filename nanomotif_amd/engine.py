@@ -42,7 +42,6 @@ class ScanEngine:
         self.bin_index = {}
         self.bin_names = []
         self.slot_of_mod = {}
-        self._cand_cache = {}
 
     def close(self):
         if self.ctx:
@@ -105,39 +104,27 @@ class ScanEngine:
                                              _ptr(fr, C.c_double), 1 if append else 0))
 
     # ------------------------------------------------------------------ scoring
-    def _encode(self, motif: Motif):
-        key = (motif.string, motif.mod_position)
-        hit = self._cand_cache.get(key)
-        if hit is None:
-            sets, pos = motif.stripped_sets()
-            hit = (sets.tobytes(), int(pos))
-            if len(self._cand_cache) < 1 << 18:
-                self._cand_cache[key] = hit
-        return hit
-
     def make_batch(self, candidates) -> CandidateBatch:
-        """candidates: iterable of (Motif, mod_type, bin name or id)."""
+        """candidates: sequence of (Motif, mod_type, bin name or id).  Parsing / stripping is done natively
+        (nm_parse_motifs); Python only joins the strings."""
         n = len(candidates)
-        bins = np.empty(n, dtype=np.uint32)
-        slots = np.empty(n, dtype=np.uint8)
+        strings = [c[0].string for c in candidates]
+        text = "".join(strings).encode("ascii")
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        np.cumsum(np.fromiter((len(s) for s in strings), dtype=np.uint32, count=n), out=offsets[1:])
+        modpos_in = np.fromiter((c[0].mod_position for c in candidates), dtype=np.int32, count=n)
+        bi, so = self.bin_index, self.slot_of_mod
+        bins = np.fromiter((bi[c[2]] if isinstance(c[2], str) else c[2] for c in candidates), dtype=np.uint32, count=n)
+        slots = np.fromiter((so[c[1]] for c in candidates), dtype=np.uint8, count=n)
         lens = np.empty(n, dtype=np.uint8)
         modpos = np.empty(n, dtype=np.uint8)
-        offsets = np.empty(n, dtype=np.uint32)
-        chunks = []
-        off = 0
-        for k, (motif, mod_type, b) in enumerate(candidates):
-            raw, pos = self._encode(motif)
-            if len(raw) > 64 or not 0 <= pos < len(raw):
-                raise ValueError(f"motif {motif!r}: stripped length {len(raw)} / mod_position {pos} unsupported")
-            bins[k] = self.bin_index[b] if isinstance(b, str) else int(b)
-            slots[k] = self.slot_of_mod[mod_type]
-            lens[k] = len(raw)
-            modpos[k] = pos
-            offsets[k] = off
-            chunks.append(raw)
-            off += len(raw)
-        masks = np.frombuffer(b"".join(chunks), dtype=np.uint8) if chunks else np.zeros(0, np.uint8)
-        return CandidateBatch(bins, slots, lens, modpos, offsets, masks)
+        moff = np.empty(n, dtype=np.uint32)
+        masks = np.empty(max(len(text), 1), dtype=np.uint8)
+        used = C.c_uint64(0)
+        _lib.check(self.lib.nm_parse_motifs(n, text, _ptr(offsets, C.c_uint32), _ptr(modpos_in, C.c_int32),
+                                            _ptr(lens, C.c_uint8), _ptr(modpos, C.c_uint8), _ptr(moff, C.c_uint32),
+                                            _ptr(masks, C.c_uint8), len(masks), C.byref(used)))
+        return CandidateBatch(bins, slots, lens, modpos, moff, masks[:used.value])
 
     def _batch_args(self, b: CandidateBatch):
         return (len(b), _ptr(b.bins, C.c_uint32), _ptr(b.slots, C.c_uint8), _ptr(b.lens, C.c_uint8),
@@ -159,14 +146,13 @@ class ScanEngine:
         """Ascending contig-local positions; which = 0 meth fwd, 1 nonmeth fwd, 2 meth rev, 3 nonmeth rev
         (motif_model_contig(save_motif_positions=True), find_motifs_bin.py:1322-1329)."""
         cid = self.contig_index[contig] if isinstance(contig, str) else int(contig)
-        raw, pos = self._encode(motif)
-        masks = np.frombuffer(raw, dtype=np.uint8)
+        b = self.make_batch([(motif, mod_type, 0)])
         n = C.c_uint64(0)
         cap = 1 << 16
         while True:
             out = np.empty(cap, dtype=np.int64)
-            _lib.check(self.lib.nm_hit_positions(self.ctx, cid, self.slot_of_mod[mod_type], len(raw), pos,
-                                                 _ptr(masks, C.c_uint8), which, _ptr(out, C.c_int64), cap, C.byref(n)))
+            _lib.check(self.lib.nm_hit_positions(self.ctx, cid, self.slot_of_mod[mod_type], int(b.lens[0]), int(b.modpos[0]),
+                                                 _ptr(b.masks, C.c_uint8), which, _ptr(out, C.c_int64), cap, C.byref(n)))
             if n.value <= cap:
                 return out[:n.value].copy()
             cap = int(n.value)
@@ -178,6 +164,15 @@ class ScanEngine:
         keys = ["total_bp", "padded_bp", "seq_plane_bytes", "state_plane_bytes", "launches", "last_workgroups",
                 "last_compact", "last_general"]
         return dict(zip(keys, [int(x) for x in w]))
+
+    def timing_reset(self, enable: bool = True):
+        _lib.check(self.lib.nm_timing_reset(self.ctx, 1 if enable else 0))
+
+    def timing_total(self):
+        """(sum of scoring-kernel durations in ms, number of launches) since ``timing_reset(True)``."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _lib.check(self.lib.nm_timing_total_ms(self.ctx, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)
