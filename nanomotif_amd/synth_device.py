@@ -53,6 +53,16 @@ def _match_starts(bit, seg_id, masks):
     return ok
 
 
+_FRAC_TABLE = {}
+
+
+def _fraction_table(device):
+    key = str(device)
+    if key not in _FRAC_TABLE:
+        _FRAC_TABLE[key] = torch.from_numpy(synth.pct_to_fraction(np.arange(10001))).to(device)
+    return _FRAC_TABLE[key]
+
+
 class DeviceBin:
     """Generated data of one bin: ASCII codes of its contigs (concatenated) and pileup columns per mod type."""
 
@@ -133,7 +143,9 @@ def generate_bin(mg: synth.SynthMetagenome, bin_name: str, device, min_cov: int 
         pp = torch.cat([c[1] for c in cols]).to(torch.int32)
         st = torch.cat([c[2] for c in cols])
         pct = torch.cat([c[3] for c in cols])
-        frac = (pct.to(torch.float64) / 100.0) / 100.0                        # == synth.pct_to_fraction
+        # float64 division on the device is not guaranteed to round like numpy's: look the fraction up in a
+        # table computed on the host with synth.pct_to_fraction (10 001 possible values)
+        frac = _fraction_table(device)[pct]
         pileups[mt] = dict(contig_id=cid.contiguous(), position=pp.contiguous(), strand=st.contiguous(),
                            fraction_mod=frac.contiguous())
         if keep_nvalid:
