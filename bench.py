@@ -186,6 +186,13 @@ def main():
     final = counts.cpu().numpy()
 
     result = None
+    traffic, traffic_src = None, None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        t = json.load(open(tj))
+        if (t.get("workload"), t.get("total_bp"), t.get("candidates"), t.get("n_gpus")) == \
+                (args.workload, args.total_bp, len(cands), world):
+            traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
     if rank == 0:
         value = sites_per_step * args.steps / elapsed
         achieved = algo_bytes_rank / (kernel_ms * 1e-3) / 1e9
@@ -200,7 +207,8 @@ def main():
                        "mod_types": ["a", "m"], "sharding": f"contigs over {world} GPU(s), LPT by length",
                        "motif_sites_per_step": sites_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src or "not collected for this configuration (rocprofv3 --pmc runs: profiles/)",
                          "kernel": "score_kernel<1,1,compact>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
