@@ -1,0 +1,3 @@
+from .main import main
+
+main()

@@ -59,9 +59,10 @@ class ScanEngine:
         _lib.check(self.lib.nm_set_stream(self.ctx, C.c_void_p(hip_stream_handle or 0)))
 
     # ------------------------------------------------------------------ assembly
-    def upload_assembly(self, names, sequences, bin_of_contig):
+    def upload_assembly(self, names, sequences, bin_of_contig, bin_names=None):
         """names: contig names; sequences: str / bytes / uint8 arrays (any case, IUPAC letters);
-        bin_of_contig: bin name per contig.  Bin ids are assigned in sorted bin-name order."""
+        bin_of_contig: bin name per contig.  Bin ids are assigned in sorted bin-name order, or follow
+        ``bin_names`` when given (a multi-GPU shard may hold no contig of some bins but must number them alike)."""
         names = list(names)
         if not names:
             raise ValueError("assembly is empty")
@@ -74,7 +75,7 @@ class ScanEngine:
         offsets = np.zeros(len(bufs) + 1, dtype=np.uint64)
         np.cumsum(lengths, out=offsets[1:])
         ascii_all = np.concatenate(bufs) if len(bufs) > 1 else np.ascontiguousarray(bufs[0])
-        self.bin_names = sorted(set(bin_of_contig))
+        self.bin_names = sorted(set(bin_of_contig)) if bin_names is None else list(bin_names)
         self.bin_index = {b: i for i, b in enumerate(self.bin_names)}
         bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
         _lib.check(self.lib.nm_upload_contigs(self.ctx, len(names), _ptr(offsets, C.c_uint64), _ptr(bin_ids, C.c_uint32),

@@ -1,0 +1,94 @@
+"""FASTA / contig-bin readers of the MI355X build (reference: nanomotif/fasta.py:35-187, seq.py:53-71).
+Sequences are kept as upper-case uint8 ASCII arrays — the form the engine uploads and the window extractor indexes."""
+from __future__ import annotations
+
+import gzip
+import logging as log
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+IUPAC = np.zeros(256, dtype=bool)
+for _c in "ATGCRYSWKMBDHVN":
+    IUPAC[ord(_c)] = True
+
+
+def _open(path):
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "r")
+
+
+def read_fasta_names_and_seqs(path):
+    """Yield (name = first whitespace-delimited header token, sequence string)."""
+    name, chunks = None, []
+    with _open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if line[0] == ">":
+                if name is not None:
+                    yield name, "".join(chunks)
+                name, chunks = line[1:].split()[0] if line[1:].split() else "", []
+            elif name is not None:
+                chunks.append(line)
+    if name is not None:
+        yield name, "".join(chunks)
+
+
+def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
+    """name -> upper-case uint8 array.  Empty or non-IUPAC sequences fail like DNAsequence._check_sequence
+    (seq.py:68-71)."""
+    out = {}
+    for name, seq in read_fasta_names_and_seqs(path):
+        if trim_names:
+            name = name.split(trim_character)[0]
+        arr = np.frombuffer(seq.upper().encode("ascii"), dtype=np.uint8)
+        assert len(arr) > 0, "DNA sequence must not be empty"
+        assert IUPAC[arr].all(), "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN"
+        out[name] = arr
+    return out
+
+
+def generate_contig_bin(args) -> dict:
+    """fasta.py:122-187 -> ordered dict contig -> bin.  -c: 2-column TSV without header; -f / -d: bin = file stem,
+    contig = first header token; with -f/-d the mapping is also written to OUT/temp/contig_bin.tsv."""
+    if getattr(args, "contig_bin", None):
+        out = {}
+        with open(args.contig_bin) as f:
+            for line in f:
+                line = line.rstrip("\r\n")
+                if not line:
+                    continue
+                parts = line.split("\t")
+                out[str(parts[0])] = str(parts[1])
+        return out
+    if getattr(args, "files", None):
+        files = list(args.files)
+        for fp in files:
+            if not Path(fp).exists():
+                log.warning(f"Error: File '{fp}' does not exist")
+                sys.exit(1)
+    else:
+        d = Path(args.directory)
+        if not d.exists():
+            print(f"Error: Directory '{args.directory}' does not exist", file=sys.stderr)
+            sys.exit(1)
+        ext = args.extension if args.extension.startswith(".") else "." + args.extension
+        files = [str(p) for p in sorted(d.glob(f"*{ext}"))]
+    if not files:
+        log.error("No files to process")
+        sys.exit(1)
+    out = {}
+    for fp in files:
+        stem = Path(fp).stem
+        for name, _ in read_fasta_names_and_seqs(fp):
+            if name:
+                out[name] = stem
+    path = os.path.join(args.out, "temp", "contig_bin.tsv")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        for c, b in out.items():
+            f.write(f"{c}\t{b}\n")
+    return out

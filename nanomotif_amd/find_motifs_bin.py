@@ -1,0 +1,237 @@
+"""Motif discovery driver of the MI355X build — the host-side mirror of nanomotif/find_motifs_bin.py.
+
+Same public names and argument meaning as the reference for the pieces on the hot path
+(``ProcessorConfig``, ``motif_model_bin``, ``get_parent_scores``, ``find_best_candidates``,
+``process_subpileup``, ``predictive_evaluation_score``), but the structure is GPU-first:
+
+    reference: Pool(T) workers, one (bin, mod type) task each; every candidate = one regex scan of the bin
+    here:      ONE process per GPU holds every bin in HBM; all (bin, mod type) searches advance in lock-step
+               and each round of open candidates is one nm_score_batch launch (+ one all-reduce with N GPUs)
+"""
+from __future__ import annotations
+
+import logging as log
+import os
+import random
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import pileup as pileup_mod
+from . import postprocess
+from .model import BetaBernoulliModel, predictive_evaluation_score  # noqa: F401  (re-exported like the reference)
+from .motif import MOD_TYPE_TO_CANONICAL, Motif
+from .pileup import MOD_TYPES, PileupTable
+from .search import extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
+
+IUPAC_LETTERS = set("ATGCRYSWKMBDHVN")
+
+
+# ------------------------------------------------------------------------------------------------ config
+@dataclass
+class ProcessorConfig:
+    """find_motifs_bin.py:59-130 — same fields, same validation and messages."""
+    assembly: dict
+    pileup_path: str
+    bin_contig: dict            # contig -> bin
+    threads: int
+    search_frame_size: int
+    methylation_threshold_low: float
+    methylation_threshold_high: float
+    minimum_kl_divergence: float
+    score_threshold: float
+    log_dir: str
+    seed: int
+    output_dir: str
+    verbose: bool = False
+
+    def __post_init__(self):
+        if self.assembly is None:
+            raise ValueError("assembly cannot be None")
+        if self.pileup_path is None:
+            raise ValueError("pileup_path cannot be None")
+        if not self.bin_contig:
+            raise ValueError("bin_contig cannot be None or empty")
+        missing = sorted(set(self.bin_contig) - set(self.assembly))
+        if missing:
+            log.warning("Removing %d contig-bin assignments because the contigs are absent from the assembly: %s%s",
+                        len(missing), ", ".join(missing[:5]), "..." if len(missing) > 5 else "")
+            self.bin_contig = {c: b for c, b in self.bin_contig.items() if c in self.assembly}
+        if not self.bin_contig:
+            raise ValueError("No contigs remain in bin_contig after filtering against the assembly")
+        if self.threads <= 0:
+            raise ValueError("threads must be greater than 0")
+        if self.search_frame_size <= 1:
+            raise ValueError("search_frame_size must be greater than 1")
+        if not (0 <= self.methylation_threshold_high <= 1):
+            raise ValueError("methylation_threshold_high must be in [0,1]")
+        if not (0 <= self.methylation_threshold_low <= 1):
+            raise ValueError("methylation_threshold_low must be in [0,1]")
+        if self.methylation_threshold_high <= self.methylation_threshold_low:
+            raise ValueError("methylation_threshold_high must be greater than methylation_threshold_low")
+        if self.minimum_kl_divergence <= 0:
+            raise ValueError("minimum_kl_divergence must be > 0")
+        if not (0 <= self.score_threshold):
+            raise ValueError("score_threshold must be > 0")
+
+    @property
+    def padding(self):
+        return self.search_frame_size // 2
+
+
+# ------------------------------------------------------------------------------------------------ scoring
+class BinData:
+    """What the reference passes around as (bin pileup frame, dict of contig sequences): here a handle to the
+    engine-resident bin.  ``motif_model_bin(pileup=<BinData>, contigs=<BinData>, ...)`` keeps the call shape."""
+
+    def __init__(self, scorer, bin_name: str, mod_type: str):
+        self.scorer, self.bin_name, self.mod_type = scorer, bin_name, mod_type
+
+
+def motif_model_bin(pileup: BinData, contigs: BinData, motif: Motif, model: BetaBernoulliModel,
+                    low_meth_threshold, high_meth_threshold) -> BetaBernoulliModel:
+    """find_motifs_bin.py:1265-1283 — counts methylated / unmethylated motif sites over every contig of the bin on
+    both strands and ``update``s ``model`` IN PLACE (also returned), like the reference.  The thresholds must be
+    the ones the pileup was classified with at upload."""
+    s = pileup.scorer
+    if (low_meth_threshold, high_meth_threshold) != (s.low, s.high):
+        raise ValueError(f"thresholds {low_meth_threshold}/{high_meth_threshold} differ from the uploaded pileup's {s.low}/{s.high}")
+    assert type(motif) is Motif, "Motif is not a Motif type"
+    n_mod, n_nomod = s([((pileup.bin_name, pileup.mod_type), motif)])[0]
+    model.update(int(n_mod), int(n_nomod))
+    return model
+
+
+def get_parent_scores(motif: Motif, pileup: BinData, contigs: BinData, low_meth_threshold, high_meth_threshold):
+    """find_motifs_bin.py:1382-1433 (one batched launch for the motif and all its parents)."""
+    key = (pileup.bin_name, pileup.mod_type)
+    return run_lockstep({key: get_parent_scores_co(motif)}, pileup.scorer)[key]
+
+
+class LockstepScorer:
+    """score_fn of ``run_lockstep``: ``local_counts(flat) -> int64[n, 2]`` scores one round's requests against this
+    rank's contigs (the HIP engine in production); with ``use_dist`` the per-rank tables are summed with one
+    all-reduce per round (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, local_counts, low=0.3, high=0.7, use_dist=False, group=None):
+        self.local_counts, self.low, self.high = local_counts, low, high
+        self.use_dist, self.group = use_dist, group
+        self.rounds = 0
+        self.candidates = 0
+
+    def __call__(self, flat):
+        self.rounds += 1
+        self.candidates += len(flat)
+        counts = self.local_counts(flat) if flat else np.zeros((0, 2), dtype=np.int64)
+        if self.use_dist:
+            counts = allreduce_counts(counts, self.group)
+        return counts
+
+
+def engine_scorer(engine, low=0.3, high=0.7, use_dist=False, group=None) -> LockstepScorer:
+    return LockstepScorer(lambda flat: engine.score([(m, key[1], key[0]) for key, m in flat]), low, high, use_dist, group)
+
+
+def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
+    """Sum int64 count tables over ranks: nccl(=RCCL) moves them through the GPU, gloo on CPU."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(counts))
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, group=group)
+    return t.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ per-task pipeline
+def task_coroutine(bin_name, mod_type, windows, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+    """process_subpileup (find_motifs_bin.py:468-596) as one scoring coroutine: search, then post-processing."""
+    res = yield from find_best_candidates_co(
+        windows, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
+        max_rounds_since_new_best=30, score_threshold=cfg.score_threshold,
+        log=lambda msg: log.info(f"[{bin_name} {mod_type}] {msg}"))
+    if res is None:
+        log.info(f"[{bin_name} {mod_type}] No motifs found")
+        return None
+    graph, best, bin_pssm = res
+    if temp_dir:
+        os.makedirs(temp_dir, exist_ok=True)
+        np.savetxt(os.path.join(temp_dir, "background_pssm.txt"), bin_pssm, fmt="%.4f")
+        graph.export_graph_gml(os.path.join(temp_dir, f"motif_graph_{mod_type}.gml"))
+    rows = yield from postprocess.postprocess_co(graph, best, bin_name, mod_type, cfg.padding, on_stage=stage_writer)
+    return rows
+
+
+def confident_positions(table: PileupTable, contig_ids, high):
+    """name -> positions of rows with fraction_mod >= high, split by strand (find_motifs_bin.py:625, 635-636),
+    for every contig that has at least one row."""
+    plus, minus = {}, {}
+    conf = table.fraction_mod >= high
+    for cid in contig_ids:
+        sel = table.contig == cid
+        if not sel.any():
+            continue
+        name = table.contig_names[cid]
+        plus[name] = table.position[sel & conf & (table.strand == ord("+"))]
+        minus[name] = table.position[sel & conf & (table.strand == ord("-"))]
+    return plus, minus
+
+
+def discover(cfg: ProcessorConfig, table: PileupTable, scorer: LockstepScorer, rank=0, bgzip_order=False):
+    """Run every (bin, mod type) task of the data set.  ``table``: the post-filter pileup (all rows; every rank
+    holds it for window extraction); ``scorer``: see ``engine_scorer``.  Returns (list of MotifRow, scorer) —
+    identical on every rank."""
+    if (cfg.methylation_threshold_low, cfg.methylation_threshold_high) != (0.3, 0.7):
+        # merge_motifs_in_df is hard-wired to 0.3 / 0.7 in the reference (find_motifs_bin.py:569, 1436) while the
+        # search uses the CLI values; serving both needs two resident classifications.
+        raise NotImplementedError("methylation thresholds other than the defaults 0.3 / 0.7 are not supported yet")
+    bins = {}
+    for c, b in cfg.bin_contig.items():
+        bins.setdefault(b, []).append(c)
+    name_to_id = {n: i for i, n in enumerate(table.contig_names)}
+    tasks = {}
+    out_dir = cfg.output_dir
+    # task order and seeding follow the reference: plain pileup = one task per (bin, mod type), each seeded afresh
+    # (find_motifs_bin.py:152-171); bgzip = one task per bin, seeded once, mod types in constants order (:219-222, 248)
+    for bin_name in bins:
+        ids = [name_to_id[c] for c in bins[bin_name] if c in name_to_id]
+        if bgzip_order:
+            random.seed(cfg.seed)
+        for mt_id, mod_type in enumerate(MOD_TYPES):
+            sub = table.take((table.mod_type == mt_id) & np.isin(table.contig, ids))
+            if len(sub) == 0:
+                continue
+            if not bgzip_order:
+                random.seed(cfg.seed)
+            plus, minus = confident_positions(sub, ids, cfg.methylation_threshold_high)
+            windows = extract_windows(cfg.assembly, plus, minus, mod_type, cfg.padding)
+            if windows is None:
+                log.info(f"[{bin_name} {mod_type}] No methylation sequences found")
+                continue
+            stage_writer = None
+            temp_dir = None
+            if out_dir and rank == 0:
+                pre = os.path.join(out_dir, "precleanup-motifs", f"{bin_name}-{mod_type}")
+                os.makedirs(pre, exist_ok=True)
+                stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
+                temp_dir = os.path.join(out_dir, "temp", bin_name)
+            tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows, cfg, stage_writer, temp_dir)
+    results = run_lockstep(tasks, scorer)
+    rows = []
+    for key in tasks:
+        if results.get(key):
+            rows += results[key]
+    log.info(f"scoring rounds: {scorer.rounds}, candidates scored: {scorer.candidates}")
+    return rows, scorer
+
+
+# ------------------------------------------------------------------------------------------------ reference-shaped helpers
+def find_best_candidates(bin_pileup: BinData, bin_sequences: dict, mod_type: str, bin_name: str, output_dir,
+                         low_meth_threshold, high_meth_threshold, padding, min_kl=0.2, max_dead_ends=25,
+                         max_rounds_since_new_best=30, score_threshold=0.2, windows=None):
+    """find_motifs_bin.py:606-839 for a single bin (windows must be supplied: see ``extract_windows``)."""
+    key = (bin_name, mod_type)
+    co = find_best_candidates_co(windows, mod_type, padding, min_kl=min_kl, max_dead_ends=max_dead_ends,
+                                 max_rounds_since_new_best=max_rounds_since_new_best, score_threshold=score_threshold)
+    res = run_lockstep({key: co}, bin_pileup.scorer)[key]
+    return None if res is None else (res[0], res[1])

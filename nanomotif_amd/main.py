@@ -1,0 +1,173 @@
+"""``nanomotif motif_discovery`` on the MI355X engine (reference: nanomotif/main.py:18-104, 298-321).
+
+Single GPU:   python -m nanomotif_amd motif_discovery ASSEMBLY PILEUP -c CONTIG_BIN --out OUT
+Several GPUs: python -m torch.distributed.run --nproc-per-node N -m nanomotif_amd motif_discovery ...
+              (contigs are sharded over the ranks, count tables are all-reduced over RCCL, rank 0 writes the output)
+"""
+from __future__ import annotations
+
+import json
+import logging as log
+import os
+import random
+import sys
+import time
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+from . import fasta, pileup as pileup_mod, postprocess
+from .argparser import __version__, create_parser
+from .find_motifs_bin import ProcessorConfig, discover, engine_scorer
+from .shard import assign_contigs
+
+HEADER = "\t".join(postprocess.HEADER) + "\n"
+
+
+def set_seed(seed=42):
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+def shared_setup(args, working_dir, rank=0):
+    """main.py:18-43: output directory, logs/, args.<command>.json, seeds."""
+    if not os.path.exists(args.out):
+        os.makedirs(args.out, exist_ok=True)
+    elif rank == 0:
+        log.warning(f"Output directory {args.out} already exists")
+    log_dir = working_dir + "/logs"
+    Path(log_dir).mkdir(parents=True, exist_ok=True)
+    handlers = [log.StreamHandler(sys.stdout)]
+    if rank == 0:
+        handlers.append(log.FileHandler(log_dir + f"/{args.command}.main.log"))
+    log.basicConfig(level=log.DEBUG if args.verbose else log.INFO, handlers=handlers, force=True,
+                    format="%(asctime)s - %(levelname)s - %(message)s")
+    warnings.filterwarnings("ignore")
+    log.info(f"nanomotif (MI355X build) version: {__version__}")
+    if rank == 0:
+        with open(working_dir + f"/args.{args.command}.json", "w") as f:
+            json.dump(vars(args), f, indent=2)
+    set_seed(args.seed)
+
+
+def find_motifs_bin(args):
+    """main.py:46-104."""
+    import torch
+    import torch.distributed as dist
+    from .engine import ScanEngine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = args.device if args.device is not None else local_rank
+    if not torch.cuda.is_available():
+        raise RuntimeError("nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback")
+    torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+
+    log.info("Starting nanomotif motif finder")
+    bin_contig = fasta.generate_contig_bin(args)
+    if not bin_contig:
+        log.error("No bin contig mapping found")
+        return None
+    log.info("Loading assembly")
+    assembly = fasta.load_fasta(args.assembly)
+    log.info("Identifying motifs")
+    cfg = ProcessorConfig(assembly=assembly, pileup_path=args.pileup, bin_contig=bin_contig, threads=args.threads,
+                          search_frame_size=args.search_frame_size, methylation_threshold_low=args.methylation_threshold_low,
+                          methylation_threshold_high=args.methylation_threshold_high,
+                          minimum_kl_divergence=args.minimum_kl_divergence, score_threshold=args.min_motif_score,
+                          verbose=args.verbose, log_dir=args.out + "/logs", seed=args.seed, output_dir=args.out)
+    bgzip = cfg.pileup_path.endswith(".gz")
+    if bgzip and not os.path.exists(cfg.pileup_path + ".tbi"):
+        raise FileNotFoundError(f"Tabix index for {cfg.pileup_path} not found.")     # find_motifs_bin.py:383-384
+    t0 = time.perf_counter()
+    table = pileup_mod.load_pileup(cfg.pileup_path)
+    table = pileup_mod.prefilter(table)
+    if len(table) == 0:
+        log.info("No pileup data after filtering, skipping")
+        return None
+    # inner join with contig -> bin (find_motifs_bin.py:416)
+    in_bin = np.array([n in cfg.bin_contig for n in table.contig_names], dtype=bool)
+    table = table.take(in_bin[table.contig])
+    log.info(f"pileup: {len(table):,} rows after filters ({time.perf_counter() - t0:.1f}s)")
+
+    # engine: this rank's contigs (all contigs that belong to a bin), sharded by length over the ranks
+    names = [c for c in cfg.bin_contig if c in assembly]
+    parts = assign_contigs([len(assembly[c]) for c in names], world)
+    mine = [names[i] for i in parts[rank]]
+    eng = ScanEngine(device)
+    all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
+    eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+    local_id = {c: i for i, c in enumerate(mine)}
+    for mt_id, mt in enumerate(pileup_mod.MOD_TYPES):
+        sel = table.mod_type == mt_id
+        if not sel.any():
+            continue
+        sub = table.take(sel)
+        lid = np.array([local_id.get(n, -1) for n in sub.contig_names], dtype=np.int64)[sub.contig]
+        keep = lid >= 0
+        eng.upload_pileup(mt, lid[keep], sub.position[keep], sub.strand[keep], sub.fraction_mod[keep],
+                          low=cfg.methylation_threshold_low, high=cfg.methylation_threshold_high)
+    scorer = engine_scorer(eng, cfg.methylation_threshold_low, cfg.methylation_threshold_high, use_dist=world > 1)
+    rows, scorer = discover(cfg, table, scorer, rank=rank, bgzip_order=bgzip)
+    eng.close()
+    if not rows:
+        log.info("No motifs were identified")
+        return None
+    rows = [r for r in rows if r.n_mod + r.n_nomod >= args.min_motifs_bin]      # main.py:96
+    if not rows:
+        log.info("Motif frequency of all motifs too low")
+        return None
+    if rank == 0:
+        log.info("Writing motifs")
+        postprocess.write_motif_formatted(rows, args.out + "/bin-motifs.tsv")
+    log.info(f"Identified {len(rows)} motifs in {len({r.reference for r in rows})} bins")
+    return rows
+
+
+def check_installation():
+    """main.py:330-346 runs motif_discovery on the packaged geobacillus data; its pileup is not distributable, so
+    this build runs the same command on a small synthetic data set with the same planted motifs."""
+    import shutil
+    import subprocess
+    import tempfile
+    from . import synth
+    tmp = tempfile.mkdtemp(prefix="nanomotif_check_installation_")
+    mg = synth.make_metagenome(synth.SynthSpec(
+        n_contigs=2, total_bp=200_000, n_bins=1, mod_types=("a",), seed=43, min_contig_bp=80_000,
+        fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCAAAT", 4, "a"), ("GRNGAAGY", 5, "a"))))
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    out = tmp + "/out"
+    cmd = [sys.executable, "-m", "nanomotif_amd", "motif_discovery", "-t", "1", tmp + "/assembly.fasta", tmp + "/pileup.bed",
+           "-c", tmp + "/contig_bin.tsv", "--out", out]
+    rc = subprocess.run(cmd).returncode
+    if rc == 0 and os.path.exists(out + "/bin-motifs.tsv"):
+        print(open(out + "/bin-motifs.tsv").read())
+    shutil.rmtree(tmp, ignore_errors=True)
+    return rc
+
+
+def main(argv=None):
+    parser = create_parser()
+    args = parser.parse_args(argv)
+    if args.command == "motif_discovery":
+        rank = int(os.environ.get("RANK", "0"))
+        shared_setup(args, args.out, rank=rank)
+        result = find_motifs_bin(args)
+        if result is None and rank == 0:
+            with open(os.path.join(args.out, "bin-motifs.tsv"), "w") as f:     # main.py:317-321
+                f.write(HEADER)
+    elif args.command == "check_installation":
+        sys.exit(check_installation())
+    else:
+        parser.print_help()
+        sys.exit()
+
+
+if __name__ == "__main__":
+    main()

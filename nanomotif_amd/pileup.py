@@ -1,0 +1,103 @@
+"""Pileup ingestion and the three pre-filters, as struct-of-arrays numpy columns — the input contract of
+the hot path (reference: nanomotif/dataload.py:15-34, 72-100, 191-247; find_motifs_bin.py:399-418).
+
+A ``PileupTable`` holds one row per (contig, position, strand, mod type) with integer contig / mod-type ids so
+that rows can be handed to the HIP engine without touching Python objects per row."""
+from __future__ import annotations
+
+import gzip
+import io
+from dataclasses import dataclass
+
+import numpy as np
+from scipy.ndimage import maximum_filter1d
+
+MOD_TYPES = ["m", "a", "21839"]      # constants.py MOD_CODE_TO_PRETTY order = task order (find_motifs_bin.py:152-153)
+
+
+@dataclass
+class PileupTable:
+    contig_names: list          # id -> name
+    contig: np.ndarray          # int32 id into contig_names
+    position: np.ndarray        # int64
+    mod_type: np.ndarray        # int8 id into MOD_TYPES
+    strand: np.ndarray          # uint8 ASCII '+' / '-'
+    fraction_mod: np.ndarray    # float64 = column 11 / 100
+    nvalid_cov: np.ndarray      # int64
+
+    def __len__(self):
+        return len(self.position)
+
+    def take(self, sel):
+        return PileupTable(self.contig_names, self.contig[sel], self.position[sel], self.mod_type[sel],
+                           self.strand[sel], self.fraction_mod[sel], self.nvalid_cov[sel])
+
+
+def load_pileup(path: str) -> PileupTable:
+    """modkit bedMethyl, 18 tab-separated columns, no header; used: 1 contig, 2 start, 4 mod code, 6 strand,
+    10 Nvalid_cov, 11 percent modified; nulls 'NA' / 'null' (dataload.py:72-100).  ``.gz`` (bgzip is gzip) is
+    read whole — no tabix index needed."""
+    import pandas as pd
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as fh:
+        raw = fh.read()
+    if not raw.strip():
+        raise SystemExit("Pileup is empty after initial load")          # dataload.py:89-91 exits with status 1
+    df = pd.read_csv(io.BytesIO(raw), sep="\t", header=None, usecols=[0, 1, 3, 5, 9, 10],
+                     names=["contig", "position", "mod_type", "strand", "nvalid", "pct"],
+                     dtype={"contig": str, "mod_type": str, "strand": str}, na_values=["NA", "null"], keep_default_na=False)
+    names, contig_id = np.unique(df["contig"].to_numpy(dtype=object), return_inverse=True)
+    mt = df["mod_type"].to_numpy(dtype=object)
+    mod_id = np.full(len(df), -1, dtype=np.int8)
+    for k, code in enumerate(MOD_TYPES):
+        mod_id[mt == code] = k
+    strand = np.frombuffer("".join(df["strand"].tolist()).encode("ascii"), dtype=np.uint8).copy() if len(df) else np.zeros(0, np.uint8)
+    return PileupTable(list(names), contig_id.astype(np.int32), df["position"].to_numpy(dtype=np.int64), mod_id, strand,
+                       df["pct"].to_numpy(dtype=np.float64) / 100, df["nvalid"].to_numpy(dtype=np.int64))
+
+
+def filter_pileup(t: PileupTable, min_coverage: int = 5) -> PileupTable:
+    """dataload.py:191-200: strict Nvalid_cov > 5 (the CLI's --threshold_valid_coverage is parsed but never
+    forwarded by the reference, argparser.py:126-129 vs main.py:69-83 — same here)."""
+    return t.take(t.nvalid_cov > min_coverage)
+
+
+def filter_pileup_minimummod_frequency(t: PileupTable, methylation_threshold=0.7, min_mod_frequency=0.0001,
+                                       min_mods_pr_contig=50) -> PileupTable:
+    """dataload.py:202-226: keep (contig, mod_type) groups with #(frac > thr) / #rows > 1e-4 and #(frac > thr) > 50."""
+    if len(t) == 0:
+        return t
+    key = t.contig.astype(np.int64) * 8 + (t.mod_type.astype(np.int64) + 1)
+    n = np.bincount(key)
+    n_mod = np.bincount(key, weights=(t.fraction_mod > methylation_threshold)).astype(np.int64)
+    ok = np.zeros(len(n), dtype=bool)
+    nz = n > 0
+    ok[nz] = ((n_mod[nz] / n[nz]) > min_mod_frequency) & (n_mod[nz] > min_mods_pr_contig)
+    return t.take(ok[key])
+
+
+def filter_pileup_adjacency_filter(t: PileupTable, methylation_threshold=0.7, adjacency_distance=8) -> PileupTable:
+    """dataload.py:228-247: per (contig, strand) — mod types mixed — a row survives iff its fraction equals the
+    maximum over rows at positions p-d..p+d, or is below the threshold.  Evaluated as a dense sliding maximum
+    per contig and strand (exact: max of float64 values)."""
+    if len(t) == 0:
+        return t
+    keep = np.zeros(len(t), dtype=bool)
+    order = np.lexsort((t.position, t.strand, t.contig))
+    grp = t.contig[order].astype(np.int64) * 2 + (t.strand[order] == ord("-"))
+    bounds = np.flatnonzero(np.diff(grp)) + 1
+    for lo, hi in zip(np.concatenate([[0], bounds]), np.concatenate([bounds, [len(order)]])):
+        idx = order[lo:hi]
+        pos = t.position[idx]
+        frac = t.fraction_mod[idx]
+        p0 = int(pos[0])
+        dense = np.full(int(pos[-1]) - p0 + 1, -np.inf)
+        np.maximum.at(dense, pos - p0, frac)
+        wmax = maximum_filter1d(dense, size=2 * adjacency_distance + 1, mode="constant", cval=-np.inf)[pos - p0]
+        keep[idx] = (frac == wmax) | (frac < methylation_threshold)
+    return t.take(keep)
+
+
+def prefilter(t: PileupTable) -> PileupTable:
+    """The reference's order (find_motifs_bin.py:399-414)."""
+    return filter_pileup_adjacency_filter(filter_pileup_minimummod_frequency(filter_pileup(t)))

@@ -1,0 +1,417 @@
+"""Greedy candidate search — host side of the MI355X build.
+
+Mirrors the reference's search (nanomotif/find_motifs_bin.py:606-1182, 1382-1433; seq.py:170-225, 391-422,
+474-537; motif.py:577-607) decision for decision, but restructured for the GPU:
+
+* every search is a *coroutine*: wherever the reference calls ``motif_model_bin`` (one full CPU scan per
+  candidate) the coroutine ``yield``s the list of motifs it needs scored and is resumed with their models;
+* ``run_lockstep`` advances all (bin, mod type) searches together and turns the requests of one round into ONE
+  ``nm_score_batch`` launch, so a dependent step streams every bin once for all of its open candidates;
+* windows are bit-set codes (uint8, bit0 A, bit1 C, bit2 G, bit3 T, 15 = N) instead of ``int64[n, 41, 4]``
+  one-hot tensors; ``all(onehot <= motif_onehot)`` becomes ``(window & ~motif) == 0``.
+
+Visit order, heap ties, thresholds and RNG consumption are those of the reference, so results are identical.
+"""
+from __future__ import annotations
+
+import heapq
+import math
+import random
+
+import numpy as np
+from scipy.stats import entropy
+
+from .model import BetaBernoulliModel, predictive_evaluation_score
+from .motif import BASES, MOD_TYPE_TO_CANONICAL, Motif
+
+A, C, G, T = 1, 2, 4, 8
+ROW_BITS = (A, T, G, C)                    # PSSM / one-hot row order A, T, G, C (constants.py:1)
+_SET_OF_ASCII = np.full(256, 255, dtype=np.uint8)
+for _ch, _m in (("A", A), ("C", C), ("G", G), ("T", T), ("N", 15), (".", 15)):
+    _SET_OF_ASCII[ord(_ch)] = _m
+_COMP_SET = np.array([((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3) for m in range(16)], dtype=np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# windows and PSSMs
+# ------------------------------------------------------------------------------------------------
+def windows_at(seq: np.ndarray, indices: np.ndarray, padding: int) -> np.ndarray:
+    """ASCII windows seq[i-pad : i+pad+1] for the indices with pad < i < len - pad (seq.py:170-189)."""
+    idx = indices[(indices > padding) & (indices < len(seq) - padding)]
+    if len(idx) == 0:
+        return np.zeros((0, 2 * padding + 1), dtype=np.uint8)
+    return seq[idx[:, None] + np.arange(-padding, padding + 1)[None, :]]
+
+
+def to_sets(windows_ascii: np.ndarray) -> np.ndarray:
+    """seq.py:474-478 — only A, C, G, T, N are convertible; anything else is the reference's KeyError."""
+    sets = _SET_OF_ASCII[windows_ascii]
+    if sets.size and sets.max() == 255:
+        bad = chr(int(windows_ascii[sets == 255][0]))
+        raise KeyError(bad)
+    return sets
+
+
+def revcomp_sets(sets: np.ndarray) -> np.ndarray:
+    return _COMP_SET[sets[:, ::-1]]
+
+
+def sample_background(seq: np.ndarray, length: int, n: int, base: str) -> np.ndarray:
+    """seq.py:202-225 — ``random.sample`` over the starts whose middle base is ``base``; same RNG consumption
+    as sampling from the reference's list of valid starts (sample() only looks at len() and indexes)."""
+    max_start = len(seq) - length + 1
+    if n > max_start:
+        raise ValueError("Too many samples requested for unique subsequences")
+    mid = length // 2
+    valid = np.flatnonzero(seq[mid:mid + max_start] == ord(base))
+    if len(valid) < n:
+        raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {len(valid)}, need {n})")
+    starts = valid[np.array(random.sample(range(len(valid)), n), dtype=np.int64)]
+    return seq[starts[:, None] + np.arange(length)[None, :]]
+
+
+def letter_pssm(windows_ascii: np.ndarray) -> np.ndarray:
+    """seq.py:391-422 — exact-letter frequency per column, rows A, T, G, C."""
+    n = windows_ascii.shape[0]
+    return np.array([(windows_ascii == ord(b)).sum(axis=0) / n for b in BASES])
+
+
+def sets_pssm(sets: np.ndarray) -> np.ndarray:
+    """seq.py:526-537 on bit sets: N windows count for all four rows."""
+    n = sets.shape[0]
+    return np.array([((sets & b) != 0).sum(axis=0) / n for b in ROW_BITS])
+
+
+def motif_sets(motif: Motif) -> np.ndarray:
+    return np.array(motif.sets, dtype=np.uint8)
+
+
+def filter_matches(sets: np.ndarray, motif: Motif, keep_matches=True):
+    """seq.py:499-524 — None when nothing is left."""
+    bad = (sets & ~motif_sets(motif)[None, :]) != 0
+    res = sets[~bad.any(axis=1)] if keep_matches else sets[bad.any(axis=1)]
+    return None if res.shape[0] == 0 else res
+
+
+# ------------------------------------------------------------------------------------------------
+# graph of explored motifs (stands in for MotifTree(nx.DiGraph), motif.py:577-607)
+# ------------------------------------------------------------------------------------------------
+class MotifTree:
+    def __init__(self):
+        self.nodes = {}
+        self._succ = {}
+        self._pred = {}
+
+    def has_node(self, m):
+        return m in self.nodes
+
+    def add_node(self, m, **attrs):
+        if m in self.nodes:
+            self.nodes[m].update(attrs)
+        else:
+            self.nodes[m] = dict(attrs)
+            self._succ[m] = {}
+            self._pred[m] = {}
+
+    def has_edge(self, u, v):
+        return u in self._succ and v in self._succ[u]
+
+    def add_edge(self, u, v):
+        for n in (u, v):
+            if n not in self.nodes:
+                self.add_node(n)
+        self._succ[u][v] = True
+        self._pred[v][u] = True
+
+    def edges(self):
+        return [(u, v) for u in self._succ for v in self._succ[u]]
+
+    def predecessors(self, n):
+        return list(self._pred[n])
+
+    def _reach(self, start, table):
+        seen, stack = set(), list(table[start])
+        while stack:
+            n = stack.pop()
+            if n not in seen:
+                seen.add(n)
+                stack.extend(table[n])
+        seen.discard(start)
+        return seen
+
+    def ancestors(self, n):
+        return self._reach(n, self._pred)
+
+    def descendants(self, n):
+        return self._reach(n, self._succ)
+
+    def get_missed_candidates(self, best_candidates, threshold=3):
+        high = {n for n, d in self.nodes.items() if d["score"] > threshold}
+        out = set()
+        for n in high:
+            if (not any(a in high for a in self.ancestors(n))
+                    and not any(d in best_candidates for d in self.descendants(n)) and n not in best_candidates):
+                out.add(n)
+        return out
+
+    def export_graph_gml(self, path):
+        """Minimal GML writer (find_motifs_bin.py:836-837 / motif.py:630-652): counts, score, priority, depth."""
+        ids = {n: i for i, n in enumerate(self.nodes)}
+        with open(path, "w") as f:
+            f.write("graph [\n  directed 1\n")
+            for n, d in self.nodes.items():
+                f.write(f'  node [\n    id {ids[n]}\n    label "{n.string.strip(".")}"\n    score {float(d.get("score", 0.0))}\n'
+                        f'    priority {float(d.get("priority", 0))}\n    depth {int(d.get("depth", 0))}\n'
+                        f'    visited {int(bool(d.get("visited", False)))}\n  ]\n')
+            for u, v in self.edges():
+                f.write(f"  edge [\n    source {ids[u]}\n    target {ids[v]}\n  ]\n")
+            f.write("]\n")
+
+
+# ------------------------------------------------------------------------------------------------
+# coroutines: ``models = yield [motifs]``
+# ------------------------------------------------------------------------------------------------
+def get_parent_scores_co(motif: Motif):
+    """find_motifs_bin.py:1382-1433 as a coroutine: ONE request holds the motif and all its parents."""
+    sp = motif.split()
+    parents, positions = [], []
+    for i, tok in enumerate(sp):
+        if i == motif.mod_position or tok in (".", "N"):
+            continue
+        q = list(sp)
+        q[i] = "."
+        parents.append(Motif("".join(q), motif.mod_position))
+        positions.append(i)
+    models = yield [motif] + parents
+    child_model = models[0]
+    out = {}
+    for parent, i, pm in zip(parents, positions, models[1:]):
+        out[parent] = dict(motif_position=i, parent_model=pm, child_model=child_model,
+                           score=predictive_evaluation_score(child_model, pm))
+    return out
+
+
+class MotifSearcher:
+    """find_motifs_bin.py:843-1182.  ``run`` is a coroutine (see module docstring)."""
+
+    def __init__(self, root_motif, bin_pssm, methylation_sets, padding, motif_graph=None, min_kl=0.1,
+                 freq_threshold=0.15, max_rounds_since_new_best=30, max_motif_length=25):
+        if padding < 0:
+            raise ValueError("padding must be non-negative.")
+        self.root_motif = root_motif
+        self.bin_pssm = bin_pssm
+        self.methylation_sets = methylation_sets
+        self.padding = padding
+        self.motif_graph = motif_graph or MotifTree()
+        self.min_kl = min_kl
+        self.freq_threshold = freq_threshold
+        self.max_rounds_since_new_best = max_rounds_since_new_best
+        self.max_motif_length = max_motif_length
+
+    @staticmethod
+    def _priority_function(next_model, root_model) -> float:
+        try:
+            d_alpha = 1 - (next_model._alpha / root_model._alpha)
+        except ZeroDivisionError:
+            d_alpha = 1
+        try:
+            d_beta = next_model._beta / root_model._beta
+        except ZeroDivisionError:
+            d_beta = 1
+        return d_alpha * d_beta
+
+    def _motif_child_nodes_kl_dist_max(self, motif, meth_pssm):
+        """find_motifs_bin.py:957-1023: the single '.' column of maximal KL(meth || background), one child per
+        base passing freq > 0.15 and freq > 0.5 * background, in A, T, G, C order."""
+        kl = entropy(meth_pssm, self.bin_pssm)
+        toks = motif.tokens
+        masked = np.where(np.array([t == "." for t in toks]), kl, 0.0)
+        if not any(t == "." for t in toks):
+            return []
+        if np.max(masked) < self.min_kl:
+            return []
+        pos = int(np.argmax(masked))
+        keep = np.logical_and(meth_pssm[:, pos] > self.bin_pssm[:, pos] * 0.5, meth_pssm[:, pos] > self.freq_threshold)
+        out = []
+        for bi in np.flatnonzero(keep):
+            q = list(toks)
+            q[pos] = BASES[int(bi)]
+            out.append(Motif("".join(q), motif.mod_position))
+        return out
+
+    def run(self):
+        g = self.motif_graph
+        best_guess = self.root_motif
+        root_model = (yield [self.root_motif])[0]
+        best_score = predictive_evaluation_score(root_model, root_model)
+        rounds = 0
+        visited = set()
+        if not g.has_node(self.root_motif):
+            g.add_node(self.root_motif, model=root_model, motif=self.root_motif, visited=False, score=best_score,
+                       priority=0, depth=0)
+        pq = [(0, 0, self.root_motif)]
+        while pq:
+            _, _, cur = heapq.heappop(pq)
+            if cur in visited:
+                continue
+            attrs = g.nodes[cur]
+            cur_model = attrs["model"]
+            cur_depth = attrs.get("depth", 0)
+            n_mod, n_nomod = cur_model.get_raw_counts()
+            if n_mod + n_nomod < 10:
+                continue
+            if len(cur.strip()) > self.max_motif_length:
+                continue
+            visited.add(cur)
+            g.nodes[cur]["visited"] = True
+            rounds += 1
+            active = filter_matches(self.methylation_sets, cur, keep_matches=True)
+            if active is None:
+                continue
+            neighbors = self._motif_child_nodes_kl_dist_max(cur, sets_pssm(active))
+            fresh = [m for m in neighbors if m not in g.nodes]
+            fresh_models = dict(zip(fresh, (yield fresh))) if fresh else {}     # one batch for all new children
+            for nxt in neighbors:
+                nxt_model = g.nodes[nxt]["model"] if nxt in g.nodes else fresh_models[nxt]
+                score = predictive_evaluation_score(nxt_model, cur_model)
+                n_iso = nxt.count_isolated_bases(isolation_size=1)
+                priority = self._priority_function(nxt_model, root_model)
+                if n_iso > 0:
+                    priority *= pow(10, n_iso)
+                if nxt in g.nodes:
+                    if g.nodes[nxt]["score"] < score:
+                        g.nodes[nxt]["score"] = score
+                else:
+                    g.add_node(nxt, model=nxt_model, motif=nxt, visited=False, score=score, priority=priority,
+                               depth=cur_depth + 1)
+                if not g.has_edge(cur, nxt):
+                    g.add_edge(cur, nxt)
+                if nxt not in visited:
+                    a = g.nodes[nxt]
+                    heapq.heappush(pq, (a["priority"], a["depth"], nxt))
+                if score > best_score:
+                    best_score, best_guess, rounds = score, nxt, 0
+            if rounds >= self.max_rounds_since_new_best:
+                break
+        return g, best_guess
+
+
+def extract_windows(contigs: dict, plus_pos: dict, minus_pos: dict, mod_type: str, padding: int,
+                    background_sampling_frequency=0.01):
+    """find_motifs_bin.py:625-686.  contigs: name -> uint8 upper-case ASCII; plus_pos / minus_pos: name -> int64
+    positions of the confidently methylated rows (fraction_mod >= high).  Contigs are visited in sorted-name order
+    (the reference's polars ``unique()`` order is unspecified).  Returns (methylation sets, background ASCII)
+    or None."""
+    canonical = MOD_TYPE_TO_CANONICAL[mod_type]
+    W = 2 * padding + 1
+    meth, bg = [], []
+    for name in sorted(plus_pos.keys() | minus_pos.keys()):
+        seq = contigs[name]
+        n_samples = int(max(math.ceil(len(seq) * background_sampling_frequency), 50))
+        bg.append(sample_background(seq, W, n_samples, canonical))
+        p, m = plus_pos.get(name, np.zeros(0, np.int64)), minus_pos.get(name, np.zeros(0, np.int64))
+        here = []
+        if len(p) >= 1:
+            here.append(to_sets(windows_at(seq, p, padding)))
+        if len(m) >= 1:
+            here.append(revcomp_sets(to_sets(windows_at(seq, m, padding))))
+        here = [h for h in here if h.shape[0]]
+        if not here:
+            return None                          # find_motifs_bin.py:662-664
+        meth += here
+    if not meth or not bg:
+        return None
+    return np.concatenate(meth), np.concatenate(bg)
+
+
+def find_best_candidates_co(windows, mod_type: str, padding: int, min_kl=0.2, max_dead_ends=25,
+                            max_rounds_since_new_best=30, score_threshold=0.2, remaining_sequences_threshold=0.001,
+                            log=None):
+    """find_motifs_bin.py:688-839 as a coroutine.  ``windows`` = (methylation sets, background ASCII).
+    Returns (graph, best_candidates, bin_pssm) or None."""
+    meth_sets, bg_ascii = windows
+    total = meth_sets.shape[0]
+    bin_pssm = letter_pssm(bg_ascii)
+    root = Motif("." * padding + MOD_TYPE_TO_CANONICAL[mod_type] + "." * padding, padding)
+    remaining = meth_sets
+    best, dead_ends, graph = [], 0, None
+    while True:
+        if dead_ends >= max_dead_ends:
+            break
+        searcher = MotifSearcher(root, bin_pssm, remaining, padding, motif_graph=graph, min_kl=min_kl,
+                                 max_rounds_since_new_best=max_rounds_since_new_best)
+        graph, guess = yield from searcher.run()
+        if guess == root:
+            break
+        temp, to_prune, single = guess, set(), False
+        while True:
+            parents = yield from get_parent_scores_co(temp)
+            for d in parents.values():
+                if d["score"] < 0.4:
+                    to_prune.add(d["motif_position"])
+            if not to_prune:
+                break
+            sp = temp.split()
+            for i in to_prune:
+                sp[i] = "."
+            pruned = Motif("".join(sp), temp.mod_position)
+            if len(pruned.string.replace(".", "")) == 1:
+                single = True
+                break
+            if pruned == temp:
+                break
+            temp = pruned
+        mean_parent = np.mean([d["score"] for d in parents.values()])
+        if single or mean_parent < score_threshold or temp == guess:
+            graph.nodes[guess]["score"] = mean_parent
+        else:
+            child_model = next(iter(parents.values()))["child_model"]
+            graph.add_node(temp, model=child_model, motif=temp, visited=True, score=mean_parent, priority=0, depth=0)
+            guess = temp
+        before = remaining.shape[0]
+        remaining = filter_matches(remaining, guess, keep_matches=False)
+        if remaining is None:
+            break
+        if graph.nodes[guess]["score"] < score_threshold:
+            dead_ends += 1
+            continue
+        if log:
+            log(f"Keeping {guess}, represented in {before - remaining.shape[0]} seqs. model: {graph.nodes[guess]['model']}. "
+                f"({100 * remaining.shape[0] / total:.1f} % of sequences remaining)")
+        best.append(guess)
+        if remaining.shape[0] / total < remaining_sequences_threshold:
+            break
+    if graph is None or len(graph.nodes) == 0:
+        return None
+    missed = graph.get_missed_candidates(best, score_threshold)
+    missed = [c for c in missed if not c.sub_motif_of_any(best) or not any(b.sub_motif_of(c) for b in best)]
+    best.extend(sorted(missed, key=lambda m: (m.string, m.mod_position)))
+    return graph, best, bin_pssm
+
+
+# ------------------------------------------------------------------------------------------------
+# lock-step scheduler
+# ------------------------------------------------------------------------------------------------
+def run_lockstep(coroutines: dict, score_fn):
+    """Advance all coroutines together.  ``coroutines``: key -> generator yielding lists of Motif;
+    ``score_fn(list of (key, Motif)) -> int64[n, 2]`` scores one round's requests in one batch.
+    Returns key -> the coroutine's return value."""
+    results, waiting = {}, {}
+    for key, co in coroutines.items():
+        try:
+            waiting[key] = next(co)
+        except StopIteration as e:
+            results[key] = e.value
+    while waiting:
+        flat = [(key, m) for key, req in waiting.items() for m in req]
+        counts = score_fn(flat)
+        nxt, at = {}, 0
+        for key, req in waiting.items():
+            models = [BetaBernoulliModel.from_counts(*counts[at + j]) for j in range(len(req))]
+            at += len(req)
+            try:
+                nxt[key] = coroutines[key].send(models)
+            except StopIteration as e:
+                results[key] = e.value
+        waiting = nxt
+    return results

@@ -1,0 +1,67 @@
+"""End to end on the GPU: `nanomotif motif_discovery` (text pileup, FASTA, contig-bin TSV in; bin-motifs.tsv out)
+against the CPU oracle's full pipeline on the same data — cfg 1 of BASELINE.json (CLI plumbing) with the packaged
+geobacillus motifs planted in synthetic contigs (the reference's own pileup blob is not distributable)."""
+import gzip
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import oracle_pipeline
+from nanomotif_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_cli(tmp, args, nproc=1):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "nanomotif_amd", "motif_discovery"] + args
+    r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+def test_motif_discovery_cli_matches_oracle(tmp_path):
+    spec = synth.SynthSpec(n_contigs=4, total_bp=500_000, n_bins=2, mod_types=("a", "m"), seed=61, min_contig_bp=60_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a"), ("GRNGAAGY", 5, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out", "-t", "1"])
+    got = open(tmp + "/out/bin-motifs.tsv").read()
+    expect = oracle_pipeline(mg)
+    assert got == expect, f"\n--- gpu ---\n{got}\n--- oracle ---\n{expect}"
+    motifs = {l.split("\t")[1] for l in got.strip().split("\n")[1:]}
+    assert {"GATC", "ACCCA", "CCWGG"} <= motifs
+    assert os.path.exists(tmp + "/out/args.motif_discovery.json") and os.path.exists(tmp + "/out/logs/motif_discovery.main.log")
+    assert os.path.isdir(tmp + "/out/precleanup-motifs")
+
+    # bgzip'd pileup (needs its .tbi to be present like the reference) and -f bin FASTA files
+    with open(tmp + "/pileup.bed", "rb") as f, gzip.open(tmp + "/pileup.bed.gz", "wb") as g:
+        g.write(f.read())
+    open(tmp + "/pileup.bed.gz.tbi", "wb").close()
+    os.makedirs(tmp + "/bins")
+    for b in sorted(set(mg.bin_names)):
+        with open(f"{tmp}/bins/{b}.fasta", "w") as f:
+            for i, name in enumerate(mg.names):
+                if mg.bin_names[i] == b:
+                    f.write(f">{name} some description\n{mg.contig_str(i)}\n")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed.gz", "-d", "bins", "--out", "out_gz"])
+    got_gz = open(tmp + "/out_gz/bin-motifs.tsv").read()
+    assert got_gz == oracle_pipeline(mg, bgzip_order=True)
+    assert os.path.exists(tmp + "/out_gz/temp/contig_bin.tsv")
+
+
+def test_empty_result_writes_header_only(tmp_path):
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=1, total_bp=60_000, n_bins=1, mod_types=("a",), seed=62, fixed_motifs=()))
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    mg.write_contig_bin(tmp + "/cb.tsv")
+    _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o"])
+    lines = open(tmp + "/o/bin-motifs.tsv").read().strip().split("\n")
+    assert len(lines) == 1 and lines[0].split("\t")[:4] == ["reference", "motif", "mod_position", "mod_type"]

@@ -1,0 +1,111 @@
+"""Host-side search / post-processing of the product package, driven on CPU by the oracle's scan as the scoring
+backend: must reproduce the reference-recorded search traces (tests/golden/g4_search.json) node for node."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, oracle_bin_inputs, spec_from_json
+from nanomotif_amd import postprocess as ppp
+from nanomotif_amd import search as ps
+from nanomotif_amd import synth
+from nanomotif_amd.find_motifs_bin import LockstepScorer
+from nanomotif_amd.motif import Motif
+
+
+def oracle_backend(piles, seqs):
+    """local_counts(flat) -> int64[n,2] computed by the CPU oracle; piles: {(bin, mt): pileup dict}."""
+    from oracle.scan import score_candidates
+
+    def local(flat):
+        out = np.zeros((len(flat), 2), dtype=np.int64)
+        for i, (key, m) in enumerate(flat):
+            out[i] = score_candidates(piles[key], seqs[key[0]], [(m.string, m.mod_position)])[0]
+        return out
+    return local
+
+
+def windows_for(mg, mod_type, pile, high=0.7, pad=20):
+    contigs = {mg.names[i]: mg.contig_ascii(i) for i in range(len(mg.names))}
+    plus = {n: p.position[(p.fraction_mod >= high) & (p.strand == ord("+"))] for n, p in pile.items() if len(p)}
+    minus = {n: p.position[(p.fraction_mod >= high) & (p.strand == ord("-"))] for n, p in pile.items() if len(p)}
+    return ps.extract_windows(contigs, plus, minus, mod_type, pad)
+
+
+@pytest.mark.parametrize("name", ["gatc_single", "ecoli_like_m", "geobacillus_like", "no_motif"])
+def test_product_search_reproduces_reference_trace(name):
+    g = load_golden("g4_search.json")[name]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    mt = g["mod_type"]
+    pile, seqs = oracle_bin_inputs(mg, mt)
+    P = g["params"]
+    random.seed(P["seed"])
+    windows = windows_for(mg, mt, pile, P["high"], P["padding"])
+    key = ("bin0", mt)
+    scorer = LockstepScorer(oracle_backend({key: pile}, {"bin0": seqs}))
+    co = ps.find_best_candidates_co(windows, mt, P["padding"], min_kl=P["min_kl"], max_dead_ends=25,
+                                    max_rounds_since_new_best=30, score_threshold=P["score_threshold"])
+    graph, best, bin_pssm = ps.run_lockstep({key: co}, scorer)[key]
+    assert np.allclose(bin_pssm, np.array(g["bin_pssm_4dp"]), atol=5.1e-5, rtol=0)
+    assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
+    for (n, d), r in zip(graph.nodes.items(), g["nodes"]):
+        assert list(d["model"].get_raw_counts()) == r["counts"]
+        assert d["score"] == pytest.approx(r["score"], abs=1e-9, rel=1e-9)
+        assert d["priority"] == pytest.approx(r["priority"], abs=1e-12, rel=1e-12)
+        assert d["depth"] == r["depth"] and d["visited"] == r["visited"]
+    assert sorted((u.string, v.string) for u, v in graph.edges()) == sorted(map(tuple, g["edges"]))
+    assert sorted((m.string, m.mod_position) for m in best) == sorted(map(tuple, g["best"]))
+    # far fewer launches than candidates: children and pruning parents are batched per round
+    assert scorer.rounds < scorer.candidates or scorer.candidates <= 1
+
+
+def test_lockstep_equals_sequential_and_matches_oracle_chain():
+    """Two bins advanced together give what each gives alone; the post-processing chain agrees with the oracle's."""
+    from oracle import postprocess as opp
+    from oracle import search as ose
+    g4 = load_golden("g4_search.json")
+    tasks, piles, seqs_by_bin, expect = {}, {}, {}, {}
+    for bin_name, gname in (("binA", "geobacillus_like"), ("binB", "ecoli_like_m")):
+        g = g4[gname]
+        mg = synth.make_metagenome(spec_from_json(g["spec"]))
+        mt = g["mod_type"]
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        key = (bin_name, mt)
+        piles[key], seqs_by_bin[bin_name] = pile, seqs
+        random.seed(1)
+        windows = windows_for(mg, mt, pile)
+
+        def chain(bin_name=bin_name, mt=mt, windows=windows):
+            graph, best, _ = yield from ps.find_best_candidates_co(windows, mt, 20, min_kl=0.05, score_threshold=1.5)
+            rows = yield from ppp.postprocess_co(graph, best, bin_name, mt, 20)
+            return rows
+        tasks[key] = chain()
+        random.seed(1)
+        og, ob, _ = ose.find_best_candidates(pile, seqs, mt, 0.3, 0.7, 20, min_kl=0.05, score_threshold=1.5)
+        expect[key] = opp.format_bin_motifs(opp.process_bin(pile, seqs, bin_name, mt, og, ob, 20))
+    scorer = LockstepScorer(oracle_backend(piles, seqs_by_bin))
+    res = ps.run_lockstep(tasks, scorer)
+    for key in tasks:
+        rows = [r for r in res[key] if r.n_mod + r.n_nomod >= 50]
+        assert ppp.format_bin_motifs(rows) == expect[key]
+    assert "GATC" in expect[("binA", "a")] and "CCWGG" in expect[("binB", "m")]
+
+
+def test_postprocess_kats():
+    from nanomotif_amd.model import BetaBernoulliModel
+    mk = lambda motifs, pos, mod="m": [ppp.MotifRow("ref1", m, mod, p, BetaBernoulliModel(), 1.0) for m, p in zip(motifs, pos)]
+    r = ppp.join_motif_complements(mk(["AAGGTT", "AACCTT"], [0, 0]))          # tests/test_postprocess.py:17-36
+    assert [x.motif for x in r] == ["AAGGTT"] and [x.complement.motif for x in r] == ["AACCTT"]
+    r = ppp.join_motif_complements(mk(["GCGC", "GCGC"], [1, 3]))
+    assert len(r) == 4
+    motifs = ["AATT", "GATC", "CCA......TGCC", "CAGACG..G", "GGCA......TGG", "GGGAGC", "TTAA", "CTCGAG", "GCAGATG"]
+    r = ppp.join_motif_complements(mk(motifs, [1, 1, 2, 3, 3, 3, 3, 4, 4], "a"))  # tests/test_postprocess.py:95-146
+    assert [x.motif for x in r] == ["AATT", "GATC", "CAGACG..G", "GGCA......TGG", "GGGAGC", "TTAA", "CTCGAG", "GCAGATG"]
+    assert [x.complement.motif if x.complement else None for x in r] == \
+        ["AATT", "GATC", None, "CCA......TGCC", None, "TTAA", "CTCGAG", None]
+    assert len(ppp.remove_noisy_motifs(mk(["AAGGTT", "AACCTT", "GATCC"], [0, 0, 0]))) == 3
+    m = [Motif("ACGT", 0), Motif("ACG", 0), Motif("CGT", 1), Motif("ACGTG", 0), Motif("TGCA", 1)]
+    assert set(ppp.get_motif_parental_relationship(m)) == {(m[1], m[0]), (m[1], m[3]), (m[2], m[0]), (m[2], m[3]), (m[0], m[3])}
+    text = ppp.format_bin_motifs(mk(["GATC"], [1], "a"))
+    assert text.split("\n")[0].split("\t") == ppp.HEADER and text.split("\n")[1].split("\t")[:7] == \
+        ["ref1", "GATC", "1", "a", "0", "0", "palindrome"]
