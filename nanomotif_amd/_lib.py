@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnmscan.so")
+LIB_PATH = os.environ.get("NM_LIB", os.path.join(_HERE, "libnmscan.so"))   # NM_LIB: A/B kernel experiments
 
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",

@@ -38,8 +38,9 @@ constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wa
 constexpr int GAP_BP = 64;                              // invalid positions guaranteed after every contig
 constexpr int SEG_CHUNKS = 16;                          // chunks per workgroup segment (128 Kbp)
 constexpr int BMAX = 32;                                // candidates per LDS accumulation pass
-constexpr int PROG_DW = 72;                             // dwords per candidate program
-constexpr int PROG_META = 64;                           // meta dwords start
+constexpr int PROG_DW = 64;                             // host-side program: [strand 2][word-group 4][plane 8]
+// device-side programs are packed to the word-groups the launched kernel variant reads:
+// narrow (offsets in [-32, 31]) = groups 1..2 -> 32 dwords (128 B), wide = all four -> 64 dwords
 
 thread_local std::string g_err;
 
@@ -79,10 +80,11 @@ struct ScoreArgs {
     uint32_t n_segments;
     uint32_t n_bins;
     const uint2 *cand_range;    // [active_slot_index][bin] -> {begin, count} into programs
-    const uint32_t *programs;   // [n_cand][PROG_DW], sorted by (slot, bin)
+    const uint32_t *programs;   // [n_prog][2 * (GN + GP) * 8], sorted by (slot, bin)
     const uint32_t *orig_index; // [n_cand] sorted -> caller order
     unsigned long long *out;    // [n_cand][2]
     uint32_t active_slot[NM_MAX_MOD_SLOTS];
+    uint32_t slot_is_c[NM_MAX_MOD_SLOTS];   // canonical base of the slot is C (else A)
 };
 
 // Pack: one workgroup per chunk, 64 positions per wave per step, wave ballot builds the plane words.
@@ -224,16 +226,16 @@ struct StrandMasks {
     uint32_t m[N];
     __device__ __forceinline__ void load(cu32p prog_strand) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) m[i] = prog_strand[(2 - GN) * 8 + i];
+        for (int i = 0; i < N; ++i) m[i] = prog_strand[i];
     }
 };
 
-// acc[t] &= plane p at offset d (d = 32 g + r) for every constraint bit of one strand's program.
+// acc[t] &= plane p at offset d (d = 32 g + r) for every constraint bit of one strand's program.  The caller
+// initialises acc (all ones, or the plane of the modified base: that constraint sits at offset 0 and needs no
+// alignbit).  Two constraints of the same (word-group, plane) class are folded into one 3-input AND (v_bitop3).
 template <int GN, int GP>
 __device__ __forceinline__ void eval_strand(const StrandMasks<GN, GP> &sm, const Tile<GN, GP> &tile,
                                             uint32_t (&acc)[T_WORDS]) {
-#pragma unroll
-    for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
 #pragma unroll
     for (int g = 0; g < GN + GP; ++g) {            // g = gi - (2 - GN): word pair (t + g, t + g + 1)
 #pragma unroll
@@ -242,16 +244,21 @@ __device__ __forceinline__ void eval_strand(const StrandMasks<GN, GP> &sm, const
             while (m) {
                 const uint32_t r = __builtin_ctz(m);
                 m &= m - 1;
+                if (false) {
+                } else {
 #pragma unroll
-                for (int t = 0; t < T_WORDS; ++t) acc[t] &= alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
+                    for (int t = 0; t < T_WORDS; ++t) acc[t] &= alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
+                }
             }
         }
     }
 }
 
-template <int GN, int GP, bool COMPACT>
-__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
-    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
+// CAN: canonical base of the mod-type slot, 0 = A (reverse strand sites sit on T), 1 = C (reverse on G).
+template <int GN, int GP, bool COMPACT, int CAN>
+__device__ __forceinline__ void score_body(const ScoreArgs &a, uint32_t *lds_acc) {
+    constexpr int PF = CAN == 0 ? 0 : 1;   // plane of the canonical base: A or C
+    constexpr int PR = CAN == 0 ? 3 : 2;   // plane of its complement:     T or G
     // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
     // of segments so candidate programs and counters of one bin stay in one L2.
     const uint32_t nb = gridDim.x;
@@ -297,11 +304,18 @@ __global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(Score
                 s3[0] = d4.x; s3[1] = d4.y; s3[2] = d4.z; s3[3] = d4.w;
             }
             for (uint32_t k = 0; k < nbatch; ++k) {
-                cu32p prog = (cu32p)(a.programs + (size_t)(range.x + pass0 + k) * PROG_DW);
+                cu32p prog = (cu32p)(a.programs + (size_t)(range.x + pass0 + k) * (2 * StrandMasks<GN, GP>::N));
                 StrandMasks<GN, GP> mf, mr;
                 mf.load(prog);
-                mr.load(prog + 32);
+                mr.load(prog + StrandMasks<GN, GP>::N);
                 uint32_t accf[T_WORDS], accr[T_WORDS];
+#pragma unroll
+                for (int t = 0; t < T_WORDS; ++t) {
+                    // compact batches: every candidate has the canonical literal at its modified position, the host
+                    // leaves that constraint out of the program and it becomes the accumulator's initial value
+                    accf[t] = COMPACT ? tile.w[PF][t + GN] : 0xFFFFFFFFu;
+                    accr[t] = COMPACT ? tile.w[PR][t + GN] : 0xFFFFFFFFu;
+                }
                 eval_strand<GN, GP>(mf, tile, accf);
                 eval_strand<GN, GP>(mr, tile, accr);
                 uint32_t n_mod = 0, n_non = 0;
@@ -338,6 +352,59 @@ __global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(Score
     }
 }
 
+template <int GN, int GP, bool COMPACT>
+__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
+    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
+    if (COMPACT && a.slot_is_c[a.active_slot[blockIdx.y]]) score_body<GN, GP, COMPACT, 1>(a, lds_acc);
+    else score_body<GN, GP, COMPACT, 0>(a, lds_acc);
+}
+
+// One candidate record as the host stages it (sorted by mod-type slot, then bin).
+struct CandRec {
+    uint32_t mask_off;   // into the staged mask bytes
+    uint32_t orig;       // caller's index of this candidate
+    uint8_t len, modpos, slot, pad;
+};
+
+// Compile the staged candidates into constraint programs ON THE DEVICE: one thread per candidate.  A literal is one
+// constraint on an is-X plane, a 3-set one on a valid-not-X plane, a 2-set two of those; the reverse strand takes
+// the complemented set at the negated offset (motif.py:260-266).  Program layout: [strand][word-group][plane] with
+// the word-groups the launched variant reads (narrow: groups 1..2, wide: 0..3); bit r of a word = offset 32 g + r.
+// fold_modpos: the modified position's own constraint is left out (compact batches start the accumulator from the
+// canonical plane instead).
+__global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
+                               uint32_t *__restrict__ programs, int wide, int fold_modpos) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_prog) return;
+    const int groups = wide ? 4 : 2, g0 = wide ? 0 : 1;
+    const int pdw = 2 * groups * 8;
+    uint32_t *prog = programs + (size_t)k * pdw;
+    for (int i = 0; i < pdw; ++i) prog[i] = 0;
+    const CandRec c = rec[k];
+    const uint8_t *m = masks + c.mask_off;
+    for (int j = 0; j < c.len; ++j) {
+        const uint32_t set_f = m[j] & 15u;
+        if (set_f == 15u || (fold_modpos && j == c.modpos)) continue;
+        for (int strand = 0; strand < 2; ++strand) {
+            const int d = strand == 0 ? j - (int)c.modpos : (int)c.modpos - j;
+            const uint32_t set = strand == 0 ? set_f
+                                             : (((set_f & 1) << 3) | ((set_f & 2) << 1) | ((set_f & 4) >> 1) | ((set_f & 8) >> 3));
+            const int g = (d >> 5) + 2 - g0;
+            const uint32_t bit = 1u << ((uint32_t)d & 31u);
+            uint32_t *row = prog + (strand * groups + g) * 8;
+            if (__popc(set) == 1) {
+                row[__ffs(set) - 1] |= bit;
+            } else {
+                uint32_t missing = (~set) & 15u;
+                while (missing) {
+                    row[4 + __ffs(missing) - 1] |= bit;
+                    missing &= missing - 1;
+                }
+            }
+        }
+    }
+}
+
 // Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
 template <int GN, int GP>
 __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, uint32_t chunk0, uint32_t n_chunks,
@@ -350,8 +417,10 @@ __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, u
     Tile<GN, GP> tile;
     tile.load(seq, chunk, lane);
     uint32_t acc[T_WORDS];
+#pragma unroll
+    for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
     StrandMasks<GN, GP> sm;
-    sm.load((cu32p)(prog + (which >= 2 ? 32 : 0)));
+    sm.load((cu32p)(prog + (which >= 2 ? StrandMasks<GN, GP>::N : 0)));
     eval_strand<GN, GP>(sm, tile, acc);
     const uint32_t *plane = which == 0 ? st.MP : which == 1 ? st.UP : which == 2 ? st.MM : st.UM;
     const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
@@ -374,7 +443,11 @@ struct ModSlot {
 
 struct nm_ctx {
     int device = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    std::vector<uint32_t> bucket;                     // per-call host scratch, kept to avoid reallocation
+    uint32_t *d_programs = nullptr;                   // compiled constraint programs of the current batch
+    size_t prog_cap_dw = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     // per-launch event pairs since the last nm_timing_reset (bounded pool, summed lazily: no sync per launch)
@@ -448,7 +521,7 @@ int release_stage(nm_ctx *c) {   // call after the last device work that reads t
 inline uint32_t comp_mask(uint32_t m) { return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3); }
 
 // Compile one stripped motif into the per-strand constraint masks.  Layout: prog[strand*32 + gi*8 + plane],
-// gi = floor(d/32) + 2, bit r = d mod 32; meta at PROG_META: [0] flags (1 = wide offsets used).
+// gi = floor(d/32) + 2, bit r = d mod 32.
 int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_t *prog, bool *wide,
                     uint32_t *modpos_mask) {
     if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "motif length %u outside 1..%d", len, NM_MAX_MOTIF_LEN);
@@ -461,6 +534,7 @@ int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_
         if (m == 0) return fail(NM_EINVAL, "empty base set at motif position %u", j);
         if (m == 15u) continue;
         any = true;
+        if (j == modpos) continue;      // offset 0: folded into the accumulator init, or added by add_modpos_constraint
         for (int strand = 0; strand < 2; ++strand) {
             const int d = strand == 0 ? (int)j - (int)modpos : (int)modpos - (int)j;
             const uint32_t set = strand == 0 ? m : comp_mask(m);
@@ -482,9 +556,27 @@ int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_
         }
     }
     if (!any) return fail(NM_EINVAL, "motif has no specified position");
-    prog[PROG_META] = *wide ? 1u : 0u;
     *modpos_mask = masks[modpos] & 15u;
     return NM_OK;
+}
+
+// The constraint of the modified position itself (offset 0 -> word-group 2, shift 0), for programs that run on the
+// general path where the accumulator starts from all ones.
+void add_modpos_constraint(uint32_t *prog, uint32_t modpos_mask) {
+    if (modpos_mask == 15u) return;
+    for (int strand = 0; strand < 2; ++strand) {
+        const uint32_t set = strand == 0 ? modpos_mask : comp_mask(modpos_mask);
+        uint32_t *row = prog + strand * 32 + 2 * 8;
+        if (__builtin_popcount(set) == 1) {
+            row[__builtin_ctz(set)] |= 1u;
+        } else {
+            uint32_t missing = (~set) & 15u;
+            while (missing) {
+                row[4 + __builtin_ctz(missing)] |= 1u;
+                missing &= missing - 1;
+            }
+        }
+    }
 }
 
 template <int GN, int GP, bool COMPACT>
@@ -499,56 +591,100 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
     if (n_cand == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
-    // ---- sort candidates by (slot, bin)
-    std::vector<uint32_t> order(n_cand);
-    std::iota(order.begin(), order.end(), 0u);
+    // ---- one pass over the candidates: validate, classify the batch, count per (slot, bin) bucket.
+    // Candidates whose bin has no contig on this device (multi-GPU shard) contribute zero and get no program.
+    const uint32_t n_bins = c->n_bins;
+    std::vector<uint32_t> &bucket = c->bucket;          // counting sort by (slot, bin)
+    bucket.assign((size_t)NM_MAX_MOD_SLOTS * n_bins + 1, 0);
+    bool any_wide = false, all_compact = true;
+    uint32_t n_prog = 0;
+    uint64_t mask_bytes = 0;
+    bool slot_used[NM_MAX_MOD_SLOTS] = {false, false, false, false};
     for (uint32_t k = 0; k < n_cand; ++k) {
-        if (cand_mod_slot[k] >= NM_MAX_MOD_SLOTS || !c->slots[cand_mod_slot[k]].present)
-            return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, cand_mod_slot[k]);
-        if (cand_bin[k] >= c->n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, cand_bin[k], c->n_bins);
+        const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k], len = cand_len[k], mp = cand_modpos[k];
+        if (slot >= NM_MAX_MOD_SLOTS || !c->slots[slot].present)
+            return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, slot);
+        if (bin >= n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, bin, n_bins);
+        if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "candidate %u: motif length %u outside 1..%d", k, len, NM_MAX_MOTIF_LEN);
+        if (mp >= len) return fail(NM_EINVAL, "candidate %u: mod_position %u outside motif of length %u", k, mp, len);
+        const uint8_t *m = cand_masks + cand_mask_offset[k];
+        uint32_t all_and = 15u, any_zero = 0;
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint32_t v = m[j] & 15u;
+            all_and &= v;
+            any_zero |= (v == 0);
+        }
+        if (any_zero) return fail(NM_EINVAL, "candidate %u: empty base set in the motif", k);
+        if (all_and == 15u) return fail(NM_EINVAL, "candidate %u: motif has no specified position", k);
+        mask_bytes = std::max<uint64_t>(mask_bytes, (uint64_t)cand_mask_offset[k] + len);
+        if (c->bin_nchunks[bin] == 0) continue;
+        // offsets relative to the modified base span [-mp, len-1-mp] forward and the mirror image in reverse
+        if (mp > 31 || len - 1 - mp > 31) any_wide = true;
+        const uint32_t can_mask = c->slots[slot].canonical == 'A' ? NM_BASE_A : NM_BASE_C;
+        if ((m[mp] & 15u) != can_mask) all_compact = false;
+        bucket[(size_t)slot * n_bins + bin + 1] += 1;
+        slot_used[slot] = true;
+        n_prog += 1;
     }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        if (cand_mod_slot[x] != cand_mod_slot[y]) return cand_mod_slot[x] < cand_mod_slot[y];
-        return cand_bin[x] < cand_bin[y];
-    });
     uint32_t active[NM_MAX_MOD_SLOTS], n_active = 0;
     int slot_to_active[NM_MAX_MOD_SLOTS];
-    for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) slot_to_active[s] = -1;
-    for (uint32_t k = 0; k < n_cand; ++k) {
-        const int s = cand_mod_slot[order[k]];
-        if (slot_to_active[s] < 0) { slot_to_active[s] = (int)n_active; active[n_active++] = (uint32_t)s; }
+    for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) {
+        slot_to_active[sl] = -1;
+        if (slot_used[sl]) { slot_to_active[sl] = (int)n_active; active[n_active++] = (uint32_t)sl; }
     }
-    // ---- staging layout: programs | orig_index | cand_range
-    const size_t prog_bytes = (size_t)n_cand * PROG_DW * 4;
-    const size_t orig_bytes = (size_t)n_cand * 4;
-    const size_t range_bytes = (size_t)n_active * c->n_bins * sizeof(uint2);
-    const size_t off_orig = (prog_bytes + 15) & ~(size_t)15, off_range = (off_orig + orig_bytes + 15) & ~(size_t)15;
+    // ---- staging layout: candidate records (sorted) | orig_index | mask bytes | cand_range
+    const uint32_t pdw = any_wide ? 64u : 32u;
+    const size_t rec_bytes = (size_t)n_prog * sizeof(CandRec);
+    const size_t off_orig = (rec_bytes + 15) & ~(size_t)15;
+    const size_t off_masks = (off_orig + (size_t)n_prog * 4 + 15) & ~(size_t)15;
+    const size_t off_range = (off_masks + mask_bytes + 15) & ~(size_t)15;
+    const size_t range_bytes = (size_t)std::max(n_active, 1u) * n_bins * sizeof(uint2);
     const size_t total = off_range + range_bytes;
     int rc = ensure_stage(c, total);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
-    uint32_t *h_prog = reinterpret_cast<uint32_t *>(hs);
+    CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
     uint2 *h_range = reinterpret_cast<uint2 *>(hs + off_range);
+    memcpy(hs + off_masks, cand_masks, mask_bytes);
     memset(h_range, 0, range_bytes);
-    bool any_wide = false, all_compact = true;
-    for (uint32_t k = 0; k < n_cand; ++k) {
-        const uint32_t o = order[k];
-        bool wide = false;
-        uint32_t mp_mask = 0;
-        rc = compile_program(cand_masks + cand_mask_offset[o], cand_len[o], cand_modpos[o], h_prog + (size_t)k * PROG_DW,
-                             &wide, &mp_mask);
-        if (rc) return rc;
-        any_wide |= wide;
-        const ModSlot &ms = c->slots[cand_mod_slot[o]];
-        const uint32_t can_mask = ms.canonical == 'A' ? NM_BASE_A : NM_BASE_C;
-        if (mp_mask != can_mask) all_compact = false;
-        h_orig[k] = o;
-        uint2 &r = h_range[(size_t)slot_to_active[cand_mod_slot[o]] * c->n_bins + cand_bin[o]];
-        if (r.y == 0) r.x = k;
-        r.y += 1;
+    // exclusive prefix over the buckets -> first sorted index of each (slot, bin); stable within a bucket
+    for (size_t i = 1; i < bucket.size(); ++i) bucket[i] += bucket[i - 1];
+    for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) {
+        if (slot_to_active[sl] < 0) continue;
+        for (uint32_t b = 0; b < n_bins; ++b) {
+            const uint32_t lo = bucket[(size_t)sl * n_bins + b], hi = bucket[(size_t)sl * n_bins + b + 1];
+            if (hi > lo) h_range[(size_t)slot_to_active[sl] * n_bins + b] = make_uint2(lo, hi - lo);
+        }
     }
-    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, c->stream));
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k];
+        if (c->bin_nchunks[bin] == 0) continue;
+        const uint32_t at = bucket[(size_t)slot * n_bins + bin]++;
+        h_rec[at] = CandRec{cand_mask_offset[k], k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
+        h_orig[at] = k;
+    }
+    // device-side program buffer
+    const size_t need_dw = (size_t)std::max(n_prog, 1u) * pdw;
+    if (c->prog_cap_dw < need_dw) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_programs) (void)hipFree(c->d_programs);
+        c->d_programs = nullptr;
+        c->prog_cap_dw = 0;
+        HIP_TRY(hipMalloc(&c->d_programs, need_dw * 4 * 2));
+        c->prog_cap_dw = need_dw * 2;
+    }
+    // staged tables travel on the copy stream so that the upload of batch k+1 overlaps the kernel of batch k
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
+    if (n_prog) {
+        hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->stream, n_prog,
+                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, c->d_programs, any_wide ? 1 : 0,
+                           all_compact ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
@@ -572,14 +708,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.segments = c->d_segments;
     a.n_segments = c->n_segments;
     a.n_bins = c->n_bins;
-    uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
-    a.programs = reinterpret_cast<uint32_t *>(ds);
+    a.programs = c->d_programs;
     a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
     a.cand_range = reinterpret_cast<uint2 *>(ds + off_range);
     a.out = out;
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
+    for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
-    dim3 grid(gx, n_active);
+    dim3 grid(gx, std::max(n_active, 1u));
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->ev_collect) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -594,7 +730,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         c->ev_used += 1;
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (!any_wide && all_compact) launch_score<1, 1, true>(a, grid, c->stream);
+    if (n_prog == 0) { /* nothing resident for this batch: the zeroed table is the answer */ }
+    else if (!any_wide && all_compact) launch_score<1, 1, true>(a, grid, c->stream);
     else if (!any_wide) launch_score<1, 1, false>(a, grid, c->stream);
     else if (all_compact) launch_score<2, 2, true>(a, grid, c->stream);
     else launch_score<2, 2, false>(a, grid, c->stream);
@@ -605,8 +742,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     c->timed = !c->ev_collect;
     c->launches += 1;
     c->last_wgs = (uint64_t)gx * n_active;
-    c->last_compact = all_compact ? n_cand : 0;
-    c->last_general = all_compact ? 0 : n_cand;
+    c->last_compact = all_compact ? n_prog : 0;
+    c->last_general = all_compact ? 0 : n_prog;
     if (h_out) {
         HIP_TRY(hipMemcpyAsync(h_out, out, (size_t)n_cand * 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -634,6 +771,8 @@ int nm_ctx_create(int device, nm_ctx **out) {
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc(&c->d_err, sizeof(unsigned int)));
@@ -671,6 +810,7 @@ int nm_ctx_destroy(nm_ctx *c) {
         if (st.busy) (void)hipEventDestroy(st.busy);
     }
     if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_programs) (void)hipFree(c->d_programs);
     if (c->d_err) (void)hipFree(c->d_err);
     for (auto &pr : c->ev_pool) {
         (void)hipEventDestroy(pr.first);
@@ -678,6 +818,8 @@ int nm_ctx_destroy(nm_ctx *c) {
     }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NM_OK;
@@ -897,11 +1039,19 @@ int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t l
     if (mod_slot >= NM_MAX_MOD_SLOTS || !c->slots[mod_slot].present) return fail(NM_ESTATE, "mod slot %u has no pileup", mod_slot);
     if (which < 0 || which > 3) return fail(NM_EINVAL, "which must be 0..3");
     HIP_TRY(hipSetDevice(c->device));
-    uint32_t prog[PROG_DW];
+    uint32_t full[PROG_DW], prog[PROG_DW];
     bool wide = false;
     uint32_t mpm = 0;
-    int rc = compile_program(masks, len, modpos, prog, &wide, &mpm);
+    int rc = compile_program(masks, len, modpos, full, &wide, &mpm);
     if (rc) return rc;
+    add_modpos_constraint(full, mpm);
+    if (wide) {
+        memcpy(prog, full, sizeof full);
+    } else {
+        memset(prog, 0, sizeof prog);
+        memcpy(prog, full + 8, 16 * 4);
+        memcpy(prog + 16, full + 32 + 8, 16 * 4);
+    }
     const uint32_t nch = c->contig_nchunks[contig_id];
     const size_t out_words = (size_t)nch * CHUNK_WORDS;
     rc = ensure_stage(c, sizeof prog + out_words * 4);

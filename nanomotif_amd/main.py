@@ -96,7 +96,7 @@ def find_motifs_bin(args):
 
     # engine: this rank's contigs (all contigs that belong to a bin), sharded by length over the ranks
     names = [c for c in cfg.bin_contig if c in assembly]
-    parts = assign_contigs([len(assembly[c]) for c in names], world)
+    parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
     mine = [names[i] for i in parts[rank]]
     eng = ScanEngine(device)
     all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank

@@ -1,9 +1,13 @@
 """Contig -> GPU assignment for the multi-GPU path.
 
-Counts are sums over contigs (find_motifs_bin.py:1273-1283), so contigs — not bins — are the sharding unit:
-longest-processing-time-first on contig length balances the bytes each GPU streams per scoring step; the
-contigs of one bin may land on several GPUs and the per-candidate count tables are summed with one RCCL
-all-reduce per step.
+Counts are sums over contigs (find_motifs_bin.py:1273-1283), so contigs — not bins — are the sharding unit and a
+bin may span GPUs; the per-candidate count tables are summed with one RCCL all-reduce per scoring step.
+
+The assignment is longest-processing-time-first on *pieces*: a bin that is small against a GPU's share is one piece
+(all its contigs go to the least loaded GPU); a larger bin is cut into pieces of consecutive contigs no bigger
+than that limit (down to single contigs for a metagenome with a few huge bins, or a single isolate genome).  Keeping bins whole where possible means a rank
+only compiles and uploads the candidate programs of the bins it holds (the engine skips candidates whose bin
+has no contig on the device), so the fixed per-step host cost shrinks with the number of GPUs too.
 """
 from __future__ import annotations
 
@@ -12,15 +16,43 @@ import heapq
 import numpy as np
 
 
-def assign_contigs(lengths, world_size: int):
-    """list (per rank) of ascending contig-index arrays; deterministic (ties by index)."""
+def assign_contigs(lengths, world_size: int, bins=None, whole_bin_fraction: float = 0.05):
+    """list (per rank) of ascending contig-index arrays; deterministic (ties by index / name).
+
+    bins: optional bin label per contig.  Pieces are at most ``whole_bin_fraction`` of the per-rank target load
+    (which bounds the final imbalance to about that fraction)."""
     lengths = np.asarray(lengths, dtype=np.int64)
-    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    n = len(lengths)
+    if bins is None:
+        items = [(int(lengths[i]), (i,)) for i in range(n)]
+    else:
+        target = lengths.sum() / max(world_size, 1)
+        groups = {}
+        for i, b in enumerate(bins):
+            groups.setdefault(b, []).append(i)
+        items = []
+        for b in sorted(groups, key=str):
+            idx = groups[b]
+            size = int(lengths[idx].sum())
+            limit = whole_bin_fraction * target
+            if size <= limit:
+                items.append((size, tuple(idx)))
+                continue
+            piece, psize = [], 0
+            for i in sorted(idx, key=lambda i: (-int(lengths[i]), i)):
+                if piece and psize + int(lengths[i]) > limit:
+                    items.append((psize, tuple(piece)))
+                    piece, psize = [], 0
+                piece.append(i)
+                psize += int(lengths[i])
+            if piece:
+                items.append((psize, tuple(piece)))
+    items.sort(key=lambda it: (-it[0], it[1][0]))
     heap = [(0, r) for r in range(world_size)]
     heapq.heapify(heap)
     out = [[] for _ in range(world_size)]
-    for i in order:
+    for size, idx in items:
         load, r = heapq.heappop(heap)
-        out[r].append(i)
-        heapq.heappush(heap, (load + int(lengths[i]), r))
+        out[r].extend(idx)
+        heapq.heappush(heap, (load + size, r))
     return [np.array(sorted(x), dtype=np.int64) for x in out]

@@ -83,3 +83,19 @@ def test_contig_assignment_is_balanced_and_complete():
         assert np.array_equal(allc, np.arange(len(lengths)))
         loads = np.array([lengths[p].sum() for p in parts])
         assert loads.max() / loads.mean() < 1.01
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=1000, total_bp=100_000_000, n_bins=50, seed=1))
+    for world in (2, 4, 8):
+        parts = assign_contigs(mg.lengths, world, bins=mg.bin_names)
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(1000))
+        loads = np.array([mg.lengths[p].sum() for p in parts])
+        assert loads.max() / loads.mean() < 1.05
+        # bins stay mostly together: a rank holds contigs of far fewer bins than there are
+        if world == 2:
+            owner = {}
+            for r, p in enumerate(parts):
+                for i in p:
+                    owner.setdefault(mg.bin_names[i], set()).add(r)
+            assert sum(len(v) == 1 for v in owner.values()) >= 45
+    # one huge bin must still be split
+    parts = assign_contigs(mg.lengths, 4, bins=["only"] * 1000)
+    assert min(len(p) for p in parts) > 100
