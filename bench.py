@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+VALU_PEAK_WAVE_INSTR_S = 6.1e11   # measured integer-VALU issue peak (tools/valu_peak.hip, profiles/r1/valu_peak.txt)
 ALGO_BYTES_PER_BP_STEP = 0.5   # 2-bit sequence + 2-bit methylation state per bp per mod-type step
 
 
@@ -202,13 +203,14 @@ def main():
     final = counts[(step_no[0] - 1) & 1].cpu().numpy()
 
     result = None
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_insts = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         t = json.load(open(tj))
         if (t.get("workload"), t.get("total_bp"), t.get("candidates"), t.get("n_gpus")) == \
                 (args.workload, args.total_bp, len(cands), world):
             traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
+            valu_insts = t.get("sq_insts_valu_per_launch")
     if rank == 0:
         value = sites_per_step * args.steps / elapsed
         achieved = algo_bytes_rank / (kernel_ms * 1e-3) / 1e9
@@ -230,6 +232,14 @@ def main():
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
         }
+        if valu_insts:
+            # second roofline: the kernel is integer-VALU-issue bound once a (bin, mod type) carries more than ~2
+            # candidates; instruction count from rocprofv3 (SQ_INSTS_VALU, profiles/), peak from tools/valu_peak.hip
+            rate = valu_insts / (kernel_ms * 1e-3)
+            result["roofline_valu"] = {"bound": "valu-int", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_S,
+                                       "unit": "wave64 integer instr/s", "frac": rate / VALU_PEAK_WAVE_INSTR_S,
+                                       "sq_insts_valu_per_launch": valu_insts,
+                                       "peak_source": "profiles/r1/valu_peak.txt (alignbit+and stream, 4 cycles per wave64 op per SIMD)"}
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload, and parity
     if rank == 0 and world == 1 and args.cpu_bins != 0:
