@@ -39,7 +39,7 @@ typedef enum nm_status {
 } nm_status;
 
 #define NM_MAX_MOTIF_LEN 64   /* stripped motif length; offsets relative to the modified base in [-64, 63] */
-#define NM_MAX_MOD_SLOTS 4    /* modification types resident at once (reference: m, a, 21839 — constants.py:29-33) */
+#define NM_MAX_MOD_SLOTS 8    /* pileup classifications resident at once: the reference's 3 mod types (m, a, 21839 — constants.py:29-33), each possibly under two threshold pairs */
 
 /* motif position sets are 4-bit masks: bit0 = A, bit1 = C, bit2 = G, bit3 = T; 15 = '.'/N (any character,
  * including non-ACGT assembly letters — regex '.' semantics of utils.py:61-66). */

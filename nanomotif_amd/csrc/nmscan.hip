@@ -599,7 +599,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     bool any_wide = false, all_compact = true;
     uint32_t n_prog = 0;
     uint64_t mask_bytes = 0;
-    bool slot_used[NM_MAX_MOD_SLOTS] = {false, false, false, false};
+    bool slot_used[NM_MAX_MOD_SLOTS] = {};
     for (uint32_t k = 0; k < n_cand; ++k) {
         const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k], len = cand_len[k], mp = cand_modpos[k];
         if (slot >= NM_MAX_MOD_SLOTS || !c->slots[slot].present)

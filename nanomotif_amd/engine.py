@@ -87,13 +87,18 @@ class ScanEngine:
         self.slot_of_mod = {}
 
     # ------------------------------------------------------------------ pileup
-    def upload_pileup(self, mod_type: str, contig_id, position, strand, fraction_mod, low=0.3, high=0.7, append=False):
-        """Rows of one mod type after the pre-filters (SoA).  strand: uint8 ASCII '+'/'-'."""
-        if mod_type not in self.slot_of_mod:
-            if len(self.slot_of_mod) >= 4:
-                raise ValueError("at most 4 modification types resident")
-            self.slot_of_mod[mod_type] = len(self.slot_of_mod)
-        slot = self.slot_of_mod[mod_type]
+    def upload_pileup(self, mod_type, contig_id, position, strand, fraction_mod, low=0.3, high=0.7, append=False,
+                      label=None):
+        """Rows of one mod type after the pre-filters (SoA).  strand: uint8 ASCII '+'/'-'.  ``label`` names the
+        resident classification (default: the mod type); a second label of the same mod type holds another
+        threshold pair (find_motifs_bin.state_label)."""
+        label = mod_type if label is None else label
+        if label not in self.slot_of_mod:
+            n_slots = len(set(self.slot_of_mod.values()))
+            if n_slots >= 8:
+                raise ValueError("at most 8 pileup classifications resident")
+            self.slot_of_mod[label] = n_slots
+        slot = self.slot_of_mod[label]
         cid = np.ascontiguousarray(contig_id, dtype=np.uint32)
         pos = np.ascontiguousarray(position, dtype=np.uint32)
         st = np.ascontiguousarray(strand, dtype=np.uint8)
@@ -103,6 +108,10 @@ class ScanEngine:
         _lib.check(self.lib.nm_upload_pileup(self.ctx, slot, ord(MOD_TYPE_TO_CANONICAL[mod_type]), float(low), float(high),
                                              len(cid), _ptr(cid, C.c_uint32), _ptr(pos, C.c_uint32), _ptr(st, C.c_uint8),
                                              _ptr(fr, C.c_double), 1 if append else 0))
+
+    def alias_label(self, label, existing):
+        """Make ``label`` refer to the classification already resident as ``existing``."""
+        self.slot_of_mod[label] = self.slot_of_mod[existing]
 
     # ------------------------------------------------------------------ scoring
     def make_batch(self, candidates) -> CandidateBatch:

@@ -97,7 +97,7 @@ def motif_model_bin(pileup: BinData, contigs: BinData, motif: Motif, model: Beta
     if (low_meth_threshold, high_meth_threshold) != (s.low, s.high):
         raise ValueError(f"thresholds {low_meth_threshold}/{high_meth_threshold} differ from the uploaded pileup's {s.low}/{s.high}")
     assert type(motif) is Motif, "Motif is not a Motif type"
-    n_mod, n_nomod = s([((pileup.bin_name, pileup.mod_type), motif)])[0]
+    n_mod, n_nomod = s([((pileup.bin_name, pileup.mod_type), motif, None)])[0]
     model.update(int(n_mod), int(n_nomod))
     return model
 
@@ -128,8 +128,15 @@ class LockstepScorer:
         return counts
 
 
+def state_label(mod_type, tag):
+    """Name of the engine-resident pileup classification a request runs on: the mod type itself for the search's
+    thresholds, ``(mod_type, "merge")`` for the merge stage's fixed 0.3 / 0.7."""
+    return mod_type if tag is None else (mod_type, tag)
+
+
 def engine_scorer(engine, low=0.3, high=0.7, use_dist=False, group=None) -> LockstepScorer:
-    return LockstepScorer(lambda flat: engine.score([(m, key[1], key[0]) for key, m in flat]), low, high, use_dist, group)
+    return LockstepScorer(lambda flat: engine.score([(m, state_label(key[1], tag), key[0]) for key, m, tag in flat]),
+                          low, high, use_dist, group)
 
 
 def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
@@ -181,10 +188,6 @@ def discover(cfg: ProcessorConfig, table: PileupTable, scorer: LockstepScorer, r
     """Run every (bin, mod type) task of the data set.  ``table``: the post-filter pileup (all rows; every rank
     holds it for window extraction); ``scorer``: see ``engine_scorer``.  Returns (list of MotifRow, scorer) —
     identical on every rank."""
-    if (cfg.methylation_threshold_low, cfg.methylation_threshold_high) != (0.3, 0.7):
-        # merge_motifs_in_df is hard-wired to 0.3 / 0.7 in the reference (find_motifs_bin.py:569, 1436) while the
-        # search uses the CLI values; serving both needs two resident classifications.
-        raise NotImplementedError("methylation thresholds other than the defaults 0.3 / 0.7 are not supported yet")
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)

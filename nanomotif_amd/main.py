@@ -111,6 +111,11 @@ def find_motifs_bin(args):
         keep = lid >= 0
         eng.upload_pileup(mt, lid[keep], sub.position[keep], sub.strand[keep], sub.fraction_mod[keep],
                           low=cfg.methylation_threshold_low, high=cfg.methylation_threshold_high)
+        if (cfg.methylation_threshold_low, cfg.methylation_threshold_high) == (0.3, 0.7):
+            eng.alias_label((mt, "merge"), mt)
+        else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436)
+            eng.upload_pileup(mt, lid[keep], sub.position[keep], sub.strand[keep], sub.fraction_mod[keep],
+                              low=0.3, high=0.7, label=(mt, "merge"))
     scorer = engine_scorer(eng, cfg.methylation_threshold_low, cfg.methylation_threshold_high, use_dist=world > 1)
     rows, scorer = discover(cfg, table, scorer, rank=rank, bgzip_order=bgzip)
     eng.close()

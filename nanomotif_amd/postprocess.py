@@ -12,7 +12,7 @@ import numpy as np
 
 from .model import BetaBernoulliModel, predictive_evaluation_score
 from .motif import Motif, merge_motifs, motif_type, reverse_compliment
-from .search import get_parent_scores_co
+from .search import TaggedRequest, get_parent_scores_co
 
 
 @dataclass
@@ -84,10 +84,24 @@ def get_motif_parental_relationship(motifs):
     return rel
 
 
+def _tagged(co, tag):
+    """Re-issue every request of coroutine ``co`` as a TaggedRequest."""
+    try:
+        req = next(co)
+        while True:
+            req = co.send((yield TaggedRequest(req, tag)))
+    except StopIteration as e:
+        return e.value
+
+
 def merge_motifs_co(rows, merge_threshold=0.5):
-    """find_motifs_bin.py:1436-1537 for one (bin, mod type) group, as a scoring coroutine.  The engine holds the
-    state planes for the thresholds the pileup was uploaded with; the reference evaluates this stage at its
-    default 0.3 / 0.7 (find_motifs_bin.py:569, 1436) — the driver refuses other CLI thresholds for that reason."""
+    """find_motifs_bin.py:1436-1537 for one (bin, mod type) group, as a scoring coroutine.  The reference evaluates
+    this stage at its default thresholds 0.3 / 0.7 (find_motifs_bin.py:569, 1436) regardless of the CLI values, so
+    every request is tagged ``"merge"`` and the scorer routes it to the 0.3 / 0.7 classification of the pileup."""
+    return (yield from _tagged(_merge_motifs_co(rows, merge_threshold), "merge"))
+
+
+def _merge_motifs_co(rows, merge_threshold=0.5):
     if not rows:
         return rows
     bin_name, mod_type = rows[0].reference, rows[0].mod_type

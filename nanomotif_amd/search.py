@@ -392,10 +392,20 @@ def find_best_candidates_co(windows, mod_type: str, padding: int, min_kl=0.2, ma
 # ------------------------------------------------------------------------------------------------
 # lock-step scheduler
 # ------------------------------------------------------------------------------------------------
+class TaggedRequest(list):
+    """A scoring request that must be evaluated on another classification of the pileup than the search's own:
+    ``tag == "merge"`` = the reference's hard-wired 0.3 / 0.7 thresholds of merge_motifs_in_df
+    (find_motifs_bin.py:569, 1436), whatever the CLI thresholds are."""
+
+    def __init__(self, motifs, tag):
+        super().__init__(motifs)
+        self.tag = tag
+
+
 def run_lockstep(coroutines: dict, score_fn):
-    """Advance all coroutines together.  ``coroutines``: key -> generator yielding lists of Motif;
-    ``score_fn(list of (key, Motif)) -> int64[n, 2]`` scores one round's requests in one batch.
-    Returns key -> the coroutine's return value."""
+    """Advance all coroutines together.  ``coroutines``: key -> generator yielding lists of Motif (optionally a
+    ``TaggedRequest``); ``score_fn(list of (key, Motif, tag)) -> int64[n, 2]`` scores one round's requests in one
+    batch.  Returns key -> the coroutine's return value."""
     results, waiting = {}, {}
     for key, co in coroutines.items():
         try:
@@ -403,7 +413,7 @@ def run_lockstep(coroutines: dict, score_fn):
         except StopIteration as e:
             results[key] = e.value
     while waiting:
-        flat = [(key, m) for key, req in waiting.items() for m in req]
+        flat = [(key, m, getattr(req, "tag", None)) for key, req in waiting.items() for m in req]
         counts = score_fn(flat)
         nxt, at = {}, 0
         for key, req in waiting.items():

@@ -44,7 +44,7 @@ def oracle_bin_inputs(mg, mod_type, contigs=None, min_cov=5):
     return pile, seqs
 
 
-def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False):
+def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, high=0.7):
     """bin-motifs.tsv text computed end to end by the CPU oracle (filters -> search -> post-processing),
     following the task order / seeding of the reference's plain (or bgzip) strategy."""
     import random
@@ -84,7 +84,7 @@ def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False):
                     pile[mg.names[i]] = ContigPileup(t["position"][s][o], t["strand"][s][o], t["fraction_mod"][s][o])
             if not bgzip_order:
                 random.seed(seed)
-            res = ose.find_best_candidates(pile, seqs, mt, 0.3, 0.7, 20, min_kl=0.05, score_threshold=1.5)
+            res = ose.find_best_candidates(pile, seqs, mt, low, high, 20, min_kl=0.05, score_threshold=1.5)
             if res is None:
                 continue
             out = opp.process_bin(pile, seqs, b, mt, res[0], res[1], 20)

@@ -56,6 +56,22 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     assert os.path.exists(tmp + "/out_gz/temp/contig_bin.tsv")
 
 
+def test_non_default_thresholds_search_and_merge_stage(tmp_path):
+    """--methylation_threshold_low/high drive the search; the merge stage stays at 0.3 / 0.7 like the reference."""
+    spec = synth.SynthSpec(n_contigs=2, total_bp=400_000, n_bins=1, mod_types=("a",), seed=43, min_contig_bp=150_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCAAAT", 4, "a"), ("GRNGAAGY", 5, "a")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    mg.write_contig_bin(tmp + "/cb.tsv")
+    _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--methylation_threshold_low", "0.2",
+                   "--methylation_threshold_high", "0.8"])
+    got = open(tmp + "/o/bin-motifs.tsv").read()
+    assert got == oracle_pipeline(mg, low=0.2, high=0.8)
+    assert "GATC" in got
+
+
 def test_empty_result_writes_header_only(tmp_path):
     mg = synth.make_metagenome(synth.SynthSpec(n_contigs=1, total_bp=60_000, n_bins=1, mod_types=("a",), seed=62, fixed_motifs=()))
     tmp = str(tmp_path)

@@ -19,7 +19,7 @@ def oracle_backend(piles, seqs):
 
     def local(flat):
         out = np.zeros((len(flat), 2), dtype=np.int64)
-        for i, (key, m) in enumerate(flat):
+        for i, (key, m, tag) in enumerate(flat):
             out[i] = score_candidates(piles[key], seqs[key[0]], [(m.string, m.mod_position)])[0]
         return out
     return local
