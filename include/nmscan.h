@@ -140,6 +140,22 @@ int nm_stats(nm_ctx *ctx, uint64_t what[8]);
  * (kernels only, no copies).  Blocks until the launch finished. */
 int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
 
+/*
+ * Native modkit bedMethyl reader — replaces polars' scan_csv of the 18-column pileup (dataload.py:15-34, 72-100)
+ * and the tabix reader of the bgzip path (dataload.py:102-152).  Accepts plain text, gzip and bgzip (BGZF blocks are
+ * inflated in parallel; no .tbi needed).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
+ * order, names via nm_bed_contig_name), start (col 2), mod code (col 4: 0 = m, 1 = a, 2 = 21839, -1 = other),
+ * strand (col 6), fraction_mod = col 11 / 100 (-1 for the null markers "NA" / "null"), Nvalid_cov (col 10, -1 for
+ * null).  The column pointers stay valid until nm_bed_close.  threads = 0: one per core, at most 32.
+ */
+typedef struct nm_bed nm_bed;
+int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
+int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);
+int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
+int nm_bed_columns(nm_bed *bed, const uint32_t **contig_id, const int64_t **position, const int8_t **mod_type,
+                   const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov);
+int nm_bed_close(nm_bed *bed);
+
 /* Per-launch timing over a region: nm_timing_reset(ctx, 1) starts collecting one HIP event pair per scoring
  * launch (no synchronisation per launch); nm_timing_total_ms sums the kernel durations recorded since then and
  * reports how many launches they cover; nm_timing_reset(ctx, 0) stops collecting. */

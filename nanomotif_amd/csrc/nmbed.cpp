@@ -1,0 +1,364 @@
+// nmbed — native modkit bedMethyl reader (plain text, gzip, bgzip) for libnmscan.  C ABI: include/nmscan.h.
+//
+// Replaces, on the ingestion side of the hot path, polars' scan_csv of the 18-column pileup
+// (nanomotif/dataload.py:15-34, 72-100) and the epymetheus / pysam tabix reader of the bgzip path
+// (dataload.py:102-152).  Only the six columns the reference keeps are materialised, as struct-of-arrays:
+// contig id, start (col 2), mod code (col 4), strand (col 6), Nvalid_cov (col 10), percent modified (col 11) / 100.
+//
+// The file is inflated (BGZF blocks in parallel) or mapped, cut at line ends into one slab per thread, and every
+// thread parses its slab into private columns that are concatenated at the end; contig names are interned per thread
+// (rows of one contig are consecutive in a pileup, so the last name is cached) and merged in first-appearance order.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nmscan.h"
+
+int nm_set_error(int code, const char *fmt, ...);   // defined in nmscan.hip
+
+namespace {
+
+struct Columns {
+    std::vector<uint32_t> contig;
+    std::vector<int64_t> position, nvalid;
+    std::vector<int8_t> mod_type;
+    std::vector<uint8_t> strand;
+    std::vector<double> fraction;
+    std::vector<std::string> names;               // local id -> name
+    std::string error;
+};
+
+const double POW10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16,
+                          1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+inline bool is_null(const char *p, const char *e) {
+    const size_t n = (size_t)(e - p);
+    return (n == 2 && p[0] == 'N' && p[1] == 'A') || (n == 4 && memcmp(p, "null", 4) == 0) || n == 0;
+}
+
+// Decimal text -> double, correctly rounded: mantissa < 2^53 and <= 22 decimals divide exactly once (Clinger's
+// fast path); anything else goes through strtod.
+inline bool parse_double(const char *p, const char *e, double *out) {
+    const char *q = p;
+    bool neg = false;
+    if (q < e && (*q == '-' || *q == '+')) neg = *q++ == '-';
+    uint64_t mant = 0;
+    int ndig = 0, dec = 0;
+    bool seen_dot = false, ok = true;
+    for (; q < e; ++q) {
+        if (*q >= '0' && *q <= '9') {
+            if (mant > (UINT64_MAX - 9) / 10) { ok = false; break; }
+            mant = mant * 10 + (uint64_t)(*q - '0');
+            dec += seen_dot;
+            ++ndig;
+        } else if (*q == '.' && !seen_dot) {
+            seen_dot = true;
+        } else { ok = false; break; }
+    }
+    ok = ok && ndig > 0;
+    if (ok && mant < (1ull << 53) && dec <= 22) {
+        const double v = (double)mant / POW10[dec];
+        *out = neg ? -v : v;
+        return true;
+    }
+    std::string tmp(p, e);
+    char *endp = nullptr;
+    const double v = strtod(tmp.c_str(), &endp);
+    if (endp == tmp.c_str() || *endp != '\0') return false;
+    *out = v;
+    return true;
+}
+
+inline bool parse_int(const char *p, const char *e, int64_t *out) {
+    if (p == e) return false;
+    bool neg = false;
+    if (*p == '-') { neg = true; ++p; }
+    int64_t v = 0;
+    for (; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        v = v * 10 + (*p - '0');
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+void parse_slab(const char *beg, const char *end, Columns *c) {
+    std::unordered_map<std::string, uint32_t> ids;
+    std::string last_name;
+    uint32_t last_id = 0;
+    bool have_last = false;
+    size_t line_no = 0;
+    const char *p = beg;
+    while (p < end) {
+        const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!eol) eol = end;
+        const char *le = eol;
+        if (le > p && le[-1] == '\r') --le;
+        ++line_no;
+        if (le > p) {
+            const char *f[12];
+            const char *fe[12];
+            int nf = 0;
+            const char *q = p;
+            while (nf < 11) {
+                const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
+                f[nf] = q;
+                fe[nf] = t ? t : le;
+                ++nf;
+                if (!t) break;
+                q = t + 1;
+            }
+            if (nf < 11) { c->error = "pileup line with fewer than 11 tab-separated columns"; return; }
+            // contig
+            const size_t nl = (size_t)(fe[0] - f[0]);
+            if (!have_last || nl != last_name.size() || memcmp(last_name.data(), f[0], nl) != 0) {
+                last_name.assign(f[0], nl);
+                auto it = ids.find(last_name);
+                if (it == ids.end()) {
+                    it = ids.emplace(last_name, (uint32_t)c->names.size()).first;
+                    c->names.push_back(last_name);
+                }
+                last_id = it->second;
+                have_last = true;
+            }
+            int64_t pos = 0, cov = -1;
+            double pct = 0;
+            if (!parse_int(f[1], fe[1], &pos)) { c->error = "pileup column 2 (start) is not an integer"; return; }
+            if (!is_null(f[9], fe[9]) && !parse_int(f[9], fe[9], &cov)) { c->error = "pileup column 10 (Nvalid_cov) is not an integer"; return; }
+            bool pct_null = is_null(f[10], fe[10]);
+            if (!pct_null && !parse_double(f[10], fe[10], &pct)) { c->error = "pileup column 11 (percent modified) is not a number"; return; }
+            const size_t ml = (size_t)(fe[3] - f[3]);
+            int8_t mt = -1;
+            if (ml == 1 && f[3][0] == 'm') mt = 0;
+            else if (ml == 1 && f[3][0] == 'a') mt = 1;
+            else if (ml == 5 && memcmp(f[3], "21839", 5) == 0) mt = 2;
+            c->contig.push_back(last_id);
+            c->position.push_back(pos);
+            c->mod_type.push_back(mt);
+            c->strand.push_back(fe[5] > f[5] ? (uint8_t)f[5][0] : (uint8_t)'?');
+            c->nvalid.push_back(cov);
+            c->fraction.push_back(pct_null ? -1.0 : pct / 100.0);     // dataload.py:85
+        }
+        p = eol + 1;
+    }
+}
+
+// ---- input: plain (mmap), BGZF (parallel inflate), generic gzip (serial)
+struct Buffer {
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = nullptr;
+    size_t map_size = 0;
+    std::vector<char> owned;
+};
+
+bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)n;
+    zs.next_out = reinterpret_cast<Bytef *>(dst);
+    zs.avail_out = (uInt)dst_n;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+bool load_gzip(const uint8_t *z, size_t zn, Buffer *b, unsigned threads, std::string *err) {
+    // BGZF: every member is a gzip block with FEXTRA 'B','C' subfield holding the block size
+    struct Blk { size_t in_off, in_len, out_off, out_len; };
+    std::vector<Blk> blocks;
+    size_t off = 0, out = 0;
+    bool bgzf = true;
+    while (off + 18 <= zn) {
+        if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) { bgzf = false; break; }
+        const size_t xlen = z[off + 10] | (z[off + 11] << 8);
+        size_t x = off + 12, xe = x + xlen, bsize = 0;
+        while (x + 4 <= xe) {
+            const size_t slen = z[x + 2] | (z[x + 3] << 8);
+            if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2) bsize = (size_t)(z[x + 4] | (z[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize == 0 || off + bsize > zn) { bgzf = false; break; }
+        const size_t isize = z[off + bsize - 4] | (z[off + bsize - 3] << 8) | (z[off + bsize - 2] << 16) | ((size_t)z[off + bsize - 1] << 24);
+        blocks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, out, isize});
+        out += isize;
+        off += bsize;
+    }
+    if (bgzf && off == zn && !blocks.empty()) {
+        b->owned.resize(out);
+        std::vector<std::thread> pool;
+        std::vector<int> okv(threads, 1);
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                for (size_t i = t; i < blocks.size(); i += threads)
+                    if (blocks[i].out_len && !inflate_raw(z + blocks[i].in_off, blocks[i].in_len, b->owned.data() + blocks[i].out_off, blocks[i].out_len))
+                        okv[t] = 0;
+            });
+        for (auto &th : pool) th.join();
+        for (int v : okv)
+            if (!v) { *err = "corrupt BGZF block"; return false; }
+        b->data = b->owned.data();
+        b->size = b->owned.size();
+        return true;
+    }
+    // generic (possibly multi-member) gzip
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) { *err = "zlib init failed"; return false; }
+    zs.next_in = const_cast<Bytef *>(z);
+    zs.avail_in = (uInt)std::min<size_t>(zn, 0xFFFFFFFFu);
+    size_t consumed_total = 0;
+    std::vector<char> &o = b->owned;
+    o.resize(std::max<size_t>(zn * 4, 1 << 20));
+    size_t w = 0;
+    for (;;) {
+        if (w == o.size()) o.resize(o.size() * 2);
+        zs.next_out = reinterpret_cast<Bytef *>(o.data() + w);
+        zs.avail_out = (uInt)std::min<size_t>(o.size() - w, 0x40000000u);
+        const uInt before = zs.avail_out;
+        const int rc = inflate(&zs, Z_NO_FLUSH);
+        w += before - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            consumed_total = zn - zs.avail_in;
+            if (zs.avail_in == 0) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); *err = "zlib reset failed"; return false; }
+            continue;
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); *err = "corrupt gzip stream"; return false; }
+        if (rc == Z_BUF_ERROR && zs.avail_in == 0) { inflateEnd(&zs); *err = "truncated gzip stream"; return false; }
+    }
+    (void)consumed_total;
+    inflateEnd(&zs);
+    o.resize(w);
+    b->data = o.data();
+    b->size = w;
+    return true;
+}
+
+}  // namespace
+
+struct nm_bed {
+    Columns all;
+    std::vector<const char *> name_ptrs;
+};
+
+extern "C" {
+
+int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
+    if (!path || !out) return nm_set_error(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return nm_set_error(NM_EINVAL, "cannot open pileup '%s'", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return nm_set_error(NM_EINVAL, "cannot stat pileup '%s'", path); }
+    Buffer buf;
+    if (st.st_size > 0) {
+        buf.map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        buf.map_size = (size_t)st.st_size;
+        if (buf.map == MAP_FAILED) { close(fd); return nm_set_error(NM_EINVAL, "cannot map pileup '%s'", path); }
+    }
+    close(fd);
+    const uint8_t *raw = static_cast<const uint8_t *>(buf.map);
+    std::string err;
+    if (buf.map_size >= 2 && raw[0] == 31 && raw[1] == 139) {
+        if (!load_gzip(raw, buf.map_size, &buf, threads, &err)) {
+            munmap(buf.map, buf.map_size);
+            return nm_set_error(NM_EINVAL, "%s: %s", path, err.c_str());
+        }
+    } else {
+        buf.data = static_cast<const char *>(buf.map);
+        buf.size = buf.map_size;
+    }
+    // slabs cut at line ends
+    std::vector<size_t> cut(1, 0);
+    for (unsigned t = 1; t < threads; ++t) {
+        size_t at = buf.size / threads * t;
+        if (at <= cut.back()) continue;
+        const char *nl = (const char *)memchr(buf.data + at, '\n', buf.size - at);
+        if (!nl) break;
+        cut.push_back((size_t)(nl - buf.data) + 1);
+    }
+    cut.push_back(buf.size);
+    std::vector<Columns> parts(cut.size() - 1);
+    std::vector<std::thread> pool;
+    for (size_t i = 0; i + 1 < cut.size(); ++i)
+        pool.emplace_back(parse_slab, buf.data + cut[i], buf.data + cut[i + 1], &parts[i]);
+    for (auto &th : pool) th.join();
+    if (buf.map) munmap(buf.map, buf.map_size);
+    for (auto &p : parts)
+        if (!p.error.empty()) return nm_set_error(NM_EINVAL, "%s: %s", path, p.error.c_str());
+    nm_bed *b = new (std::nothrow) nm_bed();
+    if (!b) return nm_set_error(NM_ENOMEM, "out of host memory");
+    size_t n = 0;
+    for (auto &p : parts) n += p.position.size();
+    Columns &a = b->all;
+    a.contig.reserve(n); a.position.reserve(n); a.nvalid.reserve(n); a.mod_type.reserve(n); a.strand.reserve(n); a.fraction.reserve(n);
+    std::unordered_map<std::string, uint32_t> ids;
+    for (auto &p : parts) {
+        std::vector<uint32_t> remap(p.names.size());
+        for (size_t i = 0; i < p.names.size(); ++i) {
+            auto it = ids.find(p.names[i]);
+            if (it == ids.end()) {
+                it = ids.emplace(p.names[i], (uint32_t)a.names.size()).first;
+                a.names.push_back(p.names[i]);
+            }
+            remap[i] = it->second;
+        }
+        for (uint32_t v : p.contig) a.contig.push_back(remap[v]);
+        a.position.insert(a.position.end(), p.position.begin(), p.position.end());
+        a.nvalid.insert(a.nvalid.end(), p.nvalid.begin(), p.nvalid.end());
+        a.mod_type.insert(a.mod_type.end(), p.mod_type.begin(), p.mod_type.end());
+        a.strand.insert(a.strand.end(), p.strand.begin(), p.strand.end());
+        a.fraction.insert(a.fraction.end(), p.fraction.begin(), p.fraction.end());
+        Columns().contig.swap(p.contig);
+    }
+    for (auto &s : a.names) b->name_ptrs.push_back(s.c_str());
+    *out = b;
+    return NM_OK;
+}
+
+int nm_bed_shape(nm_bed *b, uint64_t *n_rows, uint32_t *n_contigs) {
+    if (!b || !n_rows || !n_contigs) return nm_set_error(NM_EINVAL, "NULL argument");
+    *n_rows = b->all.position.size();
+    *n_contigs = (uint32_t)b->all.names.size();
+    return NM_OK;
+}
+
+int nm_bed_contig_name(nm_bed *b, uint32_t i, const char **name) {
+    if (!b || !name || i >= b->name_ptrs.size()) return nm_set_error(NM_EINVAL, "bad contig index");
+    *name = b->name_ptrs[i];
+    return NM_OK;
+}
+
+int nm_bed_columns(nm_bed *b, const uint32_t **contig_id, const int64_t **position, const int8_t **mod_type,
+                   const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov) {
+    if (!b) return nm_set_error(NM_EINVAL, "NULL argument");
+    if (contig_id) *contig_id = b->all.contig.data();
+    if (position) *position = b->all.position.data();
+    if (mod_type) *mod_type = b->all.mod_type.data();
+    if (strand) *strand = b->all.strand.data();
+    if (fraction_mod) *fraction_mod = b->all.fraction.data();
+    if (nvalid_cov) *nvalid_cov = b->all.nvalid.data();
+    return NM_OK;
+}
+
+int nm_bed_close(nm_bed *b) {
+    delete b;
+    return NM_OK;
+}
+
+}  // extern "C"

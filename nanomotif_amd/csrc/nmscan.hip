@@ -753,6 +753,17 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
 
 }  // namespace
 
+// error sink for the other translation units of the library (nmbed.cpp)
+int nm_set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
 extern "C" {
 
 int nm_abi_version(void) { return 1; }

@@ -5,8 +5,7 @@ A ``PileupTable`` holds one row per (contig, position, strand, mod type) with in
 that rows can be handed to the HIP engine without touching Python objects per row."""
 from __future__ import annotations
 
-import gzip
-import io
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -33,27 +32,36 @@ class PileupTable:
                            self.strand[sel], self.fraction_mod[sel], self.nvalid_cov[sel])
 
 
-def load_pileup(path: str) -> PileupTable:
+def load_pileup(path: str, threads: int = 0) -> PileupTable:
     """modkit bedMethyl, 18 tab-separated columns, no header; used: 1 contig, 2 start, 4 mod code, 6 strand,
-    10 Nvalid_cov, 11 percent modified; nulls 'NA' / 'null' (dataload.py:72-100).  ``.gz`` (bgzip is gzip) is
-    read whole — no tabix index needed."""
-    import pandas as pd
-    opener = gzip.open if path.endswith(".gz") else open
-    with opener(path, "rb") as fh:
-        raw = fh.read()
-    if not raw.strip():
-        raise SystemExit("Pileup is empty after initial load")          # dataload.py:89-91 exits with status 1
-    df = pd.read_csv(io.BytesIO(raw), sep="\t", header=None, usecols=[0, 1, 3, 5, 9, 10],
-                     names=["contig", "position", "mod_type", "strand", "nvalid", "pct"],
-                     dtype={"contig": str, "mod_type": str, "strand": str}, na_values=["NA", "null"], keep_default_na=False)
-    names, contig_id = np.unique(df["contig"].to_numpy(dtype=object), return_inverse=True)
-    mt = df["mod_type"].to_numpy(dtype=object)
-    mod_id = np.full(len(df), -1, dtype=np.int8)
-    for k, code in enumerate(MOD_TYPES):
-        mod_id[mt == code] = k
-    strand = np.frombuffer("".join(df["strand"].tolist()).encode("ascii"), dtype=np.uint8).copy() if len(df) else np.zeros(0, np.uint8)
-    return PileupTable(list(names), contig_id.astype(np.int32), df["position"].to_numpy(dtype=np.int64), mod_id, strand,
-                       df["pct"].to_numpy(dtype=np.float64) / 100, df["nvalid"].to_numpy(dtype=np.int64))
+    10 Nvalid_cov, 11 percent modified; nulls 'NA' / 'null' (dataload.py:72-100).  Parsed natively
+    (libnmscan: nm_bed_open — plain text, gzip or bgzip, multi-threaded); rows whose coverage or percentage is null
+    can never pass ``Nvalid_cov > 5`` in the reference either and are dropped here."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    _lib.check(lib.nm_bed_open(os.fsencode(path), int(threads), C.byref(h)))
+    try:
+        n, nc = C.c_uint64(0), C.c_uint32(0)
+        _lib.check(lib.nm_bed_shape(h, C.byref(n), C.byref(nc)))
+        if n.value == 0:
+            raise SystemExit("Pileup is empty after initial load")      # dataload.py:89-91 exits with status 1
+        names = []
+        for i in range(nc.value):
+            s = C.c_char_p()
+            _lib.check(lib.nm_bed_contig_name(h, i, C.byref(s)))
+            names.append(s.value.decode())
+        ptr = [C.c_void_p() for _ in range(6)]
+        _lib.check(lib.nm_bed_columns(h, *[C.byref(x) for x in ptr]))
+        def col(i, ctype, dtype):
+            return np.ctypeslib.as_array(C.cast(ptr[i], C.POINTER(ctype)), shape=(n.value,)).astype(dtype, copy=True)
+        t = PileupTable(names, col(0, C.c_uint32, np.int32), col(1, C.c_int64, np.int64), col(2, C.c_int8, np.int8),
+                        col(3, C.c_uint8, np.uint8), col(4, C.c_double, np.float64), col(5, C.c_int64, np.int64))
+    finally:
+        lib.nm_bed_close(h)
+    ok = (t.nvalid_cov >= 0) & (t.fraction_mod >= 0)
+    return t if ok.all() else t.take(ok)
 
 
 def filter_pileup(t: PileupTable, min_coverage: int = 5) -> PileupTable:

@@ -1,0 +1,79 @@
+"""Native bedMethyl reader (nm_bed_*, libnmscan) — host-only, runs without a GPU."""
+import gzip
+import struct
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+from nanomotif_amd import pileup as pp
+from nanomotif_amd import synth
+
+
+def _bgzf(data, bs=60000):
+    out = b""
+    for i in range(0, len(data), bs):
+        blk = data[i:i + bs]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(blk) + c.flush()
+        out += struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp
+        out += struct.pack("<II", zlib.crc32(blk), len(blk))
+    return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def test_reader_is_exact_on_plain_gzip_and_bgzf(tmp_path):
+    spec = synth.SynthSpec(n_contigs=4, total_bp=300_000, n_bins=2, mod_types=("a", "m"), seed=61, min_contig_bp=30_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    t0 = time.perf_counter()
+    tab = pp.load_pileup(path)
+    dt = time.perf_counter() - t0
+    assert len(tab) == 300_000 and sorted(tab.contig_names) == sorted(mg.names)
+    for mt_id, mt in ((1, "a"), (0, "m")):
+        for ci in range(4):
+            sel = (tab.mod_type == mt_id) & (tab.contig == tab.contig_names.index(mg.names[ci]))
+            host = mg.contig_pileup(ci, mt)
+            o = np.lexsort((tab.strand[sel], tab.position[sel]))
+            ho = np.lexsort((host["strand"], host["position"]))
+            assert np.array_equal(tab.position[sel][o], host["position"][ho])
+            assert np.array_equal(tab.strand[sel][o], host["strand"][ho])
+            assert np.array_equal(tab.fraction_mod[sel][o], synth.pct_to_fraction(host["pct_hundredths"])[ho])   # bit-exact doubles
+            assert np.array_equal(tab.nvalid_cov[sel][o], host["nvalid"][ho])
+    raw = open(path, "rb").read()
+    with gzip.open(path + ".gz", "wb") as g:
+        g.write(raw)
+    open(path + ".bgz.gz", "wb").write(_bgzf(raw))
+    for p in (path + ".gz", path + ".bgz.gz"):
+        t2 = pp.load_pileup(p)
+        assert t2.contig_names == tab.contig_names
+        for col in ("contig", "position", "mod_type", "strand", "fraction_mod", "nvalid_cov"):
+            assert np.array_equal(getattr(t2, col), getattr(tab, col)), (p, col)
+    assert dt < 5.0
+
+
+def test_reader_edge_cases(tmp_path):
+    lines = [
+        "c 1\t10\t11\ta\t12\t+\t10\t11\t255,0,0\t12\t70.00\t8\t4\t0\t0\t0\t0\t0",      # name with a space
+        "c 1\t11\t12\tm\t3\t-\t11\t12\t255,0,0\tNA\t50.5\t1\t2\t0\t0\t0\t0\t0",        # null coverage -> dropped
+        "c2\t0\t1\t21839\t9\t+\t0\t1\t255,0,0\t9\tnull\t0\t9\t0\t0\t0\t0\t0",           # null percent -> dropped
+        "c2\t5\t6\th\t9\t-\t5\t6\t255,0,0\t9\t33.333333333333336\t3\t6\t0\t0\t0\t0\t0",  # unknown mod code, long float
+        "c2\t7\t8\ta\t100\t+\t7\t8\t255,0,0\t100\t1e2\t100\t0\t0\t0\t0\t0\t0",          # exponent form -> strtod path
+    ]
+    path = str(tmp_path / "e.bed")
+    open(path, "w").write("\r\n".join(lines) + "\r\n")
+    t = pp.load_pileup(path)
+    assert t.contig_names == ["c 1", "c2"] and len(t) == 3
+    assert t.position.tolist() == [10, 5, 7] and t.mod_type.tolist() == [1, -1, 1]
+    assert t.fraction_mod.tolist() == [70.00 / 100, 33.333333333333336 / 100, 1.0]
+    assert t.strand.tolist() == [ord("+"), ord("-"), ord("+")]
+    from nanomotif_amd._lib import NmScanError
+    open(path, "w").write("c\t1\t2\ta\n")
+    with pytest.raises(NmScanError):
+        pp.load_pileup(path)
+    with pytest.raises(NmScanError):
+        pp.load_pileup(str(tmp_path / "missing.bed"))
+    open(path, "w").write("")
+    with pytest.raises(SystemExit):
+        pp.load_pileup(path)
