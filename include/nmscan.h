@@ -94,6 +94,26 @@ int nm_upload_pileup_device(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_ba
                             const uint8_t *d_strand, const double *d_fraction_mod, int append);
 
 /*
+ * Raw pileup ingestion with the reference's three pre-filters evaluated ON THE DEVICE, in the reference's order
+ * (find_motifs_bin.py:399-414): Nvalid_cov > 5 (dataload.py:191-200); per (contig, mod code) #(frac > 0.7) / #rows
+ * > 1e-4 and #(frac > 0.7) > 50 (:202-226); adjacency: per (contig, strand), mod codes mixed, keep a row iff its
+ * fraction equals the maximum over positions p-8..p+8 or is below 0.7 (:228-247).  Surviving rows of the mod codes
+ * with slot_of_mod[code] >= 0 are classified into that slot's state planes exactly as nm_upload_pileup does (the slots
+ * are cleared first); the surviving rows with fraction_mod >= high are kept as a compact list — the input of the
+ * window extraction (find_motifs_bin.py:625-661) — and fetched with nm_ingest_results together with the number of
+ * surviving rows per (contig, mod code).
+ *   rows: contig_id = engine contig index or 0xFFFFFFFF for contigs this device does not hold (ignored);
+ *   mod_code 0..7 (0 = m, 1 = a, 2 = 21839, others as numbered by the reader); nvalid_cov as read (col 10).
+ *   rows_on_device != 0: the six columns are device pointers.
+ */
+int nm_ingest_pileup(nm_ctx *ctx, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                     const int8_t *mod_code, const uint8_t *strand, const double *fraction_mod,
+                     const int32_t *nvalid_cov, const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8],
+                     double low, double high, int rows_on_device, uint64_t *n_kept, uint64_t *n_confident);
+int nm_ingest_results(nm_ctx *ctx, uint32_t *conf_contig, uint32_t *conf_position, uint8_t *conf_strand,
+                      int8_t *conf_mod, uint64_t capacity, uint32_t *kept_per_contig_mod);
+
+/*
  * Score a batch of candidate motifs — replaces n_cand calls of motif_model_bin(..., BetaBernoulliModel())
  * (find_motifs_bin.py:1265-1283).  Candidate k is the STRIPPED motif (motif.py:213-224) given as
  * cand_len[k] position masks starting at cand_masks[cand_mask_offset[k]], with the modified base at index
@@ -144,7 +164,8 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
  * Native modkit bedMethyl reader — replaces polars' scan_csv of the 18-column pileup (dataload.py:15-34, 72-100)
  * and the tabix reader of the bgzip path (dataload.py:102-152).  Accepts plain text, gzip and bgzip (BGZF blocks are
  * inflated in parallel; no .tbi needed).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
- * order, names via nm_bed_contig_name), start (col 2), mod code (col 4: 0 = m, 1 = a, 2 = 21839, -1 = other),
+ * order, names via nm_bed_contig_name), start (col 2), mod code id (col 4: 0 = m, 1 = a, 2 = 21839, other codes
+ * numbered 3, 4, ... in first-appearance order, names via nm_bed_mod_code),
  * strand (col 6), fraction_mod = col 11 / 100 (-1 for the null markers "NA" / "null"), Nvalid_cov (col 10, -1 for
  * null).  The column pointers stay valid until nm_bed_close.  threads = 0: one per core, at most 32.
  */
@@ -152,6 +173,7 @@ typedef struct nm_bed nm_bed;
 int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
 int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);
 int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
+int nm_bed_mod_code(nm_bed *bed, uint32_t id, const char **code);
 int nm_bed_columns(nm_bed *bed, const uint32_t **contig_id, const int64_t **position, const int8_t **mod_type,
                    const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov);
 int nm_bed_close(nm_bed *bed);

@@ -36,6 +36,7 @@ struct Columns {
     std::vector<uint8_t> strand;
     std::vector<double> fraction;
     std::vector<std::string> names;               // local id -> name
+    std::vector<std::string> other_mods;          // local mod id 3 + k -> code (anything but m, a, 21839)
     std::string error;
 };
 
@@ -143,6 +144,14 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
             if (ml == 1 && f[3][0] == 'm') mt = 0;
             else if (ml == 1 && f[3][0] == 'a') mt = 1;
             else if (ml == 5 && memcmp(f[3], "21839", 5) == 0) mt = 2;
+            else {
+                size_t k = 0;
+                for (; k < c->other_mods.size(); ++k)
+                    if (c->other_mods[k].size() == ml && memcmp(c->other_mods[k].data(), f[3], ml) == 0) break;
+                if (k == c->other_mods.size()) c->other_mods.emplace_back(f[3], ml);
+                if (k > 100) { c->error = "more than 100 distinct modification codes in column 4"; return; }
+                mt = (int8_t)(3 + k);
+            }
             c->contig.push_back(last_id);
             c->position.push_back(pos);
             c->mod_type.push_back(mt);
@@ -319,6 +328,16 @@ int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
             remap[i] = it->second;
         }
         for (uint32_t v : p.contig) a.contig.push_back(remap[v]);
+        std::vector<int8_t> mod_remap(3 + p.other_mods.size());
+        for (int k = 0; k < 3; ++k) mod_remap[k] = (int8_t)k;
+        for (size_t k = 0; k < p.other_mods.size(); ++k) {
+            size_t g = 0;
+            for (; g < a.other_mods.size(); ++g)
+                if (a.other_mods[g] == p.other_mods[k]) break;
+            if (g == a.other_mods.size()) a.other_mods.push_back(p.other_mods[k]);
+            mod_remap[3 + k] = (int8_t)(3 + g);
+        }
+        for (auto &m : p.mod_type) m = mod_remap[(size_t)m];
         a.position.insert(a.position.end(), p.position.begin(), p.position.end());
         a.nvalid.insert(a.nvalid.end(), p.nvalid.begin(), p.nvalid.end());
         a.mod_type.insert(a.mod_type.end(), p.mod_type.begin(), p.mod_type.end());
@@ -341,6 +360,15 @@ int nm_bed_shape(nm_bed *b, uint64_t *n_rows, uint32_t *n_contigs) {
 int nm_bed_contig_name(nm_bed *b, uint32_t i, const char **name) {
     if (!b || !name || i >= b->name_ptrs.size()) return nm_set_error(NM_EINVAL, "bad contig index");
     *name = b->name_ptrs[i];
+    return NM_OK;
+}
+
+int nm_bed_mod_code(nm_bed *b, uint32_t id, const char **code) {
+    static const char *known[3] = {"m", "a", "21839"};
+    if (!b || !code) return nm_set_error(NM_EINVAL, "NULL argument");
+    if (id < 3) { *code = known[id]; return NM_OK; }
+    if (id - 3 >= b->all.other_mods.size()) return nm_set_error(NM_EINVAL, "mod id %u not present", id);
+    *code = b->all.other_mods[id - 3].c_str();
     return NM_OK;
 }
 

@@ -109,6 +109,44 @@ class ScanEngine:
                                              len(cid), _ptr(cid, C.c_uint32), _ptr(pos, C.c_uint32), _ptr(st, C.c_uint8),
                                              _ptr(fr, C.c_double), 1 if append else 0))
 
+    def ingest_pileup(self, contig_local, position, mod_code, strand, fraction_mod, nvalid_cov, labels, low=0.3, high=0.7):
+        """RAW pileup rows -> device-side pre-filters (dataload.py:191-247) -> state planes.
+        contig_local: engine contig index per row, 0xFFFFFFFF for contigs this engine does not hold;
+        mod_code: int8 ids as numbered by the reader (0 = m, 1 = a, 2 = 21839, 3.. = others, which only take part in
+        the filters); labels: {mod code id: (label, canonical base)} for the codes to classify.
+        Returns dict(n_kept, confident=(contig_local, position, strand, mod_code) of the surviving rows with
+        fraction_mod >= high, kept=uint32[n_contigs, 8] surviving rows per (contig, mod code))."""
+        cid = np.ascontiguousarray(contig_local, dtype=np.uint32)
+        pos = np.ascontiguousarray(position, dtype=np.uint32)
+        mod = np.ascontiguousarray(mod_code, dtype=np.int8)
+        st = np.ascontiguousarray(strand, dtype=np.uint8)
+        fr = np.ascontiguousarray(fraction_mod, dtype=np.float64)
+        nv = np.ascontiguousarray(np.clip(nvalid_cov, -2**31, 2**31 - 1), dtype=np.int32)
+        n = len(cid)
+        if not (len(pos) == len(mod) == len(st) == len(fr) == len(nv) == n):
+            raise ValueError("pileup columns differ in length")
+        slot_of = (C.c_int32 * 8)(*([-1] * 8))
+        canon = (C.c_uint8 * 8)(*([0] * 8))
+        for code, (label, base) in labels.items():
+            if label not in self.slot_of_mod:
+                n_slots = len(set(self.slot_of_mod.values()))
+                if n_slots >= 8:
+                    raise ValueError("at most 8 pileup classifications resident")
+                self.slot_of_mod[label] = n_slots
+            slot_of[int(code)] = self.slot_of_mod[label]
+            canon[int(code)] = ord(base)
+        n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.lib.nm_ingest_pileup(self.ctx, n, vp(cid), vp(pos), vp(mod), vp(st), vp(fr), vp(nv), slot_of, canon,
+                                             float(low), float(high), 0, C.byref(n_kept), C.byref(n_conf)))
+        k = n_conf.value
+        cc, cp = np.empty(k, np.uint32), np.empty(k, np.uint32)
+        cs, cm = np.empty(k, np.uint8), np.empty(k, np.int8)
+        kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
+        _lib.check(self.lib.nm_ingest_results(self.ctx, _ptr(cc, C.c_uint32), _ptr(cp, C.c_uint32), _ptr(cs, C.c_uint8),
+                                              cm.ctypes.data_as(C.POINTER(C.c_int8)), k, _ptr(kept, C.c_uint32)))
+        return dict(n_kept=int(n_kept.value), confident=(cc, cp, cs, cm), kept=kept)
+
     def alias_label(self, label, existing):
         """Make ``label`` refer to the classification already resident as ``existing``."""
         self.slot_of_mod[label] = self.slot_of_mod[existing]

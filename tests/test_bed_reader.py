@@ -65,7 +65,7 @@ def test_reader_edge_cases(tmp_path):
     open(path, "w").write("\r\n".join(lines) + "\r\n")
     t = pp.load_pileup(path)
     assert t.contig_names == ["c 1", "c2"] and len(t) == 3
-    assert t.position.tolist() == [10, 5, 7] and t.mod_type.tolist() == [1, -1, 1]
+    assert t.position.tolist() == [10, 5, 7] and t.mod_type.tolist() == [1, 3, 1]
     assert t.fraction_mod.tolist() == [70.00 / 100, 33.333333333333336 / 100, 1.0]
     assert t.strand.tolist() == [ord("+"), ord("-"), ord("+")]
     from nanomotif_amd._lib import NmScanError

@@ -1,0 +1,102 @@
+"""Device-side pre-filters + classification (nm_ingest_pileup) against the CPU oracle's filters
+(oracle/pileup.py, pinned by the reference's adjacency known-answer cases)."""
+import numpy as np
+import pytest
+
+from nanomotif_amd import synth
+from nanomotif_amd.motif import Motif
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_table(mg, rng=None):
+    cols = []
+    for code, mt in ((0, "m"), (1, "a")):
+        if mt not in mg.spec.mod_types:
+            continue
+        c = mg.pileup_columns(mt)
+        c["mod"] = np.full(len(c["position"]), code, np.int8)
+        cols.append(c)
+    cat = lambda k: np.concatenate([c[k] for c in cols])
+    t = dict(contig=cat("contig_id").astype(np.int64), position=cat("position"), strand=cat("strand"), mod_type=cat("mod"),
+             fraction_mod=cat("fraction_mod").copy(), Nvalid_cov=cat("nvalid").astype(np.int64))
+    if rng is not None:      # adversarial edits: ties inside windows, exact thresholds, coverage edge, a third mod code
+        n = len(t["position"])
+        idx = rng.choice(n, size=n // 50, replace=False)
+        t["fraction_mod"][idx] = rng.choice([0.7, 0.7000000000000001, 0.6999999999999999, 0.9, 0.9, 1.0, 0.3], size=len(idx))
+        idx = rng.choice(n, size=n // 200, replace=False)
+        t["Nvalid_cov"][idx] = rng.choice([5, 6, 0], size=len(idx))
+        idx = rng.choice(n, size=n // 300, replace=False)
+        t["mod_type"][idx] = 3                                       # e.g. 'h': takes part in the filters only
+    return t
+
+
+def test_device_filters_match_oracle_filters():
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    from oracle.scan import ContigPileup, score_candidates
+    spec = synth.SynthSpec(n_contigs=6, total_bp=600_000, n_bins=2, mod_types=("a", "m"), seed=81, min_contig_bp=30_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m"), ("GAATTC", 2, "a")))
+    mg = synth.make_metagenome(spec)
+    t = _raw_table(mg, np.random.default_rng(4))
+    # contig 5 gets too few methylated rows for mod 'm' -> dropped by the frequency filter
+    sel = (t["contig"] == 5) & (t["mod_type"] == 0)
+    t["fraction_mod"][sel] = np.minimum(t["fraction_mod"][sel], 0.5)
+    exp = op.prefilter({k: v.copy() for k, v in t.items()})
+    eng = ScanEngine(0)
+    eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(6)], mg.bin_names)
+    res = eng.ingest_pileup(t["contig"].astype(np.uint32), t["position"], t["mod_type"], t["strand"], t["fraction_mod"],
+                            t["Nvalid_cov"], {0: ("m", "C"), 1: ("a", "A")})
+    assert res["n_kept"] == len(exp["position"])
+    kept = np.zeros((6, 8), dtype=np.int64)
+    np.add.at(kept, (exp["contig"], exp["mod_type"]), 1)
+    assert np.array_equal(res["kept"].astype(np.int64), kept) and kept[5, 0] == 0
+    # confident rows (fraction >= 0.7) of the scored mod codes
+    conf = (exp["fraction_mod"] >= 0.7) & (exp["mod_type"] < 2)
+    want = sorted(zip(exp["contig"][conf].tolist(), exp["position"][conf].tolist(), exp["strand"][conf].tolist(), exp["mod_type"][conf].tolist()))
+    cc, cp, cs, cm = res["confident"]
+    assert sorted(zip(cc.tolist(), cp.tolist(), cs.tolist(), cm.tolist())) == want
+    # scoring on the device-filtered planes == oracle scoring on the oracle-filtered rows
+    motifs = [("GATC", 1), ("A", 0), ("GAATTC", 2), ("CC[AT]GG", 1), ("C", 0), ("G[AG].GAAG[CT]", 5)]
+    for code, mt in ((0, "m"), (1, "a")):
+        for b in sorted(set(mg.bin_names)):
+            idx = [i for i, x in enumerate(mg.bin_names) if x == b]
+            pile = {}
+            for i in idx:
+                s = (exp["contig"] == i) & (exp["mod_type"] == code)
+                pile[mg.names[i]] = ContigPileup(exp["position"][s], exp["strand"][s], exp["fraction_mod"][s])
+            seqs = {mg.names[i]: mg.contig_str(i) for i in idx}
+            these = [(s, p) for s, p in motifs if Motif(s, p).split()[p] in ("A" if mt == "a" else "C", "[AG]")]
+            expc = score_candidates(pile, seqs, these)
+            got = eng.score([(Motif(s, p), mt, b) for s, p in these])
+            assert np.array_equal(got, expc), (mt, b)
+    # a shard: rows of absent contigs are ignored
+    eng2 = ScanEngine(0)
+    mine = [0, 2, 4]
+    eng2.upload_assembly([mg.names[i] for i in mine], [mg.contig_ascii(i) for i in mine], [mg.bin_names[i] for i in mine],
+                         bin_names=sorted(set(mg.bin_names)))
+    lut = np.full(6, 0xFFFFFFFF, dtype=np.uint32)
+    lut[mine] = np.arange(3, dtype=np.uint32)
+    res2 = eng2.ingest_pileup(lut[t["contig"]], t["position"], t["mod_type"], t["strand"], t["fraction_mod"], t["Nvalid_cov"],
+                              {0: ("m", "C"), 1: ("a", "A")})
+    assert np.array_equal(res2["kept"], res["kept"][mine])
+    eng.close(); eng2.close()
+
+
+def test_adjacency_kat_on_device():
+    """tests/test_dataload.py:37-69 shapes, scaled to the fixed d = 8 of the pipeline."""
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    rng = np.random.default_rng(9)
+    L = 4000
+    seq = "".join(rng.choice(list("ACGT"), size=L))
+    pos = np.arange(0, L, 3, dtype=np.int64)
+    frac = rng.choice([0.0, 0.2, 0.69, 0.7, 0.75, 0.8, 0.8, 0.95, 1.0], size=len(pos))
+    t = dict(contig=np.zeros(len(pos), np.int64), position=pos, strand=np.where(rng.random(len(pos)) < 0.5, ord("+"), ord("-")).astype(np.uint8),
+             mod_type=rng.choice([0, 1], size=len(pos)).astype(np.int8), fraction_mod=frac, Nvalid_cov=np.full(len(pos), 20))
+    exp = op.prefilter({k: v.copy() for k, v in t.items()})
+    eng = ScanEngine(0)
+    eng.upload_assembly(["c"], [seq], ["b"])
+    res = eng.ingest_pileup(t["contig"].astype(np.uint32), pos, t["mod_type"], t["strand"], frac, t["Nvalid_cov"], {0: ("m", "C"), 1: ("a", "A")})
+    assert res["n_kept"] == len(exp["position"]) and 0 < res["n_kept"] < len(pos)
+    eng.close()
