@@ -169,44 +169,77 @@ def task_coroutine(bin_name, mod_type, windows, cfg: ProcessorConfig, stage_writ
     return rows
 
 
-def confident_positions(table: PileupTable, contig_ids, high):
-    """name -> positions of rows with fraction_mod >= high, split by strand (find_motifs_bin.py:625, 635-636),
-    for every contig that has at least one row."""
-    plus, minus = {}, {}
-    conf = table.fraction_mod >= high
-    for cid in contig_ids:
-        sel = table.contig == cid
-        if not sel.any():
-            continue
-        name = table.contig_names[cid]
-        plus[name] = table.position[sel & conf & (table.strand == ord("+"))]
-        minus[name] = table.position[sel & conf & (table.strand == ord("-"))]
-    return plus, minus
+class FilteredPileup:
+    """What window extraction needs from the filtered pileup (find_motifs_bin.py:625-661): the surviving rows with
+    fraction_mod >= high, and which (contig, mod type) pairs have any surviving row at all.  Produced on the device
+    by ``nm_ingest_pileup`` (``from_ingest``) or from a host-side ``PileupTable`` (``from_table``)."""
+
+    def __init__(self, contig_names, conf_contig, conf_position, conf_strand, conf_mod, kept):
+        self.contig_names = list(contig_names)          # index space of conf_contig / kept rows
+        self.conf_contig, self.conf_position = np.asarray(conf_contig), np.asarray(conf_position, dtype=np.int64)
+        self.conf_strand, self.conf_mod = np.asarray(conf_strand), np.asarray(conf_mod)
+        self.kept = np.asarray(kept)                    # [n_contigs, n_mod_codes] surviving rows
+
+    @classmethod
+    def from_table(cls, table: PileupTable, high):
+        kept = np.zeros((len(table.contig_names), 8), dtype=np.int64)
+        ok = table.mod_type >= 0
+        np.add.at(kept, (table.contig[ok], table.mod_type[ok]), 1)
+        conf = (table.fraction_mod >= high) & ok
+        return cls(table.contig_names, table.contig[conf], table.position[conf], table.strand[conf], table.mod_type[conf], kept)
+
+    @classmethod
+    def merge(cls, parts):
+        """Union of per-rank results over disjoint contig sets, re-indexed by contig name (sorted)."""
+        names = sorted({n for p in parts for n in p.contig_names})
+        idx = {n: i for i, n in enumerate(names)}
+        kept = np.zeros((len(names), 8), dtype=np.int64)
+        cc, cp, cs, cm = [], [], [], []
+        for p in parts:
+            lut = np.array([idx[n] for n in p.contig_names], dtype=np.int64)
+            if len(lut):
+                kept[lut] += p.kept.astype(np.int64)
+            cc.append(lut[p.conf_contig.astype(np.int64)] if len(p.conf_contig) else np.zeros(0, np.int64))
+            cp.append(p.conf_position); cs.append(p.conf_strand); cm.append(p.conf_mod)
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+        return cls(names, cat(cc, np.int64), cat(cp, np.int64), cat(cs, np.uint8), cat(cm, np.int8), kept)
+
+    def positions(self, contig_names, mod_id):
+        """(plus, minus): name -> ascending positions of confident rows, one entry for every listed contig that has
+        at least one surviving row of this mod type (find_motifs_bin.py:629: contigs present in the bin pileup)."""
+        idx = {n: i for i, n in enumerate(self.contig_names)}
+        plus, minus = {}, {}
+        sel_mod = self.conf_mod == mod_id
+        for name in contig_names:
+            i = idx.get(name)
+            if i is None or self.kept[i, mod_id] == 0:
+                continue
+            sel = sel_mod & (self.conf_contig == i)
+            pos, st = self.conf_position[sel], self.conf_strand[sel]
+            plus[name] = np.sort(pos[st == ord("+")])
+            minus[name] = np.sort(pos[st == ord("-")])
+        return plus, minus
 
 
-def discover(cfg: ProcessorConfig, table: PileupTable, scorer: LockstepScorer, rank=0, bgzip_order=False):
-    """Run every (bin, mod type) task of the data set.  ``table``: the post-filter pileup (all rows; every rank
-    holds it for window extraction); ``scorer``: see ``engine_scorer``.  Returns (list of MotifRow, scorer) —
-    identical on every rank."""
+def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepScorer, rank=0, bgzip_order=False):
+    """Run every (bin, mod type) task of the data set.  ``filtered``: see FilteredPileup (identical on every rank);
+    ``scorer``: see ``engine_scorer``.  Returns (list of MotifRow, scorer) — identical on every rank."""
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)
-    name_to_id = {n: i for i, n in enumerate(table.contig_names)}
     tasks = {}
     out_dir = cfg.output_dir
     # task order and seeding follow the reference: plain pileup = one task per (bin, mod type), each seeded afresh
     # (find_motifs_bin.py:152-171); bgzip = one task per bin, seeded once, mod types in constants order (:219-222, 248)
     for bin_name in bins:
-        ids = [name_to_id[c] for c in bins[bin_name] if c in name_to_id]
         if bgzip_order:
             random.seed(cfg.seed)
         for mt_id, mod_type in enumerate(MOD_TYPES):
-            sub = table.take((table.mod_type == mt_id) & np.isin(table.contig, ids))
-            if len(sub) == 0:
+            plus, minus = filtered.positions(bins[bin_name], mt_id)
+            if not plus and not minus:
                 continue
             if not bgzip_order:
                 random.seed(cfg.seed)
-            plus, minus = confident_positions(sub, ids, cfg.methylation_threshold_high)
             windows = extract_windows(cfg.assembly, plus, minus, mod_type, cfg.padding)
             if windows is None:
                 log.info(f"[{bin_name} {mod_type}] No methylation sequences found")

@@ -19,7 +19,8 @@ import numpy as np
 
 from . import fasta, pileup as pileup_mod, postprocess
 from .argparser import __version__, create_parser
-from .find_motifs_bin import ProcessorConfig, discover, engine_scorer
+from .find_motifs_bin import FilteredPileup, ProcessorConfig, discover, engine_scorer
+from .motif import MOD_TYPE_TO_CANONICAL
 from .shard import assign_contigs
 
 HEADER = "\t".join(postprocess.HEADER) + "\n"
@@ -84,40 +85,51 @@ def find_motifs_bin(args):
     if bgzip and not os.path.exists(cfg.pileup_path + ".tbi"):
         raise FileNotFoundError(f"Tabix index for {cfg.pileup_path} not found.")     # find_motifs_bin.py:383-384
     t0 = time.perf_counter()
-    table = pileup_mod.load_pileup(cfg.pileup_path)
-    table = pileup_mod.prefilter(table)
-    if len(table) == 0:
-        log.info("No pileup data after filtering, skipping")
-        return None
-    # inner join with contig -> bin (find_motifs_bin.py:416)
-    in_bin = np.array([n in cfg.bin_contig for n in table.contig_names], dtype=bool)
-    table = table.take(in_bin[table.contig])
-    log.info(f"pileup: {len(table):,} rows after filters ({time.perf_counter() - t0:.1f}s)")
+    table = pileup_mod.load_pileup(cfg.pileup_path)                  # native reader, raw rows
+    log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s)")
 
-    # engine: this rank's contigs (all contigs that belong to a bin), sharded by length over the ranks
+    # engine: this rank's contigs (all contigs that belong to a bin), sharded over the ranks
     names = [c for c in cfg.bin_contig if c in assembly]
     parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
     mine = [names[i] for i in parts[rank]]
     eng = ScanEngine(device)
     all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
     eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+    # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
+    # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
     local_id = {c: i for i, c in enumerate(mine)}
-    for mt_id, mt in enumerate(pileup_mod.MOD_TYPES):
-        sel = table.mod_type == mt_id
-        if not sel.any():
-            continue
-        sub = table.take(sel)
-        lid = np.array([local_id.get(n, -1) for n in sub.contig_names], dtype=np.int64)[sub.contig]
-        keep = lid >= 0
-        eng.upload_pileup(mt, lid[keep], sub.position[keep], sub.strand[keep], sub.fraction_mod[keep],
-                          low=cfg.methylation_threshold_low, high=cfg.methylation_threshold_high)
-        if (cfg.methylation_threshold_low, cfg.methylation_threshold_high) == (0.3, 0.7):
+    lut = np.array([local_id.get(n, 0xFFFFFFFF) for n in table.contig_names], dtype=np.uint32)
+    if table.mod_type.max(initial=0) >= 8:
+        raise ValueError("more than 8 distinct modification codes in the pileup")
+    if table.position.max(initial=0) >= 2**32:
+        raise ValueError("pileup position beyond 4 Gbp")
+    labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
+    t0 = time.perf_counter()
+    low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
+    res = eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
+                            table.nvalid_cov, labels, low=low, high=high)
+    if (low, high) == (0.3, 0.7):
+        for mt in pileup_mod.MOD_TYPES:
             eng.alias_label((mt, "merge"), mt)
-        else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436)
-            eng.upload_pileup(mt, lid[keep], sub.position[keep], sub.strand[keep], sub.fraction_mod[keep],
-                              low=0.3, high=0.7, label=(mt, "merge"))
-    scorer = engine_scorer(eng, cfg.methylation_threshold_low, cfg.methylation_threshold_high, use_dist=world > 1)
-    rows, scorer = discover(cfg, table, scorer, rank=rank, bgzip_order=bgzip)
+    else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
+        eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
+                          table.nvalid_cov, {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
+                          low=0.3, high=0.7)
+    log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
+    del table
+    part = FilteredPileup(mine, *res["confident"], res["kept"])
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, part)
+        filtered = FilteredPileup.merge(gathered)
+    else:
+        filtered = part
+    if filtered.kept.sum() == 0:
+        log.info("No pileup data after filtering, skipping")
+        eng.close()
+        return None
+    scorer = engine_scorer(eng, low, high, use_dist=world > 1)
+    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip)
     eng.close()
     if not rows:
         log.info("No motifs were identified")
