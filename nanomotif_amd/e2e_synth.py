@@ -1,0 +1,107 @@
+"""End-to-end motif discovery on a synthetic metagenome generated on the device (bench ``--workload e2e``,
+BASELINE cfg 3 / cfg 5 "full candidate-expansion loop"): device generation -> nm_upload_contigs_device ->
+nm_ingest_pileup (device filters) -> host windows -> lock-step greedy search + post-processing -> motif rows."""
+from __future__ import annotations
+
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, synth, synth_device
+from .find_motifs_bin import FilteredPileup, ProcessorConfig, discover, engine_scorer
+from .motif import MOD_TYPE_TO_CANONICAL
+from .pileup import MOD_TYPES
+
+
+def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
+    """Generate (a shard of) ``mg`` on ``device`` and ingest it through the device-side filters.
+    Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
+    t = {}
+    t0 = time.perf_counter()
+    mine = list(range(len(mg.names))) if contigs is None else sorted(int(i) for i in contigs)
+    lengths = np.asarray([int(mg.lengths[i]) for i in mine], dtype=np.uint64)
+    offsets = np.zeros(len(mine) + 1, dtype=np.uint64)
+    np.cumsum(lengths, out=offsets[1:])
+    ascii_all = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=device)
+    local_of = {g: k for k, g in enumerate(mine)}
+    lut = torch.full((len(mg.names),), -1, dtype=torch.int64, device=device)
+    lut[torch.tensor(mine, dtype=torch.int64, device=device)] = torch.arange(len(mine), dtype=torch.int64, device=device)
+    bins = sorted(set(mg.bin_names))
+    by_bin = {b: [] for b in bins}
+    for i in mine:
+        by_bin[mg.bin_names[i]].append(i)
+    cols = {k: [] for k in ("contig", "position", "mod", "strand", "frac", "nvalid")}
+    for b in bins:
+        if not by_bin[b]:
+            continue
+        db = synth_device.generate_bin(mg, b, device, min_cov=-1, contigs=by_bin[b])     # raw rows, unfiltered
+        st = db.starts.tolist()
+        for k, i in enumerate(db.contigs):
+            o = int(offsets[local_of[i]])
+            ascii_all[o:o + int(mg.lengths[i])] = db.ascii_cat[st[k]:st[k] + int(mg.lengths[i])]
+        for mt in mg.spec.mod_types:
+            p = db.pileups[mt]
+            cols["contig"].append(lut[p["contig_id"].to(torch.int64)].to(torch.int32))
+            cols["position"].append(p["position"])
+            cols["mod"].append(torch.full_like(p["strand"], MOD_TYPES.index(mt)).to(torch.int8))
+            cols["strand"].append(p["strand"])
+            cols["frac"].append(p["fraction_mod"])
+            cols["nvalid"].append(p["nvalid"].to(torch.int32))
+    cat = {k: torch.cat(v).contiguous() for k, v in cols.items()}
+    torch.cuda.synchronize(device)
+    t["generate_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    engine.bin_names = bins
+    engine.bin_index = {b: i for i, b in enumerate(bins)}
+    bin_ids = np.array([engine.bin_index[mg.bin_names[i]] for i in mine], dtype=np.uint32)
+    _lib.check(engine.lib.nm_upload_contigs_device(
+        engine.ctx, len(mine), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), bin_ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+        len(bins), C.c_void_p(ascii_all.data_ptr())))
+    engine.contig_names = [mg.names[i] for i in mine]
+    engine.contig_index = {n: i for i, n in enumerate(engine.contig_names)}
+    engine.contig_lengths = lengths.astype(np.int64)
+    engine.contig_bin = bin_ids
+    engine.slot_of_mod = {}
+    slot_of = (C.c_int32 * 8)(*([-1] * 8))
+    canon = (C.c_uint8 * 8)(*([0] * 8))
+    for mt in mg.spec.mod_types:
+        engine.slot_of_mod[mt] = len(engine.slot_of_mod)
+        engine.slot_of_mod[(mt, "merge")] = engine.slot_of_mod[mt]
+        slot_of[MOD_TYPES.index(mt)] = engine.slot_of_mod[mt]
+        canon[MOD_TYPES.index(mt)] = ord(MOD_TYPE_TO_CANONICAL[mt])
+    n = int(cat["position"].numel())
+    n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    _lib.check(engine.lib.nm_ingest_pileup(engine.ctx, n, vp(cat["contig"]), vp(cat["position"]), vp(cat["mod"]), vp(cat["strand"]),
+                                           vp(cat["frac"]), vp(cat["nvalid"]), slot_of, canon, 0.3, 0.7, 1,
+                                           C.byref(n_kept), C.byref(n_conf)))
+    k = n_conf.value
+    cc, cp = np.empty(k, np.uint32), np.empty(k, np.uint32)
+    cs, cm = np.empty(k, np.uint8), np.empty(k, np.int8)
+    kept = np.zeros((len(mine), 8), dtype=np.uint32)
+    _lib.check(engine.lib.nm_ingest_results(engine.ctx, cc.ctypes.data_as(C.POINTER(C.c_uint32)), cp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            cs.ctypes.data_as(C.POINTER(C.c_uint8)), cm.ctypes.data_as(C.POINTER(C.c_int8)), k,
+                                            kept.ctypes.data_as(C.POINTER(C.c_uint32))))
+    t["upload_filter_s"] = time.perf_counter() - t0
+    t["rows_raw"], t["rows_kept"], t["rows_confident"] = n, int(n_kept.value), int(k)
+    t0 = time.perf_counter()
+    host_ascii = ascii_all.cpu().numpy()
+    assembly = {mg.names[i]: host_ascii[int(offsets[j]):int(offsets[j + 1])] for j, i in enumerate(mine)}
+    t["assembly_to_host_s"] = time.perf_counter() - t0
+    return assembly, FilteredPileup(engine.contig_names, cc, cp, cs, cm, kept), t
+
+
+def run(mg: synth.SynthMetagenome, engine, device, log=None):
+    """Single-GPU end-to-end run; returns (rows, timings)."""
+    assembly, filtered, t = load_and_filter(engine, mg, device)
+    cfg = ProcessorConfig(assembly=assembly, pileup_path="<synthetic>", bin_contig=dict(zip(mg.names, mg.bin_names)), threads=1,
+                          search_frame_size=40, methylation_threshold_low=0.3, methylation_threshold_high=0.7,
+                          minimum_kl_divergence=0.05, score_threshold=1.5, log_dir=None, seed=1, output_dir=None)
+    t0 = time.perf_counter()
+    scorer = engine_scorer(engine, 0.3, 0.7)
+    rows, scorer = discover(cfg, filtered, scorer)
+    t["search_s"] = time.perf_counter() - t0
+    t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
+    return rows, t
