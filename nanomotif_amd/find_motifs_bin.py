@@ -204,20 +204,29 @@ class FilteredPileup:
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
         return cls(names, cat(cc, np.int64), cat(cp, np.int64), cat(cs, np.uint8), cat(cm, np.int8), kept)
 
+    def _index(self):
+        """Confident rows sorted by (mod code, contig, strand, position) + run boundaries, built once."""
+        if getattr(self, "_order", None) is None:
+            minus = (self.conf_strand == ord("-")).astype(np.int64)
+            key = (self.conf_mod.astype(np.int64) * len(self.contig_names) + self.conf_contig.astype(np.int64)) * 2 + minus
+            order = np.lexsort((self.conf_position, key))
+            self._order, self._key = order, key[order]
+            self._name_index = {n: i for i, n in enumerate(self.contig_names)}
+        return self._order, self._key
+
     def positions(self, contig_names, mod_id):
         """(plus, minus): name -> ascending positions of confident rows, one entry for every listed contig that has
         at least one surviving row of this mod type (find_motifs_bin.py:629: contigs present in the bin pileup)."""
-        idx = {n: i for i, n in enumerate(self.contig_names)}
+        order, key = self._index()
         plus, minus = {}, {}
-        sel_mod = self.conf_mod == mod_id
         for name in contig_names:
-            i = idx.get(name)
+            i = self._name_index.get(name)
             if i is None or self.kept[i, mod_id] == 0:
                 continue
-            sel = sel_mod & (self.conf_contig == i)
-            pos, st = self.conf_position[sel], self.conf_strand[sel]
-            plus[name] = np.sort(pos[st == ord("+")])
-            minus[name] = np.sort(pos[st == ord("-")])
+            k0 = (mod_id * len(self.contig_names) + i) * 2
+            a, b, c = np.searchsorted(key, [k0, k0 + 1, k0 + 2])
+            plus[name] = self.conf_position[order[a:b]]
+            minus[name] = self.conf_position[order[b:c]]
         return plus, minus
 
 

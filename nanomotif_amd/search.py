@@ -76,10 +76,21 @@ def letter_pssm(windows_ascii: np.ndarray) -> np.ndarray:
     return np.array([(windows_ascii == ord(b)).sum(axis=0) / n for b in BASES])
 
 
+_LANES = np.zeros(16, dtype=np.uint64)           # base set -> one 16-bit counter lane per PSSM row (A, T, G, C)
+for _m in range(16):
+    _LANES[_m] = sum(((_m & b) != 0) << (16 * k) for k, b in enumerate(ROW_BITS))
+
+
 def sets_pssm(sets: np.ndarray) -> np.ndarray:
-    """seq.py:526-537 on bit sets: N windows count for all four rows."""
+    """seq.py:526-537 on bit sets: N windows count for all four rows.  One pass: every set is mapped to four 16-bit
+    counter lanes of a uint64 and the rows are summed in slabs of < 65536 windows (integer counts, exact)."""
     n = sets.shape[0]
-    return np.array([((sets & b) != 0).sum(axis=0) / n for b in ROW_BITS])
+    counts = np.zeros((4, sets.shape[1]), dtype=np.int64)
+    for lo in range(0, n, 65535):
+        acc = _LANES[sets[lo:lo + 65535]].sum(axis=0, dtype=np.uint64)
+        for k in range(4):
+            counts[k] += ((acc >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.int64)
+    return counts / n
 
 
 def motif_sets(motif: Motif) -> np.ndarray:

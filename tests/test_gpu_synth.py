@@ -63,3 +63,20 @@ def test_engine_loaded_from_device_matches_host_upload():
         e.close()
     assert np.array_equal(tot, ra)
     a.close(); b.close()
+
+
+def test_end_to_end_synthetic_run_matches_oracle_pipeline():
+    """Device generation -> device filters -> lock-step search -> rows, against the CPU oracle's full pipeline."""
+    import torch
+    from helpers import oracle_pipeline
+    from nanomotif_amd import e2e_synth, postprocess
+    from nanomotif_amd.engine import ScanEngine
+    spec = synth.SynthSpec(n_contigs=6, total_bp=700_000, n_bins=2, mod_types=("a", "m"), seed=91, min_contig_bp=50_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m"), ("ACCCA", 4, "a")))
+    mg = synth.make_metagenome(spec)
+    eng = ScanEngine(0)
+    rows, t = e2e_synth.run(mg, eng, torch.device("cuda:0"))
+    eng.close()
+    rows = [r for r in rows if r.n_mod + r.n_nomod >= 50]
+    assert postprocess.format_bin_motifs(rows) == oracle_pipeline(mg)
+    assert t["rows_raw"] == 700_000 and t["rows_kept"] < t["rows_raw"] and t["rounds"] < t["candidates"]
