@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--workload", choices=["cfg5", "greedy", "e2e"], default="cfg5")
     ap.add_argument("--per-group", type=int, default=2, help="greedy workload: children per (bin, mod type)")
     ap.add_argument("--cpu-bins", type=int, default=-1, help="bins in the CPU-baseline sample (-1: two per worker; 0: skip)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (debug: several ranks on one GPU)")
+    ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: min(32, host cores))")
     args = ap.parse_args()
 
@@ -146,10 +148,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         log(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if args.force_device >= 0:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     spec = synth.SynthSpec(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=1)
     spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=1)
@@ -163,7 +170,12 @@ def main():
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
     rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if world == 1 else mine, progress=log)
-    eng.use_stream(torch.cuda.current_stream(device).cuda_stream)
+    # one explicit side stream carries the engine's launches AND the collectives (the legacy default stream has the
+    # handle 0, which nm_set_stream reads as "use the ctx's own stream": never hand it that)
+    side = torch.cuda.Stream(device)
+    assert side.cuda_stream != 0
+    eng.use_stream(side.cuda_stream)
+    torch.cuda.set_stream(side)
     st = eng.stats()
     log(f"resident: {st['total_bp']:,} bp ({st['padded_bp']:,} padded), rows {rows}, setup {time.perf_counter() - t0:.1f}s")
 
@@ -194,8 +206,12 @@ def main():
         if pending[i] is not None:
             pending[i].wait()                               # table i is free again (its all-reduce finished)
         eng.score_into_device(batch, counts[i].data_ptr())
-        if world > 1:
+        if world > 1 and args.dist_backend == "nccl":
             pending[i] = dist.all_reduce(counts[i], async_op=True)   # RCCL sum over xGMI
+        elif world > 1:                                              # debug path: reduce through the host
+            host = counts[i].cpu()
+            dist.all_reduce(host)
+            counts[i].copy_(host)
 
     def drain():
         for i in (0, 1):
@@ -222,7 +238,8 @@ def main():
     kernel_ms_total, n_launch = eng.timing_total()
     eng.timing_reset(False)
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms_total / max(n_launch, 1)], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, kernel_ms_total / max(n_launch, 1)], dtype=torch.float64,
+                         device=device if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
     else:
@@ -258,6 +275,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
+            "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
+                                int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],
         }
         if valu_insts:
             # second roofline: the kernel is integer-VALU-issue bound once a (bin, mod type) carries more than ~2
