@@ -726,13 +726,15 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     bucket.assign((size_t)NM_MAX_MOD_SLOTS * n_bins + 1, 0);
     bool any_wide = false, all_compact = true;
     uint32_t n_prog = 0;
-    uint64_t mask_bytes = 0;
+    uint64_t mask_bytes = 0, mask_lo = ~0ull;   // byte range of cand_masks the resident candidates reference
     bool slot_used[NM_MAX_MOD_SLOTS] = {};
     for (uint32_t k = 0; k < n_cand; ++k) {
-        const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k], len = cand_len[k], mp = cand_modpos[k];
+        const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k];
         if (slot >= NM_MAX_MOD_SLOTS || !c->slots[slot].present)
             return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, slot);
         if (bin >= n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, bin, n_bins);
+        if (c->bin_nchunks[bin] == 0) continue;         // not resident here: the rank that holds the bin validates it
+        const uint32_t len = cand_len[k], mp = cand_modpos[k];
         if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "candidate %u: motif length %u outside 1..%d", k, len, NM_MAX_MOTIF_LEN);
         if (mp >= len) return fail(NM_EINVAL, "candidate %u: mod_position %u outside motif of length %u", k, mp, len);
         const uint8_t *m = cand_masks + cand_mask_offset[k];
@@ -744,8 +746,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         }
         if (any_zero) return fail(NM_EINVAL, "candidate %u: empty base set in the motif", k);
         if (all_and == 15u) return fail(NM_EINVAL, "candidate %u: motif has no specified position", k);
+        mask_lo = std::min<uint64_t>(mask_lo, cand_mask_offset[k]);
         mask_bytes = std::max<uint64_t>(mask_bytes, (uint64_t)cand_mask_offset[k] + len);
-        if (c->bin_nchunks[bin] == 0) continue;
         // offsets relative to the modified base span [-mp, len-1-mp] forward and the mirror image in reverse
         if (mp > 31 || len - 1 - mp > 31) any_wide = true;
         const uint32_t can_mask = c->slots[slot].canonical == 'A' ? NM_BASE_A : NM_BASE_C;
@@ -754,6 +756,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         slot_used[slot] = true;
         n_prog += 1;
     }
+    if (n_prog == 0) { mask_lo = 0; mask_bytes = 0; }
     uint32_t active[NM_MAX_MOD_SLOTS], n_active = 0;
     int slot_to_active[NM_MAX_MOD_SLOTS];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) {
@@ -765,7 +768,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const size_t rec_bytes = (size_t)n_prog * sizeof(CandRec);
     const size_t off_orig = (rec_bytes + 15) & ~(size_t)15;
     const size_t off_masks = (off_orig + (size_t)n_prog * 4 + 15) & ~(size_t)15;
-    const size_t off_range = (off_masks + mask_bytes + 15) & ~(size_t)15;
+    const size_t off_range = (off_masks + (mask_bytes - mask_lo) + 15) & ~(size_t)15;
     const size_t range_bytes = (size_t)std::max(n_active, 1u) * n_bins * sizeof(uint2);
     const size_t total = off_range + range_bytes;
     int rc = ensure_stage(c, total);
@@ -774,7 +777,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
     uint2 *h_range = reinterpret_cast<uint2 *>(hs + off_range);
-    memcpy(hs + off_masks, cand_masks, mask_bytes);
+    memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
     memset(h_range, 0, range_bytes);
     // exclusive prefix over the buckets -> first sorted index of each (slot, bin); stable within a bucket
     for (size_t i = 1; i < bucket.size(); ++i) bucket[i] += bucket[i - 1];
@@ -789,7 +792,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k];
         if (c->bin_nchunks[bin] == 0) continue;
         const uint32_t at = bucket[(size_t)slot * n_bins + bin]++;
-        h_rec[at] = CandRec{cand_mask_offset[k], k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
+        h_rec[at] = CandRec{(uint32_t)(cand_mask_offset[k] - mask_lo), k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
         h_orig[at] = k;
     }
     // device-side program buffer

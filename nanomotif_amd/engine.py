@@ -55,7 +55,11 @@ class ScanEngine:
             pass
 
     def use_stream(self, hip_stream_handle: int | None):
-        """Run engine work on another HIP stream (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        """Run engine work on another HIP stream (e.g. a ``torch.cuda.Stream().cuda_stream``); None restores the
+        engine's own stream.  The legacy default stream (handle 0) cannot be expressed through nm_set_stream —
+        create a side stream and make it torch's current stream instead (see bench.py)."""
+        if hip_stream_handle == 0:
+            raise ValueError("handle 0 is the legacy default stream: pass a side stream's handle, or None")
         _lib.check(self.lib.nm_set_stream(self.ctx, C.c_void_p(hip_stream_handle or 0)))
 
     # ------------------------------------------------------------------ assembly
@@ -175,8 +179,12 @@ class ScanEngine:
         return CandidateBatch(bins, slots, lens, modpos, moff, masks[:used.value])
 
     def _batch_args(self, b: CandidateBatch):
-        return (len(b), _ptr(b.bins, C.c_uint32), _ptr(b.slots, C.c_uint8), _ptr(b.lens, C.c_uint8),
-                _ptr(b.modpos, C.c_uint8), _ptr(b.offsets, C.c_uint32), _ptr(b.masks, C.c_uint8))
+        args = getattr(b, "_args", None)            # the ctypes views are reusable as long as the arrays live
+        if args is None:
+            args = (len(b), _ptr(b.bins, C.c_uint32), _ptr(b.slots, C.c_uint8), _ptr(b.lens, C.c_uint8),
+                    _ptr(b.modpos, C.c_uint8), _ptr(b.offsets, C.c_uint32), _ptr(b.masks, C.c_uint8))
+            b._args = args
+        return args
 
     def score(self, candidates) -> np.ndarray:
         """int64[n, 2] = (n_mod, n_nomod) per candidate — what ``model.update`` receives (find_motifs_bin.py:1320)."""
