@@ -306,7 +306,7 @@ struct Tile {
     static constexpr int NW = T_WORDS + GN + GP;
     uint32_t w[8][NW];
 
-    __device__ __forceinline__ void load(const Planes &s, uint32_t chunk, int lane) {
+    __device__ __forceinline__ void load(const Planes &s, uint32_t chunk, int lane, bool need_v) {
         const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
         uint32_t h[NW], l[NW], v[NW];
         const uint4 h4 = *reinterpret_cast<const uint4 *>(s.H + base);
@@ -317,7 +317,7 @@ struct Tile {
         for (int j = 0; j < GN; ++j) { h[j] = s.H[base - GN + j]; l[j] = s.L[base - GN + j]; }
 #pragma unroll
         for (int j = 0; j < GP; ++j) { h[GN + T_WORDS + j] = s.H[base + T_WORDS + j]; l[GN + T_WORDS + j] = s.L[base + T_WORDS + j]; }
-        if (((cu8p)s.needs_v)[chunk]) {                              // wave-uniform, scalar load
+        if (need_v) {                                                // wave-uniform
             const uint4 v4 = *reinterpret_cast<const uint4 *>(s.V + base);
             v[GN + 0] = v4.x; v[GN + 1] = v4.y; v[GN + 2] = v4.z; v[GN + 3] = v4.w;
 #pragma unroll
@@ -378,11 +378,68 @@ __device__ __forceinline__ void eval_strand(const StrandMasks<GN, GP> &sm, const
     }
 }
 
-// CAN: canonical base of the mod-type slot, 0 = A (reverse strand sites sit on T), 1 = C (reverse on G).
+// The candidates [k0, k0 + nb) of one mod-type slot against the tile this wave holds: match masks, site counts,
+// per-lane counts into LDS rows lds_row0 + k.  CAN: canonical base of the slot, 0 = A (reverse-strand sites sit on T),
+// 1 = C (reverse on G).
+// State words of one slot for this lane's T words: compact = {M, U}, general = {MP, UP, MM, UM}.
+template <bool COMPACT>
+struct StateWords {
+    uint32_t s[COMPACT ? 2 : 4][T_WORDS];
+    __device__ __forceinline__ void load(const StatePlanes &st, size_t base) {
+        const uint32_t *src[4] = {COMPACT ? st.M : st.MP, COMPACT ? st.U : st.UP, st.MM, st.UM};
+#pragma unroll
+        for (int i = 0; i < (COMPACT ? 2 : 4); ++i) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src[i] + base);
+            s[i][0] = v.x; s[i][1] = v.y; s[i][2] = v.z; s[i][3] = v.w;
+        }
+    }
+};
+
 template <int GN, int GP, bool COMPACT, int CAN>
-__device__ __forceinline__ void score_body(const ScoreArgs &a, uint32_t *lds_acc) {
+__device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<GN, GP> &tile, const StateWords<COMPACT> &sw,
+                                                 uint32_t k0, uint32_t nb, uint32_t *lds_acc, uint32_t lds_row0, int lane) {
     constexpr int PF = CAN == 0 ? 0 : 1;   // plane of the canonical base: A or C
     constexpr int PR = CAN == 0 ? 3 : 2;   // plane of its complement:     T or G
+    for (uint32_t k = 0; k < nb; ++k) {
+        cu32p prog = (cu32p)(a.programs + (size_t)(k0 + k) * (2 * StrandMasks<GN, GP>::N));
+        StrandMasks<GN, GP> mf, mr;
+        mf.load(prog);
+        mr.load(prog + StrandMasks<GN, GP>::N);
+        uint32_t accf[T_WORDS], accr[T_WORDS];
+#pragma unroll
+        for (int t = 0; t < T_WORDS; ++t) {
+            // compact batches: every candidate has the canonical literal at its modified position, the host leaves
+            // that constraint out of the program and it becomes the accumulator's initial value
+            accf[t] = COMPACT ? tile.w[PF][t + GN] : 0xFFFFFFFFu;
+            accr[t] = COMPACT ? tile.w[PR][t + GN] : 0xFFFFFFFFu;
+        }
+        eval_strand<GN, GP>(mf, tile, accf);
+        eval_strand<GN, GP>(mr, tile, accr);
+        uint32_t n_mod = 0, n_non = 0;
+#pragma unroll
+        for (int t = 0; t < T_WORDS; ++t) {
+            if (COMPACT) {
+                const uint32_t sites = accf[t] | accr[t];
+                n_mod += __popc(sites & sw.s[0][t]);
+                n_non += __popc(sites & sw.s[1][t]);
+            } else {
+                n_mod += __popc(accf[t] & sw.s[0][t]) + __popc(accr[t] & sw.s[COMPACT ? 0 : 2][t]);
+                n_non += __popc(accf[t] & sw.s[1][t]) + __popc(accr[t] & sw.s[COMPACT ? 1 : 3][t]);
+            }
+        }
+        atomicAdd(&lds_acc[((lds_row0 + k) * 2 + 0) * 64 + lane], n_mod);
+        atomicAdd(&lds_acc[((lds_row0 + k) * 2 + 1) * 64 + lane], n_non);
+    }
+}
+
+// NS = mod-type slots fused into one workgroup: with NS > 1 a tile's sequence planes are loaded and expanded once
+// and serve the candidates of all NS slots (each slot brings its own M / U planes); with NS = 1 the slot comes
+// from blockIdx.y (batches that touch more than two classifications).  A pass handles up to BMAX / NS candidates
+// per slot; LDS rows are [slot j][candidate k].
+template <int GN, int GP, bool COMPACT, int NS>
+__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
+    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
+    constexpr uint32_t H = BMAX / NS;
     // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
     // of segments so candidate programs and counters of one bin stay in one L2.
     const uint32_t nb = gridDim.x;
@@ -393,94 +450,74 @@ __device__ __forceinline__ void score_body(const ScoreArgs &a, uint32_t *lds_acc
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
     sg.y = __builtin_amdgcn_readfirstlane(sg.y);
     sg.z = __builtin_amdgcn_readfirstlane(sg.z);
-    const uint32_t slot_i = blockIdx.y;
-    const uint32_t slot = a.active_slot[slot_i];
-    uint2 range = a.cand_range[(size_t)slot_i * a.n_bins + sg.z];
-    range.x = __builtin_amdgcn_readfirstlane(range.x);
-    range.y = __builtin_amdgcn_readfirstlane(range.y);
-    if (range.y == 0) return;
-    const StatePlanes st = a.st[slot];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 range[NS];
+    uint32_t most = 0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const uint32_t slot_i = NS == 1 ? blockIdx.y : (uint32_t)j;
+        range[j] = a.cand_range[(size_t)slot_i * a.n_bins + sg.z];
+        range[j].x = __builtin_amdgcn_readfirstlane(range[j].x);
+        range[j].y = __builtin_amdgcn_readfirstlane(range[j].y);
+        most = max(most, range[j].y);
+    }
+    if (most == 0) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: chunk indices stay scalar
+    // per-slot facts are read from the kernel arguments once, not per chunk
+    StatePlanes stp[NS];
+    bool is_c[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const uint32_t slot = a.active_slot[NS == 1 ? blockIdx.y : (uint32_t)j];
+        stp[j] = a.st[slot];
+        is_c[j] = a.slot_is_c[slot] != 0;
+    }
 
-    for (uint32_t pass0 = 0; pass0 < range.y; pass0 += BMAX) {
-        const uint32_t nbatch = min((uint32_t)BMAX, range.y - pass0);
-        for (uint32_t i = threadIdx.x; i < nbatch * 128; i += 256) lds_acc[i] = 0;
+    for (uint32_t pass0 = 0; pass0 < most; pass0 += H) {
+        for (uint32_t i = threadIdx.x; i < BMAX * 128; i += 256) lds_acc[i] = 0;
         __syncthreads();
         for (uint32_t ck = wave; ck < sg.y; ck += 4) {
             const uint32_t chunk = sg.x + ck;
-            Tile<GN, GP> tile;
-            tile.load(a.seq, chunk, lane);
+            const bool need_v = ((cu8p)a.seq.needs_v)[chunk] != 0;          // scalar load, issued first
             const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
-            uint32_t s0[T_WORDS], s1[T_WORDS], s2[T_WORDS], s3[T_WORDS];
-            if (COMPACT) {
-                const uint4 m4 = *reinterpret_cast<const uint4 *>(st.M + base);
-                const uint4 u4 = *reinterpret_cast<const uint4 *>(st.U + base);
-                s0[0] = m4.x; s0[1] = m4.y; s0[2] = m4.z; s0[3] = m4.w;
-                s1[0] = u4.x; s1[1] = u4.y; s1[2] = u4.z; s1[3] = u4.w;
-            } else {
-                const uint4 a4 = *reinterpret_cast<const uint4 *>(st.MP + base);
-                const uint4 b4 = *reinterpret_cast<const uint4 *>(st.UP + base);
-                const uint4 c4 = *reinterpret_cast<const uint4 *>(st.MM + base);
-                const uint4 d4 = *reinterpret_cast<const uint4 *>(st.UM + base);
-                s0[0] = a4.x; s0[1] = a4.y; s0[2] = a4.z; s0[3] = a4.w;
-                s1[0] = b4.x; s1[1] = b4.y; s1[2] = b4.z; s1[3] = b4.w;
-                s2[0] = c4.x; s2[1] = c4.y; s2[2] = c4.z; s2[3] = c4.w;
-                s3[0] = d4.x; s3[1] = d4.y; s3[2] = d4.z; s3[3] = d4.w;
-            }
-            for (uint32_t k = 0; k < nbatch; ++k) {
-                cu32p prog = (cu32p)(a.programs + (size_t)(range.x + pass0 + k) * (2 * StrandMasks<GN, GP>::N));
-                StrandMasks<GN, GP> mf, mr;
-                mf.load(prog);
-                mr.load(prog + StrandMasks<GN, GP>::N);
-                uint32_t accf[T_WORDS], accr[T_WORDS];
+            // all global loads of this chunk are issued back to back (state planes first, then the sequence planes)
+            // so that one memory latency covers them; the expansion into the eight derived planes follows
+            StateWords<COMPACT> sw[NS];
 #pragma unroll
-                for (int t = 0; t < T_WORDS; ++t) {
-                    // compact batches: every candidate has the canonical literal at its modified position, the host
-                    // leaves that constraint out of the program and it becomes the accumulator's initial value
-                    accf[t] = COMPACT ? tile.w[PF][t + GN] : 0xFFFFFFFFu;
-                    accr[t] = COMPACT ? tile.w[PR][t + GN] : 0xFFFFFFFFu;
-                }
-                eval_strand<GN, GP>(mf, tile, accf);
-                eval_strand<GN, GP>(mr, tile, accr);
-                uint32_t n_mod = 0, n_non = 0;
+            for (int j = 0; j < NS; ++j) sw[j].load(stp[j], base);          // unconditional: no control flow between loads
+            Tile<GN, GP> tile;
+            tile.load(a.seq, chunk, lane, need_v);
 #pragma unroll
-                for (int t = 0; t < T_WORDS; ++t) {
-                    if (COMPACT) {
-                        const uint32_t sites = accf[t] | accr[t];
-                        n_mod += __popc(sites & s0[t]);
-                        n_non += __popc(sites & s1[t]);
-                    } else {
-                        n_mod += __popc(accf[t] & s0[t]) + __popc(accr[t] & s2[t]);
-                        n_non += __popc(accf[t] & s1[t]) + __popc(accr[t] & s3[t]);
-                    }
-                }
-                atomicAdd(&lds_acc[(k * 2 + 0) * 64 + lane], n_mod);
-                atomicAdd(&lds_acc[(k * 2 + 1) * 64 + lane], n_non);
+            for (int j = 0; j < NS; ++j) {
+                if (range[j].y <= pass0) continue;                       // wave-uniform
+                const uint32_t nbj = min(H, range[j].y - pass0);
+                if (COMPACT && is_c[j])
+                    score_candidates<GN, GP, COMPACT, 1>(a, tile, sw[j], range[j].x + pass0, nbj, lds_acc, j * H, lane);
+                else
+                    score_candidates<GN, GP, COMPACT, 0>(a, tile, sw[j], range[j].x + pass0, nbj, lds_acc, j * H, lane);
             }
         }
         __syncthreads();
         // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
-        for (uint32_t idx = threadIdx.x; idx < nbatch * 8; idx += 256) {
-            const uint32_t i = idx >> 2, q = idx & 3;
+        for (uint32_t idx = threadIdx.x; idx < BMAX * 8; idx += 256) {
+            const uint32_t i = idx >> 2, q = idx & 3;               // i = counter row: (j * H + k) * 2 + which
+            const uint32_t j = (i >> 1) / H, k = (i >> 1) % H;
             uint32_t s = 0;
 #pragma unroll 4
-            for (int j = 0; j < 16; ++j) s += lds_acc[i * 64 + q * 16 + j];
+            for (int jj = 0; jj < 16; ++jj) s += lds_acc[i * 64 + q * 16 + jj];
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             if (q == 0 && s) {
-                const uint32_t orig = a.orig_index[range.x + pass0 + (i >> 1)];
+                uint2 rj = range[0];
+#pragma unroll
+                for (int t = 1; t < NS; ++t)
+                    if (j == (uint32_t)t) rj = range[t];
+                const uint32_t orig = a.orig_index[rj.x + pass0 + k];
                 atomicAdd(a.out + (size_t)orig * 2 + (i & 1), (unsigned long long)s);
             }
         }
         __syncthreads();
     }
-}
-
-template <int GN, int GP, bool COMPACT>
-__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
-    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
-    if (COMPACT && a.slot_is_c[a.active_slot[blockIdx.y]]) score_body<GN, GP, COMPACT, 1>(a, lds_acc);
-    else score_body<GN, GP, COMPACT, 0>(a, lds_acc);
 }
 
 // One candidate record as the host stages it (sorted by mod-type slot, then bin).
@@ -539,7 +576,7 @@ __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, u
     if (ck >= n_chunks) return;
     const uint32_t chunk = chunk0 + ck;
     Tile<GN, GP> tile;
-    tile.load(seq, chunk, lane);
+    tile.load(seq, chunk, lane, seq.needs_v[chunk] != 0);
     uint32_t acc[T_WORDS];
 #pragma unroll
     for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
@@ -708,8 +745,11 @@ void add_modpos_constraint(uint32_t *prog, uint32_t modpos_mask) {
 }
 
 template <int GN, int GP, bool COMPACT>
-void launch_score(const ScoreArgs &a, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT>), grid, dim3(256), 0, s, a);
+void launch_score(const ScoreArgs &a, uint32_t gx, uint32_t n_active, bool fuse, hipStream_t s) {
+    // two classifications (the usual 6mA + 5mC batch) share one pass over the sequence planes when the batch is
+    // light (HBM-bound: a greedy round); heavy batches are VALU-bound and run better as twice as many workgroups
+    if (n_active == 2 && fuse) hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT, 2>), dim3(gx, 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT, 1>), dim3(gx, std::max(n_active, 1u)), dim3(256), 0, s, a);
 }
 
 int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
@@ -779,13 +819,17 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     uint2 *h_range = reinterpret_cast<uint2 *>(hs + off_range);
     memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
     memset(h_range, 0, range_bytes);
+    uint32_t n_groups = 0;
     // exclusive prefix over the buckets -> first sorted index of each (slot, bin); stable within a bucket
     for (size_t i = 1; i < bucket.size(); ++i) bucket[i] += bucket[i - 1];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) {
         if (slot_to_active[sl] < 0) continue;
         for (uint32_t b = 0; b < n_bins; ++b) {
             const uint32_t lo = bucket[(size_t)sl * n_bins + b], hi = bucket[(size_t)sl * n_bins + b + 1];
-            if (hi > lo) h_range[(size_t)slot_to_active[sl] * n_bins + b] = make_uint2(lo, hi - lo);
+            if (hi > lo) {
+                h_range[(size_t)slot_to_active[sl] * n_bins + b] = make_uint2(lo, hi - lo);
+                n_groups += 1;
+            }
         }
     }
     for (uint32_t k = 0; k < n_cand; ++k) {
@@ -846,7 +890,9 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
-    dim3 grid(gx, std::max(n_active, 1u));
+    // measured crossover (profiles/): up to ~6 candidates per (slot, bin) group the launch is HBM-bound
+    const bool fuse = n_active == 2 && (uint64_t)n_prog <= 6ull * n_groups;
+
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->ev_collect) {
         if (c->ev_used == c->ev_pool.size()) {
@@ -862,17 +908,17 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
     if (n_prog == 0) { /* nothing resident for this batch: the zeroed table is the answer */ }
-    else if (!any_wide && all_compact) launch_score<1, 1, true>(a, grid, c->stream);
-    else if (!any_wide) launch_score<1, 1, false>(a, grid, c->stream);
-    else if (all_compact) launch_score<2, 2, true>(a, grid, c->stream);
-    else launch_score<2, 2, false>(a, grid, c->stream);
+    else if (!any_wide && all_compact) launch_score<1, 1, true>(a, gx, n_active, fuse, c->stream);
+    else if (!any_wide) launch_score<1, 1, false>(a, gx, n_active, fuse, c->stream);
+    else if (all_compact) launch_score<2, 2, true>(a, gx, n_active, fuse, c->stream);
+    else launch_score<2, 2, false>(a, gx, n_active, fuse, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, c->stream));
     rc = release_stage(c);
     if (rc) return rc;
     c->timed = !c->ev_collect;
     c->launches += 1;
-    c->last_wgs = (uint64_t)gx * n_active;
+    c->last_wgs = (uint64_t)gx * (fuse ? 1 : std::max(n_active, 1u));
     c->last_compact = all_compact ? n_prog : 0;
     c->last_general = all_compact ? 0 : n_prog;
     if (h_out) {
