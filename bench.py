@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--cpu-bins", type=int, default=-1, help="bins in the CPU-baseline sample (-1: two per worker; 0: skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (debug: several ranks on one GPU)")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
+    ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: min(32, host cores))")
     args = ap.parse_args()
 
@@ -246,6 +247,35 @@ def main():
         kernel_ms = kernel_ms_total / max(n_launch, 1)
     final = counts[(step_no[0] - 1) & 1].cpu().numpy()
 
+    # ---- the same engine in its HBM-bound regime: one lock-step greedy round (2 sibling children per (bin, mod type),
+    # the shape MotifSearcher.run submits), kernel time from HIP events; reported next to the main roofline
+    hbm_round = None
+    if args.workload == "cfg5" and args.hbm_round_steps > 0:
+        g_cands = build_candidates(mg, "greedy", 0, 2)
+        g_batch = eng.make_batch(g_cands)
+        g_counts = torch.zeros((len(g_cands), 2), dtype=torch.int64, device=device)
+        for _ in range(3):
+            eng.score_into_device(g_batch, g_counts.data_ptr())
+        torch.cuda.synchronize(device)
+        eng.timing_reset(True)
+        for _ in range(args.hbm_round_steps):
+            eng.score_into_device(g_batch, g_counts.data_ptr())
+        torch.cuda.synchronize(device)
+        g_ms, g_n = eng.timing_total()
+        eng.timing_reset(False)
+        g_ms /= max(g_n, 1)
+        g_groups = {(b, mt) for _, mt, b in g_cands}
+        g_bytes = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in g_groups) + 16 * len(g_cands)
+        if world > 1:
+            tt = torch.tensor([g_ms], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            g_ms = float(tt[0])
+        hbm_round = {"workload": f"greedy round: {len(g_cands)} candidates = 2 sibling children per (bin, mod type)",
+                     "bound": "hbm", "kernel_ms": g_ms, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": g_bytes, "launches": g_n,
+                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3) / max(world, 1) * world}
+
     result = None
     traffic, traffic_src, valu_insts = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
@@ -278,6 +308,8 @@ def main():
             "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
                                 int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],
         }
+        if hbm_round:
+            result["roofline_hbm_bound_round"] = hbm_round
         if valu_insts:
             # second roofline: the kernel is integer-VALU-issue bound once a (bin, mod type) carries more than ~2
             # candidates; instruction count from rocprofv3 (SQ_INSTS_VALU, profiles/), peak from tools/valu_peak.hip
