@@ -142,6 +142,27 @@ int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, c
                     uint64_t masks_capacity, uint64_t *masks_used);
 
 /*
+ * Window engine — the per-expansion work of the greedy search on the device.  The windows around the confidently
+ * methylated sites of one (bin, mod type) search (find_motifs_bin.py:635-677) are kept as bit planes over windows;
+ * a request then replaces DNAarray.filter_sequence_matches (seq.py:499-524) + DNAarray.pssm (seq.py:526-537):
+ *   nm_win_add_task  windows as base-set bytes [n][width] (bit0 A, bit1 C, bit2 G, bit3 T, 15 = N), width <= 64;
+ *                    returns the task id.  nm_win_clear drops all tasks.
+ *   nm_win_batch     n_req requests (task, kind, motif as one base-set byte per column in a 64-byte slot):
+ *                    kind 0: out = { n_active, 0, counts[4][64] } — number of not-yet-removed windows that match the
+ *                            motif and, per column, how many of them carry A / T / G / C (rows in the reference's
+ *                            A, T, G, C order; an N window counts for all four) => pssm = counts / n_active;
+ *                    kind 1: remove the matching windows (filter_sequence_matches(keep_matches=False),
+ *                            find_motifs_bin.py:803); out = { alive before, alive after, ... }.
+ *                    out is int32[n_req][2 + 4*64].  Requests of one batch must not mix kinds on one task.
+ */
+#define NM_WIN_MAX_WIDTH 64
+#define NM_WIN_OUT_STRIDE (2 + 4 * NM_WIN_MAX_WIDTH)
+int nm_win_clear(nm_ctx *ctx);
+int nm_win_add_task(nm_ctx *ctx, uint32_t n_windows, uint32_t width, const uint8_t *sets, uint32_t *task_id);
+int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind,
+                 const uint8_t *req_sets, int32_t *out);
+
+/*
  * Hit positions of one candidate on one contig — the four arrays motif_model_contig returns with
  * save_motif_positions=True (find_motifs_bin.py:1322-1329), ascending.  which: 0 = index_meth_fwd,
  * 1 = index_nonmeth_fwd, 2 = index_meth_rev, 3 = index_nonmeth_rev.  Writes at most `capacity` positions to

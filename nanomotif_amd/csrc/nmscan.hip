@@ -291,6 +291,107 @@ __global__ void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__re
     if (v && h == want_h && l == sl.can_l[slot]) atomicOr((meth ? pl[0] : pl[1]) + w, bit);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Window engine: the methylated-site windows of every (bin, mod type) search stay on the device as bit planes over
+// WINDOWS (bit i of a plane = window i), so that the per-expansion work of the search — filter_sequence_matches
+// (seq.py:499-524) + DNAarray.pssm (seq.py:526-537) — is the same AND / popcount pattern as the genome scan.
+//   per task: plane1[col][b] = windows whose base at column col is exactly b (b in A, C, G, T),
+//             planeN[col]   = windows with N there (one-hot 1111: counts for all four rows, matches only '.'),
+//             alive         = windows not yet removed by an accepted / dead-end motif (find_motifs_bin.py:801-806).
+// ------------------------------------------------------------------------------------------------------
+constexpr int WIN_MAX_W = 64;                // window width limit (reference default 41)
+
+struct WinTask {
+    uint64_t plane_off;     // into the plane pool (words): [col][5][nw]
+    uint64_t alive_off;     // into the alive pool (words): [nw]
+    uint32_t n, nw, width, pad;
+};
+
+// windows given as base-set bytes [n][width] (bit0 A, bit1 C, bit2 G, bit3 T, 15 = N): one thread per (word, col)
+__global__ void win_pack_kernel(WinTask t, const uint8_t *__restrict__ sets, uint32_t *__restrict__ planes,
+                                uint32_t *__restrict__ alive) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;     // word of 32 windows
+    const uint32_t col = blockIdx.y;
+    if (w >= t.nw) return;
+    uint32_t pa = 0, pc = 0, pg = 0, pt = 0, pn = 0, al = 0;
+    for (uint32_t b = 0; b < 32; ++b) {
+        const uint64_t i = (uint64_t)w * 32 + b;
+        if (i >= t.n) break;
+        const uint32_t m = sets[i * t.width + col];
+        al |= 1u << b;
+        if (m == 1) pa |= 1u << b;
+        else if (m == 2) pc |= 1u << b;
+        else if (m == 4) pg |= 1u << b;
+        else if (m == 8) pt |= 1u << b;
+        else pn |= 1u << b;
+    }
+    uint32_t *p = planes + t.plane_off + (uint64_t)col * 5 * t.nw + w;
+    p[0] = pa; p[(uint64_t)t.nw] = pc; p[2ull * t.nw] = pg; p[3ull * t.nw] = pt; p[4ull * t.nw] = pn;
+    if (col == 0) alive[t.alive_off + w] = al;
+}
+
+// One request = (task, motif as one base-set byte per column, kind).  kind 0: PSSM counts of the alive windows that
+// match the motif (every window base must be inside the motif's set at that column; an N window only matches '.');
+// kind 1: remove the matching windows from alive and report alive counts before / after.
+// out[req] = { n_active | before, 0 | after, counts[4 rows A,T,G,C][width] }  (int32)
+__global__ __launch_bounds__(256) void win_request_kernel(const WinTask *__restrict__ tasks, uint32_t n_req,
+                                                          const uint32_t *__restrict__ req_task,
+                                                          const uint8_t *__restrict__ req_kind,
+                                                          const uint8_t *__restrict__ req_sets /*[n_req][WIN_MAX_W]*/,
+                                                          const uint32_t *__restrict__ planes, uint32_t *alive,
+                                                          int *__restrict__ out, uint32_t out_stride) {
+    __shared__ int cnt[2 + 4 * WIN_MAX_W];
+    __shared__ uint8_t mset[WIN_MAX_W];
+    const uint32_t r = blockIdx.x;
+    const WinTask t = tasks[req_task[r]];
+    const uint32_t kind = req_kind[r];
+    for (uint32_t i = threadIdx.x; i < 2 + 4 * WIN_MAX_W; i += blockDim.x) cnt[i] = 0;
+    if (threadIdx.x < WIN_MAX_W) mset[threadIdx.x] = threadIdx.x < t.width ? req_sets[(size_t)r * WIN_MAX_W + threadIdx.x] : 15;
+    __syncthreads();
+    const uint32_t *pl = planes + t.plane_off;
+    uint32_t *al = alive + t.alive_off;
+    // word slices of this request are spread over gridDim.y workgroups
+    for (uint32_t w = blockIdx.y * blockDim.x + threadIdx.x; w < t.nw; w += gridDim.y * blockDim.x) {
+        uint32_t match = 0xFFFFFFFFu;
+        for (uint32_t col = 0; col < t.width; ++col) {
+            const uint32_t m = mset[col];
+            if (m == 15) continue;
+            const uint32_t *p = pl + (uint64_t)col * 5 * t.nw + w;
+            uint32_t ok = 0;
+            if (m & 1) ok |= p[0];
+            if (m & 2) ok |= p[(uint64_t)t.nw];
+            if (m & 4) ok |= p[2ull * t.nw];
+            if (m & 8) ok |= p[3ull * t.nw];
+            match &= ok;
+        }
+        const uint32_t a = al[w];
+        if (kind == 1) {
+            const uint32_t na = a & ~match;
+            al[w] = na;
+            atomicAdd(&cnt[0], __popc(a));
+            atomicAdd(&cnt[1], __popc(na));
+            continue;
+        }
+        const uint32_t active = a & match;
+        if (!active) continue;
+        atomicAdd(&cnt[0], __popc(active));
+        for (uint32_t col = 0; col < t.width; ++col) {
+            const uint32_t *p = pl + (uint64_t)col * 5 * t.nw + w;
+            const int n_any = __popc(active & p[4ull * t.nw]);
+            const int ca = __popc(active & p[0]) + n_any, cc = __popc(active & p[(uint64_t)t.nw]) + n_any;
+            const int cg = __popc(active & p[2ull * t.nw]) + n_any, ct = __popc(active & p[3ull * t.nw]) + n_any;
+            if (ca) atomicAdd(&cnt[2 + 0 * WIN_MAX_W + col], ca);      // row order A, T, G, C (constants.py:1)
+            if (ct) atomicAdd(&cnt[2 + 1 * WIN_MAX_W + col], ct);
+            if (cg) atomicAdd(&cnt[2 + 2 * WIN_MAX_W + col], cg);
+            if (cc) atomicAdd(&cnt[2 + 3 * WIN_MAX_W + col], cc);
+        }
+    }
+    __syncthreads();
+    int *o = out + (size_t)r * out_stride;
+    for (uint32_t i = threadIdx.x; i < 2 + 4 * WIN_MAX_W; i += blockDim.x)
+        if (cnt[i]) atomicAdd(&o[i], cnt[i]);
+}
+
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
@@ -607,6 +708,13 @@ struct nm_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
     std::vector<uint32_t> bucket;                     // per-call host scratch, kept to avoid reallocation
+    // window engine
+    std::vector<WinTask> win_tasks;
+    uint32_t *d_win_planes = nullptr, *d_win_alive = nullptr;
+    uint64_t win_planes_cap = 0, win_alive_cap = 0, win_planes_used = 0, win_alive_used = 0;
+    WinTask *d_win_tasks = nullptr;
+    size_t d_win_tasks_cap = 0;
+    bool win_tasks_dirty = false;
     // results of the last nm_ingest_pileup
     std::vector<uint32_t> ing_contig, ing_pos, ing_kept;   // confident rows; kept rows per (contig, mod code)
     std::vector<uint8_t> ing_strand;
@@ -999,6 +1107,9 @@ int nm_ctx_destroy(nm_ctx *c) {
     }
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_programs) (void)hipFree(c->d_programs);
+    if (c->d_win_planes) (void)hipFree(c->d_win_planes);
+    if (c->d_win_alive) (void)hipFree(c->d_win_alive);
+    if (c->d_win_tasks) (void)hipFree(c->d_win_tasks);
     if (c->d_err) (void)hipFree(c->d_err);
     for (auto &pr : c->ev_pool) {
         (void)hipEventDestroy(pr.first);
@@ -1452,6 +1563,110 @@ int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, c
         used += len;
     }
     *masks_used = used;
+    return NM_OK;
+}
+
+// ---- window engine host side ------------------------------------------------------------------------
+static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uint64_t need_words) {
+    if (used + need_words <= *cap) return NM_OK;
+    const uint64_t ncap = std::max<uint64_t>((used + need_words) * 3 / 2, 1u << 20);
+    uint32_t *nb = nullptr;
+    HIP_TRY(hipMalloc(&nb, ncap * 4));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*buf && used) HIP_TRY(hipMemcpy(nb, *buf, used * 4, hipMemcpyDeviceToDevice));
+    if (*buf) (void)hipFree(*buf);
+    *buf = nb;
+    *cap = ncap;
+    return NM_OK;
+}
+
+int nm_win_clear(nm_ctx *c) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->win_tasks.clear();
+    c->win_planes_used = c->win_alive_used = 0;
+    c->win_tasks_dirty = true;
+    return NM_OK;
+}
+
+int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t *sets, uint32_t *task_id) {
+    if (!c || !task_id || (n_windows && !sets)) return fail(NM_EINVAL, "NULL argument");
+    if (width == 0 || width > WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", width, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    WinTask t{};
+    t.n = n_windows;
+    t.nw = (n_windows + 31) / 32;
+    t.width = width;
+    t.plane_off = c->win_planes_used;
+    t.alive_off = c->win_alive_used;
+    int rc = win_grow(c, &c->d_win_planes, &c->win_planes_cap, c->win_planes_used, (uint64_t)width * 5 * t.nw);
+    if (rc) return rc;
+    rc = win_grow(c, &c->d_win_alive, &c->win_alive_cap, c->win_alive_used, t.nw);
+    if (rc) return rc;
+    if (n_windows) {
+        uint8_t *d_sets = nullptr;
+        HIP_TRY(hipMalloc(&d_sets, (size_t)n_windows * width));
+        HIP_TRY(hipMemcpyAsync(d_sets, sets, (size_t)n_windows * width, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(win_pack_kernel, dim3((t.nw + 255) / 256, width), dim3(256), 0, c->stream, t, d_sets,
+                           c->d_win_planes, c->d_win_alive);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_sets);
+    }
+    c->win_planes_used += (uint64_t)width * 5 * t.nw;
+    c->win_alive_used += t.nw;
+    *task_id = (uint32_t)c->win_tasks.size();
+    c->win_tasks.push_back(t);
+    c->win_tasks_dirty = true;
+    return NM_OK;
+}
+
+int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                 int32_t *out) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (n_req == 0) return NM_OK;
+    if (!req_task || !req_kind || !req_sets || !out) return fail(NM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t max_nw = 1;
+    for (uint32_t r = 0; r < n_req; ++r) {
+        if (req_task[r] >= c->win_tasks.size()) return fail(NM_EINVAL, "request %u: window task %u does not exist", r, req_task[r]);
+        if (req_kind[r] > 1) return fail(NM_EINVAL, "request %u: kind must be 0 (pssm) or 1 (remove)", r);
+        max_nw = std::max(max_nw, c->win_tasks[req_task[r]].nw);
+    }
+    if (c->win_tasks_dirty) {
+        if (c->d_win_tasks_cap < c->win_tasks.size()) {
+            if (c->d_win_tasks) (void)hipFree(c->d_win_tasks);
+            c->d_win_tasks = nullptr;
+            c->d_win_tasks_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_win_tasks, c->win_tasks.size() * 2 * sizeof(WinTask)));
+            c->d_win_tasks_cap = c->win_tasks.size() * 2;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(c->d_win_tasks, c->win_tasks.data(), c->win_tasks.size() * sizeof(WinTask), hipMemcpyHostToDevice));
+        c->win_tasks_dirty = false;
+    }
+    const uint32_t stride = 2 + 4 * WIN_MAX_W;
+    const size_t o_kind = (size_t)n_req * 4, o_sets = (o_kind + n_req + 15) & ~(size_t)15;
+    const size_t o_out = (o_sets + (size_t)n_req * WIN_MAX_W + 15) & ~(size_t)15;
+    const size_t total = o_out + (size_t)n_req * stride * 4;
+    int rc = ensure_stage(c, total);
+    if (rc) return rc;
+    uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    memcpy(hs, req_task, (size_t)n_req * 4);
+    memcpy(hs + o_kind, req_kind, n_req);
+    memcpy(hs + o_sets, req_sets, (size_t)n_req * WIN_MAX_W);
+    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
+    const uint32_t gy = std::min<uint32_t>(64, (max_nw + 255) / 256);
+    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, gy), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
+                       reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
+                       reinterpret_cast<int *>(ds + o_out), stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, c->stream));
+    rc = release_stage(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, hs + o_out, (size_t)n_req * stride * 4);
     return NM_OK;
 }
 

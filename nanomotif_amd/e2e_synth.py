@@ -101,7 +101,8 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None):
                           minimum_kl_divergence=0.05, score_threshold=1.5, log_dir=None, seed=1, output_dir=None)
     t0 = time.perf_counter()
     scorer = engine_scorer(engine, 0.3, 0.7)
-    rows, scorer = discover(cfg, filtered, scorer)
+    from .engine import DeviceWindowStore
+    rows, scorer = discover(cfg, filtered, scorer, window_store=DeviceWindowStore(engine))
     t["search_s"] = time.perf_counter() - t0
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
     return rows, t

@@ -26,6 +26,51 @@ class CandidateBatch:
         return len(self.bins)
 
 
+class DeviceWindowStore:
+    """Window requests of the lock-step search served by the engine's window kernels (nm_win_*): same interface as
+    search.HostWindowStore.  Windows are bit planes over windows in HBM; a ``pssm`` request returns integer counts,
+    a ``remove`` request clears the matching windows from the task's alive mask."""
+
+    STRIDE = 2 + 4 * 64
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.task_id = {}
+        self.totals = {}
+        self.width = {}
+        _lib.check(engine.lib.nm_win_clear(engine.ctx))
+
+    def add_task(self, key, sets: np.ndarray):
+        sets = np.ascontiguousarray(sets, dtype=np.uint8)
+        tid = C.c_uint32(0)
+        _lib.check(self.engine.lib.nm_win_add_task(self.engine.ctx, sets.shape[0], sets.shape[1], _ptr(sets, C.c_uint8), C.byref(tid)))
+        self.task_id[key], self.totals[key], self.width[key] = int(tid.value), int(sets.shape[0]), int(sets.shape[1])
+
+    def execute(self, batch):
+        out = [None] * len(batch)
+        dev = [(i, key, req) for i, (key, req) in enumerate(batch) if req.kind != "total"]
+        for i, (key, req) in enumerate(batch):
+            if req.kind == "total":
+                out[i] = self.totals[key]
+        if dev:
+            n = len(dev)
+            task = np.fromiter((self.task_id[k] for _, k, _ in dev), dtype=np.uint32, count=n)
+            kind = np.fromiter((1 if r.kind == "remove" else 0 for _, _, r in dev), dtype=np.uint8, count=n)
+            sets = np.full((n, 64), 15, dtype=np.uint8)
+            for j, (_, k, r) in enumerate(dev):
+                sets[j, :self.width[k]] = r.motif.sets
+            res = np.zeros((n, self.STRIDE), dtype=np.int32)
+            _lib.check(self.engine.lib.nm_win_batch(self.engine.ctx, n, _ptr(task, C.c_uint32), _ptr(kind, C.c_uint8),
+                                                    _ptr(sets, C.c_uint8), res.ctypes.data_as(C.POINTER(C.c_int32))))
+            for j, (i, k, r) in enumerate(dev):
+                if r.kind == "remove":
+                    out[i] = (int(res[j, 0]), int(res[j, 1]))
+                else:
+                    w = self.width[k]
+                    out[i] = (int(res[j, 0]), res[j, 2:].reshape(4, 64)[:, :w].astype(np.int64))
+        return out
+
+
 class ScanEngine:
     """One engine per GPU / process.  Mirrors what ``motif_model_bin`` needs (find_motifs_bin.py:1265-1283):
     the bin's contig sequences and the (bin, mod_type) pileup, but resident in HBM across calls."""

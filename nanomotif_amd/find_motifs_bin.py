@@ -22,7 +22,7 @@ from . import postprocess
 from .model import BetaBernoulliModel, predictive_evaluation_score  # noqa: F401  (re-exported like the reference)
 from .motif import MOD_TYPE_TO_CANONICAL, Motif
 from .pileup import MOD_TYPES, PileupTable
-from .search import extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
+from .search import HostWindowStore, extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
 
 IUPAC_LETTERS = set("ATGCRYSWKMBDHVN")
 
@@ -151,10 +151,10 @@ def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ per-task pipeline
-def task_coroutine(bin_name, mod_type, windows, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+def task_coroutine(bin_name, mod_type, bg_ascii, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
     """process_subpileup (find_motifs_bin.py:468-596) as one scoring coroutine: search, then post-processing."""
     res = yield from find_best_candidates_co(
-        windows, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
+        bg_ascii, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
         max_rounds_since_new_best=30, score_threshold=cfg.score_threshold,
         log=lambda msg: log.info(f"[{bin_name} {mod_type}] {msg}"))
     if res is None:
@@ -230,9 +230,12 @@ class FilteredPileup:
         return plus, minus
 
 
-def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepScorer, rank=0, bgzip_order=False):
+def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepScorer, rank=0, bgzip_order=False,
+             window_store=None):
     """Run every (bin, mod type) task of the data set.  ``filtered``: see FilteredPileup (identical on every rank);
-    ``scorer``: see ``engine_scorer``.  Returns (list of MotifRow, scorer) — identical on every rank."""
+    ``scorer``: see ``engine_scorer``; ``window_store``: where the methylation windows live (default: host numpy;
+    the CLI passes the engine's device store).  Returns (list of MotifRow, scorer) — identical on every rank."""
+    store = window_store if window_store is not None else HostWindowStore()
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)
@@ -260,8 +263,9 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 os.makedirs(pre, exist_ok=True)
                 stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
                 temp_dir = os.path.join(out_dir, "temp", bin_name)
-            tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows, cfg, stage_writer, temp_dir)
-    results = run_lockstep(tasks, scorer)
+            store.add_task((bin_name, mod_type), windows[0])
+            tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
+    results = run_lockstep(tasks, scorer, store.execute)
     rows = []
     for key in tasks:
         if results.get(key):
@@ -274,9 +278,12 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
 def find_best_candidates(bin_pileup: BinData, bin_sequences: dict, mod_type: str, bin_name: str, output_dir,
                          low_meth_threshold, high_meth_threshold, padding, min_kl=0.2, max_dead_ends=25,
                          max_rounds_since_new_best=30, score_threshold=0.2, windows=None):
-    """find_motifs_bin.py:606-839 for a single bin (windows must be supplied: see ``extract_windows``)."""
+    """find_motifs_bin.py:606-839 for a single bin; ``windows`` = (methylation sets, background ASCII) from
+    ``extract_windows``."""
     key = (bin_name, mod_type)
-    co = find_best_candidates_co(windows, mod_type, padding, min_kl=min_kl, max_dead_ends=max_dead_ends,
+    store = HostWindowStore()
+    store.add_task(key, windows[0])
+    co = find_best_candidates_co(windows[1], mod_type, padding, min_kl=min_kl, max_dead_ends=max_dead_ends,
                                  max_rounds_since_new_best=max_rounds_since_new_best, score_threshold=score_threshold)
-    res = run_lockstep({key: co}, bin_pileup.scorer)[key]
+    res = run_lockstep({key: co}, bin_pileup.scorer, store.execute)[key]
     return None if res is None else (res[0], res[1])

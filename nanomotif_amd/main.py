@@ -129,7 +129,8 @@ def find_motifs_bin(args):
         eng.close()
         return None
     scorer = engine_scorer(eng, low, high, use_dist=world > 1)
-    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip)
+    from .engine import DeviceWindowStore
+    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip, window_store=DeviceWindowStore(eng))
     eng.close()
     if not rows:
         log.info("No motifs were identified")

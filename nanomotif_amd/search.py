@@ -81,16 +81,22 @@ for _m in range(16):
     _LANES[_m] = sum(((_m & b) != 0) << (16 * k) for k, b in enumerate(ROW_BITS))
 
 
-def sets_pssm(sets: np.ndarray) -> np.ndarray:
-    """seq.py:526-537 on bit sets: N windows count for all four rows.  One pass: every set is mapped to four 16-bit
-    counter lanes of a uint64 and the rows are summed in slabs of < 65536 windows (integer counts, exact)."""
+def sets_counts(sets: np.ndarray) -> np.ndarray:
+    """Per column, how many windows carry A / T / G / C (int64[4, W], rows in the reference's order; an N window counts
+    for all four).  One pass: every set is mapped to four 16-bit counter lanes of a uint64 and the rows are summed in
+    slabs of < 65536 windows (integer counts, exact)."""
     n = sets.shape[0]
     counts = np.zeros((4, sets.shape[1]), dtype=np.int64)
     for lo in range(0, n, 65535):
         acc = _LANES[sets[lo:lo + 65535]].sum(axis=0, dtype=np.uint64)
         for k in range(4):
             counts[k] += ((acc >> np.uint64(16 * k)) & np.uint64(0xFFFF)).astype(np.int64)
-    return counts / n
+    return counts
+
+
+def sets_pssm(sets: np.ndarray) -> np.ndarray:
+    """seq.py:526-537 on bit sets."""
+    return sets_counts(sets) / sets.shape[0]
 
 
 def motif_sets(motif: Motif) -> np.ndarray:
@@ -180,7 +186,53 @@ class MotifTree:
 
 
 # ------------------------------------------------------------------------------------------------
-# coroutines: ``models = yield [motifs]``
+# window requests: what the search asks of the windows of its (bin, mod type) task
+# ------------------------------------------------------------------------------------------------
+class WinReq:
+    """``("pssm", motif)``  -> (n_active, int64 counts[4, W]) over the not-yet-removed windows that match ``motif``
+                              (filter_sequence_matches(keep_matches=True) + pssm, seq.py:499-537);
+    ``("remove", motif)`` -> (alive before, alive after): drop the matching windows (keep_matches=False, :803);
+    ``("total", None)``   -> number of windows of the task."""
+    __slots__ = ("kind", "motif")
+
+    def __init__(self, kind, motif=None):
+        self.kind, self.motif = kind, motif
+
+
+class HostWindowStore:
+    """Reference implementation of the window requests with numpy (CPU tests; the GPU path uses
+    engine.DeviceWindowStore, same interface)."""
+
+    def __init__(self):
+        self.remaining = {}
+        self.totals = {}
+
+    def add_task(self, key, sets: np.ndarray):
+        self.remaining[key] = sets
+        self.totals[key] = int(sets.shape[0])
+
+    def execute(self, batch):
+        """batch: list of (key, WinReq) -> list of results."""
+        out = []
+        for key, req in batch:
+            sets = self.remaining[key]
+            if req.kind == "total":
+                out.append(self.totals[key])
+            elif req.kind == "pssm":
+                active = filter_matches(sets, req.motif, keep_matches=True) if sets is not None else None
+                out.append((0, None) if active is None else (int(active.shape[0]), sets_counts(active)))
+            elif req.kind == "remove":
+                before = 0 if sets is None else int(sets.shape[0])
+                left = filter_matches(sets, req.motif, keep_matches=False) if sets is not None else None
+                self.remaining[key] = left
+                out.append((before, 0 if left is None else int(left.shape[0])))
+            else:
+                raise ValueError(req.kind)
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# coroutines: ``models = yield [motifs]``  /  ``result = yield WinReq(...)``
 # ------------------------------------------------------------------------------------------------
 def get_parent_scores_co(motif: Motif):
     """find_motifs_bin.py:1382-1433 as a coroutine: ONE request holds the motif and all its parents."""
@@ -205,13 +257,12 @@ def get_parent_scores_co(motif: Motif):
 class MotifSearcher:
     """find_motifs_bin.py:843-1182.  ``run`` is a coroutine (see module docstring)."""
 
-    def __init__(self, root_motif, bin_pssm, methylation_sets, padding, motif_graph=None, min_kl=0.1,
+    def __init__(self, root_motif, bin_pssm, padding, motif_graph=None, min_kl=0.1,
                  freq_threshold=0.15, max_rounds_since_new_best=30, max_motif_length=25):
         if padding < 0:
             raise ValueError("padding must be non-negative.")
         self.root_motif = root_motif
         self.bin_pssm = bin_pssm
-        self.methylation_sets = methylation_sets
         self.padding = padding
         self.motif_graph = motif_graph or MotifTree()
         self.min_kl = min_kl
@@ -276,10 +327,10 @@ class MotifSearcher:
             visited.add(cur)
             g.nodes[cur]["visited"] = True
             rounds += 1
-            active = filter_matches(self.methylation_sets, cur, keep_matches=True)
-            if active is None:
+            n_active, counts = yield WinReq("pssm", cur)      # windows of this task still alive and matching cur
+            if n_active == 0:
                 continue
-            neighbors = self._motif_child_nodes_kl_dist_max(cur, sets_pssm(active))
+            neighbors = self._motif_child_nodes_kl_dist_max(cur, counts / n_active)
             fresh = [m for m in neighbors if m not in g.nodes]
             fresh_models = dict(zip(fresh, (yield fresh))) if fresh else {}     # one batch for all new children
             for nxt in neighbors:
@@ -335,21 +386,20 @@ def extract_windows(contigs: dict, plus_pos: dict, minus_pos: dict, mod_type: st
     return np.concatenate(meth), np.concatenate(bg)
 
 
-def find_best_candidates_co(windows, mod_type: str, padding: int, min_kl=0.2, max_dead_ends=25,
+def find_best_candidates_co(bg_ascii, mod_type: str, padding: int, min_kl=0.2, max_dead_ends=25,
                             max_rounds_since_new_best=30, score_threshold=0.2, remaining_sequences_threshold=0.001,
                             log=None):
-    """find_motifs_bin.py:688-839 as a coroutine.  ``windows`` = (methylation sets, background ASCII).
+    """find_motifs_bin.py:688-839 as a coroutine.  ``bg_ascii``: the background windows (ASCII) of the task; the
+    methylation windows live in the window store under this coroutine's key and are reached through ``WinReq``s.
     Returns (graph, best_candidates, bin_pssm) or None."""
-    meth_sets, bg_ascii = windows
-    total = meth_sets.shape[0]
+    total = yield WinReq("total")
     bin_pssm = letter_pssm(bg_ascii)
     root = Motif("." * padding + MOD_TYPE_TO_CANONICAL[mod_type] + "." * padding, padding)
-    remaining = meth_sets
     best, dead_ends, graph = [], 0, None
     while True:
         if dead_ends >= max_dead_ends:
             break
-        searcher = MotifSearcher(root, bin_pssm, remaining, padding, motif_graph=graph, min_kl=min_kl,
+        searcher = MotifSearcher(root, bin_pssm, padding, motif_graph=graph, min_kl=min_kl,
                                  max_rounds_since_new_best=max_rounds_since_new_best)
         graph, guess = yield from searcher.run()
         if guess == root:
@@ -379,18 +429,17 @@ def find_best_candidates_co(windows, mod_type: str, padding: int, min_kl=0.2, ma
             child_model = next(iter(parents.values()))["child_model"]
             graph.add_node(temp, model=child_model, motif=temp, visited=True, score=mean_parent, priority=0, depth=0)
             guess = temp
-        before = remaining.shape[0]
-        remaining = filter_matches(remaining, guess, keep_matches=False)
-        if remaining is None:
+        before, left = yield WinReq("remove", guess)
+        if left == 0:
             break
         if graph.nodes[guess]["score"] < score_threshold:
             dead_ends += 1
             continue
         if log:
-            log(f"Keeping {guess}, represented in {before - remaining.shape[0]} seqs. model: {graph.nodes[guess]['model']}. "
-                f"({100 * remaining.shape[0] / total:.1f} % of sequences remaining)")
+            log(f"Keeping {guess}, represented in {before - left} seqs. model: {graph.nodes[guess]['model']}. "
+                f"({100 * left / total:.1f} % of sequences remaining)")
         best.append(guess)
-        if remaining.shape[0] / total < remaining_sequences_threshold:
+        if left / total < remaining_sequences_threshold:
             break
     if graph is None or len(graph.nodes) == 0:
         return None
@@ -413,26 +462,39 @@ class TaggedRequest(list):
         self.tag = tag
 
 
-def run_lockstep(coroutines: dict, score_fn):
-    """Advance all coroutines together.  ``coroutines``: key -> generator yielding lists of Motif (optionally a
-    ``TaggedRequest``); ``score_fn(list of (key, Motif, tag)) -> int64[n, 2]`` scores one round's requests in one
-    batch.  Returns key -> the coroutine's return value."""
+def run_lockstep(coroutines: dict, score_fn, window_fn=None):
+    """Advance all coroutines together.  ``coroutines``: key -> generator that yields either a list of Motif
+    (optionally a ``TaggedRequest``) to be scored, or a ``WinReq``.  Every round, all pending scoring requests go to
+    ``score_fn(list of (key, Motif, tag)) -> int64[n, 2]`` in one batch and all pending window requests to
+    ``window_fn(list of (key, WinReq)) -> list of results`` in one batch.  Returns key -> the coroutine's return value."""
     results, waiting = {}, {}
-    for key, co in coroutines.items():
+
+    def advance(key, value, first=False):
         try:
-            waiting[key] = next(co)
+            waiting[key] = next(coroutines[key]) if first else coroutines[key].send(value)
         except StopIteration as e:
+            waiting.pop(key, None)
             results[key] = e.value
+
+    for key in list(coroutines):
+        advance(key, None, first=True)
     while waiting:
-        flat = [(key, m, getattr(req, "tag", None)) for key, req in waiting.items() for m in req]
-        counts = score_fn(flat)
-        nxt, at = {}, 0
-        for key, req in waiting.items():
-            models = [BetaBernoulliModel.from_counts(*counts[at + j]) for j in range(len(req))]
-            at += len(req)
-            try:
-                nxt[key] = coroutines[key].send(models)
-            except StopIteration as e:
-                results[key] = e.value
-        waiting = nxt
+        score_keys = [k for k, r in waiting.items() if not isinstance(r, WinReq)]
+        win_keys = [k for k, r in waiting.items() if isinstance(r, WinReq)]
+        replies = {}
+        if win_keys:
+            if window_fn is None:
+                raise RuntimeError("a coroutine issued a window request but no window store was given")
+            for k, res in zip(win_keys, window_fn([(k, waiting[k]) for k in win_keys])):
+                replies[k] = res
+        if score_keys:
+            flat = [(k, m, getattr(waiting[k], "tag", None)) for k in score_keys for m in waiting[k]]
+            counts = score_fn(flat)
+            at = 0
+            for k in score_keys:
+                n = len(waiting[k])
+                replies[k] = [BetaBernoulliModel.from_counts(*counts[at + j]) for j in range(n)]
+                at += n
+        for k, v in replies.items():
+            advance(k, v)
     return results

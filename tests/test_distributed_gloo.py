@@ -31,6 +31,7 @@ def _worker(rank, world, port, q):
     g = load_golden("g4_search.json")["ecoli_like_a"]
     mg = synth.make_metagenome(spec_from_json(g["spec"]))
     tasks, piles, seqs_by_bin = {}, {}, {}
+    store = ps.HostWindowStore()
     shard = set(assign_contigs(mg.lengths, world)[rank].tolist())
     for mt in ("a", "m"):
         pile, seqs = oracle_bin_inputs(mg, mt)
@@ -41,12 +42,14 @@ def _worker(rank, world, port, q):
         piles[key] = {n: pile[n] for n in mine}        # ... but scores only its own contigs
         seqs_by_bin["bin0"] = {n: seqs[n] for n in mine}
 
+        store.add_task(key, windows[0])
+
         def chain(mt=mt, windows=windows):
-            graph, best, _ = yield from ps.find_best_candidates_co(windows, mt, 20, min_kl=0.05, score_threshold=1.5)
+            graph, best, _ = yield from ps.find_best_candidates_co(windows[1], mt, 20, min_kl=0.05, score_threshold=1.5)
             return (yield from ppp.postprocess_co(graph, best, "bin0", mt, 20))
         tasks[key] = chain()
     scorer = LockstepScorer(oracle_backend(piles, seqs_by_bin), use_dist=world > 1)
-    res = ps.run_lockstep(tasks, scorer)
+    res = ps.run_lockstep(tasks, scorer, store.execute)
     rows = [r for k in tasks for r in (res[k] or [])]
     q.put((rank, ppp.format_bin_motifs(rows), scorer.rounds))
     dist.barrier()

@@ -160,3 +160,34 @@ def test_large_contig_properties(engine_cls):
     got = eng.score([M("GATC", 1), M("GCAC......GTT", 2), M("A", 0), M("G[AG].GAAG[CT]", 5)])
     assert np.array_equal(got, exp)
     eng.close()
+
+
+def test_window_engine_matches_host_store():
+    """nm_win_* (bit planes over windows) against the numpy window store, request for request."""
+    from nanomotif_amd import search as ps
+    from nanomotif_amd.engine import DeviceWindowStore, ScanEngine
+    rng = np.random.default_rng(12)
+    eng = ScanEngine(0)
+    dev, host = DeviceWindowStore(eng), ps.HostWindowStore()
+    keys = []
+    for t, n in enumerate([1, 31, 32, 33, 1000, 70_001]):
+        sets = rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), size=(n, 41), p=[0.35, 0.15, 0.2, 0.3])
+        sets[rng.random((n, 41)) < 0.002] = 15                      # a few N positions
+        sets[:, 20] = 1
+        key = (f"bin{t}", "a")
+        keys.append(key)
+        dev.add_task(key, sets)
+        host.add_task(key, sets.copy())
+    motifs = [Motif("." * 20 + "A" + "." * 20, 20), Motif("." * 19 + "GATC" + "." * 18, 20), Motif("." * 18 + "[AG]CA.T" + "." * 17, 20),
+              Motif("." * 10 + "T" + "." * 9 + "A" + "." * 19 + "C", 20), Motif("G" + "." * 19 + "A" + "." * 20, 20)]
+    for rnd, kind in enumerate(["total", "pssm", "pssm", "remove", "pssm", "remove", "pssm", "pssm"]):
+        m = motifs[rnd % len(motifs)]
+        batch = [(k, ps.WinReq(kind, None if kind == "total" else m)) for k in keys]
+        a, b = dev.execute(batch), host.execute(batch)
+        for x, y in zip(a, b):
+            if kind == "pssm":
+                assert x[0] == y[0]
+                assert (y[1] is None and x[0] == 0) or np.array_equal(x[1], y[1])
+            else:
+                assert x == y
+    eng.close()

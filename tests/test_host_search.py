@@ -43,9 +43,11 @@ def test_product_search_reproduces_reference_trace(name):
     windows = windows_for(mg, mt, pile, P["high"], P["padding"])
     key = ("bin0", mt)
     scorer = LockstepScorer(oracle_backend({key: pile}, {"bin0": seqs}))
-    co = ps.find_best_candidates_co(windows, mt, P["padding"], min_kl=P["min_kl"], max_dead_ends=25,
+    store = ps.HostWindowStore()
+    store.add_task(key, windows[0])
+    co = ps.find_best_candidates_co(windows[1], mt, P["padding"], min_kl=P["min_kl"], max_dead_ends=25,
                                     max_rounds_since_new_best=30, score_threshold=P["score_threshold"])
-    graph, best, bin_pssm = ps.run_lockstep({key: co}, scorer)[key]
+    graph, best, bin_pssm = ps.run_lockstep({key: co}, scorer, store.execute)[key]
     assert np.allclose(bin_pssm, np.array(g["bin_pssm_4dp"]), atol=5.1e-5, rtol=0)
     assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
     for (n, d), r in zip(graph.nodes.items(), g["nodes"]):
@@ -65,6 +67,7 @@ def test_lockstep_equals_sequential_and_matches_oracle_chain():
     from oracle import search as ose
     g4 = load_golden("g4_search.json")
     tasks, piles, seqs_by_bin, expect = {}, {}, {}, {}
+    store = ps.HostWindowStore()
     for bin_name, gname in (("binA", "geobacillus_like"), ("binB", "ecoli_like_m")):
         g = g4[gname]
         mg = synth.make_metagenome(spec_from_json(g["spec"]))
@@ -75,8 +78,10 @@ def test_lockstep_equals_sequential_and_matches_oracle_chain():
         random.seed(1)
         windows = windows_for(mg, mt, pile)
 
+        store.add_task(key, windows[0])
+
         def chain(bin_name=bin_name, mt=mt, windows=windows):
-            graph, best, _ = yield from ps.find_best_candidates_co(windows, mt, 20, min_kl=0.05, score_threshold=1.5)
+            graph, best, _ = yield from ps.find_best_candidates_co(windows[1], mt, 20, min_kl=0.05, score_threshold=1.5)
             rows = yield from ppp.postprocess_co(graph, best, bin_name, mt, 20)
             return rows
         tasks[key] = chain()
@@ -84,7 +89,7 @@ def test_lockstep_equals_sequential_and_matches_oracle_chain():
         og, ob, _ = ose.find_best_candidates(pile, seqs, mt, 0.3, 0.7, 20, min_kl=0.05, score_threshold=1.5)
         expect[key] = opp.format_bin_motifs(opp.process_bin(pile, seqs, bin_name, mt, og, ob, 20))
     scorer = LockstepScorer(oracle_backend(piles, seqs_by_bin))
-    res = ps.run_lockstep(tasks, scorer)
+    res = ps.run_lockstep(tasks, scorer, store.execute)
     for key in tasks:
         rows = [r for r in res[key] if r.n_mod + r.n_nomod >= 50]
         assert ppp.format_bin_motifs(rows) == expect[key]
