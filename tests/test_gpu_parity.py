@@ -178,7 +178,7 @@ def test_window_engine_matches_host_store():
         keys.append(key)
         dev.add_task(key, sets)
         host.add_task(key, sets.copy())
-    motifs = [Motif("." * 20 + "A" + "." * 20, 20), Motif("." * 19 + "GATC" + "." * 18, 20), Motif("." * 18 + "[AG]CA.T" + "." * 17, 20),
+    motifs = [Motif("." * 20 + "A" + "." * 20, 20), Motif("." * 19 + "GATC" + "." * 18, 20), Motif("." * 18 + "[AG]CA.T" + "." * 18, 20),
               Motif("." * 10 + "T" + "." * 9 + "A" + "." * 19 + "C", 20), Motif("G" + "." * 19 + "A" + "." * 20, 20)]
     for rnd, kind in enumerate(["total", "pssm", "pssm", "remove", "pssm", "remove", "pssm", "pssm"]):
         m = motifs[rnd % len(motifs)]
