@@ -199,6 +199,19 @@ int nm_bed_columns(nm_bed *bed, const uint32_t **contig_id, const int64_t **posi
                    const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov);
 int nm_bed_close(nm_bed *bed);
 
+/*
+ * Host helpers of the window-extraction step (no GPU involved).
+ * nm_py_random_sample: the indices CPython's random.sample(range(n), k) would return from the MT19937 state
+ *   mt_state[0..623] + position mt_state[624] (random.getstate()[1]); the state is advanced in place, so that
+ *   random.setstate() afterwards leaves the interpreter's generator where the reference's call would have left it
+ *   (the reference samples its background windows this way: seq.py:202-225, find_motifs_bin.py:640-642).
+ * nm_window_letter_counts: counts[4][width] (rows A, T, G, C) of exact letters per column over the windows
+ *   seq[starts[i] : starts[i] + width] — EqualLengthDNASet.pssm before the division (seq.py:391-422).
+ */
+int nm_py_random_sample(uint32_t mt_state[625], uint64_t n, uint64_t k, uint32_t *out_indices);
+int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows,
+                            uint32_t width, int64_t *counts);
+
 /* Per-launch timing over a region: nm_timing_reset(ctx, 1) starts collecting one HIP event pair per scoring
  * launch (no synchronisation per launch); nm_timing_total_ms sums the kernel durations recorded since then and
  * reports how many launches they cover; nm_timing_reset(ctx, 0) stops collecting. */

@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "nmscan.hip")
-SRC_HOST = [os.path.join(_HERE, "csrc", "nmbed.cpp")]
+SRC_HOST = [os.path.join(_HERE, "csrc", "nmbed.cpp"), os.path.join(_HERE, "csrc", "nmhost.cpp")]
 OUT = os.path.join(_HERE, "libnmscan.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")
 

@@ -151,10 +151,10 @@ def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ per-task pipeline
-def task_coroutine(bin_name, mod_type, bg_ascii, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+def task_coroutine(bin_name, mod_type, bin_pssm, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
     """process_subpileup (find_motifs_bin.py:468-596) as one scoring coroutine: search, then post-processing."""
     res = yield from find_best_candidates_co(
-        bg_ascii, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
+        bin_pssm, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
         max_rounds_since_new_best=30, score_threshold=cfg.score_threshold,
         log=lambda msg: log.info(f"[{bin_name} {mod_type}] {msg}"))
     if res is None:

@@ -56,9 +56,24 @@ def revcomp_sets(sets: np.ndarray) -> np.ndarray:
     return _COMP_SET[sets[:, ::-1]]
 
 
-def sample_background(seq: np.ndarray, length: int, n: int, base: str) -> np.ndarray:
-    """seq.py:202-225 — ``random.sample`` over the starts whose middle base is ``base``; same RNG consumption
-    as sampling from the reference's list of valid starts (sample() only looks at len() and indexes)."""
+def _native_random_sample(n: int, k: int) -> np.ndarray:
+    """``random.sample(range(n), k)`` drawn natively from the interpreter's own MT19937 state (libnmscan:
+    nm_py_random_sample replicates CPython's algorithm bit for bit); the interpreter's generator is advanced exactly as
+    the pure-Python call would have advanced it."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    version, state, gauss = random.getstate()
+    arr = np.array(state, dtype=np.uint32)
+    out = np.empty(k, dtype=np.uint32)
+    _lib.check(lib.nm_py_random_sample(arr.ctypes.data_as(C.POINTER(C.c_uint32)), n, k, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    random.setstate((version, tuple(arr.tolist()), gauss))
+    return out.astype(np.int64)
+
+
+def sample_background_starts(seq: np.ndarray, length: int, n: int, base: str) -> np.ndarray:
+    """seq.py:202-225 — ``random.sample`` over the starts whose middle base is ``base``; same RNG consumption as
+    sampling from the reference's list of valid starts (sample() only looks at len() and indexes)."""
     max_start = len(seq) - length + 1
     if n > max_start:
         raise ValueError("Too many samples requested for unique subsequences")
@@ -66,8 +81,25 @@ def sample_background(seq: np.ndarray, length: int, n: int, base: str) -> np.nda
     valid = np.flatnonzero(seq[mid:mid + max_start] == ord(base))
     if len(valid) < n:
         raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {len(valid)}, need {n})")
-    starts = valid[np.array(random.sample(range(len(valid)), n), dtype=np.int64)]
+    return valid[_native_random_sample(len(valid), n)]
+
+
+def sample_background(seq: np.ndarray, length: int, n: int, base: str) -> np.ndarray:
+    starts = sample_background_starts(seq, length, n, base)
     return seq[starts[:, None] + np.arange(length)[None, :]]
+
+
+def letter_counts(seq: np.ndarray, starts: np.ndarray, length: int) -> np.ndarray:
+    """int64[4, length]: exact-letter counts per column (rows A, T, G, C) over the windows seq[s : s + length]."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    starts = np.ascontiguousarray(starts, dtype=np.int64)
+    out = np.zeros((4, length), dtype=np.int64)
+    _lib.check(lib.nm_window_letter_counts(seq.ctypes.data_as(C.POINTER(C.c_uint8)), len(seq), starts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           len(starts), length, out.ctypes.data_as(C.POINTER(C.c_int64))))
+    return out
 
 
 def letter_pssm(windows_ascii: np.ndarray) -> np.ndarray:
@@ -362,15 +394,18 @@ def extract_windows(contigs: dict, plus_pos: dict, minus_pos: dict, mod_type: st
                     background_sampling_frequency=0.01):
     """find_motifs_bin.py:625-686.  contigs: name -> uint8 upper-case ASCII; plus_pos / minus_pos: name -> int64
     positions of the confidently methylated rows (fraction_mod >= high).  Contigs are visited in sorted-name order
-    (the reference's polars ``unique()`` order is unspecified).  Returns (methylation sets, background ASCII)
-    or None."""
+    (the reference's polars ``unique()`` order is unspecified).  Returns (methylation window sets uint8[n, W],
+    background PSSM float64[4, W] = ``background_sequences.pssm()``) or None."""
     canonical = MOD_TYPE_TO_CANONICAL[mod_type]
     W = 2 * padding + 1
-    meth, bg = [], []
+    meth = []
+    bg_counts, n_bg = np.zeros((4, W), dtype=np.int64), 0
     for name in sorted(plus_pos.keys() | minus_pos.keys()):
         seq = contigs[name]
         n_samples = int(max(math.ceil(len(seq) * background_sampling_frequency), 50))
-        bg.append(sample_background(seq, W, n_samples, canonical))
+        starts = sample_background_starts(seq, W, n_samples, canonical)
+        bg_counts += letter_counts(seq, starts, W)
+        n_bg += n_samples
         p, m = plus_pos.get(name, np.zeros(0, np.int64)), minus_pos.get(name, np.zeros(0, np.int64))
         here = []
         if len(p) >= 1:
@@ -381,19 +416,18 @@ def extract_windows(contigs: dict, plus_pos: dict, minus_pos: dict, mod_type: st
         if not here:
             return None                          # find_motifs_bin.py:662-664
         meth += here
-    if not meth or not bg:
+    if not meth or n_bg == 0:
         return None
-    return np.concatenate(meth), np.concatenate(bg)
+    return np.concatenate(meth), bg_counts / n_bg
 
 
-def find_best_candidates_co(bg_ascii, mod_type: str, padding: int, min_kl=0.2, max_dead_ends=25,
+def find_best_candidates_co(bin_pssm, mod_type: str, padding: int, min_kl=0.2, max_dead_ends=25,
                             max_rounds_since_new_best=30, score_threshold=0.2, remaining_sequences_threshold=0.001,
                             log=None):
-    """find_motifs_bin.py:688-839 as a coroutine.  ``bg_ascii``: the background windows (ASCII) of the task; the
+    """find_motifs_bin.py:688-839 as a coroutine.  ``bin_pssm``: the background PSSM of the task (float64[4, W]); the
     methylation windows live in the window store under this coroutine's key and are reached through ``WinReq``s.
     Returns (graph, best_candidates, bin_pssm) or None."""
     total = yield WinReq("total")
-    bin_pssm = letter_pssm(bg_ascii)
     root = Motif("." * padding + MOD_TYPE_TO_CANONICAL[mod_type] + "." * padding, padding)
     best, dead_ends, graph = [], 0, None
     while True:

@@ -114,3 +114,26 @@ def test_postprocess_kats():
     text = ppp.format_bin_motifs(mk(["GATC"], [1], "a"))
     assert text.split("\n")[0].split("\t") == ppp.HEADER and text.split("\n")[1].split("\t")[:7] == \
         ["ref1", "GATC", "1", "a", "0", "0", "palindrome"]
+
+
+def test_native_random_sample_is_cpython_exact():
+    """nm_py_random_sample == random.sample(range(n), k), and the interpreter's generator ends in the same state."""
+    for seed in (1, 2403, 99):
+        for n, k in [(10, 3), (21, 5), (22, 6), (50, 50), (100, 6), (85, 21), (86, 21), (5000, 50), (300_000, 3000),
+                     (2 ** 20 + 5, 77), (64, 64), (1, 1), (5, 0)]:
+            random.seed(seed)
+            want = random.sample(range(n), k)
+            after = random.random()
+            random.seed(seed)
+            got = ps._native_random_sample(n, k).tolist()
+            assert got == want and random.random() == after, (seed, n, k)
+
+
+def test_letter_counts_matches_numpy():
+    rng = np.random.default_rng(2)
+    seq = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=100_000, p=[0.3, 0.2, 0.2, 0.29, 0.01])
+    starts = rng.integers(0, 100_000 - 41, size=30_000)
+    win = seq[starts[:, None] + np.arange(41)[None, :]]
+    want = np.array([(win == ord(b)).sum(axis=0) for b in "ATGC"])
+    assert np.array_equal(ps.letter_counts(seq, starts, 41), want)
+    assert np.array_equal(ps.letter_pssm(win), want / len(starts))
