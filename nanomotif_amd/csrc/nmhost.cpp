@@ -95,20 +95,24 @@ int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t 
         if (starts[i] < 0 || (uint64_t)starts[i] + width > seq_len) return nm_set_error(NM_EINVAL, "window %llu outside the sequence", (unsigned long long)i);
     unsigned threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     if (n_windows < 20000) threads = 1;
+    auto count_range = [&](int64_t *c, uint64_t first, uint64_t step) {
+        for (uint64_t i = first; i < n_windows; i += step) {
+            const uint8_t *w = seq + starts[i];
+            for (uint32_t j = 0; j < width; ++j) {
+                const uint8_t ch = w[j];
+                const int row = ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'G' ? 2 : ch == 'C' ? 3 : -1;
+                if (row >= 0) c[(size_t)row * width + j] += 1;
+            }
+        }
+    };
+    if (threads == 1) {                                   // the common case (one contig's ~1 % sample): no thread spawn
+        memset(counts, 0, sizeof(int64_t) * 4 * width);
+        count_range(counts, 0, 1);
+        return NM_OK;
+    }
     std::vector<std::vector<int64_t>> part(threads, std::vector<int64_t>(4 * (size_t)width, 0));
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-        pool.emplace_back([&, t] {
-            int64_t *c = part[t].data();
-            for (uint64_t i = t; i < n_windows; i += threads) {
-                const uint8_t *w = seq + starts[i];
-                for (uint32_t j = 0; j < width; ++j) {
-                    const uint8_t ch = w[j];
-                    const int row = ch == 'A' ? 0 : ch == 'T' ? 1 : ch == 'G' ? 2 : ch == 'C' ? 3 : -1;
-                    if (row >= 0) c[(size_t)row * width + j] += 1;
-                }
-            }
-        });
+    for (unsigned t = 0; t < threads; ++t) pool.emplace_back(count_range, part[t].data(), (uint64_t)t, (uint64_t)threads);
     for (auto &th : pool) th.join();
     memset(counts, 0, sizeof(int64_t) * 4 * width);
     for (auto &p : part)

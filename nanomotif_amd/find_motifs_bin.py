@@ -209,7 +209,10 @@ class FilteredPileup:
         if getattr(self, "_order", None) is None:
             minus = (self.conf_strand == ord("-")).astype(np.int64)
             key = (self.conf_mod.astype(np.int64) * len(self.contig_names) + self.conf_contig.astype(np.int64)) * 2 + minus
-            order = np.lexsort((self.conf_position, key))
+            if len(key) and key.max() < 2 ** 31 and self.conf_position.max(initial=0) < 2 ** 32:
+                order = np.argsort((key.astype(np.uint64) << np.uint64(32)) | self.conf_position.astype(np.uint64), kind="stable")
+            else:
+                order = np.lexsort((self.conf_position, key))
             self._order, self._key = order, key[order]
             self._name_index = {n: i for i, n in enumerate(self.contig_names)}
         return self._order, self._key

@@ -19,7 +19,7 @@ import math
 import random
 
 import numpy as np
-from scipy.stats import entropy
+from scipy.special import rel_entr
 
 from .model import BetaBernoulliModel, predictive_evaluation_score
 from .motif import BASES, MOD_TYPE_TO_CANONICAL, Motif
@@ -286,6 +286,15 @@ def get_parent_scores_co(motif: Motif):
     return out
 
 
+def kl_divergence_columns(pk: np.ndarray, qk: np.ndarray) -> np.ndarray:
+    """``scipy.stats.entropy(pk, qk)`` along axis 0 (find_motifs_bin.py:974) — the same three operations scipy performs
+    (normalise both to column sums, ``special.rel_entr``, column sum) without its argument-checking wrapper."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pk = 1.0 * pk / np.sum(pk, axis=0, keepdims=True)
+        qk = 1.0 * qk / np.sum(qk, axis=0, keepdims=True)
+    return np.sum(rel_entr(pk, qk), axis=0)
+
+
 class MotifSearcher:
     """find_motifs_bin.py:843-1182.  ``run`` is a coroutine (see module docstring)."""
 
@@ -317,7 +326,7 @@ class MotifSearcher:
     def _motif_child_nodes_kl_dist_max(self, motif, meth_pssm):
         """find_motifs_bin.py:957-1023: the single '.' column of maximal KL(meth || background), one child per
         base passing freq > 0.15 and freq > 0.5 * background, in A, T, G, C order."""
-        kl = entropy(meth_pssm, self.bin_pssm)
+        kl = kl_divergence_columns(meth_pssm, self.bin_pssm)
         toks = motif.tokens
         masked = np.where(np.array([t == "." for t in toks]), kl, 0.0)
         if not any(t == "." for t in toks):

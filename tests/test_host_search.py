@@ -137,3 +137,15 @@ def test_letter_counts_matches_numpy():
     want = np.array([(win == ord(b)).sum(axis=0) for b in "ATGC"])
     assert np.array_equal(ps.letter_counts(seq, starts, 41), want)
     assert np.array_equal(ps.letter_pssm(win), want / len(starts))
+
+
+def test_kl_columns_equals_scipy_entropy():
+    from scipy.stats import entropy
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        p = rng.random((4, 41))
+        q = rng.random((4, 41))
+        p[:, rng.integers(41)] = [1, 0, 0, 0]
+        q[rng.integers(4), rng.integers(41)] = 0.0          # inf where p > 0
+        a, b = ps.kl_divergence_columns(p, q), entropy(p, q)
+        assert np.array_equal(a, b, equal_nan=True)
