@@ -191,3 +191,28 @@ def test_window_engine_matches_host_store():
             else:
                 assert x == y
     eng.close()
+
+
+def test_fused_slots_with_uneven_groups(engine_cls):
+    """Two mod types fused in one pass (light batch) where one (bin, mod type) group needs several LDS passes."""
+    spec = synth.SynthSpec(n_contigs=24, total_bp=1_200_000, n_bins=12, mod_types=("a", "m"), seed=55, min_contig_bp=9_000)
+    mg = synth.make_metagenome(spec)
+    eng = engine_cls()
+    _upload_metagenome(eng, mg, ("a", "m"))
+    bins = sorted(set(mg.bin_names))
+    zoo = synth.random_candidates(90, seed=21)
+    cands, expect = [], []
+    for bi, b in enumerate(bins):
+        contigs = [i for i, x in enumerate(mg.bin_names) if x == b]
+        for mt in ("a", "m"):
+            these = [(s, p) for s, p, t in zoo if t == mt]
+            these = these[:40] if (bi == 3 and mt == "a") else (these[:19] if (bi == 5 and mt == "m") else these[bi % 3:bi % 3 + 1 + bi % 2])
+            if not these:
+                continue
+            expect.append(_oracle_counts(mg, mt, contigs, these))
+            cands += [(Motif(s, p), mt, b) for s, p in these]
+    out = eng.score(cands)
+    st = eng.stats()
+    assert st["last_workgroups"] < 2 * 16 * len(bins) * 2      # fused launch: one workgroup column, not one per slot
+    assert np.array_equal(out, np.concatenate(expect))
+    eng.close()
