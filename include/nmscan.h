@@ -163,6 +163,30 @@ int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const ui
                  const uint8_t *req_sets, int32_t *out);
 
 /*
+ * Window extraction on the device (find_motifs_bin.py:625-686) — the windows never exist as bytes on the host.
+ *   nm_win_add_task_rows   the methylation windows of one search, gathered from the resident sequence planes:
+ *                          row i = (contig id as uploaded, position, minus strand flag); the window is
+ *                          seq[pos-pad : pos+pad+1] (seq.py:170-189), reverse-complemented for minus rows
+ *                          (find_motifs_bin.py:655-659).  Every row must satisfy pad < pos < len - pad (the
+ *                          reference's edge filter is the caller's job); width = 2*pad+1 <= 64.  A base that is not
+ *                          A/C/G/T becomes N — callers must keep contigs with other IUPAC letters on the host path
+ *                          (the reference raises KeyError there; nm_assembly_other_letters tells).
+ *   nm_contig_base_counts  out[contig] = number of positions p in [pad, len-pad) whose base is `base`
+ *                          ('A','C','G','T') = len(valid starts) of sample_n_subsequences (seq.py:202-225).
+ *   nm_bg_counts           background letter counts of the sampled sub-sequences: sample j = (contig, rank k) stands
+ *                          for the k-th (ascending) valid start of that contig; samples are grouped by task,
+ *                          task_begin[n_tasks+1] delimits them.  out = int64[n_tasks][4][width], rows A, T, G, C
+ *                          (DNAarray.pssm numerators, seq.py:391-422: exact letters only).
+ */
+int nm_win_add_task_rows(nm_ctx *ctx, uint32_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                         const uint8_t *minus, uint32_t pad, uint32_t *task_id);
+int nm_contig_base_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t *out);
+int nm_bg_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
+                 const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out);
+/* Number of assembly letters that are none of A C G T N (any case) seen by the last nm_upload_contigs. */
+int nm_assembly_other_letters(nm_ctx *ctx, uint64_t *n);
+
+/*
  * Hit positions of one candidate on one contig — the four arrays motif_model_contig returns with
  * save_motif_positions=True (find_motifs_bin.py:1322-1329), ascending.  which: 0 = index_meth_fwd,
  * 1 = index_nonmeth_fwd, 2 = index_meth_rev, 3 = index_nonmeth_rev.  Writes at most `capacity` positions to

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
                                                    const uint32_t *__restrict__ chunk_contig,
                                                    const uint32_t *__restrict__ chunk_first,
                                                    uint32_t *__restrict__ H, uint32_t *__restrict__ L,
-                                                   uint32_t *__restrict__ V) {
+                                                   uint32_t *__restrict__ V, unsigned long long *__restrict__ other) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t contig = chunk_contig[chunk];
     if (contig == 0xFFFFFFFFu) return;                               // pad chunk, planes already zero
@@ -108,6 +108,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         const unsigned long long bv = __ballot(valid);
         const unsigned long long bh = __ballot(valid && (c & 4));    // A=00 C=01 G=11 T=10 as (H,L) = bits 2,1
         const unsigned long long bl = __ballot(valid && (c & 2));
+        const unsigned long long bo = __ballot(p < len && !valid && c != 'N');   // IUPAC ambiguity codes etc.
+        if (bo && lane == 0) atomicAdd(other, (unsigned long long)__popcll(bo));
         if (lane < 2) {
             const size_t w = (size_t)chunk * CHUNK_WORDS + (size_t)it * 2 + lane;
             H[w] = (uint32_t)(bh >> (32 * lane));
@@ -390,6 +392,205 @@ __global__ __launch_bounds__(256) void win_request_kernel(const WinTask *__restr
     int *o = out + (size_t)r * out_stride;
     for (uint32_t i = threadIdx.x; i < 2 + 4 * WIN_MAX_W; i += blockDim.x)
         if (cnt[i]) atomicAdd(&o[i], cnt[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Window extraction on the device (find_motifs_bin.py:625-686): gather of the methylation windows from the resident
+// sequence planes, and the background sample (seq.py:202-225) as "k-th position whose base is X" through a rank
+// table (popcount prefix per 512-bp block, per contig).
+// ------------------------------------------------------------------------------------------------------
+constexpr int RANK_BLOCK_WORDS = 16;                          // 512 bp per rank entry
+constexpr int RANK_PER_CHUNK = CHUNK_WORDS / RANK_BLOCK_WORDS;
+
+__device__ __forceinline__ uint32_t base_word(uint32_t h, uint32_t l, uint32_t v, int b) {   // b: 0 A, 1 C, 2 G, 3 T
+    const uint32_t hh = (b >= 2) ? h : ~h;                    // A=00 C=01 G=11 T=10 as (H, L)
+    const uint32_t ll = (b == 1 || b == 2) ? l : ~l;
+    return v & hh & ll;
+}
+
+// bits [g, g+n) of a plane as the low n bits of a uint64, n <= 64; touches only the words that hold them
+__device__ __forceinline__ uint64_t plane_field(const uint32_t *__restrict__ P, uint64_t g, uint32_t n) {
+    const size_t w0 = (size_t)(g >> 5);
+    const uint32_t sh = (uint32_t)(g & 31);
+    uint64_t x = P[w0];
+    if (sh + n > 32) x |= (uint64_t)P[w0 + 1] << 32;
+    x >>= sh;
+    if (sh + n > 64) x |= (uint64_t)P[w0 + 2] << (64 - sh);
+    return n >= 64 ? x : (x & ((1ull << n) - 1));
+}
+
+// one wave per contig: rank[block] = number of positions with base b in the contig before the block
+__global__ __launch_bounds__(64) void rank_build_kernel(Planes s, const uint32_t *__restrict__ contig_chunk,
+                                                        const uint64_t *__restrict__ contig_len, int b,
+                                                        uint32_t *__restrict__ rank, uint64_t *__restrict__ total) {
+    const uint32_t ci = blockIdx.x, lane = threadIdx.x;
+    const uint32_t c0 = contig_chunk[ci];
+    const uint32_t nblk = (uint32_t)((contig_len[ci] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < nblk; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        uint32_t cnt = 0;
+        if (j < nblk) {
+            const size_t w = (size_t)c0 * CHUNK_WORDS + (size_t)j * RANK_BLOCK_WORDS;
+            for (int k = 0; k < RANK_BLOCK_WORDS; ++k) cnt += __popc(base_word(s.H[w + k], s.L[w + k], s.V[w + k], b));
+        }
+        uint32_t x = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((int)lane >= d) x += y;
+        }
+        if (j < nblk) rank[(size_t)c0 * RANK_PER_CHUNK + j] = carry + x - cnt;
+        carry += __shfl(x, 63);
+    }
+    if (lane == 0) total[ci] = carry;
+}
+
+// n_valid[contig] = positions p in [pad, len - pad) with base b
+__global__ void base_count_kernel(Planes s, const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ contig_len,
+                                  uint32_t n_contigs, int b, uint32_t pad, const uint64_t *__restrict__ total,
+                                  uint64_t *__restrict__ out) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= n_contigs) return;
+    const uint64_t len = contig_len[ci], g0 = (uint64_t)contig_chunk[ci] * CHUNK_BP;
+    if (len < 2ull * pad + 1) { out[ci] = 0; return; }
+    uint64_t n = total[ci];
+    if (pad) {
+        const uint64_t hh = plane_field(s.H, g0, pad), hl = plane_field(s.L, g0, pad), hv = plane_field(s.V, g0, pad);
+        const uint64_t th = plane_field(s.H, g0 + len - pad, pad), tl = plane_field(s.L, g0 + len - pad, pad),
+                       tv = plane_field(s.V, g0 + len - pad, pad);
+        const uint64_t head = hv & ((b >= 2) ? hh : ~hh) & ((b == 1 || b == 2) ? hl : ~hl);
+        const uint64_t tail = tv & ((b >= 2) ? th : ~th) & ((b == 1 || b == 2) ? tl : ~tl);
+        n -= __popcll(head) + __popcll(tail);
+    }
+    out[ci] = n;
+}
+
+struct BgBlock { uint32_t task, begin_lo, begin_hi, count; };
+
+// Background sample: thread per sample finds the k-th valid centre of its contig (binary search in the rank table,
+// scan of one 512-bp block, select in a word), reads the 2*pad+1 letters around it; per column the wave ballots the
+// four letters and lane 0 adds the popcounts into the workgroup's LDS table; one workgroup serves one task.
+__global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t *__restrict__ rank,
+                                                        const uint32_t *__restrict__ contig_chunk,
+                                                        const uint64_t *__restrict__ contig_len,
+                                                        const BgBlock *__restrict__ blocks,
+                                                        const uint32_t *__restrict__ sample_contig,
+                                                        const uint32_t *__restrict__ sample_rank, int b, uint32_t pad,
+                                                        unsigned long long *__restrict__ out, unsigned int *err) {
+    __shared__ uint32_t cnt[4 * WIN_MAX_W];
+    const BgBlock blk = blocks[blockIdx.x];
+    const uint64_t begin = ((uint64_t)blk.begin_hi << 32) | blk.begin_lo;
+    const uint32_t W = 2 * pad + 1, lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x; i < 4 * WIN_MAX_W; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < blk.count; i0 += blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool on = i < blk.count;
+        uint64_t fh = 0, fl = 0, fv = 0;
+        if (on) {
+            const uint32_t ci = sample_contig[begin + i];
+            const uint32_t c0 = contig_chunk[ci];
+            const uint64_t g0 = (uint64_t)c0 * CHUNK_BP;
+            const uint32_t nblk = (uint32_t)((contig_len[ci] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
+            uint32_t k = sample_rank[begin + i];
+            if (pad) {
+                const uint64_t hh = plane_field(s.H, g0, pad), hl = plane_field(s.L, g0, pad), hv = plane_field(s.V, g0, pad);
+                k += __popcll(hv & ((b >= 2) ? hh : ~hh) & ((b == 1 || b == 2) ? hl : ~hl));
+            }
+            const uint32_t *rk = rank + (size_t)c0 * RANK_PER_CHUNK;
+            uint32_t lo = 0, hi = nblk - 1;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (rk[mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            uint32_t r = k - rk[lo];
+            const size_t w = (size_t)c0 * CHUNK_WORDS + (size_t)lo * RANK_BLOCK_WORDS;
+            uint32_t x = 0;
+            int q = 0;
+            for (; q < RANK_BLOCK_WORDS; ++q) {
+                x = base_word(s.H[w + q], s.L[w + q], s.V[w + q], b);
+                const uint32_t pc = __popc(x);
+                if (r < pc) break;
+                r -= pc;
+            }
+            if (q == RANK_BLOCK_WORDS) {
+                atomicOr(err, 4u);                       // rank beyond the contig's valid starts
+                on = false;
+            } else {
+                for (; r; --r) x &= x - 1;
+                const uint64_t centre = (uint64_t)(w + q) * 32 + (uint32_t)__builtin_ctz(x);
+                if (centre < g0 + pad) {
+                    atomicOr(err, 4u);
+                    on = false;
+                } else {
+                    fh = plane_field(s.H, centre - pad, W);
+                    fl = plane_field(s.L, centre - pad, W);
+                    fv = plane_field(s.V, centre - pad, W);
+                }
+            }
+        }
+        for (uint32_t col = 0; col < W; ++col) {
+            const bool v = on && ((fv >> col) & 1), h = (fh >> col) & 1, l = (fl >> col) & 1;
+            const unsigned long long ba = __ballot(v && !h && !l), bt = __ballot(v && h && !l);
+            const unsigned long long bg = __ballot(v && h && l), bc = __ballot(v && !h && l);
+            if (lane == 0) {                              // rows A, T, G, C (constants.py:1)
+                if (ba) atomicAdd(&cnt[0 * WIN_MAX_W + col], (uint32_t)__popcll(ba));
+                if (bt) atomicAdd(&cnt[1 * WIN_MAX_W + col], (uint32_t)__popcll(bt));
+                if (bg) atomicAdd(&cnt[2 * WIN_MAX_W + col], (uint32_t)__popcll(bg));
+                if (bc) atomicAdd(&cnt[3 * WIN_MAX_W + col], (uint32_t)__popcll(bc));
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *o = out + (size_t)blk.task * 4 * WIN_MAX_W;
+    for (uint32_t i = threadIdx.x; i < 4 * WIN_MAX_W; i += blockDim.x)
+        if (cnt[i]) atomicAdd(&o[i], (unsigned long long)cnt[i]);
+}
+
+// Methylation windows of one task from the sequence planes: a wave packs 64 windows; per column it ballots the five
+// window planes (A, C, G, T, N) and lanes 0 / 1 store the two words.  Minus rows are reverse-complemented
+// (complement = flip H in the (H, L) code; N stays N).
+__global__ __launch_bounds__(256) void win_gather_kernel(WinTask t, Planes s, const uint64_t *__restrict__ row_centre,
+                                                         const uint8_t *__restrict__ row_minus, uint32_t pad,
+                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ alive) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t i = (uint64_t)wave * 64 + lane;
+    if ((uint64_t)wave * 64 >= t.n) return;
+    const bool on = i < t.n;
+    const uint32_t W = t.width;
+    uint64_t fh = 0, fl = 0, fv = 0;
+    if (on) {
+        const uint64_t g = row_centre[i] - pad;
+        fh = plane_field(s.H, g, W);
+        fl = plane_field(s.L, g, W);
+        fv = plane_field(s.V, g, W);
+        if (row_minus[i]) {
+            fh = __brevll(fh) >> (64 - W);
+            fl = __brevll(fl) >> (64 - W);
+            fv = __brevll(fv) >> (64 - W);
+            fh = ~fh & fv;
+        }
+    }
+    const uint32_t w = wave * 2 + lane;                   // word written by lanes 0 and 1
+    const bool writer = lane < 2 && w < t.nw;
+    const uint32_t shift = 32 * (lane & 1);
+    for (uint32_t col = 0; col < W; ++col) {
+        const bool v = (fv >> col) & 1, h = (fh >> col) & 1, l = (fl >> col) & 1;
+        const unsigned long long ba = __ballot(on && v && !h && !l), bc = __ballot(on && v && !h && l);
+        const unsigned long long bg = __ballot(on && v && h && l), bt = __ballot(on && v && h && !l);
+        const unsigned long long bn = __ballot(on && !v);
+        if (writer) {
+            uint32_t *p = planes + t.plane_off + (uint64_t)col * 5 * t.nw + w;
+            p[0] = (uint32_t)(ba >> shift);
+            p[(uint64_t)t.nw] = (uint32_t)(bc >> shift);
+            p[2ull * t.nw] = (uint32_t)(bg >> shift);
+            p[3ull * t.nw] = (uint32_t)(bt >> shift);
+            p[4ull * t.nw] = (uint32_t)(bn >> shift);
+        }
+    }
+    const unsigned long long bal = __ballot(on);
+    if (writer) alive[t.alive_off + w] = (uint32_t)(bal >> shift);
 }
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
@@ -754,6 +955,11 @@ struct nm_ctx {
     unsigned long long *d_counts = nullptr;
     size_t counts_cap = 0;
     unsigned int *d_err = nullptr;
+    // window extraction: per-base rank tables over the sequence planes (built on first use), other-letter count
+    uint32_t *d_rank[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_base_total[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long *d_other = nullptr;
+    uint64_t other_letters = 0;
     uint64_t launches = 0, last_wgs = 0, last_compact = 0, last_general = 0;
 };
 
@@ -1072,6 +1278,7 @@ int nm_ctx_create(int device, nm_ctx **out) {
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc(&c->d_err, sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&c->d_other, sizeof(unsigned long long)));
     *out = c;
     return NM_OK;
 }
@@ -1085,6 +1292,12 @@ static void free_assembly(nm_ctx *c) {
     c->d_contig_chunk = nullptr;
     c->d_contig_len = nullptr;
     c->d_segments = nullptr;
+    for (int b = 0; b < 4; ++b) {
+        if (c->d_rank[b]) (void)hipFree(c->d_rank[b]);
+        if (c->d_base_total[b]) (void)hipFree(c->d_base_total[b]);
+        c->d_rank[b] = nullptr;
+        c->d_base_total[b] = nullptr;
+    }
     for (auto &s : c->slots) {
         for (auto &p : s.planes) {
             if (p) (void)hipFree(p);
@@ -1111,6 +1324,7 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (c->d_win_alive) (void)hipFree(c->d_win_alive);
     if (c->d_win_tasks) (void)hipFree(c->d_win_tasks);
     if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_other) (void)hipFree(c->d_other);
     for (auto &pr : c->ev_pool) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -1198,8 +1412,9 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     if (!on_device) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_other, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, d_chunk_contig,
-                       c->d_contig_chunk, c->dH, c->dL, c->dV);
+                       c->d_contig_chunk, c->dH, c->dL, c->dV, c->d_other);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(needs_v_kernel, dim3(c->n_chunks), dim3(CHUNK_WORDS), 0, c->stream, c->dV, c->d_needs_v, c->n_chunks);
     HIP_TRY(hipGetLastError());
@@ -1211,7 +1426,10 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     c->n_segments = (uint32_t)segs.size();
     HIP_TRY(hipMalloc(&c->d_segments, segs.size() * sizeof(uint4)));
     HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    unsigned long long other = 0;
+    HIP_TRY(hipMemcpyAsync(&other, c->d_other, sizeof other, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->other_letters = other;
     if (!on_device) (void)hipFree(d_ascii);
     (void)hipFree(d_off);
     (void)hipFree(d_chunk_contig);
@@ -1667,6 +1885,170 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, hs + o_out, (size_t)n_req * stride * 4);
+    return NM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// window extraction on the device
+// ------------------------------------------------------------------------------------------------------
+static int base_index(uint8_t base) {
+    switch (base) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
+}
+
+static Planes seq_planes(const nm_ctx *c) {
+    Planes p;
+    p.H = c->dH;
+    p.L = c->dL;
+    p.V = c->dV;
+    p.needs_v = c->d_needs_v;
+    return p;
+}
+
+static int ensure_rank(nm_ctx *c, int b) {
+    if (c->d_rank[b]) return NM_OK;
+    HIP_TRY(hipMalloc(&c->d_rank[b], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
+    HIP_TRY(hipMalloc(&c->d_base_total[b], (size_t)c->n_contigs * 8));
+    hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c), c->d_contig_chunk,
+                       c->d_contig_len, b, c->d_rank[b], c->d_base_total[b]);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+int nm_assembly_other_letters(nm_ctx *c, uint64_t *n) {
+    if (!c || !n) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    *n = c->other_letters;
+    return NM_OK;
+}
+
+int nm_contig_base_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t *out) {
+    if (!c || !out) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    const int b = base_index(base);
+    if (b < 0) return fail(NM_EINVAL, "base must be one of A C G T");
+    if (2 * pad + 1 > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", 2 * pad + 1, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_rank(c, b);
+    if (rc) return rc;
+    uint64_t *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 8));
+    hipLaunchKernelGGL(base_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, seq_planes(c),
+                       c->d_contig_chunk, c->d_contig_len, c->n_contigs, b, pad, c->d_base_total[b], d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)c->n_contigs * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_out);
+    return NM_OK;
+}
+
+int nm_bg_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
+                 const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out) {
+    if (!c || !task_begin || !out) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    const int b = base_index(base);
+    if (b < 0) return fail(NM_EINVAL, "base must be one of A C G T");
+    const uint32_t W = 2 * pad + 1;
+    if (W > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", W, WIN_MAX_W);
+    if (n_tasks == 0) return NM_OK;
+    if (n_samples && (!sample_contig || !sample_rank)) return fail(NM_EINVAL, "NULL sample column");
+    if (task_begin[0] != 0 || task_begin[n_tasks] != n_samples) return fail(NM_EINVAL, "task_begin must run from 0 to n_samples");
+    constexpr uint32_t SPB = 2048;                       // samples per workgroup
+    std::vector<BgBlock> blocks;
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        if (task_begin[t + 1] < task_begin[t]) return fail(NM_EINVAL, "task_begin must be non-decreasing");
+        for (uint64_t s0 = task_begin[t]; s0 < task_begin[t + 1]; s0 += SPB)
+            blocks.push_back(BgBlock{t, (uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)std::min<uint64_t>(SPB, task_begin[t + 1] - s0)});
+    }
+    for (uint64_t i = 0; i < n_samples; ++i)
+        if (sample_contig[i] >= c->n_contigs) return fail(NM_EINVAL, "sample %llu: contig %u >= %u", (unsigned long long)i, sample_contig[i], c->n_contigs);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_rank(c, b);
+    if (rc) return rc;
+    const size_t o_rank = (size_t)n_samples * 4, o_blk = (o_rank + (size_t)n_samples * 4 + 15) & ~(size_t)15;
+    const size_t o_out = (o_blk + blocks.size() * sizeof(BgBlock) + 15) & ~(size_t)15;
+    const size_t out_bytes = (size_t)n_tasks * 4 * WIN_MAX_W * 8;
+    rc = ensure_stage(c, o_out + out_bytes);
+    if (rc) return rc;
+    uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    if (n_samples) {
+        memcpy(hs, sample_contig, (size_t)n_samples * 4);
+        memcpy(hs + o_rank, sample_rank, (size_t)n_samples * 4);
+    }
+    if (!blocks.empty()) memcpy(hs + o_blk, blocks.data(), blocks.size() * sizeof(BgBlock));
+    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(ds + o_out, 0, out_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
+    if (!blocks.empty()) {
+        hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)blocks.size()), dim3(256), 0, c->stream, seq_planes(c),
+                           c->d_rank[b], c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_blk),
+                           reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint32_t *>(ds + o_rank), b, pad,
+                           reinterpret_cast<unsigned long long *>(ds + o_out), c->d_err);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    rc = release_stage(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err) return fail(NM_EINVAL, "a sample rank is not below the contig's number of valid starts (nm_contig_base_counts)");
+    const uint64_t *ho = reinterpret_cast<const uint64_t *>(hs + o_out);
+    for (uint32_t t = 0; t < n_tasks; ++t)
+        for (uint32_t r = 0; r < 4; ++r)
+            for (uint32_t col = 0; col < W; ++col)
+                out[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * WIN_MAX_W + col];
+    return NM_OK;
+}
+
+int nm_win_add_task_rows(nm_ctx *c, uint32_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                         const uint8_t *minus, uint32_t pad, uint32_t *task_id) {
+    if (!c || !task_id || (n_rows && (!contig_id || !position || !minus))) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    const uint32_t width = 2 * pad + 1;
+    if (width > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", width, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    WinTask t{};
+    t.n = n_rows;
+    t.nw = (n_rows + 31) / 32;
+    t.width = width;
+    t.plane_off = c->win_planes_used;
+    t.alive_off = c->win_alive_used;
+    int rc = win_grow(c, &c->d_win_planes, &c->win_planes_cap, c->win_planes_used, (uint64_t)width * 5 * t.nw);
+    if (rc) return rc;
+    rc = win_grow(c, &c->d_win_alive, &c->win_alive_cap, c->win_alive_used, t.nw);
+    if (rc) return rc;
+    if (n_rows) {
+        const size_t o_minus = (size_t)n_rows * 8;
+        rc = ensure_stage(c, o_minus + n_rows);
+        if (rc) return rc;
+        uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+        uint64_t *centre = reinterpret_cast<uint64_t *>(hs);
+        for (uint32_t i = 0; i < n_rows; ++i) {
+            const uint32_t ci = contig_id[i];
+            if (ci >= c->n_contigs) return fail(NM_EINVAL, "row %u: contig %u >= %u", i, ci, c->n_contigs);
+            if (!(position[i] > pad && (uint64_t)position[i] + pad < c->contig_len[ci]))
+                return fail(NM_EINVAL, "row %u: position %u is within %u bp of an end of contig %u (seq.py:186)", i, position[i], pad, ci);
+            centre[i] = (uint64_t)c->contig_chunk[ci] * CHUNK_BP + position[i];
+        }
+        memcpy(hs + o_minus, minus, n_rows);
+        HIP_TRY(hipMemcpyAsync(ds, hs, o_minus + n_rows, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(win_gather_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
+                           reinterpret_cast<const uint64_t *>(ds), ds + o_minus, pad, c->d_win_planes, c->d_win_alive);
+        HIP_TRY(hipGetLastError());
+        rc = release_stage(c);
+        if (rc) return rc;
+    }
+    c->win_planes_used += (uint64_t)width * 5 * t.nw;
+    c->win_alive_used += t.nw;
+    *task_id = (uint32_t)c->win_tasks.size();
+    c->win_tasks.push_back(t);
+    c->win_tasks_dirty = true;
     return NM_OK;
 }
 

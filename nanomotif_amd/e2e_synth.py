@@ -101,8 +101,9 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None):
                           minimum_kl_divergence=0.05, score_threshold=1.5, log_dir=None, seed=1, output_dir=None)
     t0 = time.perf_counter()
     scorer = engine_scorer(engine, 0.3, 0.7)
-    from .engine import DeviceWindowStore
-    rows, scorer = discover(cfg, filtered, scorer, window_store=DeviceWindowStore(engine))
+    from .main import device_window_pipeline
+    store, extractor = device_window_pipeline(engine, dict(zip(mg.names, (int(x) for x in mg.lengths))), list(mg.names), cfg.padding)
+    rows, scorer = discover(cfg, filtered, scorer, window_store=store, extractor=extractor)
     t["search_s"] = time.perf_counter() - t0
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
     return rows, t

@@ -33,12 +33,28 @@ class DeviceWindowStore:
 
     STRIDE = 2 + 4 * 64
 
-    def __init__(self, engine):
+    def __init__(self, engine, allreduce=None):
+        """``allreduce``: callable summing an int32 numpy array over the ranks of a multi-GPU run, in which every rank
+        holds only the windows of its own contigs (tasks added with ``add_task_rows``)."""
         self.engine = engine
+        self.allreduce = allreduce
         self.task_id = {}
         self.totals = {}
         self.width = {}
         _lib.check(engine.lib.nm_win_clear(engine.ctx))
+
+    def add_task_rows(self, key, contig, position, minus, pad, total=None):
+        """Windows gathered on the device from the resident sequence planes (nm_win_add_task_rows): rows are
+        (engine contig index, position, minus flag), already edge-filtered.  ``total``: number of windows of the task
+        over all ranks (default: the rows given)."""
+        contig = np.ascontiguousarray(contig, dtype=np.uint32)
+        position = np.ascontiguousarray(position, dtype=np.uint32)
+        minus = np.ascontiguousarray(minus, dtype=np.uint8)
+        tid = C.c_uint32(0)
+        _lib.check(self.engine.lib.nm_win_add_task_rows(self.engine.ctx, len(contig), _ptr(contig, C.c_uint32),
+                                                        _ptr(position, C.c_uint32), _ptr(minus, C.c_uint8), int(pad), C.byref(tid)))
+        self.task_id[key], self.width[key] = int(tid.value), 2 * int(pad) + 1
+        self.totals[key] = int(len(contig) if total is None else total)
 
     def add_task(self, key, sets: np.ndarray):
         sets = np.ascontiguousarray(sets, dtype=np.uint8)
@@ -62,6 +78,8 @@ class DeviceWindowStore:
             res = np.zeros((n, self.STRIDE), dtype=np.int32)
             _lib.check(self.engine.lib.nm_win_batch(self.engine.ctx, n, _ptr(task, C.c_uint32), _ptr(kind, C.c_uint8),
                                                     _ptr(sets, C.c_uint8), res.ctypes.data_as(C.POINTER(C.c_int32))))
+            if self.allreduce is not None:
+                res = self.allreduce(res)
             for j, (i, k, r) in enumerate(dev):
                 if r.kind == "remove":
                     out[i] = (int(res[j, 0]), int(res[j, 1]))
@@ -69,6 +87,95 @@ class DeviceWindowStore:
                     w = self.width[k]
                     out[i] = (int(res[j, 0]), res[j, 2:].reshape(4, 64)[:, :w].astype(np.int64))
         return out
+
+
+class DeviceWindowExtractor:
+    """``extract_windows`` (find_motifs_bin.py:625-686) with the window gather and the background letter counts on the
+    device: the host only draws the sample indices (``random.sample`` order and consumption are the reference's) and
+    applies the edge filter to the row positions; sequences are read from the resident bit planes.
+
+    ``lengths`` / ``n_valid[base]``: contig name -> length / number of valid sample starts (``contig_base_counts``),
+    for EVERY contig of the data set; ``resident``: name -> engine contig index for the contigs this rank holds (all of
+    them on one GPU).  Samples and rows of other contigs are left to their rank; ``allreduce_i64`` sums the counts."""
+
+    MAX_SAMPLES_PER_CALL = 4 << 20
+
+    def __init__(self, engine, store: DeviceWindowStore, lengths, n_valid, padding, resident=None, allreduce_i64=None,
+                 background_sampling_frequency=0.01):
+        self.engine, self.store, self.lengths, self.n_valid, self.pad = engine, store, lengths, n_valid, int(padding)
+        self.resident = engine.contig_index if resident is None else resident
+        self.allreduce_i64 = allreduce_i64
+        self.freq = background_sampling_frequency
+        self.tasks = []           # (key, base, n_bg, [sample contig arrays], [sample rank arrays])
+
+    def plan(self, key, plus_pos: dict, minus_pos: dict, mod_type: str) -> bool:
+        """One task; consumes the interpreter's RNG exactly like extract_windows.  False = no methylation windows."""
+        import math
+        from .search import _native_random_sample
+        base = MOD_TYPE_TO_CANONICAL[mod_type]
+        pad, W = self.pad, 2 * self.pad + 1
+        nv_of = self.n_valid[base]
+        s_contig, s_rank, rows_c, rows_p, rows_m = [], [], [], [], []
+        n_bg = total = 0
+        empty = np.zeros(0, np.int64)
+        for name in sorted(plus_pos.keys() | minus_pos.keys()):
+            length = int(self.lengths[name])
+            n_samples = int(max(math.ceil(length * self.freq), 50))
+            if n_samples > length - W + 1:
+                raise ValueError("Too many samples requested for unique subsequences")
+            nv = int(nv_of[name])
+            if nv < n_samples:
+                raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
+            ranks = _native_random_sample(nv, n_samples)
+            n_bg += n_samples
+            ci = self.resident.get(name)
+            if ci is not None:
+                s_contig.append(np.full(n_samples, ci, dtype=np.uint32))
+                s_rank.append(ranks.astype(np.uint32))
+            p, m = plus_pos.get(name, empty), minus_pos.get(name, empty)
+            p = p[(p > pad) & (p < length - pad)]
+            m = m[(m > pad) & (m < length - pad)]
+            if len(p) + len(m) == 0:
+                return False                         # find_motifs_bin.py:662-664
+            total += len(p) + len(m)
+            if ci is not None:
+                rows_c.append(np.full(len(p) + len(m), ci, dtype=np.uint32))
+                rows_p += [p, m]
+                rows_m.append(np.concatenate([np.zeros(len(p), np.uint8), np.ones(len(m), np.uint8)]))
+        if total == 0 or n_bg == 0:
+            return False
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
+        self.store.add_task_rows(key, cat(rows_c, np.uint32), cat(rows_p, np.uint32), cat(rows_m, np.uint8), pad, total=total)
+        self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
+        return True
+
+    def finish(self) -> dict:
+        """Background PSSM (``background_sequences.pssm()``, float64[4, W]) of every planned task."""
+        W = 2 * self.pad + 1
+        counts = np.zeros((len(self.tasks), 4, W), dtype=np.int64)
+        for base in sorted({t[1] for t in self.tasks}):
+            idx = [i for i, t in enumerate(self.tasks) if t[1] == base]
+            lo = 0
+            while lo < len(idx):
+                hi, n = lo, 0
+                while hi < len(idx) and (hi == lo or n + len(self.tasks[idx[hi]][3]) <= self.MAX_SAMPLES_PER_CALL):
+                    n += len(self.tasks[idx[hi]][3])
+                    hi += 1
+                part = idx[lo:hi]
+                begin = np.zeros(len(part) + 1, dtype=np.uint64)
+                np.cumsum([len(self.tasks[i][3]) for i in part], out=begin[1:])
+                sc = np.concatenate([self.tasks[i][3] for i in part]) if n else np.zeros(0, np.uint32)
+                sr = np.concatenate([self.tasks[i][4] for i in part]) if n else np.zeros(0, np.uint32)
+                out = np.zeros((len(part), 4, W), dtype=np.int64)
+                _lib.check(self.engine.lib.nm_bg_counts(self.engine.ctx, ord(base), self.pad, n, _ptr(sc, C.c_uint32), _ptr(sr, C.c_uint32),
+                                                        len(part), _ptr(begin, C.c_uint64), _ptr(out, C.c_int64)))
+                counts[part] = out
+                lo = hi
+        if self.allreduce_i64 is not None:
+            counts = self.allreduce_i64(counts)
+        res = {t[0]: counts[i] / t[2] for i, t in enumerate(self.tasks)}
+        self.tasks = []
+        return res
 
 
 class ScanEngine:
@@ -134,6 +241,19 @@ class ScanEngine:
         self.contig_lengths = lengths.astype(np.int64)
         self.contig_bin = bin_ids
         self.slot_of_mod = {}
+
+    def contig_base_counts(self, base: str, padding: int) -> np.ndarray:
+        """Per resident contig: positions p in [padding, len - padding) whose base is ``base`` — the number of valid
+        starts ``sample_n_subsequences`` draws from (seq.py:202-225)."""
+        out = np.zeros(len(self.contig_names), dtype=np.uint64)
+        _lib.check(self.lib.nm_contig_base_counts(self.ctx, ord(base), int(padding), _ptr(out, C.c_uint64)))
+        return out
+
+    def other_letters(self) -> int:
+        """Assembly letters that are none of A C G T N (the reference's window code raises KeyError on them)."""
+        n = C.c_uint64(0)
+        _lib.check(self.lib.nm_assembly_other_letters(self.ctx, C.byref(n)))
+        return int(n.value)
 
     # ------------------------------------------------------------------ pileup
     def upload_pileup(self, mod_type, contig_id, position, strand, fraction_mod, low=0.3, high=0.7, append=False,

@@ -234,11 +234,14 @@ class FilteredPileup:
 
 
 def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepScorer, rank=0, bgzip_order=False,
-             window_store=None):
+             window_store=None, extractor=None):
     """Run every (bin, mod type) task of the data set.  ``filtered``: see FilteredPileup (identical on every rank);
     ``scorer``: see ``engine_scorer``; ``window_store``: where the methylation windows live (default: host numpy;
-    the CLI passes the engine's device store).  Returns (list of MotifRow, scorer) — identical on every rank."""
+    the CLI passes the engine's device store); ``extractor``: an ``engine.DeviceWindowExtractor`` bound to that store
+    to gather windows / count the background on the device instead of from ``cfg.assembly`` on the host.
+    Returns (list of MotifRow, scorer) — identical on every rank."""
     store = window_store if window_store is not None else HostWindowStore()
+    planned = []
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)
@@ -255,10 +258,16 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 continue
             if not bgzip_order:
                 random.seed(cfg.seed)
-            windows = extract_windows(cfg.assembly, plus, minus, mod_type, cfg.padding)
-            if windows is None:
-                log.info(f"[{bin_name} {mod_type}] No methylation sequences found")
-                continue
+            if extractor is not None:
+                windows = None
+                if not extractor.plan((bin_name, mod_type), plus, minus, mod_type):
+                    log.info(f"[{bin_name} {mod_type}] No methylation sequences found")
+                    continue
+            else:
+                windows = extract_windows(cfg.assembly, plus, minus, mod_type, cfg.padding)
+                if windows is None:
+                    log.info(f"[{bin_name} {mod_type}] No methylation sequences found")
+                    continue
             stage_writer = None
             temp_dir = None
             if out_dir and rank == 0:
@@ -266,8 +275,15 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 os.makedirs(pre, exist_ok=True)
                 stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
                 temp_dir = os.path.join(out_dir, "temp", bin_name)
+            if extractor is not None:
+                planned.append(((bin_name, mod_type), stage_writer, temp_dir))
+                continue
             store.add_task((bin_name, mod_type), windows[0])
             tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
+    if extractor is not None:
+        pssms = extractor.finish()
+        for key, stage_writer, temp_dir in planned:
+            tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
     results = run_lockstep(tasks, scorer, store.execute)
     rows = []
     for key in tasks:

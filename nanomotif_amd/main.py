@@ -19,7 +19,7 @@ import numpy as np
 
 from . import fasta, pileup as pileup_mod, postprocess
 from .argparser import __version__, create_parser
-from .find_motifs_bin import FilteredPileup, ProcessorConfig, discover, engine_scorer
+from .find_motifs_bin import FilteredPileup, ProcessorConfig, allreduce_counts, discover, engine_scorer
 from .motif import MOD_TYPE_TO_CANONICAL
 from .shard import assign_contigs
 
@@ -129,8 +129,8 @@ def find_motifs_bin(args):
         eng.close()
         return None
     scorer = engine_scorer(eng, low, high, use_dist=world > 1)
-    from .engine import DeviceWindowStore
-    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip, window_store=DeviceWindowStore(eng))
+    store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
+    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip, window_store=store, extractor=extractor)
     eng.close()
     if not rows:
         log.info("No motifs were identified")
@@ -144,6 +144,32 @@ def find_motifs_bin(args):
         postprocess.write_motif_formatted(rows, args.out + "/bin-motifs.tsv")
     log.info(f"Identified {len(rows)} motifs in {len({r.reference for r in rows})} bins")
     return rows
+
+
+def device_window_pipeline(eng, lengths: dict, mine: list, padding: int, world: int = 1):
+    """(window store, extractor) for ``discover``: windows are gathered and the background is counted on the device,
+    every rank for its own contigs, with the per-request counts summed over the ranks.  An assembly with letters
+    other than A C G T N keeps window extraction on the host (the reference raises KeyError when a window meets one,
+    seq.py:474-478, and so does the host path); then every rank holds all windows."""
+    import torch.distributed as dist
+    from .engine import DeviceWindowExtractor, DeviceWindowStore
+    other = np.array([eng.other_letters()], dtype=np.int64)
+    if world > 1:
+        other = allreduce_counts(other)
+    if int(other[0]):
+        log.info(f"{int(other[0])} assembly letters outside ACGTN: window extraction stays on the host")
+        return DeviceWindowStore(eng), None
+    n_valid = {}
+    for base in sorted({MOD_TYPE_TO_CANONICAL[mt] for mt in pileup_mod.MOD_TYPES}):
+        local = dict(zip(mine, eng.contig_base_counts(base, padding).tolist()))
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, local)
+            local = {k: v for g in gathered for k, v in g.items()}
+        n_valid[base] = local
+    reduce = allreduce_counts if world > 1 else None
+    store = DeviceWindowStore(eng, allreduce=reduce)
+    return store, DeviceWindowExtractor(eng, store, lengths, n_valid, padding, resident=eng.contig_index, allreduce_i64=reduce)
 
 
 def check_installation():

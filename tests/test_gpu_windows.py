@@ -1,0 +1,133 @@
+"""Window extraction on the device (nm_win_add_task_rows / nm_contig_base_counts / nm_bg_counts) against the host numpy
+path of the same interface (search.extract_windows, itself pinned to the reference by golden g3/g4)."""
+import random
+
+import numpy as np
+import pytest
+
+from nanomotif_amd import search as ps
+from nanomotif_amd.motif import Motif
+
+pytestmark = pytest.mark.gpu
+
+
+def _assembly(rng, lengths, n_frac=0.0005):
+    seqs = {}
+    for i, n in enumerate(lengths):
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=n, p=[0.3, 0.2, 0.2, 0.3])
+        s[rng.random(n) < n_frac] = ord("N")
+        if i % 3 == 0:
+            s[:25] = ord("A")                         # valid centres inside the edge padding must not be counted
+            s[-25:] = ord("C")
+        seqs[f"contig_{i:03d}"] = s
+    return seqs
+
+
+def _rows(rng, seqs, base):
+    plus, minus = {}, {}
+    comp = {"A": "T", "C": "G"}[base]
+    for name, s in seqs.items():
+        p = np.flatnonzero(s == ord(base))
+        m = np.flatnonzero(s == ord(comp))
+        plus[name] = np.sort(rng.choice(p, size=min(len(p), max(1, len(s) // 200)), replace=False)).astype(np.int64)
+        minus[name] = np.sort(rng.choice(m, size=min(len(m), max(1, len(s) // 300)), replace=False)).astype(np.int64)
+        # rows inside the edge padding exist in real pileups: both paths must drop them
+        plus[name] = np.unique(np.concatenate([plus[name], [0, 3, 20, len(s) - 21, len(s) - 20, len(s) - 1]]))
+    return plus, minus
+
+
+@pytest.mark.parametrize("padding", [20, 7])
+def test_device_extraction_matches_host(padding):
+    from nanomotif_amd.engine import DeviceWindowExtractor, DeviceWindowStore, ScanEngine
+    rng = np.random.default_rng(5)
+    lengths = [6_000, 8_191, 8_192, 8_193, 16_400, 70_000, 5_500, 300_000]
+    seqs = _assembly(rng, lengths)
+    names = list(seqs)
+    bins = [f"bin{i % 3}" for i in range(len(names))]
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, [seqs[n] for n in names], bins)
+    assert eng.other_letters() == 0
+    W = 2 * padding + 1
+    # valid-start counts
+    for base in "ACGT":
+        got = eng.contig_base_counts(base, padding)
+        want = [int((seqs[n][padding:len(seqs[n]) - padding] == ord(base)).sum()) for n in names]
+        assert got.tolist() == want
+    n_valid = {b: dict(zip(names, eng.contig_base_counts(b, padding).tolist())) for b in "AC"}
+    lengths_of = {n: len(seqs[n]) for n in names}
+    dev_store, host_store = DeviceWindowStore(eng), ps.HostWindowStore()
+    ext = DeviceWindowExtractor(eng, dev_store, lengths_of, n_valid, padding)
+    keys, host_pssm = [], {}
+    for b in sorted(set(bins)):
+        members = [n for n, x in zip(names, bins) if x == b]
+        for mt, base in (("a", "A"), ("m", "C")):
+            plus, minus = _rows(rng, {n: seqs[n] for n in members}, base)
+            key = (b, mt)
+            random.seed(11)
+            host = ps.extract_windows(seqs, plus, minus, mt, padding)
+            state_after_host = random.getstate()
+            random.seed(11)
+            assert ext.plan(key, plus, minus, mt)
+            assert random.getstate() == state_after_host          # same RNG consumption
+            host_store.add_task(key, host[0])
+            host_pssm[key] = host[1]
+            keys.append(key)
+    dev_pssm = ext.finish()
+    for key in keys:
+        assert np.array_equal(dev_pssm[key], host_pssm[key]), key          # counts / n: bitwise equal
+    pad = padding
+    motifs = [Motif("." * pad + "A" + "." * pad, pad), Motif("." * pad + "C" + "." * pad, pad),
+              Motif("." * (pad - 1) + "GATC" + "." * (pad - 2), pad), Motif("." * (pad - 2) + "[AG]CA.T" + "." * (pad - 2), pad),
+              Motif("T" + "." * (pad - 1) + "C" + "." * (pad - 1) + "G", pad)]
+    for rnd, kind in enumerate(["total", "pssm", "pssm", "pssm", "remove", "pssm", "remove", "pssm", "pssm"]):
+        m = motifs[rnd % len(motifs)]
+        batch = [(k, ps.WinReq(kind, None if kind == "total" else m)) for k in keys]
+        a, b = dev_store.execute(batch), host_store.execute(batch)
+        for x, y in zip(a, b):
+            if kind == "pssm":
+                assert x[0] == y[0]
+                assert (y[1] is None and x[0] == 0) or np.array_equal(x[1], y[1])
+            else:
+                assert x == y
+    eng.close()
+
+
+def test_task_without_windows_and_bad_rows():
+    from nanomotif_amd import _lib
+    from nanomotif_amd.engine import DeviceWindowExtractor, DeviceWindowStore, ScanEngine
+    rng = np.random.default_rng(9)
+    seqs = _assembly(rng, [9_000, 12_000], n_frac=0)
+    names = list(seqs)
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, [seqs[n] for n in names], ["b", "b"])
+    store = DeviceWindowStore(eng)
+    n_valid = {b: dict(zip(names, eng.contig_base_counts(b, 20).tolist())) for b in "AC"}
+    ext = DeviceWindowExtractor(eng, store, {n: len(seqs[n]) for n in names}, n_valid, 20)
+    # second contig has rows, but all within the edge padding: the reference gives up on the whole task (:662-664)
+    plus = {names[0]: np.array([100, 200], dtype=np.int64), names[1]: np.array([5, 11_995], dtype=np.int64)}
+    random.seed(3)
+    host = ps.extract_windows(seqs, plus, {}, "a", 20)
+    st = random.getstate()
+    random.seed(3)
+    assert host is None and ext.plan(("b", "a"), plus, {}, "a") is False
+    assert random.getstate() == st
+    assert ext.finish() == {}
+    # the C ABI refuses rows the edge filter should have removed, and ranks beyond the valid starts
+    with pytest.raises(_lib.NmScanError, match="within 20 bp"):
+        store.add_task_rows("x", [0], [20], [0], 20)
+    import ctypes as C
+    out = np.zeros((1, 4, 41), dtype=np.int64)
+    sc, sr = np.zeros(1, np.uint32), np.array([n_valid["A"][names[0]]], dtype=np.uint32)
+    begin = np.array([0, 1], dtype=np.uint64)
+    rc = eng.lib.nm_bg_counts(eng.ctx, ord("A"), 20, 1, sc.ctypes.data_as(C.POINTER(C.c_uint32)), sr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              1, begin.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    assert rc != 0 and b"valid starts" in eng.lib.nm_last_error()
+    eng.close()
+
+
+def test_other_letters_are_counted():
+    from nanomotif_amd.engine import ScanEngine
+    eng = ScanEngine(0)
+    eng.upload_assembly(["c1", "c2"], ["ACGTNNRYacgtn" * 700, "ACGT" * 3000 + "W"], ["b", "b"])
+    assert eng.other_letters() == 2 * 700 + 1
+    eng.close()
