@@ -66,7 +66,12 @@ def find_motifs_bin(args):
         raise RuntimeError("nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback")
     torch.cuda.set_device(device)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        # RCCL unless NANOMOTIF_DIST_BACKEND=gloo (debugging aid: lets several ranks share one GPU with --device)
+        backend = os.environ.get("NANOMOTIF_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     log.info("Starting nanomotif motif finder")
     bin_contig = fasta.generate_contig_bin(args)

@@ -18,6 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run_cli(tmp, args, nproc=1):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "nanomotif_amd", "motif_discovery"] + args
+    if nproc > 1:      # several ranks on the one GPU of the test box: gloo carries the all-reduces
+        env["NANOMOTIF_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", "29653", "-m", "nanomotif_amd", "motif_discovery", "--device", "0"] + args
     r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
@@ -81,3 +85,19 @@ def test_empty_result_writes_header_only(tmp_path):
     _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o"])
     lines = open(tmp + "/o/bin-motifs.tsv").read().strip().split("\n")
     assert len(lines) == 1 and lines[0].split("\t")[:4] == ["reference", "motif", "mod_position", "mod_type"]
+
+
+def test_two_ranks_give_the_single_rank_output(tmp_path):
+    """Contigs, windows and background samples sharded over two ranks (one GPU shared, gloo): same bin-motifs.tsv."""
+    spec = synth.SynthSpec(n_contigs=9, total_bp=700_000, n_bins=3, mod_types=("a", "m"), seed=62, min_contig_bp=40_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m"), ("GAAGNNNNNTAC", 2, "a")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out1"])
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out2"], nproc=2)
+    one, two = open(tmp + "/out1/bin-motifs.tsv").read(), open(tmp + "/out2/bin-motifs.tsv").read()
+    assert len(one.strip().split("\n")) > 3
+    assert one == two
