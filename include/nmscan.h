@@ -171,6 +171,12 @@ int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const ui
  *                          reference's edge filter is the caller's job); width = 2*pad+1 <= 64.  A base that is not
  *                          A/C/G/T becomes N — callers must keep contigs with other IUPAC letters on the host path
  *                          (the reference raises KeyError there; nm_assembly_other_letters tells).
+ *   nm_methylated_row_counts   out[contig][2] = confidently methylated rows of the slot's pileup (fraction >= high,
+ *                          after the pre-filters) on the plus / minus strand with pad < pos < len - pad — the rows
+ *                          window extraction uses (find_motifs_bin.py:635-661); they are the bits of the slot's
+ *                          methylated-state planes, no row list is kept.
+ *   nm_win_add_task_contigs    the methylation windows of one search = all those rows of the listed contigs (per
+ *                          contig plus rows then minus rows, ascending); *n_windows = how many.
  *   nm_contig_base_counts  out[contig] = number of positions p in [pad, len-pad) whose base is `base`
  *                          ('A','C','G','T') = len(valid starts) of sample_n_subsequences (seq.py:202-225).
  *   nm_bg_counts           background letter counts of the sampled sub-sequences: sample j = (contig, rank k) stands
@@ -180,6 +186,9 @@ int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const ui
  */
 int nm_win_add_task_rows(nm_ctx *ctx, uint32_t n_rows, const uint32_t *contig_id, const uint32_t *position,
                          const uint8_t *minus, uint32_t pad, uint32_t *task_id);
+int nm_methylated_row_counts(nm_ctx *ctx, uint32_t mod_slot, uint32_t pad, uint64_t *out);
+int nm_win_add_task_contigs(nm_ctx *ctx, uint32_t mod_slot, uint32_t n_contigs, const uint32_t *contig_id, uint32_t pad,
+                            uint32_t *task_id, uint64_t *n_windows);
 int nm_contig_base_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t *out);
 int nm_bg_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
                  const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out);

@@ -420,7 +420,9 @@ __device__ __forceinline__ uint64_t plane_field(const uint32_t *__restrict__ P, 
 }
 
 // one wave per contig: rank[block] = number of positions with base b in the contig before the block
-__global__ __launch_bounds__(64) void rank_build_kernel(Planes s, const uint32_t *__restrict__ contig_chunk,
+// (b < 0: the set bits of `plane`, e.g. a slot's methylated-row plane, instead of a base)
+__global__ __launch_bounds__(64) void rank_build_kernel(Planes s, const uint32_t *__restrict__ plane,
+                                                        const uint32_t *__restrict__ contig_chunk,
                                                         const uint64_t *__restrict__ contig_len, int b,
                                                         uint32_t *__restrict__ rank, uint64_t *__restrict__ total) {
     const uint32_t ci = blockIdx.x, lane = threadIdx.x;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(64) void rank_build_kernel(Planes s, const uint32_t
         uint32_t cnt = 0;
         if (j < nblk) {
             const size_t w = (size_t)c0 * CHUNK_WORDS + (size_t)j * RANK_BLOCK_WORDS;
-            for (int k = 0; k < RANK_BLOCK_WORDS; ++k) cnt += __popc(base_word(s.H[w + k], s.L[w + k], s.V[w + k], b));
+            for (int k = 0; k < RANK_BLOCK_WORDS; ++k)
+                cnt += __popc(b < 0 ? plane[w + k] : base_word(s.H[w + k], s.L[w + k], s.V[w + k], b));
         }
         uint32_t x = cnt;
         for (int d = 1; d < 64; d <<= 1) {
@@ -463,6 +466,49 @@ __global__ void base_count_kernel(Planes s, const uint32_t *__restrict__ contig_
         n -= __popcll(head) + __popcll(tail);
     }
     out[ci] = n;
+}
+
+// Global bit index of the k-th (0-based, ascending) set bit of a contig in `plane` (b < 0) or among the positions
+// with base b; rk = the contig's slice of the rank table.  ~0 when k is beyond the contig's set bits.
+__device__ __forceinline__ uint64_t select_kth(const Planes &s, const uint32_t *__restrict__ plane, int b,
+                                               const uint32_t *__restrict__ rk, uint32_t c0, uint32_t nblk, uint32_t k) {
+    uint32_t lo = 0, hi = nblk - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (rk[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    uint32_t r = k - rk[lo];
+    const size_t w = (size_t)c0 * CHUNK_WORDS + (size_t)lo * RANK_BLOCK_WORDS;
+    for (int q = 0; q < RANK_BLOCK_WORDS; ++q) {
+        uint32_t x = b < 0 ? plane[w + q] : base_word(s.H[w + q], s.L[w + q], s.V[w + q], b);
+        const uint32_t pc = __popc(x);
+        if (r < pc) {
+            for (; r; --r) x &= x - 1;
+            return (uint64_t)(w + q) * 32 + (uint32_t)__builtin_ctz(x);
+        }
+        r -= pc;
+    }
+    return ~0ull;
+}
+
+// per contig and strand: rows (set bits of the methylated planes) with pad < pos < len - pad, and how many lie
+// before that range — out[contig] = {n_plus, n_minus, head_plus, head_minus}
+__global__ void meth_count_kernel(const uint32_t *__restrict__ MP, const uint32_t *__restrict__ MM,
+                                  const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ contig_len,
+                                  uint32_t n_contigs, uint32_t pad, const uint64_t *__restrict__ total_p,
+                                  const uint64_t *__restrict__ total_m, uint64_t *__restrict__ out) {
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= n_contigs) return;
+    const uint64_t len = contig_len[ci], g0 = (uint64_t)contig_chunk[ci] * CHUNK_BP;
+    uint64_t *o = out + (size_t)ci * 4;
+    if (len < 2ull * pad + 2) { o[0] = o[1] = o[2] = o[3] = 0; return; }
+    const uint64_t hp = __popcll(plane_field(MP, g0, pad + 1)), hm = __popcll(plane_field(MM, g0, pad + 1));
+    const uint64_t tp = pad ? __popcll(plane_field(MP, g0 + len - pad, pad)) : 0;
+    const uint64_t tm = pad ? __popcll(plane_field(MM, g0 + len - pad, pad)) : 0;
+    o[0] = total_p[ci] - hp - tp;
+    o[1] = total_m[ci] - hm - tm;
+    o[2] = hp;
+    o[3] = hm;
 }
 
 struct BgBlock { uint32_t task, begin_lo, begin_hi, count; };
@@ -497,36 +543,14 @@ __global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t
                 const uint64_t hh = plane_field(s.H, g0, pad), hl = plane_field(s.L, g0, pad), hv = plane_field(s.V, g0, pad);
                 k += __popcll(hv & ((b >= 2) ? hh : ~hh) & ((b == 1 || b == 2) ? hl : ~hl));
             }
-            const uint32_t *rk = rank + (size_t)c0 * RANK_PER_CHUNK;
-            uint32_t lo = 0, hi = nblk - 1;
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (rk[mid] <= k) lo = mid; else hi = mid - 1;
-            }
-            uint32_t r = k - rk[lo];
-            const size_t w = (size_t)c0 * CHUNK_WORDS + (size_t)lo * RANK_BLOCK_WORDS;
-            uint32_t x = 0;
-            int q = 0;
-            for (; q < RANK_BLOCK_WORDS; ++q) {
-                x = base_word(s.H[w + q], s.L[w + q], s.V[w + q], b);
-                const uint32_t pc = __popc(x);
-                if (r < pc) break;
-                r -= pc;
-            }
-            if (q == RANK_BLOCK_WORDS) {
+            const uint64_t centre = select_kth(s, nullptr, b, rank + (size_t)c0 * RANK_PER_CHUNK, c0, nblk, k);
+            if (centre == ~0ull || centre < g0 + pad) {
                 atomicOr(err, 4u);                       // rank beyond the contig's valid starts
                 on = false;
             } else {
-                for (; r; --r) x &= x - 1;
-                const uint64_t centre = (uint64_t)(w + q) * 32 + (uint32_t)__builtin_ctz(x);
-                if (centre < g0 + pad) {
-                    atomicOr(err, 4u);
-                    on = false;
-                } else {
-                    fh = plane_field(s.H, centre - pad, W);
-                    fl = plane_field(s.L, centre - pad, W);
-                    fv = plane_field(s.V, centre - pad, W);
-                }
+                fh = plane_field(s.H, centre - pad, W);
+                fl = plane_field(s.L, centre - pad, W);
+                fv = plane_field(s.V, centre - pad, W);
             }
         }
         for (uint32_t col = 0; col < W; ++col) {
@@ -550,22 +574,17 @@ __global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t
 // Methylation windows of one task from the sequence planes: a wave packs 64 windows; per column it ballots the five
 // window planes (A, C, G, T, N) and lanes 0 / 1 store the two words.  Minus rows are reverse-complemented
 // (complement = flip H in the (H, L) code; N stays N).
-__global__ __launch_bounds__(256) void win_gather_kernel(WinTask t, Planes s, const uint64_t *__restrict__ row_centre,
-                                                         const uint8_t *__restrict__ row_minus, uint32_t pad,
-                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ alive) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint64_t i = (uint64_t)wave * 64 + lane;
-    if ((uint64_t)wave * 64 >= t.n) return;
-    const bool on = i < t.n;
+__device__ __forceinline__ void pack_windows(const WinTask &t, const Planes &s, uint32_t wave, uint32_t lane, bool on,
+                                             uint64_t centre, bool minus, uint32_t pad, uint32_t *__restrict__ planes,
+                                             uint32_t *__restrict__ alive) {
     const uint32_t W = t.width;
     uint64_t fh = 0, fl = 0, fv = 0;
     if (on) {
-        const uint64_t g = row_centre[i] - pad;
+        const uint64_t g = centre - pad;
         fh = plane_field(s.H, g, W);
         fl = plane_field(s.L, g, W);
         fv = plane_field(s.V, g, W);
-        if (row_minus[i]) {
+        if (minus) {
             fh = __brevll(fh) >> (64 - W);
             fl = __brevll(fl) >> (64 - W);
             fv = __brevll(fv) >> (64 - W);
@@ -591,6 +610,58 @@ __global__ __launch_bounds__(256) void win_gather_kernel(WinTask t, Planes s, co
     }
     const unsigned long long bal = __ballot(on);
     if (writer) alive[t.alive_off + w] = (uint32_t)(bal >> shift);
+}
+
+// windows around explicit rows (global bit index of the centre, strand flag)
+__global__ __launch_bounds__(256) void win_gather_kernel(WinTask t, Planes s, const uint64_t *__restrict__ row_centre,
+                                                         const uint8_t *__restrict__ row_minus, uint32_t pad,
+                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ alive) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t i = (uint64_t)wave * 64 + lane;
+    if ((uint64_t)wave * 64 >= t.n) return;
+    const bool on = i < t.n;
+    pack_windows(t, s, wave, lane, on, on ? row_centre[i] : 0, on && row_minus[i], pad, planes, alive);
+}
+
+// windows around the methylated rows of a list of contigs, read from the slot's methylated-row planes: window i
+// belongs to the segment (contig, strand) with the largest dst_start <= i and is that segment's
+// (i - dst_start + head)-th set bit (head = rows before the edge-filtered range)
+struct WinSegment { uint32_t dst_start, contig, minus, head; };
+
+__global__ __launch_bounds__(256) void win_gather_contigs_kernel(WinTask t, Planes s, const uint32_t *__restrict__ MP,
+                                                                 const uint32_t *__restrict__ MM,
+                                                                 const uint32_t *__restrict__ rank_p,
+                                                                 const uint32_t *__restrict__ rank_m,
+                                                                 const uint32_t *__restrict__ contig_chunk,
+                                                                 const uint64_t *__restrict__ contig_len,
+                                                                 const WinSegment *__restrict__ seg, uint32_t n_seg,
+                                                                 uint32_t pad, uint32_t *__restrict__ planes,
+                                                                 uint32_t *__restrict__ alive, unsigned int *err) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t i = (uint64_t)wave * 64 + lane;
+    if ((uint64_t)wave * 64 >= t.n) return;
+    bool on = i < t.n, minus = false;
+    uint64_t centre = 0;
+    if (on) {
+        uint32_t lo = 0, hi = n_seg - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (seg[mid].dst_start <= (uint32_t)i) lo = mid; else hi = mid - 1;
+        }
+        const WinSegment sg = seg[lo];
+        minus = sg.minus != 0;
+        const uint32_t c0 = contig_chunk[sg.contig];
+        const uint32_t nblk = (uint32_t)((contig_len[sg.contig] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
+        centre = select_kth(s, minus ? MM : MP, -1, (minus ? rank_m : rank_p) + (size_t)c0 * RANK_PER_CHUNK, c0, nblk,
+                            (uint32_t)i - sg.dst_start + sg.head);
+        if (centre == ~0ull) {
+            atomicOr(err, 8u);
+            on = false;
+        }
+    }
+    pack_windows(t, s, wave, lane, on, centre, minus, pad, planes, alive);
 }
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
@@ -902,7 +973,24 @@ struct ModSlot {
     double low = 0.3, high = 0.7;
     uint32_t *planes[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // M U MP UP MM UM
     uint64_t n_rows = 0;
+    // window extraction: rank tables over the methylated-row planes MP / MM and the per-contig row counts for the
+    // edge padding `meth_pad` ({n_plus, n_minus, head_plus, head_minus} per contig); dropped when the planes change
+    uint32_t *rank[2] = {nullptr, nullptr};
+    uint64_t *rank_total[2] = {nullptr, nullptr};
+    std::vector<uint64_t> meth_counts;
+    uint32_t meth_pad = 0xFFFFFFFFu;
 };
+
+static void drop_slot_ranks(ModSlot &ms) {
+    for (int k = 0; k < 2; ++k) {
+        if (ms.rank[k]) (void)hipFree(ms.rank[k]);
+        if (ms.rank_total[k]) (void)hipFree(ms.rank_total[k]);
+        ms.rank[k] = nullptr;
+        ms.rank_total[k] = nullptr;
+    }
+    ms.meth_counts.clear();
+    ms.meth_pad = 0xFFFFFFFFu;
+}
 
 struct nm_ctx {
     int device = 0;
@@ -917,9 +1005,11 @@ struct nm_ctx {
     size_t d_win_tasks_cap = 0;
     bool win_tasks_dirty = false;
     // results of the last nm_ingest_pileup
-    std::vector<uint32_t> ing_contig, ing_pos, ing_kept;   // confident rows; kept rows per (contig, mod code)
-    std::vector<uint8_t> ing_strand;
-    std::vector<int8_t> ing_mod;
+    std::vector<uint32_t> ing_kept;                   // kept rows per (contig, mod code)
+    uint32_t *d_ing_contig = nullptr, *d_ing_pos = nullptr;   // confident rows stay on the device until asked for
+    uint8_t *d_ing_strand = nullptr;
+    int8_t *d_ing_mod = nullptr;
+    uint64_t ing_nconf = 0;
     uint32_t *d_programs = nullptr;                   // compiled constraint programs of the current batch
     size_t prog_cap_dw = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1283,7 +1373,18 @@ int nm_ctx_create(int device, nm_ctx **out) {
     return NM_OK;
 }
 
+static void drop_ingest_rows(nm_ctx *c) {
+    void *ptrs[] = {c->d_ing_contig, c->d_ing_pos, c->d_ing_strand, c->d_ing_mod};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_ing_contig = c->d_ing_pos = nullptr;
+    c->d_ing_strand = nullptr;
+    c->d_ing_mod = nullptr;
+    c->ing_nconf = 0;
+}
+
 static void free_assembly(nm_ctx *c) {
+    drop_ingest_rows(c);
     void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1305,6 +1406,7 @@ static void free_assembly(nm_ctx *c) {
         }
         s.present = false;
         s.n_rows = 0;
+        drop_slot_ranks(s);
     }
 }
 
@@ -1447,6 +1549,7 @@ static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_ba
     if (n_rows && (!contig_id || !position || !strand || !fraction_mod)) return fail(NM_EINVAL, "NULL column");
     HIP_TRY(hipSetDevice(c->device));
     ModSlot &ms = c->slots[mod_slot];
+    drop_slot_ranks(ms);
     const size_t words = plane_words(c);
     if (!ms.present || !append) {
         for (auto &p : ms.planes) {
@@ -1550,6 +1653,7 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
         if (slot_of_mod[m] >= NM_MAX_MOD_SLOTS) return fail(NM_EINVAL, "slot %d >= %d", slot_of_mod[m], NM_MAX_MOD_SLOTS);
         if (canonical_of_mod[m] != 'A' && canonical_of_mod[m] != 'C') return fail(NM_EINVAL, "canonical base must be 'A' or 'C'");
         ModSlot &ms = c->slots[slot_of_mod[m]];
+        drop_slot_ranks(ms);
         for (auto &p : ms.planes) {
             if (!p) HIP_TRY(hipMalloc(&p, words * 4));
             HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
@@ -1626,13 +1730,19 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
     const uint64_t nconf = scal[1];
-    c->ing_contig.resize(nconf); c->ing_pos.resize(nconf); c->ing_strand.resize(nconf); c->ing_mod.resize(nconf);
+    drop_ingest_rows(c);
     c->ing_kept.resize(n_groups);
-    if (nconf) {
-        (void)hipMemcpy(c->ing_contig.data(), d_cc, nconf * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(c->ing_pos.data(), d_cp, nconf * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(c->ing_strand.data(), d_cs, nconf, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(c->ing_mod.data(), d_cm, nconf, hipMemcpyDeviceToHost);
+    if (nconf) {        // exact-size copies; the n_rows-sized scratch goes away with cleanup()
+        e = hipMalloc(&c->d_ing_contig, nconf * 4);
+        if (e == hipSuccess) e = hipMalloc(&c->d_ing_pos, nconf * 4);
+        if (e == hipSuccess) e = hipMalloc(&c->d_ing_strand, nconf);
+        if (e == hipSuccess) e = hipMalloc(&c->d_ing_mod, nconf);
+        if (e == hipSuccess) e = hipMemcpy(c->d_ing_contig, d_cc, nconf * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_ing_pos, d_cp, nconf * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_ing_strand, d_cs, nconf, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) e = hipMemcpy(c->d_ing_mod, d_cm, nconf, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { cleanup(); drop_ingest_rows(c); return fail(NM_EHIP, "keeping the confident rows failed: %s", hipGetErrorString(e)); }
+        c->ing_nconf = nconf;
     }
     (void)hipMemcpy(c->ing_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost);
     cleanup();
@@ -1648,14 +1758,17 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
 int nm_ingest_results(nm_ctx *c, uint32_t *conf_contig, uint32_t *conf_position, uint8_t *conf_strand, int8_t *conf_mod,
                       uint64_t capacity, uint32_t *kept_per_contig_mod /*[n_contigs][8]*/) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
-    if (capacity < c->ing_contig.size()) return fail(NM_ERANGE, "capacity %llu < %zu confident rows", (unsigned long long)capacity, c->ing_contig.size());
-    const size_t n = c->ing_contig.size();
-    if (n) {
-        if (!conf_contig || !conf_position || !conf_strand || !conf_mod) return fail(NM_EINVAL, "NULL argument");
-        memcpy(conf_contig, c->ing_contig.data(), n * 4);
-        memcpy(conf_position, c->ing_pos.data(), n * 4);
-        memcpy(conf_strand, c->ing_strand.data(), n);
-        memcpy(conf_mod, c->ing_mod.data(), n);
+    const size_t n = c->ing_nconf;
+    if (conf_contig || conf_position || conf_strand || conf_mod) {          // all NULL: only the kept table is wanted
+        if (capacity < n) return fail(NM_ERANGE, "capacity %llu < %zu confident rows", (unsigned long long)capacity, n);
+        if (n) {
+            if (!conf_contig || !conf_position || !conf_strand || !conf_mod) return fail(NM_EINVAL, "NULL argument");
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipMemcpy(conf_contig, c->d_ing_contig, n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(conf_position, c->d_ing_pos, n * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(conf_strand, c->d_ing_strand, n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(conf_mod, c->d_ing_mod, n, hipMemcpyDeviceToHost));
+        }
     }
     if (kept_per_contig_mod) memcpy(kept_per_contig_mod, c->ing_kept.data(), c->ing_kept.size() * 4);
     return NM_OK;
@@ -1914,8 +2027,9 @@ static int ensure_rank(nm_ctx *c, int b) {
     if (c->d_rank[b]) return NM_OK;
     HIP_TRY(hipMalloc(&c->d_rank[b], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
     HIP_TRY(hipMalloc(&c->d_base_total[b], (size_t)c->n_contigs * 8));
-    hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c), c->d_contig_chunk,
-                       c->d_contig_len, b, c->d_rank[b], c->d_base_total[b]);
+    hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
+                       static_cast<const uint32_t *>(nullptr), c->d_contig_chunk, c->d_contig_len, b, c->d_rank[b],
+                       c->d_base_total[b]);
     HIP_TRY(hipGetLastError());
     return NM_OK;
 }
@@ -2047,6 +2161,108 @@ int nm_win_add_task_rows(nm_ctx *c, uint32_t n_rows, const uint32_t *contig_id, 
     c->win_planes_used += (uint64_t)width * 5 * t.nw;
     c->win_alive_used += t.nw;
     *task_id = (uint32_t)c->win_tasks.size();
+    c->win_tasks.push_back(t);
+    c->win_tasks_dirty = true;
+    return NM_OK;
+}
+
+// rank tables over a slot's methylated-row planes + the per-contig row counts inside the edge-filtered range
+static int ensure_slot_counts(nm_ctx *c, uint32_t slot, uint32_t pad) {
+    ModSlot &ms = c->slots[slot];
+    if (!ms.rank[0]) {
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipMalloc(&ms.rank[k], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
+            HIP_TRY(hipMalloc(&ms.rank_total[k], (size_t)c->n_contigs * 8));
+            hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
+                               static_cast<const uint32_t *>(ms.planes[k == 0 ? 2 : 4]), c->d_contig_chunk, c->d_contig_len, -1,
+                               ms.rank[k], ms.rank_total[k]);
+            HIP_TRY(hipGetLastError());
+        }
+        ms.meth_pad = 0xFFFFFFFFu;
+    }
+    if (ms.meth_pad == pad && ms.meth_counts.size() == (size_t)c->n_contigs * 4) return NM_OK;
+    uint64_t *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 4 * 8));
+    hipLaunchKernelGGL(meth_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, ms.planes[2], ms.planes[4],
+                       c->d_contig_chunk, c->d_contig_len, c->n_contigs, pad, ms.rank_total[0], ms.rank_total[1], d_out);
+    HIP_TRY(hipGetLastError());
+    ms.meth_counts.assign((size_t)c->n_contigs * 4, 0);
+    HIP_TRY(hipMemcpyAsync(ms.meth_counts.data(), d_out, (size_t)c->n_contigs * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_out);
+    ms.meth_pad = pad;
+    return NM_OK;
+}
+
+int nm_methylated_row_counts(nm_ctx *c, uint32_t mod_slot, uint32_t pad, uint64_t *out) {
+    if (!c || !out) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (mod_slot >= NM_MAX_MOD_SLOTS || !c->slots[mod_slot].present) return fail(NM_ESTATE, "mod slot %u holds no pileup", mod_slot);
+    if (2 * pad + 1 > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", 2 * pad + 1, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_slot_counts(c, mod_slot, pad);
+    if (rc) return rc;
+    const std::vector<uint64_t> &mc = c->slots[mod_slot].meth_counts;
+    for (uint32_t i = 0; i < c->n_contigs; ++i) {
+        out[2 * (size_t)i] = mc[4 * (size_t)i];
+        out[2 * (size_t)i + 1] = mc[4 * (size_t)i + 1];
+    }
+    return NM_OK;
+}
+
+int nm_win_add_task_contigs(nm_ctx *c, uint32_t mod_slot, uint32_t n_contigs, const uint32_t *contig_id, uint32_t pad,
+                            uint32_t *task_id, uint64_t *n_windows) {
+    if (!c || !task_id || !n_windows || (n_contigs && !contig_id)) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (mod_slot >= NM_MAX_MOD_SLOTS || !c->slots[mod_slot].present) return fail(NM_ESTATE, "mod slot %u holds no pileup", mod_slot);
+    const uint32_t width = 2 * pad + 1;
+    if (width > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", width, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_slot_counts(c, mod_slot, pad);
+    if (rc) return rc;
+    ModSlot &ms = c->slots[mod_slot];
+    std::vector<WinSegment> segs;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_contigs; ++k) {
+        const uint32_t ci = contig_id[k];
+        if (ci >= c->n_contigs) return fail(NM_EINVAL, "contig %u >= %u", ci, c->n_contigs);
+        for (uint32_t strand = 0; strand < 2; ++strand) {       // plus rows, then minus rows (find_motifs_bin.py:640-659)
+            const uint64_t n = ms.meth_counts[4 * (size_t)ci + strand];
+            if (!n) continue;
+            segs.push_back(WinSegment{(uint32_t)total, ci, strand, (uint32_t)ms.meth_counts[4 * (size_t)ci + 2 + strand]});
+            total += n;
+        }
+    }
+    if (total >= 0xFFFFFFFFull) return fail(NM_ERANGE, "more than 4G windows in one task");
+    WinTask t{};
+    t.n = (uint32_t)total;
+    t.nw = (t.n + 31) / 32;
+    t.width = width;
+    t.plane_off = c->win_planes_used;
+    t.alive_off = c->win_alive_used;
+    rc = win_grow(c, &c->d_win_planes, &c->win_planes_cap, c->win_planes_used, (uint64_t)width * 5 * t.nw);
+    if (rc) return rc;
+    rc = win_grow(c, &c->d_win_alive, &c->win_alive_cap, c->win_alive_used, t.nw);
+    if (rc) return rc;
+    if (total) {
+        rc = ensure_stage(c, segs.size() * sizeof(WinSegment));
+        if (rc) return rc;
+        memcpy(c->h_stage, segs.data(), segs.size() * sizeof(WinSegment));
+        HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, segs.size() * sizeof(WinSegment), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(win_gather_contigs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
+                           static_cast<const uint32_t *>(ms.planes[2]), static_cast<const uint32_t *>(ms.planes[4]),
+                           static_cast<const uint32_t *>(ms.rank[0]), static_cast<const uint32_t *>(ms.rank[1]), c->d_contig_chunk,
+                           c->d_contig_len, reinterpret_cast<const WinSegment *>(c->d_stage), (uint32_t)segs.size(), pad,
+                           c->d_win_planes, c->d_win_alive, c->d_err);
+        HIP_TRY(hipGetLastError());
+        rc = release_stage(c);
+        if (rc) return rc;
+    }
+    c->win_planes_used += (uint64_t)width * 5 * t.nw;
+    c->win_alive_used += t.nw;
+    *task_id = (uint32_t)c->win_tasks.size();
+    *n_windows = total;
     c->win_tasks.push_back(t);
     c->win_tasks_dirty = true;
     return NM_OK;

@@ -78,12 +78,12 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
                                            vp(cat["frac"]), vp(cat["nvalid"]), slot_of, canon, 0.3, 0.7, 1,
                                            C.byref(n_kept), C.byref(n_conf)))
     k = n_conf.value
-    cc, cp = np.empty(k, np.uint32), np.empty(k, np.uint32)
-    cs, cm = np.empty(k, np.uint8), np.empty(k, np.int8)
+    engine._n_confident = int(k)
     kept = np.zeros((len(mine), 8), dtype=np.uint32)
-    _lib.check(engine.lib.nm_ingest_results(engine.ctx, cc.ctypes.data_as(C.POINTER(C.c_uint32)), cp.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                            cs.ctypes.data_as(C.POINTER(C.c_uint8)), cm.ctypes.data_as(C.POINTER(C.c_int8)), k,
-                                            kept.ctypes.data_as(C.POINTER(C.c_uint32))))
+    _lib.check(engine.lib.nm_ingest_results(engine.ctx, None, None, None, None, 0, kept.ctypes.data_as(C.POINTER(C.c_uint32))))
+    # the confident rows stay on the device (methylated-state planes); the host path would fetch them with
+    # engine.confident_rows()
+    cc, cp, cs, cm = (np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
     t["upload_filter_s"] = time.perf_counter() - t0
     t["rows_raw"], t["rows_kept"], t["rows_confident"] = n, int(n_kept.value), int(k)
     t0 = time.perf_counter()

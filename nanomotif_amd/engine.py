@@ -62,6 +62,17 @@ class DeviceWindowStore:
         _lib.check(self.engine.lib.nm_win_add_task(self.engine.ctx, sets.shape[0], sets.shape[1], _ptr(sets, C.c_uint8), C.byref(tid)))
         self.task_id[key], self.totals[key], self.width[key] = int(tid.value), int(sets.shape[0]), int(sets.shape[1])
 
+    def add_task_contigs(self, key, label, contigs, pad, total=None):
+        """Windows around every confidently methylated row (pad < pos < len - pad) of the listed resident contigs,
+        taken from the methylated-state planes of the classification ``label`` (nm_win_add_task_contigs)."""
+        contigs = np.ascontiguousarray(contigs, dtype=np.uint32)
+        tid, n = C.c_uint32(0), C.c_uint64(0)
+        _lib.check(self.engine.lib.nm_win_add_task_contigs(self.engine.ctx, self.engine.slot_of_mod[label], len(contigs),
+                                                           _ptr(contigs, C.c_uint32), int(pad), C.byref(tid), C.byref(n)))
+        self.task_id[key], self.width[key] = int(tid.value), 2 * int(pad) + 1
+        self.totals[key] = int(n.value if total is None else total)
+        return int(n.value)
+
     def execute(self, batch):
         out = [None] * len(batch)
         dev = [(i, key, req) for i, (key, req) in enumerate(batch) if req.kind != "total"]
@@ -101,8 +112,11 @@ class DeviceWindowExtractor:
     MAX_SAMPLES_PER_CALL = 4 << 20
 
     def __init__(self, engine, store: DeviceWindowStore, lengths, n_valid, padding, resident=None, allreduce_i64=None,
-                 background_sampling_frequency=0.01):
+                 background_sampling_frequency=0.01, row_counts=None):
+        """``row_counts[mod type]``: contig name -> (plus, minus) confident rows inside the edge padding
+        (``methylated_row_counts``), over all ranks — needed by ``plan_contigs`` only."""
         self.engine, self.store, self.lengths, self.n_valid, self.pad = engine, store, lengths, n_valid, int(padding)
+        self.row_counts = row_counts
         self.resident = engine.contig_index if resident is None else resident
         self.allreduce_i64 = allreduce_i64
         self.freq = background_sampling_frequency
@@ -110,11 +124,15 @@ class DeviceWindowExtractor:
 
     def plan(self, key, plus_pos: dict, minus_pos: dict, mod_type: str) -> bool:
         """One task; consumes the interpreter's RNG exactly like extract_windows.  False = no methylation windows."""
-        import math
-        from .search import _native_random_sample
+        from .search import NativeRandom
         base = MOD_TYPE_TO_CANONICAL[mod_type]
-        pad, W = self.pad, 2 * self.pad + 1
         nv_of = self.n_valid[base]
+        with NativeRandom() as rng:
+            return self._plan(rng, key, plus_pos, minus_pos, base, nv_of)
+
+    def _plan(self, rng, key, plus_pos, minus_pos, base, nv_of):
+        import math
+        pad, W = self.pad, 2 * self.pad + 1
         s_contig, s_rank, rows_c, rows_p, rows_m = [], [], [], [], []
         n_bg = total = 0
         empty = np.zeros(0, np.int64)
@@ -126,7 +144,7 @@ class DeviceWindowExtractor:
             nv = int(nv_of[name])
             if nv < n_samples:
                 raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
-            ranks = _native_random_sample(nv, n_samples)
+            ranks = rng.sample(nv, n_samples)
             n_bg += n_samples
             ci = self.resident.get(name)
             if ci is not None:
@@ -146,6 +164,44 @@ class DeviceWindowExtractor:
             return False
         cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
         self.store.add_task_rows(key, cat(rows_c, np.uint32), cat(rows_p, np.uint32), cat(rows_m, np.uint8), pad, total=total)
+        self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
+        return True
+
+    def plan_contigs(self, key, names, mod_type: str) -> bool:
+        """``plan`` without row lists: the task's windows are all confident rows of the contigs ``names`` (those present
+        in the filtered pileup of this mod type), read on the device from the methylated-state planes."""
+        import math
+        from .search import NativeRandom
+        base = MOD_TYPE_TO_CANONICAL[mod_type]
+        nv_of, counts = self.n_valid[base], self.row_counts[mod_type]
+        pad, W = self.pad, 2 * self.pad + 1
+        s_contig, s_rank, mine = [], [], []
+        n_bg = total = 0
+        with NativeRandom() as rng:
+            for name in sorted(names):
+                length = int(self.lengths[name])
+                n_samples = int(max(math.ceil(length * self.freq), 50))
+                if n_samples > length - W + 1:
+                    raise ValueError("Too many samples requested for unique subsequences")
+                nv = int(nv_of[name])
+                if nv < n_samples:
+                    raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
+                ranks = rng.sample(nv, n_samples)
+                n_bg += n_samples
+                ci = self.resident.get(name)
+                if ci is not None:
+                    s_contig.append(np.full(n_samples, ci, dtype=np.uint32))
+                    s_rank.append(ranks.astype(np.uint32))
+                n_rows = int(counts[name][0]) + int(counts[name][1])
+                if n_rows == 0:
+                    return False                     # find_motifs_bin.py:662-664
+                total += n_rows
+                if ci is not None:
+                    mine.append(ci)
+        if total == 0 or n_bg == 0:
+            return False
+        cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
+        self.store.add_task_contigs(key, mod_type, mine, pad, total=total)
         self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
         return True
 
@@ -278,13 +334,16 @@ class ScanEngine:
                                              len(cid), _ptr(cid, C.c_uint32), _ptr(pos, C.c_uint32), _ptr(st, C.c_uint8),
                                              _ptr(fr, C.c_double), 1 if append else 0))
 
-    def ingest_pileup(self, contig_local, position, mod_code, strand, fraction_mod, nvalid_cov, labels, low=0.3, high=0.7):
+    def ingest_pileup(self, contig_local, position, mod_code, strand, fraction_mod, nvalid_cov, labels, low=0.3, high=0.7,
+                      want_rows=True):
         """RAW pileup rows -> device-side pre-filters (dataload.py:191-247) -> state planes.
         contig_local: engine contig index per row, 0xFFFFFFFF for contigs this engine does not hold;
         mod_code: int8 ids as numbered by the reader (0 = m, 1 = a, 2 = 21839, 3.. = others, which only take part in
         the filters); labels: {mod code id: (label, canonical base)} for the codes to classify.
-        Returns dict(n_kept, confident=(contig_local, position, strand, mod_code) of the surviving rows with
-        fraction_mod >= high, kept=uint32[n_contigs, 8] surviving rows per (contig, mod code))."""
+        Returns dict(n_kept, n_confident, confident=(contig_local, position, strand, mod_code) of the surviving rows
+        with fraction_mod >= high (None unless ``want_rows``: the device keeps them as the methylated-state planes, see
+        ``methylated_row_counts`` / ``DeviceWindowStore.add_task_contigs``; ``confident_rows()`` fetches them later),
+        kept=uint32[n_contigs, 8] surviving rows per (contig, mod code))."""
         cid = np.ascontiguousarray(contig_local, dtype=np.uint32)
         pos = np.ascontiguousarray(position, dtype=np.uint32)
         mod = np.ascontiguousarray(mod_code, dtype=np.int8)
@@ -308,13 +367,29 @@ class ScanEngine:
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         _lib.check(self.lib.nm_ingest_pileup(self.ctx, n, vp(cid), vp(pos), vp(mod), vp(st), vp(fr), vp(nv), slot_of, canon,
                                              float(low), float(high), 0, C.byref(n_kept), C.byref(n_conf)))
-        k = n_conf.value
+        self._n_confident = int(n_conf.value)
+        kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
+        _lib.check(self.lib.nm_ingest_results(self.ctx, None, None, None, None, 0, _ptr(kept, C.c_uint32)))
+        return dict(n_kept=int(n_kept.value), n_confident=self._n_confident,
+                    confident=self.confident_rows() if want_rows else None, kept=kept)
+
+    def confident_rows(self):
+        """(contig_local, position, strand, mod_code) of the rows the last ``ingest_pileup`` kept with
+        fraction_mod >= high, copied from the device."""
+        k = getattr(self, "_n_confident", 0)
         cc, cp = np.empty(k, np.uint32), np.empty(k, np.uint32)
         cs, cm = np.empty(k, np.uint8), np.empty(k, np.int8)
-        kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
-        _lib.check(self.lib.nm_ingest_results(self.ctx, _ptr(cc, C.c_uint32), _ptr(cp, C.c_uint32), _ptr(cs, C.c_uint8),
-                                              cm.ctypes.data_as(C.POINTER(C.c_int8)), k, _ptr(kept, C.c_uint32)))
-        return dict(n_kept=int(n_kept.value), confident=(cc, cp, cs, cm), kept=kept)
+        if k:
+            _lib.check(self.lib.nm_ingest_results(self.ctx, _ptr(cc, C.c_uint32), _ptr(cp, C.c_uint32), _ptr(cs, C.c_uint8),
+                                                  cm.ctypes.data_as(C.POINTER(C.c_int8)), k, None))
+        return cc, cp, cs, cm
+
+    def methylated_row_counts(self, label, padding: int) -> np.ndarray:
+        """uint64[n_contigs, 2]: confidently methylated rows (plus, minus) of the classification ``label`` per resident
+        contig with padding < position < len - padding — the rows window extraction uses."""
+        out = np.zeros((len(self.contig_names), 2), dtype=np.uint64)
+        _lib.check(self.lib.nm_methylated_row_counts(self.ctx, self.slot_of_mod[label], int(padding), _ptr(out, C.c_uint64)))
+        return out
 
     def alias_label(self, label, existing):
         """Make ``label`` refer to the classification already resident as ``existing``."""

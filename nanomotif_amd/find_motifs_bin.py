@@ -217,6 +217,17 @@ class FilteredPileup:
             self._name_index = {n: i for i, n in enumerate(self.contig_names)}
         return self._order, self._key
 
+    def present(self, contig_names, mod_id):
+        """The listed contigs that have at least one surviving row of this mod type (find_motifs_bin.py:629)."""
+        if getattr(self, "_name_index", None) is None:
+            self._name_index = {n: i for i, n in enumerate(self.contig_names)}
+        out = []
+        for name in contig_names:
+            i = self._name_index.get(name)
+            if i is not None and self.kept[i, mod_id] != 0:
+                out.append(name)
+        return out
+
     def positions(self, contig_names, mod_id):
         """(plus, minus): name -> ascending positions of confident rows, one entry for every listed contig that has
         at least one surviving row of this mod type (find_motifs_bin.py:629: contigs present in the bin pileup)."""
@@ -253,14 +264,22 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
         if bgzip_order:
             random.seed(cfg.seed)
         for mt_id, mod_type in enumerate(MOD_TYPES):
-            plus, minus = filtered.positions(bins[bin_name], mt_id)
-            if not plus and not minus:
-                continue
+            if extractor is not None and extractor.row_counts is not None:
+                plus = minus = None
+                names = filtered.present(bins[bin_name], mt_id)
+                if not names:
+                    continue
+            else:
+                plus, minus = filtered.positions(bins[bin_name], mt_id)
+                if not plus and not minus:
+                    continue
             if not bgzip_order:
                 random.seed(cfg.seed)
             if extractor is not None:
                 windows = None
-                if not extractor.plan((bin_name, mod_type), plus, minus, mod_type):
+                planned_ok = (extractor.plan_contigs((bin_name, mod_type), names, mod_type) if plus is None
+                              else extractor.plan((bin_name, mod_type), plus, minus, mod_type))
+                if not planned_ok:
                     log.info(f"[{bin_name} {mod_type}] No methylation sequences found")
                     continue
             else:

@@ -112,7 +112,9 @@ def find_motifs_bin(args):
     t0 = time.perf_counter()
     low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
     res = eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
-                            table.nvalid_cov, labels, low=low, high=high)
+                            table.nvalid_cov, labels, low=low, high=high, want_rows=False)
+    store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
+    rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
     if (low, high) == (0.3, 0.7):
         for mt in pileup_mod.MOD_TYPES:
             eng.alias_label((mt, "merge"), mt)
@@ -122,7 +124,7 @@ def find_motifs_bin(args):
                           low=0.3, high=0.7)
     log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
     del table
-    part = FilteredPileup(mine, *res["confident"], res["kept"])
+    part = FilteredPileup(mine, *rows_part, res["kept"])
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, part)
@@ -134,7 +136,6 @@ def find_motifs_bin(args):
         eng.close()
         return None
     scorer = engine_scorer(eng, low, high, use_dist=world > 1)
-    store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
     rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip, window_store=store, extractor=extractor)
     eng.close()
     if not rows:
@@ -164,17 +165,24 @@ def device_window_pipeline(eng, lengths: dict, mine: list, padding: int, world: 
     if int(other[0]):
         log.info(f"{int(other[0])} assembly letters outside ACGTN: window extraction stays on the host")
         return DeviceWindowStore(eng), None
-    n_valid = {}
-    for base in sorted({MOD_TYPE_TO_CANONICAL[mt] for mt in pileup_mod.MOD_TYPES}):
-        local = dict(zip(mine, eng.contig_base_counts(base, padding).tolist()))
-        if world > 1:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, local)
-            local = {k: v for g in gathered for k, v in g.items()}
-        n_valid[base] = local
+
+    def everywhere(local: dict) -> dict:
+        if world == 1:
+            return local
+        gathered = [None] * world
+        dist.all_gather_object(gathered, local)
+        return {k: v for g in gathered for k, v in g.items()}
+
+    # valid sample starts per contig (seq.py:202-225), counted on the device
+    n_valid = {base: everywhere(dict(zip(mine, eng.contig_base_counts(base, padding).tolist())))
+               for base in sorted({MOD_TYPE_TO_CANONICAL[mt] for mt in pileup_mod.MOD_TYPES})}
+    # confident rows per contig and strand: the windows themselves are read from the methylated-state planes
+    row_counts = {mt: everywhere(dict(zip(mine, eng.methylated_row_counts(mt, padding).tolist())))
+                  for mt in pileup_mod.MOD_TYPES if mt in eng.slot_of_mod}
     reduce = allreduce_counts if world > 1 else None
     store = DeviceWindowStore(eng, allreduce=reduce)
-    return store, DeviceWindowExtractor(eng, store, lengths, n_valid, padding, resident=eng.contig_index, allreduce_i64=reduce)
+    return store, DeviceWindowExtractor(eng, store, lengths, n_valid, padding, resident=eng.contig_index, allreduce_i64=reduce,
+                                        row_counts=row_counts)
 
 
 def check_installation():

@@ -56,19 +56,34 @@ def revcomp_sets(sets: np.ndarray) -> np.ndarray:
     return _COMP_SET[sets[:, ::-1]]
 
 
+class NativeRandom:
+    """The interpreter's MT19937 state held in a numpy array for a run of native ``random.sample`` calls (libnmscan:
+    nm_py_random_sample replicates CPython's algorithm bit for bit); on exit the interpreter's generator is set to
+    where the pure-Python calls would have left it."""
+
+    def __enter__(self):
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self.version, state, self.gauss = random.getstate()
+        self.state = np.array(state, dtype=np.uint32)
+        return self
+
+    def sample(self, n: int, k: int) -> np.ndarray:
+        """``random.sample(range(n), k)`` as int64."""
+        import ctypes as C
+        out = np.empty(k, dtype=np.uint32)
+        self._check(self._lib.nm_py_random_sample(self.state.ctypes.data_as(C.POINTER(C.c_uint32)), n, k,
+                                                  out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out.astype(np.int64)
+
+    def __exit__(self, *exc):
+        random.setstate((self.version, tuple(self.state.tolist()), self.gauss))
+        return False
+
+
 def _native_random_sample(n: int, k: int) -> np.ndarray:
-    """``random.sample(range(n), k)`` drawn natively from the interpreter's own MT19937 state (libnmscan:
-    nm_py_random_sample replicates CPython's algorithm bit for bit); the interpreter's generator is advanced exactly as
-    the pure-Python call would have advanced it."""
-    import ctypes as C
-    from . import _lib
-    lib = _lib.load()
-    version, state, gauss = random.getstate()
-    arr = np.array(state, dtype=np.uint32)
-    out = np.empty(k, dtype=np.uint32)
-    _lib.check(lib.nm_py_random_sample(arr.ctypes.data_as(C.POINTER(C.c_uint32)), n, k, out.ctypes.data_as(C.POINTER(C.c_uint32))))
-    random.setstate((version, tuple(arr.tolist()), gauss))
-    return out.astype(np.int64)
+    with NativeRandom() as rng:
+        return rng.sample(n, k)
 
 
 def sample_background_starts(seq: np.ndarray, length: int, n: int, base: str) -> np.ndarray:

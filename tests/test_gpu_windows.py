@@ -57,7 +57,7 @@ def test_device_extraction_matches_host(padding):
     lengths_of = {n: len(seqs[n]) for n in names}
     dev_store, host_store = DeviceWindowStore(eng), ps.HostWindowStore()
     ext = DeviceWindowExtractor(eng, dev_store, lengths_of, n_valid, padding)
-    keys, host_pssm = [], {}
+    keys, host_pssm, task_rows = [], {}, {}
     for b in sorted(set(bins)):
         members = [n for n, x in zip(names, bins) if x == b]
         for mt, base in (("a", "A"), ("m", "C")):
@@ -72,9 +72,42 @@ def test_device_extraction_matches_host(padding):
             host_store.add_task(key, host[0])
             host_pssm[key] = host[1]
             keys.append(key)
+            task_rows[key] = (plus, minus, members)
     dev_pssm = ext.finish()
     for key in keys:
         assert np.array_equal(dev_pssm[key], host_pssm[key]), key          # counts / n: bitwise equal
+    # the same tasks without row lists: the rows are the bits of the methylated-state planes (plan_contigs)
+    for mt in ("a", "m"):
+        cid, pos, strand, frac = [], [], [], []
+        for key, (plus, minus, members) in task_rows.items():
+            if key[1] != mt:
+                continue
+            for name in members:
+                for arr, ch in ((plus[name], "+"), (minus[name], "-")):
+                    cid.append(np.full(len(arr), eng.contig_index[name])); pos.append(arr)
+                    strand.append(np.full(len(arr), ord(ch), np.uint8)); frac.append(np.full(len(arr), 0.9))
+                # rows that are not confidently methylated must not become windows
+                free = np.setdiff1d(np.arange(30, 300), np.concatenate([plus[name], minus[name]]))
+                cid.append(np.full(len(free), eng.contig_index[name])); pos.append(free)
+                strand.append(np.full(len(free), ord("+"), np.uint8)); frac.append(np.where(free % 2 == 0, 0.1, 0.5))
+        eng.upload_pileup(mt, np.concatenate(cid), np.concatenate(pos), np.concatenate(strand), np.concatenate(frac))
+    row_counts = {}
+    for mt in ("a", "m"):
+        got = eng.methylated_row_counts(mt, padding)
+        row_counts[mt] = dict(zip(names, got.tolist()))
+        for key, (plus, minus, members) in task_rows.items():
+            if key[1] == mt:
+                for name in members:
+                    L = len(seqs[name])
+                    want = [int(((a > padding) & (a < L - padding)).sum()) for a in (plus[name], minus[name])]
+                    assert row_counts[mt][name] == want, (key, name)
+    ext2 = DeviceWindowExtractor(eng, dev_store, lengths_of, n_valid, padding, row_counts=row_counts)
+    for key in keys:
+        random.seed(11)
+        assert ext2.plan_contigs((key, "planes"), task_rows[key][2], key[1])
+    pssm2 = ext2.finish()
+    for key in keys:
+        assert np.array_equal(pssm2[(key, "planes")], host_pssm[key]), key
     pad = padding
     motifs = [Motif("." * pad + "A" + "." * pad, pad), Motif("." * pad + "C" + "." * pad, pad),
               Motif("." * (pad - 1) + "GATC" + "." * (pad - 2), pad), Motif("." * (pad - 2) + "[AG]CA.T" + "." * (pad - 2), pad),
@@ -82,13 +115,15 @@ def test_device_extraction_matches_host(padding):
     for rnd, kind in enumerate(["total", "pssm", "pssm", "pssm", "remove", "pssm", "remove", "pssm", "pssm"]):
         m = motifs[rnd % len(motifs)]
         batch = [(k, ps.WinReq(kind, None if kind == "total" else m)) for k in keys]
-        a, b = dev_store.execute(batch), host_store.execute(batch)
-        for x, y in zip(a, b):
-            if kind == "pssm":
-                assert x[0] == y[0]
-                assert (y[1] is None and x[0] == 0) or np.array_equal(x[1], y[1])
-            else:
-                assert x == y
+        b = host_store.execute(batch)
+        for rename in (lambda k: k, lambda k: (k, "planes")):
+            a = dev_store.execute([(rename(k), r) for k, r in batch])
+            for x, y in zip(a, b):
+                if kind == "pssm":
+                    assert x[0] == y[0]
+                    assert (y[1] is None and x[0] == 0) or np.array_equal(x[1], y[1])
+                else:
+                    assert x == y
     eng.close()
 
 
