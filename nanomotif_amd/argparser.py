@@ -40,6 +40,10 @@ def create_parser():
     o.add_argument("--min_motifs_bin", type=int, default=50,
                    help="Minimum number of motif observations in a bin. Default: %(default)s")
     o.add_argument("--device", type=int, default=None, help="GPU to use (default: LOCAL_RANK or 0).")
+    o.add_argument("--shard", choices=["auto", "bins", "contigs"], default="auto",
+                   help="Multi-GPU runs: give every GPU whole bins (independent searches, no collective) or shard the "
+                        "contigs of every bin over the GPUs (count tables all-reduced per round). Default: bins when "
+                        "they balance within 15%%, else contigs.")
     gen = p.add_argument_group("general arguments")
     gen.add_argument("-t", "--threads", type=int, default=1, help="Accepted for compatibility; the GPU engine does not use worker processes.")
     gen.add_argument("-v", "--verbose", action="store_true", help="Increase output verbosity. (set logger to debug level)")

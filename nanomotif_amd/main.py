@@ -21,7 +21,7 @@ from . import fasta, pileup as pileup_mod, postprocess
 from .argparser import __version__, create_parser
 from .find_motifs_bin import FilteredPileup, ProcessorConfig, allreduce_counts, discover, engine_scorer
 from .motif import MOD_TYPE_TO_CANONICAL
-from .shard import assign_contigs
+from .shard import assign_bins, assign_contigs
 
 HEADER = "\t".join(postprocess.HEADER) + "\n"
 
@@ -93,10 +93,29 @@ def find_motifs_bin(args):
     table = pileup_mod.load_pileup(cfg.pileup_path)                  # native reader, raw rows
     log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s)")
 
-    # engine: this rank's contigs (all contigs that belong to a bin), sharded over the ranks
+    # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they
+    # balance (independent searches, no collective until the rows are gathered), else the contigs of every bin are
+    # sharded and the count tables all-reduced every round.
     names = [c for c in cfg.bin_contig if c in assembly]
+    bin_order = list(dict.fromkeys(cfg.bin_contig.values()))         # task order of the reference (:152-171)
+    by_bins = None
+    if world > 1 and args.shard != "contigs":
+        sizes = {}
+        for c in names:
+            sizes[cfg.bin_contig[c]] = sizes.get(cfg.bin_contig[c], 0) + len(assembly[c])
+        by_bins = assign_bins(sizes, world, tolerance=0.15 if args.shard == "auto" else float("inf"))
+    if by_bins is not None:
+        my_bins = set(by_bins[rank])
+        log.info(f"rank {rank}: {len(my_bins)} of {len(sizes)} bins (whole bins per GPU)")
+        cfg.bin_contig = {c: b for c, b in cfg.bin_contig.items() if b in my_bins}
+        names = [c for c in names if cfg.bin_contig.get(c) in my_bins]
+        gather_world, world = world, 1                               # the data path below is a single-GPU run
+        if not names:                                                # more GPUs than bins
+            return _gather_rows(args, [], rank, gather_world, bin_order)
+    else:
+        gather_world = 1
     parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
-    mine = [names[i] for i in parts[rank]]
+    mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
     eng = ScanEngine(device)
     all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
     eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
@@ -134,10 +153,26 @@ def find_motifs_bin(args):
     if filtered.kept.sum() == 0:
         log.info("No pileup data after filtering, skipping")
         eng.close()
-        return None
+        return _gather_rows(args, [], rank, gather_world, bin_order) if gather_world > 1 else None
     scorer = engine_scorer(eng, low, high, use_dist=world > 1)
-    rows, scorer = discover(cfg, filtered, scorer, rank=rank, bgzip_order=bgzip, window_store=store, extractor=extractor)
+    rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
+                            window_store=store, extractor=extractor)
     eng.close()
+    return _gather_rows(args, rows, rank, gather_world, bin_order)
+
+
+def _gather_rows(args, rows, rank, gather_world, bin_order):
+    """Collect the motif rows (whole-bin sharding: from every rank, back into the reference's bin order), apply the
+    bin-level filter and let rank 0 write bin-motifs.tsv."""
+    if gather_world > 1:
+        import torch.distributed as dist
+        gathered = [None] * gather_world
+        dist.all_gather_object(gathered, rows)
+        by_bin = {}
+        for part in gathered:
+            for r in part:
+                by_bin.setdefault(r.reference, []).append(r)
+        rows = [r for b in bin_order for r in by_bin.get(b, [])]
     if not rows:
         log.info("No motifs were identified")
         return None

@@ -1,4 +1,8 @@
-"""Contig -> GPU assignment for the multi-GPU path.
+"""Bin -> GPU and contig -> GPU assignment for the multi-GPU path.
+
+Bins are independent searches (find_motifs_bin.py:152-171): when the bins can be spread evenly, every GPU takes WHOLE
+bins (``assign_bins``) and runs their searches alone — no collective on the data path, the motif rows are gathered at
+the end.  Otherwise (few / huge bins, a single isolate genome) contigs are the unit:
 
 Counts are sums over contigs (find_motifs_bin.py:1273-1283), so contigs — not bins — are the sharding unit and a
 bin may span GPUs; the per-candidate count tables are summed with one RCCL all-reduce per scoring step.
@@ -56,3 +60,26 @@ def assign_contigs(lengths, world_size: int, bins=None, whole_bin_fraction: floa
         out[r].extend(idx)
         heapq.heappush(heap, (load + size, r))
     return [np.array(sorted(x), dtype=np.int64) for x in out]
+
+
+def assign_bins(bin_sizes: dict, world_size: int, tolerance: float = 0.15):
+    """Whole bins -> ranks, longest-processing-time-first on the bins' total bp (ties by name).  Returns a list (per
+    rank) of bin-name lists in ``bin_sizes`` order, or None when the heaviest rank would exceed the mean load by more
+    than ``tolerance`` (then contigs should be the sharding unit, ``assign_contigs``)."""
+    if world_size <= 1:
+        return [list(bin_sizes)]
+    order = sorted(bin_sizes, key=lambda b: (-int(bin_sizes[b]), str(b)))
+    heap = [(0, r) for r in range(world_size)]
+    heapq.heapify(heap)
+    owner = {}
+    for b in order:
+        load, r = heapq.heappop(heap)
+        owner[b] = r
+        heapq.heappush(heap, (load + int(bin_sizes[b]), r))
+    loads = [0] * world_size
+    for b, r in owner.items():
+        loads[r] += int(bin_sizes[b])
+    mean = sum(loads) / world_size
+    if mean == 0 or max(loads) > (1.0 + tolerance) * mean:
+        return None
+    return [[b for b in bin_sizes if owner[b] == r] for r in range(world_size)]

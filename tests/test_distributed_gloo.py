@@ -102,3 +102,17 @@ def test_contig_assignment_is_balanced_and_complete():
     # one huge bin must still be split
     parts = assign_contigs(mg.lengths, 4, bins=["only"] * 1000)
     assert min(len(p) for p in parts) > 100
+
+
+def test_assign_bins_balances_or_declines():
+    from nanomotif_amd.shard import assign_bins
+    sizes = {f"bin{i}": 1_000_000 + 1000 * i for i in range(40)}
+    parts = assign_bins(sizes, 4)
+    assert parts is not None and sorted(b for p in parts for b in p) == sorted(sizes)
+    loads = [sum(sizes[b] for b in p) for p in parts]
+    assert max(loads) <= 1.15 * (sum(loads) / 4)
+    for p in parts:                                             # bins keep their input order inside a rank
+        assert p == [b for b in sizes if b in set(p)]
+    assert assign_bins({"big": 10_000_000, "small": 100_000}, 2) is None          # contigs must be the unit then
+    assert assign_bins({"big": 10_000_000, "small": 100_000}, 2, tolerance=float("inf")) == [["big"], ["small"]]
+    assert assign_bins(sizes, 1) == [list(sizes)]

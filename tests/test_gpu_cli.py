@@ -97,7 +97,12 @@ def test_two_ranks_give_the_single_rank_output(tmp_path):
     mg.write_bed(tmp + "/pileup.bed")
     mg.write_contig_bin(tmp + "/contig_bin.tsv")
     _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out1"])
-    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out2"], nproc=2)
-    one, two = open(tmp + "/out1/bin-motifs.tsv").read(), open(tmp + "/out2/bin-motifs.tsv").read()
+    one = open(tmp + "/out1/bin-motifs.tsv").read()
     assert len(one.strip().split("\n")) > 3
-    assert one == two
+    # contigs of every bin over both ranks (all-reduce per round) / whole bins per rank (rows gathered at the end)
+    for mode in ("contigs", "bins"):
+        r = _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_" + mode, "--shard", mode], nproc=2)
+        assert open(f"{tmp}/out_{mode}/bin-motifs.tsv").read() == one, mode
+        assert ("whole bins per GPU" in r.stdout + r.stderr) == (mode == "bins")
+        assert os.path.isdir(f"{tmp}/out_{mode}/precleanup-motifs")
+        assert sorted(os.listdir(f"{tmp}/out_{mode}/precleanup-motifs")) == sorted(os.listdir(tmp + "/out1/precleanup-motifs"))
