@@ -8,10 +8,14 @@ A *step* = one pass of the hot path over one batch: the cfg 5 candidate table (1
 table in HBM — and, with more than one GPU, one RCCL all-reduce (sum, int64) of the count table.
 A *motif-site* = one (candidate x reference bp x strand) match test: a candidate on a bin of L bp is 2·L sites.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--total-bp B] [--workload cfg5|greedy]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--total-bp B] [--workload cfg5|greedy] [--scaling weak|strong]
 
-Multi-GPU: launched by torch.distributed.run, one rank per GPU; contigs are sharded across ranks
-(longest-first), total work is fixed ("strong" scaling), every rank compiles the same candidate table.
+Multi-GPU: launched by torch.distributed.run, one rank per GPU.  Bins are independent searches, so the default
+("weak" scaling) gives every GPU whole bins — its own cfg 5 metagenome of --total-bp (rank r is seeded 1 + r) and
+that metagenome's candidate table — with no collective on the data path, the way ``python -m nanomotif_amd`` shards
+a metagenome whose bins balance (nanomotif_amd/shard.py: assign_bins); value = motif-sites of all ranks / the
+slowest rank's time.  ``--scaling strong`` keeps ONE --total-bp metagenome, shards the contigs of every bin over the
+ranks (longest-first) and sums the count tables with one RCCL all-reduce per step — the path for few / huge bins.
 Inputs are generated on the device (nanomotif_amd/synth_device.py) and are resident in HBM before the timed
 region.  Rank 0 prints ONE JSON line.
 """
@@ -136,6 +140,9 @@ def main():
     ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: min(32, host cores))")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = whole bins per GPU, one --total-bp metagenome each, no collective (default); "
+                         "strong = one metagenome, contigs sharded, count tables all-reduced every step")
     args = ap.parse_args()
 
     import torch
@@ -159,18 +166,23 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    spec = synth.SynthSpec(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=1)
-    spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=1)
+    weak = args.scaling == "weak"
+    reduce_counts = world > 1 and not weak
+    seed = 1 + rank if weak else 1
+    spec = synth.SynthSpec(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
+    spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
     mg = synth.make_metagenome(spec)
-    parts = assign_contigs(mg.lengths, world, bins=mg.bin_names)
-    mine = parts[rank]
+    if weak:
+        mine = np.arange(len(mg.names))
+    else:
+        mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
 
     if args.workload == "e2e":
         return run_e2e(args, mg, device, local_rank, world)
 
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
-    rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if world == 1 else mine, progress=log)
+    rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if (world == 1 or weak) else mine, progress=log)
     # one explicit side stream carries the engine's launches AND the collectives (the legacy default stream has the
     # handle 0, which nm_set_stream reads as "use the ctx's own stream": never hand it that)
     side = torch.cuda.Stream(device)
@@ -207,9 +219,9 @@ def main():
         if pending[i] is not None:
             pending[i].wait()                               # table i is free again (its all-reduce finished)
         eng.score_into_device(batch, counts[i].data_ptr())
-        if world > 1 and args.dist_backend == "nccl":
+        if reduce_counts and args.dist_backend == "nccl":
             pending[i] = dist.all_reduce(counts[i], async_op=True)   # RCCL sum over xGMI
-        elif world > 1:                                              # debug path: reduce through the host
+        elif reduce_counts:                                          # debug path: reduce through the host
             host = counts[i].cpu()
             dist.all_reduce(host)
             counts[i].copy_(host)
@@ -274,30 +286,35 @@ def main():
                      "bound": "hbm", "kernel_ms": g_ms, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": g_bytes, "launches": g_n,
-                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3) / max(world, 1) * world}
+                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) * (world if weak else 1) / (g_ms * 1e-3)}
 
     result = None
     traffic, traffic_src, valu_insts = None, None, None
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         t = json.load(open(tj))
-        if (t.get("workload"), t.get("total_bp"), t.get("candidates"), t.get("n_gpus")) == \
-                (args.workload, args.total_bp, len(cands), world):
+        # measured per launch on one GPU; every rank of a weak-scaling run launches that same configuration
+        if (t.get("workload"), t.get("total_bp"), t.get("candidates")) == (args.workload, args.total_bp, len(cands)) \
+                and (t.get("n_gpus") == world or (weak and t.get("n_gpus") == 1)):
             traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
             valu_insts = t.get("sq_insts_valu_per_launch")
     if rank == 0:
-        value = sites_per_step * args.steps / elapsed
+        value = sites_per_step * (world if weak else 1) * args.steps / elapsed
         achieved = algo_bytes_rank / (kernel_ms * 1e-3) / 1e9
         result = {
             "metric": "motif-sites scored/sec (1 Gbp synthetic metagenome)", "value": value, "unit": "motif-sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 bit-planes / int64 counts",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 bit-planes / int64 counts",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {len(cands)} candidate motifs x {args.total_bp:,} bp metagenome "
+            "config": {"workload": f"{args.workload}: {len(cands) * (world if weak else 1)} candidate motifs x {args.total_bp * (world if weak else 1):,} bp metagenome "
                                    f"({args.contigs} contigs, {args.bins} bins, 6mA+5mC), both strands",
-                       "candidates": len(cands), "total_bp": args.total_bp, "contigs": args.contigs, "bins": args.bins,
-                       "mod_types": ["a", "m"], "sharding": f"contigs over {world} GPU(s), longest-first, bins kept whole when small",
-                       "motif_sites_per_step": sites_per_step},
+                       "candidates": len(cands) * (world if weak else 1), "total_bp": args.total_bp * (world if weak else 1),
+                       "contigs": args.contigs * (world if weak else 1), "bins": args.bins * (world if weak else 1),
+                       "per_gpu": {"total_bp": args.total_bp, "candidates": len(cands)} if weak else None,
+                       "mod_types": ["a", "m"],
+                       "sharding": (f"whole bins per GPU: {world} x ({args.bins} bins, {args.total_bp:,} bp, {len(cands)} candidates), no collective"
+                                    if weak else f"contigs over {world} GPU(s), longest-first, bins kept whole when small; count tables all-reduced"),
+                       "motif_sites_per_step": sites_per_step * (world if weak else 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src or "not collected for this configuration (rocprofv3 --pmc runs: profiles/)",
