@@ -100,6 +100,111 @@ __device__ __forceinline__ void strand(cu8p prog, int c, int NC, const uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Variant 2: VGPR index mode.  The extended planes are pinned to v40..v199 (plane p at v[40 + 40 p + k]) and a
+// constraint (p, d) is ONE straight-line block of 16 ANDs whose src0 register number is offset by M0 = 40 p + d + DMAX
+// (s_set_gpr_idx_on, SRC0 relative): no switch, no branch.
+// ---------------------------------------------------------------------------------------------------
+#define V10(a) "v" #a "0", "v" #a "1", "v" #a "2", "v" #a "3", "v" #a "4", "v" #a "5", "v" #a "6", "v" #a "7", "v" #a "8", "v" #a "9"
+#define E_CLOBBER V10(4), V10(5), V10(6), V10(7), V10(8), V10(9), V10(10), V10(11), V10(12), V10(13), V10(14), V10(15), V10(16), V10(17), V10(18), V10(19)
+#define ALL_CLOBBER E_CLOBBER, ACC_CLOBBER
+
+template <int N> struct PinE;     // write E value into physical register v[40 + N]
+template <int N>
+__device__ __forceinline__ void pin(uint32_t x);
+#define PIN1(N) template <> __device__ __forceinline__ void pin<N>(uint32_t x) { asm volatile("v_mov_b32 v" STR(N) ", %0" :: "v"(x) : ALL_CLOBBER); }
+#define PIN10(a) PIN1(a##0) PIN1(a##1) PIN1(a##2) PIN1(a##3) PIN1(a##4) PIN1(a##5) PIN1(a##6) PIN1(a##7) PIN1(a##8) PIN1(a##9)
+PIN10(4) PIN10(5) PIN10(6) PIN10(7) PIN10(8) PIN10(9) PIN10(10) PIN10(11) PIN10(12) PIN10(13) PIN10(14) PIN10(15) PIN10(16) PIN10(17) PIN10(18) PIN10(19)
+
+template <int P, int K = 0>
+__device__ __forceinline__ void pin_plane(const uint32_t (&w)[R], const uint32_t (&nx)[R], const uint32_t (&pv)[R]) {
+    if constexpr (K < EXT) {
+        uint32_t x;
+        if constexpr (K < DMAX) x = (w[R - DMAX + K] << 1) | (pv[R - DMAX + K] >> 31);          // one bit row down, carry from the previous block
+        else if constexpr (K < DMAX + R) x = w[K - DMAX];
+        else x = (w[K - DMAX - R] >> 1) | (nx[K - DMAX - R] << 31);                               // one bit row up
+        pin<40 + 40 * P + K>(x);
+        pin_plane<P, K + 1>(w, nx, pv);
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void and_indexed(uint32_t idx) {
+    if constexpr (S == 0)
+        asm volatile("s_set_gpr_idx_on %0, 0x1\n\ts_nop 1\n\t"
+                     "v_and_b32 v200, v40, v200\n\tv_and_b32 v201, v41, v201\n\tv_and_b32 v202, v42, v202\n\tv_and_b32 v203, v43, v203\n\t"
+                     "v_and_b32 v204, v44, v204\n\tv_and_b32 v205, v45, v205\n\tv_and_b32 v206, v46, v206\n\tv_and_b32 v207, v47, v207\n\t"
+                     "v_and_b32 v208, v48, v208\n\tv_and_b32 v209, v49, v209\n\tv_and_b32 v210, v50, v210\n\tv_and_b32 v211, v51, v211\n\t"
+                     "v_and_b32 v212, v52, v212\n\tv_and_b32 v213, v53, v213\n\tv_and_b32 v214, v54, v214\n\tv_and_b32 v215, v55, v215\n\t"
+                     "s_set_gpr_idx_off" :: "s"(idx) : ALL_CLOBBER, "m0");
+    else
+        asm volatile("s_set_gpr_idx_on %0, 0x1\n\ts_nop 1\n\t"
+                     "v_and_b32 v216, v40, v216\n\tv_and_b32 v217, v41, v217\n\tv_and_b32 v218, v42, v218\n\tv_and_b32 v219, v43, v219\n\t"
+                     "v_and_b32 v220, v44, v220\n\tv_and_b32 v221, v45, v221\n\tv_and_b32 v222, v46, v222\n\tv_and_b32 v223, v47, v223\n\t"
+                     "v_and_b32 v224, v48, v224\n\tv_and_b32 v225, v49, v225\n\tv_and_b32 v226, v50, v226\n\tv_and_b32 v227, v51, v227\n\t"
+                     "v_and_b32 v228, v52, v228\n\tv_and_b32 v229, v53, v229\n\tv_and_b32 v230, v54, v230\n\tv_and_b32 v231, v55, v231\n\t"
+                     "s_set_gpr_idx_off" :: "s"(idx) : ALL_CLOBBER, "m0");
+}
+template <int S>
+__device__ __forceinline__ void init_indexed(uint32_t idx) {          // acc = plane registers at idx (the modified-base plane at offset 0)
+    if constexpr (S == 0)
+        asm volatile("s_set_gpr_idx_on %0, 0x1\n\ts_nop 1\n\t"
+                     "v_mov_b32 v200, v40\n\tv_mov_b32 v201, v41\n\tv_mov_b32 v202, v42\n\tv_mov_b32 v203, v43\n\tv_mov_b32 v204, v44\n\tv_mov_b32 v205, v45\n\t"
+                     "v_mov_b32 v206, v46\n\tv_mov_b32 v207, v47\n\tv_mov_b32 v208, v48\n\tv_mov_b32 v209, v49\n\tv_mov_b32 v210, v50\n\tv_mov_b32 v211, v51\n\t"
+                     "v_mov_b32 v212, v52\n\tv_mov_b32 v213, v53\n\tv_mov_b32 v214, v54\n\tv_mov_b32 v215, v55\n\ts_set_gpr_idx_off" :: "s"(idx) : ALL_CLOBBER, "m0");
+    else
+        asm volatile("s_set_gpr_idx_on %0, 0x1\n\ts_nop 1\n\t"
+                     "v_mov_b32 v216, v40\n\tv_mov_b32 v217, v41\n\tv_mov_b32 v218, v42\n\tv_mov_b32 v219, v43\n\tv_mov_b32 v220, v44\n\tv_mov_b32 v221, v45\n\t"
+                     "v_mov_b32 v222, v46\n\tv_mov_b32 v223, v47\n\tv_mov_b32 v224, v48\n\tv_mov_b32 v225, v49\n\tv_mov_b32 v226, v50\n\tv_mov_b32 v227, v51\n\t"
+                     "v_mov_b32 v228, v52\n\tv_mov_b32 v229, v53\n\tv_mov_b32 v230, v54\n\tv_mov_b32 v231, v55\n\ts_set_gpr_idx_off" :: "s"(idx) : ALL_CLOBBER, "m0");
+}
+
+typedef const unsigned long long __attribute__((address_space(4))) *cu64p;
+template <int S>
+__device__ __forceinline__ void strand_indexed(cu64p prog8, int c, int NC) {
+    // the (candidate, strand) program = up to 8 register-index bytes, fetched with ONE scalar load
+    unsigned long long codes = prog8[c * 2 + S];
+    init_indexed<S>(40 * S + DMAX);
+    for (int q = 0; q < NC; ++q) {
+        and_indexed<S>((uint32_t)(codes & 0xFF));
+        codes >>= 8;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void proto_indexed(const uint32_t *__restrict__ planes, size_t words,
+                                                        const unsigned long long *__restrict__ prog_, int B, int NC, int tiles_per_block,
+                                                        unsigned long long *out) {
+    cu64p prog = (cu64p)prog_;
+    const int lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long total = 0;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const size_t w0 = ((size_t)t * gridDim.x * blockDim.x + lane_global) * R;
+        {
+            uint32_t w[R], nx[R], pv[R];
+#define LOAD_PLANE(P) \
+            for (int j = 0; j < R; ++j) { w[j] = planes[P * words + w0 + j]; } \
+            for (int j = 0; j < R; ++j) { nx[j] = __shfl_down(w[j], 1); pv[j] = __shfl_up(w[j], 1); } \
+            pin_plane<P>(w, nx, pv);
+            _Pragma("unroll") LOAD_PLANE(0)
+            _Pragma("unroll") LOAD_PLANE(1)
+            _Pragma("unroll") LOAD_PLANE(2)
+            _Pragma("unroll") LOAD_PLANE(3)
+        }
+        uint32_t M[R], U[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) { M[j] = planes[4 * words + w0 + j]; U[j] = planes[5 * words + w0 + j]; }
+        for (int c = 0; c < B; ++c) {
+            strand_indexed<0>(prog, c, NC);
+            strand_indexed<1>(prog, c, NC);
+            uint32_t nm = 0, nu = 0;
+            count(M, U, nm, nu);
+            total += ((unsigned long long)nm << 32) + nu + c;
+        }
+    }
+    if (total == 0x123456789ull) out[0] = total;
+    atomicAdd(out + 1, total & 0xFFFF);
+}
+
 __global__ __launch_bounds__(256, 2) void proto(const uint32_t *__restrict__ planes /*[6][words]*/, size_t words,
                                                 const uint8_t *__restrict__ prog_ /*[B][2][NC] codes*/, int B, int NC,
                                                 int tiles_per_block, unsigned long long *out) {
@@ -152,8 +257,24 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double positions = (double)words * 32, owned = positions * 28.0 / 32.0;      // 2 bit rows of overlap each side
+    printf("[switch dispatch] ");
     printf("transposed-tile proxy: %d candidates x %d constraints/strand, %.3f ms for %.3g positions (%.3g owned)\n", B, NC, ms, positions, owned);
     printf("  motif-sites/s (2 strands, owned positions): %.3e   [current kernel on cfg5: 6.9e13 kernel-only]\n", owned * 2 * B / (ms * 1e-3));
     printf("  bytes/s if planes were 0.5 B/bp per group: %.2f TB/s algorithmic\n", owned * 0.5 / (ms * 1e-3) / 1e12);
+    std::vector<unsigned long long> prog8(B * 2, 0);
+    for (int i = 0; i < B * 2; ++i)
+        for (int q = 0; q < NC && q < 8; ++q) {
+            const int code = prog[i * NC + q], pl = code / (2 * DMAX + 1), k = code % (2 * DMAX + 1);
+            prog8[i] |= (unsigned long long)(40 * pl + k) << (8 * q);
+        }
+    unsigned long long *d_prog8; (void)hipMalloc(&d_prog8, prog8.size() * 8); (void)hipMemcpy(d_prog8, prog8.data(), prog8.size() * 8, hipMemcpyHostToDevice);
+    proto_indexed<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, 1, d_out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    proto_indexed<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, tiles, d_out);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("[VGPR index mode] %d candidates x %d constraints/strand, %.3f ms: %.3e motif-sites/s\n", B, NC, ms, owned * 2 * B / (ms * 1e-3));
+    printf("  hip error state: %s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
