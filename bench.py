@@ -100,28 +100,45 @@ def cpu_baseline_worker(args):
     return bin_name, [out[k] for k in range(len(cands))], t1 - t0, t0 - t_gen, bp
 
 
-def run_e2e(args, mg, device, local_rank, world):
-    """--workload e2e: the whole motif_discovery pipeline on the synthetic metagenome (single GPU): raw pileup rows
-    -> device-side filters -> windows -> lock-step greedy search with pruning -> post-processing.  One step = one
-    full run; motif-sites = 2 x bin length for every candidate the search scored."""
-    if world != 1:
-        raise SystemExit("--workload e2e is single-GPU in this round")
+def run_e2e(args, mg, device, local_rank, world, rank):
+    """--workload e2e: the whole motif_discovery pipeline on the synthetic metagenome: raw pileup rows -> device-side
+    filters -> windows -> lock-step greedy search with pruning -> post-processing.  One step = one full run.  N > 1:
+    whole bins per GPU (weak scaling) — every rank runs the pipeline on its own metagenome (seed 1 + rank), no
+    collective; wall = slowest rank."""
+    import torch
+    import torch.distributed as dist
     from nanomotif_amd import e2e_synth
     from nanomotif_amd.engine import ScanEngine
+    if world > 1 and args.scaling != "weak":
+        raise SystemExit("--workload e2e at N > 1 is the whole-bin (weak) mode; contig sharding of the CLI is covered by tests/test_gpu_cli.py")
     eng = ScanEngine(local_rank)
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     rows, t = e2e_synth.run(mg, eng, device)
+    torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     eng.close()
     rows = [r for r in rows if r.n_mod + r.n_nomod >= 50]
     planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() for m in ms}
     found = {(r.reference, r.motif_iupac) for r in rows}
-    print(json.dumps({
-        "metric": "end-to-end motif_discovery wall seconds (synthetic metagenome)", "value": wall, "unit": "s", "n_gpus": 1,
-        "steps": 1, "warmup": 0, "ms_per_step": wall * 1e3, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-        "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
-        "config": {"workload": f"e2e: motif_discovery on {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC)"},
-        "timings": t, "motifs_reported": len(rows), "planted_motifs": len(planted), "planted_recovered": len(planted & found)}), flush=True)
+    stats = [wall, len(rows), len(planted), len(planted & found)]
+    if world > 1:
+        tt = torch.tensor(stats, dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt)
+        stats = [float(mx[0]), int(tt[1]), int(tt[2]), int(tt[3])]
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "end-to-end motif_discovery wall seconds (synthetic metagenome)", "value": stats[0], "unit": "s", "n_gpus": world,
+            "steps": 1, "warmup": 0, "ms_per_step": stats[0] * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
+            "config": {"workload": f"e2e: motif_discovery on {world} x {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC per GPU)"},
+            "timings_rank0": t, "motifs_reported": stats[1], "planted_motifs": stats[2], "planted_recovered": stats[3]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -178,7 +195,7 @@ def main():
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
 
     if args.workload == "e2e":
-        return run_e2e(args, mg, device, local_rank, world)
+        return run_e2e(args, mg, device, local_rank, world, rank)
 
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
