@@ -5,18 +5,19 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(_HERE, "csrc", "nmscan.hip")
+SRC_HIP = [os.path.join(_HERE, "csrc", f) for f in ("nmscan.hip", "nmingest.hip", "nmwindows.hip")]
 SRC_HOST = [os.path.join(_HERE, "csrc", "nmbed.cpp"), os.path.join(_HERE, "csrc", "nmhost.cpp")]
+INTERNAL = os.path.join(_HERE, "csrc", "nmscan_internal.h")
 OUT = os.path.join(_HERE, "libnmscan.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    deps = [SRC, HEADER] + SRC_HOST
+    deps = SRC_HIP + [HEADER, INTERNAL] + SRC_HOST
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, SRC] + SRC_HOST + ["-lz", "-lpthread"]
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + SRC_HIP + SRC_HOST + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

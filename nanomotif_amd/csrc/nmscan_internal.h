@@ -1,0 +1,175 @@
+// Internal to the translation units of libnmscan (nmscan.hip, nmingest.hip, nmwindows.hip): engine constants, the
+// plane / context structures and the small host helpers they share.  Not part of the C ABI (include/nmscan.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/nmscan.h"
+
+// error sink shared by all translation units (defined in nmscan.hip; the text is what nm_last_error() returns)
+int nm_set_error(int code, const char *fmt, ...);
+#define fail nm_set_error
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(NM_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+namespace nmdetail {
+
+constexpr int T_WORDS = 4;                              // 32-bit words per lane
+constexpr int CHUNK_WORDS = 64 * T_WORDS;               // 256 words
+constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wave-chunk
+constexpr int GAP_BP = 64;                              // invalid positions guaranteed after every contig
+constexpr int SEG_CHUNKS = 16;                          // chunks per workgroup segment (128 Kbp)
+constexpr int BMAX = 32;                                // candidates per LDS accumulation pass
+constexpr int PROG_DW = 64;                             // host-side program: [strand 2][word-group 4][plane 8]
+// device-side programs are packed to the word-groups the launched kernel variant reads:
+// narrow (offsets in [-32, 31]) = groups 1..2 -> 32 dwords (128 B), wide = all four -> 64 dwords
+constexpr int NM_MAX_MOD_CODES = 8;
+constexpr int WIN_MAX_W = 64;                // window width limit (reference default 41)
+constexpr int RANK_BLOCK_WORDS = 16;                          // 512 bp per rank entry
+constexpr int RANK_PER_CHUNK = CHUNK_WORDS / RANK_BLOCK_WORDS;
+
+struct Planes {
+    const uint32_t *H, *L, *V;
+    const uint8_t *needs_v;   // per chunk: 1 => V (and halo) must be consulted
+};
+
+struct StatePlanes {
+    const uint32_t *M, *U;               // compact (strand implied by base)
+    const uint32_t *MP, *UP, *MM, *UM;   // general
+};
+
+struct WinTask {
+    uint64_t plane_off;     // into the plane pool (words): [col][5][nw]
+    uint64_t alive_off;     // into the alive pool (words): [nw]
+    uint32_t n, nw, width, pad;
+};
+
+struct ModSlot {
+    bool present = false;
+    uint8_t canonical = 0;          // 'A' or 'C'
+    double low = 0.3, high = 0.7;
+    uint32_t *planes[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // M U MP UP MM UM
+    uint64_t n_rows = 0;
+    // window extraction: rank tables over the methylated-row planes MP / MM and the per-contig row counts for the
+    // edge padding `meth_pad` ({n_plus, n_minus, head_plus, head_minus} per contig); dropped when the planes change
+    uint32_t *rank[2] = {nullptr, nullptr};
+    uint64_t *rank_total[2] = {nullptr, nullptr};
+    std::vector<uint64_t> meth_counts;
+    uint32_t meth_pad = 0xFFFFFFFFu;
+};
+
+}  // namespace nmdetail
+
+struct nm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    std::vector<uint32_t> bucket;                     // per-call host scratch, kept to avoid reallocation
+    // window engine
+    std::vector<nmdetail::WinTask> win_tasks;
+    uint32_t *d_win_planes = nullptr, *d_win_alive = nullptr;
+    uint64_t win_planes_cap = 0, win_alive_cap = 0, win_planes_used = 0, win_alive_used = 0;
+    nmdetail::WinTask *d_win_tasks = nullptr;
+    size_t d_win_tasks_cap = 0;
+    bool win_tasks_dirty = false;
+    // results of the last nm_ingest_pileup
+    std::vector<uint32_t> ing_kept;                   // kept rows per (contig, mod code)
+    uint32_t *d_ing_contig = nullptr, *d_ing_pos = nullptr;   // confident rows stay on the device until asked for
+    uint8_t *d_ing_strand = nullptr;
+    int8_t *d_ing_mod = nullptr;
+    uint64_t ing_nconf = 0;
+    uint32_t *d_programs = nullptr;                   // compiled constraint programs of the current batch
+    size_t prog_cap_dw = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // per-launch event pairs since the last nm_timing_reset (bounded pool, summed lazily: no sync per launch)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    bool ev_collect = false;
+    // assembly
+    uint32_t n_contigs = 0, n_bins = 0, n_chunks = 0;
+    uint64_t total_bp = 0;
+    std::vector<uint64_t> contig_len;
+    std::vector<uint32_t> contig_chunk, contig_bin, contig_nchunks;
+    std::vector<uint32_t> bin_chunk0, bin_nchunks;
+    uint32_t *dH = nullptr, *dL = nullptr, *dV = nullptr;
+    uint8_t *d_needs_v = nullptr;
+    uint32_t *d_contig_chunk = nullptr;
+    uint64_t *d_contig_len = nullptr;
+    uint4 *d_segments = nullptr;
+    uint32_t n_segments = 0;
+    nmdetail::ModSlot slots[NM_MAX_MOD_SLOTS];
+    // per-call staging: ring of two (device, pinned host) buffer pairs so that compiling the next batch on the
+    // host overlaps the previous launch; `busy` marks the last device work that read the pair.
+    struct Stage {
+        void *d = nullptr, *h = nullptr;
+        size_t bytes = 0;
+        hipEvent_t busy = nullptr;
+        bool pending = false;
+    } stage[2];
+    int stage_next = 0;
+    void *d_stage = nullptr, *h_stage = nullptr;   // the pair acquired by the current call
+    Stage *cur_stage = nullptr;
+    unsigned long long *d_counts = nullptr;
+    size_t counts_cap = 0;
+    unsigned int *d_err = nullptr;
+    // window extraction: per-base rank tables over the sequence planes (built on first use), other-letter count
+    uint32_t *d_rank[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t *d_base_total[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long *d_other = nullptr;
+    uint64_t other_letters = 0;
+    uint64_t launches = 0, last_wgs = 0, last_compact = 0, last_general = 0;
+};
+
+namespace nmdetail {
+
+inline size_t plane_words(const nm_ctx *c) { return (size_t)c->n_chunks * CHUNK_WORDS; }
+
+inline Planes seq_planes(const nm_ctx *c) {
+    Planes p;
+    p.H = c->dH;
+    p.L = c->dL;
+    p.V = c->dV;
+    p.needs_v = c->d_needs_v;
+    return p;
+}
+
+inline void drop_slot_ranks(ModSlot &ms) {
+    for (int k = 0; k < 2; ++k) {
+        if (ms.rank[k]) (void)hipFree(ms.rank[k]);
+        if (ms.rank_total[k]) (void)hipFree(ms.rank_total[k]);
+        ms.rank[k] = nullptr;
+        ms.rank_total[k] = nullptr;
+    }
+    ms.meth_counts.clear();
+    ms.meth_pad = 0xFFFFFFFFu;
+}
+
+inline void drop_ingest_rows(nm_ctx *c) {
+    void *ptrs[] = {c->d_ing_contig, c->d_ing_pos, c->d_ing_strand, c->d_ing_mod};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_ing_contig = c->d_ing_pos = nullptr;
+    c->d_ing_strand = nullptr;
+    c->d_ing_mod = nullptr;
+    c->ing_nconf = 0;
+}
+
+// pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it
+// busy until the work enqueued so far on the ctx stream has run
+int ensure_stage(nm_ctx *c, size_t bytes);
+int release_stage(nm_ctx *c);
+
+}  // namespace nmdetail
