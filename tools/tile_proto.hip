@@ -238,6 +238,89 @@ __global__ __launch_bounds__(256, 2) void proto(const uint32_t *__restrict__ pla
     atomicAdd(out + 1, total & 0xFFFF);
 }
 
+// Variant 3: the whole (candidate, strand) program in ONE asm block — index mode stays on, s_set_gpr_idx_idx per
+// constraint, scalar loop in asm; popcounts in four independent chains.
+template <int S>
+__device__ __forceinline__ void strand_asm(cu64p prog8, int c, int NC) {
+    const unsigned long long codes = prog8[c * 2 + S];
+    uint32_t lo = (uint32_t)codes, hi = (uint32_t)(codes >> 32);
+    uint32_t n = NC, init_idx = 40 * S + DMAX, tmp;
+#define ANDS(B0) \
+    "v_and_b32 v" STR(B0) "0, v40, v" STR(B0) "0\n\tv_and_b32 v" STR(B0) "1, v41, v" STR(B0) "1\n\t"
+    if constexpr (S == 0)
+        asm volatile(
+            "s_set_gpr_idx_on %4, 0x1\n\ts_nop 1\n\t"
+            "v_mov_b32 v200, v40\n\tv_mov_b32 v201, v41\n\tv_mov_b32 v202, v42\n\tv_mov_b32 v203, v43\n\tv_mov_b32 v204, v44\n\tv_mov_b32 v205, v45\n\t"
+            "v_mov_b32 v206, v46\n\tv_mov_b32 v207, v47\n\tv_mov_b32 v208, v48\n\tv_mov_b32 v209, v49\n\tv_mov_b32 v210, v50\n\tv_mov_b32 v211, v51\n\t"
+            "v_mov_b32 v212, v52\n\tv_mov_b32 v213, v53\n\tv_mov_b32 v214, v54\n\tv_mov_b32 v215, v55\n\t"
+            "s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 2f\n\t"
+            "1:\n\t"
+            "s_and_b32 %2, %0, 0xff\n\ts_set_gpr_idx_idx %2\n\ts_lshr_b32 %0, %0, 8\n\ts_lshl_b32 %2, %3, 24\n\ts_or_b32 %0, %0, %2\n\ts_lshr_b32 %3, %3, 8\n\ts_sub_u32 %1, %1, 1\n\t"
+            "v_and_b32 v200, v40, v200\n\tv_and_b32 v201, v41, v201\n\tv_and_b32 v202, v42, v202\n\tv_and_b32 v203, v43, v203\n\t"
+            "v_and_b32 v204, v44, v204\n\tv_and_b32 v205, v45, v205\n\tv_and_b32 v206, v46, v206\n\tv_and_b32 v207, v47, v207\n\t"
+            "v_and_b32 v208, v48, v208\n\tv_and_b32 v209, v49, v209\n\tv_and_b32 v210, v50, v210\n\tv_and_b32 v211, v51, v211\n\t"
+            "v_and_b32 v212, v52, v212\n\tv_and_b32 v213, v53, v213\n\tv_and_b32 v214, v54, v214\n\tv_and_b32 v215, v55, v215\n\t"
+            "s_cmp_lg_u32 %1, 0\n\ts_cbranch_scc1 1b\n\t"
+            "2:\n\ts_set_gpr_idx_off"
+            : "+s"(lo), "+s"(n), "=&s"(tmp), "+s"(hi) : "s"(init_idx) : ALL_CLOBBER, "m0", "scc");
+    else
+        asm volatile(
+            "s_set_gpr_idx_on %4, 0x1\n\ts_nop 1\n\t"
+            "v_mov_b32 v216, v40\n\tv_mov_b32 v217, v41\n\tv_mov_b32 v218, v42\n\tv_mov_b32 v219, v43\n\tv_mov_b32 v220, v44\n\tv_mov_b32 v221, v45\n\t"
+            "v_mov_b32 v222, v46\n\tv_mov_b32 v223, v47\n\tv_mov_b32 v224, v48\n\tv_mov_b32 v225, v49\n\tv_mov_b32 v226, v50\n\tv_mov_b32 v227, v51\n\t"
+            "v_mov_b32 v228, v52\n\tv_mov_b32 v229, v53\n\tv_mov_b32 v230, v54\n\tv_mov_b32 v231, v55\n\t"
+            "s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 2f\n\t"
+            "1:\n\t"
+            "s_and_b32 %2, %0, 0xff\n\ts_set_gpr_idx_idx %2\n\ts_lshr_b32 %0, %0, 8\n\ts_lshl_b32 %2, %3, 24\n\ts_or_b32 %0, %0, %2\n\ts_lshr_b32 %3, %3, 8\n\ts_sub_u32 %1, %1, 1\n\t"
+            "v_and_b32 v216, v40, v216\n\tv_and_b32 v217, v41, v217\n\tv_and_b32 v218, v42, v218\n\tv_and_b32 v219, v43, v219\n\t"
+            "v_and_b32 v220, v44, v220\n\tv_and_b32 v221, v45, v221\n\tv_and_b32 v222, v46, v222\n\tv_and_b32 v223, v47, v223\n\t"
+            "v_and_b32 v224, v48, v224\n\tv_and_b32 v225, v49, v225\n\tv_and_b32 v226, v50, v226\n\tv_and_b32 v227, v51, v227\n\t"
+            "v_and_b32 v228, v52, v228\n\tv_and_b32 v229, v53, v229\n\tv_and_b32 v230, v54, v230\n\tv_and_b32 v231, v55, v231\n\t"
+            "s_cmp_lg_u32 %1, 0\n\ts_cbranch_scc1 1b\n\t"
+            "2:\n\ts_set_gpr_idx_off"
+            : "+s"(lo), "+s"(n), "=&s"(tmp), "+s"(hi) : "s"(init_idx) : ALL_CLOBBER, "m0", "scc");
+}
+
+template <int J = 0>
+__device__ __forceinline__ void count4(const uint32_t (&M)[R], const uint32_t (&U)[R], uint32_t (&nm)[4], uint32_t (&nu)[4]) {
+    if constexpr (J < R) {
+        const uint32_t h = HitReg<J>::get();
+        nm[J & 3] += __popc(h & M[J]);
+        nu[J & 3] += __popc(h & U[J]);
+        count4<J + 1>(M, U, nm, nu);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void proto_asm(const uint32_t *__restrict__ planes, size_t words,
+                                                    const unsigned long long *__restrict__ prog_, int B, int NC, int tiles_per_block,
+                                                    unsigned long long *out) {
+    cu64p prog = (cu64p)prog_;
+    const int lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long total = 0;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const size_t w0 = ((size_t)t * gridDim.x * blockDim.x + lane_global) * R;
+        {
+            uint32_t w[R], nx[R], pv[R];
+            _Pragma("unroll") LOAD_PLANE(0)
+            _Pragma("unroll") LOAD_PLANE(1)
+            _Pragma("unroll") LOAD_PLANE(2)
+            _Pragma("unroll") LOAD_PLANE(3)
+        }
+        uint32_t M[R], U[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) { M[j] = planes[4 * words + w0 + j]; U[j] = planes[5 * words + w0 + j]; }
+        for (int c = 0; c < B; ++c) {
+            strand_asm<0>(prog, c, NC);
+            strand_asm<1>(prog, c, NC);
+            uint32_t nm[4] = {0, 0, 0, 0}, nu[4] = {0, 0, 0, 0};
+            count4(M, U, nm, nu);
+            total += ((unsigned long long)(nm[0] + nm[1] + nm[2] + nm[3]) << 32) + nu[0] + nu[1] + nu[2] + nu[3] + c;
+        }
+    }
+    if (total == 0x123456789ull) out[0] = total;
+    atomicAdd(out + 1, total & 0xFFFF);
+}
+
 int main(int argc, char **argv) {
     const int B = 20, NC = argc > 1 ? atoi(argv[1]) : 5, blocks = 2048, tiles = 8;
     const size_t words = (size_t)blocks * 256 * R * tiles;
@@ -275,6 +358,13 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("[VGPR index mode] %d candidates x %d constraints/strand, %.3f ms: %.3e motif-sites/s\n", B, NC, ms, owned * 2 * B / (ms * 1e-3));
+    proto_asm<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, 1, d_out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    proto_asm<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, tiles, d_out);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("[index mode, asm strand loop] %d candidates x %d constraints/strand, %.3f ms: %.3e motif-sites/s\n", B, NC, ms, owned * 2 * B / (ms * 1e-3));
     printf("  hip error state: %s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
