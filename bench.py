@@ -136,6 +136,7 @@ def run_e2e(args, mg, device, local_rank, world, rank):
             "steps": 1, "warmup": 0, "ms_per_step": stats[0] * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
             "config": {"workload": f"e2e: motif_discovery on {world} x {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC per GPU)"},
+            "pipeline_s_rank0": t["upload_filter_s"] + t["search_s"],     # device filters + search, without the synthetic data generation
             "timings_rank0": t, "motifs_reported": stats[1], "planted_motifs": stats[2], "planted_recovered": stats[3]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
