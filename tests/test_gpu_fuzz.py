@@ -1,0 +1,81 @@
+"""Seeded fuzz parity: random assemblies (N runs, lower case, other IUPAC letters, contigs around the chunk / word
+edges), random pileups (rows on any base and strand, fractions on and around the thresholds) and random motifs
+(literals, 2- and 3-base sets, gaps, offsets out to +-63, modified position on a set or on '.') through the C ABI
+against the CPU oracle — integer counts bit-exact."""
+import numpy as np
+import pytest
+
+from nanomotif_amd.motif import Motif
+
+pytestmark = pytest.mark.gpu
+
+SETS = ["A", "C", "G", "T", "[AC]", "[AG]", "[AT]", "[CG]", "[CT]", "[GT]", "[ACG]", "[ACT]", "[AGT]", "[CGT]", "."]
+
+
+def _motif(rng, wide):
+    n = int(rng.integers(1, 64 if wide else 18))
+    w = np.array([0.13] * 4 + [0.02] * 6 + [0.015] * 4 + [0.3])
+    pos = [SETS[int(rng.choice(len(SETS), p=w / w.sum()))] for _ in range(n)]
+    if wide:                                   # mostly gaps, so that something still matches
+        for i in rng.choice(n, size=max(0, n - 4), replace=False):
+            pos[int(i)] = "."
+    if all(p == "." for p in pos):
+        pos[int(rng.integers(n))] = "ACGT"[int(rng.integers(4))]
+    spec = [i for i, p in enumerate(pos) if p != "."]
+    # the modified position may sit on a set or on an inner '.', but not on a flank that stripping removes
+    # (Motif.new_stripped_motif would leave it outside the motif; the engine refuses that loudly)
+    return "".join(pos), int(rng.integers(spec[0], spec[-1] + 1))
+
+
+def _contig(rng, n):
+    s = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n, p=[0.3, 0.2, 0.2, 0.3])
+    for _ in range(int(rng.integers(0, 4))):                         # N runs and stray IUPAC letters
+        a = int(rng.integers(0, n)); s[a:a + int(rng.integers(1, 70))] = ord("N")
+    for ch in b"RYKMSWN":
+        if rng.random() < 0.5:
+            s[rng.integers(0, n, size=max(1, n // 5000))] = ch
+    txt = s.tobytes().decode()
+    return txt.lower() if rng.random() < 0.2 else txt
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fuzz_counts_match_oracle(seed):
+    from nanomotif_amd.engine import ScanEngine
+    from oracle.scan import ContigPileup, score_candidates
+    rng = np.random.default_rng(1000 + seed)
+    lens = [int(x) for x in rng.choice([1, 2, 31, 33, 100, 8191, 8192, 8193, 12_000, 16_384, 30_000, 70_000], size=9)]
+    names = [f"c{i}" for i in range(len(lens))]
+    seqs = [_contig(rng, n) for n in lens]
+    bins = [f"b{int(rng.integers(3))}" for _ in lens]
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, seqs, bins)
+    fr_values = np.array([0.0, 0.1, 0.3, 0.30000000000000004, 0.29999999999999993, 0.5, 0.7, 0.7000000000000001, 0.6999999999999999, 0.95, 1.0])
+    piles = {}
+    for mt in ("a", "m"):
+        piles[mt] = {}
+        cid, pos, st, fr = [], [], [], []
+        for i, n in enumerate(lens):
+            k = int(rng.integers(0, 2 * n + 1))
+            flat = rng.choice(2 * n, size=min(k, 2 * n), replace=False)          # unique (position, strand)
+            p, strand = (flat // 2).astype(np.int64), np.where(flat % 2 == 0, ord("+"), ord("-")).astype(np.uint8)
+            f = rng.choice(fr_values, size=len(p))
+            piles[mt][names[i]] = ContigPileup(p, strand, f)
+            cid.append(np.full(len(p), i, np.uint32)); pos.append(p); st.append(strand); fr.append(f)
+        eng.upload_pileup(mt, np.concatenate(cid), np.concatenate(pos), np.concatenate(st), np.concatenate(fr))
+    cands, spec = [], []
+    for k in range(160):
+        s, p = _motif(rng, wide=(k % 5 == 0))
+        mt, b = ("a", "m")[int(rng.integers(2))], f"b{int(rng.integers(3))}"
+        if b not in bins:
+            continue
+        cands.append((Motif(s, p), mt, b)); spec.append((s, p, mt, b))
+    got = eng.score(cands)
+    for mt in ("a", "m"):
+        for b in sorted(set(bins)):
+            idx = [k for k, (_, _, m2, b2) in enumerate(spec) if (m2, b2) == (mt, b)]
+            if not idx:
+                continue
+            contigs = {names[i]: seqs[i].upper() for i in range(len(lens)) if bins[i] == b}
+            exp = score_candidates({n: piles[mt][n] for n in contigs}, contigs, [(spec[k][0], spec[k][1]) for k in idx])
+            assert np.array_equal(got[idx], exp), (seed, mt, b, [spec[k] for k in idx if got[k].tolist() != exp[idx.index(k)].tolist()][:3])
+    eng.close()
