@@ -321,6 +321,87 @@ __global__ __launch_bounds__(256, 2) void proto_asm(const uint32_t *__restrict__
     atomicAdd(out + 1, total & 0xFFFF);
 }
 
+// Variant 4: statically addressed 16-AND blocks behind an INDIRECT JUMP.  One block per register offset (160 per
+// strand, 68 bytes each, generated with assembler .rept), dispatch = s_mul / s_add / s_setpc_b64, every block ends with
+// a direct s_branch back to the loop head.  The ANDs keep the plain 2.6-cycle rate.
+template <int S>
+__device__ __forceinline__ void strand_jump(cu64p prog8, int c, int NC) {
+    const unsigned long long codes = prog8[c * 2 + S];
+    uint32_t lo = (uint32_t)codes, hi = (uint32_t)(codes >> 32), n = NC, tmp;
+    if constexpr (S == 0)
+        asm volatile(
+            "v_mov_b32 v200, v52\n\tv_mov_b32 v201, v53\n\tv_mov_b32 v202, v54\n\tv_mov_b32 v203, v55\n\tv_mov_b32 v204, v56\n\tv_mov_b32 v205, v57\n\t"
+            "v_mov_b32 v206, v58\n\tv_mov_b32 v207, v59\n\tv_mov_b32 v208, v60\n\tv_mov_b32 v209, v61\n\tv_mov_b32 v210, v62\n\tv_mov_b32 v211, v63\n\t"
+            "v_mov_b32 v212, v64\n\tv_mov_b32 v213, v65\n\tv_mov_b32 v214, v66\n\tv_mov_b32 v215, v67\n\t"
+            "s_getpc_b64 s[96:97]\n"
+            "10:\n\t"
+            "s_add_u32 s96, s96, 30f-10b\n\ts_addc_u32 s97, s97, 0\n"
+            "11:\n\t"
+            "s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 40f\n\t"
+            "s_and_b32 %2, %0, 0xff\n\ts_lshr_b32 %0, %0, 8\n\ts_lshl_b32 s98, %3, 24\n\ts_or_b32 %0, %0, s98\n\ts_lshr_b32 %3, %3, 8\n\ts_sub_u32 %1, %1, 1\n\t"
+            "s_mul_i32 %2, %2, 68\n\ts_add_u32 s98, s96, %2\n\ts_addc_u32 s99, s97, 0\n\ts_setpc_b64 s[98:99]\n"
+            "30:\n\t"
+            ".set nm_k, 0\n\t.rept 160\n\t"
+            "v_and_b32 v200, v[40+nm_k], v200\n\tv_and_b32 v201, v[41+nm_k], v201\n\tv_and_b32 v202, v[42+nm_k], v202\n\tv_and_b32 v203, v[43+nm_k], v203\n\t"
+            "v_and_b32 v204, v[44+nm_k], v204\n\tv_and_b32 v205, v[45+nm_k], v205\n\tv_and_b32 v206, v[46+nm_k], v206\n\tv_and_b32 v207, v[47+nm_k], v207\n\t"
+            "v_and_b32 v208, v[48+nm_k], v208\n\tv_and_b32 v209, v[49+nm_k], v209\n\tv_and_b32 v210, v[50+nm_k], v210\n\tv_and_b32 v211, v[51+nm_k], v211\n\t"
+            "v_and_b32 v212, v[52+nm_k], v212\n\tv_and_b32 v213, v[53+nm_k], v213\n\tv_and_b32 v214, v[54+nm_k], v214\n\tv_and_b32 v215, v[55+nm_k], v215\n\t"
+            "s_branch 11b\n\t.set nm_k, nm_k+1\n\t.endr\n"
+            "40:\n\t"
+            : "+s"(lo), "+s"(n), "=&s"(tmp), "+s"(hi) :: ALL_CLOBBER, "s96", "s97", "s98", "s99", "scc");
+    else
+        asm volatile(
+            "v_mov_b32 v216, v92\n\tv_mov_b32 v217, v93\n\tv_mov_b32 v218, v94\n\tv_mov_b32 v219, v95\n\tv_mov_b32 v220, v96\n\tv_mov_b32 v221, v97\n\t"
+            "v_mov_b32 v222, v98\n\tv_mov_b32 v223, v99\n\tv_mov_b32 v224, v100\n\tv_mov_b32 v225, v101\n\tv_mov_b32 v226, v102\n\tv_mov_b32 v227, v103\n\t"
+            "v_mov_b32 v228, v104\n\tv_mov_b32 v229, v105\n\tv_mov_b32 v230, v106\n\tv_mov_b32 v231, v107\n\t"
+            "s_getpc_b64 s[96:97]\n"
+            "10:\n\t"
+            "s_add_u32 s96, s96, 30f-10b\n\ts_addc_u32 s97, s97, 0\n"
+            "11:\n\t"
+            "s_cmp_eq_u32 %1, 0\n\ts_cbranch_scc1 40f\n\t"
+            "s_and_b32 %2, %0, 0xff\n\ts_lshr_b32 %0, %0, 8\n\ts_lshl_b32 s98, %3, 24\n\ts_or_b32 %0, %0, s98\n\ts_lshr_b32 %3, %3, 8\n\ts_sub_u32 %1, %1, 1\n\t"
+            "s_mul_i32 %2, %2, 68\n\ts_add_u32 s98, s96, %2\n\ts_addc_u32 s99, s97, 0\n\ts_setpc_b64 s[98:99]\n"
+            "30:\n\t"
+            ".set nm_k, 0\n\t.rept 160\n\t"
+            "v_and_b32 v216, v[40+nm_k], v216\n\tv_and_b32 v217, v[41+nm_k], v217\n\tv_and_b32 v218, v[42+nm_k], v218\n\tv_and_b32 v219, v[43+nm_k], v219\n\t"
+            "v_and_b32 v220, v[44+nm_k], v220\n\tv_and_b32 v221, v[45+nm_k], v221\n\tv_and_b32 v222, v[46+nm_k], v222\n\tv_and_b32 v223, v[47+nm_k], v223\n\t"
+            "v_and_b32 v224, v[48+nm_k], v224\n\tv_and_b32 v225, v[49+nm_k], v225\n\tv_and_b32 v226, v[50+nm_k], v226\n\tv_and_b32 v227, v[51+nm_k], v227\n\t"
+            "v_and_b32 v228, v[52+nm_k], v228\n\tv_and_b32 v229, v[53+nm_k], v229\n\tv_and_b32 v230, v[54+nm_k], v230\n\tv_and_b32 v231, v[55+nm_k], v231\n\t"
+            "s_branch 11b\n\t.set nm_k, nm_k+1\n\t.endr\n"
+            "40:\n\t"
+            : "+s"(lo), "+s"(n), "=&s"(tmp), "+s"(hi) :: ALL_CLOBBER, "s96", "s97", "s98", "s99", "scc");
+}
+
+__global__ __launch_bounds__(256, 2) void proto_jump(const uint32_t *__restrict__ planes, size_t words,
+                                                     const unsigned long long *__restrict__ prog_, int B, int NC, int tiles_per_block,
+                                                     unsigned long long *out) {
+    cu64p prog = (cu64p)prog_;
+    const int lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long total = 0;
+    for (int t = 0; t < tiles_per_block; ++t) {
+        const size_t w0 = ((size_t)t * gridDim.x * blockDim.x + lane_global) * R;
+        {
+            uint32_t w[R], nx[R], pv[R];
+            _Pragma("unroll") LOAD_PLANE(0)
+            _Pragma("unroll") LOAD_PLANE(1)
+            _Pragma("unroll") LOAD_PLANE(2)
+            _Pragma("unroll") LOAD_PLANE(3)
+        }
+        uint32_t M[R], U[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) { M[j] = planes[4 * words + w0 + j]; U[j] = planes[5 * words + w0 + j]; }
+        for (int c = 0; c < B; ++c) {
+            strand_jump<0>(prog, c, NC);
+            strand_jump<1>(prog, c, NC);
+            uint32_t nm[4] = {0, 0, 0, 0}, nu[4] = {0, 0, 0, 0};
+            count4(M, U, nm, nu);
+            total += ((unsigned long long)(nm[0] + nm[1] + nm[2] + nm[3]) << 32) + nu[0] + nu[1] + nu[2] + nu[3] + c;
+        }
+    }
+    if (total == 0x123456789ull) out[0] = total;
+    atomicAdd(out + 1, total & 0xFFFF);
+}
+
 int main(int argc, char **argv) {
     const int B = 20, NC = argc > 1 ? atoi(argv[1]) : 5, blocks = 2048, tiles = 8;
     const size_t words = (size_t)blocks * 256 * R * tiles;
@@ -365,6 +446,13 @@ int main(int argc, char **argv) {
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     printf("[index mode, asm strand loop] %d candidates x %d constraints/strand, %.3f ms: %.3e motif-sites/s\n", B, NC, ms, owned * 2 * B / (ms * 1e-3));
+    proto_jump<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, 1, d_out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    proto_jump<<<blocks, 256>>>(d_planes, words, d_prog8, B, NC, tiles, d_out);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("[indirect jump to static blocks] %d candidates x %d constraints/strand, %.3f ms: %.3e motif-sites/s\n", B, NC, ms, owned * 2 * B / (ms * 1e-3));
     printf("  hip error state: %s\n", hipGetErrorString(hipGetLastError()));
     return 0;
 }
