@@ -621,27 +621,30 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         h_rec[at] = CandRec{(uint32_t)(cand_mask_offset[k] - mask_lo), k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
         h_orig[at] = k;
     }
-    // device-side program buffer
+    // device-side program buffer: two halves, one per staging pair, so that compiling batch k+1 (on the copy stream)
+    // overlaps the scoring kernel of batch k; reuse of a half is gated like its staging pair (ensure_stage)
     const size_t need_dw = (size_t)std::max(n_prog, 1u) * pdw;
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
         if (c->d_programs) (void)hipFree(c->d_programs);
         c->d_programs = nullptr;
         c->prog_cap_dw = 0;
-        HIP_TRY(hipMalloc(&c->d_programs, need_dw * 4 * 2));
+        HIP_TRY(hipMalloc(&c->d_programs, need_dw * 2 * 4 * 2));
         c->prog_cap_dw = need_dw * 2;
     }
-    // staged tables travel on the copy stream so that the upload of batch k+1 overlaps the kernel of batch k
+    uint32_t *const d_prog = c->d_programs + (size_t)(c->cur_stage - c->stage) * c->prog_cap_dw;
+    // staged tables travel and are compiled on the copy stream; the scoring stream waits for the compiled programs
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_done, 0));
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_prog) {
-        hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->stream, n_prog,
-                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, c->d_programs, any_wide ? 1 : 0,
+        hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->copy_stream, n_prog,
+                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide ? 1 : 0,
                            all_compact ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_done, 0));
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
@@ -665,7 +668,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.segments = c->d_segments;
     a.n_segments = c->n_segments;
     a.n_bins = c->n_bins;
-    a.programs = c->d_programs;
+    a.programs = d_prog;
     a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
     a.cand_range = reinterpret_cast<uint2 *>(ds + off_range);
     a.out = out;
