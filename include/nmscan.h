@@ -99,9 +99,12 @@ int nm_upload_pileup_device(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_ba
  * > 1e-4 and #(frac > 0.7) > 50 (:202-226); adjacency: per (contig, strand), mod codes mixed, keep a row iff its
  * fraction equals the maximum over positions p-8..p+8 or is below 0.7 (:228-247).  Surviving rows of the mod codes
  * with slot_of_mod[code] >= 0 are classified into that slot's state planes exactly as nm_upload_pileup does (the slots
- * are cleared first); the surviving rows with fraction_mod >= high are kept as a compact list — the input of the
- * window extraction (find_motifs_bin.py:625-661) — and fetched with nm_ingest_results together with the number of
- * surviving rows per (contig, mod code).
+ * are cleared first).  The surviving rows with fraction_mod >= high — the input of the window extraction
+ * (find_motifs_bin.py:625-661) — are exactly the set bits of the slots' per-strand methylated planes; no list is built
+ * (*n_confident is their number).  nm_ingest_results returns the number of surviving rows per (contig, mod code) and,
+ * when the four conf_* pointers are given, enumerates those rows from the planes (host-side, by mod code, strand,
+ * contig, position; valid until a slot is uploaded again).  The device-side window extraction
+ * (nm_win_add_task_contigs) never needs the list.
  *   rows: contig_id = engine contig index or 0xFFFFFFFF for contigs this device does not hold (ignored);
  *   mod_code 0..7 (0 = m, 1 = a, 2 = 21839, others as numbered by the reader); nvalid_cov as read (col 10).
  *   rows_on_device != 0: the six columns are device pointers.

@@ -22,19 +22,41 @@ struct RawRows {
     const int32_t *nvalid;
 };
 
+// Pileup rows arrive sorted by contig, so the lanes of a wave almost always share their (contig, mod code) key: counters
+// are updated with ONE atomic per distinct key per wave (leader election over the ballot) instead of one per row —
+// a billion same-address atomics were 0.75 s of the 1 Gbp ingest.  All active lanes must call this together.
+__device__ __forceinline__ void wave_add_keyed(unsigned int *counters, uint32_t key, bool pred0, bool pred1, uint32_t stride) {
+    const uint32_t lane = __lane_id();
+    unsigned long long todo = __ballot(pred0);
+    while (todo) {                                           // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = __shfl(key, leader);
+        const bool mine = pred0 && key == k;
+        const unsigned long long same = __ballot(mine);
+        const unsigned long long same1 = __ballot(mine && pred1);
+        if ((int)lane == leader) {
+            atomicAdd(counters + (size_t)k * stride, (unsigned int)__popcll(same));
+            if (stride > 1 && same1) atomicAdd(counters + (size_t)k * stride + 1, (unsigned int)__popcll(same1));
+        }
+        todo &= ~same;
+    }
+}
+
 // (1) coverage filter + per (contig, mod code) counts for the frequency filter
 __global__ void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
                                     int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r.n) return;
     const uint32_t c = r.contig[i];
-    if (c == 0xFFFFFFFFu) return;
     const int m = r.mod[i];
-    if (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0 || m >= NM_MAX_MOD_CODES) { atomicOr(err, 1u); return; }
-    if (r.nvalid[i] <= min_cov) return;                                     // dataload.py:199: Nvalid_cov > 5
-    unsigned int *p = cnt + ((size_t)c * NM_MAX_MOD_CODES + m) * 2;
-    atomicAdd(p, 1u);
-    if (r.frac[i] > meth_thr) atomicAdd(p + 1, 1u);                         // dataload.py:215: fraction_mod > 0.7
+    bool counted = c != 0xFFFFFFFFu;
+    if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0 || m >= NM_MAX_MOD_CODES)) {
+        atomicOr(err, 1u);
+        counted = false;
+    }
+    counted = counted && r.nvalid[i] > min_cov;                              // dataload.py:199: Nvalid_cov > 5
+    const bool is_mod = counted && r.frac[i] > meth_thr;                    // dataload.py:215: fraction_mod > 0.7
+    wave_add_keyed(cnt, counted ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, counted, is_mod, 2);
 }
 
 // (2) frequency filter verdict per (contig, mod code): n_mod / n > 1e-4 and n_mod > 50 (dataload.py:218-219)
@@ -81,52 +103,76 @@ struct IngestSlots {
     uint32_t can_l[NM_MAX_MOD_SLOTS];         // canonical base C (1) or A (0)
 };
 
-__global__ void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
+__global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                      const uint32_t *__restrict__ contig_chunk, const unsigned long long *__restrict__ dense_plus,
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
-                                     double low, double high, IngestSlots sl, const uint32_t *__restrict__ H,
-                                     const uint32_t *__restrict__ L, const uint32_t *__restrict__ V,
+                                     double low, double high, IngestSlots sl,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
-                                     unsigned long long *conf_count, uint32_t *conf_contig, uint32_t *conf_pos,
-                                     uint8_t *conf_strand, int8_t *conf_mod, uint64_t conf_cap, unsigned int *err) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= r.n) return;
-    uint32_t c;
-    bool plus;
-    if (!ingest_row_alive(r, i, min_cov, ok, &c, &plus)) return;
-    const double f = r.frac[i];
-    const uint64_t g = (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i];
-    if (!(f < meth_thr)) {
-        const unsigned long long *d = plus ? dense_plus : dense_minus;
-        unsigned long long mx = 0;
-        for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[g + k]);   // >= 64 zero positions around every contig
-        if (mx != (unsigned long long)__double_as_longlong(f)) return;
-    }
-    const int m = r.mod[i];
-    atomicAdd(kept + (size_t)c * NM_MAX_MOD_CODES + m, 1u);
-    atomicAdd(n_kept, 1ull);
-    const int slot = sl.slot_of_mod[m];
-    if (slot < 0) return;
-    const bool meth = f >= high, non = f <= low;
-    if (meth) {
-        const unsigned long long at = atomicAdd(conf_count, 1ull);
-        if (at < conf_cap) {
-            conf_contig[at] = c;
-            conf_pos[at] = r.position[i];
-            conf_strand[at] = plus ? '+' : '-';
-            conf_mod[at] = (int8_t)m;
+                                     unsigned long long *n_classified) {
+    // grid-stride over the rows: the two global totals are kept in registers and leave as ONE atomic per wave at the
+    // end (a per-row or even per-wave-iteration atomic on one address was most of this kernel's time at 1e9 rows)
+    unsigned long long my_kept = 0, my_cls = 0;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < r.n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + threadIdx.x;
+        uint32_t c = 0;
+        bool plus = true;
+        bool alive = i < r.n && ingest_row_alive(r, i, min_cov, ok, &c, &plus);
+        const double f = alive ? r.frac[i] : 0.0;
+        const uint64_t g = alive ? (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i] : 0;
+        if (alive && !(f < meth_thr)) {
+            const unsigned long long *d = plus ? dense_plus : dense_minus;
+            unsigned long long mx = 0;
+            for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[g + k]);   // >= 64 zero positions around every contig
+            if (mx != (unsigned long long)__double_as_longlong(f)) alive = false;
         }
+        const int m = alive ? r.mod[i] : 0;
+        wave_add_keyed(kept, alive ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, alive, false, 1);     // all lanes take part
+        my_kept += alive;
+        const int slot = alive ? sl.slot_of_mod[m] : -1;
+        const bool meth = slot >= 0 && f >= high, non = slot >= 0 && f <= low;
+        if (!meth && !non) continue;
+        // classified rows are counted; the host compares the total with the population count of the general planes
+        // afterwards — a duplicate (contig, position, strand) row sets a bit twice and shows up there, which lets the
+        // atomicOr run without a return value.  The compact planes M / U follow from the general ones
+        // (compact_planes_kernel), and so does the list of confident rows (nm_ingest_results).
+        my_cls += 1;
+        uint32_t *const *pl = sl.planes[slot];
+        uint32_t *gen = plus ? (meth ? pl[2] : pl[3]) : (meth ? pl[4] : pl[5]);
+        atomicOr(gen + (g >> 5), 1u << (g & 31));
     }
-    if (!meth && !non) return;
-    const size_t w = g >> 5;
-    const uint32_t bit = 1u << (g & 31);
-    uint32_t *const *pl = sl.planes[slot];
-    uint32_t *gen = plus ? (meth ? pl[2] : pl[3]) : (meth ? pl[4] : pl[5]);
-    const uint32_t old = atomicOr(gen + w, bit);
-    if (old & bit) atomicOr(err, 4u);
-    const uint32_t h = (H[w] & bit) != 0, l = (L[w] & bit) != 0, v = (V[w] & bit) != 0;
-    const uint32_t want_h = plus ? 0u : 1u;
-    if (v && h == want_h && l == sl.can_l[slot]) atomicOr((meth ? pl[0] : pl[1]) + w, bit);
+    for (int d = 32; d; d >>= 1) {
+        my_kept += __shfl_xor(my_kept, d);
+        my_cls += __shfl_xor(my_cls, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (my_kept) atomicAdd(n_kept, my_kept);
+        if (my_cls) atomicAdd(n_classified, my_cls);
+    }
+}
+
+// compact planes of a slot from its general planes: a row counts on the compact path only when the base under it is the
+// one its strand implies ('+' rows on the canonical base, '-' rows on its complement) — word-parallel, no atomics
+__global__ __launch_bounds__(256) void compact_planes_kernel(const uint32_t *__restrict__ H, const uint32_t *__restrict__ L,
+                                                             const uint32_t *__restrict__ V, const uint32_t *__restrict__ MP,
+                                                             const uint32_t *__restrict__ UP, const uint32_t *__restrict__ MM,
+                                                             const uint32_t *__restrict__ UM, uint32_t can_l,
+                                                             uint32_t *__restrict__ M, uint32_t *__restrict__ U, size_t n_words) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t h = H[i], l = L[i], v = V[i];
+        const uint32_t lsel = can_l ? l : ~l;                 // A = 00 / C = 01 on '+', T = 10 / G = 11 on '-'
+        const uint32_t fwd = v & ~h & lsel, rev = v & h & lsel;
+        M[i] = (MP[i] & fwd) | (MM[i] & rev);
+        U[i] = (UP[i] & fwd) | (UM[i] & rev);
+    }
+}
+
+// population count of a plane (duplicate-row check of nm_ingest_pileup)
+__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint32_t *__restrict__ plane, size_t n_words,
+                                                             unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) acc += __popc(plane[i]);
+    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
 }  // namespace
@@ -190,26 +236,18 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
     unsigned int *d_cnt = nullptr, *d_kept = nullptr;
     uint8_t *d_ok = nullptr;
     unsigned long long *d_dense = nullptr, *d_scalars = nullptr;
-    uint32_t *d_cc = nullptr, *d_cp = nullptr;
-    uint8_t *d_cs = nullptr;
-    int8_t *d_cm = nullptr;
-    const uint64_t conf_cap = std::max<uint64_t>(n_rows, 1);
 #define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (hipMalloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
     ING_ALLOC(d_cnt, n_groups * 2 * 4);
     ING_ALLOC(d_kept, n_groups * 4);
     ING_ALLOC(d_ok, n_groups);
     ING_ALLOC(d_dense, npos * 8 * 2);
-    ING_ALLOC(d_scalars, 16);
-    ING_ALLOC(d_cc, conf_cap * 4);
-    ING_ALLOC(d_cp, conf_cap * 4);
-    ING_ALLOC(d_cs, conf_cap);
-    ING_ALLOC(d_cm, conf_cap);
+    ING_ALLOC(d_scalars, 32);          // n_kept, n_classified, population of the methylated / unmethylated general planes
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
     e = hipMemsetAsync(d_cnt, 0, n_groups * 2 * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 16, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 32, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
     if (n_rows) {
@@ -217,36 +255,38 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
         hipLaunchKernelGGL(ingest_count_kernel, grid, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
         hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
         hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense, d_dense + npos);
-        hipLaunchKernelGGL(ingest_decide_kernel, grid, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense, d_dense + npos, 8, 0.7,
-                           low, high, sl, c->dH, c->dL, c->dV, d_kept, d_scalars, d_scalars + 1, d_cc, d_cp, d_cs, d_cm, conf_cap, c->d_err);
+        hipLaunchKernelGGL(ingest_decide_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)), blk, 0, c->stream, r, 5, d_ok,
+                           c->d_contig_chunk, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
+        // duplicate check: every classified row must have set its own bit in the general planes of its slot
+        bool seen[NM_MAX_MOD_SLOTS] = {};
+        for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
+            const int slot = slot_of_mod[m];
+            if (slot < 0 || seen[slot]) continue;
+            seen[slot] = true;
+            uint32_t *const *pl = c->slots[slot].planes;
+            for (int k = 2; k < 6; ++k)          // MP, MM -> scalar 2 (the confident rows), UP, UM -> scalar 3
+                hipLaunchKernelGGL(plane_popcount_kernel, dim3(2048), blk, 0, c->stream, pl[k], words, d_scalars + (k == 2 || k == 4 ? 2 : 3));
+            hipLaunchKernelGGL(compact_planes_kernel, dim3(4096), blk, 0, c->stream, c->dH, c->dL, c->dV, pl[2], pl[3], pl[4], pl[5],
+                               sl.can_l[slot], pl[0], pl[1], words);
+        }
         e = hipGetLastError();
         if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
     }
-    unsigned long long scal[2] = {0, 0};
+    unsigned long long scal[4] = {0, 0, 0, 0};
     unsigned int err = 0;
-    e = hipMemcpyAsync(scal, d_scalars, 16, hipMemcpyDeviceToHost, c->stream);
+    e = hipMemcpyAsync(scal, d_scalars, 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
-    const uint64_t nconf = scal[1];
+    const uint64_t nconf = scal[2];
     drop_ingest_rows(c);
     c->ing_kept.resize(n_groups);
-    if (nconf) {        // exact-size copies; the n_rows-sized scratch goes away with cleanup()
-        e = hipMalloc(&c->d_ing_contig, nconf * 4);
-        if (e == hipSuccess) e = hipMalloc(&c->d_ing_pos, nconf * 4);
-        if (e == hipSuccess) e = hipMalloc(&c->d_ing_strand, nconf);
-        if (e == hipSuccess) e = hipMalloc(&c->d_ing_mod, nconf);
-        if (e == hipSuccess) e = hipMemcpy(c->d_ing_contig, d_cc, nconf * 4, hipMemcpyDeviceToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->d_ing_pos, d_cp, nconf * 4, hipMemcpyDeviceToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->d_ing_strand, d_cs, nconf, hipMemcpyDeviceToDevice);
-        if (e == hipSuccess) e = hipMemcpy(c->d_ing_mod, d_cm, nconf, hipMemcpyDeviceToDevice);
-        if (e != hipSuccess) { cleanup(); drop_ingest_rows(c); return fail(NM_EHIP, "keeping the confident rows failed: %s", hipGetErrorString(e)); }
-        c->ing_nconf = nconf;
-    }
+    for (int m = 0; m < NM_MAX_MOD_CODES; ++m) c->ing_slot_of_mod[m] = slot_of_mod[m];
+    c->ing_nconf = nconf;
     (void)hipMemcpy(c->ing_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost);
     cleanup();
     if (err & 1u) return fail(NM_EINVAL, "pileup row with contig_id / position / mod code outside the uploaded assembly");
-    if (err & 4u) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
+    if ((err & 4u) || scal[1] != scal[2] + scal[3]) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
     for (int m = 0; m < NM_MAX_MOD_CODES; ++m)
         if (slot_of_mod[m] >= 0) c->slots[slot_of_mod[m]].n_rows = scal[0];
     *n_kept = scal[0];
@@ -262,11 +302,36 @@ int nm_ingest_results(nm_ctx *c, uint32_t *conf_contig, uint32_t *conf_position,
         if (capacity < n) return fail(NM_ERANGE, "capacity %llu < %zu confident rows", (unsigned long long)capacity, n);
         if (n) {
             if (!conf_contig || !conf_position || !conf_strand || !conf_mod) return fail(NM_EINVAL, "NULL argument");
+            // the confident rows ARE the set bits of the slots' MP ('+') and MM ('-') planes: enumerate them on the host
+            // (rare path: the device-side window extraction never needs the list)
             HIP_TRY(hipSetDevice(c->device));
-            HIP_TRY(hipMemcpy(conf_contig, c->d_ing_contig, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(conf_position, c->d_ing_pos, n * 4, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(conf_strand, c->d_ing_strand, n, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(conf_mod, c->d_ing_mod, n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const size_t words = plane_words(c);
+            std::vector<uint32_t> plane(words);
+            size_t at = 0;
+            for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
+                const int slot = c->ing_slot_of_mod[m];
+                if (slot < 0 || !c->slots[slot].present) continue;
+                for (int strand = 0; strand < 2; ++strand) {
+                    HIP_TRY(hipMemcpy(plane.data(), c->slots[slot].planes[strand ? 4 : 2], words * 4, hipMemcpyDeviceToHost));
+                    for (uint32_t ci = 0; ci < c->n_contigs; ++ci) {
+                        const size_t w0 = (size_t)c->contig_chunk[ci] * CHUNK_WORDS, nw = (size_t)((c->contig_len[ci] + 31) / 32);
+                        for (size_t w = 0; w < nw; ++w) {
+                            uint32_t x = plane[w0 + w];
+                            while (x) {
+                                if (at >= n) return fail(NM_ESTATE, "the slot's planes changed since nm_ingest_pileup");
+                                conf_contig[at] = ci;
+                                conf_position[at] = (uint32_t)(w * 32 + (uint32_t)__builtin_ctz(x));
+                                conf_strand[at] = strand ? '-' : '+';
+                                conf_mod[at] = (int8_t)m;
+                                ++at;
+                                x &= x - 1;
+                            }
+                        }
+                    }
+                }
+            }
+            if (at != n) return fail(NM_ESTATE, "the slot's planes changed since nm_ingest_pileup");
         }
     }
     if (kept_per_contig_mod) memcpy(kept_per_contig_mod, c->ing_kept.data(), c->ing_kept.size() * 4);

@@ -86,9 +86,8 @@ struct nm_ctx {
     bool win_tasks_dirty = false;
     // results of the last nm_ingest_pileup
     std::vector<uint32_t> ing_kept;                   // kept rows per (contig, mod code)
-    uint32_t *d_ing_contig = nullptr, *d_ing_pos = nullptr;   // confident rows stay on the device until asked for
-    uint8_t *d_ing_strand = nullptr;
-    int8_t *d_ing_mod = nullptr;
+    // the confident rows of the last ingest are the set bits of the MP / MM planes of these slots (no list is built)
+    int ing_slot_of_mod[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     uint64_t ing_nconf = 0;
     uint32_t *d_programs = nullptr;                   // compiled constraint programs of the current batch
     size_t prog_cap_dw = 0;
@@ -158,12 +157,7 @@ inline void drop_slot_ranks(ModSlot &ms) {
 }
 
 inline void drop_ingest_rows(nm_ctx *c) {
-    void *ptrs[] = {c->d_ing_contig, c->d_ing_pos, c->d_ing_strand, c->d_ing_mod};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
-    c->d_ing_contig = c->d_ing_pos = nullptr;
-    c->d_ing_strand = nullptr;
-    c->d_ing_mod = nullptr;
+    for (int &x : c->ing_slot_of_mod) x = -1;
     c->ing_nconf = 0;
 }
 

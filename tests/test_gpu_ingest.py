@@ -100,3 +100,26 @@ def test_adjacency_kat_on_device():
     res = eng.ingest_pileup(t["contig"].astype(np.uint32), pos, t["mod_type"], t["strand"], frac, t["Nvalid_cov"], {0: ("m", "C"), 1: ("a", "A")})
     assert res["n_kept"] == len(exp["position"]) and 0 < res["n_kept"] < len(pos)
     eng.close()
+
+
+def test_duplicate_rows_are_refused():
+    """Two surviving rows on one (contig, position, strand) of a mod type: the reference's np.isin(assume_unique=True)
+    would miscount silently (find_motifs_bin.py:1258); the engine refuses the pileup."""
+    from nanomotif_amd._lib import NmScanError
+    from nanomotif_amd.engine import ScanEngine
+    rng = np.random.default_rng(4)
+    L = 3000
+    seq = "".join(rng.choice(list("ACGT"), size=L))
+    pos = np.arange(0, L, 2, dtype=np.int64)
+    frac = np.where(rng.random(len(pos)) < 0.3, 0.95, 0.05)
+    cols = dict(contig=np.zeros(len(pos), np.uint32), position=pos, mod=np.ones(len(pos), np.int8),
+                strand=np.full(len(pos), ord("+"), np.uint8), frac=frac, nvalid=np.full(len(pos), 20))
+    eng = ScanEngine(0)
+    eng.upload_assembly(["c"], [seq], ["b"])
+    ok = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod"], cols["strand"], cols["frac"], cols["nvalid"], {1: ("a", "A")})
+    assert ok["n_kept"] > 0
+    k = int(np.flatnonzero(frac < 0.3)[5])                        # an unmethylated row: never touched by the adjacency filter
+    dup = {n: np.concatenate([v, v[k:k + 1]]) for n, v in cols.items()}
+    with pytest.raises(NmScanError, match="duplicate"):
+        eng.ingest_pileup(dup["contig"], dup["position"], dup["mod"], dup["strand"], dup["frac"], dup["nvalid"], {1: ("a", "A")})
+    eng.close()
