@@ -106,3 +106,24 @@ def test_two_ranks_give_the_single_rank_output(tmp_path):
         assert ("whole bins per GPU" in r.stdout + r.stderr) == (mode == "bins")
         assert os.path.isdir(f"{tmp}/out_{mode}/precleanup-motifs")
         assert sorted(os.listdir(f"{tmp}/out_{mode}/precleanup-motifs")) == sorted(os.listdir(tmp + "/out1/precleanup-motifs"))
+
+
+def test_assembly_with_other_iupac_letters_takes_the_host_window_path(tmp_path):
+    """A letter outside ACGTN anywhere in the assembly keeps window extraction on the host (where the reference's
+    KeyError semantics live); the result is the same bin-motifs.tsv."""
+    spec = synth.SynthSpec(n_contigs=6, total_bp=500_000, n_bins=2, mod_types=("a", "m"), seed=63, min_contig_bp=40_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_device"])
+    # one more contig, in a bin of its own and without pileup rows, carrying an 'R'
+    with open(tmp + "/assembly.fasta", "a") as f:
+        f.write(">extra_contig\n" + "ACGTTGCA" * 500 + "R" + "ACGT" * 300 + "\n")
+    with open(tmp + "/contig_bin.tsv", "a") as f:
+        f.write("extra_contig\tbin_extra\n")
+    r = _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_host"])
+    assert "window extraction stays on the host" in r.stdout + r.stderr
+    assert open(tmp + "/out_host/bin-motifs.tsv").read() == open(tmp + "/out_device/bin-motifs.tsv").read()
