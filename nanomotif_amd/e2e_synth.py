@@ -53,17 +53,8 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
     torch.cuda.synchronize(device)
     t["generate_s"] = time.perf_counter() - t0
     t0 = time.perf_counter()
-    engine.bin_names = bins
-    engine.bin_index = {b: i for i, b in enumerate(bins)}
-    bin_ids = np.array([engine.bin_index[mg.bin_names[i]] for i in mine], dtype=np.uint32)
-    _lib.check(engine.lib.nm_upload_contigs_device(
-        engine.ctx, len(mine), offsets.ctypes.data_as(C.POINTER(C.c_uint64)), bin_ids.ctypes.data_as(C.POINTER(C.c_uint32)),
-        len(bins), C.c_void_p(ascii_all.data_ptr())))
-    engine.contig_names = [mg.names[i] for i in mine]
-    engine.contig_index = {n: i for i, n in enumerate(engine.contig_names)}
-    engine.contig_lengths = lengths.astype(np.int64)
-    engine.contig_bin = bin_ids
-    engine.slot_of_mod = {}
+    engine.upload_assembly_device([mg.names[i] for i in mine], lengths, [mg.bin_names[i] for i in mine], ascii_all.data_ptr(),
+                                  bin_names=bins)
     slot_of = (C.c_int32 * 8)(*([-1] * 8))
     canon = (C.c_uint8 * 8)(*([0] * 8))
     for mt in mg.spec.mod_types:

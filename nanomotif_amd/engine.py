@@ -122,44 +122,47 @@ class DeviceWindowExtractor:
         self.freq = background_sampling_frequency
         self.tasks = []           # (key, base, n_bg, [sample contig arrays], [sample rank arrays])
 
-    def plan(self, key, plus_pos: dict, minus_pos: dict, mod_type: str) -> bool:
-        """One task; consumes the interpreter's RNG exactly like extract_windows.  False = no methylation windows."""
-        from .search import NativeRandom
-        base = MOD_TYPE_TO_CANONICAL[mod_type]
-        nv_of = self.n_valid[base]
-        with NativeRandom() as rng:
-            return self._plan(rng, key, plus_pos, minus_pos, base, nv_of)
-
-    def _plan(self, rng, key, plus_pos, minus_pos, base, nv_of):
+    def _draw(self, rng, name, base, s_contig, s_rank) -> int:
+        """The background sample of one contig (seq.py:202-225): draws its start ranks from ``rng`` (consumed on every
+        rank alike), keeps them if the contig is resident here, returns the number of samples."""
         import math
-        pad, W = self.pad, 2 * self.pad + 1
+        length = int(self.lengths[name])
+        n_samples = int(max(math.ceil(length * self.freq), 50))
+        if n_samples > length - (2 * self.pad + 1) + 1:
+            raise ValueError("Too many samples requested for unique subsequences")
+        nv = int(self.n_valid[base][name])
+        if nv < n_samples:
+            raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
+        ranks = rng.sample(nv, n_samples)
+        ci = self.resident.get(name)
+        if ci is not None:
+            s_contig.append(np.full(n_samples, ci, dtype=np.uint32))
+            s_rank.append(ranks.astype(np.uint32))
+        return n_samples
+
+    def plan(self, key, plus_pos: dict, minus_pos: dict, mod_type: str) -> bool:
+        """One task from explicit row positions (name -> ascending positions of the confident rows per strand);
+        consumes the interpreter's RNG exactly like extract_windows.  False = no methylation windows."""
+        from .search import NativeRandom
+        base, pad = MOD_TYPE_TO_CANONICAL[mod_type], self.pad
         s_contig, s_rank, rows_c, rows_p, rows_m = [], [], [], [], []
         n_bg = total = 0
         empty = np.zeros(0, np.int64)
-        for name in sorted(plus_pos.keys() | minus_pos.keys()):
-            length = int(self.lengths[name])
-            n_samples = int(max(math.ceil(length * self.freq), 50))
-            if n_samples > length - W + 1:
-                raise ValueError("Too many samples requested for unique subsequences")
-            nv = int(nv_of[name])
-            if nv < n_samples:
-                raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
-            ranks = rng.sample(nv, n_samples)
-            n_bg += n_samples
-            ci = self.resident.get(name)
-            if ci is not None:
-                s_contig.append(np.full(n_samples, ci, dtype=np.uint32))
-                s_rank.append(ranks.astype(np.uint32))
-            p, m = plus_pos.get(name, empty), minus_pos.get(name, empty)
-            p = p[(p > pad) & (p < length - pad)]
-            m = m[(m > pad) & (m < length - pad)]
-            if len(p) + len(m) == 0:
-                return False                         # find_motifs_bin.py:662-664
-            total += len(p) + len(m)
-            if ci is not None:
-                rows_c.append(np.full(len(p) + len(m), ci, dtype=np.uint32))
-                rows_p += [p, m]
-                rows_m.append(np.concatenate([np.zeros(len(p), np.uint8), np.ones(len(m), np.uint8)]))
+        with NativeRandom() as rng:
+            for name in sorted(plus_pos.keys() | minus_pos.keys()):
+                n_bg += self._draw(rng, name, base, s_contig, s_rank)
+                length = int(self.lengths[name])
+                p, m = plus_pos.get(name, empty), minus_pos.get(name, empty)
+                p = p[(p > pad) & (p < length - pad)]
+                m = m[(m > pad) & (m < length - pad)]
+                if len(p) + len(m) == 0:
+                    return False                         # find_motifs_bin.py:662-664
+                total += len(p) + len(m)
+                ci = self.resident.get(name)
+                if ci is not None:
+                    rows_c.append(np.full(len(p) + len(m), ci, dtype=np.uint32))
+                    rows_p += [p, m]
+                    rows_m.append(np.concatenate([np.zeros(len(p), np.uint8), np.ones(len(m), np.uint8)]))
         if total == 0 or n_bg == 0:
             return False
         cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
@@ -170,38 +173,24 @@ class DeviceWindowExtractor:
     def plan_contigs(self, key, names, mod_type: str) -> bool:
         """``plan`` without row lists: the task's windows are all confident rows of the contigs ``names`` (those present
         in the filtered pileup of this mod type), read on the device from the methylated-state planes."""
-        import math
         from .search import NativeRandom
-        base = MOD_TYPE_TO_CANONICAL[mod_type]
-        nv_of, counts = self.n_valid[base], self.row_counts[mod_type]
-        pad, W = self.pad, 2 * self.pad + 1
+        base, counts = MOD_TYPE_TO_CANONICAL[mod_type], self.row_counts[mod_type]
         s_contig, s_rank, mine = [], [], []
         n_bg = total = 0
         with NativeRandom() as rng:
             for name in sorted(names):
-                length = int(self.lengths[name])
-                n_samples = int(max(math.ceil(length * self.freq), 50))
-                if n_samples > length - W + 1:
-                    raise ValueError("Too many samples requested for unique subsequences")
-                nv = int(nv_of[name])
-                if nv < n_samples:
-                    raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv}, need {n_samples})")
-                ranks = rng.sample(nv, n_samples)
-                n_bg += n_samples
-                ci = self.resident.get(name)
-                if ci is not None:
-                    s_contig.append(np.full(n_samples, ci, dtype=np.uint32))
-                    s_rank.append(ranks.astype(np.uint32))
+                n_bg += self._draw(rng, name, base, s_contig, s_rank)
                 n_rows = int(counts[name][0]) + int(counts[name][1])
                 if n_rows == 0:
                     return False                     # find_motifs_bin.py:662-664
                 total += n_rows
+                ci = self.resident.get(name)
                 if ci is not None:
                     mine.append(ci)
         if total == 0 or n_bg == 0:
             return False
         cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
-        self.store.add_task_contigs(key, mod_type, mine, pad, total=total)
+        self.store.add_task_contigs(key, mod_type, mine, self.pad, total=total)
         self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
         return True
 
@@ -292,6 +281,25 @@ class ScanEngine:
         bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
         _lib.check(self.lib.nm_upload_contigs(self.ctx, len(names), _ptr(offsets, C.c_uint64), _ptr(bin_ids, C.c_uint32),
                                               len(self.bin_names), _ptr(ascii_all, C.c_uint8)))
+        self.contig_names = names
+        self.contig_index = {n: i for i, n in enumerate(names)}
+        self.contig_lengths = lengths.astype(np.int64)
+        self.contig_bin = bin_ids
+        self.slot_of_mod = {}
+
+    def upload_assembly_device(self, names, lengths, bin_of_contig, device_ptr: int, bin_names=None):
+        """``upload_assembly`` for sequences that are already in device memory: ``device_ptr`` addresses the contigs'
+        ASCII bytes back to back in the order of ``names`` (nm_upload_contigs_device), e.g. a torch uint8 tensor's
+        ``data_ptr()``."""
+        names = list(names)
+        lengths = np.asarray(lengths, dtype=np.uint64)
+        offsets = np.zeros(len(names) + 1, dtype=np.uint64)
+        np.cumsum(lengths, out=offsets[1:])
+        self.bin_names = sorted(set(bin_of_contig)) if bin_names is None else list(bin_names)
+        self.bin_index = {b: i for i, b in enumerate(self.bin_names)}
+        bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
+        _lib.check(self.lib.nm_upload_contigs_device(self.ctx, len(names), _ptr(offsets, C.c_uint64), _ptr(bin_ids, C.c_uint32),
+                                                     len(self.bin_names), C.c_void_p(int(device_ptr))))
         self.contig_names = names
         self.contig_index = {n: i for i, n in enumerate(names)}
         self.contig_lengths = lengths.astype(np.int64)

@@ -187,16 +187,8 @@ def load_engine_from_device(engine, mg: synth.SynthMetagenome, device, low=0.3, 
         if progress and (bi + 1) % 100 == 0:
             progress(f"generated {bi + 1}/{len(bins)} bins")
     torch.cuda.synchronize(device)
-    engine.bin_names = bins
-    engine.bin_index = {b: i for i, b in enumerate(bins)}
-    bin_ids = np.array([engine.bin_index[mg.bin_names[i]] for i in mine], dtype=np.uint32)
-    _lib.check(engine.lib.nm_upload_contigs_device(
-        engine.ctx, len(lengths), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
-        bin_ids.ctypes.data_as(C.POINTER(C.c_uint32)), len(bins), C.c_void_p(ascii_all.data_ptr())))
-    engine.contig_names = [mg.names[i] for i in mine]
-    engine.contig_index = {n: i for i, n in enumerate(engine.contig_names)}
-    engine.contig_lengths = lengths.astype(np.int64)
-    engine.contig_bin = bin_ids
+    engine.upload_assembly_device([mg.names[i] for i in mine], lengths, [mg.bin_names[i] for i in mine], ascii_all.data_ptr(),
+                                  bin_names=bins)
     engine.slot_of_mod = {mt: k for k, mt in enumerate(mg.spec.mod_types)}
     rows = {mt: 0 for mt in mg.spec.mod_types}
     for mt in mg.spec.mod_types:
