@@ -31,3 +31,23 @@ def test_bad_arguments_fail_loudly_without_gpu():
     assert lib.nm_ctx_create(0, None) == -1          # NM_EINVAL, no HIP call made
     assert b"NULL" in lib.nm_last_error()
     assert lib.nm_score_batch(None, 0, None, None, None, None, None, None, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it;
+    nothing under nanomotif_amd/ (the product) may import it, and the product has no CPU fallback for the engine."""
+    import ast
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "nanomotif_amd", "**", "*.py"), recursive=True):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path} imports the oracle"
+    src = open(os.path.join(root, "nanomotif_amd", "_lib.py")).read()
+    assert "no CPU fallback" in src and "raise NmScanError" in src
