@@ -29,3 +29,28 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert d["parity"]["mismatches"] == 0 and d["parity"]["candidates_checked"] > 0
+
+
+def _bench(extra, nproc=1):
+    small = ["--steps", "3", "--warmup", "1", "--total-bp", "20000000", "--contigs", "200", "--bins", "10", "--candidates", "200",
+             "--cpu-bins", "0", "--hbm-round-steps", "0"]
+    cmd = [sys.executable, "bench.py"] if nproc == 1 else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+         "--master-port", "29677", "bench.py", "--gpus", str(nproc), "--dist-backend", "gloo", "--force-device", "0"]
+    r = subprocess.run(cmd + small + extra, cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])
+
+
+def test_two_rank_bench_weak_and_strong():
+    """N = 2 on the one GPU of the test box (gloo): strong scaling reproduces the single-rank count table, weak scaling
+    doubles the work and reports it."""
+    one = _bench([])
+    strong = _bench(["--scaling", "strong"], nproc=2)
+    weak = _bench(["--scaling", "weak"], nproc=2)
+    assert strong["n_gpus"] == weak["n_gpus"] == 2
+    assert strong["scaling"] == "strong" and weak["scaling"] == "weak"
+    assert strong["counts_checksum"] == one["counts_checksum"]                     # all-reduced table == unsharded table
+    assert weak["counts_checksum"] == one["counts_checksum"]                       # rank 0 holds the seed-1 metagenome
+    assert weak["config"]["motif_sites_per_step"] == 2 * one["config"]["motif_sites_per_step"]
+    assert strong["config"]["motif_sites_per_step"] == one["config"]["motif_sites_per_step"]
