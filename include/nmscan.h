@@ -113,6 +113,16 @@ int nm_ingest_pileup(nm_ctx *ctx, uint64_t n_rows, const uint32_t *contig_id, co
                      const int8_t *mod_code, const uint8_t *strand, const double *fraction_mod,
                      const int32_t *nvalid_cov, const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8],
                      double low, double high, int rows_on_device, uint64_t *n_kept, uint64_t *n_confident);
+/* The same for a pileup that arrives in PARTS (a file too large to hold at once): every contig's rows must lie within
+ * one part — the three filters are per contig — and part_contigs[n_part_contigs] lists the engine contig ids whose rows
+ * this part holds; the dense adjacency arrays (16 B per bp) then cover those contigs only.  first != 0 clears the slots
+ * and the accumulated tables; later parts must repeat the slots / thresholds.  *n_kept and *n_confident are cumulative;
+ * nm_ingest_results reports the union. */
+int nm_ingest_pileup_part(nm_ctx *ctx, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                          const int8_t *mod_code, const uint8_t *strand, const double *fraction_mod,
+                          const int32_t *nvalid_cov, const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8],
+                          double low, double high, int rows_on_device, int first, uint32_t n_part_contigs,
+                          const uint32_t *part_contigs, uint64_t *n_kept, uint64_t *n_confident);
 int nm_ingest_results(nm_ctx *ctx, uint32_t *conf_contig, uint32_t *conf_position, uint8_t *conf_strand,
                       int8_t *conf_mod, uint64_t capacity, uint32_t *kept_per_contig_mod);
 

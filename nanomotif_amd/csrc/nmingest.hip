@@ -83,14 +83,15 @@ __device__ __forceinline__ bool ingest_row_alive(const RawRows &r, uint64_t i, i
 
 // (3a) adjacency filter, scatter: per strand the maximal fraction at every position (mod codes mixed, dataload.py:237)
 __global__ void ingest_scatter_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
-                                      const uint32_t *__restrict__ contig_chunk, unsigned long long *dense_plus,
-                                      unsigned long long *dense_minus) {
+                                      const uint64_t *__restrict__ dense_off, unsigned long long *dense_plus,
+                                      unsigned long long *dense_minus, unsigned int *err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r.n) return;
     uint32_t c;
     bool plus;
     if (!ingest_row_alive(r, i, min_cov, ok, &c, &plus)) return;
-    const uint64_t g = (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i];
+    if (dense_off[c] == ~0ull) { atomicOr(err, 8u); return; }          // contig not listed for this part
+    const uint64_t g = dense_off[c] + r.position[i];
     // fractions are >= 0, so their IEEE bit patterns order like the values
     atomicMax((plus ? dense_plus : dense_minus) + g, (unsigned long long)__double_as_longlong(r.frac[i]));
 }
@@ -104,7 +105,8 @@ struct IngestSlots {
 };
 
 __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
-                                     const uint32_t *__restrict__ contig_chunk, const unsigned long long *__restrict__ dense_plus,
+                                     const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ dense_off,
+                                     const unsigned long long *__restrict__ dense_plus,
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
                                      double low, double high, IngestSlots sl,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
@@ -117,12 +119,13 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         uint32_t c = 0;
         bool plus = true;
         bool alive = i < r.n && ingest_row_alive(r, i, min_cov, ok, &c, &plus);
+        alive = alive && dense_off[c] != ~0ull;                  // (flagged by the scatter pass)
         const double f = alive ? r.frac[i] : 0.0;
         const uint64_t g = alive ? (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i] : 0;
         if (alive && !(f < meth_thr)) {
-            const unsigned long long *d = plus ? dense_plus : dense_minus;
+            const unsigned long long *d = (plus ? dense_plus : dense_minus) + dense_off[c] + r.position[i];
             unsigned long long mx = 0;
-            for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[g + k]);   // >= 64 zero positions around every contig
+            for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[k]);       // >= 64 zero positions around every contig
             if (mx != (unsigned long long)__double_as_longlong(f)) alive = false;
         }
         const int m = alive ? r.mod[i] : 0;
@@ -179,10 +182,13 @@ __global__ __launch_bounds__(256) void plane_popcount_kernel(const uint32_t *__r
 
 extern "C" {
 
-int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_code,
-                     const uint8_t *strand, const double *fraction_mod, const int32_t *nvalid_cov,
-                     const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8], double low, double high,
-                     int rows_on_device, uint64_t *n_kept, uint64_t *n_confident) {
+// One part of a pileup (or all of it): `part_contigs` lists the engine contig ids whose rows are in this call (NULL: all
+// contigs); the dense adjacency arrays cover only those.  `first`: clear the slots and the accumulated tables.
+static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_code,
+                       const uint8_t *strand, const double *fraction_mod, const int32_t *nvalid_cov,
+                       const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8], double low, double high,
+                       int rows_on_device, int first, uint32_t n_part_contigs, const uint32_t *part_contigs,
+                       uint64_t *n_kept, uint64_t *n_confident) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
     if (!slot_of_mod || !canonical_of_mod || !n_kept || !n_confident) return fail(NM_EINVAL, "NULL argument");
@@ -191,6 +197,7 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t words = plane_words(c);
+    const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;
     IngestSlots sl{};
     for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
         sl.slot_of_mod[m] = slot_of_mod[m];
@@ -199,17 +206,46 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
         if (canonical_of_mod[m] != 'A' && canonical_of_mod[m] != 'C') return fail(NM_EINVAL, "canonical base must be 'A' or 'C'");
         ModSlot &ms = c->slots[slot_of_mod[m]];
         drop_slot_ranks(ms);
-        for (auto &p : ms.planes) {
-            if (!p) HIP_TRY(hipMalloc(&p, words * 4));
-            HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
+        if (first) {
+            for (auto &p : ms.planes) {
+                if (!p) HIP_TRY(hipMalloc(&p, words * 4));
+                HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
+            }
+            ms.present = true;
+            ms.canonical = canonical_of_mod[m];
+            ms.low = low;
+            ms.high = high;
+            ms.n_rows = 0;
+        } else if (!ms.present || ms.canonical != canonical_of_mod[m] || ms.low != low || ms.high != high || c->ing_slot_of_mod[m] != slot_of_mod[m]) {
+            return fail(NM_ESTATE, "a later part must use the slots, canonical bases and thresholds of the first part");
         }
-        ms.present = true;
-        ms.canonical = canonical_of_mod[m];
-        ms.low = low;
-        ms.high = high;
-        ms.n_rows = 0;
         for (int k = 0; k < 6; ++k) sl.planes[slot_of_mod[m]][k] = ms.planes[k];
         sl.can_l[slot_of_mod[m]] = canonical_of_mod[m] == 'C' ? 1u : 0u;
+    }
+    if (first) {
+        drop_ingest_rows(c);
+        c->ing_kept.assign(n_groups, 0);
+        c->ing_total_kept = c->ing_classified = 0;
+        for (int m = 0; m < NM_MAX_MOD_CODES; ++m) c->ing_slot_of_mod[m] = slot_of_mod[m];
+    } else if (c->ing_kept.size() != n_groups) {
+        return fail(NM_ESTATE, "no first part was ingested for this assembly");
+    }
+    // dense coordinates of this part: the listed contigs back to back, 128 zero positions between them
+    std::vector<uint64_t> dense_off(c->n_contigs, ~0ull);
+    uint64_t npos = 64;
+    if (part_contigs) {
+        for (uint32_t k = 0; k < n_part_contigs; ++k) {
+            const uint32_t ci = part_contigs[k];
+            if (ci >= c->n_contigs) return fail(NM_EINVAL, "part contig %u >= %u", ci, c->n_contigs);
+            if (dense_off[ci] != ~0ull) continue;
+            dense_off[ci] = npos;
+            npos += c->contig_len[ci] + 128;
+        }
+    } else {
+        for (uint32_t ci = 0; ci < c->n_contigs; ++ci) {
+            dense_off[ci] = npos;
+            npos += c->contig_len[ci] + 128;
+        }
     }
     // device copies of the raw columns
     std::vector<void *> owned;
@@ -231,17 +267,17 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
         r.contig = (const uint32_t *)dst[0]; r.position = (const uint32_t *)dst[1]; r.mod = (const int8_t *)dst[2];
         r.strand = (const uint8_t *)dst[3]; r.frac = (const double *)dst[4]; r.nvalid = (const int32_t *)dst[5];
     }
-    const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;
-    const uint64_t npos = (uint64_t)c->n_chunks * CHUNK_BP;
     unsigned int *d_cnt = nullptr, *d_kept = nullptr;
     uint8_t *d_ok = nullptr;
     unsigned long long *d_dense = nullptr, *d_scalars = nullptr;
+    uint64_t *d_dense_off = nullptr;
 #define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (hipMalloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
     ING_ALLOC(d_cnt, n_groups * 2 * 4);
     ING_ALLOC(d_kept, n_groups * 4);
     ING_ALLOC(d_ok, n_groups);
     ING_ALLOC(d_dense, npos * 8 * 2);
-    ING_ALLOC(d_scalars, 32);          // n_kept, n_classified, population of the methylated / unmethylated general planes
+    ING_ALLOC(d_dense_off, (size_t)c->n_contigs * 8);
+    ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
     e = hipMemsetAsync(d_cnt, 0, n_groups * 2 * 4, c->stream);
@@ -249,49 +285,72 @@ int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, cons
     if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 32, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dense_off, dense_off.data(), (size_t)c->n_contigs * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
+    const dim3 blk(256);
     if (n_rows) {
-        const dim3 grid((unsigned)((n_rows + 255) / 256)), blk(256);
+        const dim3 grid((unsigned)((n_rows + 255) / 256));
         hipLaunchKernelGGL(ingest_count_kernel, grid, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
         hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
-        hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense, d_dense + npos);
+        hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, c->d_err);
         hipLaunchKernelGGL(ingest_decide_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)), blk, 0, c->stream, r, 5, d_ok,
-                           c->d_contig_chunk, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
-        // duplicate check: every classified row must have set its own bit in the general planes of its slot
-        bool seen[NM_MAX_MOD_SLOTS] = {};
-        for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
-            const int slot = slot_of_mod[m];
-            if (slot < 0 || seen[slot]) continue;
-            seen[slot] = true;
-            uint32_t *const *pl = c->slots[slot].planes;
-            for (int k = 2; k < 6; ++k)          // MP, MM -> scalar 2 (the confident rows), UP, UM -> scalar 3
-                hipLaunchKernelGGL(plane_popcount_kernel, dim3(2048), blk, 0, c->stream, pl[k], words, d_scalars + (k == 2 || k == 4 ? 2 : 3));
-            hipLaunchKernelGGL(compact_planes_kernel, dim3(4096), blk, 0, c->stream, c->dH, c->dL, c->dV, pl[2], pl[3], pl[4], pl[5],
-                               sl.can_l[slot], pl[0], pl[1], words);
-        }
-        e = hipGetLastError();
-        if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
+                           c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
     }
+    // population of the general planes (all parts so far): the confident rows, and the duplicate check — every
+    // classified row must have set its own bit; then the compact planes
+    bool seen[NM_MAX_MOD_SLOTS] = {};
+    for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
+        const int slot = slot_of_mod[m];
+        if (slot < 0 || seen[slot]) continue;
+        seen[slot] = true;
+        uint32_t *const *pl = c->slots[slot].planes;
+        for (int k = 2; k < 6; ++k)          // MP, MM -> scalar 2 (the confident rows), UP, UM -> scalar 3
+            hipLaunchKernelGGL(plane_popcount_kernel, dim3(2048), blk, 0, c->stream, pl[k], words, d_scalars + (k == 2 || k == 4 ? 2 : 3));
+        hipLaunchKernelGGL(compact_planes_kernel, dim3(4096), blk, 0, c->stream, c->dH, c->dL, c->dV, pl[2], pl[3], pl[4], pl[5],
+                           sl.can_l[slot], pl[0], pl[1], words);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
     unsigned long long scal[4] = {0, 0, 0, 0};
     unsigned int err = 0;
+    std::vector<uint32_t> part_kept(n_groups);
     e = hipMemcpyAsync(scal, d_scalars, 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(part_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
-    const uint64_t nconf = scal[2];
-    drop_ingest_rows(c);
-    c->ing_kept.resize(n_groups);
-    for (int m = 0; m < NM_MAX_MOD_CODES; ++m) c->ing_slot_of_mod[m] = slot_of_mod[m];
-    c->ing_nconf = nconf;
-    (void)hipMemcpy(c->ing_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost);
     cleanup();
+    if (e != hipSuccess) return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e));
     if (err & 1u) return fail(NM_EINVAL, "pileup row with contig_id / position / mod code outside the uploaded assembly");
-    if ((err & 4u) || scal[1] != scal[2] + scal[3]) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
+    if (err & 8u) return fail(NM_EINVAL, "pileup row of a contig that is not listed in part_contigs");
+    c->ing_total_kept += scal[0];
+    c->ing_classified += scal[1];
+    c->ing_nconf = scal[2];
+    for (size_t i = 0; i < n_groups; ++i) c->ing_kept[i] += part_kept[i];
+    if ((err & 4u) || c->ing_classified != scal[2] + scal[3]) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
     for (int m = 0; m < NM_MAX_MOD_CODES; ++m)
-        if (slot_of_mod[m] >= 0) c->slots[slot_of_mod[m]].n_rows = scal[0];
-    *n_kept = scal[0];
-    *n_confident = nconf;
+        if (slot_of_mod[m] >= 0) c->slots[slot_of_mod[m]].n_rows = c->ing_total_kept;
+    *n_kept = c->ing_total_kept;
+    *n_confident = c->ing_nconf;
     return NM_OK;
+}
+
+int nm_ingest_pileup(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_code,
+                     const uint8_t *strand, const double *fraction_mod, const int32_t *nvalid_cov,
+                     const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8], double low, double high,
+                     int rows_on_device, uint64_t *n_kept, uint64_t *n_confident) {
+    return ingest_impl(c, n_rows, contig_id, position, mod_code, strand, fraction_mod, nvalid_cov, slot_of_mod, canonical_of_mod,
+                       low, high, rows_on_device, 1, 0, nullptr, n_kept, n_confident);
+}
+
+int nm_ingest_pileup_part(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_code,
+                          const uint8_t *strand, const double *fraction_mod, const int32_t *nvalid_cov,
+                          const int32_t slot_of_mod[8], const uint8_t canonical_of_mod[8], double low, double high,
+                          int rows_on_device, int first, uint32_t n_part_contigs, const uint32_t *part_contigs,
+                          uint64_t *n_kept, uint64_t *n_confident) {
+    if (n_part_contigs && !part_contigs) return fail(NM_EINVAL, "part_contigs is NULL");
+    static const uint32_t none = 0;
+    return ingest_impl(c, n_rows, contig_id, position, mod_code, strand, fraction_mod, nvalid_cov, slot_of_mod, canonical_of_mod,
+                       low, high, rows_on_device, first, n_part_contigs, part_contigs ? part_contigs : &none, n_kept, n_confident);
 }
 
 int nm_ingest_results(nm_ctx *c, uint32_t *conf_contig, uint32_t *conf_position, uint8_t *conf_strand, int8_t *conf_mod,

@@ -88,7 +88,7 @@ struct nm_ctx {
     std::vector<uint32_t> ing_kept;                   // kept rows per (contig, mod code)
     // the confident rows of the last ingest are the set bits of the MP / MM planes of these slots (no list is built)
     int ing_slot_of_mod[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    uint64_t ing_nconf = 0;
+    uint64_t ing_nconf = 0, ing_total_kept = 0, ing_classified = 0;   // accumulated over the parts of one pileup
     uint32_t *d_programs = nullptr;                   // compiled constraint programs of the current batch
     size_t prog_cap_dw = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -158,7 +158,7 @@ inline void drop_slot_ranks(ModSlot &ms) {
 
 inline void drop_ingest_rows(nm_ctx *c) {
     for (int &x : c->ing_slot_of_mod) x = -1;
-    c->ing_nconf = 0;
+    c->ing_nconf = c->ing_total_kept = c->ing_classified = 0;
 }
 
 // pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it

@@ -343,7 +343,7 @@ class ScanEngine:
                                              _ptr(fr, C.c_double), 1 if append else 0))
 
     def ingest_pileup(self, contig_local, position, mod_code, strand, fraction_mod, nvalid_cov, labels, low=0.3, high=0.7,
-                      want_rows=True):
+                      want_rows=True, max_part_rows=None):
         """RAW pileup rows -> device-side pre-filters (dataload.py:191-247) -> state planes.
         contig_local: engine contig index per row, 0xFFFFFFFF for contigs this engine does not hold;
         mod_code: int8 ids as numbered by the reader (0 = m, 1 = a, 2 = 21839, 3.. = others, which only take part in
@@ -351,7 +351,10 @@ class ScanEngine:
         Returns dict(n_kept, n_confident, confident=(contig_local, position, strand, mod_code) of the surviving rows
         with fraction_mod >= high (None unless ``want_rows``: the device keeps them as the methylated-state planes, see
         ``methylated_row_counts`` / ``DeviceWindowStore.add_task_contigs``; ``confident_rows()`` fetches them later),
-        kept=uint32[n_contigs, 8] surviving rows per (contig, mod code))."""
+        kept=uint32[n_contigs, 8] surviving rows per (contig, mod code)).
+        ``max_part_rows``: ingest a pileup whose rows are grouped by contig (modkit output is) in parts of about that many
+        rows, cut at contig boundaries (nm_ingest_pileup_part) — bounds the device memory of the raw rows and of the
+        dense adjacency arrays; the result is the same."""
         cid = np.ascontiguousarray(contig_local, dtype=np.uint32)
         pos = np.ascontiguousarray(position, dtype=np.uint32)
         mod = np.ascontiguousarray(mod_code, dtype=np.int8)
@@ -373,13 +376,43 @@ class ScanEngine:
             canon[int(code)] = ord(base)
         n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(self.lib.nm_ingest_pileup(self.ctx, n, vp(cid), vp(pos), vp(mod), vp(st), vp(fr), vp(nv), slot_of, canon,
-                                             float(low), float(high), 0, C.byref(n_kept), C.byref(n_conf)))
+        parts = self._pileup_parts(cid, max_part_rows) if max_part_rows and n > max_part_rows else None
+        if parts is None:
+            _lib.check(self.lib.nm_ingest_pileup(self.ctx, n, vp(cid), vp(pos), vp(mod), vp(st), vp(fr), vp(nv), slot_of, canon,
+                                                 float(low), float(high), 0, C.byref(n_kept), C.byref(n_conf)))
+        else:
+            for k, (a, b) in enumerate(parts):
+                ids = np.unique(cid[a:b])
+                ids = np.ascontiguousarray(ids[ids != 0xFFFFFFFF], dtype=np.uint32)
+                sl = lambda x: vp(x[a:b]) if b > a else None
+                _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, b - a, sl(cid), sl(pos), sl(mod), sl(st), sl(fr), sl(nv), slot_of, canon,
+                                                          float(low), float(high), 0, 1 if k == 0 else 0, len(ids), _ptr(ids, C.c_uint32),
+                                                          C.byref(n_kept), C.byref(n_conf)))
         self._n_confident = int(n_conf.value)
         kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
         _lib.check(self.lib.nm_ingest_results(self.ctx, None, None, None, None, 0, _ptr(kept, C.c_uint32)))
         return dict(n_kept=int(n_kept.value), n_confident=self._n_confident,
                     confident=self.confident_rows() if want_rows else None, kept=kept)
+
+    @staticmethod
+    def _pileup_parts(cid: np.ndarray, max_rows: int):
+        """[(begin, end)] row ranges of about ``max_rows`` rows cut where the contig id changes, or None when some contig's
+        rows are not contiguous (then the pileup has to be ingested in one piece)."""
+        change = np.flatnonzero(cid[1:] != cid[:-1]) + 1
+        starts = np.concatenate([[0], change])
+        ids = cid[starts]
+        real = ids[ids != 0xFFFFFFFF]
+        if len(np.unique(real)) != len(real):
+            return None
+        ends = np.concatenate([change, [len(cid)]])
+        parts, a = [], 0
+        for e in ends.tolist():
+            if e - a >= max_rows:
+                parts.append((a, e))
+                a = e
+        if a < len(cid):
+            parts.append((a, len(cid)))
+        return parts
 
     def confident_rows(self):
         """(contig_local, position, strand, mod_code) of the rows the last ``ingest_pileup`` kept with

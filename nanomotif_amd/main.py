@@ -130,8 +130,10 @@ def find_motifs_bin(args):
     labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
     t0 = time.perf_counter()
     low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
+    # large pileups go to the device in parts of whole contigs (bounds the memory of the raw rows and filter scratch)
+    part_rows = int(os.environ.get("NANOMOTIF_INGEST_PART_ROWS", 250_000_000))
     res = eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
-                            table.nvalid_cov, labels, low=low, high=high, want_rows=False)
+                            table.nvalid_cov, labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
     store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
     rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
     if (low, high) == (0.3, 0.7):
@@ -140,7 +142,7 @@ def find_motifs_bin(args):
     else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
         eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
                           table.nvalid_cov, {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
-                          low=0.3, high=0.7)
+                          low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows)
     log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
     del table
     part = FilteredPileup(mine, *rows_part, res["kept"])

@@ -123,3 +123,33 @@ def test_duplicate_rows_are_refused():
     with pytest.raises(NmScanError, match="duplicate"):
         eng.ingest_pileup(dup["contig"], dup["position"], dup["mod"], dup["strand"], dup["frac"], dup["nvalid"], {1: ("a", "A")})
     eng.close()
+
+
+def test_ingest_in_parts_equals_one_piece():
+    """nm_ingest_pileup_part: the pileup cut at contig boundaries gives the same planes, tables and confident rows."""
+    from nanomotif_amd.engine import ScanEngine
+    spec = synth.SynthSpec(n_contigs=9, total_bp=700_000, n_bins=3, mod_types=("a", "m"), seed=83, min_contig_bp=30_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    t = _raw_table(mg, np.random.default_rng(6))
+    order = np.argsort(t["contig"], kind="stable")                  # rows grouped by contig, mod types interleaved
+    t = {k: v[order] for k, v in t.items()}
+    labels = {0: ("m", "C"), 1: ("a", "A")}
+    motifs = [(Motif("GATC", 1), "a"), (Motif("A", 0), "a"), (Motif("CC[AT]GG", 1), "m"), (Motif("C", 0), "m")]
+    cands = [(m, mt, b) for b in sorted(set(mg.bin_names)) for m, mt in motifs]
+    out = []
+    for max_rows in (None, 50_000):
+        eng = ScanEngine(0)
+        eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(len(mg.names))], mg.bin_names)
+        cid = t["contig"].astype(np.uint32)
+        if max_rows:
+            assert len(ScanEngine._pileup_parts(cid, max_rows)) >= 4
+        res = eng.ingest_pileup(cid, t["position"], t["mod_type"], t["strand"], t["fraction_mod"], t["Nvalid_cov"], labels,
+                                max_part_rows=max_rows)
+        rows = sorted(zip(*[x.tolist() for x in res["confident"]]))
+        out.append((res["n_kept"], res["n_confident"], res["kept"].tolist(), rows, eng.score(cands).tolist(),
+                    eng.methylated_row_counts("a", 20).tolist()))
+        eng.close()
+    assert out[0] == out[1] and out[0][0] > 0 and out[0][1] > 0
+    # rows of one contig in two places: no parts possible
+    assert ScanEngine._pileup_parts(np.array([0, 0, 1, 1, 0], np.uint32), 2) is None
