@@ -116,3 +116,45 @@ def test_assign_bins_balances_or_declines():
     assert assign_bins({"big": 10_000_000, "small": 100_000}, 2) is None          # contigs must be the unit then
     assert assign_bins({"big": 10_000_000, "small": 100_000}, 2, tolerance=float("inf")) == [["big"], ["small"]]
     assert assign_bins(sizes, 1) == [list(sizes)]
+
+
+def _gather_worker(rank, world, port, out_dir, q):
+    """Whole-bin sharding: every rank brings the motif rows of ITS bins; main._gather_rows puts them back into the
+    reference's bin order, applies the bin-level filter and lets rank 0 write bin-motifs.tsv."""
+    import types
+    import torch.distributed as dist
+    from nanomotif_amd import main as nm_main
+    from nanomotif_amd.model import BetaBernoulliModel
+    from nanomotif_amd.postprocess import MotifRow
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def row(bin_name, motif, pos, n_mod, n_nomod):
+        m = BetaBernoulliModel()
+        m.update(n_mod, n_nomod)
+        return MotifRow(bin_name, motif, "a", pos, m, 2.0)
+    mine = {0: [row("bin_b", "GATC", 1, 500, 10), row("bin_d", "CCWGG", 1, 30, 2)],       # bin_d: below --min_motifs_bin
+            1: [row("bin_a", "ACCCA", 4, 300, 40), row("bin_c", "GAAG", 1, 90, 5)]}[rank]
+    args = types.SimpleNamespace(min_motifs_bin=50, out=out_dir)
+    rows = nm_main._gather_rows(args, mine, rank, world, ["bin_a", "bin_b", "bin_c", "bin_d"])
+    q.put((rank, [(r.reference, r.motif) for r in rows]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bin_sharded_rows_are_gathered_in_bin_order(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [("bin_a", "ACCCA"), ("bin_b", "GATC"), ("bin_c", "GAAG")]
+    assert got[0] == want and got[1] == want                       # identical on every rank, bin_d filtered out
+    lines = open(tmp_path / "bin-motifs.tsv").read().strip().split("\n")
+    assert [l.split("\t")[0] for l in lines[1:]] == ["bin_a", "bin_b", "bin_c"]
