@@ -243,6 +243,13 @@ int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
 int nm_bed_mod_code(nm_bed *bed, uint32_t id, const char **code);
 int nm_bed_columns(nm_bed *bed, const uint32_t **contig_id, const int64_t **position, const int8_t **mod_type,
                    const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov);
+/* The columns in the exact types nm_ingest_pileup[_part] takes, without further copies: contig ids mapped through
+ * contig_lut[n_contigs of the file] (engine contig id, or 0xFFFFFFFF for contigs the engine does not hold), positions
+ * as uint32, Nvalid_cov as int32 with -1 for rows whose coverage or percentage is null (they fall to the coverage
+ * filter like in the reference).  Releases the 64-bit originals: nm_bed_columns must not be used afterwards. */
+int nm_bed_ingest_columns(nm_bed *bed, const uint32_t *contig_lut, uint32_t n_lut, const uint32_t **contig_id,
+                          const uint32_t **position, const int8_t **mod_type, const uint8_t **strand,
+                          const double **fraction_mod, const int32_t **nvalid_cov);
 int nm_bed_close(nm_bed *bed);
 
 /*

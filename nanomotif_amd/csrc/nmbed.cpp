@@ -262,6 +262,9 @@ bool load_gzip(const uint8_t *z, size_t zn, Buffer *b, unsigned threads, std::st
 struct nm_bed {
     Columns all;
     std::vector<const char *> name_ptrs;
+    // the columns in the exact types nm_ingest_pileup takes (nm_bed_ingest_columns)
+    std::vector<uint32_t> ing_contig, ing_position;
+    std::vector<int32_t> ing_nvalid;
 };
 
 extern "C" {
@@ -381,6 +384,54 @@ int nm_bed_columns(nm_bed *b, const uint32_t **contig_id, const int64_t **positi
     if (strand) *strand = b->all.strand.data();
     if (fraction_mod) *fraction_mod = b->all.fraction.data();
     if (nvalid_cov) *nvalid_cov = b->all.nvalid.data();
+    return NM_OK;
+}
+
+int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut, const uint32_t **contig_id,
+                          const uint32_t **position, const int8_t **mod_type, const uint8_t **strand,
+                          const double **fraction_mod, const int32_t **nvalid_cov) {
+    if (!b || !contig_lut || !contig_id || !position || !mod_type || !strand || !fraction_mod || !nvalid_cov)
+        return nm_set_error(NM_EINVAL, "NULL argument");
+    if (n_lut != b->all.names.size()) return nm_set_error(NM_EINVAL, "contig_lut has %u entries, the pileup names %zu contigs", n_lut, b->all.names.size());
+    const size_t n = b->all.contig.size();
+    b->ing_contig.resize(n);
+    b->ing_position.resize(n);
+    b->ing_nvalid.resize(n);
+    unsigned threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < (1u << 20)) threads = 1;
+    std::vector<int> bad(threads, 0);
+    auto work = [&](unsigned t) {
+        const size_t lo = n * t / threads, hi = n * (t + 1) / threads;
+        for (size_t i = lo; i < hi; ++i) {
+            const int64_t p = b->all.position[i], v = b->all.nvalid[i];
+            const int8_t m = b->all.mod_type[i];
+            if (p < 0 || p > 0xFFFFFFFEll) bad[t] |= 1;
+            if (m < 0 || m >= 8) bad[t] |= 2;
+            b->ing_contig[i] = contig_lut[b->all.contig[i]];
+            b->ing_position[i] = (uint32_t)p;
+            // a null coverage or percentage can never pass Nvalid_cov > 5: such rows leave through the coverage filter
+            b->ing_nvalid[i] = (v < 0 || b->all.fraction[i] < 0) ? -1 : (int32_t)std::min<int64_t>(v, 0x7FFFFFFF);
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    int any = 0;
+    for (int x : bad) any |= x;
+    if (any & 1) return nm_set_error(NM_ERANGE, "pileup position beyond 4 Gbp");
+    if (any & 2) return nm_set_error(NM_ERANGE, "more than 8 distinct modification codes in the pileup");
+    std::vector<int64_t>().swap(b->all.position);          // the 64-bit originals are no longer needed
+    std::vector<int64_t>().swap(b->all.nvalid);
+    *contig_id = b->ing_contig.data();
+    *position = b->ing_position.data();
+    *mod_type = b->all.mod_type.data();
+    *strand = b->all.strand.data();
+    *fraction_mod = b->all.fraction.data();
+    *nvalid_cov = b->ing_nvalid.data();
     return NM_OK;
 }
 

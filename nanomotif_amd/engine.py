@@ -360,7 +360,8 @@ class ScanEngine:
         mod = np.ascontiguousarray(mod_code, dtype=np.int8)
         st = np.ascontiguousarray(strand, dtype=np.uint8)
         fr = np.ascontiguousarray(fraction_mod, dtype=np.float64)
-        nv = np.ascontiguousarray(np.clip(nvalid_cov, -2**31, 2**31 - 1), dtype=np.int32)
+        nv = nvalid_cov if getattr(nvalid_cov, "dtype", None) == np.int32 else np.clip(nvalid_cov, -2**31, 2**31 - 1)
+        nv = np.ascontiguousarray(nv, dtype=np.int32)
         n = len(cid)
         if not (len(pos) == len(mod) == len(st) == len(fr) == len(nv) == n):
             raise ValueError("pileup columns differ in length")

@@ -90,7 +90,7 @@ def find_motifs_bin(args):
     if bgzip and not os.path.exists(cfg.pileup_path + ".tbi"):
         raise FileNotFoundError(f"Tabix index for {cfg.pileup_path} not found.")     # find_motifs_bin.py:383-384
     t0 = time.perf_counter()
-    table = pileup_mod.load_pileup(cfg.pileup_path)                  # native reader, raw rows
+    table = pileup_mod.NativePileup(cfg.pileup_path)                 # native reader, raw rows kept in native memory
     log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s)")
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they
@@ -123,28 +123,26 @@ def find_motifs_bin(args):
     # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
     local_id = {c: i for i, c in enumerate(mine)}
     lut = np.array([local_id.get(n, 0xFFFFFFFF) for n in table.contig_names], dtype=np.uint32)
-    if table.mod_type.max(initial=0) >= 8:
-        raise ValueError("more than 8 distinct modification codes in the pileup")
-    if table.position.max(initial=0) >= 2**32:
-        raise ValueError("pileup position beyond 4 Gbp")
+    cols = table.ingest_columns(lut)          # views in the engine's types; refuses > 8 mod codes / positions >= 4 Gbp
     labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
     t0 = time.perf_counter()
     low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
     # large pileups go to the device in parts of whole contigs (bounds the memory of the raw rows and filter scratch)
     part_rows = int(os.environ.get("NANOMOTIF_INGEST_PART_ROWS", 250_000_000))
-    res = eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
-                            table.nvalid_cov, labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
+    res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
+                            cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
     store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
     rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
     if (low, high) == (0.3, 0.7):
         for mt in pileup_mod.MOD_TYPES:
             eng.alias_label((mt, "merge"), mt)
     else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
-        eng.ingest_pileup(lut[table.contig], table.position, table.mod_type, table.strand, table.fraction_mod,
-                          table.nvalid_cov, {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
+        eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
+                          cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
                           low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows)
     log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
-    del table
+    del cols
+    table.close()
     part = FilteredPileup(mine, *rows_part, res["kept"])
     if world > 1:
         gathered = [None] * world

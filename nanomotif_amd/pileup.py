@@ -64,6 +64,54 @@ def load_pileup(path: str, threads: int = 0) -> PileupTable:
     return t if ok.all() else t.take(ok)
 
 
+class NativePileup:
+    """A bedMethyl file parsed by the native reader and kept in native memory: ``ingest_columns(lut)`` hands out numpy
+    VIEWS in exactly the types ``ScanEngine.ingest_pileup`` takes (no per-column copies at 1e9 rows); valid until
+    ``close()``.  ``contig_names``: first-appearance order of the file = index space of ``lut``."""
+
+    def __init__(self, path: str, threads: int = 0):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self._h = C.c_void_p()
+        self._check(self._lib.nm_bed_open(os.fsencode(path), int(threads), C.byref(self._h)))
+        n, nc = C.c_uint64(0), C.c_uint32(0)
+        self._check(self._lib.nm_bed_shape(self._h, C.byref(n), C.byref(nc)))
+        self.n = int(n.value)
+        if self.n == 0:
+            self.close()
+            raise SystemExit("Pileup is empty after initial load")      # dataload.py:89-91 exits with status 1
+        self.contig_names = []
+        for i in range(nc.value):
+            s = C.c_char_p()
+            self._check(self._lib.nm_bed_contig_name(self._h, i, C.byref(s)))
+            self.contig_names.append(s.value.decode())
+
+    def __len__(self):
+        return self.n
+
+    def ingest_columns(self, lut: np.ndarray) -> dict:
+        import ctypes as C
+        lut = np.ascontiguousarray(lut, dtype=np.uint32)
+        ptr = [C.c_void_p() for _ in range(6)]
+        self._check(self._lib.nm_bed_ingest_columns(self._h, lut.ctypes.data_as(C.POINTER(C.c_uint32)), len(lut),
+                                                    *[C.byref(x) for x in ptr]))
+        kinds = (("contig", C.c_uint32), ("position", C.c_uint32), ("mod_type", C.c_int8), ("strand", C.c_uint8),
+                 ("fraction_mod", C.c_double), ("nvalid_cov", C.c_int32))
+        return {name: np.ctypeslib.as_array(C.cast(ptr[i], C.POINTER(ct)), shape=(self.n,)) for i, (name, ct) in enumerate(kinds)}
+
+    def close(self):
+        if self._h:
+            self._lib.nm_bed_close(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def filter_pileup(t: PileupTable, min_coverage: int = 5) -> PileupTable:
     """dataload.py:191-200: strict Nvalid_cov > 5 (the CLI's --threshold_valid_coverage is parsed but never
     forwarded by the reference, argparser.py:126-129 vs main.py:69-83 — same here)."""

@@ -77,3 +77,29 @@ def test_reader_edge_cases(tmp_path):
     open(path, "w").write("")
     with pytest.raises(SystemExit):
         pp.load_pileup(path)
+
+
+def test_native_ingest_columns_match_the_table(tmp_path):
+    """NativePileup.ingest_columns: zero-copy views in the engine's types == load_pileup + the numpy conversions."""
+    from nanomotif_amd import pileup, synth
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=4, total_bp=60_000, n_bins=2, mod_types=("a", "m"), seed=5))
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    with open(path, "a") as f:          # a null percentage and a null coverage: both rows must fall to the coverage filter
+        f.write("contig_0000\t7\t8\ta\t9\t+\t7\t8\t255,0,0\t9\tNA\t0\t9\t0\t0\t0\t0\t0\n")
+        f.write("contig_0001\t9\t10\tm\tnull\t-\t9\t10\t255,0,0\tnull\t1.00\t0\t0\t0\t0\t0\t0\t0\n")
+    t = pileup.load_pileup(path)                       # drops the two null rows
+    nat = pileup.NativePileup(path)
+    assert len(nat) == len(t) + 2 and nat.contig_names[:len(t.contig_names)] == t.contig_names
+    lut = np.arange(len(nat.contig_names), dtype=np.uint32)[::-1].copy()
+    lut[0] = 0xFFFFFFFF
+    cols = nat.ingest_columns(lut)
+    assert [cols[k].dtype for k in ("contig", "position", "mod_type", "strand", "fraction_mod", "nvalid_cov")] == \
+        [np.uint32, np.uint32, np.int8, np.uint8, np.float64, np.int32]
+    live = cols["nvalid_cov"] >= 0
+    assert int((~live).sum()) == 2
+    assert np.array_equal(cols["contig"][live], lut[t.contig])
+    assert np.array_equal(cols["position"][live], t.position) and np.array_equal(cols["mod_type"][live], t.mod_type)
+    assert np.array_equal(cols["strand"][live], t.strand) and np.array_equal(cols["fraction_mod"][live], t.fraction_mod)
+    assert np.array_equal(cols["nvalid_cov"][live], t.nvalid_cov)
+    nat.close()
