@@ -253,6 +253,19 @@ int nm_bed_ingest_columns(nm_bed *bed, const uint32_t *contig_lut, uint32_t n_lu
 int nm_bed_close(nm_bed *bed);
 
 /*
+ * Native FASTA reader — replaces pyfastx / the line loop of fasta.py:35-49 plus DNAsequence's checks (seq.py:53-71):
+ * plain or gzip / bgzip files; record name = first whitespace-delimited token of the header; sequences upper-cased,
+ * all records back to back in nm_fasta_sequence; an empty record or a letter outside ATGCRYSWKMBDHVN is an error (the
+ * reference asserts).  Records are parsed in parallel.
+ */
+typedef struct nm_fasta nm_fasta;
+int nm_fasta_open(const char *path, uint32_t threads, nm_fasta **out);
+int nm_fasta_shape(nm_fasta *fa, uint32_t *n_records, uint64_t *total_bp);
+int nm_fasta_record(nm_fasta *fa, uint32_t i, const char **name, uint64_t *offset, uint64_t *length);
+int nm_fasta_sequence(nm_fasta *fa, const uint8_t **seq_upper);
+int nm_fasta_close(nm_fasta *fa);
+
+/*
  * Host helpers of the window-extraction step (no GPU involved).
  * nm_py_random_sample: the indices CPython's random.sample(range(n), k) would return from the MT19937 state
  *   mt_state[0..623] + position mt_state[624] (random.getstate()[1]); the state is advanced in place, so that

@@ -15,7 +15,7 @@ SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
-    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_window_letter_counts", "nm_bed_open", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close",
+    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_window_letter_counts", "nm_bed_open", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
 ]
 
 _lib = None
@@ -83,6 +83,11 @@ def load():
     lib.nm_bed_columns.argtypes = [p] + [C.POINTER(p)] * 6
     lib.nm_bed_ingest_columns.argtypes = [p, u32p, C.c_uint32] + [C.POINTER(p)] * 6
     lib.nm_bed_close.argtypes = [p]
+    lib.nm_fasta_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(p)]
+    lib.nm_fasta_shape.argtypes = [p, u32p, u64p]
+    lib.nm_fasta_record.argtypes = [p, C.c_uint32, C.POINTER(C.c_char_p), u64p, u64p]
+    lib.nm_fasta_sequence.argtypes = [p, C.POINTER(p)]
+    lib.nm_fasta_close.argtypes = [p]
     lib.nm_timing_reset.argtypes = [p, C.c_int]
     lib.nm_timing_total_ms.argtypes = [p, C.POINTER(C.c_double), u64p]
     for s in SYMBOLS:

@@ -257,6 +257,33 @@ bool load_gzip(const uint8_t *z, size_t zn, Buffer *b, unsigned threads, std::st
     return true;
 }
 
+// map a file and, when it is gzip / BGZF, inflate it; *buf owns whatever it needs
+static int load_file(const char *path, unsigned threads, Buffer *buf, const char *what) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return nm_set_error(NM_EINVAL, "cannot open %s '%s'", what, path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return nm_set_error(NM_EINVAL, "cannot stat %s '%s'", what, path); }
+    if (st.st_size > 0) {
+        buf->map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        buf->map_size = (size_t)st.st_size;
+        if (buf->map == MAP_FAILED) { buf->map = nullptr; close(fd); return nm_set_error(NM_EINVAL, "cannot map %s '%s'", what, path); }
+    }
+    close(fd);
+    const uint8_t *raw = static_cast<const uint8_t *>(buf->map);
+    std::string err;
+    if (buf->map_size >= 2 && raw[0] == 31 && raw[1] == 139) {
+        if (!load_gzip(raw, buf->map_size, buf, threads, &err)) {
+            munmap(buf->map, buf->map_size);
+            buf->map = nullptr;
+            return nm_set_error(NM_EINVAL, "%s: %s", path, err.c_str());
+        }
+    } else {
+        buf->data = static_cast<const char *>(buf->map);
+        buf->size = buf->map_size;
+    }
+    return NM_OK;
+}
+
 }  // namespace
 
 struct nm_bed {
@@ -437,6 +464,118 @@ int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut,
 
 int nm_bed_close(nm_bed *b) {
     delete b;
+    return NM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// FASTA reader (reference: nanomotif/fasta.py:35-49 + DNAsequence checks, seq.py:53-71): names = first whitespace token
+// of the header, sequences upper-cased and validated against the IUPAC alphabet, all records back to back.
+// ------------------------------------------------------------------------------------------------------
+struct nm_fasta {
+    std::vector<std::string> names;
+    std::vector<uint64_t> offset;         // n + 1
+    std::vector<uint8_t> seq;
+};
+
+int nm_fasta_open(const char *path, uint32_t threads, nm_fasta **out) {
+    if (!path || !out) return nm_set_error(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    Buffer buf;
+    int rc = load_file(path, threads, &buf, "assembly");
+    if (rc) return rc;
+    auto release = [&]() { if (buf.map) munmap(buf.map, buf.map_size); };
+    const char *d = buf.data, *end = buf.data + buf.size;
+    // record starts: '>' at the beginning of a line
+    struct Rec { const char *hdr, *body, *stop; uint64_t len; };
+    std::vector<Rec> recs;
+    for (const char *p = d; p < end;) {
+        const char *eol = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        if (!eol) eol = end;
+        if (*p == '>') {
+            if (!recs.empty()) recs.back().stop = p;
+            recs.push_back(Rec{p, eol < end ? eol + 1 : end, end, 0});
+        }
+        p = eol < end ? eol + 1 : end;
+    }
+    nm_fasta *f = new (std::nothrow) nm_fasta();
+    if (!f) { release(); return nm_set_error(NM_ENOMEM, "out of host memory"); }
+    static bool iupac[256];
+    static bool init = false;
+    if (!init) { for (const char *c = "ATGCRYSWKMBDHVN"; *c; ++c) iupac[(unsigned char)*c] = true; init = true; }
+    const size_t n = recs.size();
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n));
+    auto for_records = [&](auto fn) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] { for (size_t i = t; i < n; i += threads) fn(i); });
+        for (auto &th : pool) th.join();
+    };
+    for_records([&](size_t i) {                                   // pass 1: sequence lengths (bytes that are not \r \n)
+        uint64_t len = 0;
+        for (const char *p = recs[i].body; p < recs[i].stop; ++p) len += (*p != '\n' && *p != '\r');
+        recs[i].len = len;
+    });
+    f->offset.assign(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) f->offset[i + 1] = f->offset[i] + recs[i].len;
+    f->seq.resize(f->offset[n]);
+    std::vector<int> bad(n, 0);
+    for_records([&](size_t i) {                                   // pass 2: copy, upper-case, validate
+        uint8_t *o = f->seq.data() + f->offset[i];
+        int b = 0;
+        for (const char *p = recs[i].body; p < recs[i].stop; ++p) {
+            unsigned char c = (unsigned char)*p;
+            if (c == '\n' || c == '\r') continue;
+            if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+            b |= !iupac[c];
+            *o++ = c;
+        }
+        bad[i] = b;
+    });
+    for (size_t i = 0; i < n; ++i) {
+        const char *h = recs[i].hdr + 1, *he = static_cast<const char *>(memchr(h, '\n', (size_t)(end - h)));
+        if (!he) he = end;
+        while (h < he && (*h == ' ' || *h == '\t' || *h == '\r' || *h == '\f' || *h == '\v')) ++h;      // str.split(): leading whitespace
+        const char *t = h;
+        while (t < he && !(*t == ' ' || *t == '\t' || *t == '\r' || *t == '\f' || *t == '\v')) ++t;
+        f->names.emplace_back(h, (size_t)(t - h));
+        if (recs[i].len == 0 || bad[i]) {
+            const std::string name = f->names.back();            // copied before the file mapping goes away
+            const bool empty = recs[i].len == 0;
+            delete f;
+            release();
+            return empty ? nm_set_error(NM_EINVAL, "DNA sequence must not be empty (record '%s')", name.c_str())
+                         : nm_set_error(NM_EINVAL, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", name.c_str());
+        }
+    }
+    release();
+    *out = f;
+    return NM_OK;
+}
+
+int nm_fasta_shape(nm_fasta *f, uint32_t *n_records, uint64_t *total_bp) {
+    if (!f || !n_records || !total_bp) return nm_set_error(NM_EINVAL, "NULL argument");
+    *n_records = (uint32_t)f->names.size();
+    *total_bp = f->offset.back();
+    return NM_OK;
+}
+
+int nm_fasta_record(nm_fasta *f, uint32_t i, const char **name, uint64_t *offset, uint64_t *length) {
+    if (!f || !name || !offset || !length || i >= f->names.size()) return nm_set_error(NM_EINVAL, "bad record index");
+    *name = f->names[i].c_str();
+    *offset = f->offset[i];
+    *length = f->offset[i + 1] - f->offset[i];
+    return NM_OK;
+}
+
+int nm_fasta_sequence(nm_fasta *f, const uint8_t **seq_upper) {
+    if (!f || !seq_upper) return nm_set_error(NM_EINVAL, "NULL argument");
+    *seq_upper = f->seq.data();
+    return NM_OK;
+}
+
+int nm_fasta_close(nm_fasta *f) {
+    delete f;
     return NM_OK;
 }
 

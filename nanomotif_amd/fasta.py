@@ -38,16 +38,34 @@ def read_fasta_names_and_seqs(path):
 
 
 def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
-    """name -> upper-case uint8 array.  Empty or non-IUPAC sequences fail like DNAsequence._check_sequence
-    (seq.py:68-71)."""
-    out = {}
-    for name, seq in read_fasta_names_and_seqs(path):
-        if trim_names:
-            name = name.split(trim_character)[0]
-        arr = np.frombuffer(seq.upper().encode("ascii"), dtype=np.uint8)
-        assert len(arr) > 0, "DNA sequence must not be empty"
-        assert IUPAC[arr].all(), "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN"
-        out[name] = arr
+    """name -> upper-case uint8 array (views into one buffer).  Parsed natively (libnmscan: nm_fasta_open — plain or
+    gzip, records in parallel); empty or non-IUPAC sequences fail like DNAsequence._check_sequence (seq.py:68-71)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.nm_fasta_open(os.fsencode(str(path)), 0, C.byref(h))
+    if rc:
+        msg = lib.nm_last_error().decode()
+        if "DNA sequence must" in msg:
+            raise AssertionError(msg)
+        _lib.check(rc)
+    try:
+        n, total = C.c_uint32(0), C.c_uint64(0)
+        _lib.check(lib.nm_fasta_shape(h, C.byref(n), C.byref(total)))
+        ptr = C.c_void_p()
+        _lib.check(lib.nm_fasta_sequence(h, C.byref(ptr)))
+        whole = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(total.value,)).copy() if total.value else np.zeros(0, np.uint8)
+        out = {}
+        for i in range(n.value):
+            name, off, ln = C.c_char_p(), C.c_uint64(0), C.c_uint64(0)
+            _lib.check(lib.nm_fasta_record(h, i, C.byref(name), C.byref(off), C.byref(ln)))
+            key = name.value.decode()
+            if trim_names:
+                key = key.split(trim_character)[0]
+            out[key] = whole[off.value:off.value + ln.value]
+    finally:
+        lib.nm_fasta_close(h)
     return out
 
 

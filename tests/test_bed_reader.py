@@ -103,3 +103,39 @@ def test_native_ingest_columns_match_the_table(tmp_path):
     assert np.array_equal(cols["strand"][live], t.strand) and np.array_equal(cols["fraction_mod"][live], t.fraction_mod)
     assert np.array_equal(cols["nvalid_cov"][live], t.nvalid_cov)
     nat.close()
+
+
+def test_native_fasta_matches_the_line_loop(tmp_path):
+    """nm_fasta_open (fasta.load_fasta) against the pure-Python reading of the same file: wrapped lines, CRLF, blank
+    lines, lower case, header descriptions, text before the first header, gzip; and the reference's two assertions."""
+    import gzip as gz
+    from nanomotif_amd import fasta
+    rng = np.random.default_rng(2)
+    recs = []
+    for i in range(7):
+        n = int(rng.integers(1, 5000))
+        s = "".join(rng.choice(list("ACGTNRYacgtn"), size=n))
+        recs.append((f"contig_{i}" + ("" if i % 2 else f" len={n} some text"), s))
+    txt = "ignored line before any header\n"
+    for k, (hdr, s) in enumerate(recs):
+        w = [60, 80, 7, 10_000][k % 4]
+        eol = "\r\n" if k == 2 else "\n"
+        txt += ">" + hdr + eol + eol.join(s[j:j + w] for j in range(0, len(s), w)) + eol + ("\n" if k == 3 else "")
+    p = tmp_path / "a.fasta"
+    p.write_text(txt, newline="")
+    want = {name: np.frombuffer(seq.upper().encode(), np.uint8) for name, seq in fasta.read_fasta_names_and_seqs(str(p))}
+    got = fasta.load_fasta(str(p))
+    assert list(got) == list(want) == [h.split()[0] for h, _ in recs]
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    with gz.open(str(p) + ".gz", "wt", newline="") as f:
+        f.write(txt)
+    got_gz = fasta.load_fasta(str(p) + ".gz")
+    assert list(got_gz) == list(want) and all(np.array_equal(got_gz[k], want[k]) for k in want)
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">x\nACGTXACGT\n")
+    with pytest.raises(AssertionError, match="ATGCRYSWKMBDHVN"):
+        fasta.load_fasta(str(bad))
+    bad.write_text(">x\nACGT\n>empty\n>y\nAC\n")
+    with pytest.raises(AssertionError, match="must not be empty"):
+        fasta.load_fasta(str(bad))
