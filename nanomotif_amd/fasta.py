@@ -37,6 +37,26 @@ def read_fasta_names_and_seqs(path):
         yield name, "".join(chunks)
 
 
+def read_fasta_names(path):
+    """First whitespace-delimited header token of every record, in file order (headers only: the bin FASTA files of -f / -d
+    are read for their contig names, fasta.py:150-170)."""
+    import mmap
+    import re
+    if str(path).endswith(".gz"):
+        with gzip.open(path, "rb") as f:
+            data = f.read()
+    else:
+        with open(path, "rb") as f:
+            if os.fstat(f.fileno()).st_size == 0:
+                return []
+            data = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    names = []
+    for m in re.finditer(rb"^>([^\r\n]*)", data, re.M):
+        tok = m.group(1).split()
+        names.append(tok[0].decode() if tok else "")
+    return names
+
+
 def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
     """name -> upper-case uint8 array (views into one buffer).  Parsed natively (libnmscan: nm_fasta_open — plain or
     gzip, records in parallel); empty or non-IUPAC sequences fail like DNAsequence._check_sequence (seq.py:68-71)."""
@@ -101,7 +121,7 @@ def generate_contig_bin(args) -> dict:
     out = {}
     for fp in files:
         stem = Path(fp).stem
-        for name, _ in read_fasta_names_and_seqs(fp):
+        for name in read_fasta_names(fp):
             if name:
                 out[name] = stem
     path = os.path.join(args.out, "temp", "contig_bin.tsv")
