@@ -7,6 +7,13 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,7 +43,7 @@ def _bench(extra, nproc=1):
              "--cpu-bins", "0", "--hbm-round-steps", "0"]
     cmd = [sys.executable, "bench.py"] if nproc == 1 else \
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-         "--master-port", "29677", "bench.py", "--gpus", str(nproc), "--dist-backend", "gloo", "--force-device", "0"]
+         "--master-port", str(_free_port()), "bench.py", "--gpus", str(nproc), "--dist-backend", "gloo", "--force-device", "0"]
     r = subprocess.run(cmd + small + extra, cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads([l for l in r.stdout.strip().split("\n") if l.startswith("{")][-1])

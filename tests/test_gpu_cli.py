@@ -12,6 +12,13 @@ from helpers import oracle_pipeline
 from nanomotif_amd import synth
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -21,7 +28,7 @@ def _run_cli(tmp, args, nproc=1):
     if nproc > 1:      # several ranks on the one GPU of the test box: gloo carries the all-reduces
         env["NANOMOTIF_DIST_BACKEND"] = "gloo"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-               "--master-port", "29653", "-m", "nanomotif_amd", "motif_discovery", "--device", "0"] + args
+               "--master-port", str(_free_port()), "-m", "nanomotif_amd", "motif_discovery", "--device", "0"] + args
     r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
