@@ -21,6 +21,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/nmscan.h"
@@ -29,12 +30,30 @@ int nm_set_error(int code, const char *fmt, ...);   // defined in nmscan.hip
 
 namespace {
 
+// std::vector whose resize() leaves new elements uninitialised: the merged columns are sized once and then filled by
+// all parser threads at the same time (no serial zero-fill of tens of gigabytes first)
+template <class T>
+struct NoInit {
+    using value_type = T;
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(::operator new(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { ::operator delete(p); }
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+    template <class U> bool operator==(const NoInit<U> &) const { return true; }
+    template <class U> bool operator!=(const NoInit<U> &) const { return false; }
+};
+template <class T> using Vec = std::vector<T, NoInit<T>>;
+
 struct Columns {
-    std::vector<uint32_t> contig;
-    std::vector<int64_t> position, nvalid;
-    std::vector<int8_t> mod_type;
-    std::vector<uint8_t> strand;
-    std::vector<double> fraction;
+    Vec<uint32_t> contig;
+    Vec<int64_t> position, nvalid;
+    Vec<int8_t> mod_type;
+    Vec<uint8_t> strand;
+    Vec<double> fraction;
     std::vector<std::string> names;               // local id -> name
     std::vector<std::string> other_mods;          // local mod id 3 + k -> code (anything but m, a, 21839)
     std::string error;
@@ -290,8 +309,8 @@ struct nm_bed {
     Columns all;
     std::vector<const char *> name_ptrs;
     // the columns in the exact types nm_ingest_pileup takes (nm_bed_ingest_columns)
-    std::vector<uint32_t> ing_contig, ing_position;
-    std::vector<int32_t> ing_nvalid;
+    Vec<uint32_t> ing_contig, ing_position;
+    Vec<int32_t> ing_nvalid;
 };
 
 extern "C" {
@@ -342,38 +361,56 @@ int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
         if (!p.error.empty()) return nm_set_error(NM_EINVAL, "%s: %s", path, p.error.c_str());
     nm_bed *b = new (std::nothrow) nm_bed();
     if (!b) return nm_set_error(NM_ENOMEM, "out of host memory");
-    size_t n = 0;
-    for (auto &p : parts) n += p.position.size();
     Columns &a = b->all;
-    a.contig.reserve(n); a.position.reserve(n); a.nvalid.reserve(n); a.mod_type.reserve(n); a.strand.reserve(n); a.fraction.reserve(n);
+    // serial and cheap: global contig / mod ids of every part, and where its rows go; then all parts copy at once
+    std::vector<size_t> at(parts.size() + 1, 0);
+    std::vector<std::vector<uint32_t>> remap(parts.size());
+    std::vector<std::vector<int8_t>> mod_remap(parts.size());
     std::unordered_map<std::string, uint32_t> ids;
-    for (auto &p : parts) {
-        std::vector<uint32_t> remap(p.names.size());
+    for (size_t k = 0; k < parts.size(); ++k) {
+        Columns &p = parts[k];
+        at[k + 1] = at[k] + p.position.size();
+        remap[k].resize(p.names.size());
         for (size_t i = 0; i < p.names.size(); ++i) {
             auto it = ids.find(p.names[i]);
             if (it == ids.end()) {
                 it = ids.emplace(p.names[i], (uint32_t)a.names.size()).first;
                 a.names.push_back(p.names[i]);
             }
-            remap[i] = it->second;
+            remap[k][i] = it->second;
         }
-        for (uint32_t v : p.contig) a.contig.push_back(remap[v]);
-        std::vector<int8_t> mod_remap(3 + p.other_mods.size());
-        for (int k = 0; k < 3; ++k) mod_remap[k] = (int8_t)k;
-        for (size_t k = 0; k < p.other_mods.size(); ++k) {
+        mod_remap[k].resize(3 + p.other_mods.size());
+        for (int j = 0; j < 3; ++j) mod_remap[k][j] = (int8_t)j;
+        for (size_t j = 0; j < p.other_mods.size(); ++j) {
             size_t g = 0;
             for (; g < a.other_mods.size(); ++g)
-                if (a.other_mods[g] == p.other_mods[k]) break;
-            if (g == a.other_mods.size()) a.other_mods.push_back(p.other_mods[k]);
-            mod_remap[3 + k] = (int8_t)(3 + g);
+                if (a.other_mods[g] == p.other_mods[j]) break;
+            if (g == a.other_mods.size()) a.other_mods.push_back(p.other_mods[j]);
+            mod_remap[k][3 + j] = (int8_t)(3 + g);
         }
-        for (auto &m : p.mod_type) m = mod_remap[(size_t)m];
-        a.position.insert(a.position.end(), p.position.begin(), p.position.end());
-        a.nvalid.insert(a.nvalid.end(), p.nvalid.begin(), p.nvalid.end());
-        a.mod_type.insert(a.mod_type.end(), p.mod_type.begin(), p.mod_type.end());
-        a.strand.insert(a.strand.end(), p.strand.begin(), p.strand.end());
-        a.fraction.insert(a.fraction.end(), p.fraction.begin(), p.fraction.end());
-        Columns().contig.swap(p.contig);
+    }
+    const size_t n = at.back();
+    a.contig.resize(n); a.position.resize(n); a.nvalid.resize(n); a.mod_type.resize(n); a.strand.resize(n); a.fraction.resize(n);
+    {
+        std::vector<std::thread> copiers;
+        for (size_t k = 0; k < parts.size(); ++k)
+            copiers.emplace_back([&, k] {
+                Columns &p = parts[k];
+                const size_t o = at[k], m = p.position.size();
+                for (size_t i = 0; i < m; ++i) a.contig[o + i] = remap[k][p.contig[i]];
+                for (size_t i = 0; i < m; ++i) a.mod_type[o + i] = mod_remap[k][(size_t)p.mod_type[i]];
+                if (m) {
+                    memcpy(a.position.data() + o, p.position.data(), m * sizeof(int64_t));
+                    memcpy(a.nvalid.data() + o, p.nvalid.data(), m * sizeof(int64_t));
+                    memcpy(a.strand.data() + o, p.strand.data(), m);
+                    memcpy(a.fraction.data() + o, p.fraction.data(), m * sizeof(double));
+                }
+                Columns().contig.swap(p.contig);
+                Columns().position.swap(p.position);
+                Columns().nvalid.swap(p.nvalid);
+                Columns().fraction.swap(p.fraction);
+            });
+        for (auto &th : copiers) th.join();
     }
     for (auto &s : a.names) b->name_ptrs.push_back(s.c_str());
     *out = b;
@@ -451,8 +488,8 @@ int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut,
     for (int x : bad) any |= x;
     if (any & 1) return nm_set_error(NM_ERANGE, "pileup position beyond 4 Gbp");
     if (any & 2) return nm_set_error(NM_ERANGE, "more than 8 distinct modification codes in the pileup");
-    std::vector<int64_t>().swap(b->all.position);          // the 64-bit originals are no longer needed
-    std::vector<int64_t>().swap(b->all.nvalid);
+    Vec<int64_t>().swap(b->all.position);          // the 64-bit originals are no longer needed
+    Vec<int64_t>().swap(b->all.nvalid);
     *contig_id = b->ing_contig.data();
     *position = b->ing_position.data();
     *mod_type = b->all.mod_type.data();
