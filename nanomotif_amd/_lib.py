@@ -25,6 +25,13 @@ class NmScanError(RuntimeError):
     pass
 
 
+def _cli_process() -> bool:
+    """True when this interpreter was started as ``python -m nanomotif_amd`` (the only torch-free entry point)."""
+    import sys
+    main = sys.modules.get("__main__")
+    return getattr(getattr(main, "__spec__", None), "name", "") in ("nanomotif_amd.__main__", "nanomotif_amd")
+
+
 def load():
     """Load libnmscan.so (after torch, so both share one HIP runtime) and declare prototypes."""
     global _lib
@@ -34,10 +41,16 @@ def load():
         raise NmScanError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  nanomotif_amd has no CPU fallback.")
-    try:
-        import torch  # noqa: F401  — loads torch's bundled libamdhip64 first; SONAME matches ours
-    except Exception:  # pragma: no cover - torch is plumbing only
-        pass
+    # In a process that uses torch (tests, bench, multi-rank runs) torch's bundled libamdhip64 must be loaded first so
+    # that both share ONE HIP runtime (the SONAME matches ours).  A single-GPU CLI run never touches torch and loads
+    # the system runtime through the library's RUNPATH instead — a second of start-up saved.
+    import sys
+    if "torch" in sys.modules or os.environ.get("WORLD_SIZE", "1") != "1" or os.environ.get("NANOMOTIF_WITH_TORCH") == "1" \
+            or not _cli_process():
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing only
+            pass
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     p = C.c_void_p
     u8p, u32p, u64p, i64p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int64, C.c_double))

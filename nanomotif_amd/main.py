@@ -54,24 +54,31 @@ def shared_setup(args, working_dir, rank=0):
 
 def find_motifs_bin(args):
     """main.py:46-104."""
-    import torch
-    import torch.distributed as dist
-    from .engine import ScanEngine
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = args.device if args.device is not None else local_rank
-    if not torch.cuda.is_available():
-        raise RuntimeError("nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback")
-    torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
-        # RCCL unless NANOMOTIF_DIST_BACKEND=gloo (debugging aid: lets several ranks share one GPU with --device)
-        backend = os.environ.get("NANOMOTIF_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend)
+    dist = None
+    if world > 1:
+        # torch is plumbing for the multi-rank run only (process group, RCCL); a single-GPU run never imports it
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise RuntimeError("nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback")
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            # RCCL unless NANOMOTIF_DIST_BACKEND=gloo (debugging aid: lets several ranks share one GPU with --device)
+            backend = os.environ.get("NANOMOTIF_DIST_BACKEND", "nccl")
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            else:
+                dist.init_process_group(backend)
+    from ._lib import NmScanError
+    from .engine import ScanEngine
+    try:
+        eng = ScanEngine(device)                 # fails loudly without a GPU: there is no CPU fallback
+    except NmScanError as e:
+        raise RuntimeError(f"nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback ({e})") from e
 
     log.info("Starting nanomotif motif finder")
     bin_contig = fasta.generate_contig_bin(args)
@@ -116,7 +123,6 @@ def find_motifs_bin(args):
         gather_world = 1
     parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
     mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
-    eng = ScanEngine(device)
     all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
     eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
     # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
@@ -192,8 +198,9 @@ def device_window_pipeline(eng, lengths: dict, mine: list, padding: int, world: 
     every rank for its own contigs, with the per-request counts summed over the ranks.  An assembly with letters
     other than A C G T N keeps window extraction on the host (the reference raises KeyError when a window meets one,
     seq.py:474-478, and so does the host path); then every rank holds all windows."""
-    import torch.distributed as dist
     from .engine import DeviceWindowExtractor, DeviceWindowStore
+    if world > 1:
+        import torch.distributed as dist
     other = np.array([eng.other_letters()], dtype=np.int64)
     if world > 1:
         other = allreduce_counts(other)
