@@ -1,29 +1,37 @@
 #!/usr/bin/env python3
-"""Benchmark of the motif-scoring hot path (BASELINE.json metric: motif-sites scored / second on the
-1 Gbp synthetic metagenome).
+"""Benchmark of the motif-scoring hot path (BASELINE.json metric: motif-sites scored / second on the 1 Gbp synthetic
+metagenome at 1 / 2 / 4 / 8 MI355X).
 
-A *step* = one pass of the hot path over one batch: the cfg 5 candidate table (10 000 seeded IUPAC motifs,
-20 per bin, half 6mA half 5mC) scored against every contig of its bin on both strands through
-``nm_score_batch_device`` — compile the candidates on the host, ship the programs, one scoring launch, count
-table in HBM — and, with more than one GPU, one RCCL all-reduce (sum, int64) of the count table.
-A *motif-site* = one (candidate x reference bp x strand) match test: a candidate on a bin of L bp is 2·L sites.
+A *step* = one pass of the hot path over one batch: the cfg 5 candidate table (10 000 seeded IUPAC motifs, 20 per bin,
+half 6mA half 5mC) scored against every contig of its bin on both strands through ``nm_score_batch_device`` — validate
+and sort the candidate records on the host, ship them through the pinned staging ring, compile them to constraint
+programs on the device, one scoring launch, count table in HBM — and, with more than one GPU, ONE RCCL all-reduce
+(sum, int64) of the count table.  A *motif-site* = one (candidate x reference bp x strand) match test: a candidate on a
+bin of L bp is 2·L sites.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--total-bp B] [--workload cfg5|greedy] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Multi-GPU: launched by torch.distributed.run, one rank per GPU.  Bins are independent searches, so the default
-("weak" scaling) gives every GPU whole bins — its own cfg 5 metagenome of --total-bp (rank r is seeded 1 + r) and
-that metagenome's candidate table — with no collective on the data path, the way ``python -m nanomotif_amd`` shards
-a metagenome whose bins balance (nanomotif_amd/shard.py: assign_bins); value = motif-sites of all ranks / the
-slowest rank's time.  ``--scaling strong`` keeps ONE --total-bp metagenome, shards the contigs of every bin over the
-ranks (longest-first) and sums the count tables with one RCCL all-reduce per step — the path for few / huge bins.
-Inputs are generated on the device (nanomotif_amd/synth_device.py) and are resident in HBM before the timed
-region.  Rank 0 prints ONE JSON line.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torch.distributed.run child,
+before this process touches the GPU); under torchrun it is one of the ranks.  Multi-GPU is STRONG scaling on the
+BASELINE configuration (cfg 4/5): ONE --total-bp metagenome, its contigs sharded over the ranks
+(nanomotif_amd/shard.py: longest-first, bins kept whole while they are small against a GPU's share), every rank scores
+the candidates of the bins it holds and the int64[n_candidates, 2] count tables are summed with one all-reduce per step
+(find_motifs_bin.py:1273-1283: counts are sums over contigs).  value = motif-sites of the whole job / slowest rank.
+``--scaling weak`` (every rank its own metagenome, no collective) is kept as an explicit extra mode and is reported by
+the default run only as the ``weak_scaling`` key, never as ``value``.
+
+Inputs are generated on the device (nanomotif_amd/synth_device.py, bit-identical to the numpy generator) and are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.  Extra keys of the default run:
+``roofline_hbm_bound_round`` (one greedy lock-step round, the HBM-bound regime), ``e2e`` (the whole motif_discovery
+pipeline on the same metagenome, generation excluded), ``cfg5_all`` (every candidate against every bin),
+``cpu_baseline`` (the oracle on all host cores and on one), ``per_rank`` (kernel / host / all-reduce times).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,7 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+HBM_STREAM_GBS = 6350.0        # what a plain streaming-read kernel reaches on this device (tools/hbm_peak.hip, profiles/r1/hbm_peak.txt)
 VALU_PEAK_WAVE_INSTR_S = 6.1e11   # measured integer-VALU issue peak (tools/valu_peak.hip, profiles/r1/valu_peak.txt)
 ALGO_BYTES_PER_BP_STEP = 0.5   # 2-bit sequence + 2-bit methylation state per bp per mod-type step
 
@@ -71,75 +80,158 @@ def build_candidates(mg, workload, n_cand, per_group):
     return out
 
 
-def cpu_baseline_worker(args):
-    """Score one bin's candidates with the CPU oracle (regex + numpy, the reference's own primitives)."""
-    spec_kw, bin_name, cands = args
-    from nanomotif_amd import synth
-    from oracle.scan import ContigPileup, score_candidates
-    mg = synth.make_metagenome(synth.SynthSpec(**spec_kw))
-    t_gen = time.perf_counter()
-    idx = [i for i, b in enumerate(mg.bin_names) if b == bin_name]
-    seqs = {mg.names[i]: mg.contig_str(i) for i in idx}
-    piles = {}
-    for mt in sorted({c[2] for c in cands}):
-        piles[mt] = {}
-        for i in idx:
-            p = mg.contig_pileup(i, mt)
-            keep = p["nvalid"] > 5
-            piles[mt][mg.names[i]] = ContigPileup(p["position"][keep], p["strand"][keep],
-                                                  synth.pct_to_fraction(p["pct_hundredths"][keep]))
+def self_launch(args) -> int:
+    """--gpus N without a launcher: become the launcher.  The child is torch.distributed.run with this script, started
+    BEFORE anything in this process touches the GPU; stdout (the JSON line of rank 0) is passed through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"starting {args.gpus} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Collective:
+    """Sum of the int64 count tables over the ranks.  ``native``: nm_allreduce_counts of the C ABI (RCCL through the
+    library's own communicator, on its communication stream); ``torch``: torch.distributed (RCCL with backend nccl,
+    host round trip with gloo — the debugging backend that lets several ranks share one GPU)."""
+
+    def __init__(self, kind, eng, world, rank, device, backend):
+        import torch.distributed as dist
+        self.kind, self.eng, self.dist, self.backend, self.world = kind, eng, dist, backend, world
+        self.pending = {}
+        if kind == "native":
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init(rank, world, uid[0])
+
+    def start(self, slot, tensor):
+        if self.kind == "native":
+            self.eng.allreduce_counts_device(tensor.data_ptr(), tensor.numel(), slot)
+        elif self.backend == "nccl":
+            self.pending[slot] = self.dist.all_reduce(tensor, async_op=True)
+        else:
+            host = tensor.cpu()
+            self.dist.all_reduce(host)
+            tensor.copy_(host)
+
+    def wait(self, slot):
+        """Order the engine stream (and torch's current stream) after the all-reduce started on ``slot``."""
+        if self.kind == "native":
+            self.eng.comm_wait(slot)
+        elif slot in self.pending:
+            self.pending.pop(slot).wait()
+
+    def drain(self):
+        if self.kind == "native":
+            self.eng.comm_sync()
+        for slot in list(self.pending):
+            self.pending.pop(slot).wait()
+
+
+def cpu_baseline(result, final, cands, mg, spec_kw, args):
+    """Rank 0, N = 1: the oracle on a bounded sample of the same workload, on ALL host cores (T = os.cpu_count(),
+    wall-clock of the concurrent scan phase, pool overhead included) and on ONE core, with the
+    sampled bins' counts compared bit for bit with the GPU table."""
+    from oracle import pipeline as opl
+    ncores = os.cpu_count() or 1
+    procs = args.cpu_procs if args.cpu_procs > 0 else ncores
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+        procs = max(1, min(procs, int(avail * 0.5 / (250 << 20))))      # ~250 MB per worker holding two 2 Mbp bins (measured 130 MB with one)
+    except Exception:
+        pass
+    bins = sorted(set(mg.bin_names))
+    nb = args.cpu_bins if args.cpu_bins > 0 else min(len(bins), 2 * procs)
+    sample = [bins[(k * 37) % len(bins)] for k in range(nb)]
+    sample = list(dict.fromkeys(sample))
+    by_bin = {}
+    for k, c in enumerate(cands):
+        by_bin.setdefault(c[2], []).append(k)
+    jobs = [(spec_kw, b, [(cands[k][0].string, cands[k][0].mod_position, cands[k][1]) for k in by_bin.get(b, [])]) for b in sample]
+    jobs = [j for j in jobs if j[2]]
+    procs = min(procs, len(jobs))
     t0 = time.perf_counter()
-    out = {}
-    for mt in piles:
-        these = [(k, s, p) for k, (s, p, m) in enumerate(cands) if m == mt]
-        res = score_candidates(piles[mt], seqs, [(s, p) for _, s, p in these])
-        for (k, _, _), r in zip(these, res):
-            out[k] = r.tolist()
-    t1 = time.perf_counter()
-    bp = int(sum(int(mg.lengths[i]) for i in idx))
-    return bin_name, [out[k] for k in range(len(cands))], t1 - t0, t0 - t_gen, bp
+    res, wall, cpu_seconds = opl.timed_pool(jobs, procs)
+    total_wall = time.perf_counter() - t0
+    cpu_sites, mismatches, checked = 0, 0, 0
+    for (b, table, bp), job in zip(res, jobs):
+        idx = by_bin[b]
+        cpu_sites += 2 * bp * len(idx)
+        checked += len(idx)
+        for k, row in zip(idx, table):
+            if final[k].tolist() != row:
+                mismatches += 1
+    # one core: the first jobs until ~10 s of scanning
+    t1_sites, t1_secs = 0, 0.0
+    for job in jobs[:max(1, args.cpu_t1_bins)]:
+        _, _, secs, _, bp = opl.score_worker(job)
+        t1_sites += 2 * bp * len(job[2])
+        t1_secs += secs
+    result["cpu_baseline"] = {
+        "value": cpu_sites / wall, "unit": "motif-sites/s", "cores": procs, "kind": "port",
+        "value_t1": t1_sites / t1_secs, "per_core_in_pool": cpu_sites / cpu_seconds,
+        "sample": f"{len(jobs)} of {len(bins)} bins x their {len(jobs[0][2])} candidates ({cpu_sites:.3g} motif-sites): oracle/scan.py "
+                  f"(regex overlapped finditer + numpy.isin per contig and strand) on {procs} concurrent spawn processes, one bin per task, "
+                  f"wall-clock {wall:.2f} s of the scan phase (inputs built before a barrier; {total_wall:.1f} s with process start and "
+                  f"input generation), {cpu_seconds:.1f} CPU-seconds; -t 1: {min(len(jobs), max(1, args.cpu_t1_bins))} bins in {t1_secs:.1f} s",
+        "host_cores_available": ncores,
+    }
+    result["parity"] = {"candidates_checked": checked, "mismatches": mismatches,
+                        "against": "oracle/scan.py on the sampled bins (bit-exact integer counts)"}
+    result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    if mismatches:
+        log(f"PARITY FAILURE: {mismatches} candidates differ from the oracle")
 
 
-def run_e2e(args, mg, device, local_rank, world, rank):
-    """--workload e2e: the whole motif_discovery pipeline on the synthetic metagenome: raw pileup rows -> device-side
-    filters -> windows -> lock-step greedy search with pruning -> post-processing.  One step = one full run.  N > 1:
-    whole bins per GPU (weak scaling) — every rank runs the pipeline on its own metagenome (seed 1 + rank), no
-    collective; wall = slowest rank."""
+def time_launches(eng, batch, out_ptr, n, device):
+    """Mean scoring-kernel duration (HIP events on the launch stream, nm_timing_*) over ``n`` launches of ``batch``."""
     import torch
-    import torch.distributed as dist
+    for _ in range(2):
+        eng.score_into_device(batch, out_ptr)
+    torch.cuda.synchronize(device)
+    eng.timing_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.score_into_device(batch, out_ptr)
+    torch.cuda.synchronize(device)
+    wall = (time.perf_counter() - t0) / n
+    ms, k = eng.timing_total()
+    eng.timing_reset(False)
+    return ms / max(k, 1), wall * 1e3
+
+
+def load_traffic(workload, total_bp, n_cand):
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tj):
+        return None
+    t = json.load(open(tj))
+    entries = t if isinstance(t, list) else t.get("entries", [t])
+    for e in entries:
+        if (e.get("workload"), e.get("total_bp"), e.get("candidates"), e.get("n_gpus", 1)) == (workload, total_bp, n_cand, 1):
+            return e
+    return None
+
+
+def run_e2e(mg, eng_device, device, my_bins=None):
+    """The whole motif_discovery pipeline on (the bins ``my_bins`` of) the metagenome: raw pileup rows -> device-side
+    filters -> windows -> lock-step greedy search with pruning -> post-processing.  Returns (rows, timings)."""
+    import torch
     from nanomotif_amd import e2e_synth
     from nanomotif_amd.engine import ScanEngine
-    if world > 1 and args.scaling != "weak":
-        raise SystemExit("--workload e2e at N > 1 is the whole-bin (weak) mode; contig sharding of the CLI is covered by tests/test_gpu_cli.py")
-    eng = ScanEngine(local_rank)
-    if world > 1:
-        dist.barrier()
+    eng = ScanEngine(eng_device)
     t0 = time.perf_counter()
-    rows, t = e2e_synth.run(mg, eng, device)
+    rows, t = e2e_synth.run(mg, eng, device, bins=my_bins)
     torch.cuda.synchronize(device)
-    wall = time.perf_counter() - t0
+    t["wall_with_generation_s"] = time.perf_counter() - t0
     eng.close()
-    rows = [r for r in rows if r.n_mod + r.n_nomod >= 50]
-    planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() for m in ms}
-    found = {(r.reference, r.motif_iupac) for r in rows}
-    stats = [wall, len(rows), len(planted), len(planted & found)]
-    if world > 1:
-        tt = torch.tensor(stats, dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
-        mx = tt.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt)
-        stats = [float(mx[0]), int(tt[1]), int(tt[2]), int(tt[3])]
-        dist.barrier()
-    if rank == 0:
-        print(json.dumps({
-            "metric": "end-to-end motif_discovery wall seconds (synthetic metagenome)", "value": stats[0], "unit": "s", "n_gpus": world,
-            "steps": 1, "warmup": 0, "ms_per_step": stats[0] * 1e3, "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
-            "config": {"workload": f"e2e: motif_discovery on {world} x {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC per GPU)"},
-            "pipeline_s_rank0": t["upload_filter_s"] + t["search_s"],     # device filters + search, without the synthetic data generation
-            "timings_rank0": t, "motifs_reported": stats[1], "planted_motifs": stats[2], "planted_recovered": stats[3]}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return [r for r in rows if r.n_mod + r.n_nomod >= 50], t
 
 
 def main():
@@ -151,29 +243,38 @@ def main():
     ap.add_argument("--contigs", type=int, default=10_000)
     ap.add_argument("--bins", type=int, default=500)
     ap.add_argument("--candidates", type=int, default=10_000)
-    ap.add_argument("--workload", choices=["cfg5", "greedy", "e2e"], default="cfg5")
+    ap.add_argument("--workload", choices=["cfg5", "greedy", "cfg5_all", "e2e"], default="cfg5")
     ap.add_argument("--per-group", type=int, default=2, help="greedy workload: children per (bin, mod type)")
-    ap.add_argument("--cpu-bins", type=int, default=-1, help="bins in the CPU-baseline sample (-1: two per worker; 0: skip)")
+    ap.add_argument("--cpu-bins", type=int, default=-1, help="bins in the CPU-baseline sample (-1: two per worker, at most all; 0: skip)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: os.cpu_count())")
+    ap.add_argument("--cpu-t1-bins", type=int, default=3, help="bins scored by the single-core (-t 1) CPU leg")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (debug: several ranks on one GPU)")
+    ap.add_argument("--allreduce", choices=["auto", "native", "torch"], default="auto",
+                    help="count-table all-reduce: nm_allreduce_counts of the C ABI (RCCL) or torch.distributed; auto = native with nccl")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: min(32, host cores))")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = whole bins per GPU, one --total-bp metagenome each, no collective (default); "
-                         "strong = one metagenome, contigs sharded, count tables all-reduced every step")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak (auto: all that apply; none)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = ONE metagenome, contigs sharded, count tables all-reduced every step (default, the BASELINE "
+                         "configuration); weak = every rank its own --total-bp metagenome, no collective")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                      # nothing above has touched the GPU
 
     import torch
     import torch.distributed as dist
     from nanomotif_amd import synth, synth_device
     from nanomotif_amd.engine import ScanEngine
-    from nanomotif_amd.shard import assign_contigs
+    from nanomotif_amd.shard import assign_bins, assign_contigs
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        log(f"note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if args.force_device >= 0:
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
@@ -183,25 +284,71 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.dist_backend)
+        log(f"{world} ranks, backend {dist.get_backend()}")
+    red_dev = device if args.dist_backend == "nccl" else "cpu"
+
+    def allmax(vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.tolist()
+
+    def gather(vals):
+        if world == 1:
+            return [[float(v) for v in vals]]
+        t = torch.tensor(vals, dtype=torch.float64, device=red_dev)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.tolist() for o in out]
 
     weak = args.scaling == "weak"
     reduce_counts = world > 1 and not weak
     seed = 1 + rank if weak else 1
-    spec = synth.SynthSpec(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
     spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
-    mg = synth.make_metagenome(spec)
-    if weak:
+    mg = synth.make_metagenome(synth.SynthSpec(**spec_kw))
+    if weak or world == 1:
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
+    extras = {"e2e", "cfg5_all", "weak"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
+    if args.workload != "cfg5" or weak:
+        extras = set()
+    if world == 1:
+        extras.discard("weak")
+    else:
+        extras.discard("cfg5_all")
 
     if args.workload == "e2e":
-        return run_e2e(args, mg, device, local_rank, world, rank)
+        sizes = {}
+        for i, b in enumerate(mg.bin_names):
+            sizes[b] = sizes.get(b, 0) + int(mg.lengths[i])
+        my_bins = None if world == 1 else assign_bins(sizes, world, tolerance=float("inf"))[rank]
+        if world > 1:
+            dist.barrier()
+        rows, t = run_e2e(mg, local_rank, device, my_bins)
+        pipeline = t["upload_filter_s"] + t["search_s"]
+        planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() if my_bins is None or b in set(my_bins) for m in ms}
+        found = {(r.reference, r.motif_iupac) for r in rows}
+        per = gather([pipeline, t["search_s"], t["upload_filter_s"], len(rows), len(planted), len(planted & found), t["rounds"], t["candidates"]])
+        if rank == 0:
+            wall = max(p[0] for p in per)
+            print(json.dumps({
+                "metric": "end-to-end motif_discovery seconds (1 Gbp synthetic metagenome, device filters + search + post-processing)",
+                "value": wall, "unit": "s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": wall * 1e3, "higher_is_better": False,
+                "scaling": "strong", "vs_baseline": None, "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
+                "config": {"workload": f"e2e: motif_discovery on {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC), "
+                                       f"whole bins per GPU over {world} GPU(s), no collective until the rows are gathered"},
+                "per_rank": [dict(zip(["pipeline_s", "search_s", "upload_filter_s", "motif_rows", "planted", "planted_recovered", "rounds", "candidates"], p)) for p in per],
+                "timings_rank0": t}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
     rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if (world == 1 or weak) else mine, progress=log)
-    # one explicit side stream carries the engine's launches AND the collectives (the legacy default stream has the
+    # one explicit side stream carries the engine's launches AND torch's collectives (the legacy default stream has the
     # handle 0, which nm_set_stream reads as "use the ctx's own stream": never hand it that)
     side = torch.cuda.Stream(device)
     assert side.cuda_stream != 0
@@ -210,45 +357,62 @@ def main():
     st = eng.stats()
     log(f"resident: {st['total_bp']:,} bp ({st['padded_bp']:,} padded), rows {rows}, setup {time.perf_counter() - t0:.1f}s")
 
-    cands = build_candidates(mg, args.workload, args.candidates, args.per_group)
-    bin_bp = {}
+    all_bins = sorted(set(mg.bin_names))
+    bin_bp, my_bin_bp = {}, {}
     for i, b in enumerate(mg.bin_names):
         bin_bp[b] = bin_bp.get(b, 0) + int(mg.lengths[i])
-    sites_per_step = sum(2 * bin_bp[b] for _, _, b in cands)
-    groups = {(b, mt) for _, mt, b in cands}
-    algo_bytes_total = ALGO_BYTES_PER_BP_STEP * sum(bin_bp[b] for b, _ in groups) + 16 * len(cands)
-    my_bin_bp = {}
     for i in mine:
         my_bin_bp[mg.bin_names[i]] = my_bin_bp.get(mg.bin_names[i], 0) + int(mg.lengths[i])
-    algo_bytes_rank = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in groups) + 16 * len(cands)
 
-    # two count tables: the all-reduce of step k (RCCL stream) overlaps the scoring launch of step k+1
-    counts = [torch.zeros((len(cands), 2), dtype=torch.int64, device=device) for _ in range(2)]
-    pending = [None, None]
-    batch = eng.make_batch(cands)      # the step's input: the candidate table in the C-ABI's flat SoA form
+    base = build_candidates(mg, "cfg5" if args.workload == "cfg5_all" else args.workload, args.candidates, args.per_group)
+
+    def expand_all_bins(batch):
+        """cfg5_all: every candidate of the table against EVERY bin — the flat SoA arrays are tiled, the mask bytes shared."""
+        from nanomotif_amd.engine import CandidateBatch
+        nb = len(all_bins)
+        return CandidateBatch(np.repeat(np.arange(nb, dtype=np.uint32), len(batch)), np.tile(batch.slots, nb), np.tile(batch.lens, nb),
+                              np.tile(batch.modpos, nb), np.tile(batch.offsets, nb), batch.masks)
+
+    if args.workload == "cfg5_all":
+        batch = expand_all_bins(eng.make_batch(base))
+        n_cand = len(batch)
+        sites_per_step = 2 * args.total_bp * len(base)
+        groups = {(b, mt) for b in all_bins for mt in mg.spec.mod_types}
+        cands = None
+    else:
+        cands = base
+        batch = eng.make_batch(cands)      # the step's input: the candidate table in the C-ABI's flat SoA form
+        n_cand = len(cands)
+        sites_per_step = sum(2 * bin_bp[b] for _, _, b in cands)
+        groups = {(b, mt) for _, mt, b in cands}
+    algo_bytes_rank = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in groups) + 16 * n_cand
+
+    use_native = reduce_counts and (args.allreduce == "native" or (args.allreduce == "auto" and args.dist_backend == "nccl"
+                                                                  and hasattr(eng, "comm_init")))
+    coll = Collective("native" if use_native else "torch", eng, world, rank, device, args.dist_backend) if reduce_counts else None
+
+    # two count tables: the all-reduce of step k (communication stream) overlaps the scoring launch of step k+1
+    counts = [torch.zeros((n_cand, 2), dtype=torch.int64, device=device) for _ in range(2)]
     step_no = [0]
+    host_s = [0.0]
 
     def step():
-        # inside the C ABI, every call: drop candidates of bins this rank does not hold, sort by (mod type, bin),
-        # compile every motif to its constraint program, ship programs + tables (pinned staging ring, copy stream),
-        # zero the counters, one scoring launch (async)
+        # inside the C ABI, every call: drop candidates of bins this rank does not hold, sort by (mod type, bin), ship the
+        # records (pinned staging ring, copy stream), compile every motif to its constraint program on the device, zero the
+        # counters, one scoring launch (async); then the all-reduce of this table is started on the communication stream
+        t_in = time.perf_counter()
         i = step_no[0] & 1
         step_no[0] += 1
-        if pending[i] is not None:
-            pending[i].wait()                               # table i is free again (its all-reduce finished)
+        if coll:
+            coll.wait(i)                                    # table i is free again (its all-reduce of step k-2 finished)
         eng.score_into_device(batch, counts[i].data_ptr())
-        if reduce_counts and args.dist_backend == "nccl":
-            pending[i] = dist.all_reduce(counts[i], async_op=True)   # RCCL sum over xGMI
-        elif reduce_counts:                                          # debug path: reduce through the host
-            host = counts[i].cpu()
-            dist.all_reduce(host)
-            counts[i].copy_(host)
+        if coll:
+            coll.start(i, counts[i])
+        host_s[0] += time.perf_counter() - t_in
 
     def drain():
-        for i in (0, 1):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+        if coll:
+            coll.drain()
 
     for _ in range(args.warmup):
         step()
@@ -258,6 +422,7 @@ def main():
         dist.barrier()
     eng.timing_reset(True)
     torch.cuda.synchronize(device)
+    host_s[0] = 0.0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -265,17 +430,28 @@ def main():
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t_start
+    elapsed_local = time.perf_counter() - t_start
     kernel_ms_total, n_launch = eng.timing_total()
     eng.timing_reset(False)
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms_total / max(n_launch, 1)], dtype=torch.float64,
-                         device=device if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
-    else:
-        kernel_ms = kernel_ms_total / max(n_launch, 1)
+    kernel_ms_local = kernel_ms_total / max(n_launch, 1)
+    elapsed, kernel_ms = allmax([elapsed_local, kernel_ms_local])
     final = counts[(step_no[0] - 1) & 1].cpu().numpy()
+
+    # the collective alone: K all-reduces of the table back to back, slowest rank
+    allreduce_ms = None
+    if coll:
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            coll.wait(k & 1)
+            coll.start(k & 1, counts[k & 1])
+        coll.drain()
+        torch.cuda.synchronize(device)
+        allreduce_ms = allmax([(time.perf_counter() - t0) / args.steps * 1e3])[0]
+        # put the tables back: `final` was read above, the all-reduced copies are multiples now
+    per_rank = gather([elapsed_local / args.steps * 1e3, kernel_ms_local, host_s[0] / args.steps * 1e3, float(len(mine)),
+                       float(sum(my_bin_bp.values())), algo_bytes_rank])
 
     # ---- the same engine in its HBM-bound regime: one lock-step greedy round (2 sibling children per (bin, mod type),
     # the shape MotifSearcher.run submits), kernel time from HIP events; reported next to the main roofline
@@ -284,122 +460,151 @@ def main():
         g_cands = build_candidates(mg, "greedy", 0, 2)
         g_batch = eng.make_batch(g_cands)
         g_counts = torch.zeros((len(g_cands), 2), dtype=torch.int64, device=device)
-        for _ in range(3):
-            eng.score_into_device(g_batch, g_counts.data_ptr())
-        torch.cuda.synchronize(device)
-        eng.timing_reset(True)
-        for _ in range(args.hbm_round_steps):
-            eng.score_into_device(g_batch, g_counts.data_ptr())
-        torch.cuda.synchronize(device)
-        g_ms, g_n = eng.timing_total()
-        eng.timing_reset(False)
-        g_ms /= max(g_n, 1)
+        g_ms, _ = time_launches(eng, g_batch, g_counts.data_ptr(), args.hbm_round_steps, device)
         g_groups = {(b, mt) for _, mt, b in g_cands}
         g_bytes = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in g_groups) + 16 * len(g_cands)
-        if world > 1:
-            tt = torch.tensor([g_ms], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            g_ms = float(tt[0])
+        g_ms = allmax([g_ms])[0]
+        tr = load_traffic("greedy", args.total_bp, len(g_cands)) if world == 1 else None
         hbm_round = {"workload": f"greedy round: {len(g_cands)} candidates = 2 sibling children per (bin, mod type)",
                      "bound": "hbm", "kernel_ms": g_ms, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_launch": g_bytes, "launches": g_n,
-                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) * (world if weak else 1) / (g_ms * 1e-3)}
+                     "algorithmic_bytes_per_launch": g_bytes, "launches": args.hbm_round_steps,
+                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                     # the fused two-slot launch reads the sequence planes once for both mod types: real DRAM bytes are
+                     # below the algorithmic 0.5 B/bp/slot; this is the fraction of the device's streaming rate they reach
+                     "traffic_rate_GBs": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 if tr else None,
+                     "traffic_frac_of_spec": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
+                     "traffic_frac_of_streaming": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_STREAM_GBS if tr else None,
+                     "streaming_peak_GBs": HBM_STREAM_GBS,
+                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3)}
 
     result = None
-    traffic, traffic_src, valu_insts = None, None, None
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tj):
-        t = json.load(open(tj))
-        # measured per launch on one GPU; every rank of a weak-scaling run launches that same configuration
-        if (t.get("workload"), t.get("total_bp"), t.get("candidates")) == (args.workload, args.total_bp, len(cands)) \
-                and (t.get("n_gpus") == world or (weak and t.get("n_gpus") == 1)):
-            traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
-            valu_insts = t.get("sq_insts_valu_per_launch")
+    tr = load_traffic(args.workload, args.total_bp, n_cand) if world == 1 else None
     if rank == 0:
-        value = sites_per_step * (world if weak else 1) * args.steps / elapsed
+        nw = world if weak else 1
+        value = sites_per_step * nw * args.steps / elapsed
         achieved = algo_bytes_rank / (kernel_ms * 1e-3) / 1e9
+        if weak:
+            workload = (f"{args.workload} (weak scaling): {world} x ({n_cand} candidate motifs x {args.total_bp:,} bp metagenome, {args.contigs} contigs, "
+                        f"{args.bins} bins, 6mA+5mC), both strands, no collective")
+        else:
+            per_bin = "every candidate x every bin" if args.workload == "cfg5_all" else f"{n_cand // max(len(all_bins), 1)} per bin"
+            workload = (f"{args.workload}: {len(base)} candidate motifs ({per_bin}) x {args.total_bp:,} bp total metagenome ({args.contigs} contigs, "
+                        f"{args.bins} bins, 6mA+5mC), both strands" + (f", contig-sharded over {world} GPUs, one all-reduce of the int64[{n_cand},2] count table per step" if world > 1 else ""))
         result = {
             "metric": "motif-sites scored/sec (1 Gbp synthetic metagenome)", "value": value, "unit": "motif-sites/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 bit-planes / int64 counts",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {len(cands) * (world if weak else 1)} candidate motifs x {args.total_bp * (world if weak else 1):,} bp metagenome "
-                                   f"({args.contigs} contigs, {args.bins} bins, 6mA+5mC), both strands",
-                       "candidates": len(cands) * (world if weak else 1), "total_bp": args.total_bp * (world if weak else 1),
-                       "contigs": args.contigs * (world if weak else 1), "bins": args.bins * (world if weak else 1),
-                       "per_gpu": {"total_bp": args.total_bp, "candidates": len(cands)} if weak else None,
-                       "mod_types": ["a", "m"],
-                       "sharding": (f"whole bins per GPU: {world} x ({args.bins} bins, {args.total_bp:,} bp, {len(cands)} candidates), no collective"
-                                    if weak else f"contigs over {world} GPU(s), longest-first, bins kept whole when small; count tables all-reduced"),
-                       "motif_sites_per_step": sites_per_step * (world if weak else 1)},
+            "config": {"workload": workload, "candidates": n_cand * nw, "total_bp": args.total_bp * nw,
+                       "contigs": args.contigs * nw, "bins": args.bins * nw, "mod_types": ["a", "m"],
+                       "sharding": ("whole metagenome per GPU, no collective" if weak or world == 1 else
+                                    f"contigs over {world} GPUs, longest-first, bins kept whole when small (nanomotif_amd/shard.py); "
+                                    f"count tables summed by {'nm_allreduce_counts (RCCL, C ABI)' if use_native else 'torch.distributed ' + args.dist_backend}"),
+                       "motif_sites_per_step": sites_per_step * nw},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src or "not collected for this configuration (rocprofv3 --pmc runs: profiles/)",
-                         "kernel": "score_kernel<1,1,compact>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         "traffic_source": tr["source"] if tr else "not collected for this configuration (rocprofv3 --pmc runs: profiles/)",
+                         "kernel": "score_kernel (narrow, compact)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
+            "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
+            "allreduce_ms": allreduce_ms,
             "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
                                 int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],
         }
         if hbm_round:
             result["roofline_hbm_bound_round"] = hbm_round
-        if valu_insts:
+        if tr and tr.get("sq_insts_valu_per_launch"):
             # second roofline: the kernel is integer-VALU-issue bound once a (bin, mod type) carries more than ~2
             # candidates; instruction count from rocprofv3 (SQ_INSTS_VALU, profiles/), peak from tools/valu_peak.hip
-            rate = valu_insts / (kernel_ms * 1e-3)
+            rate = tr["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
             result["roofline_valu"] = {"bound": "valu-int", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_S,
                                        "unit": "wave64 integer instr/s", "frac": rate / VALU_PEAK_WAVE_INSTR_S,
-                                       "sq_insts_valu_per_launch": valu_insts,
+                                       "sq_insts_valu_per_launch": tr["sq_insts_valu_per_launch"],
                                        "peak_source": "profiles/r1/valu_peak.txt (alignbit+and stream, 4 cycles per wave64 op per SIMD)"}
 
+    # ---- extra: every candidate x every bin (SURVEY §8(d) cfg 5 as 2e13 motif-sites per step), N = 1
+    if "cfg5_all" in extras:
+        a_batch = expand_all_bins(batch)
+        a_counts = torch.zeros((len(a_batch), 2), dtype=torch.int64, device=device)
+        a_ms, a_wall_ms = time_launches(eng, a_batch, a_counts.data_ptr(), 3, device)
+        a_sites = 2 * args.total_bp * len(base)
+        a_bytes = ALGO_BYTES_PER_BP_STEP * args.total_bp * len(mg.spec.mod_types) + 16 * len(a_batch)
+        # every bin must give each candidate the same counts it got in the 20-per-bin table where they coincide
+        a_host = a_counts.cpu().numpy().reshape(len(all_bins), len(base), 2)
+        own = np.array([all_bins.index(c[2]) for c in base])
+        same = bool(np.array_equal(a_host[own, np.arange(len(base))], final))
+        tr_a = load_traffic("cfg5_all", args.total_bp, len(a_batch))
+        result["cfg5_all"] = {"workload": f"{len(base)} candidates x all {len(all_bins)} bins = {len(a_batch)} (candidate, bin) pairs, {a_sites:.3g} motif-sites per step",
+                              "value": a_sites / (a_wall_ms * 1e-3), "unit": "motif-sites/s", "ms_per_step": a_wall_ms, "kernel_ms": a_ms,
+                              "roofline_hbm_frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "roofline_valu_frac": (tr_a["sq_insts_valu_per_launch"] / (a_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_S) if tr_a and tr_a.get("sq_insts_valu_per_launch") else None,
+                              "agrees_with_per_bin_table": same}
+        del a_counts, a_batch
+        torch.cuda.empty_cache()
+
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload, and parity
-    if rank == 0 and world == 1 and args.cpu_bins != 0:
-        import multiprocessing as mp
-        ncores = os.cpu_count() or 1
-        procs = args.cpu_procs if args.cpu_procs > 0 else min(32, ncores)
-        nb = args.cpu_bins if args.cpu_bins > 0 else 2 * procs
-        bins = sorted(set(mg.bin_names))
-        sample = [bins[(k * 37) % len(bins)] for k in range(nb)]
-        jobs = []
-        for b in sample:
-            idx = [k for k, c in enumerate(cands) if c[2] == b]
-            jobs.append((spec_kw, b, [(cands[k][0].string, cands[k][0].mod_position, cands[k][1]) for k in idx]))
-        procs = min(nb, procs)
+    if rank == 0 and world == 1 and args.cpu_bins != 0 and cands is not None:
+        cpu_baseline(result, final, cands, mg, spec_kw, args)
+
+    eng.close()
+    del counts
+    torch.cuda.empty_cache()
+
+    # ---- extra: end to end on the same metagenome (generation excluded): whole bins per GPU, no collective
+    if "e2e" in extras:
+        sizes = dict(bin_bp)
+        my_bins = None if world == 1 else assign_bins(sizes, world, tolerance=float("inf"))[rank]
+        if world > 1:
+            dist.barrier()
+        e_rows, t = run_e2e(mg, local_rank, device, my_bins)
+        planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() if my_bins is None or b in set(my_bins) for m in ms}
+        found = {(r.reference, r.motif_iupac) for r in e_rows}
+        per = gather([t["upload_filter_s"] + t["search_s"], t["search_s"], t["upload_filter_s"], t.get("gpu_busy_s", 0.0), t["rounds"], t["candidates"],
+                      len(e_rows), len(planted), len(planted & found)])
+        if rank == 0:
+            result["e2e"] = {"what": "motif_discovery on the same metagenome: 1e9 raw pileup rows -> device filters -> windows -> lock-step greedy "
+                                     "search + pruning -> post-processing; synthetic-data generation excluded; N > 1: whole bins per GPU",
+                             "wall_s": max(p[0] for p in per), "search_s": max(p[1] for p in per), "upload_filter_s": max(p[2] for p in per),
+                             "gpu_busy_s": max(p[3] for p in per), "rounds": int(max(p[4] for p in per)), "candidates": int(sum(p[5] for p in per)),
+                             "motif_rows": int(sum(p[6] for p in per)), "planted": int(sum(p[7] for p in per)),
+                             "planted_recovered": int(sum(p[8] for p in per)), "timings_rank0": t}
+
+    # ---- extra (N > 1): weak scaling — every rank its own metagenome (seed 1 + rank) and candidate table, no collective
+    if "weak" in extras:
+        mg_w = synth.make_metagenome(synth.SynthSpec(**dict(spec_kw, seed=1 + rank)))
+        eng_w = ScanEngine(local_rank)
+        synth_device.load_engine_from_device(eng_w, mg_w, device)
+        eng_w.use_stream(side.cuda_stream)
+        c_w = build_candidates(mg_w, "cfg5", args.candidates, 2)
+        b_w = eng_w.make_batch(c_w)
+        o_w = torch.zeros((len(c_w), 2), dtype=torch.int64, device=device)
+        bb = {}
+        for i, b in enumerate(mg_w.bin_names):
+            bb[b] = bb.get(b, 0) + int(mg_w.lengths[i])
+        s_w = sum(2 * bb[b] for _, _, b in c_w)
+        for _ in range(args.warmup):
+            eng_w.score_into_device(b_w, o_w.data_ptr())
+        torch.cuda.synchronize(device)
+        dist.barrier()
         t0 = time.perf_counter()
-        with mp.get_context("spawn").Pool(procs) as pool:
-            res = pool.map(cpu_baseline_worker, jobs, chunksize=1)
-        wall = time.perf_counter() - t0
-        cpu_sites = 0
-        cpu_seconds = 0.0
-        mismatches = 0
-        for (b, table, secs, gen_secs, bp), job in zip(res, jobs):
-            idx = [k for k, c in enumerate(cands) if c[2] == b]
-            cpu_sites += 2 * bp * len(idx)
-            cpu_seconds += secs
-            for k, row in zip(idx, table):
-                if final[k].tolist() != row:
-                    mismatches += 1
-        result["cpu_baseline"] = {
-            # aggregate rate of `procs` concurrent workers = sites / (summed scan seconds / procs)
-            "value": cpu_sites / (cpu_seconds / procs), "unit": "motif-sites/s", "cores": procs, "kind": "port",
-            "per_core": cpu_sites / cpu_seconds,
-            "sample": f"{nb} of {len(bins)} bins x their {len(jobs[0][2])} candidates ({cpu_sites:.3g} motif-sites), "
-                      f"oracle/scan.py (regex overlapped finditer + numpy.isin) in a spawn Pool({procs}), one bin per task; "
-                      f"{cpu_seconds:.1f} CPU-seconds of scanning, wall incl. host data generation {wall:.1f}s",
-            "host_cores_available": ncores,
-        }
-        result["parity"] = {"candidates_checked": int(sum(len(j[2]) for j in jobs)), "mismatches": mismatches,
-                            "against": "oracle/scan.py on the sampled bins (bit-exact integer counts)"}
-        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-        if mismatches:
-            log(f"PARITY FAILURE: {mismatches} candidates differ from the oracle")
+        for _ in range(args.steps):
+            eng_w.score_into_device(b_w, o_w.data_ptr())
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        el = allmax([time.perf_counter() - t0])[0]
+        tot = gather([float(s_w)])
+        if rank == 0:
+            result["weak_scaling"] = {"what": f"{world} x (own {args.total_bp:,} bp metagenome, seed 1 + rank, own {len(c_w)}-candidate table), no collective",
+                                      "value": sum(t[0] for t in tot) * args.steps / el, "unit": "motif-sites/s", "ms_per_step": el / args.steps * 1e3}
+        eng_w.close()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -84,17 +84,30 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
     return assembly, FilteredPileup(engine.contig_names, cc, cp, cs, cm, kept), t
 
 
-def run(mg: synth.SynthMetagenome, engine, device, log=None):
-    """Single-GPU end-to-end run; returns (rows, timings)."""
-    assembly, filtered, t = load_and_filter(engine, mg, device)
-    cfg = ProcessorConfig(assembly=assembly, pileup_path="<synthetic>", bin_contig=dict(zip(mg.names, mg.bin_names)), threads=1,
+def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
+    """End-to-end run on one GPU; ``bins``: only these bins (whole-bin sharding of a multi-GPU run: every rank runs the
+    searches of its own bins alone, find_motifs_bin.py:152-171).  Returns (rows, timings)."""
+    contigs = None
+    if bins is not None:
+        keep = set(bins)
+        contigs = [i for i, b in enumerate(mg.bin_names) if b in keep]
+    assembly, filtered, t = load_and_filter(engine, mg, device, contigs=contigs)
+    names = mg.names if contigs is None else [mg.names[i] for i in contigs]
+    bin_of = mg.bin_names if contigs is None else [mg.bin_names[i] for i in contigs]
+    lengths = [int(mg.lengths[i]) for i in (range(len(mg.names)) if contigs is None else contigs)]
+    cfg = ProcessorConfig(assembly=assembly, pileup_path="<synthetic>", bin_contig=dict(zip(names, bin_of)), threads=1,
                           search_frame_size=40, methylation_threshold_low=0.3, methylation_threshold_high=0.7,
                           minimum_kl_divergence=0.05, score_threshold=1.5, log_dir=None, seed=1, output_dir=None)
     t0 = time.perf_counter()
     scorer = engine_scorer(engine, 0.3, 0.7)
     from .main import device_window_pipeline
-    store, extractor = device_window_pipeline(engine, dict(zip(mg.names, (int(x) for x in mg.lengths))), list(mg.names), cfg.padding)
+    engine.timing_reset(True)
+    store, extractor = device_window_pipeline(engine, dict(zip(names, lengths)), list(names), cfg.padding)
     rows, scorer = discover(cfg, filtered, scorer, window_store=store, extractor=extractor)
     t["search_s"] = time.perf_counter() - t0
+    ms, n = engine.timing_total()
+    engine.timing_reset(False)
+    t["gpu_busy_s"] = ms * 1e-3              # scoring launches of the search (HIP events on the launch stream)
+    t["score_launches"] = n
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
     return rows, t

@@ -31,6 +31,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
 
 import refstub  # noqa: E402
 from nanomotif_amd import synth  # noqa: E402
@@ -48,44 +49,7 @@ def dump(name, obj):
     print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-# ---------------------------------------------------------------------------------------------
-# motif zoo shared by G1/G2 (regex-style strings as the reference uses them)
-# ---------------------------------------------------------------------------------------------
-def motif_zoo():
-    zoo = [
-        # literals / palindromes
-        ("A", 0), ("C", 0), ("AA", 0), ("AA", 1), ("AAAA", 2), ("GATC", 1), ("GATC", 3), ("CCGG", 1),
-        ("GAATTC", 2), ("CTGCAG", 4), ("ACCCA", 4), ("CCAAAT", 4), ("TTCGAA", 5), ("GTAC", 2),
-        ("ACGT", 0), ("ACGT", 1), ("ACGT", 2), ("ACGT", 3), ("TTTT", 0), ("CAGAG", 3),
-        # gaps and bipartite
-        ("GA.TC", 1), ("A.A", 0), ("A.A", 2), ("C..G", 0), ("GCAC......GTT", 2), ("AAC......GTGC", 1),
-        ("CAC.....TGG", 1), ("A..........T", 0), ("A...................C", 0),
-        ("C....................A....................G", 21),
-        # IUPAC sets
-        ("CC[AT]GG", 1), ("G[AG].GAAG[CT]", 5), ("[AG]GC[CT]", 2), ("GC.GC", 1), ("[ACG]A[CGT]", 1),
-        ("[AC][AC][AC]", 1), ("[CGT]A", 1), ("A[ACT]", 0), ("[AG][CT][AG][CT]", 0), ("[GT]A[AC]..[ACG]C", 1),
-        # modified base not canonical / at a bracket (generic API use)
-        ("GATC", 0), ("GATC", 2), ("CC[AT]GG", 2), ("TTAA", 0), ("TTAA", 1),
-        # flanking dots (search-window form, pad 20)
-        ("." * 19 + "GATC" + "." * 18, 20), ("." * 20 + "A" + "." * 20, 20), ("." * 20 + "C" + "." * 20, 20),
-        ("." * 18 + "CCAGG" + "." * 18, 19), ("." * 14 + "GCAC......GTT" + "." * 14, 16),
-        ("." * 20 + "AATT" + "." * 17, 20), ("..GA.TC..", 3), (".A", 1), ("A.", 0),
-    ]
-    # seeded extras: random stripped motifs incl. long ones
-    for s, p, _ in synth.random_candidates(40, seed=11, mod_types=("a", "m")):
-        zoo.append((s, p))
-    rng = np.random.Generator(np.random.PCG64(5))
-    for _ in range(20):
-        L = int(rng.integers(20, 42))
-        chars = ["."] * L
-        for q in rng.choice(L, size=int(rng.integers(3, 9)), replace=False):
-            chars[int(q)] = "ACGT"[int(rng.integers(4))]
-        if chars[0] == "." and chars[-1] == ".":
-            chars[0] = "G"
-        pos = int(rng.integers(0, L))
-        chars[pos] = "AC"[int(rng.integers(2))]
-        zoo.append(("".join(chars), pos))
-    return zoo
+from helpers import motif_zoo  # noqa: E402  (tests/helpers.py: shared with the GPU parity tests)
 
 
 def g1(nm):

@@ -44,50 +44,78 @@ def oracle_bin_inputs(mg, mod_type, contigs=None, min_cov=5):
     return pile, seqs
 
 
-def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, high=0.7):
+def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, high=0.7, bins=None):
     """bin-motifs.tsv text computed end to end by the CPU oracle (filters -> search -> post-processing),
-    following the task order / seeding of the reference's plain (or bgzip) strategy."""
-    import random
-    from oracle import pileup as op
+    following the task order / seeding of the reference's plain (or bgzip) strategy.  ``bins``: restrict to these
+    bins (bins are independent tasks, find_motifs_bin.py:152-171)."""
+    from oracle import pipeline as opl
     from oracle import postprocess as opp
-    from oracle import search as ose
-    from oracle.scan import ContigPileup
-    mods = ["m", "a", "21839"]
-    cols = []
-    for mt in mg.spec.mod_types:
-        c = mg.pileup_columns(mt)
-        c["mod_type"] = np.full(len(c["position"]), mods.index(mt), dtype=np.int8)
-        cols.append(c)
-    cat = lambda k: np.concatenate([c[k] for c in cols])
-    t = dict(contig=cat("contig_id").astype(np.int64), position=cat("position"), strand=cat("strand"),
-             mod_type=cat("mod_type"), fraction_mod=cat("fraction_mod"), Nvalid_cov=cat("nvalid").astype(np.int64))
-    t = op.prefilter(t)
-    rows = []
-    bins = []
+    order = []
     for b in mg.bin_names:
-        if b not in bins:
-            bins.append(b)
-    for b in bins:
-        idx = [i for i, x in enumerate(mg.bin_names) if x == b]
-        seqs = {mg.names[i]: mg.contig_str(i) for i in idx}
-        if bgzip_order:
-            random.seed(seed)
-        for mt_id, mt in enumerate(mods):
-            sel = (t["mod_type"] == mt_id) & np.isin(t["contig"], idx)
-            if not sel.any():
-                continue
-            pile = {}
-            for i in idx:
-                s = sel & (t["contig"] == i)
-                if s.any():
-                    o = np.argsort(t["position"][s], kind="stable")
-                    pile[mg.names[i]] = ContigPileup(t["position"][s][o], t["strand"][s][o], t["fraction_mod"][s][o])
-            if not bgzip_order:
-                random.seed(seed)
-            res = ose.find_best_candidates(pile, seqs, mt, low, high, 20, min_kl=0.05, score_threshold=1.5)
-            if res is None:
-                continue
-            out = opp.process_bin(pile, seqs, b, mt, res[0], res[1], 20)
-            if out:
-                rows += out
+        if b not in order and (bins is None or b in bins):
+            order.append(b)
+    rows = []
+    for b in order:
+        rows += opl.bin_rows(mg, b, seed=seed, bgzip_order=bgzip_order, low=low, high=high)
     return opp.format_bin_motifs(rows, min_motifs_bin=min_motifs_bin)
+
+
+def spec_kwargs(spec) -> dict:
+    """SynthSpec -> plain dict that survives pickling into a spawn worker (oracle.pipeline workers)."""
+    import dataclasses
+    return dataclasses.asdict(spec)
+
+
+def oracle_pipeline_parallel(mg, bins, procs, min_motifs_bin=50, **kw):
+    """``oracle_pipeline`` restricted to ``bins`` with one spawn worker per bin (the oracle needs seconds to minutes
+    per 2 Mbp bin)."""
+    import multiprocessing as mp
+    from oracle import pipeline as opl
+    from oracle import postprocess as opp
+    jobs = [(spec_kwargs(mg.spec), b, kw) for b in bins]
+    with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
+        res = pool.map(opl.bin_rows_worker, jobs, chunksize=1)
+    order = [b for b in dict.fromkeys(mg.bin_names) if b in set(bins)]
+    by_bin = {b: rows for b, rows, _ in res}
+    rows = [r for b in order for r in by_bin[b]]
+    return opp.format_bin_motifs(rows, min_motifs_bin=min_motifs_bin)
+
+
+# ---------------------------------------------------------------------------------------------
+# motif zoo shared by G1/G2 (regex-style strings as the reference uses them)
+# ---------------------------------------------------------------------------------------------
+def motif_zoo():
+    zoo = [
+        # literals / palindromes
+        ("A", 0), ("C", 0), ("AA", 0), ("AA", 1), ("AAAA", 2), ("GATC", 1), ("GATC", 3), ("CCGG", 1),
+        ("GAATTC", 2), ("CTGCAG", 4), ("ACCCA", 4), ("CCAAAT", 4), ("TTCGAA", 5), ("GTAC", 2),
+        ("ACGT", 0), ("ACGT", 1), ("ACGT", 2), ("ACGT", 3), ("TTTT", 0), ("CAGAG", 3),
+        # gaps and bipartite
+        ("GA.TC", 1), ("A.A", 0), ("A.A", 2), ("C..G", 0), ("GCAC......GTT", 2), ("AAC......GTGC", 1),
+        ("CAC.....TGG", 1), ("A..........T", 0), ("A...................C", 0),
+        ("C....................A....................G", 21),
+        # IUPAC sets
+        ("CC[AT]GG", 1), ("G[AG].GAAG[CT]", 5), ("[AG]GC[CT]", 2), ("GC.GC", 1), ("[ACG]A[CGT]", 1),
+        ("[AC][AC][AC]", 1), ("[CGT]A", 1), ("A[ACT]", 0), ("[AG][CT][AG][CT]", 0), ("[GT]A[AC]..[ACG]C", 1),
+        # modified base not canonical / at a bracket (generic API use)
+        ("GATC", 0), ("GATC", 2), ("CC[AT]GG", 2), ("TTAA", 0), ("TTAA", 1),
+        # flanking dots (search-window form, pad 20)
+        ("." * 19 + "GATC" + "." * 18, 20), ("." * 20 + "A" + "." * 20, 20), ("." * 20 + "C" + "." * 20, 20),
+        ("." * 18 + "CCAGG" + "." * 18, 19), ("." * 14 + "GCAC......GTT" + "." * 14, 16),
+        ("." * 20 + "AATT" + "." * 17, 20), ("..GA.TC..", 3), (".A", 1), ("A.", 0),
+    ]
+    # seeded extras: random stripped motifs incl. long ones
+    for s, p, _ in synth.random_candidates(40, seed=11, mod_types=("a", "m")):
+        zoo.append((s, p))
+    rng = np.random.Generator(np.random.PCG64(5))
+    for _ in range(20):
+        L = int(rng.integers(20, 42))
+        chars = ["."] * L
+        for q in rng.choice(L, size=int(rng.integers(3, 9)), replace=False):
+            chars[int(q)] = "ACGT"[int(rng.integers(4))]
+        if chars[0] == "." and chars[-1] == ".":
+            chars[0] = "G"
+        pos = int(rng.integers(0, L))
+        chars[pos] = "AC"[int(rng.integers(2))]
+        zoo.append(("".join(chars), pos))
+    return zoo
