@@ -34,7 +34,7 @@ struct ScoreArgs {
     const uint4 *segments;      // {first chunk, n chunks, bin, 0}
     uint32_t n_segments;
     uint32_t n_bins;
-    const uint2 *cand_range;    // [active_slot_index][bin] -> {begin, count} into programs
+    const uint4 *cand_range;    // [active_slot_index][bin] -> {begin, count, common program or ~0, -} into programs
     const uint32_t *programs;   // [n_prog][2 * (GN + GP) * 8], sorted by (slot, bin)
     const uint32_t *orig_index; // [n_cand] sorted -> caller order
     unsigned long long *out;    // [n_cand][2]
@@ -133,144 +133,173 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
 typedef const uint32_t __attribute__((address_space(4))) *cu32p;
 typedef const uint8_t __attribute__((address_space(4))) *cu8p;
 
-// Eight derived planes for the T main words of this lane plus GN halo words left and GP right.
-template <int GN, int GP>
-struct Tile {
-    static constexpr int NW = T_WORDS + GN + GP;
-    uint32_t w[8][NW];
+// Kernel variant: GN / GP halo words left / right (narrow 1 / 1: offsets in [-32, 31]; wide 2 / 2), COMPACT state planes
+// {M, U} or the four per-strand planes, NS mod-type slots fused per workgroup, LIT = every constraint of the batch is a
+// literal (only the four is-X planes are built — every batch of the greedy search is: children are single letters,
+// find_motifs_bin.py:1005-1018), CF = the constraints common to all candidates of a (slot, bin) group are evaluated
+// once per tile (sibling children of one expansion differ in ONE position, :1116-1135).
+// Tried and dropped for the light variants (same-device A/B, tools/gpu_ab.sh, 1 Gbp greedy round): a register double
+// buffer of the next chunk's raw words (120 VGPRs, 4 waves: -18 %); touching the next chunk's lines with one dword per
+// lane and plane so that they are on their way into L2 (-25 %; with nontemporal touches -45 %); 8 waves per SIMD by
+// launch bounds (3 spills; -4 % with two children per group, +6 % with four); segments of 8 / 32 / 64 chunks (all
+// slower than 16); handing segments out through a device-wide atomic queue instead of one workgroup per segment
+// (-60 %: device-scope atomics are served at the memory side on this multi-die part and serialise).  A 10 Gbp run
+// takes 10.0 x the 1 Gbp time: there is no partial-last-round tail worth chasing.
+#ifndef NM_LIT_WAVES
+#define NM_LIT_WAVES 4      // minimum waves per SIMD the literal-only variants are compiled for
+#endif
 
-    __device__ __forceinline__ void load(const Planes &s, uint32_t chunk, int lane, bool need_v) {
+template <int GN_, int GP_, bool COMPACT_, int NS_, bool LIT_, bool CF_>
+struct Variant {
+    static constexpr int GN = GN_, GP = GP_, NS = NS_;
+    static constexpr bool COMPACT = COMPACT_, LIT = LIT_, CF = CF_;
+    static constexpr int NW = T_WORDS + GN + GP;
+    static constexpr int NP = LIT ? 4 : 8;                 // planes per tile
+    static constexpr int NST = COMPACT ? 2 : 4;            // state planes per slot
+    static constexpr int PDW = (GN + GP) * NP;             // dwords of one strand's program
+};
+
+// The raw words one lane holds of one chunk: T main words of H / L (/ V) plus the halo, and the state words of the
+// NS slots.  All loads of a chunk are issued back to back, nothing is waited for here.
+template <class K>
+struct RawChunk {
+    uint32_t h[K::NW], l[K::NW], v[K::NW];
+    uint32_t s[K::NS][K::NST][T_WORDS];
+    bool need_v;                                           // wave-uniform
+
+    __device__ __forceinline__ void load(const Planes &seq, const StatePlanes (&stp)[K::NS], uint32_t chunk, int lane) {
+        constexpr int GN = K::GN, GP = K::GP;
+        need_v = ((cu8p)seq.needs_v)[chunk] != 0;          // scalar load, issued first
         const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
-        uint32_t h[NW], l[NW], v[NW];
-        const uint4 h4 = *reinterpret_cast<const uint4 *>(s.H + base);
-        const uint4 l4 = *reinterpret_cast<const uint4 *>(s.L + base);
+#pragma unroll
+        for (int j = 0; j < K::NS; ++j) {
+            const uint32_t *src[4] = {K::COMPACT ? stp[j].M : stp[j].MP, K::COMPACT ? stp[j].U : stp[j].UP, stp[j].MM, stp[j].UM};
+#pragma unroll
+            for (int i = 0; i < K::NST; ++i) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(src[i] + base);
+                s[j][i][0] = q.x; s[j][i][1] = q.y; s[j][i][2] = q.z; s[j][i][3] = q.w;
+            }
+        }
+        const uint4 h4 = *reinterpret_cast<const uint4 *>(seq.H + base);
+        const uint4 l4 = *reinterpret_cast<const uint4 *>(seq.L + base);
         h[GN + 0] = h4.x; h[GN + 1] = h4.y; h[GN + 2] = h4.z; h[GN + 3] = h4.w;
         l[GN + 0] = l4.x; l[GN + 1] = l4.y; l[GN + 2] = l4.z; l[GN + 3] = l4.w;
 #pragma unroll
-        for (int j = 0; j < GN; ++j) { h[j] = s.H[base - GN + j]; l[j] = s.L[base - GN + j]; }
+        for (int j = 0; j < GN; ++j) { h[j] = seq.H[base - GN + j]; l[j] = seq.L[base - GN + j]; }
 #pragma unroll
-        for (int j = 0; j < GP; ++j) { h[GN + T_WORDS + j] = s.H[base + T_WORDS + j]; l[GN + T_WORDS + j] = s.L[base + T_WORDS + j]; }
-        if (need_v) {                                                // wave-uniform
-            const uint4 v4 = *reinterpret_cast<const uint4 *>(s.V + base);
+        for (int j = 0; j < GP; ++j) { h[GN + T_WORDS + j] = seq.H[base + T_WORDS + j]; l[GN + T_WORDS + j] = seq.L[base + T_WORDS + j]; }
+        if (need_v) {                                      // wave-uniform
+            const uint4 v4 = *reinterpret_cast<const uint4 *>(seq.V + base);
             v[GN + 0] = v4.x; v[GN + 1] = v4.y; v[GN + 2] = v4.z; v[GN + 3] = v4.w;
 #pragma unroll
-            for (int j = 0; j < GN; ++j) v[j] = s.V[base - GN + j];
+            for (int j = 0; j < GN; ++j) v[j] = seq.V[base - GN + j];
 #pragma unroll
-            for (int j = 0; j < GP; ++j) v[GN + T_WORDS + j] = s.V[base + T_WORDS + j];
+            for (int j = 0; j < GP; ++j) v[GN + T_WORDS + j] = seq.V[base + T_WORDS + j];
         } else {
 #pragma unroll
-            for (int j = 0; j < NW; ++j) v[j] = 0xFFFFFFFFu;
+            for (int j = 0; j < K::NW; ++j) v[j] = 0xFFFFFFFFu;
         }
+    }
+};
+
+// Derived planes of the tile: is-A/C/G/T and (unless LIT) valid-not-A/C/G/T, NW words each.
+template <class K>
+struct Tile {
+    uint32_t w[K::NP][K::NW];
+
+    __device__ __forceinline__ void expand(const RawChunk<K> &r) {
 #pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const uint32_t hh = h[j], ll = l[j], vv = v[j];
+        for (int j = 0; j < K::NW; ++j) {
+            const uint32_t hh = r.h[j], ll = r.l[j], vv = r.v[j];
             w[0][j] = vv & ~hh & ~ll;          // A = 00
             w[1][j] = vv & ~hh & ll;           // C = 01
             w[2][j] = vv & hh & ll;            // G = 11
             w[3][j] = vv & hh & ~ll;           // T = 10
-            w[4][j] = vv & (hh | ll);          // valid, not A
-            w[5][j] = vv & (hh | ~ll);         // valid, not C
-            w[6][j] = vv & ~(hh & ll);         // valid, not G
-            w[7][j] = vv & (~hh | ll);         // valid, not T
+            if (!K::LIT) {
+                w[4][j] = vv & (hh | ll);          // valid, not A
+                w[5][j] = vv & (hh | ~ll);         // valid, not C
+                w[6][j] = vv & ~(hh & ll);         // valid, not G
+                w[7][j] = vv & (~hh | ll);         // valid, not T
+            }
         }
     }
 };
 
-// One strand's constraint masks for the offset groups this kernel variant supports: m[(gi - (2 - GN)) * 8 + p].
-template <int GN, int GP>
-struct StrandMasks {
-    static constexpr int N = (GN + GP) * 8;
-    uint32_t m[N];
-    __device__ __forceinline__ void load(cu32p prog_strand) {
+// acc[t] &= plane p at offset d (d = 32 g + r) for every constraint bit of one strand's program
+// (prog[g * NP + p], bit r; g counts from the leftmost word-group the variant reads).  Control flow is scalar and
+// wave-uniform (s_ff1 over the SGPR masks), register indices are static.
+template <class K>
+__device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uint32_t (&acc)[T_WORDS]) {
+    uint32_t m[K::PDW];
 #pragma unroll
-        for (int i = 0; i < N; ++i) m[i] = prog_strand[i];
-    }
-};
-
-// acc[t] &= plane p at offset d (d = 32 g + r) for every constraint bit of one strand's program.  The caller
-// initialises acc (all ones, or the plane of the modified base: that constraint sits at offset 0 and needs no
-// alignbit).  Two constraints of the same (word-group, plane) class are folded into one 3-input AND (v_bitop3).
-template <int GN, int GP>
-__device__ __forceinline__ void eval_strand(const StrandMasks<GN, GP> &sm, const Tile<GN, GP> &tile,
-                                            uint32_t (&acc)[T_WORDS]) {
+    for (int i = 0; i < K::PDW; ++i) m[i] = prog[i];
 #pragma unroll
-    for (int g = 0; g < GN + GP; ++g) {            // g = gi - (2 - GN): word pair (t + g, t + g + 1)
+    for (int g = 0; g < K::GN + K::GP; ++g) {            // word pair (t + g, t + g + 1)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            uint32_t m = sm.m[g * 8 + p];
-            while (m) {
-                const uint32_t r = __builtin_ctz(m);
-                m &= m - 1;
-                if (false) {
-                } else {
+        for (int p = 0; p < K::NP; ++p) {
+            uint32_t mm = m[g * K::NP + p];
+            while (mm) {
+                const uint32_t r = __builtin_ctz(mm);
+                mm &= mm - 1;
 #pragma unroll
-                    for (int t = 0; t < T_WORDS; ++t) acc[t] &= alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
-                }
+                for (int t = 0; t < T_WORDS; ++t) acc[t] &= alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
             }
         }
     }
 }
 
-// The candidates [k0, k0 + nb) of one mod-type slot against the tile this wave holds: match masks, site counts,
-// per-lane counts into LDS rows lds_row0 + k.  CAN: canonical base of the slot, 0 = A (reverse-strand sites sit on T),
-// 1 = C (reverse on G).
-// State words of one slot for this lane's T words: compact = {M, U}, general = {MP, UP, MM, UM}.
-template <bool COMPACT>
-struct StateWords {
-    uint32_t s[COMPACT ? 2 : 4][T_WORDS];
-    __device__ __forceinline__ void load(const StatePlanes &st, size_t base) {
-        const uint32_t *src[4] = {COMPACT ? st.M : st.MP, COMPACT ? st.U : st.UP, st.MM, st.UM};
-#pragma unroll
-        for (int i = 0; i < (COMPACT ? 2 : 4); ++i) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(src[i] + base);
-            s[i][0] = v.x; s[i][1] = v.y; s[i][2] = v.z; s[i][3] = v.w;
-        }
-    }
-};
-
-template <int GN, int GP, bool COMPACT, int CAN>
-__device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<GN, GP> &tile, const StateWords<COMPACT> &sw,
-                                                 uint32_t k0, uint32_t nb, uint32_t *lds_acc, uint32_t lds_row0, int lane) {
+// One slot's candidates [k0, k0 + nb) against the tile this wave holds: match masks, site counts, per-lane counts into
+// LDS rows k * NS + lds_row0 (lds_row0 = the slot's index in the workgroup).  CAN: canonical base of the slot, 0 = A (reverse-strand sites sit on T), 1 = C (reverse on G).
+// common != ~0u: program index of the constraints shared by all nb candidates (their own programs hold the rest).
+template <class K, int CAN>
+__device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<K> &tile, const uint32_t (&sw)[K::NST][T_WORDS],
+                                                 uint32_t k0, uint32_t nb, uint32_t common, uint32_t *lds_acc, uint32_t lds_row0,
+                                                 int lane) {
     constexpr int PF = CAN == 0 ? 0 : 1;   // plane of the canonical base: A or C
     constexpr int PR = CAN == 0 ? 3 : 2;   // plane of its complement:     T or G
+    uint32_t basef[T_WORDS], baser[T_WORDS];
+#pragma unroll
+    for (int t = 0; t < T_WORDS; ++t) {
+        // compact batches: every candidate has the canonical literal at its modified position, the compiler leaves
+        // that constraint out of the program and it becomes the accumulator's initial value
+        basef[t] = K::COMPACT ? tile.w[PF][t + K::GN] : 0xFFFFFFFFu;
+        baser[t] = K::COMPACT ? tile.w[PR][t + K::GN] : 0xFFFFFFFFu;
+    }
+    if (K::CF && common != 0xFFFFFFFFu) {                                    // wave-uniform
+        cu32p prog = (cu32p)(a.programs + (size_t)common * (2 * K::PDW));
+        eval_strand<K>(prog, tile, basef);
+        eval_strand<K>(prog + K::PDW, tile, baser);
+    }
     for (uint32_t k = 0; k < nb; ++k) {
-        cu32p prog = (cu32p)(a.programs + (size_t)(k0 + k) * (2 * StrandMasks<GN, GP>::N));
-        StrandMasks<GN, GP> mf, mr;
-        mf.load(prog);
-        mr.load(prog + StrandMasks<GN, GP>::N);
+        cu32p prog = (cu32p)(a.programs + (size_t)(k0 + k) * (2 * K::PDW));
         uint32_t accf[T_WORDS], accr[T_WORDS];
 #pragma unroll
-        for (int t = 0; t < T_WORDS; ++t) {
-            // compact batches: every candidate has the canonical literal at its modified position, the host leaves
-            // that constraint out of the program and it becomes the accumulator's initial value
-            accf[t] = COMPACT ? tile.w[PF][t + GN] : 0xFFFFFFFFu;
-            accr[t] = COMPACT ? tile.w[PR][t + GN] : 0xFFFFFFFFu;
-        }
-        eval_strand<GN, GP>(mf, tile, accf);
-        eval_strand<GN, GP>(mr, tile, accr);
+        for (int t = 0; t < T_WORDS; ++t) { accf[t] = basef[t]; accr[t] = baser[t]; }
+        eval_strand<K>(prog, tile, accf);
+        eval_strand<K>(prog + K::PDW, tile, accr);
         uint32_t n_mod = 0, n_non = 0;
 #pragma unroll
         for (int t = 0; t < T_WORDS; ++t) {
-            if (COMPACT) {
-                const uint32_t sites = accf[t] | accr[t];
-                n_mod += __popc(sites & sw.s[0][t]);
-                n_non += __popc(sites & sw.s[1][t]);
+            if (K::COMPACT) {
+                const uint32_t sites = accf[t] | accr[t];       // forward sites sit on the canonical base, reverse on its complement
+                n_mod += __popc(sites & sw[0][t]);
+                n_non += __popc(sites & sw[1][t]);
             } else {
-                n_mod += __popc(accf[t] & sw.s[0][t]) + __popc(accr[t] & sw.s[COMPACT ? 0 : 2][t]);
-                n_non += __popc(accf[t] & sw.s[1][t]) + __popc(accr[t] & sw.s[COMPACT ? 1 : 3][t]);
+                n_mod += __popc(accf[t] & sw[0][t]) + __popc(accr[t] & sw[K::COMPACT ? 0 : 2][t]);
+                n_non += __popc(accf[t] & sw[1][t]) + __popc(accr[t] & sw[K::COMPACT ? 1 : 3][t]);
             }
         }
-        atomicAdd(&lds_acc[((lds_row0 + k) * 2 + 0) * 64 + lane], n_mod);
-        atomicAdd(&lds_acc[((lds_row0 + k) * 2 + 1) * 64 + lane], n_non);
+        atomicAdd(&lds_acc[((k * K::NS + lds_row0) * 2 + 0) * 64 + lane], n_mod);
+        atomicAdd(&lds_acc[((k * K::NS + lds_row0) * 2 + 1) * 64 + lane], n_non);
     }
 }
 
-// NS = mod-type slots fused into one workgroup: with NS > 1 a tile's sequence planes are loaded and expanded once
-// and serve the candidates of all NS slots (each slot brings its own M / U planes); with NS = 1 the slot comes
-// from blockIdx.y (batches that touch more than two classifications).  A pass handles up to BMAX / NS candidates
-// per slot; LDS rows are [slot j][candidate k].
-template <int GN, int GP, bool COMPACT, int NS>
-__global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(ScoreArgs a) {
+// With NS > 1 a tile's sequence planes are loaded and expanded once and serve the candidates of all NS slots (each slot
+// brings its own state planes); with NS = 1 the slot comes from blockIdx.y.  A pass handles up to BMAX / NS candidates
+// per slot; LDS rows are [candidate k][slot j].
+template <class K>
+__global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVES : 4))) void score_kernel(ScoreArgs a) {
+    constexpr int NS = K::NS;
     __shared__ uint32_t lds_acc[BMAX * 2 * 64];
     constexpr uint32_t H = BMAX / NS;
     // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(Score
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
     sg.y = __builtin_amdgcn_readfirstlane(sg.y);
     sg.z = __builtin_amdgcn_readfirstlane(sg.z);
-    uint2 range[NS];
+    uint4 range[NS];                                // {first program, candidates, common program or ~0, -}
     uint32_t most = 0;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -291,6 +320,7 @@ __global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(Score
         range[j] = a.cand_range[(size_t)slot_i * a.n_bins + sg.z];
         range[j].x = __builtin_amdgcn_readfirstlane(range[j].x);
         range[j].y = __builtin_amdgcn_readfirstlane(range[j].y);
+        range[j].z = __builtin_amdgcn_readfirstlane(range[j].z);
         most = max(most, range[j].y);
     }
     if (most == 0) return;
@@ -307,46 +337,44 @@ __global__ __launch_bounds__(256, (GN + GP > 2 ? 2 : 4)) void score_kernel(Score
     }
 
     for (uint32_t pass0 = 0; pass0 < most; pass0 += H) {
-        for (uint32_t i = threadIdx.x; i < BMAX * 128; i += 256) lds_acc[i] = 0;
+        // LDS rows in use this pass: row = k * NS + j for candidate k of slot j
+        const uint32_t rows_hi = NS * min(H, most - pass0);
+        for (uint32_t i = threadIdx.x; i < rows_hi * 128; i += 256) lds_acc[i] = 0;
         __syncthreads();
         for (uint32_t ck = wave; ck < sg.y; ck += 4) {
-            const uint32_t chunk = sg.x + ck;
-            const bool need_v = ((cu8p)a.seq.needs_v)[chunk] != 0;          // scalar load, issued first
-            const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
-            // all global loads of this chunk are issued back to back (state planes first, then the sequence planes)
-            // so that one memory latency covers them; the expansion into the eight derived planes follows
-            StateWords<COMPACT> sw[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) sw[j].load(stp[j], base);          // unconditional: no control flow between loads
-            Tile<GN, GP> tile;
-            tile.load(a.seq, chunk, lane, need_v);
+            RawChunk<K> cur;
+            cur.load(a.seq, stp, sg.x + ck, lane);
+            Tile<K> tile;
+            tile.expand(cur);
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 if (range[j].y <= pass0) continue;                       // wave-uniform
                 const uint32_t nbj = min(H, range[j].y - pass0);
-                if (COMPACT && is_c[j])
-                    score_candidates<GN, GP, COMPACT, 1>(a, tile, sw[j], range[j].x + pass0, nbj, lds_acc, j * H, lane);
+                if (K::COMPACT && is_c[j])
+                    score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, lds_acc, j, lane);
                 else
-                    score_candidates<GN, GP, COMPACT, 0>(a, tile, sw[j], range[j].x + pass0, nbj, lds_acc, j * H, lane);
+                    score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, lds_acc, j, lane);
             }
         }
         __syncthreads();
         // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
-        for (uint32_t idx = threadIdx.x; idx < BMAX * 8; idx += 256) {
-            const uint32_t i = idx >> 2, q = idx & 3;               // i = counter row: (j * H + k) * 2 + which
-            const uint32_t j = (i >> 1) / H, k = (i >> 1) % H;
+        for (uint32_t idx = threadIdx.x; idx < rows_hi * 8; idx += 256) {
+            const uint32_t i = idx >> 2, q = idx & 3;               // i = counter row: (k * NS + j) * 2 + which
+            const uint32_t j = (i >> 1) % NS, k = (i >> 1) / NS;
             uint32_t s = 0;
 #pragma unroll 4
             for (int jj = 0; jj < 16; ++jj) s += lds_acc[i * 64 + q * 16 + jj];
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             if (q == 0 && s) {
-                uint2 rj = range[0];
+                uint4 rj = range[0];
 #pragma unroll
                 for (int t = 1; t < NS; ++t)
                     if (j == (uint32_t)t) rj = range[t];
-                const uint32_t orig = a.orig_index[rj.x + pass0 + k];
-                atomicAdd(a.out + (size_t)orig * 2 + (i & 1), (unsigned long long)s);
+                if (pass0 + k < rj.y) {
+                    const uint32_t orig = a.orig_index[rj.x + pass0 + k];
+                    atomicAdd(a.out + (size_t)orig * 2 + (i & 1), (unsigned long long)s);
+                }
             }
         }
         __syncthreads();
@@ -363,15 +391,16 @@ struct CandRec {
 // Compile the staged candidates into constraint programs ON THE DEVICE: one thread per candidate.  A literal is one
 // constraint on an is-X plane, a 3-set one on a valid-not-X plane, a 2-set two of those; the reverse strand takes
 // the complemented set at the negated offset (motif.py:260-266).  Program layout: [strand][word-group][plane] with
-// the word-groups the launched variant reads (narrow: groups 1..2, wide: 0..3); bit r of a word = offset 32 g + r.
+// the word-groups the launched variant reads (narrow: groups 1..2, wide: 0..3) and its planes (np = 4: literal-only
+// batch, is-X planes; np = 8); bit r of a word = offset 32 g + r.
 // fold_modpos: the modified position's own constraint is left out (compact batches start the accumulator from the
 // canonical plane instead).
 __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
-                               uint32_t *__restrict__ programs, int wide, int fold_modpos) {
+                               uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_prog) return;
     const int groups = wide ? 4 : 2, g0 = wide ? 0 : 1;
-    const int pdw = 2 * groups * 8;
+    const int pdw = 2 * groups * np;
     uint32_t *prog = programs + (size_t)k * pdw;
     for (int i = 0; i < pdw; ++i) prog[i] = 0;
     const CandRec c = rec[k];
@@ -385,10 +414,10 @@ __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
                                              : (((set_f & 1) << 3) | ((set_f & 2) << 1) | ((set_f & 4) >> 1) | ((set_f & 8) >> 3));
             const int g = (d >> 5) + 2 - g0;
             const uint32_t bit = 1u << ((uint32_t)d & 31u);
-            uint32_t *row = prog + (strand * groups + g) * 8;
+            uint32_t *row = prog + (strand * groups + g) * np;
             if (__popc(set) == 1) {
                 row[__ffs(set) - 1] |= bit;
-            } else {
+            } else {                                    // never reached with np = 4: the host checked the batch
                 uint32_t missing = (~set) & 15u;
                 while (missing) {
                     row[4 + __ffs(missing) - 1] |= bit;
@@ -399,27 +428,55 @@ __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
     }
 }
 
+// Light batches (a round of the greedy search): the constraints shared by ALL candidates of a (slot, bin) group — the
+// parent of sibling children (find_motifs_bin.py:1116-1135), the motif under its parents in a pruning round
+// (:1408-1432) — become the group's COMMON program (index n_prog + group), evaluated once per tile; the candidates keep
+// the rest.  One thread per group; groups of 1 or of more than max_group candidates are left alone (range.z = ~0).
+__global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
+                              uint32_t n_prog, uint32_t max_group) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_entries) return;
+    uint4 r = range[g];
+    r.z = 0xFFFFFFFFu;
+    if (r.y >= 2 && r.y <= max_group) {
+        uint32_t *common = programs + (size_t)(n_prog + g) * pdw;
+        uint32_t any = 0;
+        for (uint32_t i = 0; i < pdw; ++i) {
+            uint32_t c = programs[(size_t)r.x * pdw + i];
+            for (uint32_t k = 1; k < r.y; ++k) c &= programs[(size_t)(r.x + k) * pdw + i];
+            common[i] = c;
+            any |= c;
+        }
+        if (any) {
+            for (uint32_t k = 0; k < r.y; ++k)
+                for (uint32_t i = 0; i < pdw; ++i) programs[(size_t)(r.x + k) * pdw + i] &= ~common[i];
+            r.z = n_prog + g;
+        }
+    }
+    range[g] = r;
+}
+
 // Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
 template <int GN, int GP>
 __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, uint32_t chunk0, uint32_t n_chunks,
                                                    const uint32_t *__restrict__ prog, int which,
                                                    uint32_t *__restrict__ out) {
+    using K = Variant<GN, GP, false, 1, false, false>;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ck = blockIdx.x * 4 + wave;
     if (ck >= n_chunks) return;
     const uint32_t chunk = chunk0 + ck;
-    Tile<GN, GP> tile;
-    tile.load(seq, chunk, lane, seq.needs_v[chunk] != 0);
+    const StatePlanes stp[1] = {st};
+    RawChunk<K> raw;
+    raw.load(seq, stp, chunk, lane);
+    Tile<K> tile;
+    tile.expand(raw);
     uint32_t acc[T_WORDS];
 #pragma unroll
     for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
-    StrandMasks<GN, GP> sm;
-    sm.load((cu32p)(prog + (which >= 2 ? StrandMasks<GN, GP>::N : 0)));
-    eval_strand<GN, GP>(sm, tile, acc);
-    const uint32_t *plane = which == 0 ? st.MP : which == 1 ? st.UP : which == 2 ? st.MM : st.UM;
-    const size_t base = (size_t)chunk * CHUNK_WORDS + (size_t)lane * T_WORDS;
+    eval_strand<K>((cu32p)(prog + (which >= 2 ? K::PDW : 0)), tile, acc);
 #pragma unroll
-    for (int t = 0; t < T_WORDS; ++t) out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & plane[base + t];
+    for (int t = 0; t < T_WORDS; ++t) out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & raw.s[0][which][t];
 }
 
 }  // namespace
@@ -526,12 +583,33 @@ void add_modpos_constraint(uint32_t *prog, uint32_t modpos_mask) {
     }
 }
 
-template <int GN, int GP, bool COMPACT>
-void launch_score(const ScoreArgs &a, uint32_t gx, uint32_t n_active, bool fuse, hipStream_t s) {
-    // two classifications (the usual 6mA + 5mC batch) share one pass over the sequence planes when the batch is
-    // light (HBM-bound: a greedy round); heavy batches are VALU-bound and run better as twice as many workgroups
-    if (n_active == 2 && fuse) hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT, 2>), dim3(gx, 1), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((score_kernel<GN, GP, COMPACT, 1>), dim3(gx, std::max(n_active, 1u)), dim3(256), 0, s, a);
+// Launch shape of a batch.  heavy: one workgroup column per classification (blockIdx.y), candidates VALU-bound;
+// light (<= 6 candidates per (slot, bin) group on average — a round of the greedy search): HBM-bound, groups share their
+// common constraints (CF), two classifications (the usual 6mA + 5mC batch) share one pass over the sequence planes.
+struct LaunchShape {
+    bool wide, compact, lit, light;
+    uint32_t n_active;
+};
+
+template <class K>
+void launch_variant(const ScoreArgs &a, uint32_t gx, uint32_t gy, hipStream_t s) {
+    hipLaunchKernelGGL((score_kernel<K>), dim3(gx, gy), dim3(256), 0, s, a);
+}
+
+template <int G, bool COMPACT, bool LIT>
+void launch_by_load(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStream_t s) {
+    if (!sh.light) launch_variant<Variant<G, G, COMPACT, 1, LIT, false>>(a, gx, std::max(sh.n_active, 1u), s);
+    else if (sh.n_active == 2) launch_variant<Variant<G, G, COMPACT, 2, LIT, true>>(a, gx, 1, s);
+    else launch_variant<Variant<G, G, COMPACT, 1, LIT, true>>(a, gx, std::max(sh.n_active, 1u), s);
+}
+
+void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStream_t s) {
+    if (!sh.wide && sh.compact) {
+        if (sh.lit) launch_by_load<1, true, true>(a, gx, sh, s);
+        else launch_by_load<1, true, false>(a, gx, sh, s);
+    } else if (!sh.wide) launch_by_load<1, false, false>(a, gx, sh, s);
+    else if (sh.compact) launch_by_load<2, true, false>(a, gx, sh, s);
+    else launch_by_load<2, false, false>(a, gx, sh, s);
 }
 
 int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
@@ -546,7 +624,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const uint32_t n_bins = c->n_bins;
     std::vector<uint32_t> &bucket = c->bucket;          // counting sort by (slot, bin)
     bucket.assign((size_t)NM_MAX_MOD_SLOTS * n_bins + 1, 0);
-    bool any_wide = false, all_compact = true;
+    bool any_wide = false, all_compact = true, all_literal = true;
     uint32_t n_prog = 0;
     uint64_t mask_bytes = 0, mask_lo = ~0ull;   // byte range of cand_masks the resident candidates reference
     bool slot_used[NM_MAX_MOD_SLOTS] = {};
@@ -560,12 +638,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "candidate %u: motif length %u outside 1..%d", k, len, NM_MAX_MOTIF_LEN);
         if (mp >= len) return fail(NM_EINVAL, "candidate %u: mod_position %u outside motif of length %u", k, mp, len);
         const uint8_t *m = cand_masks + cand_mask_offset[k];
-        uint32_t all_and = 15u, any_zero = 0;
+        uint32_t all_and = 15u, any_zero = 0, any_set = 0;
         for (uint32_t j = 0; j < len; ++j) {
             const uint32_t v = m[j] & 15u;
             all_and &= v;
             any_zero |= (v == 0);
+            any_set |= (v != 15u) & ((v & (v - 1)) != 0);      // a 2- or 3-base set
         }
+        if (any_set) all_literal = false;
         if (any_zero) return fail(NM_EINVAL, "candidate %u: empty base set in the motif", k);
         if (all_and == 15u) return fail(NM_EINVAL, "candidate %u: motif has no specified position", k);
         mask_lo = std::min<uint64_t>(mask_lo, cand_mask_offset[k]);
@@ -586,19 +666,22 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (slot_used[sl]) { slot_to_active[sl] = (int)n_active; active[n_active++] = (uint32_t)sl; }
     }
     // ---- staging layout: candidate records (sorted) | orig_index | mask bytes | cand_range
-    const uint32_t pdw = any_wide ? 64u : 32u;
+    const bool lit = all_literal && all_compact && !any_wide && !c->opt_no_lit;   // literal-only tiles exist for the narrow compact kernels
+    const uint32_t np = lit ? 4u : 8u;
+    const uint32_t pdw = 2u * (any_wide ? 4u : 2u) * np;         // dwords per program: [strand][word-group][plane]
     const size_t rec_bytes = (size_t)n_prog * sizeof(CandRec);
     const size_t off_orig = (rec_bytes + 15) & ~(size_t)15;
     const size_t off_masks = (off_orig + (size_t)n_prog * 4 + 15) & ~(size_t)15;
     const size_t off_range = (off_masks + (mask_bytes - mask_lo) + 15) & ~(size_t)15;
-    const size_t range_bytes = (size_t)std::max(n_active, 1u) * n_bins * sizeof(uint2);
+    const uint32_t n_entries = std::max(n_active, 1u) * n_bins;
+    const size_t range_bytes = (size_t)n_entries * sizeof(uint4);
     const size_t total = off_range + range_bytes;
     int rc = ensure_stage(c, total);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
     CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
-    uint2 *h_range = reinterpret_cast<uint2 *>(hs + off_range);
+    uint4 *h_range = reinterpret_cast<uint4 *>(hs + off_range);
     memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
     memset(h_range, 0, range_bytes);
     uint32_t n_groups = 0;
@@ -609,7 +692,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         for (uint32_t b = 0; b < n_bins; ++b) {
             const uint32_t lo = bucket[(size_t)sl * n_bins + b], hi = bucket[(size_t)sl * n_bins + b + 1];
             if (hi > lo) {
-                h_range[(size_t)slot_to_active[sl] * n_bins + b] = make_uint2(lo, hi - lo);
+                h_range[(size_t)slot_to_active[sl] * n_bins + b] = make_uint4(lo, hi - lo, 0xFFFFFFFFu, 0);
                 n_groups += 1;
             }
         }
@@ -621,9 +704,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         h_rec[at] = CandRec{(uint32_t)(cand_mask_offset[k] - mask_lo), k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
         h_orig[at] = k;
     }
+    // measured crossover (profiles/): up to ~6 candidates per (slot, bin) group the launch is HBM-bound
+    const bool light = (uint64_t)n_prog <= 6ull * n_groups;
+    const bool cf = light && !c->opt_no_cf;
     // device-side program buffer: two halves, one per staging pair, so that compiling batch k+1 (on the copy stream)
-    // overlaps the scoring kernel of batch k; reuse of a half is gated like its staging pair (ensure_stage)
-    const size_t need_dw = (size_t)std::max(n_prog, 1u) * pdw;
+    // overlaps the scoring kernel of batch k; reuse of a half is gated like its staging pair (ensure_stage).  A light
+    // batch appends one common program per (slot, bin) entry.
+    const size_t need_dw = ((size_t)std::max(n_prog, 1u) + (cf ? n_entries : 0)) * pdw;
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
@@ -639,9 +726,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_prog) {
         hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->copy_stream, n_prog,
-                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide ? 1 : 0,
+                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide ? 1 : 0, (int)np,
                            all_compact ? 1 : 0);
         HIP_TRY(hipGetLastError());
+        if (cf) {
+            hipLaunchKernelGGL(common_kernel, dim3((n_entries + 63) / 64), dim3(64), 0, c->copy_stream, n_entries,
+                               reinterpret_cast<uint4 *>(ds + off_range), d_prog, pdw, n_prog, 8u);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_done, 0));
@@ -670,13 +762,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.n_bins = c->n_bins;
     a.programs = d_prog;
     a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
-    a.cand_range = reinterpret_cast<uint2 *>(ds + off_range);
+    a.cand_range = reinterpret_cast<uint4 *>(ds + off_range);
     a.out = out;
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
-    // measured crossover (profiles/): up to ~6 candidates per (slot, bin) group the launch is HBM-bound
-    const bool fuse = n_active == 2 && (uint64_t)n_prog <= 6ull * n_groups;
+    const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active};
+    const bool fuse = n_active == 2 && shape.light;
 
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->ev_collect) {
@@ -692,11 +784,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         c->ev_used += 1;
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
-    if (n_prog == 0) { /* nothing resident for this batch: the zeroed table is the answer */ }
-    else if (!any_wide && all_compact) launch_score<1, 1, true>(a, gx, n_active, fuse, c->stream);
-    else if (!any_wide) launch_score<1, 1, false>(a, gx, n_active, fuse, c->stream);
-    else if (all_compact) launch_score<2, 2, true>(a, gx, n_active, fuse, c->stream);
-    else launch_score<2, 2, false>(a, gx, n_active, fuse, c->stream);
+    if (n_prog) launch_score(a, gx, shape, c->stream);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, c->stream));
     rc = release_stage(c);
@@ -742,6 +830,9 @@ int nm_ctx_create(int device, nm_ctx **out) {
     nm_ctx *c = new (std::nothrow) nm_ctx();
     if (!c) return fail(NM_ENOMEM, "out of host memory");
     c->device = device;
+    c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
+    c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
+    if (const char *e = getenv("NM_SEG_CHUNKS")) c->seg_chunks = (uint32_t)std::max(4, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -894,8 +985,8 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     // static segment table: every bin's chunk range cut into pieces of SEG_CHUNKS
     std::vector<uint4> segs;
     for (uint32_t b = 0; b < n_bins; ++b)
-        for (uint32_t k = 0; k < c->bin_nchunks[b]; k += SEG_CHUNKS)
-            segs.push_back(make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(SEG_CHUNKS, c->bin_nchunks[b] - k), b, 0));
+        for (uint32_t k = 0; k < c->bin_nchunks[b]; k += c->seg_chunks)
+            segs.push_back(make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(c->seg_chunks, c->bin_nchunks[b] - k), b, 0));
     c->n_segments = (uint32_t)segs.size();
     HIP_TRY(hipMalloc(&c->d_segments, segs.size() * sizeof(uint4)));
     HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));

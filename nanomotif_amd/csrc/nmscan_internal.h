@@ -130,6 +130,9 @@ struct nm_ctx {
     unsigned long long *d_other = nullptr;
     uint64_t other_letters = 0;
     uint64_t launches = 0, last_wgs = 0, last_compact = 0, last_general = 0;
+    // kernel-variant switches for A/B runs (environment: NM_NO_LIT, NM_NO_CF, NM_PREFETCH), read at nm_ctx_create
+    bool opt_no_lit = false, opt_no_cf = false;
+    uint32_t seg_chunks = nmdetail::SEG_CHUNKS;      // chunks per workgroup segment (NM_SEG_CHUNKS)
 };
 
 namespace nmdetail {
