@@ -248,13 +248,32 @@ __device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uin
     }
 }
 
+// acc = base & (the ONE constraint `desc` = (mask index << 5) | r of a strand): the residual of a sibling child once the
+// parent's constraints are in `base`.  The mask index selects registers, so it is dispatched through a switch.
+template <class K, int I = 0>
+__device__ __forceinline__ void apply_single(uint32_t idx, uint32_t r, const Tile<K> &tile, const uint32_t (&base)[T_WORDS],
+                                             uint32_t (&acc)[T_WORDS]) {
+    if constexpr (I < K::PDW) {
+        if (idx == I) {
+            constexpr int g = I / K::NP, p = I % K::NP;
+#pragma unroll
+            for (int t = 0; t < T_WORDS; ++t) acc[t] = base[t] & alignbit(tile.w[p][t + g + 1], tile.w[p][t + g], r);
+        } else {
+            apply_single<K, I + 1>(idx, r, tile, base, acc);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < T_WORDS; ++t) acc[t] = base[t];      // idx == PDW: no constraint left on this strand
+    }
+}
+
 // One slot's candidates [k0, k0 + nb) against the tile this wave holds: match masks, site counts, per-lane counts into
 // LDS rows k * NS + lds_row0 (lds_row0 = the slot's index in the workgroup).  CAN: canonical base of the slot, 0 = A (reverse-strand sites sit on T), 1 = C (reverse on G).
 // common != ~0u: program index of the constraints shared by all nb candidates (their own programs hold the rest).
 template <class K, int CAN>
 __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<K> &tile, const uint32_t (&sw)[K::NST][T_WORDS],
-                                                 uint32_t k0, uint32_t nb, uint32_t common, uint32_t *lds_acc, uint32_t lds_row0,
-                                                 int lane) {
+                                                 uint32_t k0, uint32_t nb, uint32_t common, bool siblings, uint32_t *lds_acc,
+                                                 uint32_t lds_row0, int lane) {
     constexpr int PF = CAN == 0 ? 0 : 1;   // plane of the canonical base: A or C
     constexpr int PR = CAN == 0 ? 3 : 2;   // plane of its complement:     T or G
     uint32_t basef[T_WORDS], baser[T_WORDS];
@@ -273,10 +292,16 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
     for (uint32_t k = 0; k < nb; ++k) {
         cu32p prog = (cu32p)(a.programs + (size_t)(k0 + k) * (2 * K::PDW));
         uint32_t accf[T_WORDS], accr[T_WORDS];
+        if (K::CF && siblings) {                                             // wave-uniform: one constraint per strand left
+            const uint32_t df = prog[0], dr = prog[1];
+            apply_single<K>(df >> 5, df & 31u, tile, basef, accf);
+            apply_single<K>(dr >> 5, dr & 31u, tile, baser, accr);
+        } else {
 #pragma unroll
-        for (int t = 0; t < T_WORDS; ++t) { accf[t] = basef[t]; accr[t] = baser[t]; }
-        eval_strand<K>(prog, tile, accf);
-        eval_strand<K>(prog + K::PDW, tile, accr);
+            for (int t = 0; t < T_WORDS; ++t) { accf[t] = basef[t]; accr[t] = baser[t]; }
+            eval_strand<K>(prog, tile, accf);
+            eval_strand<K>(prog + K::PDW, tile, accr);
+        }
         uint32_t n_mod = 0, n_non = 0;
 #pragma unroll
         for (int t = 0; t < T_WORDS; ++t) {
@@ -306,7 +331,8 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
     // of segments so candidate programs and counters of one bin stay in one L2.
     const uint32_t nb = gridDim.x;
     const uint32_t per = (nb + 7) / 8;
-    uint32_t seg = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // (a light batch streams: there the remap costs 3 % of the read rate, tools/stream_pattern.hip)
+    uint32_t seg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
     if (seg >= a.n_segments) return;
     uint4 sg = a.segments[seg];
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
         range[j].x = __builtin_amdgcn_readfirstlane(range[j].x);
         range[j].y = __builtin_amdgcn_readfirstlane(range[j].y);
         range[j].z = __builtin_amdgcn_readfirstlane(range[j].z);
+        range[j].w = __builtin_amdgcn_readfirstlane(range[j].w);
         most = max(most, range[j].y);
     }
     if (most == 0) return;
@@ -351,9 +378,9 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
                 if (range[j].y <= pass0) continue;                       // wave-uniform
                 const uint32_t nbj = min(H, range[j].y - pass0);
                 if (K::COMPACT && is_c[j])
-                    score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, lds_acc, j, lane);
+                    score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
                 else
-                    score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, lds_acc, j, lane);
+                    score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
             }
         }
         __syncthreads();
@@ -438,6 +465,7 @@ __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uin
     if (g >= n_entries) return;
     uint4 r = range[g];
     r.z = 0xFFFFFFFFu;
+    r.w = 0;
     if (r.y >= 2 && r.y <= max_group) {
         uint32_t *common = programs + (size_t)(n_prog + g) * pdw;
         uint32_t any = 0;
@@ -448,8 +476,33 @@ __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uin
             any |= c;
         }
         if (any) {
-            for (uint32_t k = 0; k < r.y; ++k)
-                for (uint32_t i = 0; i < pdw; ++i) programs[(size_t)(r.x + k) * pdw + i] &= ~common[i];
+            // siblings: every candidate keeps at most ONE constraint per strand -> its program shrinks to two
+            // descriptors (mask index << 5 | r; index = dwords per strand when nothing is left) and range.w = 1
+            bool single = true;
+            const uint32_t sdw = pdw / 2;
+            for (uint32_t k = 0; k < r.y; ++k) {
+                uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
+                for (uint32_t i = 0; i < pdw; ++i) prog[i] &= ~common[i];
+                for (uint32_t st = 0; st < 2; ++st) {
+                    uint32_t bits = 0;
+                    for (uint32_t i = 0; i < sdw; ++i) bits += __popc(prog[st * sdw + i]);
+                    if (bits > 1) single = false;
+                }
+            }
+            if (single) {
+                for (uint32_t k = 0; k < r.y; ++k) {
+                    uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
+                    uint32_t desc[2];
+                    for (uint32_t st = 0; st < 2; ++st) {
+                        desc[st] = sdw << 5;
+                        for (uint32_t i = 0; i < sdw; ++i)
+                            if (prog[st * sdw + i]) desc[st] = (i << 5) | (uint32_t)(__ffs(prog[st * sdw + i]) - 1);
+                    }
+                    prog[0] = desc[0];
+                    prog[1] = desc[1];
+                }
+                r.w = 1;
+            }
             r.z = n_prog + g;
         }
     }
