@@ -338,7 +338,24 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
     sg.y = __builtin_amdgcn_readfirstlane(sg.y);
     sg.z = __builtin_amdgcn_readfirstlane(sg.z);
-    uint4 range[NS];                                // {first program, candidates, common program or ~0, -}
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: chunk indices stay scalar
+    // per-slot facts are read from the kernel arguments once, not per chunk
+    StatePlanes stp[NS];
+    bool is_c[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const uint32_t slot = a.active_slot[NS == 1 ? blockIdx.y : (uint32_t)j];
+        stp[j] = a.st[slot];
+        is_c[j] = a.slot_is_c[slot] != 0;
+    }
+    // the wave's first chunk is requested before anything else of the segment is looked at (candidate ranges, LDS
+    // clearing, the barrier): a workgroup lives for four chunks per wave, its start-up chain would otherwise sit
+    // in front of every fourth memory round trip
+    constexpr bool EARLY = K::CF && K::LIT;          // (the 8-plane light tiles would drop from 5 to 4 waves per SIMD)
+    RawChunk<K> first;
+    if (EARLY && wave < sg.y) first.load(a.seq, stp, sg.x + wave, lane);
+    uint4 range[NS];                                // {first program, candidates, common program or ~0, siblings}
     uint32_t most = 0;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
@@ -351,40 +368,28 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
         most = max(most, range[j].y);
     }
     if (most == 0) return;
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: chunk indices stay scalar
-    // per-slot facts are read from the kernel arguments once, not per chunk
-    StatePlanes stp[NS];
-    bool is_c[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const uint32_t slot = a.active_slot[NS == 1 ? blockIdx.y : (uint32_t)j];
-        stp[j] = a.st[slot];
-        is_c[j] = a.slot_is_c[slot] != 0;
-    }
 
-    for (uint32_t pass0 = 0; pass0 < most; pass0 += H) {
-        // LDS rows in use this pass: row = k * NS + j for candidate k of slot j
-        const uint32_t rows_hi = NS * min(H, most - pass0);
+    // one chunk of one pass: tile, then every slot's candidates of this pass
+    auto score_chunk = [&](const RawChunk<K> &cur, uint32_t pass0) {
+        Tile<K> tile;
+        tile.expand(cur);
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (range[j].y <= pass0) continue;                       // wave-uniform
+            const uint32_t nbj = min(H, range[j].y - pass0);
+            if (K::COMPACT && is_c[j])
+                score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
+            else
+                score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
+        }
+    };
+    auto clear_rows = [&](uint32_t rows_hi) {
         for (uint32_t i = threadIdx.x; i < rows_hi * 128; i += 256) lds_acc[i] = 0;
         __syncthreads();
-        for (uint32_t ck = wave; ck < sg.y; ck += 4) {
-            RawChunk<K> cur;
-            cur.load(a.seq, stp, sg.x + ck, lane);
-            Tile<K> tile;
-            tile.expand(cur);
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                if (range[j].y <= pass0) continue;                       // wave-uniform
-                const uint32_t nbj = min(H, range[j].y - pass0);
-                if (K::COMPACT && is_c[j])
-                    score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
-                else
-                    score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
-            }
-        }
+    };
+    // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
+    auto flush_rows = [&](uint32_t rows_hi, uint32_t pass0) {
         __syncthreads();
-        // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
         for (uint32_t idx = threadIdx.x; idx < rows_hi * 8; idx += 256) {
             const uint32_t i = idx >> 2, q = idx & 3;               // i = counter row: (k * NS + j) * 2 + which
             const uint32_t j = (i >> 1) % NS, k = (i >> 1) / NS;
@@ -405,6 +410,30 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
             }
         }
         __syncthreads();
+    };
+    // LDS rows in use in a pass: row = k * NS + j for candidate k of slot j
+    uint32_t pass0 = 0;
+    if (EARLY) {                                                     // pass 0 with the chunk already under way
+        const uint32_t rows_hi = NS * min(H, most);
+        clear_rows(rows_hi);
+        if (wave < sg.y) score_chunk(first, 0);
+        for (uint32_t ck = wave + 4; ck < sg.y; ck += 4) {
+            RawChunk<K> cur;
+            cur.load(a.seq, stp, sg.x + ck, lane);
+            score_chunk(cur, 0);
+        }
+        flush_rows(rows_hi, 0);
+        pass0 = H;
+    }
+    for (; pass0 < most; pass0 += H) {
+        const uint32_t rows_hi = NS * min(H, most - pass0);
+        clear_rows(rows_hi);
+        for (uint32_t ck = wave; ck < sg.y; ck += 4) {
+            RawChunk<K> cur;
+            cur.load(a.seq, stp, sg.x + ck, lane);
+            score_chunk(cur, pass0);
+        }
+        flush_rows(rows_hi, pass0);
     }
 }
 
