@@ -134,13 +134,44 @@ class Collective:
             self.pending.pop(slot).wait()
 
 
+def usable_cores():
+    """CPUs this process can really run on at once: the smallest of os.cpu_count(), the scheduler affinity and the
+    cgroup CPU quota (a 256-core host may hand a container 16 CPUs' worth of time: 256 busy workers then run 16x
+    throttled and a pool of that size measures the throttling, not the host)."""
+    n = os.cpu_count() or 1
+    why = f"os.cpu_count() = {n}"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, why = a, f"sched_getaffinity = {a}"
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(float(quota) / period))
+                if q < n:
+                    n, why = q, f"cgroup CPU quota = {float(quota) / period:g} CPUs ({path})"
+            break
+        except Exception:
+            continue
+    return n, why
+
+
 def cpu_baseline(result, final, cands, mg, spec_kw, args):
-    """Rank 0, N = 1: the oracle on a bounded sample of the same workload, on ALL host cores (T = os.cpu_count(),
-    wall-clock of the concurrent scan phase, pool overhead included) and on ONE core, with the
+    """Rank 0, N = 1: the oracle on a bounded sample of the same workload, on ALL host cores (T = the CPUs this process may use:
+    os.cpu_count() capped by affinity and the cgroup quota; wall-clock of the concurrent scan phase, pool overhead
+    included) and on ONE core, with the
     sampled bins' counts compared bit for bit with the GPU table."""
     from oracle import pipeline as opl
     ncores = os.cpu_count() or 1
-    procs = args.cpu_procs if args.cpu_procs > 0 else ncores
+    usable, why = usable_cores()
+    procs = args.cpu_procs if args.cpu_procs > 0 else usable
     try:
         import psutil
         avail = psutil.virtual_memory().available
@@ -181,7 +212,7 @@ def cpu_baseline(result, final, cands, mg, spec_kw, args):
                   f"(regex overlapped finditer + numpy.isin per contig and strand) on {procs} concurrent spawn processes, one bin per task, "
                   f"wall-clock {wall:.2f} s of the scan phase (inputs built before a barrier; {total_wall:.1f} s with process start and "
                   f"input generation), {cpu_seconds:.1f} CPU-seconds; -t 1: {min(len(jobs), max(1, args.cpu_t1_bins))} bins in {t1_secs:.1f} s",
-        "host_cores_available": ncores,
+        "host_cores_visible": ncores, "host_cores_usable": usable, "usable_limit": why,
     }
     result["parity"] = {"candidates_checked": checked, "mismatches": mismatches,
                         "against": "oracle/scan.py on the sampled bins (bit-exact integer counts)"}

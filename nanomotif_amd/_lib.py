@@ -19,6 +19,7 @@ SYMBOLS = [
 ]
 
 _lib = None
+loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
 
 
 class NmScanError(RuntimeError):
@@ -51,7 +52,21 @@ def load():
             import torch  # noqa: F401
         except Exception:  # pragma: no cover - torch is plumbing only
             pass
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    global loaded_with_torch
+    try:
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as first:
+        # no system HIP runtime reachable through the library's RUNPATH (a host that only has torch's bundled ROCm, or
+        # a library built elsewhere): torch's libamdhip64 has the same SONAME — load it first and try once more
+        try:
+            import torch  # noqa: F401
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        except Exception as second:
+            raise NmScanError(
+                f"cannot load {LIB_PATH}: {first}.  It needs the ROCm HIP runtime (libamdhip64.so): install ROCm under "
+                f"/opt/rocm (or set ROCM_PATH when building), or make PyTorch-ROCm importable (retry after importing torch: "
+                f"{second}).  nanomotif_amd has no CPU fallback.") from first
+    loaded_with_torch = "torch" in sys.modules
     p = C.c_void_p
     u8p, u32p, u64p, i64p, f64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint32, C.c_uint64, C.c_int64, C.c_double))
     lib.nm_abi_version.restype = C.c_int

@@ -17,7 +17,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + SRC_HIP + SRC_HOST + ["-lz", "-lpthread"]
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    # explicit RUNPATH: the torch-free CLI path loads the system HIP runtime through it (nanomotif_amd/_lib.py)
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + SRC_HIP + SRC_HOST + \
+          ["-lz", "-lpthread", "-ldl", f"-Wl,-rpath,{rocm}/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

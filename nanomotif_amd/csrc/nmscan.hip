@@ -902,16 +902,7 @@ int nm_abi_version(void) { return 1; }
 
 const char *nm_last_error(void) { return g_err.c_str(); }
 
-int nm_ctx_create(int device, nm_ctx **out) {
-    if (!out) return fail(NM_EINVAL, "out is NULL");
-    *out = nullptr;
-    int n = 0;
-    HIP_TRY(hipGetDeviceCount(&n));
-    if (device < 0 || device >= n) return fail(NM_EINVAL, "device %d not in 0..%d", device, n - 1);
-    HIP_TRY(hipSetDevice(device));
-    nm_ctx *c = new (std::nothrow) nm_ctx();
-    if (!c) return fail(NM_ENOMEM, "out of host memory");
-    c->device = device;
+static int ctx_init(nm_ctx *c) {
     c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
     c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
     if (const char *e = getenv("NM_SEG_CHUNKS")) c->seg_chunks = (uint32_t)std::max(4, atoi(e));
@@ -923,6 +914,27 @@ int nm_ctx_create(int device, nm_ctx **out) {
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc(&c->d_err, sizeof(unsigned int)));
     HIP_TRY(hipMalloc(&c->d_other, sizeof(unsigned long long)));
+    return NM_OK;
+}
+
+int nm_ctx_create(int device, nm_ctx **out) {
+    if (!out) return fail(NM_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(NM_EINVAL, "device %d not in 0..%d", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    nm_ctx *c = new (std::nothrow) nm_ctx();
+    if (!c) return fail(NM_ENOMEM, "out of host memory");
+    c->device = device;
+    c->stream = nullptr;
+    const int rc = ctx_init(c);
+    if (rc != NM_OK) {                 // nm_ctx_destroy releases whatever was created (the error text is already set)
+        const std::string keep = g_err;
+        (void)nm_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
     return NM_OK;
 }
@@ -957,7 +969,7 @@ static void free_assembly(nm_ctx *c) {
 int nm_ctx_destroy(nm_ctx *c) {
     if (!c) return NM_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_assembly(c);
     for (auto &st : c->stage) {
         if (st.d) (void)hipFree(st.d);
@@ -994,16 +1006,30 @@ int nm_set_stream(nm_ctx *c, void *hip_stream) {
 
 static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
                                uint32_t n_bins, const uint8_t *seq_ascii, bool on_device) {
-    if (!c || !offsets || !bin_id || !seq_ascii) return fail(NM_EINVAL, "NULL argument");
-    if (n_contigs == 0 || n_bins == 0) return fail(NM_EINVAL, "need at least one contig and one bin");
+    // n_contigs == 0 is a valid shard: a rank of a multi-GPU run that received no contig (more GPUs than pieces) holds
+    // the bins' numbering and two pad chunks, scores every candidate to zero and still joins every collective
+    if (!c || !offsets || (n_contigs && (!bin_id || !seq_ascii))) return fail(NM_EINVAL, "NULL argument");
+    if (n_bins == 0) return fail(NM_EINVAL, "need at least one bin");
     if (offsets[0] != 0) return fail(NM_EINVAL, "offsets[0] must be 0");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     free_assembly(c);
+    // any failure below leaves the ctx WITHOUT an assembly (dH == nullptr, so scoring refuses) and frees the temporaries
+    struct Rollback {
+        nm_ctx *c;
+        void *tmp[3] = {nullptr, nullptr, nullptr};
+        bool keep = false;
+        ~Rollback() {
+            (void)hipStreamSynchronize(c->stream);          // nothing may still read the temporaries
+            for (void *p : tmp)
+                if (p) (void)hipFree(p);
+            if (!keep) free_assembly(c);
+        }
+    } guard{c};
     c->n_contigs = n_contigs;
     c->n_bins = n_bins;
     c->contig_len.assign(n_contigs, 0);
-    c->contig_bin.assign(bin_id, bin_id + n_contigs);
+    c->contig_bin.assign(bin_id, bin_id + (bin_id ? n_contigs : 0));
     c->contig_chunk.assign(n_contigs, 0);
     c->contig_nchunks.assign(n_contigs, 0);
     c->total_bp = offsets[n_contigs];
@@ -1043,8 +1069,8 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     HIP_TRY(hipMemsetAsync(c->dH, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->dL, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->dV, 0, words * 4, c->stream));
-    HIP_TRY(hipMalloc(&c->d_contig_chunk, (size_t)n_contigs * 4));
-    HIP_TRY(hipMalloc(&c->d_contig_len, (size_t)n_contigs * 8));
+    HIP_TRY(hipMalloc(&c->d_contig_chunk, (size_t)std::max(n_contigs, 1u) * 4));
+    HIP_TRY(hipMalloc(&c->d_contig_len, (size_t)std::max(n_contigs, 1u) * 8));
     HIP_TRY(hipMemcpyAsync(c->d_contig_chunk, c->contig_chunk.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_contig_len, c->contig_len.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, c->stream));
     // temporaries for the pack pass
@@ -1052,10 +1078,15 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     uint64_t *d_off = nullptr;
     uint32_t *d_chunk_contig = nullptr;
     if (on_device) d_ascii = const_cast<uint8_t *>(seq_ascii);
-    else HIP_TRY(hipMalloc(&d_ascii, c->total_bp));
+    else {
+        HIP_TRY(hipMalloc(&d_ascii, std::max<uint64_t>(c->total_bp, 1)));
+        guard.tmp[0] = d_ascii;
+    }
     HIP_TRY(hipMalloc(&d_off, (size_t)(n_contigs + 1) * 8));
+    guard.tmp[1] = d_off;
     HIP_TRY(hipMalloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
-    if (!on_device) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
+    guard.tmp[2] = d_chunk_contig;
+    if (!on_device && c->total_bp) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_other, 0, sizeof(unsigned long long), c->stream));
@@ -1070,15 +1101,13 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         for (uint32_t k = 0; k < c->bin_nchunks[b]; k += c->seg_chunks)
             segs.push_back(make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(c->seg_chunks, c->bin_nchunks[b] - k), b, 0));
     c->n_segments = (uint32_t)segs.size();
-    HIP_TRY(hipMalloc(&c->d_segments, segs.size() * sizeof(uint4)));
-    HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMalloc(&c->d_segments, std::max<size_t>(segs.size(), 1) * sizeof(uint4)));
+    if (!segs.empty()) HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     unsigned long long other = 0;
     HIP_TRY(hipMemcpyAsync(&other, c->d_other, sizeof other, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->other_letters = other;
-    if (!on_device) (void)hipFree(d_ascii);
-    (void)hipFree(d_off);
-    (void)hipFree(d_chunk_contig);
+    guard.keep = true;
     return NM_OK;
 }
 

@@ -412,7 +412,7 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
         uint8_t *d_sets = nullptr;
         HIP_TRY(hipMalloc(&d_sets, (size_t)n_windows * width));
         HIP_TRY(hipMemcpyAsync(d_sets, sets, (size_t)n_windows * width, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(win_pack_kernel, dim3((t.nw + 255) / 256, width), dim3(256), 0, c->stream, t, d_sets,
+        if (t.nw) hipLaunchKernelGGL(win_pack_kernel, dim3((t.nw + 255) / 256, width), dim3(256), 0, c->stream, t, d_sets,
                            c->d_win_planes, c->d_win_alive);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -462,7 +462,7 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     memcpy(hs + o_sets, req_sets, (size_t)n_req * WIN_MAX_W);
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
-    const uint32_t gy = std::min<uint32_t>(64, (max_nw + 255) / 256);
+    const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
     hipLaunchKernelGGL(win_request_kernel, dim3(n_req, gy), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), stride);
@@ -492,7 +492,7 @@ static int ensure_rank(nm_ctx *c, int b) {
     if (c->d_rank[b]) return NM_OK;
     HIP_TRY(hipMalloc(&c->d_rank[b], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
     HIP_TRY(hipMalloc(&c->d_base_total[b], (size_t)c->n_contigs * 8));
-    hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
+    if (c->n_contigs) hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
                        static_cast<const uint32_t *>(nullptr), c->d_contig_chunk, c->d_contig_len, b, c->d_rank[b],
                        c->d_base_total[b]);
     HIP_TRY(hipGetLastError());
@@ -517,7 +517,7 @@ int nm_contig_base_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t *out) 
     if (rc) return rc;
     uint64_t *d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 8));
-    hipLaunchKernelGGL(base_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, seq_planes(c),
+    if (c->n_contigs) hipLaunchKernelGGL(base_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, seq_planes(c),
                        c->d_contig_chunk, c->d_contig_len, c->n_contigs, b, pad, c->d_base_total[b], d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)c->n_contigs * 8, hipMemcpyDeviceToHost, c->stream));
@@ -617,7 +617,7 @@ int nm_win_add_task_rows(nm_ctx *c, uint32_t n_rows, const uint32_t *contig_id, 
         }
         memcpy(hs + o_minus, minus, n_rows);
         HIP_TRY(hipMemcpyAsync(ds, hs, o_minus + n_rows, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(win_gather_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
+        if (n_rows) hipLaunchKernelGGL(win_gather_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
                            reinterpret_cast<const uint64_t *>(ds), ds + o_minus, pad, c->d_win_planes, c->d_win_alive);
         HIP_TRY(hipGetLastError());
         rc = release_stage(c);
@@ -638,7 +638,7 @@ static int ensure_slot_counts(nm_ctx *c, uint32_t slot, uint32_t pad) {
         for (int k = 0; k < 2; ++k) {
             HIP_TRY(hipMalloc(&ms.rank[k], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
             HIP_TRY(hipMalloc(&ms.rank_total[k], (size_t)c->n_contigs * 8));
-            hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
+            if (c->n_contigs) hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
                                static_cast<const uint32_t *>(ms.planes[k == 0 ? 2 : 4]), c->d_contig_chunk, c->d_contig_len, -1,
                                ms.rank[k], ms.rank_total[k]);
             HIP_TRY(hipGetLastError());
@@ -648,7 +648,7 @@ static int ensure_slot_counts(nm_ctx *c, uint32_t slot, uint32_t pad) {
     if (ms.meth_pad == pad && ms.meth_counts.size() == (size_t)c->n_contigs * 4) return NM_OK;
     uint64_t *d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 4 * 8));
-    hipLaunchKernelGGL(meth_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, ms.planes[2], ms.planes[4],
+    if (c->n_contigs) hipLaunchKernelGGL(meth_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, ms.planes[2], ms.planes[4],
                        c->d_contig_chunk, c->d_contig_len, c->n_contigs, pad, ms.rank_total[0], ms.rank_total[1], d_out);
     HIP_TRY(hipGetLastError());
     ms.meth_counts.assign((size_t)c->n_contigs * 4, 0);
@@ -715,7 +715,7 @@ int nm_win_add_task_contigs(nm_ctx *c, uint32_t mod_slot, uint32_t n_contigs, co
         memcpy(c->h_stage, segs.data(), segs.size() * sizeof(WinSegment));
         HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, segs.size() * sizeof(WinSegment), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
-        hipLaunchKernelGGL(win_gather_contigs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
+        if (t.n) hipLaunchKernelGGL(win_gather_contigs_kernel, dim3((t.n + 255) / 256), dim3(256), 0, c->stream, t, seq_planes(c),
                            static_cast<const uint32_t *>(ms.planes[2]), static_cast<const uint32_t *>(ms.planes[4]),
                            static_cast<const uint32_t *>(ms.rank[0]), static_cast<const uint32_t *>(ms.rank[1]), c->d_contig_chunk,
                            c->d_contig_len, reinterpret_cast<const WinSegment *>(c->d_stage), (uint32_t)segs.size(), pad,

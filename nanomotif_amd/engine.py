@@ -265,7 +265,7 @@ class ScanEngine:
         bin_of_contig: bin name per contig.  Bin ids are assigned in sorted bin-name order, or follow
         ``bin_names`` when given (a multi-GPU shard may hold no contig of some bins but must number them alike)."""
         names = list(names)
-        if not names:
+        if not names and bin_names is None:
             raise ValueError("assembly is empty")
         bufs = []
         for s in sequences:
@@ -275,10 +275,12 @@ class ScanEngine:
         lengths = np.array([len(b) for b in bufs], dtype=np.uint64)
         offsets = np.zeros(len(bufs) + 1, dtype=np.uint64)
         np.cumsum(lengths, out=offsets[1:])
-        ascii_all = np.concatenate(bufs) if len(bufs) > 1 else np.ascontiguousarray(bufs[0])
+        # no contig at all = the shard of a rank that received nothing (more GPUs than pieces): it keeps the bin
+        # numbering, scores everything to zero and joins every collective (nm_upload_contigs accepts n_contigs = 0)
+        ascii_all = np.concatenate(bufs) if len(bufs) > 1 else (np.ascontiguousarray(bufs[0]) if bufs else np.zeros(1, np.uint8))
         self.bin_names = sorted(set(bin_of_contig)) if bin_names is None else list(bin_names)
         self.bin_index = {b: i for i, b in enumerate(self.bin_names)}
-        bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
+        bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32) if names else np.zeros(1, np.uint32)
         _lib.check(self.lib.nm_upload_contigs(self.ctx, len(names), _ptr(offsets, C.c_uint64), _ptr(bin_ids, C.c_uint32),
                                               len(self.bin_names), _ptr(ascii_all, C.c_uint8)))
         self.contig_names = names
@@ -377,18 +379,24 @@ class ScanEngine:
             canon[int(code)] = ord(base)
         n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        parts = self._pileup_parts(cid, max_part_rows) if max_part_rows and n > max_part_rows else None
-        if parts is None:
-            _lib.check(self.lib.nm_ingest_pileup(self.ctx, n, vp(cid), vp(pos), vp(mod), vp(st), vp(fr), vp(nv), slot_of, canon,
+        # always ingest in PARTS of whole contigs listing the contigs that have rows (nm_ingest_pileup_part): the dense
+        # adjacency scratch (16 B per bp) then covers those contigs only, not the whole resident assembly — a multi-Gbp
+        # assembly with a modest pileup would otherwise ask for tens of GB it does not need
+        parts = self._pileup_parts(cid, max_part_rows if (max_part_rows and n > max_part_rows) else max(n, 1)) if n else []
+        if parts is None:                 # some contig's rows are not contiguous: one part with every contig present
+            parts = [(0, n)]
+        if n == 0:
+            _lib.check(self.lib.nm_ingest_pileup(self.ctx, 0, None, None, None, None, None, None, slot_of, canon,
                                                  float(low), float(high), 0, C.byref(n_kept), C.byref(n_conf)))
-        else:
-            for k, (a, b) in enumerate(parts):
-                ids = np.unique(cid[a:b])
-                ids = np.ascontiguousarray(ids[ids != 0xFFFFFFFF], dtype=np.uint32)
-                sl = lambda x: vp(x[a:b]) if b > a else None
-                _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, b - a, sl(cid), sl(pos), sl(mod), sl(st), sl(fr), sl(nv), slot_of, canon,
-                                                          float(low), float(high), 0, 1 if k == 0 else 0, len(ids), _ptr(ids, C.c_uint32),
-                                                          C.byref(n_kept), C.byref(n_conf)))
+        for k, (a, b) in enumerate(parts):
+            seg = cid[a:b]
+            edge = np.concatenate([[0], np.flatnonzero(seg[1:] != seg[:-1]) + 1]) if b > a else np.zeros(0, np.int64)
+            ids = np.unique(seg[edge])
+            ids = np.ascontiguousarray(ids[ids != 0xFFFFFFFF], dtype=np.uint32)
+            sl = lambda x: vp(x[a:b]) if b > a else None
+            _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, b - a, sl(cid), sl(pos), sl(mod), sl(st), sl(fr), sl(nv), slot_of, canon,
+                                                      float(low), float(high), 0, 1 if k == 0 else 0, len(ids), _ptr(ids, C.c_uint32),
+                                                      C.byref(n_kept), C.byref(n_conf)))
         self._n_confident = int(n_conf.value)
         kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
         _lib.check(self.lib.nm_ingest_results(self.ctx, None, None, None, None, 0, _ptr(kept, C.c_uint32)))

@@ -25,6 +25,7 @@ from .pileup import MOD_TYPES, PileupTable
 from .search import HostWindowStore, extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
 
 IUPAC_LETTERS = set("ATGCRYSWKMBDHVN")
+MAX_WINDOW_WIDTH = 64          # include/nmscan.h: NM_WIN_MAX_WIDTH
 
 
 # ------------------------------------------------------------------------------------------------ config
@@ -63,6 +64,11 @@ class ProcessorConfig:
             raise ValueError("threads must be greater than 0")
         if self.search_frame_size <= 1:
             raise ValueError("search_frame_size must be greater than 1")
+        if 2 * (self.search_frame_size // 2) + 1 > MAX_WINDOW_WIDTH:
+            # the reference takes any frame (find_motifs_bin.py:128-130); the engine's window planes and motif offsets
+            # are 64 positions wide (include/nmscan.h: NM_WIN_MAX_WIDTH, NM_MAX_MOTIF_LEN)
+            raise ValueError(f"search_frame_size must be at most {MAX_WINDOW_WIDTH - 1} on the MI355X engine "
+                             f"(windows of 2 * (search_frame_size // 2) + 1 <= {MAX_WINDOW_WIDTH} positions)")
         if not (0 <= self.methylation_threshold_high <= 1):
             raise ValueError("methylation_threshold_high must be in [0,1]")
         if not (0 <= self.methylation_threshold_low <= 1):
@@ -141,6 +147,12 @@ def engine_scorer(engine, low=0.3, high=0.7, use_dist=False, group=None) -> Lock
 
 def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
     """Sum int64 count tables over ranks: nccl(=RCCL) moves them through the GPU, gloo on CPU."""
+    from . import _lib
+    if _lib._lib is not None and not _lib.loaded_with_torch:
+        # the library came up on the system HIP runtime (torch-free CLI start); importing torch now would put a second
+        # runtime into the process
+        raise RuntimeError("allreduce_counts needs libnmscan loaded after torch (multi-rank runs import torch first: "
+                           "set NANOMOTIF_WITH_TORCH=1 or start through torch.distributed.run)")
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(counts))

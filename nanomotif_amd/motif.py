@@ -223,7 +223,6 @@ class Motif(str):
         e0, e1 = len(self.tokens) - self.mod_position, len(other.tokens) - other.mod_position
         d = 0
         for i in range(min(s0, s1), max(e0, e1)):
-            in_a, in_b = s0 <= i < e0, s1 <= i < e1
             # the reference's elif ladder (motif.py:140-157): left overhang first, then right overhang
             if i < s0:
                 d += other.tokens[i - s1] != "."
@@ -238,7 +237,6 @@ class Motif(str):
                 same = (ta == tb) or (ta not in ".N" and tb not in ".N" and self.sets[i - s0] == other.sets[i - s1]
                                       and ta.startswith("[") == tb.startswith("["))
                 d += not same
-            del in_a, in_b
         return int(d)
 
     def _isolated(self, k):

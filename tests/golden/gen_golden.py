@@ -334,6 +334,11 @@ def g7(nm):
 
 
 if __name__ == "__main__":
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        # the reference appends missed candidates in SET order (find_motifs_bin.py:826-833): pin the hash seed so that
+        # the recipe reproduces the committed fixtures byte for byte
+        os.environ["PYTHONHASHSEED"] = "0"
+        os.execv(sys.executable, [sys.executable] + sys.argv)
     nm = refstub.load_reference()
     which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for w in which:

@@ -61,7 +61,7 @@ def test_two_rank_sharded_search_equals_single_rank():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = {}
-    for world in (1, 2):
+    for world in (1, 2, 4):                  # 3 contigs: with 4 ranks one rank holds NO contig and must still take part
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -74,8 +74,9 @@ def test_two_rank_sharded_search_equals_single_rank():
         out[world] = sorted(got)
     single = out[1][0][1]
     assert "GATC" in single and "CCWGG" in single
-    assert all(text == single for _, text, _ in out[2])            # both ranks, same answer as one rank
-    assert out[2][0][2] == out[2][1][2] == out[1][0][2]            # same number of lock-step rounds
+    for world in (2, 4):
+        assert all(text == single for _, text, _ in out[world])    # every rank, same answer as one rank
+        assert {r for _, _, r in out[world]} == {out[1][0][2]}     # same number of lock-step rounds
 
 
 def test_contig_assignment_is_balanced_and_complete():

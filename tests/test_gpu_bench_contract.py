@@ -35,7 +35,7 @@ def test_bench_json_contract():
     assert "traffic" in rf and rf["kernel_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
-    assert cb["value_t1"] > 0 and cb["host_cores_available"] >= cb["cores"]
+    assert cb["value_t1"] > 0 and cb["host_cores_visible"] >= cb["host_cores_usable"] >= 1
     assert d["parity"]["mismatches"] == 0 and d["parity"]["candidates_checked"] > 0
     # extras of the default run: end to end on the same metagenome, all-bins table, the HBM-bound round
     e = d["e2e"]

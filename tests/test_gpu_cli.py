@@ -22,7 +22,7 @@ def _free_port():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_cli(tmp, args, nproc=1):
+def _run_cli(tmp, args, nproc=1, check=True):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "nanomotif_amd", "motif_discovery"] + args
     if nproc > 1:      # several ranks on the one GPU of the test box: gloo carries the all-reduces
@@ -30,7 +30,7 @@ def _run_cli(tmp, args, nproc=1):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), "-m", "nanomotif_amd", "motif_discovery", "--device", "0"] + args
     r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert not check or r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return r
 
 
@@ -113,6 +113,35 @@ def test_two_ranks_give_the_single_rank_output(tmp_path):
         assert ("whole bins per GPU" in r.stdout + r.stderr) == (mode == "bins")
         assert os.path.isdir(f"{tmp}/out_{mode}/precleanup-motifs")
         assert sorted(os.listdir(f"{tmp}/out_{mode}/precleanup-motifs")) == sorted(os.listdir(tmp + "/out1/precleanup-motifs"))
+
+
+def test_more_ranks_than_contigs(tmp_path):
+    """An isolate genome on two ranks with contig sharding: ONE contig, so rank 1 holds nothing — it uploads an empty
+    shard, contributes zero tables and empty window sets and still joins every collective (no hang, same output)."""
+    spec = synth.SynthSpec(n_contigs=1, total_bp=300_000, n_bins=1, mod_types=("a",), seed=64, fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out1"])
+    one = open(tmp + "/out1/bin-motifs.tsv").read()
+    assert "GATC" in one
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out2", "--shard", "contigs"], nproc=2)
+    assert open(tmp + "/out2/bin-motifs.tsv").read() == one
+
+
+def test_search_frame_size_beyond_the_engine_limit_is_refused(tmp_path):
+    """The reference takes any --search_frame_size (find_motifs_bin.py:128-130); the engine's windows are 64 wide."""
+    spec = synth.SynthSpec(n_contigs=1, total_bp=60_000, n_bins=1, mod_types=("a",), seed=62, fixed_motifs=())
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    mg.write_contig_bin(tmp + "/cb.tsv")
+    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "64"], check=False)
+    assert r.returncode != 0 and "search_frame_size must be at most 63" in r.stdout + r.stderr
+    _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o63", "--search_frame_size", "62"])
 
 
 def test_assembly_with_other_iupac_letters_takes_the_host_window_path(tmp_path):
