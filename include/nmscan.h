@@ -223,6 +223,35 @@ int nm_hit_positions(nm_ctx *ctx, uint32_t contig_id, uint32_t mod_slot, uint8_t
  * strand-implied ("compact") state, [7] = on the general 4-plane state. */
 int nm_stats(nm_ctx *ctx, uint64_t what[8]);
 
+/* ---- multi-GPU exchange: sum of the per-rank count tables ------------------------------------------------------
+ * One process per GPU; contigs are sharded over the ranks and counts are sums over contigs
+ * (motif_model_bin, find_motifs_bin.py:1273-1283), so a scoring step on N GPUs ends with ONE all-reduce
+ * (sum, int64) of the table nm_score_batch[_device] produced — RCCL over xGMI, loaded with dlopen("librccl.so.1").
+ *
+ * nm_comm_unique_id: rank 0 makes the 128-byte id; the HOST carries it to the other ranks by whatever it has
+ *   (MPI, a TCP store, a file, torch.distributed.broadcast_object_list — the library does no rendezvous).
+ * nm_comm_init: collective over all `world` ranks; every rank passes the same id and its own rank.  Two ranks on one
+ *   device are refused by RCCL and come back as NM_ESTATE with its message.
+ * nm_allreduce_counts: d_counts (device, int64[n], e.g. the out_counts of nm_score_batch_device) is summed in place
+ *   over all ranks; ordered after the work queued so far on the ctx stream, and later ctx-stream work is ordered
+ *   after it.  Asynchronous for the host: synchronise the ctx stream (or copy on it) before reading on the host.
+ * nm_allreduce_counts_async + nm_comm_wait: the same collective on the ctx's communication stream WITHOUT blocking
+ *   the ctx stream: start the all-reduce of table k (buffer_slot b), queue the scoring of table k+1, and call
+ *   nm_comm_wait(ctx, b) before the ctx stream touches table k's buffer again (device-side wait, returns at once).
+ * nm_allreduce_counts_host: host int64[n] in, summed host int64[n] out (staged through the ctx; blocking) — for
+ *   hosts that keep the tables in host memory (the Python lock-step scheduler).
+ * nm_comm_sync: host waits for every outstanding all-reduce.  nm_comm_destroy: also done by nm_ctx_destroy. */
+#define NM_COMM_ID_BYTES 128
+#define NM_COMM_SLOTS 4
+int nm_comm_unique_id(uint8_t id[NM_COMM_ID_BYTES]);
+int nm_comm_init(nm_ctx *ctx, int rank, int world, const uint8_t id[NM_COMM_ID_BYTES]);
+int nm_allreduce_counts(nm_ctx *ctx, int64_t *d_counts, uint64_t n);
+int nm_allreduce_counts_async(nm_ctx *ctx, int64_t *d_counts, uint64_t n, int buffer_slot);
+int nm_comm_wait(nm_ctx *ctx, int buffer_slot);
+int nm_allreduce_counts_host(nm_ctx *ctx, int64_t *counts, uint64_t n);
+int nm_comm_sync(nm_ctx *ctx);
+int nm_comm_destroy(nm_ctx *ctx);
+
 /* Device time of the last scoring launch(es) in milliseconds, measured with HIP events on the ctx stream
  * (kernels only, no copies).  Blocks until the launch finished. */
 int nm_last_kernel_ms(nm_ctx *ctx, float *ms);

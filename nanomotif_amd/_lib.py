@@ -16,6 +16,8 @@ SYMBOLS = [
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_window_letter_counts", "nm_bed_open", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
+    "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
+    "nm_comm_sync", "nm_comm_destroy",
 ]
 
 _lib = None
@@ -117,6 +119,14 @@ def load():
     lib.nm_fasta_sequence.argtypes = [p, C.POINTER(p)]
     lib.nm_fasta_close.argtypes = [p]
     lib.nm_timing_reset.argtypes = [p, C.c_int]
+    lib.nm_comm_unique_id.argtypes = [u8p]
+    lib.nm_comm_init.argtypes = [p, C.c_int, C.c_int, u8p]
+    lib.nm_allreduce_counts.argtypes = [p, p, C.c_uint64]
+    lib.nm_allreduce_counts_async.argtypes = [p, p, C.c_uint64, C.c_int]
+    lib.nm_comm_wait.argtypes = [p, C.c_int]
+    lib.nm_allreduce_counts_host.argtypes = [p, i64p, C.c_uint64]
+    lib.nm_comm_sync.argtypes = [p]
+    lib.nm_comm_destroy.argtypes = [p]
     lib.nm_timing_total_ms.argtypes = [p, C.POINTER(C.c_double), u64p]
     for s in SYMBOLS:
         if s != "nm_last_error":

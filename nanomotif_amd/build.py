@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_HIP = [os.path.join(_HERE, "csrc", f) for f in ("nmscan.hip", "nmingest.hip", "nmwindows.hip")]
-SRC_HOST = [os.path.join(_HERE, "csrc", "nmbed.cpp"), os.path.join(_HERE, "csrc", "nmhost.cpp")]
+SRC_HOST = [os.path.join(_HERE, "csrc", f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp")]
 INTERNAL = os.path.join(_HERE, "csrc", "nmscan_internal.h")
 OUT = os.path.join(_HERE, "libnmscan.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")

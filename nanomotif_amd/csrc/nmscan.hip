@@ -970,6 +970,7 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (!c) return NM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)nm_comm_destroy(c);
     free_assembly(c);
     for (auto &st : c->stage) {
         if (st.d) (void)hipFree(st.d);

@@ -130,6 +130,12 @@ struct nm_ctx {
     unsigned long long *d_other = nullptr;
     uint64_t other_letters = 0;
     uint64_t launches = 0, last_wgs = 0, last_compact = 0, last_general = 0;
+    // multi-GPU exchange (nmcomm.cpp): RCCL communicator, its stream, one completion event per table buffer
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr, comm_done[NM_COMM_SLOTS] = {};
+    bool comm_pending[NM_COMM_SLOTS] = {};
     // kernel-variant switches for A/B runs (environment: NM_NO_LIT, NM_NO_CF, NM_PREFETCH), read at nm_ctx_create
     bool opt_no_lit = false, opt_no_cf = false;
     uint32_t seg_chunks = nmdetail::SEG_CHUNKS;      // chunks per workgroup segment (NM_SEG_CHUNKS)

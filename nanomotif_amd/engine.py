@@ -239,6 +239,7 @@ class ScanEngine:
         self.bin_index = {}
         self.bin_names = []
         self.slot_of_mod = {}
+        self.comm_world = 0
 
     def close(self):
         if self.ctx:
@@ -502,6 +503,37 @@ class ScanEngine:
             if n.value <= cap:
                 return out[:n.value].copy()
             cap = int(n.value)
+
+    # ------------------------------------------------------------------ multi-GPU exchange (nm_comm_*, RCCL)
+    def comm_unique_id(self) -> bytes:
+        """The 128-byte id rank 0 creates; the host carries it to the other ranks (nm_comm_unique_id)."""
+        buf = (C.c_uint8 * 128)()
+        _lib.check(self.lib.nm_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        """Collective: join the RCCL communicator of the run (nm_comm_init)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self.lib.nm_comm_init(self.ctx, int(rank), int(world), buf))
+        self.comm_world = int(world)
+
+    def allreduce_counts_device(self, device_ptr: int, n: int, slot: int = 0):
+        """Start the in-place sum of a device int64[n] table over all ranks on the communication stream
+        (nm_allreduce_counts_async); ``comm_wait(slot)`` before the engine stream touches that buffer again."""
+        _lib.check(self.lib.nm_allreduce_counts_async(self.ctx, C.c_void_p(device_ptr), int(n), int(slot)))
+
+    def comm_wait(self, slot: int = 0):
+        _lib.check(self.lib.nm_comm_wait(self.ctx, int(slot)))
+
+    def comm_sync(self):
+        _lib.check(self.lib.nm_comm_sync(self.ctx))
+
+    def allreduce_host(self, counts: np.ndarray) -> np.ndarray:
+        """Sum an integer numpy array over all ranks (nm_allreduce_counts_host); returns the same dtype and shape."""
+        a = np.ascontiguousarray(counts, dtype=np.int64).copy()
+        if a.size:
+            _lib.check(self.lib.nm_allreduce_counts_host(self.ctx, _ptr(a, C.c_int64), a.size))
+        return a.astype(counts.dtype, copy=False).reshape(counts.shape)
 
     # ------------------------------------------------------------------ measurement
     def stats(self) -> dict:

@@ -145,8 +145,21 @@ def engine_scorer(engine, low=0.3, high=0.7, use_dist=False, group=None) -> Lock
                           low, high, use_dist, group)
 
 
+_native_reducer = None
+
+
+def use_native_allreduce(engine):
+    """Route ``allreduce_counts`` through the C ABI's own RCCL communicator (``engine.comm_init`` done on every rank;
+    include/nmscan.h: nm_allreduce_counts_host) instead of torch.distributed; ``None`` switches back."""
+    global _native_reducer
+    _native_reducer = engine
+
+
 def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
-    """Sum int64 count tables over ranks: nccl(=RCCL) moves them through the GPU, gloo on CPU."""
+    """Sum int64 count tables over ranks: the library's RCCL communicator when one is up
+    (``use_native_allreduce``), else torch.distributed — nccl(=RCCL) through the GPU, gloo on CPU."""
+    if _native_reducer is not None and group is None:
+        return _native_reducer.allreduce_host(np.asarray(counts))
     from . import _lib
     if _lib._lib is not None and not _lib.loaded_with_torch:
         # the library came up on the system HIP runtime (torch-free CLI start); importing torch now would put a second

@@ -19,7 +19,7 @@ import numpy as np
 
 from . import fasta, pileup as pileup_mod, postprocess
 from .argparser import __version__, create_parser
-from .find_motifs_bin import FilteredPileup, ProcessorConfig, allreduce_counts, discover, engine_scorer
+from .find_motifs_bin import FilteredPileup, ProcessorConfig, allreduce_counts, discover, engine_scorer, use_native_allreduce
 from .motif import MOD_TYPE_TO_CANONICAL
 from .shard import assign_bins, assign_contigs
 
@@ -121,6 +121,14 @@ def find_motifs_bin(args):
             return _gather_rows(args, [], rank, gather_world, bin_order)
     else:
         gather_world = 1
+    if world > 1 and dist.get_backend() == "nccl" and os.environ.get("NANOMOTIF_ALLREDUCE", "native") == "native":
+        # the per-round count tables travel through the C ABI's own RCCL communicator (nm_allreduce_counts_host);
+        # torch.distributed only carried the 128-byte id to the ranks
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(rank, world, uid[0])
+        use_native_allreduce(eng)
+        log.info(f"rank {rank}: count tables all-reduced by nm_allreduce_counts (RCCL, {world} ranks)")
     parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
     mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
     all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
@@ -163,6 +171,7 @@ def find_motifs_bin(args):
     scorer = engine_scorer(eng, low, high, use_dist=world > 1)
     rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
                             window_store=store, extractor=extractor)
+    use_native_allreduce(None)
     eng.close()
     return _gather_rows(args, rows, rank, gather_world, bin_order)
 

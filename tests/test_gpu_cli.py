@@ -115,6 +115,23 @@ def test_two_ranks_give_the_single_rank_output(tmp_path):
         assert sorted(os.listdir(f"{tmp}/out_{mode}/precleanup-motifs")) == sorted(os.listdir(tmp + "/out1/precleanup-motifs"))
 
 
+def test_cli_5mc_and_4mc_in_one_pileup(tmp_path):
+    """'m' and '21839' rows share the canonical C (and their positions): two searches per bin on one set of cytosines,
+    their rows mixed in the adjacency filter (dataload.py:236-245)."""
+    spec = synth.SynthSpec(n_contigs=3, total_bp=450_000, n_bins=1, mod_types=("m", "21839"), seed=65, min_contig_bp=80_000,
+                           fixed_motifs=(("CCWGG", 1, "m"), ("GGCC", 2, "21839"), ("CACAG", 1, "21839")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    mg.write_contig_bin(tmp + "/contig_bin.tsv")
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out"])
+    got = open(tmp + "/out/bin-motifs.tsv").read()
+    assert got == oracle_pipeline(mg)
+    mods = {l.split("\t")[3] for l in got.strip().split("\n")[1:]}
+    assert mods == {"m", "21839"}
+
+
 def test_more_ranks_than_contigs(tmp_path):
     """An isolate genome on two ranks with contig sharding: ONE contig, so rank 1 holds nothing — it uploads an empty
     shard, contributes zero tables and empty window sets and still joins every collective (no hang, same output)."""

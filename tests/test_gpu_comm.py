@@ -1,0 +1,91 @@
+"""nm_comm_* / nm_allreduce_counts (include/nmscan.h): the RCCL exchange step of the C ABI.  The GPU test box has ONE
+device, so the collective itself runs with a world of one rank (the sum over one rank is the identity, all the
+stream / event ordering is exercised); two ranks on one device must come back as a clear error, not a hang."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_communicator_orders_allreduce_after_scoring():
+    import torch
+    from nanomotif_amd import synth
+    from nanomotif_amd._lib import NmScanError
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.motif import Motif
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=4, total_bp=400_000, n_bins=2, mod_types=("a",), seed=7))
+    eng = ScanEngine(0)
+    with pytest.raises(NmScanError, match="nm_comm_init"):
+        eng.allreduce_host(np.arange(4, dtype=np.int64))
+    eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(4)], mg.bin_names)
+    for i in range(4):
+        p = mg.contig_pileup(i, "a")
+        eng.upload_pileup("a", np.full(len(p["position"]), i, np.uint32), p["position"], p["strand"],
+                          synth.pct_to_fraction(p["pct_hundredths"]), append=i > 0)
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128
+    eng.comm_init(0, 1, uid)
+    with pytest.raises(NmScanError, match="already has a communicator"):
+        eng.comm_init(0, 1, uid)
+    cands = [(Motif(s, p), "a", b) for b in sorted(set(mg.bin_names)) for s, p in (("GATC", 1), ("A", 0), ("CA.T", 1))]
+    want = eng.score(cands)
+    batch = eng.make_batch(cands)
+    tables = [torch.zeros((len(cands), 2), dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    for k in range(6):                                   # the bench's double-buffered step
+        i = k & 1
+        eng.comm_wait(i)
+        eng.score_into_device(batch, tables[i].data_ptr())
+        eng.allreduce_counts_device(tables[i].data_ptr(), tables[i].numel(), i)
+    eng.comm_sync()
+    torch.cuda.synchronize()
+    assert np.array_equal(tables[0].cpu().numpy(), want) and np.array_equal(tables[1].cpu().numpy(), want)
+    a = np.arange(10, dtype=np.int64).reshape(5, 2)
+    assert np.array_equal(eng.allreduce_host(a), a)
+    b = np.arange(6, dtype=np.int32)
+    r = eng.allreduce_host(b)
+    assert r.dtype == np.int32 and np.array_equal(r, b)
+    eng.close()
+
+
+_TWO_RANKS = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from nanomotif_amd.engine import ScanEngine
+from nanomotif_amd._lib import NmScanError
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+eng = ScanEngine(0)                                     # both ranks on device 0
+uid = [eng.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+try:
+    eng.comm_init(rank, 2, uid[0])
+    print("RANK", rank, "INIT-OK")
+except NmScanError as e:
+    print("RANK", rank, "REFUSED", e)
+eng.close()
+"""
+
+
+def test_two_ranks_on_one_device_are_refused_not_hung(tmp_path):
+    script = tmp_path / "two.py"
+    script.write_text(_TWO_RANKS)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), ROOT]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.fail("nm_comm_init with two ranks on one device hung instead of failing")
+    out = r.stdout + r.stderr
+    assert "REFUSED" in out and "INIT-OK" not in out, out[-2000:]
+    assert "ncclCommInitRank" in out

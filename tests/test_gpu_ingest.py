@@ -153,3 +153,53 @@ def test_ingest_in_parts_equals_one_piece():
     assert out[0] == out[1] and out[0][0] > 0 and out[0][1] > 0
     # rows of one contig in two places: no parts possible
     assert ScanEngine._pileup_parts(np.array([0, 0, 1, 1, 0], np.uint32), 2) is None
+
+
+def test_5mc_and_4mc_rows_share_positions_and_the_adjacency_filter():
+    """'m' (5mC) and '21839' (4mC) rows sit on the SAME cytosines; the adjacency filter groups by (contig, strand) with
+    the mod types mixed (dataload.py:236-245), so a strong 4mC call can remove a weaker 5mC neighbour and vice versa.
+    Device filters + per-mod-type classification against the oracle filters, then scoring on both classifications."""
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    from oracle.scan import ContigPileup, score_candidates
+    spec = synth.SynthSpec(n_contigs=4, total_bp=500_000, n_bins=2, mod_types=("m", "21839"), seed=83, min_contig_bp=60_000,
+                           fixed_motifs=(("CCWGG", 1, "m"), ("GGCC", 2, "21839"), ("CACAG", 1, "21839")))
+    mg = synth.make_metagenome(spec)
+    cols = []
+    for code, mt in ((0, "m"), (2, "21839")):
+        c = mg.pileup_columns(mt)
+        c["mod"] = np.full(len(c["position"]), code, np.int8)
+        cols.append(c)
+    cat = lambda k: np.concatenate([c[k] for c in cols])
+    t = dict(contig=cat("contig_id").astype(np.int64), position=cat("position"), strand=cat("strand"), mod_type=cat("mod"),
+             fraction_mod=cat("fraction_mod").copy(), Nvalid_cov=cat("nvalid").astype(np.int64))
+    # modkit writes a contig's rows together, ordered by position: both mod codes of one cytosine are neighbours
+    order = np.lexsort((t["mod_type"], t["position"], t["contig"]))
+    t = {k: v[order] for k, v in t.items()}
+    both = (t["position"][1:] == t["position"][:-1]) & (t["contig"][1:] == t["contig"][:-1]) & (t["strand"][1:] == t["strand"][:-1])
+    assert both.sum() > 100_000                                     # the two mod types really share their rows' positions
+    exp = op.prefilter({k: v.copy() for k, v in t.items()})
+    solo = sum(len(op.prefilter({k: v[t["mod_type"] == code].copy() for k, v in t.items()})["position"]) for code in (0, 2))
+    assert len(exp["position"]) < solo                              # mixing the mod types removed rows a per-type filter keeps
+    eng = ScanEngine(0)
+    eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(4)], mg.bin_names)
+    res = eng.ingest_pileup(t["contig"].astype(np.uint32), t["position"], t["mod_type"], t["strand"], t["fraction_mod"],
+                            t["Nvalid_cov"], {0: ("m", "C"), 2: ("21839", "C")})
+    assert res["n_kept"] == len(exp["position"])
+    kept = np.zeros((4, 8), dtype=np.int64)
+    np.add.at(kept, (exp["contig"], exp["mod_type"]), 1)
+    assert np.array_equal(res["kept"].astype(np.int64), kept) and (kept[:, 0] > 0).all() and (kept[:, 2] > 0).all()
+    motifs = [("CC[AT]GG", 1), ("GGCC", 2), ("CACAG", 1), ("C", 0), ("GC", 1), ("[AG]C[CT]", 1)]
+    for code, mt in ((0, "m"), (2, "21839")):
+        for b in sorted(set(mg.bin_names)):
+            idx = [i for i, x in enumerate(mg.bin_names) if x == b]
+            pile = {}
+            for i in idx:
+                s = (exp["contig"] == i) & (exp["mod_type"] == code)
+                pile[mg.names[i]] = ContigPileup(exp["position"][s], exp["strand"][s], exp["fraction_mod"][s])
+            seqs = {mg.names[i]: mg.contig_str(i) for i in idx}
+            expc = score_candidates(pile, seqs, motifs)
+            got = eng.score([(Motif(s, p), mt, b) for s, p in motifs])
+            assert np.array_equal(got, expc), (mt, b)
+            assert got[0].sum() > 0
+    eng.close()
