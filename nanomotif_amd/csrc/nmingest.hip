@@ -272,11 +272,11 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     unsigned long long *d_dense = nullptr, *d_scalars = nullptr;
     uint64_t *d_dense_off = nullptr;
 #define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (hipMalloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
-    ING_ALLOC(d_cnt, n_groups * 2 * 4);
-    ING_ALLOC(d_kept, n_groups * 4);
-    ING_ALLOC(d_ok, n_groups);
+    ING_ALLOC(d_cnt, std::max<size_t>(n_groups, 1) * 2 * 4);
+    ING_ALLOC(d_kept, std::max<size_t>(n_groups, 1) * 4);
+    ING_ALLOC(d_ok, std::max<size_t>(n_groups, 1));
     ING_ALLOC(d_dense, npos * 8 * 2);
-    ING_ALLOC(d_dense_off, (size_t)c->n_contigs * 8);
+    ING_ALLOC(d_dense_off, (size_t)std::max(c->n_contigs, 1u) * 8);
     ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
@@ -288,10 +288,10 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (e == hipSuccess) e = hipMemcpyAsync(d_dense_off, dense_off.data(), (size_t)c->n_contigs * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
     const dim3 blk(256);
-    if (n_rows) {
+    if (n_rows && n_groups) {              // (a shard without contigs ignores every row)
         const dim3 grid((unsigned)((n_rows + 255) / 256));
         hipLaunchKernelGGL(ingest_count_kernel, grid, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
-        hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
+        if (n_groups) hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
         hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, c->d_err);
         hipLaunchKernelGGL(ingest_decide_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)), blk, 0, c->stream, r, 5, d_ok,
                            c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
