@@ -223,6 +223,53 @@ int nm_hit_positions(nm_ctx *ctx, uint32_t contig_id, uint32_t mod_slot, uint8_t
  * strand-implied ("compact") state, [7] = on the general 4-plane state. */
 int nm_stats(nm_ctx *ctx, uint64_t what[8]);
 
+/* ---- the greedy candidate search of all (bin, mod type) tasks, in lock-step ---------------------------------------
+ * find_best_candidates (find_motifs_bin.py:688-839) with MotifSearcher.run (:1026-1182), the KL child generation
+ * (:957-1023), get_parent_scores pruning (:1382-1433), the dead-end / remaining-windows stops and the missed-candidate
+ * rescue (motif.py:594-607), for EVERY task at once: each round, the open requests of all tasks become one window
+ * batch (nm_win_batch: filter_sequence_matches + pssm, or window removal) and one scoring batch (nm_score_batch).
+ * Scores are float64 in the reference's operation order (model.py:78-92, :1371-1379); visit order, heap ties and
+ * thresholds are the reference's, so graphs and best candidates are identical to the Python path.
+ *
+ * Task i: windows of width W = 2 * padding + 1 live in window-engine task task_window[i] (nm_win_add_task*), its
+ * candidates are scored on bin task_bin[i] with classification task_slot[i]; bg_pssm[i] = float64[4][W] background
+ * (rows A, T, G, C, seq.py:391-422); total_windows[i] = windows of the task over all ranks; canonical[i] = 'A' / 'C'.
+ * reduce (may be NULL): sums an int64 array over the ranks of a contig-sharded run, called once per batch.
+ * nm_search_run_custom runs the same state machine on caller-supplied back ends (the CPU tests drive it with the
+ * oracle): score_fn gets n motifs of W characters (A C G T .) with their task index and fills int64[n][2];
+ * window_fn gets n requests (kind 0 = pssm, 1 = remove) and fills int32[n][NM_WIN_OUT_STRIDE] like nm_win_batch.
+ *
+ * Results (nm_search_result_sizes / _export, then _free): per task either "none" (no graph) or the graph in insertion
+ * order — motif characters, raw counts, score, priority, depth, visited, edges as task-local node index pairs — and
+ * the best candidates as node indices (the reference's list order, missed candidates appended in string order). */
+typedef struct nm_search_params {
+    uint32_t padding;                    /* search_frame_size // 2 */
+    uint32_t max_dead_ends;              /* 25 */
+    uint32_t max_rounds_since_new_best;  /* 30 */
+    uint32_t max_motif_length;           /* 25 */
+    double min_kl;                       /* --minimum_kl_divergence */
+    double score_threshold;              /* --min_motif_score */
+    double remaining_threshold;          /* 0.001 */
+    double freq_threshold;               /* 0.15 */
+} nm_search_params;
+typedef struct nm_search_result nm_search_result;
+typedef int (*nm_search_score_fn)(void *user, uint32_t n, const uint32_t *task, const char *motifs, int64_t *out_counts);
+typedef int (*nm_search_window_fn)(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs, int32_t *out);
+typedef int (*nm_search_reduce_fn)(void *user, int64_t *values, uint64_t n);
+int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const uint32_t *task_slot, const uint32_t *task_window,
+                  const nm_search_params *params, const double *bg_pssm, const uint64_t *total_windows, const uint8_t *canonical,
+                  nm_search_reduce_fn reduce, void *reduce_user, nm_search_result **out);
+int nm_search_run_custom(uint32_t n_tasks, const nm_search_params *params, const double *bg_pssm, const uint64_t *total_windows,
+                         const uint8_t *canonical, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user,
+                         nm_search_result **out);
+/* stats[3] = scoring batches (lock-step rounds), candidates scored, window requests */
+int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_best, uint64_t stats[3]);
+/* offsets are [n_tasks + 1]; any of the column pointers may be NULL */
+int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uint64_t *edge_off, uint64_t *best_off, uint8_t *task_none,
+                            char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,
+                            uint8_t *node_visited, int32_t *edges, int32_t *best);
+int nm_search_result_free(nm_search_result *res);
+
 /* ---- multi-GPU exchange: sum of the per-rank count tables ------------------------------------------------------
  * One process per GPU; contigs are sharded over the ranks and counts are sums over contigs
  * (motif_model_bin, find_motifs_bin.py:1273-1283), so a scoring step on N GPUs ends with ONE all-reduce
@@ -304,6 +351,8 @@ int nm_fasta_close(nm_fasta *fa);
  *   seq[starts[i] : starts[i] + width] — EqualLengthDNASet.pssm before the division (seq.py:391-422).
  */
 int nm_py_random_sample(uint32_t mt_state[625], uint64_t n, uint64_t k, uint32_t *out_indices);
+/* m consecutive calls on one generator (the background samples of the contigs of one task), results back to back */
+int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t *n, const uint64_t *k, uint32_t *out_indices);
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows,
                             uint32_t width, int64_t *counts);
 

@@ -15,10 +15,23 @@ SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
-    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_window_letter_counts", "nm_bed_open", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
+    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_window_letter_counts", "nm_bed_open", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
     "nm_comm_sync", "nm_comm_destroy",
+    "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_export", "nm_search_result_free",
 ]
+
+class SearchParams(C.Structure):
+    """include/nmscan.h: nm_search_params."""
+    _fields_ = [("padding", C.c_uint32), ("max_dead_ends", C.c_uint32), ("max_rounds_since_new_best", C.c_uint32),
+                ("max_motif_length", C.c_uint32), ("min_kl", C.c_double), ("score_threshold", C.c_double),
+                ("remaining_threshold", C.c_double), ("freq_threshold", C.c_double)]
+
+
+SEARCH_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_char), C.POINTER(C.c_int64))
+SEARCH_WINDOW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_char),
+                               C.POINTER(C.c_int32))
+SEARCH_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_uint64)
 
 _lib = None
 loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
@@ -105,6 +118,7 @@ def load():
                                           C.c_int, C.c_int, C.c_uint32, u32p, u64p, u64p]
     lib.nm_ingest_results.argtypes = [p, u32p, u32p, u8p, C.POINTER(C.c_int8), C.c_uint64, u32p]
     lib.nm_py_random_sample.argtypes = [u32p, C.c_uint64, C.c_uint64, u32p]
+    lib.nm_py_random_sample_many.argtypes = [u32p, C.c_uint32, u64p, u64p, u32p]
     lib.nm_window_letter_counts.argtypes = [u8p, C.c_uint64, i64p, C.c_uint64, C.c_uint32, i64p]
     lib.nm_bed_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(p)]
     lib.nm_bed_shape.argtypes = [p, u64p, u32p]
@@ -119,6 +133,12 @@ def load():
     lib.nm_fasta_sequence.argtypes = [p, C.POINTER(p)]
     lib.nm_fasta_close.argtypes = [p]
     lib.nm_timing_reset.argtypes = [p, C.c_int]
+    lib.nm_search_run.argtypes = [p, C.c_uint32, u32p, u32p, u32p, C.POINTER(SearchParams), f64p, u64p, u8p, SEARCH_REDUCE_FN, p, C.POINTER(p)]
+    lib.nm_search_run_custom.argtypes = [C.c_uint32, C.POINTER(SearchParams), f64p, u64p, u8p, SEARCH_SCORE_FN, SEARCH_WINDOW_FN, p, C.POINTER(p)]
+    lib.nm_search_result_sizes.argtypes = [p, u64p, u64p, u64p, u64p]
+    lib.nm_search_result_export.argtypes = [p, u64p, u64p, u64p, u8p, C.c_char_p, i64p, f64p, f64p, C.POINTER(C.c_int32), u8p,
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.nm_search_result_free.argtypes = [p]
     lib.nm_comm_unique_id.argtypes = [u8p]
     lib.nm_comm_init.argtypes = [p, C.c_int, C.c_int, u8p]
     lib.nm_allreduce_counts.argtypes = [p, p, C.c_uint64]

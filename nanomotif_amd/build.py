@@ -6,7 +6,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_HIP = [os.path.join(_HERE, "csrc", f) for f in ("nmscan.hip", "nmingest.hip", "nmwindows.hip")]
-SRC_HOST = [os.path.join(_HERE, "csrc", f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp")]
+SRC_HOST = [os.path.join(_HERE, "csrc", f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp", "nmsearch.cpp")]
 INTERNAL = os.path.join(_HERE, "csrc", "nmscan_internal.h")
 OUT = os.path.join(_HERE, "libnmscan.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")
@@ -20,7 +20,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     # explicit RUNPATH: the torch-free CLI path loads the system HIP runtime through it (nanomotif_amd/_lib.py)
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + SRC_HIP + SRC_HOST + \
-          ["-lz", "-lpthread", "-ldl", f"-Wl,-rpath,{rocm}/lib"]
+          ["-lz", "-lpthread", "-ldl", "-ffp-contract=off", f"-Wl,-rpath,{rocm}/lib"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -88,6 +88,17 @@ int nm_py_random_sample(uint32_t mt_state[625], uint64_t n, uint64_t k, uint32_t
     return NM_OK;
 }
 
+int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t *n, const uint64_t *k, uint32_t *out_indices) {
+    if (m && (!n || !k)) return nm_set_error(NM_EINVAL, "NULL argument");
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < m; ++i) {          // consecutive random.sample(range(n[i]), k[i]) calls on one generator
+        const int rc = nm_py_random_sample(mt_state, n[i], k[i], out_indices ? out_indices + at : nullptr);
+        if (rc) return rc;
+        at += k[i];
+    }
+    return NM_OK;
+}
+
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows, uint32_t width,
                             int64_t *counts /*[4][width], rows A,T,G,C*/) {
     if (!seq || !counts || (n_windows && !starts)) return nm_set_error(NM_EINVAL, "NULL argument");

@@ -1,0 +1,770 @@
+// nmsearch — the greedy candidate search of ALL (bin, mod type) tasks advanced in lock-step, natively.
+//
+// Restates, decision for decision, nanomotif/find_motifs_bin.py:688-839 (find_best_candidates: outer loop, pruning by
+// parent scores, dead ends, missed candidates), :843-1182 (MotifSearcher: best-first search, KL child generation,
+// priority, stale-round stop), :1360-1433 (predictive_evaluation_score, get_parent_scores), model.py:11-92 and
+// motif.py:98-125, 160-194, 594-607 — the same algorithm nanomotif_amd/search.py runs as Python coroutines.  With a
+// thousand searches open, those coroutines cost about a second of interpreter time per 1 Gbp metagenome while the GPU
+// needs milliseconds; here a round is: collect every task's request, ONE window batch (nm_win_batch) and ONE scoring
+// batch (nm_score_batch) for all of them, hand the replies back.
+//
+// Arithmetic is float64 in the reference's own operation order: digamma = scipy.special.psi restated for the integer
+// arguments it receives (harmonic sum up to 10, the Cephes asymptotic series above; bit-equal to scipy on this host,
+// tests/test_native_search.py), column KL = scipy.stats.entropy's normalise / rel_entr / sum with numpy's axis-0
+// order, np.mean with numpy's pairwise blocks.  Heap ties compare (priority, depth, motif string) like Python tuples.
+//
+// The scoring and window back ends are callbacks, so the same state machine runs against the HIP engine
+// (nm_search_run) and, in the CPU tests, against the oracle's scan (nm_search_run_custom).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nmscan.h"
+
+int nm_set_error(int code, const char *fmt, ...);
+
+namespace {
+
+constexpr int STRIDE = NM_WIN_OUT_STRIDE;
+constexpr int MAXW = NM_WIN_MAX_WIDTH;
+
+// scipy.special.psi for positive integers (Cephes psi: exact harmonic sum for x <= 10, asymptotic series beyond)
+double psi_int(double x) {
+    static const double A[7] = {8.33333333333333333333E-2, -2.10927960927960927961E-2, 7.57575757575757575758E-3,
+                                -4.16666666666666666667E-3, 3.96825396825396825397E-3, -8.33333333333333333333E-3,
+                                8.33333333333333333333E-2};
+    if (x <= 10.0) {
+        double y = 0.0;
+        const int n = (int)x;
+        for (int i = 1; i < n; ++i) y += 1.0 / i;
+        y -= 0.577215664901532860606512090082402431;
+        return y;
+    }
+    const double z = 1.0 / (x * x);
+    double ans = A[0];
+    for (int i = 1; i < 7; ++i) ans = ans * z + A[i];
+    const double y = z * ans;
+    return std::log(x) - (0.5 / x) - y;
+}
+
+struct Model {                      // BetaBernoulliModel with the default prior 5 / 5 (model.py:11-33)
+    int64_t a = 5, b = 5;
+    static Model from_counts(int64_t n_mod, int64_t n_nomod) { return Model{5 + n_mod, 5 + n_nomod}; }
+    int64_t n_mod() const { return a - 5; }
+    int64_t n_nomod() const { return b - 5; }
+    double mean() const { return (double)a / (double)(a + b); }
+    double ppo(int64_t np, int64_t nn) const {      // posterior_predictive_per_obs (model.py:78-92)
+        const int64_t n = np + nn;
+        if (n == 0) return 0.0;
+        const double both = psi_int((double)(a + b));
+        const double pp = (double)np * (psi_int((double)a) - both) + (double)nn * (psi_int((double)b) - both);
+        return pp / (double)n;
+    }
+};
+
+double evaluation_score(const Model &next, const Model &cur) {    // find_motifs_bin.py:1360-1379
+    const double pp_next = next.ppo(next.a, next.b);
+    const double pp_extra = next.ppo(cur.a - next.a, cur.b - next.b);
+    return (next.mean() / cur.mean()) * (pp_next - pp_extra);
+}
+
+double np_mean(const std::vector<double> &v) {      // numpy's pairwise summation (blocks of 8 accumulators), then / n
+    const size_t n = v.size();
+    if (n == 0) return std::nan("");
+    double res;
+    size_t i;
+    if (n < 8) {
+        res = 0.0;
+        for (i = 0; i < n; ++i) res += v[i];
+    } else {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = v[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += v[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += v[i];
+    }
+    return res / (double)n;
+}
+
+double rel_entr(double x, double y) {               // scipy.special.rel_entr
+    if (std::isnan(x) || std::isnan(y)) return std::nan("");
+    if (x > 0 && y > 0) return x * std::log(x / y);
+    if (x == 0 && y >= 0) return 0.0;
+    return INFINITY;
+}
+
+int count_isolated(const std::string &s, int k) {   // Motif.count_isolated_bases (motif.py:178-194) incl. the n-1 cap
+    const int n = (int)s.size();
+    int cnt = 0;
+    for (int p = 0; p < n; ++p) {
+        if (s[p] == '.') continue;
+        int len = 0;
+        bool all_dot = true, all_n = true;
+        for (int q = std::max(p - k, 0); q < p; ++q) { ++len; all_dot &= s[q] == '.'; all_n &= s[q] == 'N'; }
+        for (int q = p + 1; q < std::min(p + k + 1, n - 1); ++q) { ++len; all_dot &= s[q] == '.'; all_n &= s[q] == 'N'; }
+        if (len && all_dot) ++cnt;
+        if (len && all_n) ++cnt;
+    }
+    return cnt;
+}
+
+size_t stripped_length(const std::string &s) {
+    size_t lo = 0, hi = s.size();
+    while (lo < hi && s[lo] == '.') ++lo;
+    while (hi > lo && s[hi - 1] == '.') --hi;
+    return hi - lo;
+}
+
+// Motif.sub_motif_of (motif.py:57-96) for search-window motifs (letters and dots, same mod position in both)
+bool sub_motif_of(const std::string &self, const std::string &other, int modpos) {
+    if (self == other) return false;
+    auto bounds = [](const std::string &s, size_t &lo, size_t &hi) {
+        lo = 0; hi = s.size();
+        while (lo < hi && s[lo] == '.') ++lo;
+        if (lo == s.size()) { lo = 0; return; }
+        while (hi > lo && s[hi - 1] == '.') --hi;
+    };
+    size_t alo, ahi, blo, bhi;
+    bounds(self, alo, ahi);
+    bounds(other, blo, bhi);
+    const int na = (int)(ahi - alo), nb = (int)(bhi - blo);
+    if (na < nb) return false;
+    const int off = (modpos - (int)blo) - (modpos - (int)alo);
+    if (off > 0) return false;
+    for (int i = 0; i < na; ++i) {
+        const int k = i + off;
+        if (k < 0) continue;
+        if (k >= nb) return true;
+        const char tb = other[blo + k], ta = self[alo + i];
+        if (tb != '.') {
+            // _tok_subset for single characters: '.' is a subset of '.' only; letters must be equal
+            const bool subset = ta == '.' ? false : ta == tb;
+            if (!subset) return false;
+        }
+    }
+    return true;
+}
+
+struct Node {
+    std::string motif;
+    Model model;
+    double score = 0, priority = 0;
+    int depth = 0;
+    bool visited = false;
+    std::vector<int> succ, pred;
+};
+
+struct Graph {                                      // MotifTree (motif.py:577-607): insertion-ordered nodes
+    std::vector<Node> nodes;
+    std::unordered_map<std::string, int> index;
+    int find(const std::string &m) const {
+        auto it = index.find(m);
+        return it == index.end() ? -1 : it->second;
+    }
+    int add(const std::string &m) {
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
+        nodes.back().motif = m;
+        index.emplace(m, id);
+        return id;
+    }
+    bool has_edge(int u, int v) const { return std::find(nodes[u].succ.begin(), nodes[u].succ.end(), v) != nodes[u].succ.end(); }
+    void add_edge(int u, int v) {
+        nodes[u].succ.push_back(v);
+        nodes[v].pred.push_back(u);
+    }
+    void reach(int start, bool forward, std::vector<char> &seen) const {
+        seen.assign(nodes.size(), 0);
+        std::vector<int> stack(forward ? nodes[start].succ : nodes[start].pred);
+        while (!stack.empty()) {
+            const int n = stack.back();
+            stack.pop_back();
+            if (seen[n]) continue;
+            seen[n] = 1;
+            const auto &nx = forward ? nodes[n].succ : nodes[n].pred;
+            stack.insert(stack.end(), nx.begin(), nx.end());
+        }
+        seen[start] = 0;
+    }
+};
+
+struct Params {
+    uint32_t width, padding;
+    double min_kl, score_threshold, remaining_threshold, freq_threshold;
+    uint32_t max_dead_ends, max_rounds, max_motif_length;
+};
+
+enum ReqKind { REQ_NONE = 0, REQ_SCORE, REQ_PSSM, REQ_REMOVE, REQ_DONE };
+
+struct HeapEntry {
+    double priority;
+    int depth;
+    std::string motif;
+};
+struct HeapCmp {                                    // min-heap on the Python tuple (priority, depth, motif)
+    bool operator()(const HeapEntry &x, const HeapEntry &y) const {
+        if (x.priority != y.priority) return x.priority > y.priority;
+        if (x.depth != y.depth) return x.depth > y.depth;
+        return x.motif > y.motif;
+    }
+};
+
+// One (bin, mod type) search as a resumable state machine.  `resume` consumes the reply to the pending request and
+// runs to the next one.
+struct Task {
+    const Params *P = nullptr;
+    const double *bg = nullptr;                     // [4][W] rows A, T, G, C
+    uint64_t total = 0;
+    char canonical = 'A';
+    std::string root;
+    Graph g;
+    bool graph_made = false;
+    std::vector<std::string> best;
+    // pending request
+    ReqKind req = REQ_NONE;
+    std::vector<std::string> req_motifs;            // REQ_SCORE: motifs; REQ_PSSM / REQ_REMOVE: one motif
+    // replies
+    std::vector<Model> rep_models;
+    int64_t rep_a = 0, rep_b = 0;                   // pssm: n_active ; remove: before, left
+    int64_t rep_counts[4][MAXW];
+    // --- state
+    int state = 0;
+    uint32_t dead_ends = 0;
+    // MotifSearcher.run
+    std::priority_queue<HeapEntry, std::vector<HeapEntry>, HeapCmp> pq;
+    std::unordered_map<std::string, char> visited;
+    Model root_model;
+    double best_score = 0;
+    std::string best_guess;
+    uint32_t rounds = 0;
+    std::string cur;
+    int cur_id = -1;
+    std::vector<std::string> neighbors, fresh;
+    // pruning
+    std::string guess, temp;
+    std::vector<int> to_prune;                      // cumulative set of positions
+    std::vector<int> parent_pos;
+    std::vector<std::string> parent_motifs;
+    Model child_model;
+    double mean_parent = 0;
+    bool single = false;
+    bool result_none = false;
+
+    void init(const Params *p, const double *bg_, uint64_t total_, char canonical_) {
+        P = p; bg = bg_; total = total_; canonical = canonical_;
+        root.assign(p->width, '.');
+        root[p->padding] = canonical_;
+        result_none = false;
+    }
+
+    // ---- MotifSearcher._motif_child_nodes_kl_dist_max (find_motifs_bin.py:957-1023)
+    void children_of(const std::string &motif, int64_t n_active) {
+        neighbors.clear();
+        const int W = (int)P->width;
+        double meth[4][MAXW], kl[MAXW];
+        for (int r = 0; r < 4; ++r)
+            for (int j = 0; j < W; ++j) meth[r][j] = (double)rep_counts[r][j] / (double)n_active;
+        bool any_dot = false;
+        for (int j = 0; j < W; ++j) {
+            const double sp = ((meth[0][j] + meth[1][j]) + meth[2][j]) + meth[3][j];
+            const double sq = ((bg[0 * W + j] + bg[1 * W + j]) + bg[2 * W + j]) + bg[3 * W + j];
+            double e[4];
+            for (int r = 0; r < 4; ++r) e[r] = rel_entr(meth[r][j] / sp, bg[r * W + j] / sq);
+            const double v = ((e[0] + e[1]) + e[2]) + e[3];
+            kl[j] = motif[j] == '.' ? v : 0.0;
+            any_dot |= motif[j] == '.';
+        }
+        if (!any_dot) return;
+        // np.max / np.argmax: NaN propagates and wins, otherwise the first maximum
+        int pos = 0;
+        bool nan = false;
+        for (int j = 0; j < W; ++j) {
+            if (std::isnan(kl[j])) { pos = j; nan = true; break; }
+            if (kl[j] > kl[pos]) pos = j;
+        }
+        if (!nan && kl[pos] < P->min_kl) return;
+        static const char BASES[4] = {'A', 'T', 'G', 'C'};
+        for (int r = 0; r < 4; ++r) {
+            if (meth[r][pos] > bg[r * W + pos] * 0.5 && meth[r][pos] > P->freq_threshold) {
+                std::string c = motif;
+                c[pos] = BASES[r];
+                neighbors.push_back(std::move(c));
+            }
+        }
+    }
+
+    void request_score(std::vector<std::string> motifs) { req = REQ_SCORE; req_motifs = std::move(motifs); }
+    void request_win(ReqKind k, const std::string &m) { req = k; req_motifs.assign(1, m); }
+
+    // get_parent_scores_co request for `temp` (find_motifs_bin.py:1382-1433)
+    void request_parents() {
+        parent_pos.clear();
+        parent_motifs.clear();
+        for (int i = 0; i < (int)temp.size(); ++i) {
+            if (i == (int)P->padding || temp[i] == '.' || temp[i] == 'N') continue;
+            std::string q = temp;
+            q[i] = '.';
+            parent_motifs.push_back(std::move(q));
+            parent_pos.push_back(i);
+        }
+        std::vector<std::string> r;
+        r.push_back(temp);
+        r.insert(r.end(), parent_motifs.begin(), parent_motifs.end());
+        request_score(std::move(r));
+    }
+
+    void finish() {
+        // get_missed_candidates + the sub-motif filter + sorted extension (find_motifs_bin.py:826-833, motif.py:594-607)
+        if (!graph_made || g.nodes.empty()) { result_none = true; req = REQ_DONE; return; }
+        std::vector<char> high(g.nodes.size(), 0), in_best(g.nodes.size(), 0);
+        for (size_t i = 0; i < g.nodes.size(); ++i) high[i] = g.nodes[i].score > P->score_threshold;
+        for (const auto &b : best) {
+            const int id = g.find(b);
+            if (id >= 0) in_best[id] = 1;
+        }
+        std::vector<std::string> missed;
+        std::vector<char> seen;
+        for (size_t i = 0; i < g.nodes.size(); ++i) {
+            if (!high[i] || in_best[i]) continue;
+            g.reach((int)i, false, seen);
+            bool bad = false;
+            for (size_t k = 0; k < seen.size() && !bad; ++k) bad = seen[k] && high[k];
+            if (bad) continue;
+            g.reach((int)i, true, seen);
+            for (size_t k = 0; k < seen.size() && !bad; ++k) bad = seen[k] && in_best[k];
+            if (bad) continue;
+            const std::string &c = g.nodes[i].motif;
+            bool sub_of_any = false, any_sub_of_c = false;
+            for (const auto &b : best) {
+                sub_of_any |= sub_motif_of(c, b, (int)P->padding);
+                any_sub_of_c |= sub_motif_of(b, c, (int)P->padding);
+            }
+            if (!sub_of_any || !any_sub_of_c) missed.push_back(c);
+        }
+        std::sort(missed.begin(), missed.end());
+        best.insert(best.end(), missed.begin(), missed.end());
+        req = REQ_DONE;
+    }
+
+    void resume() {
+        switch (state) {
+            case 0: goto OUTER;
+            case 1: goto ROOT_SCORED;
+            case 2: goto PSSM_DONE;
+            case 3: goto CHILDREN_SCORED;
+            case 4: goto PARENTS_SCORED;
+            case 5: goto REMOVED;
+            default: req = REQ_DONE; return;
+        }
+    OUTER:
+        if (dead_ends >= P->max_dead_ends) { finish(); return; }
+        // ---- MotifSearcher.run (find_motifs_bin.py:1026-1182); the graph persists across outer iterations
+        best_guess = root;
+        request_score({root});
+        state = 1;
+        return;
+    ROOT_SCORED:
+        root_model = rep_models[0];
+        best_score = evaluation_score(root_model, root_model);
+        rounds = 0;
+        visited.clear();
+        graph_made = true;
+        if (g.find(root) < 0) {
+            const int id = g.add(root);
+            g.nodes[id].model = root_model;
+            g.nodes[id].score = best_score;
+        }
+        pq = decltype(pq)();
+        pq.push(HeapEntry{0.0, 0, root});
+        while (!pq.empty()) {
+            cur = pq.top().motif;
+            pq.pop();
+            if (visited.count(cur)) continue;
+            cur_id = g.find(cur);
+            {
+                const Node &n = g.nodes[cur_id];
+                if (n.model.n_mod() + n.model.n_nomod() < 10) continue;
+                if (stripped_length(cur) > P->max_motif_length) continue;
+            }
+            visited.emplace(cur, 1);
+            g.nodes[cur_id].visited = true;
+            rounds += 1;
+            request_win(REQ_PSSM, cur);
+            state = 2;
+            return;
+        PSSM_DONE:
+            if (rep_a == 0) continue;
+            children_of(cur, rep_a);
+            fresh.clear();
+            for (const auto &m : neighbors)
+                if (g.find(m) < 0) fresh.push_back(m);
+            if (!fresh.empty()) {
+                request_score(fresh);
+                state = 3;
+                return;
+            }
+            rep_models.clear();
+        CHILDREN_SCORED:
+            {
+                const Model cur_model = g.nodes[cur_id].model;
+                const int cur_depth = g.nodes[cur_id].depth;
+                for (const auto &nxt : neighbors) {
+                    int id = g.find(nxt);
+                    Model nm;
+                    if (id >= 0) nm = g.nodes[id].model;
+                    else {
+                        const size_t k = std::find(fresh.begin(), fresh.end(), nxt) - fresh.begin();
+                        nm = rep_models[k];
+                    }
+                    const double score = evaluation_score(nm, cur_model);
+                    const int n_iso = count_isolated(nxt, 1);
+                    double d_alpha = 1.0 - ((double)nm.a / (double)root_model.a);
+                    double d_beta = (double)nm.b / (double)root_model.b;
+                    double priority = d_alpha * d_beta;
+                    if (n_iso > 0) priority *= std::pow(10.0, n_iso);
+                    if (id >= 0) {
+                        if (g.nodes[id].score < score) g.nodes[id].score = score;
+                    } else {
+                        id = g.add(nxt);
+                        Node &n = g.nodes[id];
+                        n.model = nm;
+                        n.score = score;
+                        n.priority = priority;
+                        n.depth = cur_depth + 1;
+                    }
+                    if (!g.has_edge(cur_id, id)) g.add_edge(cur_id, id);
+                    if (!visited.count(nxt)) pq.push(HeapEntry{g.nodes[id].priority, g.nodes[id].depth, nxt});
+                    if (score > best_score) {
+                        best_score = score;
+                        best_guess = nxt;
+                        rounds = 0;
+                    }
+                }
+            }
+            if (rounds >= P->max_rounds) break;
+        }
+        // ---- back in find_best_candidates
+        guess = best_guess;
+        if (guess == root) { finish(); return; }
+        temp = guess;
+        to_prune.clear();
+        single = false;
+    PRUNE:
+        request_parents();
+        state = 4;
+        return;
+    PARENTS_SCORED:
+        {
+            child_model = rep_models[0];
+            std::vector<double> scores;
+            for (size_t k = 0; k < parent_motifs.size(); ++k) {
+                const double s = evaluation_score(child_model, rep_models[1 + k]);
+                scores.push_back(s);
+                if (s < 0.4 && std::find(to_prune.begin(), to_prune.end(), parent_pos[k]) == to_prune.end()) to_prune.push_back(parent_pos[k]);
+            }
+            mean_parent = np_mean(scores);
+            if (!to_prune.empty()) {
+                std::string pruned = temp;
+                for (int i : to_prune) pruned[i] = '.';
+                size_t specified = 0;
+                for (char ch : pruned) specified += ch != '.';
+                if (specified == 1) single = true;
+                else if (pruned != temp) {
+                    temp = pruned;
+                    goto PRUNE;
+                }
+            }
+        }
+        {
+            const int gid = g.find(guess);
+            if (single || mean_parent < P->score_threshold || temp == guess) {
+                g.nodes[gid].score = mean_parent;
+            } else {
+                int id = g.find(temp);
+                if (id < 0) id = g.add(temp);
+                Node &n = g.nodes[id];
+                n.model = child_model;
+                n.visited = true;
+                n.score = mean_parent;
+                n.priority = 0;
+                n.depth = 0;
+                guess = temp;
+            }
+        }
+        request_win(REQ_REMOVE, guess);
+        state = 5;
+        return;
+    REMOVED:
+        {
+            const int64_t before = rep_a, left = rep_b;
+            (void)before;
+            if (left == 0) { finish(); return; }
+            if (g.nodes[g.find(guess)].score < P->score_threshold) {
+                dead_ends += 1;
+                goto OUTER;
+            }
+            best.push_back(guess);
+            if ((double)left / (double)total < P->remaining_threshold) { finish(); return; }
+        }
+        goto OUTER;
+    }
+};
+
+}  // namespace
+
+struct nm_search_result {
+    uint32_t width = 0;
+    std::vector<Task> tasks;
+    uint64_t rounds = 0, candidates = 0, window_requests = 0;
+};
+
+namespace {
+
+int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user) {
+    auto &tasks = res->tasks;
+    const uint32_t W = P.width;
+    for (auto &t : tasks) t.resume();
+    std::vector<uint32_t> s_task, w_task;
+    std::vector<char> s_motifs, w_motifs;
+    std::vector<uint8_t> w_kind;
+    std::vector<int64_t> counts;
+    std::vector<int32_t> wout;
+    for (;;) {
+        s_task.clear(); w_task.clear(); s_motifs.clear(); w_motifs.clear(); w_kind.clear();
+        for (uint32_t i = 0; i < tasks.size(); ++i) {
+            Task &t = tasks[i];
+            if (t.req == REQ_SCORE) {
+                for (const auto &m : t.req_motifs) {
+                    s_task.push_back(i);
+                    s_motifs.insert(s_motifs.end(), m.begin(), m.end());
+                }
+            } else if (t.req == REQ_PSSM || t.req == REQ_REMOVE) {
+                w_task.push_back(i);
+                w_kind.push_back(t.req == REQ_REMOVE ? 1 : 0);
+                w_motifs.insert(w_motifs.end(), t.req_motifs[0].begin(), t.req_motifs[0].end());
+            }
+        }
+        if (s_task.empty() && w_task.empty()) break;
+        if (!w_task.empty()) {
+            wout.assign(w_task.size() * (size_t)STRIDE, 0);
+            const int rc = window_fn(user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
+            if (rc) return rc;
+            res->window_requests += w_task.size();
+        }
+        if (!s_task.empty()) {
+            counts.assign(s_task.size() * 2, 0);
+            const int rc = score_fn(user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data(), counts.data());
+            if (rc) return rc;
+            res->rounds += 1;
+            res->candidates += s_task.size();
+        }
+        // hand the replies back
+        size_t si = 0;
+        for (size_t k = 0; k < w_task.size(); ++k) {
+            Task &t = tasks[w_task[k]];
+            const int32_t *o = wout.data() + k * (size_t)STRIDE;
+            t.rep_a = o[0];
+            t.rep_b = o[1];
+            if (w_kind[k] == 0)
+                for (int r = 0; r < 4; ++r)
+                    for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * MAXW + j];
+        }
+        while (si < s_task.size()) {
+            Task &t = tasks[s_task[si]];
+            t.rep_models.clear();
+            for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(counts[2 * si], counts[2 * si + 1]));
+        }
+        for (auto &t : tasks)
+            if (t.req != REQ_DONE && t.req != REQ_NONE) {
+                t.req = REQ_NONE;
+                t.resume();
+            }
+    }
+    (void)W;
+    return NM_OK;
+}
+
+int check_params(const nm_search_params *p) {
+    if (!p) return nm_set_error(NM_EINVAL, "params is NULL");
+    if (p->padding == 0 || 2 * p->padding + 1 > (uint32_t)MAXW) return nm_set_error(NM_ERANGE, "padding %u: windows of 2 * padding + 1 must fit %d positions", p->padding, MAXW);
+    return NM_OK;
+}
+
+Params make_params(const nm_search_params *p) {
+    return Params{2 * p->padding + 1, p->padding, p->min_kl, p->score_threshold, p->remaining_threshold, p->freq_threshold,
+                  p->max_dead_ends, p->max_rounds_since_new_best, p->max_motif_length};
+}
+
+// engine-backed callbacks
+struct EngineUser {
+    nm_ctx *ctx;
+    const uint32_t *task_bin, *task_slot, *task_win;
+    uint32_t width, padding;
+    nm_search_reduce_fn reduce;
+    void *reduce_user;
+    std::vector<uint32_t> bins, offs, wtask;
+    std::vector<uint8_t> slots, lens, modpos, masks, sets;
+    std::vector<int64_t> tmp64;
+};
+
+inline uint8_t set_of(char ch) { return ch == 'A' ? NM_BASE_A : ch == 'C' ? NM_BASE_C : ch == 'G' ? NM_BASE_G : ch == 'T' ? NM_BASE_T : 15; }
+
+int engine_score(void *user, uint32_t n, const uint32_t *task, const char *motifs, int64_t *out) {
+    EngineUser &u = *static_cast<EngineUser *>(user);
+    const uint32_t W = u.width;
+    u.bins.resize(n); u.offs.resize(n); u.slots.resize(n); u.lens.resize(n); u.modpos.resize(n);
+    u.masks.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const char *m = motifs + (size_t)i * W;
+        uint32_t lo = 0, hi = W;
+        while (lo < hi && m[lo] == '.') ++lo;
+        while (hi > lo && m[hi - 1] == '.') --hi;
+        u.bins[i] = u.task_bin[task[i]];
+        u.slots[i] = (uint8_t)u.task_slot[task[i]];
+        u.lens[i] = (uint8_t)(hi - lo);
+        u.modpos[i] = (uint8_t)(u.padding - lo);
+        u.offs[i] = (uint32_t)u.masks.size();
+        for (uint32_t j = lo; j < hi; ++j) u.masks.push_back(set_of(m[j]));
+    }
+    int rc = nm_score_batch(u.ctx, n, u.bins.data(), u.slots.data(), u.lens.data(), u.modpos.data(), u.offs.data(), u.masks.data(), out);
+    if (rc) return rc;
+    if (u.reduce) rc = u.reduce(u.reduce_user, out, (uint64_t)n * 2);
+    return rc;
+}
+
+int engine_window(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs, int32_t *out) {
+    EngineUser &u = *static_cast<EngineUser *>(user);
+    const uint32_t W = u.width;
+    u.wtask.resize(n);
+    u.sets.assign((size_t)n * MAXW, 15);
+    for (uint32_t i = 0; i < n; ++i) {
+        u.wtask[i] = u.task_win[task[i]];
+        for (uint32_t j = 0; j < W; ++j) u.sets[(size_t)i * MAXW + j] = set_of(motifs[(size_t)i * W + j]);
+    }
+    int rc = nm_win_batch(u.ctx, n, u.wtask.data(), kind, u.sets.data(), out);
+    if (rc) return rc;
+    if (u.reduce) {                                  // contig-sharded run: every rank holds the windows of its contigs
+        const size_t m = (size_t)n * STRIDE;
+        u.tmp64.resize(m);
+        for (size_t i = 0; i < m; ++i) u.tmp64[i] = out[i];
+        rc = u.reduce(u.reduce_user, u.tmp64.data(), m);
+        for (size_t i = 0; i < m; ++i) out[i] = (int32_t)u.tmp64[i];
+    }
+    return rc;
+}
+
+int start(uint32_t n_tasks, const nm_search_params *p, const double *bg_pssm, const uint64_t *total_windows, const uint8_t *canonical,
+          nm_search_result **out, Params &P) {
+    if (!out) return nm_set_error(NM_EINVAL, "out is NULL");
+    *out = nullptr;
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_tasks && (!bg_pssm || !total_windows || !canonical)) return nm_set_error(NM_EINVAL, "NULL argument");
+    P = make_params(p);
+    nm_search_result *res = new (std::nothrow) nm_search_result();
+    if (!res) return nm_set_error(NM_ENOMEM, "out of host memory");
+    res->width = P.width;
+    res->tasks.resize(n_tasks);
+    for (uint32_t i = 0; i < n_tasks; ++i) {
+        if (canonical[i] != 'A' && canonical[i] != 'C') {
+            delete res;
+            return nm_set_error(NM_EINVAL, "task %u: canonical base must be 'A' or 'C'", i);
+        }
+        res->tasks[i].init(&P, bg_pssm + (size_t)i * 4 * P.width, total_windows[i], (char)canonical[i]);
+    }
+    *out = res;
+    return NM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_search_run_custom(uint32_t n_tasks, const nm_search_params *params, const double *bg_pssm, const uint64_t *total_windows,
+                         const uint8_t *canonical, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user,
+                         nm_search_result **out) {
+    if (!score_fn || !window_fn) return nm_set_error(NM_EINVAL, "NULL callback");
+    Params P;
+    int rc = start(n_tasks, params, bg_pssm, total_windows, canonical, out, P);
+    if (rc) return rc;
+    rc = run_tasks(*out, P, score_fn, window_fn, user);
+    for (auto &t : (*out)->tasks) t.P = nullptr;
+    if (rc) {
+        delete *out;
+        *out = nullptr;
+    }
+    return rc;
+}
+
+int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const uint32_t *task_slot, const uint32_t *task_window,
+                  const nm_search_params *params, const double *bg_pssm, const uint64_t *total_windows, const uint8_t *canonical,
+                  nm_search_reduce_fn reduce, void *reduce_user, nm_search_result **out) {
+    if (!ctx || (n_tasks && (!task_bin || !task_slot || !task_window))) return nm_set_error(NM_EINVAL, "NULL argument");
+    int rc = check_params(params);
+    if (rc) return rc;
+    EngineUser u{ctx, task_bin, task_slot, task_window, 2 * params->padding + 1, params->padding, reduce, reduce_user, {}, {}, {}, {}, {}, {}, {}, {}, {}};
+    return nm_search_run_custom(n_tasks, params, bg_pssm, total_windows, canonical, engine_score, engine_window, &u, out);
+}
+
+int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_best, uint64_t stats[3]) {
+    if (!res || !n_nodes || !n_edges || !n_best) return nm_set_error(NM_EINVAL, "NULL argument");
+    uint64_t nn = 0, ne = 0, nb = 0;
+    for (const auto &t : res->tasks) {
+        if (t.result_none) continue;
+        nn += t.g.nodes.size();
+        nb += t.best.size();
+        for (const auto &n : t.g.nodes) ne += n.succ.size();
+    }
+    *n_nodes = nn; *n_edges = ne; *n_best = nb;
+    if (stats) { stats[0] = res->rounds; stats[1] = res->candidates; stats[2] = res->window_requests; }
+    return NM_OK;
+}
+
+int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uint64_t *edge_off, uint64_t *best_off, uint8_t *task_none,
+                            char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,
+                            uint8_t *node_visited, int32_t *edges, int32_t *best) {
+    if (!res || !node_off || !edge_off || !best_off || !task_none) return nm_set_error(NM_EINVAL, "NULL argument");
+    uint64_t nn = 0, ne = 0, nb = 0;
+    const uint32_t W = res->width;
+    for (size_t i = 0; i < res->tasks.size(); ++i) {
+        const Task &t = res->tasks[i];
+        node_off[i] = nn; edge_off[i] = ne; best_off[i] = nb;
+        task_none[i] = t.result_none ? 1 : 0;
+        if (t.result_none) continue;
+        for (size_t k = 0; k < t.g.nodes.size(); ++k) {
+            const Node &n = t.g.nodes[k];
+            if (node_motif) memcpy(node_motif + (nn + k) * W, n.motif.data(), W);
+            if (node_counts) { node_counts[2 * (nn + k)] = n.model.n_mod(); node_counts[2 * (nn + k) + 1] = n.model.n_nomod(); }
+            if (node_score) node_score[nn + k] = n.score;
+            if (node_priority) node_priority[nn + k] = n.priority;
+            if (node_depth) node_depth[nn + k] = n.depth;
+            if (node_visited) node_visited[nn + k] = n.visited ? 1 : 0;
+            for (int v : n.succ) {
+                if (edges) { edges[2 * ne] = (int32_t)k; edges[2 * ne + 1] = v; }
+                ++ne;
+            }
+        }
+        for (const auto &b : t.best) {
+            if (best) best[nb] = t.g.find(b);
+            ++nb;
+        }
+        nn += t.g.nodes.size();
+    }
+    node_off[res->tasks.size()] = nn;
+    edge_off[res->tasks.size()] = ne;
+    best_off[res->tasks.size()] = nb;
+    return NM_OK;
+}
+
+int nm_search_result_free(nm_search_result *res) {
+    delete res;
+    return NM_OK;
+}
+
+}  // extern "C"

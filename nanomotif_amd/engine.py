@@ -172,26 +172,45 @@ class DeviceWindowExtractor:
 
     def plan_contigs(self, key, names, mod_type: str) -> bool:
         """``plan`` without row lists: the task's windows are all confident rows of the contigs ``names`` (those present
-        in the filtered pileup of this mod type), read on the device from the methylated-state planes."""
+        in the filtered pileup of this mod type), read on the device from the methylated-state planes.  The background
+        samples of all its contigs are drawn by ONE native call (same draws, same order as contig-by-contig)."""
+        import math
         from .search import NativeRandom
         base, counts = MOD_TYPE_TO_CANONICAL[mod_type], self.row_counts[mod_type]
-        s_contig, s_rank, mine = [], [], []
-        n_bg = total = 0
+        names = sorted(names)
+        W = 2 * self.pad + 1
+        lengths = [int(self.lengths[n]) for n in names]
+        n_samples = [int(max(math.ceil(L * self.freq), 50)) for L in lengths]
+        nv = [int(self.n_valid[base][n]) for n in names]
+        # the reference draws contig by contig and stops at the first contig without rows (find_motifs_bin.py:662-664):
+        # only the contigs before it consume random numbers
+        stop = next((i for i, n in enumerate(names) if int(counts[n][0]) + int(counts[n][1]) == 0), len(names))
+        for i in range(min(stop + 1, len(names))):
+            if n_samples[i] > lengths[i] - W + 1:
+                raise ValueError("Too many samples requested for unique subsequences")
+            if nv[i] < n_samples[i]:
+                raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv[i]}, need {n_samples[i]})")
+        drawn = min(stop + 1, len(names))
         with NativeRandom() as rng:
-            for name in sorted(names):
-                n_bg += self._draw(rng, name, base, s_contig, s_rank)
-                n_rows = int(counts[name][0]) + int(counts[name][1])
-                if n_rows == 0:
-                    return False                     # find_motifs_bin.py:662-664
-                total += n_rows
-                ci = self.resident.get(name)
-                if ci is not None:
-                    mine.append(ci)
+            ranks = rng.sample_many(nv[:drawn], n_samples[:drawn])
+        if stop < len(names):
+            return False
+        total = sum(int(counts[n][0]) + int(counts[n][1]) for n in names)
+        n_bg = sum(n_samples)
         if total == 0 or n_bg == 0:
             return False
-        cat = lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dt)
+        res = [self.resident.get(n) for n in names]
+        mine = [ci for ci in res if ci is not None]
+        if len(mine) == len(names):
+            s_contig = np.repeat(np.asarray(mine, dtype=np.uint32), n_samples)
+            s_rank = ranks
+        else:
+            off = np.concatenate([[0], np.cumsum(n_samples)])
+            keep = [i for i, ci in enumerate(res) if ci is not None]
+            s_contig = np.repeat(np.asarray([res[i] for i in keep], dtype=np.uint32), [n_samples[i] for i in keep]) if keep else np.zeros(0, np.uint32)
+            s_rank = np.concatenate([ranks[off[i]:off[i + 1]] for i in keep]) if keep else np.zeros(0, np.uint32)
         self.store.add_task_contigs(key, mod_type, mine, self.pad, total=total)
-        self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
+        self.tasks.append((key, base, n_bg, s_contig, np.ascontiguousarray(s_rank, dtype=np.uint32)))
         return True
 
     def finish(self) -> dict:

@@ -182,6 +182,12 @@ def task_coroutine(bin_name, mod_type, bin_pssm, cfg: ProcessorConfig, stage_wri
         bin_pssm, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
         max_rounds_since_new_best=30, score_threshold=cfg.score_threshold,
         log=lambda msg: log.info(f"[{bin_name} {mod_type}] {msg}"))
+    return (yield from post_coroutine(bin_name, mod_type, res, cfg, stage_writer, temp_dir))
+
+
+def post_coroutine(bin_name, mod_type, res, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+    """The part of process_subpileup after the search (find_motifs_bin.py:537-596): ``res`` = what
+    find_best_candidates returned — (graph, best candidates, background PSSM) or None."""
     if res is None:
         log.info(f"[{bin_name} {mod_type}] No motifs found")
         return None
@@ -326,8 +332,22 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
             tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
     if extractor is not None:
         pssms = extractor.finish()
-        for key, stage_writer, temp_dir in planned:
-            tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
+        engine = getattr(store, "engine", None)
+        if engine is not None and os.environ.get("NANOMOTIF_PY_SEARCH") != "1":
+            # the searches of ALL tasks run inside libnmscan (nm_search_run: one window batch + one scoring batch per
+            # lock-step round, no interpreter in the loop); only post-processing comes back to the coroutines below
+            from . import native_search
+            reduce = (lambda a: allreduce_counts(a, scorer.group)) if scorer.use_dist else None
+            found = native_search.find_best_candidates_all(
+                engine, [(key, store.task_id[key], store.totals[key], pssms[key]) for key, _, _ in planned], cfg.padding,
+                cfg.minimum_kl_divergence, cfg.score_threshold, reduce=reduce)
+            scorer.rounds += found.rounds
+            scorer.candidates += found.candidates
+            for t, (key, stage_writer, temp_dir) in enumerate(planned):
+                tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir)
+        else:
+            for key, stage_writer, temp_dir in planned:
+                tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
     results = run_lockstep(tasks, scorer, store.execute)
     rows = []
     for key in tasks:

@@ -1,0 +1,164 @@
+"""Python face of the native lock-step search (csrc/nmsearch.cpp, include/nmscan.h: nm_search_*).
+
+``find_best_candidates_all`` is what ``run_lockstep`` over ``search.find_best_candidates_co`` coroutines computes —
+(graph, best candidates, background PSSM) per (bin, mod type) task, reference: find_motifs_bin.py:606-839 — with the
+whole state machine of every task running inside libnmscan: per round one window batch and one scoring batch on the
+engine, no interpreter in the loop.  ``search.py`` stays as the readable twin (CPU tests drive both against the same
+recorded traces)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .model import BetaBernoulliModel
+from .motif import MOD_TYPE_TO_CANONICAL, Motif
+from .search import MotifTree
+
+
+def _params(padding, min_kl, score_threshold, max_dead_ends=25, max_rounds_since_new_best=30, remaining_sequences_threshold=0.001,
+            freq_threshold=0.15, max_motif_length=25):
+    return _lib.SearchParams(int(padding), int(max_dead_ends), int(max_rounds_since_new_best), int(max_motif_length),
+                             float(min_kl), float(score_threshold), float(remaining_sequences_threshold), float(freq_threshold))
+
+
+class SearchResults:
+    """Per-task results of one native run; graphs are materialised on demand (only the CLI's GML export and the tests
+    look at more than the best candidates)."""
+
+    def __init__(self, lib, handle, keys, mod_types, pssms, padding):
+        self.keys, self.mod_types, self.pssms, self.padding = list(keys), list(mod_types), pssms, int(padding)
+        W = 2 * self.padding + 1
+        n = len(self.keys)
+        nn, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        stats = (C.c_uint64 * 3)()
+        _lib.check(lib.nm_search_result_sizes(handle, C.byref(nn), C.byref(ne), C.byref(nb), stats))
+        self.rounds, self.candidates, self.window_requests = (int(x) for x in stats)
+        self.node_off, self.edge_off, self.best_off = (np.zeros(n + 1, dtype=np.uint64) for _ in range(3))
+        self.none = np.zeros(max(n, 1), dtype=np.uint8)
+        self.motif = np.zeros(max(int(nn.value) * W, 1), dtype=np.uint8)
+        self.counts = np.zeros((max(int(nn.value), 1), 2), dtype=np.int64)
+        self.score = np.zeros(max(int(nn.value), 1), dtype=np.float64)
+        self.priority = np.zeros(max(int(nn.value), 1), dtype=np.float64)
+        self.depth = np.zeros(max(int(nn.value), 1), dtype=np.int32)
+        self.visited = np.zeros(max(int(nn.value), 1), dtype=np.uint8)
+        self.edges = np.zeros((max(int(ne.value), 1), 2), dtype=np.int32)
+        self.best = np.zeros(max(int(nb.value), 1), dtype=np.int32)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        _lib.check(lib.nm_search_result_export(handle, p(self.node_off, C.c_uint64), p(self.edge_off, C.c_uint64), p(self.best_off, C.c_uint64),
+                                               p(self.none, C.c_uint8), self.motif.ctypes.data_as(C.c_char_p), p(self.counts, C.c_int64),
+                                               p(self.score, C.c_double), p(self.priority, C.c_double), p(self.depth, C.c_int32),
+                                               p(self.visited, C.c_uint8), p(self.edges, C.c_int32), p(self.best, C.c_int32)))
+        lib.nm_search_result_free(handle)
+        self.W = W
+        self._text = self.motif.tobytes().decode("ascii") if nn.value else ""
+
+    def _node(self, t, k):
+        i = int(self.node_off[t]) + k
+        m = Motif(self._text[i * self.W:(i + 1) * self.W], self.padding)
+        attrs = dict(model=BetaBernoulliModel.from_counts(*self.counts[i]), motif=m, visited=bool(self.visited[i]), score=float(self.score[i]),
+                     priority=(0 if self.priority[i] == 0 and self.depth[i] == 0 else float(self.priority[i])), depth=int(self.depth[i]))
+        return m, attrs
+
+    def result(self, t, full_graph=False):
+        """(graph, best, bin_pssm) of task ``t`` or None, as ``find_best_candidates_co`` returns it.  Without
+        ``full_graph`` the graph holds the best candidates only (all that post-processing reads)."""
+        if self.none[t]:
+            return None
+        g = MotifTree()
+        a, b = int(self.node_off[t]), int(self.node_off[t + 1])
+        best_idx = self.best[int(self.best_off[t]):int(self.best_off[t + 1])].tolist()
+        wanted = range(b - a) if full_graph else sorted(set(best_idx))
+        made = {}
+        for k in wanted:
+            m, attrs = self._node(t, k)
+            g.add_node(m, **attrs)
+            made[k] = m
+        if full_graph:
+            for u, v in self.edges[int(self.edge_off[t]):int(self.edge_off[t + 1])].tolist():
+                g.add_edge(made[u], made[v])
+        return g, [made[k] for k in best_idx], self.pssms[t]
+
+
+def find_best_candidates_all(engine, tasks, padding, min_kl, score_threshold, reduce=None, **kw):
+    """tasks: list of (key=(bin name, mod type), window-store task id, total windows, background PSSM float64[4, W]).
+    Runs every search on ``engine`` (nm_search_run); ``reduce``: callable summing an int64 numpy array over the ranks of a
+    contig-sharded run (None on one GPU).  Returns SearchResults."""
+    lib = engine.lib
+    n = len(tasks)
+    W = 2 * int(padding) + 1
+    keys = [t[0] for t in tasks]
+    mods = [k[1] for k in keys]
+    u32 = lambda xs: np.ascontiguousarray(np.fromiter(xs, dtype=np.uint32, count=n))
+    bins = u32(engine.bin_index[k[0]] for k in keys)
+    slots = u32(engine.slot_of_mod[k[1]] for k in keys)
+    wins = u32(t[1] for t in tasks)
+    totals = np.ascontiguousarray(np.fromiter((t[2] for t in tasks), dtype=np.uint64, count=n))
+    canon = np.frombuffer("".join(MOD_TYPE_TO_CANONICAL[m] for m in mods).encode("ascii"), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
+    pssm = np.ascontiguousarray(np.stack([np.asarray(t[3], dtype=np.float64).reshape(4, W) for t in tasks])) if n else np.zeros((1, 4, W))
+    err = []
+
+    def _reduce(_user, ptr, count):
+        try:
+            a = np.ctypeslib.as_array(ptr, shape=(int(count),))
+            a[:] = reduce(a.copy())
+            return 0
+        except Exception as e:          # a Python exception cannot cross the C frames
+            err.append(e)
+            return -3
+    cb = _lib.SEARCH_REDUCE_FN(_reduce) if reduce is not None else C.cast(None, _lib.SEARCH_REDUCE_FN)
+    params = _params(padding, min_kl, score_threshold, **kw)
+    handle = C.c_void_p()
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib.nm_search_run(engine.ctx, n, p(bins, C.c_uint32), p(slots, C.c_uint32), p(wins, C.c_uint32), C.byref(params),
+                           p(pssm, C.c_double), p(totals, C.c_uint64), p(canon, C.c_uint8), cb, None, C.byref(handle))
+    if err:
+        raise err[0]
+    _lib.check(rc)
+    return SearchResults(lib, handle, keys, mods, [t[3] for t in tasks], padding)
+
+
+def find_best_candidates_custom(tasks, padding, min_kl, score_threshold, score_fn, window_fn, **kw):
+    """The same state machine on Python back ends (CPU tests): ``score_fn(list of (task index, Motif)) -> int64[n, 2]``,
+    ``window_fn(list of (task index, kind, Motif)) -> int32[n, 258]`` (kind 'pssm' / 'remove', rows like nm_win_batch).
+    tasks: list of (key, total windows, background PSSM)."""
+    lib = _lib.load()
+    n = len(tasks)
+    W = 2 * int(padding) + 1
+    keys = [t[0] for t in tasks]
+    mods = [k[1] for k in keys]
+    totals = np.ascontiguousarray(np.fromiter((t[1] for t in tasks), dtype=np.uint64, count=n))
+    canon = np.frombuffer("".join(MOD_TYPE_TO_CANONICAL[m] for m in mods).encode("ascii"), dtype=np.uint8).copy()
+    pssm = np.ascontiguousarray(np.stack([np.asarray(t[2], dtype=np.float64).reshape(4, W) for t in tasks]))
+    err = []
+
+    def _score(_user, cnt, task, motifs, out):
+        try:
+            text = C.string_at(motifs, cnt * W).decode("ascii")
+            res = np.asarray(score_fn([(int(task[i]), Motif(text[i * W:(i + 1) * W], int(padding))) for i in range(cnt)]), dtype=np.int64)
+            np.ctypeslib.as_array(out, shape=(cnt, 2))[:] = res
+            return 0
+        except Exception as e:
+            err.append(e)
+            return -3
+
+    def _window(_user, cnt, task, kind, motifs, out):
+        try:
+            text = C.string_at(motifs, cnt * W).decode("ascii")
+            res = np.asarray(window_fn([(int(task[i]), "remove" if kind[i] else "pssm", Motif(text[i * W:(i + 1) * W], int(padding)))
+                                        for i in range(cnt)]), dtype=np.int32)
+            np.ctypeslib.as_array(out, shape=(cnt, 2 + 4 * 64))[:] = res
+            return 0
+        except Exception as e:
+            err.append(e)
+            return -3
+    params = _params(padding, min_kl, score_threshold, **kw)
+    handle = C.c_void_p()
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib.nm_search_run_custom(n, C.byref(params), p(pssm, C.c_double), p(totals, C.c_uint64), p(canon, C.c_uint8),
+                                  _lib.SEARCH_SCORE_FN(_score), _lib.SEARCH_WINDOW_FN(_window), None, C.byref(handle))
+    if err:
+        raise err[0]
+    _lib.check(rc)
+    return SearchResults(lib, handle, keys, mods, [t[2] for t in tasks], padding)

@@ -76,6 +76,18 @@ class NativeRandom:
                                                   out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out.astype(np.int64)
 
+    def sample_many(self, ns, ks) -> np.ndarray:
+        """Consecutive ``random.sample(range(n), k)`` calls for the pairs of ``ns`` / ``ks``, results back to back
+        (uint32)."""
+        import ctypes as C
+        ns = np.ascontiguousarray(ns, dtype=np.uint64)
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        out = np.empty(max(int(ks.sum()), 1), dtype=np.uint32)
+        self._check(self._lib.nm_py_random_sample_many(self.state.ctypes.data_as(C.POINTER(C.c_uint32)), len(ns),
+                                                       ns.ctypes.data_as(C.POINTER(C.c_uint64)), ks.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                       out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out[:int(ks.sum())]
+
     def __exit__(self, *exc):
         random.setstate((self.version, tuple(self.state.tolist()), self.gauss))
         return False

@@ -1,0 +1,152 @@
+"""The native lock-step search (csrc/nmsearch.cpp) on CPU: nm_search_run_custom driven by the oracle's scan and the
+numpy window store must reproduce the reference-recorded search traces (tests/golden/g4_search.json) node for node,
+agree with the Python coroutine search on several tasks advanced together, and its digamma must be scipy's bit for bit."""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import load_golden, oracle_bin_inputs, spec_from_json
+from nanomotif_amd import native_search as ns
+from nanomotif_amd import search as ps
+from nanomotif_amd import synth
+from nanomotif_amd.find_motifs_bin import LockstepScorer
+from test_host_search import oracle_backend, windows_for
+
+
+def _backends(keys, piles, seqs_by_bin, store):
+    from oracle.scan import score_candidates
+
+    def score_fn(reqs):
+        out = np.zeros((len(reqs), 2), dtype=np.int64)
+        for i, (t, m) in enumerate(reqs):
+            key = keys[t]
+            out[i] = score_candidates(piles[key], seqs_by_bin[key[0]], [(m.string, m.mod_position)])[0]
+        return out
+
+    def window_fn(reqs):
+        res = store.execute([(keys[t], ps.WinReq(kind, m)) for t, kind, m in reqs])
+        out = np.zeros((len(reqs), 2 + 4 * 64), dtype=np.int32)
+        for i, ((t, kind, m), r) in enumerate(zip(reqs, res)):
+            if kind == "remove":
+                out[i, 0], out[i, 1] = r
+            else:
+                out[i, 0] = r[0]
+                if r[1] is not None:
+                    out[i, 2:].reshape(4, 64)[:, :r[1].shape[1]] = r[1]
+        return out
+    return score_fn, window_fn
+
+
+@pytest.mark.parametrize("name", ["gatc_single", "ecoli_like_m", "ecoli_like_a", "geobacillus_like", "no_motif"])
+def test_native_search_reproduces_reference_trace(name):
+    g = load_golden("g4_search.json")[name]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    mt = g["mod_type"]
+    pile, seqs = oracle_bin_inputs(mg, mt)
+    P = g["params"]
+    random.seed(P["seed"])
+    windows = windows_for(mg, mt, pile, P["high"], P["padding"])
+    key = ("bin0", mt)
+    store = ps.HostWindowStore()
+    store.add_task(key, windows[0])
+    score_fn, window_fn = _backends([key], {key: pile}, {"bin0": seqs}, store)
+    res = ns.find_best_candidates_custom([(key, store.totals[key], windows[1])], P["padding"], P["min_kl"], P["score_threshold"],
+                                         score_fn, window_fn)
+    graph, best, _ = res.result(0, full_graph=True)
+    assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
+    for (n, d), r in zip(graph.nodes.items(), g["nodes"]):
+        assert list(d["model"].get_raw_counts()) == r["counts"]
+        assert d["score"] == pytest.approx(r["score"], abs=1e-9, rel=1e-9)
+        assert d["priority"] == pytest.approx(r["priority"], abs=1e-12, rel=1e-12)
+        assert d["depth"] == r["depth"] and d["visited"] == r["visited"]
+    assert sorted((u.string, v.string) for u, v in graph.edges()) == sorted(map(tuple, g["edges"]))
+    assert sorted((m.string, m.mod_position) for m in best) == sorted(map(tuple, g["best"]))
+    # the light result (what post-processing reads) carries the same best candidates with the same models and scores
+    light, best2, _ = ns.find_best_candidates_custom([(key, store.totals[key], windows[1])], P["padding"], P["min_kl"], P["score_threshold"],
+                                                     *_fresh_backends(mg, mt, pile, seqs, P, key)).result(0)
+    assert best2 == best and set(light.nodes) == set(best)
+    for m in best:
+        assert light.nodes[m]["score"] == graph.nodes[m]["score"] and light.nodes[m]["model"].get_raw_counts() == graph.nodes[m]["model"].get_raw_counts()
+
+
+def _fresh_backends(mg, mt, pile, seqs, P, key):
+    random.seed(P["seed"])
+    windows = windows_for(mg, mt, pile, P["high"], P["padding"])
+    store = ps.HostWindowStore()
+    store.add_task(key, windows[0])
+    return _backends([key], {key: pile}, {"bin0": seqs}, store)
+
+
+def test_native_lockstep_equals_python_coroutines_bit_for_bit():
+    """Three tasks advanced together: graphs (node order, counts, depth, visited), best lists, and every score and
+    priority EXACTLY equal to the Python coroutine path's float64 values; same number of rounds and candidates."""
+    g4 = load_golden("g4_search.json")
+    keys, piles, seqs_by_bin, wins = [], {}, {}, {}
+    for bin_name, gname in (("binA", "geobacillus_like"), ("binB", "ecoli_like_m"), ("binC", "ecoli_like_a")):
+        g = g4[gname]
+        mg = synth.make_metagenome(spec_from_json(g["spec"]))
+        mt = g["mod_type"]
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        key = (bin_name, mt)
+        keys.append(key)
+        piles[key], seqs_by_bin[bin_name] = pile, seqs
+        random.seed(1)
+        wins[key] = windows_for(mg, mt, pile)
+    # Python coroutines
+    store = ps.HostWindowStore()
+    tasks = {}
+    for key in keys:
+        store.add_task(key, wins[key][0].copy())
+        tasks[key] = ps.find_best_candidates_co(wins[key][1], key[1], 20, min_kl=0.05, score_threshold=1.5)
+    scorer = LockstepScorer(oracle_backend(piles, seqs_by_bin))
+    want = ps.run_lockstep(tasks, scorer, store.execute)
+    # native
+    store2 = ps.HostWindowStore()
+    for key in keys:
+        store2.add_task(key, wins[key][0].copy())
+    score_fn, window_fn = _backends(keys, piles, seqs_by_bin, store2)
+    res = ns.find_best_candidates_custom([(k, store2.totals[k], wins[k][1]) for k in keys], 20, 0.05, 1.5, score_fn, window_fn)
+    assert (res.rounds, res.candidates) == (scorer.rounds, scorer.candidates)
+    for t, key in enumerate(keys):
+        graph, best, _ = res.result(t, full_graph=True)
+        wg, wbest, _ = want[key]
+        assert list(graph.nodes) == list(wg.nodes) and best == wbest
+        for n in graph.nodes:
+            a, b = graph.nodes[n], wg.nodes[n]
+            assert a["model"].get_raw_counts() == b["model"].get_raw_counts()
+            assert a["score"] == b["score"] and a["priority"] == b["priority"], (n, a["score"], b["score"])
+            assert a["depth"] == b["depth"] and a["visited"] == b["visited"]
+        assert sorted(graph.edges()) == sorted(wg.edges())
+
+
+def test_native_scores_are_scipy_exact():
+    """Counts in, scores out: a one-node search per (alpha, beta) pair exposes the native evaluation score; compare with
+    model.predictive_evaluation_score (scipy.special.psi) bit for bit over a grid that covers the harmonic branch
+    (alpha + beta <= 10), the asymptotic branch and large counts."""
+    from nanomotif_amd.model import BetaBernoulliModel, predictive_evaluation_score
+    rng = np.random.default_rng(12)
+    grid = [(0, 0), (1, 0), (0, 1), (5, 0), (3, 2), (10, 0), (100, 3), (1545, 5), (7, 100000), (123456, 789), (9999999, 12345678)]
+    grid += [tuple(int(x) for x in rng.integers(0, 10 ** rng.integers(1, 8), size=2)) for _ in range(300)]
+    key = ("b", "a")
+    bg = np.full((4, 41), 0.25)
+    for n_mod, n_nomod in grid:
+        score_fn = lambda reqs: np.array([[n_mod, n_nomod]] * len(reqs), dtype=np.int64)
+        window_fn = lambda reqs: np.zeros((len(reqs), 2 + 4 * 64), dtype=np.int32)          # no active windows: the search stops at the root
+        res = ns.find_best_candidates_custom([(key, 100, bg)], 20, 0.05, 1.5, score_fn, window_fn)
+        graph, best, _ = res.result(0, full_graph=True)
+        m = BetaBernoulliModel.from_counts(n_mod, n_nomod)
+        (root, attrs), = graph.nodes.items()
+        assert attrs["score"] == predictive_evaluation_score(m, m), (n_mod, n_nomod)
+        assert best == []
+
+
+def test_sample_many_is_a_run_of_random_sample_calls():
+    ns_, ks = [30, 5000, 22, 100000, 64], [5, 50, 6, 1000, 64]
+    random.seed(77)
+    want = [i for n, k in zip(ns_, ks) for i in random.sample(range(n), k)]
+    after = random.random()
+    random.seed(77)
+    with ps.NativeRandom() as rng:
+        got = rng.sample_many(ns_, ks).tolist()
+    assert got == want and random.random() == after
