@@ -353,6 +353,11 @@ int nm_fasta_close(nm_fasta *fa);
 int nm_py_random_sample(uint32_t mt_state[625], uint64_t n, uint64_t k, uint32_t *out_indices);
 /* m consecutive calls on one generator (the background samples of the contigs of one task), results back to back */
 int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t *n, const uint64_t *k, uint32_t *out_indices);
+/* n_groups independent generator streams (group g starts from init_state[g] and makes the calls group_off[g] ..
+ * group_off[g + 1]), drawn on several host threads; results back to back in call order; final_state = the state the last
+ * group ends in (where the interpreter's generator stands after a sequential run of the same calls) */
+int nm_py_random_sample_groups(uint32_t n_groups, const uint32_t *init_state, const uint64_t *group_off, const uint64_t *n,
+                               const uint64_t *k, uint32_t *out_indices, uint32_t final_state[625]);
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows,
                             uint32_t width, int64_t *counts);
 

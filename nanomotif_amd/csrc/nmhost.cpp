@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <unordered_set>
 #include <vector>
@@ -96,6 +97,41 @@ int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t 
         if (rc) return rc;
         at += k[i];
     }
+    return NM_OK;
+}
+
+int nm_py_random_sample_groups(uint32_t n_groups, const uint32_t *init_state /*[n_groups][625]*/, const uint64_t *group_off /*[n_groups + 1]*/,
+                                const uint64_t *n, const uint64_t *k, uint32_t *out_indices, uint32_t final_state[625]) {
+    if (n_groups && (!init_state || !group_off || !n || !k || !final_state)) return nm_set_error(NM_EINVAL, "NULL argument");
+    if (n_groups == 0) return NM_OK;
+    const uint64_t total = group_off[n_groups];
+    std::vector<uint64_t> out_off(total + 1, 0);
+    for (uint64_t i = 0; i < total; ++i) out_off[i + 1] = out_off[i] + k[i];
+    // every group is its own generator stream (the reference seeds each task afresh, find_motifs_bin.py:152-171): the
+    // groups are drawn concurrently, the draws inside a group stay in order
+    std::vector<int> rcs(n_groups, NM_OK);
+    std::vector<std::string> errs(n_groups);
+    const unsigned threads = std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), n_groups}));
+    std::vector<std::vector<uint32_t>> last(threads);
+    auto work = [&](unsigned t) {
+        std::vector<uint32_t> st(625);
+        for (uint32_t g = t; g < n_groups; g += threads) {
+            memcpy(st.data(), init_state + (size_t)g * 625, 625 * 4);
+            for (uint64_t i = group_off[g]; i < group_off[g + 1] && rcs[g] == NM_OK; ++i) {
+                rcs[g] = nm_py_random_sample(st.data(), n[i], k[i], out_indices ? out_indices + out_off[i] : nullptr);
+                if (rcs[g] != NM_OK) errs[g] = nm_last_error();
+            }
+            if (g == n_groups - 1) last[t] = st;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (rcs[g] != NM_OK) return nm_set_error(rcs[g], "%s", errs[g].c_str());
+    for (unsigned t = 0; t < threads; ++t)
+        if (!last[t].empty()) memcpy(final_state, last[t].data(), 625 * 4);
     return NM_OK;
 }
 

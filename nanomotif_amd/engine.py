@@ -121,6 +121,7 @@ class DeviceWindowExtractor:
         self.allreduce_i64 = allreduce_i64
         self.freq = background_sampling_frequency
         self.tasks = []           # (key, base, n_bg, [sample contig arrays], [sample rank arrays])
+        self._groups = []         # deferred draws: [(MT19937 state at the group's start, [(task index or None, nv, n_samples, keep)])]
 
     def _draw(self, rng, name, base, s_contig, s_rank) -> int:
         """The background sample of one contig (seq.py:202-225): draws its start ranks from ``rng`` (consumed on every
@@ -170,6 +171,14 @@ class DeviceWindowExtractor:
         self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
         return True
 
+    def begin_group(self):
+        """Called right after the caller (re)seeded ``random`` for the next task(s): the ``plan_contigs`` calls that follow
+        form one generator stream whose draws are DEFERRED to ``finish`` — where the streams of all tasks are drawn on
+        several host threads at once (a thousand tasks x 1 % of a Gbp is 1e7 sequential Mersenne-Twister draws)."""
+        import random
+        _, state, _ = random.getstate()
+        self._groups.append((np.array(state, dtype=np.uint32), []))
+
     def plan_contigs(self, key, names, mod_type: str) -> bool:
         """``plan`` without row lists: the task's windows are all confident rows of the contigs ``names`` (those present
         in the filtered pileup of this mod type), read on the device from the methylated-state planes.  The background
@@ -191,9 +200,15 @@ class DeviceWindowExtractor:
             if nv[i] < n_samples[i]:
                 raise ValueError(f"Not enough subsequences with '{base}' in the middle (found {nv[i]}, need {n_samples[i]})")
         drawn = min(stop + 1, len(names))
-        with NativeRandom() as rng:
-            ranks = rng.sample_many(nv[:drawn], n_samples[:drawn])
+        deferred = bool(self._groups)
+        if deferred:
+            ranks = None
+        else:
+            with NativeRandom() as rng:
+                ranks = rng.sample_many(nv[:drawn], n_samples[:drawn])
         if stop < len(names):
+            if deferred:
+                self._groups[-1][1].append((None, nv[:drawn], n_samples[:drawn], None))      # consumes numbers, keeps none
             return False
         total = sum(int(counts[n][0]) + int(counts[n][1]) for n in names)
         n_bg = sum(n_samples)
@@ -201,6 +216,13 @@ class DeviceWindowExtractor:
             return False
         res = [self.resident.get(n) for n in names]
         mine = [ci for ci in res if ci is not None]
+        if deferred:
+            keep = [i for i, ci in enumerate(res) if ci is not None]
+            s_contig = np.repeat(np.asarray(mine, dtype=np.uint32), [n_samples[i] for i in keep]) if keep else np.zeros(0, np.uint32)
+            self._groups[-1][1].append((len(self.tasks), nv, n_samples, keep))
+            self.store.add_task_contigs(key, mod_type, mine, self.pad, total=total)
+            self.tasks.append([key, base, n_bg, s_contig, None])
+            return True
         if len(mine) == len(names):
             s_contig = np.repeat(np.asarray(mine, dtype=np.uint32), n_samples)
             s_rank = ranks
@@ -213,9 +235,14 @@ class DeviceWindowExtractor:
         self.tasks.append((key, base, n_bg, s_contig, np.ascontiguousarray(s_rank, dtype=np.uint32)))
         return True
 
+    def _draw_deferred(self):
+        _draw_deferred_impl(self)
+
     def finish(self) -> dict:
         """Background PSSM (``background_sequences.pssm()``, float64[4, W]) of every planned task."""
         W = 2 * self.pad + 1
+        if self._groups:
+            self._draw_deferred()
         counts = np.zeros((len(self.tasks), 4, W), dtype=np.int64)
         for base in sorted({t[1] for t in self.tasks}):
             idx = [i for i, t in enumerate(self.tasks) if t[1] == base]
@@ -240,6 +267,35 @@ class DeviceWindowExtractor:
         res = {t[0]: counts[i] / t[2] for i, t in enumerate(self.tasks)}
         self.tasks = []
         return res
+
+
+def _draw_deferred_impl(extractor):
+    import random
+    groups = extractor._groups
+    calls = [c for _, cs in groups for c in cs]
+    group_off = np.zeros(len(groups) + 1, dtype=np.uint64)
+    np.cumsum([sum(len(c[1]) for c in cs) for _, cs in groups], out=group_off[1:])
+    ns = np.ascontiguousarray(np.concatenate([np.asarray(c[1], dtype=np.uint64) for c in calls]) if calls else np.zeros(0, np.uint64))
+    ks = np.ascontiguousarray(np.concatenate([np.asarray(c[2], dtype=np.uint64) for c in calls]) if calls else np.zeros(0, np.uint64))
+    init = np.ascontiguousarray(np.stack([st for st, _ in groups]))
+    out = np.empty(max(int(ks.sum()), 1), dtype=np.uint32)
+    final = np.zeros(625, dtype=np.uint32)
+    _lib.check(extractor.engine.lib.nm_py_random_sample_groups(len(groups), _ptr(init, C.c_uint32), _ptr(group_off, C.c_uint64), _ptr(ns, C.c_uint64),
+                                                               _ptr(ks, C.c_uint64), _ptr(out, C.c_uint32), _ptr(final, C.c_uint32)))
+    off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+    at = 0
+    for task, nv, n_samples, keep in calls:
+        m = len(nv)
+        if task is not None:
+            if len(keep) == m:
+                ranks = out[off[at]:off[at + m]]
+            else:
+                ranks = np.concatenate([out[off[at + i]:off[at + i + 1]] for i in keep]) if keep else np.zeros(0, np.uint32)
+            extractor.tasks[task][4] = np.ascontiguousarray(ranks, dtype=np.uint32)
+        at += m
+    version, _, gauss = random.getstate()
+    random.setstate((version, tuple(final.tolist()), gauss))       # where a sequential run would have left the interpreter
+    extractor._groups = []
 
 
 class ScanEngine:

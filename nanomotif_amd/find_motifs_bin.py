@@ -292,6 +292,8 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
     # task order and seeding follow the reference: plain pileup = one task per (bin, mod type), each seeded afresh
     # (find_motifs_bin.py:152-171); bgzip = one task per bin, seeded once, mod types in constants order (:219-222, 248)
     for bin_name in bins:
+        if extractor is not None:
+            extractor._bin_open = False
         if bgzip_order:
             random.seed(cfg.seed)
         for mt_id, mod_type in enumerate(MOD_TYPES):
@@ -307,6 +309,9 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
             if not bgzip_order:
                 random.seed(cfg.seed)
             if extractor is not None:
+                if plus is None and (not bgzip_order or not getattr(extractor, "_bin_open", False)):
+                    extractor.begin_group()              # a fresh generator stream: its draws are made in extractor.finish()
+                    extractor._bin_open = True
                 windows = None
                 planned_ok = (extractor.plan_contigs((bin_name, mod_type), names, mod_type) if plus is None
                               else extractor.plan((bin_name, mod_type), plus, minus, mod_type))

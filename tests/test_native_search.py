@@ -150,3 +150,33 @@ def test_sample_many_is_a_run_of_random_sample_calls():
     with ps.NativeRandom() as rng:
         got = rng.sample_many(ns_, ks).tolist()
     assert got == want and random.random() == after
+
+
+def test_sample_groups_equal_sequential_streams():
+    """nm_py_random_sample_groups: every group is its own generator stream drawn on some thread; results and the final
+    state equal the sequential run."""
+    import ctypes as C
+    from nanomotif_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    groups, init = [], []
+    for g in range(37):
+        random.seed(1 if g % 3 else 100 + g)
+        init.append(np.array(random.getstate()[1], dtype=np.uint32))
+        groups.append([(int(n), int(min(n, k))) for n, k in zip(rng.integers(1, 60000, size=rng.integers(0, 9)), rng.integers(0, 700, size=8))])
+    want = []
+    for st, calls in zip(init, groups):
+        random.setstate((3, tuple(st.tolist()), None))
+        for n, k in calls:
+            want += random.sample(range(n), k)
+    final_want = np.array(random.getstate()[1], dtype=np.uint32)
+    off = np.zeros(len(groups) + 1, dtype=np.uint64)
+    np.cumsum([len(c) for c in groups], out=off[1:])
+    ns_ = np.array([n for c in groups for n, _ in c], dtype=np.uint64)
+    ks = np.array([k for c in groups for _, k in c], dtype=np.uint64)
+    out = np.zeros(int(ks.sum()), dtype=np.uint32)
+    final = np.zeros(625, dtype=np.uint32)
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    _lib.check(lib.nm_py_random_sample_groups(len(groups), p(np.ascontiguousarray(np.stack(init)), C.c_uint32), p(off, C.c_uint64), p(ns_, C.c_uint64),
+                                              p(ks, C.c_uint64), p(out, C.c_uint32), p(final, C.c_uint32)))
+    assert out.tolist() == want and np.array_equal(final, final_want)
