@@ -102,9 +102,12 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
     scorer = engine_scorer(engine, 0.3, 0.7)
     from .main import device_window_pipeline
     engine.timing_reset(True)
+    t1 = time.perf_counter()
     store, extractor = device_window_pipeline(engine, dict(zip(names, lengths)), list(names), cfg.padding)
+    t["window_pipeline_s"] = time.perf_counter() - t1
     rows, scorer = discover(cfg, filtered, scorer, window_store=store, extractor=extractor)
     t["search_s"] = time.perf_counter() - t0
+    t.update(getattr(scorer, "timings", {}))
     ms, n = engine.timing_total()
     engine.timing_reset(False)
     t["gpu_busy_s"] = ms * 1e-3              # scoring launches of the search (HIP events on the launch stream)

@@ -282,7 +282,16 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
     the CLI passes the engine's device store); ``extractor``: an ``engine.DeviceWindowExtractor`` bound to that store
     to gather windows / count the background on the device instead of from ``cfg.assembly`` on the host.
     Returns (list of MotifRow, scorer) — identical on every rank."""
+    import time
     store = window_store if window_store is not None else HostWindowStore()
+    t_mark = time.perf_counter()
+    timings = {}
+
+    def lap(name):
+        nonlocal t_mark
+        now = time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + now - t_mark
+        t_mark = now
     planned = []
     bins = {}
     for c, b in cfg.bin_contig.items():
@@ -335,8 +344,10 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 continue
             store.add_task((bin_name, mod_type), windows[0])
             tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
+    lap("plan_s")
     if extractor is not None:
         pssms = extractor.finish()
+        lap("background_s")
         engine = getattr(store, "engine", None)
         if engine is not None and os.environ.get("NANOMOTIF_PY_SEARCH") != "1":
             # the searches of ALL tasks run inside libnmscan (nm_search_run: one window batch + one scoring batch per
@@ -348,12 +359,15 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 cfg.minimum_kl_divergence, cfg.score_threshold, reduce=reduce)
             scorer.rounds += found.rounds
             scorer.candidates += found.candidates
+            lap("native_search_s")
             for t, (key, stage_writer, temp_dir) in enumerate(planned):
                 tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir)
         else:
             for key, stage_writer, temp_dir in planned:
                 tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
     results = run_lockstep(tasks, scorer, store.execute)
+    lap("coroutines_s")
+    scorer.timings = timings
     rows = []
     for key in tasks:
         if results.get(key):

@@ -35,16 +35,21 @@ class MotifRow:
     def n_nomod(self):
         return int(self.model._beta - self.model._beta_prior)
 
-    def _stripped(self):
-        return Motif(self.motif, self.mod_position).new_stripped_motif()
+    def _derived(self):
+        """(motif_iupac, mod_position_iupac), computed once per row (rows are never mutated after creation)."""
+        d = self.__dict__.get("_cache")
+        if d is None:
+            st = Motif(self.motif, self.mod_position).new_stripped_motif()
+            d = self.__dict__["_cache"] = (st.iupac(), int(st.mod_position))
+        return d
 
     @property
     def motif_iupac(self):
-        return self._stripped().iupac()
+        return self._derived()[0]
 
     @property
     def mod_position_iupac(self):
-        return int(self._stripped().mod_position)
+        return self._derived()[1]
 
     def key(self):
         return (self.reference, self.motif, self.mod_type, self.mod_position, self.n_mod, self.n_nomod, self.score,
