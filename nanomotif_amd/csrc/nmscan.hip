@@ -33,6 +33,7 @@ struct ScoreArgs {
     StatePlanes st[NM_MAX_MOD_SLOTS];
     const uint4 *segments;      // {first chunk, n chunks, bin, 0}
     uint32_t n_segments;
+    uint32_t split_log2;        // every segment is cut into 1 << split_log2 workgroups
     uint32_t n_bins;
     const uint4 *cand_range;    // [active_slot_index][bin] -> {begin, count, common program or ~0, -} into programs
     const uint32_t *programs;   // [n_prog][2 * (GN + GP) * 8], sorted by (slot, bin)
@@ -332,12 +333,22 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
     const uint32_t nb = gridDim.x;
     const uint32_t per = (nb + 7) / 8;
     // (a light batch streams: there the remap costs 3 % of the read rate, tools/stream_pattern.hip)
-    uint32_t seg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const uint32_t vseg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // a small assembly (a shard of a multi-GPU run, a single genome) has too few 16-chunk segments to fill the device
+    // for more than a round or two of workgroups: the host then cuts every segment into 2 or 4 pieces (split_log2)
+    const uint32_t seg = vseg >> a.split_log2;
     if (seg >= a.n_segments) return;
     uint4 sg = a.segments[seg];
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
     sg.y = __builtin_amdgcn_readfirstlane(sg.y);
     sg.z = __builtin_amdgcn_readfirstlane(sg.z);
+    if (a.split_log2) {
+        const uint32_t piece = (sg.y + (1u << a.split_log2) - 1) >> a.split_log2;
+        const uint32_t at = (vseg & ((1u << a.split_log2) - 1)) * piece;
+        if (at >= sg.y) return;
+        sg.x += at;
+        sg.y = min(piece, sg.y - at);
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: chunk indices stay scalar
     // per-slot facts are read from the kernel arguments once, not per chunk
@@ -848,7 +859,16 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.out = out;
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
-    const uint32_t gx = ((c->n_segments + 7) / 8) * 8;
+    // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
+    // workgroups the last, partly filled round is a large share of the launch -> smaller pieces
+    uint64_t est_wgs = (uint64_t)c->n_segments * n_groups / std::max<uint32_t>(n_bins, 1);
+    if (light && n_active == 2) est_wgs = (est_wgs + 1) / 2;          // fused slots: one workgroup serves both
+    const uint64_t resident = (uint64_t)c->n_cus * 6;
+    uint32_t split_log2 = 0;
+    while (split_log2 < 2 && (est_wgs << split_log2) < 2 * resident) ++split_log2;      // measured (tools/gpu_r2f.sh): halves win below ~2 rounds, quarters never
+    if (c->opt_split >= 0) split_log2 = (uint32_t)c->opt_split;
+    a.split_log2 = split_log2;
+    const uint32_t gx = (((c->n_segments << split_log2) + 7) / 8) * 8;
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active};
     const bool fuse = n_active == 2 && shape.light;
 
@@ -905,6 +925,11 @@ const char *nm_last_error(void) { return g_err.c_str(); }
 static int ctx_init(nm_ctx *c) {
     c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
     c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
+    if (const char *e = getenv("NM_SPLIT")) c->opt_split = std::max(0, std::min(2, atoi(e)));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) c->n_cus = (uint32_t)cus;
+    }
     if (const char *e = getenv("NM_SEG_CHUNKS")) c->seg_chunks = (uint32_t)std::max(4, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
