@@ -223,6 +223,18 @@ int nm_hit_positions(nm_ctx *ctx, uint32_t contig_id, uint32_t mod_slot, uint8_t
  * strand-implied ("compact") state, [7] = on the general 4-plane state. */
 int nm_stats(nm_ctx *ctx, uint64_t what[8]);
 
+/* Per-CONTIG counters: what nm_score_batch sums over a bin, kept apart per contig — motif_model_contig
+ * (find_motifs_bin.py:1285-1331) for every contig of the candidate's bin in one launch; the per-contig motif
+ * methylation table binnary builds its contamination / inclusion calls on (main.py:167-178 consumes one row per
+ * (contig, motif); there the numbers come from the epymetheus crate).  Candidate k gets
+ * row_offset[k + 1] - row_offset[k] rows = the resident contigs of its bin in nm_bin_contigs order; out_counts is
+ * int64[row_offset[n_cand]][2] = (n_mod, n_nomod) per (candidate, contig), fwd + rev summed, host memory. */
+int nm_score_batch_per_contig(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                              const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                              const uint8_t *cand_masks, const uint64_t *row_offset, int64_t *out_counts);
+/* resident contigs of a bin (nm_upload_contigs indices) in the order of the per-contig rows */
+int nm_bin_contigs(nm_ctx *ctx, uint32_t bin, uint32_t *contig_ids, uint32_t capacity, uint32_t *n_contigs);
+
 /* ---- the greedy candidate search of all (bin, mod type) tasks, in lock-step ---------------------------------------
  * find_best_candidates (find_motifs_bin.py:688-839) with MotifSearcher.run (:1026-1182), the KL child generation
  * (:957-1023), get_parent_scores pruning (:1382-1433), the dead-end / remaining-windows stops and the missed-candidate

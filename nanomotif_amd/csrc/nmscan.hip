@@ -38,7 +38,9 @@ struct ScoreArgs {
     const uint4 *cand_range;    // [active_slot_index][bin] -> {begin, count, common program or ~0, -} into programs
     const uint32_t *programs;   // [n_prog][2 * (GN + GP) * 8], sorted by (slot, bin)
     const uint32_t *orig_index; // [n_cand] sorted -> caller order
-    unsigned long long *out;    // [n_cand][2]
+    unsigned long long *out;    // [n_cand][2]; per-contig mode: [rows][2], row = row_base[candidate] + rank of the contig in its bin
+    const uint32_t *chunk_rank; // per chunk: rank of its contig within its bin (per-contig mode)
+    const uint64_t *row_base;   // [n_prog] sorted order (per-contig mode)
     uint32_t active_slot[NM_MAX_MOD_SLOTS];
     uint32_t slot_is_c[NM_MAX_MOD_SLOTS];   // canonical base of the slot is C (else A)
 };
@@ -150,10 +152,10 @@ typedef const uint8_t __attribute__((address_space(4))) *cu8p;
 #define NM_LIT_WAVES 4      // minimum waves per SIMD the literal-only variants are compiled for
 #endif
 
-template <int GN_, int GP_, bool COMPACT_, int NS_, bool LIT_, bool CF_>
+template <int GN_, int GP_, bool COMPACT_, int NS_, bool LIT_, bool CF_, bool PC_ = false>
 struct Variant {
     static constexpr int GN = GN_, GP = GP_, NS = NS_;
-    static constexpr bool COMPACT = COMPACT_, LIT = LIT_, CF = CF_;
+    static constexpr bool COMPACT = COMPACT_, LIT = LIT_, CF = CF_, PC = PC_;   // PC: counters keyed by (candidate, contig)
     static constexpr int NW = T_WORDS + GN + GP;
     static constexpr int NP = LIT ? 4 : 8;                 // planes per tile
     static constexpr int NST = COMPACT ? 2 : 4;            // state planes per slot
@@ -274,7 +276,7 @@ __device__ __forceinline__ void apply_single(uint32_t idx, uint32_t r, const Til
 template <class K, int CAN>
 __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<K> &tile, const uint32_t (&sw)[K::NST][T_WORDS],
                                                  uint32_t k0, uint32_t nb, uint32_t common, bool siblings, uint32_t *lds_acc,
-                                                 uint32_t lds_row0, int lane) {
+                                                 uint32_t lds_row0, int lane, uint32_t contig_rank = 0) {
     constexpr int PF = CAN == 0 ? 0 : 1;   // plane of the canonical base: A or C
     constexpr int PR = CAN == 0 ? 3 : 2;   // plane of its complement:     T or G
     uint32_t basef[T_WORDS], baser[T_WORDS];
@@ -314,6 +316,21 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
                 n_mod += __popc(accf[t] & sw[0][t]) + __popc(accr[t] & sw[K::COMPACT ? 0 : 2][t]);
                 n_non += __popc(accf[t] & sw[1][t]) + __popc(accr[t] & sw[K::COMPACT ? 1 : 3][t]);
             }
+        }
+        if (K::PC) {
+            // per-contig counters (motif_model_contig per contig, find_motifs_bin.py:1285-1331): a chunk lies inside ONE
+            // contig, so the wave's sum goes straight to that (candidate, contig) row
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                n_mod += __shfl_xor(n_mod, o);
+                n_non += __shfl_xor(n_non, o);
+            }
+            if (lane == 0 && (n_mod | n_non)) {
+                unsigned long long *row = a.out + (a.row_base[k0 + k] + contig_rank) * 2;
+                if (n_mod) atomicAdd(row, (unsigned long long)n_mod);
+                if (n_non) atomicAdd(row + 1, (unsigned long long)n_non);
+            }
+            continue;
         }
         atomicAdd(&lds_acc[((k * K::NS + lds_row0) * 2 + 0) * 64 + lane], n_mod);
         atomicAdd(&lds_acc[((k * K::NS + lds_row0) * 2 + 1) * 64 + lane], n_non);
@@ -381,25 +398,28 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
     if (most == 0) return;
 
     // one chunk of one pass: tile, then every slot's candidates of this pass
-    auto score_chunk = [&](const RawChunk<K> &cur, uint32_t pass0) {
+    auto score_chunk = [&](const RawChunk<K> &cur, uint32_t pass0, uint32_t chunk) {
         Tile<K> tile;
         tile.expand(cur);
+        const uint32_t rank = K::PC ? ((cu32p)a.chunk_rank)[chunk] : 0u;
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             if (range[j].y <= pass0) continue;                       // wave-uniform
             const uint32_t nbj = min(H, range[j].y - pass0);
             if (K::COMPACT && is_c[j])
-                score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
+                score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane, rank);
             else
-                score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane);
+                score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane, rank);
         }
     };
     auto clear_rows = [&](uint32_t rows_hi) {
+        if (K::PC) return;
         for (uint32_t i = threadIdx.x; i < rows_hi * 128; i += 256) lds_acc[i] = 0;
         __syncthreads();
     };
     // 4 threads per counter, 16 lane-slots each, then a 4-lane butterfly; one 64-bit atomic per counter
     auto flush_rows = [&](uint32_t rows_hi, uint32_t pass0) {
+        if (K::PC) return;
         __syncthreads();
         for (uint32_t idx = threadIdx.x; idx < rows_hi * 8; idx += 256) {
             const uint32_t i = idx >> 2, q = idx & 3;               // i = counter row: (k * NS + j) * 2 + which
@@ -427,11 +447,11 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
     if (EARLY) {                                                     // pass 0 with the chunk already under way
         const uint32_t rows_hi = NS * min(H, most);
         clear_rows(rows_hi);
-        if (wave < sg.y) score_chunk(first, 0);
+        if (wave < sg.y) score_chunk(first, 0, sg.x + wave);
         for (uint32_t ck = wave + 4; ck < sg.y; ck += 4) {
             RawChunk<K> cur;
             cur.load(a.seq, stp, sg.x + ck, lane);
-            score_chunk(cur, 0);
+            score_chunk(cur, 0, sg.x + ck);
         }
         flush_rows(rows_hi, 0);
         pass0 = H;
@@ -442,7 +462,7 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
         for (uint32_t ck = wave; ck < sg.y; ck += 4) {
             RawChunk<K> cur;
             cur.load(a.seq, stp, sg.x + ck, lane);
-            score_chunk(cur, pass0);
+            score_chunk(cur, pass0, sg.x + ck);
         }
         flush_rows(rows_hi, pass0);
     }
@@ -682,6 +702,7 @@ void add_modpos_constraint(uint32_t *prog, uint32_t modpos_mask) {
 struct LaunchShape {
     bool wide, compact, lit, light;
     uint32_t n_active;
+    bool per_contig = false;
 };
 
 template <class K>
@@ -697,6 +718,14 @@ void launch_by_load(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipS
 }
 
 void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStream_t s) {
+    if (sh.per_contig) {      // (candidate, contig) counters: the plain one-slot-per-column kernels with the other reduction key
+        const uint32_t gy = std::max(sh.n_active, 1u);
+        if (!sh.wide && sh.compact) launch_variant<Variant<1, 1, true, 1, false, false, true>>(a, gx, gy, s);
+        else if (!sh.wide) launch_variant<Variant<1, 1, false, 1, false, false, true>>(a, gx, gy, s);
+        else if (sh.compact) launch_variant<Variant<2, 2, true, 1, false, false, true>>(a, gx, gy, s);
+        else launch_variant<Variant<2, 2, false, 1, false, false, true>>(a, gx, gy, s);
+        return;
+    }
     if (!sh.wide && sh.compact) {
         if (sh.lit) launch_by_load<1, true, true>(a, gx, sh, s);
         else launch_by_load<1, true, false>(a, gx, sh, s);
@@ -707,7 +736,7 @@ void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStr
 
 int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
-               const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out) {
+               const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out, const uint64_t *row_offset = nullptr) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
     if (n_cand == 0) return NM_OK;
@@ -759,7 +788,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (slot_used[sl]) { slot_to_active[sl] = (int)n_active; active[n_active++] = (uint32_t)sl; }
     }
     // ---- staging layout: candidate records (sorted) | orig_index | mask bytes | cand_range
-    const bool lit = all_literal && all_compact && !any_wide && !c->opt_no_lit;   // literal-only tiles exist for the narrow compact kernels
+    const bool per_contig = row_offset != nullptr;
+    const uint64_t out_rows = per_contig ? row_offset[n_cand] : n_cand;
+    if (per_contig)
+        for (uint32_t k = 0; k < n_cand; ++k)
+            if (row_offset[k + 1] - row_offset[k] != c->bin_ncontigs[cand_bin[k]])
+                return fail(NM_EINVAL, "candidate %u: %llu output rows for a bin of %u resident contigs", k,
+                            (unsigned long long)(row_offset[k + 1] - row_offset[k]), c->bin_ncontigs[cand_bin[k]]);
+    const bool lit = all_literal && all_compact && !any_wide && !c->opt_no_lit && !per_contig;   // literal-only tiles exist for the narrow compact kernels
     const uint32_t np = lit ? 4u : 8u;
     const uint32_t pdw = 2u * (any_wide ? 4u : 2u) * np;         // dwords per program: [strand][word-group][plane]
     const size_t rec_bytes = (size_t)n_prog * sizeof(CandRec);
@@ -768,7 +804,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const size_t off_range = (off_masks + (mask_bytes - mask_lo) + 15) & ~(size_t)15;
     const uint32_t n_entries = std::max(n_active, 1u) * n_bins;
     const size_t range_bytes = (size_t)n_entries * sizeof(uint4);
-    const size_t total = off_range + range_bytes;
+    const size_t off_rows = (off_range + range_bytes + 15) & ~(size_t)15;          // per-contig mode: row base per sorted candidate
+    const size_t total = off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
     int rc = ensure_stage(c, total);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
@@ -796,9 +833,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         const uint32_t at = bucket[(size_t)slot * n_bins + bin]++;
         h_rec[at] = CandRec{(uint32_t)(cand_mask_offset[k] - mask_lo), k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
         h_orig[at] = k;
+        if (per_contig) reinterpret_cast<uint64_t *>(hs + off_rows)[at] = row_offset[k];
     }
     // measured crossover (profiles/): up to ~6 candidates per (slot, bin) group the launch is HBM-bound
-    const bool light = (uint64_t)n_prog <= 6ull * n_groups;
+    const bool light = (uint64_t)n_prog <= 6ull * n_groups && !per_contig;
     const bool cf = light && !c->opt_no_cf;
     // device-side program buffer: two halves, one per staging pair, so that compiling batch k+1 (on the copy stream)
     // overlaps the scoring kernel of batch k; reuse of a half is gated like its staging pair (ensure_stage).  A light
@@ -833,16 +871,16 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
-        if (c->counts_cap < n_cand) {
+        if (c->counts_cap < out_rows) {
             if (c->d_counts) (void)hipFree(c->d_counts);
             c->d_counts = nullptr;
             c->counts_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_counts, (size_t)n_cand * 2 * sizeof(unsigned long long) * 2));
-            c->counts_cap = (size_t)n_cand * 2;
+            HIP_TRY(hipMalloc(&c->d_counts, (size_t)out_rows * 2 * sizeof(unsigned long long) * 2));
+            c->counts_cap = (size_t)out_rows * 2;
         }
         out = c->d_counts;
     }
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_cand * 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)out_rows * 2 * sizeof(unsigned long long), c->stream));
     // ---- launch
     ScoreArgs a{};
     a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
@@ -857,6 +895,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
     a.cand_range = reinterpret_cast<uint4 *>(ds + off_range);
     a.out = out;
+    a.chunk_rank = c->d_chunk_rank;
+    a.row_base = reinterpret_cast<const uint64_t *>(ds + off_rows);
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
@@ -869,7 +909,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (c->opt_split >= 0) split_log2 = (uint32_t)c->opt_split;
     a.split_log2 = split_log2;
     const uint32_t gx = (((c->n_segments << split_log2) + 7) / 8) * 8;
-    const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active};
+    const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
     const bool fuse = n_active == 2 && shape.light;
 
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
@@ -897,7 +937,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     c->last_compact = all_compact ? n_prog : 0;
     c->last_general = all_compact ? 0 : n_prog;
     if (h_out) {
-        HIP_TRY(hipMemcpyAsync(h_out, out, (size_t)n_cand * 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_out, out, (size_t)out_rows * 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return NM_OK;
@@ -966,7 +1006,8 @@ int nm_ctx_create(int device, nm_ctx **out) {
 
 static void free_assembly(nm_ctx *c) {
     drop_ingest_rows(c);
-    void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments};
+    void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments, c->d_chunk_rank};
+    c->d_chunk_rank = nullptr;
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     c->dH = c->dL = c->dV = nullptr;
@@ -1071,6 +1112,8 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bin_id[x] < bin_id[y]; });
     c->bin_chunk0.assign(n_bins, 0);
     c->bin_nchunks.assign(n_bins, 0);
+    c->bin_ncontigs.assign(n_bins, 0);
+    c->contig_rank.assign(n_contigs, 0);
     uint64_t next = 1;
     std::vector<uint32_t> chunk_contig(1, 0xFFFFFFFFu);
     for (uint32_t oi = 0; oi < n_contigs; ++oi) {
@@ -1080,6 +1123,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         c->contig_chunk[i] = (uint32_t)next;
         c->contig_nchunks[i] = (uint32_t)nch;
         const uint32_t b = bin_id[i];
+        c->contig_rank[i] = c->bin_ncontigs[b]++;              // position of the contig inside its bin (upload order)
         if (c->bin_nchunks[b] == 0) c->bin_chunk0[b] = (uint32_t)next;
         c->bin_nchunks[b] += (uint32_t)nch;
         chunk_contig.insert(chunk_contig.end(), nch, i);
@@ -1115,6 +1159,13 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     if (!on_device && c->total_bp) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
+    {   // per chunk: rank of its contig within its bin (the row of the per-contig counters)
+        std::vector<uint32_t> chunk_rank(c->n_chunks, 0);
+        for (uint32_t ch = 0; ch < c->n_chunks; ++ch)
+            if (chunk_contig[ch] != 0xFFFFFFFFu) chunk_rank[ch] = c->contig_rank[chunk_contig[ch]];
+        HIP_TRY(hipMalloc(&c->d_chunk_rank, (size_t)c->n_chunks * 4));
+        HIP_TRY(hipMemcpy(c->d_chunk_rank, chunk_rank.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemsetAsync(c->d_other, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, d_chunk_contig,
                        c->d_contig_chunk, c->dH, c->dL, c->dV, c->d_other);
@@ -1248,6 +1299,26 @@ int nm_score_batch_device(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, 
         return fail(NM_EINVAL, "NULL argument");
     return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks,
                       reinterpret_cast<unsigned long long *>(d_out_counts), nullptr);
+}
+
+int nm_score_batch_per_contig(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const uint8_t *cand_len,
+                              const uint8_t *cand_modpos, const uint32_t *cand_mask_offset, const uint8_t *cand_masks,
+                              const uint64_t *row_offset, int64_t *out_counts) {
+    if (!row_offset || (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !out_counts)))
+        return fail(NM_EINVAL, "NULL argument");
+    if (row_offset[0] != 0) return fail(NM_EINVAL, "row_offset[0] must be 0");
+    return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, out_counts, row_offset);
+}
+
+int nm_bin_contigs(nm_ctx *c, uint32_t bin, uint32_t *contig_ids, uint32_t capacity, uint32_t *n_contigs) {
+    if (!c || !n_contigs) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    if (bin >= c->n_bins) return fail(NM_EINVAL, "bin %u >= n_bins %u", bin, c->n_bins);
+    *n_contigs = c->bin_ncontigs[bin];
+    if (contig_ids)
+        for (uint32_t i = 0; i < c->n_contigs; ++i)
+            if (c->contig_bin[i] == bin && c->contig_rank[i] < capacity) contig_ids[c->contig_rank[i]] = i;
+    return NM_OK;
 }
 
 int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t len, uint8_t modpos, const uint8_t *masks,

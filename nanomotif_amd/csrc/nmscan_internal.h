@@ -102,7 +102,8 @@ struct nm_ctx {
     uint64_t total_bp = 0;
     std::vector<uint64_t> contig_len;
     std::vector<uint32_t> contig_chunk, contig_bin, contig_nchunks;
-    std::vector<uint32_t> bin_chunk0, bin_nchunks;
+    std::vector<uint32_t> bin_chunk0, bin_nchunks, bin_ncontigs, contig_rank;   // contig_rank: position of a contig inside its bin
+    uint32_t *d_chunk_rank = nullptr;                 // per chunk: contig_rank of its contig (per-contig counters)
     uint32_t *dH = nullptr, *dL = nullptr, *dV = nullptr;
     uint8_t *d_needs_v = nullptr;
     uint32_t *d_contig_chunk = nullptr;

@@ -560,6 +560,30 @@ class ScanEngine:
             _lib.check(self.lib.nm_score_batch(self.ctx, *self._batch_args(b), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def bin_contigs(self, bin_name) -> list:
+        """Resident contig names of a bin in the row order of ``score_per_contig`` (nm_bin_contigs)."""
+        b = self.bin_index[bin_name] if isinstance(bin_name, str) else int(bin_name)
+        n = C.c_uint32(0)
+        _lib.check(self.lib.nm_bin_contigs(self.ctx, b, None, 0, C.byref(n)))
+        ids = np.zeros(max(n.value, 1), dtype=np.uint32)
+        _lib.check(self.lib.nm_bin_contigs(self.ctx, b, _ptr(ids, C.c_uint32), n.value, C.byref(n)))
+        return [self.contig_names[i] for i in ids[:n.value].tolist()]
+
+    def score_per_contig(self, candidates):
+        """Per-contig (n_mod, n_nomod): ``motif_model_contig`` (find_motifs_bin.py:1285-1331) for every resident contig of
+        each candidate's bin in one launch (nm_score_batch_per_contig).  Returns a list, per candidate, of
+        (contig names, int64[n_contigs, 2])."""
+        b = candidates if isinstance(candidates, CandidateBatch) else self.make_batch(candidates)
+        names = {}
+        for bid in np.unique(b.bins).tolist():
+            names[bid] = self.bin_contigs(int(bid))
+        rows = np.zeros(len(b) + 1, dtype=np.uint64)
+        np.cumsum([len(names[int(x)]) for x in b.bins], out=rows[1:])
+        out = np.zeros((max(int(rows[-1]), 1), 2), dtype=np.int64)
+        if len(b):
+            _lib.check(self.lib.nm_score_batch_per_contig(self.ctx, *self._batch_args(b), _ptr(rows, C.c_uint64), _ptr(out, C.c_int64)))
+        return [(names[int(b.bins[k])], out[int(rows[k]):int(rows[k + 1])]) for k in range(len(b))]
+
     def score_into_device(self, batch: CandidateBatch, device_ptr: int):
         """Asynchronous variant: counts land in device memory (e.g. a torch int64 tensor) on the engine stream."""
         _lib.check(self.lib.nm_score_batch_device(self.ctx, *self._batch_args(batch), C.c_void_p(device_ptr)))
