@@ -147,7 +147,10 @@ typedef const uint8_t __attribute__((address_space(4))) *cu8p;
 // launch bounds (3 spills; -4 % with two children per group, +6 % with four); segments of 8 / 32 / 64 chunks (all
 // slower than 16); handing segments out through a device-wide atomic queue instead of one workgroup per segment
 // (-60 %: device-scope atomics are served at the memory side on this multi-die part and serialise).  A 10 Gbp run
-// takes 10.0 x the 1 Gbp time: there is no partial-last-round tail worth chasing.
+// takes 10.0 x the 1 Gbp time: there is no partial-last-round tail worth chasing at that size.  An EVEN static split —
+// exactly the resident number of workgroups, each walking an equal, candidate-weighted share of the active bins' chunks
+// across bin boundaries (parity green) — was 28 % slower at 1 Gbp and 20 % slower on a 125 Mbp shard: equal shares do
+// not finish together, and nothing rebalances them; the hardware dispatcher's one-workgroup-per-segment order does.
 #ifndef NM_LIT_WAVES
 #define NM_LIT_WAVES 4      // minimum waves per SIMD the literal-only variants are compiled for
 #endif
@@ -340,43 +343,14 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
 // With NS > 1 a tile's sequence planes are loaded and expanded once and serve the candidates of all NS slots (each slot
 // brings its own state planes); with NS = 1 the slot comes from blockIdx.y.  A pass handles up to BMAX / NS candidates
 // per slot; LDS rows are [candidate k][slot j].
+// One PIECE of work: the chunks [sg.x, sg.x + sg.y) of bin sg.z, all candidates of the workgroup's slot column(s), counters
+// accumulated in LDS and flushed to the count table at the end.  Called once per workgroup by score_kernel (piece = a
+// segment or a part of one).
 template <class K>
-__global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVES : 4))) void score_kernel(ScoreArgs a) {
+__device__ __forceinline__ void score_piece(const ScoreArgs &a, const uint4 sg, const StatePlanes (&stp)[K::NS], const bool (&is_c)[K::NS],
+                                            uint32_t *lds_acc, const int lane, const uint32_t wave) {
     constexpr int NS = K::NS;
-    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
     constexpr uint32_t H = BMAX / NS;
-    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
-    // of segments so candidate programs and counters of one bin stay in one L2.
-    const uint32_t nb = gridDim.x;
-    const uint32_t per = (nb + 7) / 8;
-    // (a light batch streams: there the remap costs 3 % of the read rate, tools/stream_pattern.hip)
-    const uint32_t vseg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
-    // a small assembly (a shard of a multi-GPU run, a single genome) has too few 16-chunk segments to fill the device
-    // for more than a round or two of workgroups: the host then cuts every segment into 2 or 4 pieces (split_log2)
-    const uint32_t seg = vseg >> a.split_log2;
-    if (seg >= a.n_segments) return;
-    uint4 sg = a.segments[seg];
-    sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
-    sg.y = __builtin_amdgcn_readfirstlane(sg.y);
-    sg.z = __builtin_amdgcn_readfirstlane(sg.z);
-    if (a.split_log2) {
-        const uint32_t piece = (sg.y + (1u << a.split_log2) - 1) >> a.split_log2;
-        const uint32_t at = (vseg & ((1u << a.split_log2) - 1)) * piece;
-        if (at >= sg.y) return;
-        sg.x += at;
-        sg.y = min(piece, sg.y - at);
-    }
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: chunk indices stay scalar
-    // per-slot facts are read from the kernel arguments once, not per chunk
-    StatePlanes stp[NS];
-    bool is_c[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const uint32_t slot = a.active_slot[NS == 1 ? blockIdx.y : (uint32_t)j];
-        stp[j] = a.st[slot];
-        is_c[j] = a.slot_is_c[slot] != 0;
-    }
     // the wave's first chunk is requested before anything else of the segment is looked at (candidate ranges, LDS
     // clearing, the barrier): a workgroup lives for four chunks per wave, its start-up chain would otherwise sit
     // in front of every fourth memory round trip
@@ -466,6 +440,48 @@ __global__ __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVE
         }
         flush_rows(rows_hi, pass0);
     }
+}
+
+#define NM_SCORE_BOUNDS __launch_bounds__(256, (K::GN + K::GP > 2 ? 2 : (K::LIT ? NM_LIT_WAVES : 4)))
+
+// per-slot facts are read from the kernel arguments once per workgroup
+#define NM_SLOT_SETUP                                                                                               \
+    const int lane = threadIdx.x & 63;                                                                              \
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); /* provably uniform: chunk indices stay scalar */ \
+    StatePlanes stp[K::NS];                                                                                         \
+    bool is_c[K::NS];                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < K::NS; ++j) {                                                             \
+        const uint32_t slot = a.active_slot[K::NS == 1 ? blockIdx.y : (uint32_t)j];                                 \
+        stp[j] = a.st[slot];                                                                                        \
+        is_c[j] = a.slot_is_c[slot] != 0;                                                                           \
+    }
+
+template <class K>
+__global__ NM_SCORE_BOUNDS void score_kernel(ScoreArgs a) {
+    __shared__ uint32_t lds_acc[BMAX * 2 * 64];
+    // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
+    // of segments so candidate programs and counters of one bin stay in one L2.
+    const uint32_t nb = gridDim.x;
+    const uint32_t per = (nb + 7) / 8;
+    // (a light batch streams: there the remap costs 3 % of the read rate, tools/stream_pattern.hip)
+    const uint32_t vseg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
+    // a small assembly (a shard of a multi-GPU run, a single genome) has too few 16-chunk segments to fill the device
+    // for more than a round or two of workgroups: the host then cuts every segment into 2 or 4 pieces (split_log2)
+    const uint32_t seg = vseg >> a.split_log2;
+    if (seg >= a.n_segments) return;
+    uint4 sg = a.segments[seg];
+    sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
+    sg.y = __builtin_amdgcn_readfirstlane(sg.y);
+    sg.z = __builtin_amdgcn_readfirstlane(sg.z);
+    if (a.split_log2) {
+        const uint32_t piece = (sg.y + (1u << a.split_log2) - 1) >> a.split_log2;
+        const uint32_t at = (vseg & ((1u << a.split_log2) - 1)) * piece;
+        if (at >= sg.y) return;
+        sg.x += at;
+        sg.y = min(piece, sg.y - at);
+    }
+    NM_SLOT_SETUP
+    score_piece<K>(a, sg, stp, is_c, lds_acc, lane, wave);
 }
 
 // One candidate record as the host stages it (sorted by mod-type slot, then bin).
@@ -896,7 +912,6 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.cand_range = reinterpret_cast<uint4 *>(ds + off_range);
     a.out = out;
     a.chunk_rank = c->d_chunk_rank;
-    a.row_base = reinterpret_cast<const uint64_t *>(ds + off_rows);
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
