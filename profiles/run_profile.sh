@@ -7,7 +7,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-B="python3 bench.py --cpu-bins 0 $*"
+B="python3 bench.py --cpu-bins 0 --extras none --hbm-round-steps 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/trace -- $B --steps 10 --warmup 2 > $out/bench_under_trace.log 2>&1
 find /tmp/prof_$tag/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 find /tmp/prof_$tag/trace -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > '$out'/kernel_trace_score.csv; grep score_kernel "$1" >> '$out'/kernel_trace_score.csv' _ {} \;
