@@ -79,3 +79,85 @@ def test_fuzz_counts_match_oracle(seed):
             exp = score_candidates({n: piles[mt][n] for n in contigs}, contigs, [(spec[k][0], spec[k][1]) for k in idx])
             assert np.array_equal(got[idx], exp), (seed, mt, b, [spec[k] for k in idx if got[k].tolist() != exp[idx.index(k)].tolist()][:3])
     eng.close()
+
+
+def _variants(rng, can, style):
+    """A (bin, mod type) group of a LIGHT batch: candidates that share most constraints, the shapes the common-constraint
+    factoring and the sibling descriptors of score_kernel see (find_motifs_bin.py:1116-1135, 1408-1432)."""
+    W = 41
+    core = ["."] * W
+    core[20] = can
+    alphabet = ["A", "C", "G", "T"] if style != "sets" else ["A", "C", "G", "T", "[AG]", "[CT]", "[ACG]", "[GT]"]
+    span = range(0, W) if style == "wide" else range(10, 31)
+    spots = [i for i in span if i != 20]
+    for q in rng.choice(spots, size=int(rng.integers(0, 5)), replace=False):
+        core[int(q)] = alphabet[int(rng.integers(len(alphabet)))]
+    free = [i for i in spots if core[i] == "."]
+    n = int(rng.integers(1, 9))
+    out = []
+    kind = rng.choice(["siblings", "two_extra", "mixed", "parents"])
+    for k in range(n):
+        c = list(core)
+        if kind == "siblings":                    # one more literal at ONE shared position
+            c[free[0]] = "ATGC"[k % 4] if k < 4 else c[free[0]]
+        elif kind == "two_extra":
+            for q in rng.choice(free, size=2, replace=False):
+                c[int(q)] = alphabet[int(rng.integers(len(alphabet)))]
+        elif kind == "mixed":                     # the parent itself, a child, a grandchild, a duplicate
+            for q in rng.choice(free, size=int(rng.integers(0, 3)), replace=False):
+                c[int(q)] = "ACGT"[int(rng.integers(4))]
+        else:                                     # pruning round: the motif and its parents (one position blanked each)
+            spec = [i for i in range(W) if c[i] != "." and i != 20]
+            if k and spec:
+                c[spec[(k - 1) % len(spec)]] = "."
+        out.append(("".join(c), 20))
+    return out
+
+
+@pytest.mark.parametrize("seed,style", [(0, "literal"), (1, "literal"), (2, "sets"), (3, "wide"), (4, "general"), (5, "literal")])
+def test_fuzz_light_batches_common_factoring_and_siblings(seed, style):
+    """Light batches (<= 6 candidates per group on average): literal-only tiles, common-constraint factoring, sibling
+    descriptors, fused two-slot launches — against the oracle, with motifs that share their parent."""
+    from nanomotif_amd.engine import ScanEngine
+    from oracle.scan import ContigPileup, score_candidates
+    rng = np.random.default_rng(7000 + seed)
+    lens = [int(x) for x in rng.choice([40, 100, 8191, 8192, 8193, 20_000, 16_384, 50_000, 130_000], size=10)]
+    names = [f"c{i}" for i in range(len(lens))]
+    seqs = [_contig(rng, n) for n in lens]
+    bins = [f"b{int(rng.integers(5))}" for _ in lens]
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, seqs, bins)
+    fr_values = np.array([0.0, 0.1, 0.3, 0.5, 0.7, 0.95, 1.0])
+    piles = {}
+    mods = ("a", "m") if seed != 5 else ("a",)                      # seed 5: one slot (no fusion)
+    for mt in mods:
+        piles[mt] = {}
+        cid, pos, st, fr = [], [], [], []
+        for i, n in enumerate(lens):
+            flat = rng.choice(2 * n, size=int(rng.integers(0, 2 * n + 1)), replace=False)
+            p, strand = (flat // 2).astype(np.int64), np.where(flat % 2 == 0, ord("+"), ord("-")).astype(np.uint8)
+            f = rng.choice(fr_values, size=len(p))
+            piles[mt][names[i]] = ContigPileup(p, strand, f)
+            cid.append(np.full(len(p), i, np.uint32)); pos.append(p); st.append(strand); fr.append(f)
+        eng.upload_pileup(mt, np.concatenate(cid), np.concatenate(pos), np.concatenate(st), np.concatenate(fr))
+    for rnd in range(6):
+        cands, spec = [], []
+        for b in sorted(set(bins)):
+            for mt in mods:
+                if rng.random() < 0.25:
+                    continue                                           # a search that is not asking this round
+                can = {"a": "A", "m": "C"}[mt] if style != "general" else "ACGT"[int(rng.integers(4))]
+                for s, p in _variants(rng, can, style):
+                    cands.append((Motif(s, p), mt, b)); spec.append((s, p, mt, b))
+        if not cands:
+            continue
+        got = eng.score(cands)
+        for mt in mods:
+            for b in sorted(set(bins)):
+                idx = [k for k, (_, _, m2, b2) in enumerate(spec) if (m2, b2) == (mt, b)]
+                if not idx:
+                    continue
+                contigs = {names[i]: seqs[i].upper() for i in range(len(lens)) if bins[i] == b}
+                exp = score_candidates({n: piles[mt][n] for n in contigs}, contigs, [(spec[k][0], spec[k][1]) for k in idx])
+                assert np.array_equal(got[idx], exp), (seed, style, rnd, mt, b, [spec[k] for k in idx if got[k].tolist() != exp[idx.index(k)].tolist()][:3])
+    eng.close()
