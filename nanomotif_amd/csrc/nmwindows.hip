@@ -42,62 +42,97 @@ __global__ void win_pack_kernel(WinTask t, const uint8_t *__restrict__ sets, uin
 // match the motif (every window base must be inside the motif's set at that column; an N window only matches '.');
 // kind 1: remove the matching windows from alive and report alive counts before / after.
 // out[req] = { n_active | before, 0 | after, counts[4 rows A,T,G,C][width] }  (int32)
+// Work split: blockIdx.x = request, blockIdx.y = group of WIN_COL_GROUP columns whose counters this workgroup keeps in
+// registers (a lane owns 32 windows per word it visits; the 4 x WIN_COL_GROUP per-lane counters are reduced over the wave
+// ONCE, after the last word — reducing 164 counters per visited word, as the first version did, was the largest kernel
+// of the whole search), blockIdx.z = slice of the task's words.  Every column group recomputes the match mask (a few
+// plane words per specified motif position); group 0 also counts the active windows and serves the removals.
+constexpr int WIN_COL_GROUP = 8;
+
 __global__ __launch_bounds__(256) void win_request_kernel(const WinTask *__restrict__ tasks, uint32_t n_req,
                                                           const uint32_t *__restrict__ req_task,
                                                           const uint8_t *__restrict__ req_kind,
                                                           const uint8_t *__restrict__ req_sets /*[n_req][WIN_MAX_W]*/,
                                                           const uint32_t *__restrict__ planes, uint32_t *alive,
                                                           int *__restrict__ out, uint32_t out_stride) {
-    __shared__ int cnt[2 + 4 * WIN_MAX_W];
     __shared__ uint8_t mset[WIN_MAX_W];
     const uint32_t r = blockIdx.x;
     const WinTask t = tasks[req_task[r]];
     const uint32_t kind = req_kind[r];
-    for (uint32_t i = threadIdx.x; i < 2 + 4 * WIN_MAX_W; i += blockDim.x) cnt[i] = 0;
+    const uint32_t col0 = blockIdx.y * WIN_COL_GROUP;
+    if (col0 >= t.width || (kind == 1 && blockIdx.y != 0)) return;
     if (threadIdx.x < WIN_MAX_W) mset[threadIdx.x] = threadIdx.x < t.width ? req_sets[(size_t)r * WIN_MAX_W + threadIdx.x] : 15;
     __syncthreads();
     const uint32_t *pl = planes + t.plane_off;
     uint32_t *al = alive + t.alive_off;
-    // word slices of this request are spread over gridDim.y workgroups
-    for (uint32_t w = blockIdx.y * blockDim.x + threadIdx.x; w < t.nw; w += gridDim.y * blockDim.x) {
+    const uint64_t nw = t.nw;
+    int cnt[WIN_COL_GROUP][4];
+#pragma unroll
+    for (int c = 0; c < WIN_COL_GROUP; ++c)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cnt[c][b] = 0;
+    int n_a = 0, n_b = 0;
+    for (uint32_t w = blockIdx.z * blockDim.x + threadIdx.x; w < t.nw; w += gridDim.z * blockDim.x) {
         uint32_t match = 0xFFFFFFFFu;
         for (uint32_t col = 0; col < t.width; ++col) {
             const uint32_t m = mset[col];
             if (m == 15) continue;
-            const uint32_t *p = pl + (uint64_t)col * 5 * t.nw + w;
+            const uint32_t *p = pl + (uint64_t)col * 5 * nw + w;
             uint32_t ok = 0;
             if (m & 1) ok |= p[0];
-            if (m & 2) ok |= p[(uint64_t)t.nw];
-            if (m & 4) ok |= p[2ull * t.nw];
-            if (m & 8) ok |= p[3ull * t.nw];
+            if (m & 2) ok |= p[nw];
+            if (m & 4) ok |= p[2 * nw];
+            if (m & 8) ok |= p[3 * nw];
             match &= ok;
         }
         const uint32_t a = al[w];
         if (kind == 1) {
             const uint32_t na = a & ~match;
             al[w] = na;
-            atomicAdd(&cnt[0], __popc(a));
-            atomicAdd(&cnt[1], __popc(na));
+            n_a += __popc(a);
+            n_b += __popc(na);
             continue;
         }
         const uint32_t active = a & match;
         if (!active) continue;
-        atomicAdd(&cnt[0], __popc(active));
-        for (uint32_t col = 0; col < t.width; ++col) {
-            const uint32_t *p = pl + (uint64_t)col * 5 * t.nw + w;
-            const int n_any = __popc(active & p[4ull * t.nw]);
-            const int ca = __popc(active & p[0]) + n_any, cc = __popc(active & p[(uint64_t)t.nw]) + n_any;
-            const int cg = __popc(active & p[2ull * t.nw]) + n_any, ct = __popc(active & p[3ull * t.nw]) + n_any;
-            if (ca) atomicAdd(&cnt[2 + 0 * WIN_MAX_W + col], ca);      // row order A, T, G, C (constants.py:1)
-            if (ct) atomicAdd(&cnt[2 + 1 * WIN_MAX_W + col], ct);
-            if (cg) atomicAdd(&cnt[2 + 2 * WIN_MAX_W + col], cg);
-            if (cc) atomicAdd(&cnt[2 + 3 * WIN_MAX_W + col], cc);
+        n_a += __popc(active);
+#pragma unroll
+        for (int c = 0; c < WIN_COL_GROUP; ++c) {
+            if (col0 + c >= t.width) break;                            // uniform
+            const uint32_t *p = pl + (uint64_t)(col0 + c) * 5 * nw + w;
+            const uint32_t any = p[4 * nw];                            // an N window counts for all four letters
+            cnt[c][0] += __popc(active & (p[0] | any));
+            cnt[c][1] += __popc(active & (p[nw] | any));
+            cnt[c][2] += __popc(active & (p[2 * nw] | any));
+            cnt[c][3] += __popc(active & (p[3 * nw] | any));
         }
     }
-    __syncthreads();
+    // one reduction per counter and wave, one atomic per non-zero sum
     int *o = out + (size_t)r * out_stride;
-    for (uint32_t i = threadIdx.x; i < 2 + 4 * WIN_MAX_W; i += blockDim.x)
-        if (cnt[i]) atomicAdd(&o[i], cnt[i]);
+    const int lane = threadIdx.x & 63;
+    auto wave_sum = [](int v) {
+#pragma unroll
+        for (int s = 32; s; s >>= 1) v += __shfl_xor(v, s);
+        return v;
+    };
+    if (blockIdx.y == 0) {
+        n_a = wave_sum(n_a);
+        n_b = wave_sum(n_b);
+        if (lane == 0 && n_a) atomicAdd(&o[0], n_a);
+        if (lane == 0 && n_b) atomicAdd(&o[1], n_b);
+    }
+    if (kind == 1) return;
+#pragma unroll
+    for (int c = 0; c < WIN_COL_GROUP; ++c) {
+        if (col0 + c >= t.width) break;
+        const int ca = wave_sum(cnt[c][0]), cc = wave_sum(cnt[c][1]), cg = wave_sum(cnt[c][2]), ct = wave_sum(cnt[c][3]);
+        if (lane == 0) {                                               // row order A, T, G, C (constants.py:1)
+            if (ca) atomicAdd(&o[2 + 0 * WIN_MAX_W + col0 + c], ca);
+            if (ct) atomicAdd(&o[2 + 1 * WIN_MAX_W + col0 + c], ct);
+            if (cg) atomicAdd(&o[2 + 2 * WIN_MAX_W + col0 + c], cg);
+            if (cc) atomicAdd(&o[2 + 3 * WIN_MAX_W + col0 + c], cc);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -462,8 +497,8 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     memcpy(hs + o_sets, req_sets, (size_t)n_req * WIN_MAX_W);
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
-    const uint32_t gy = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
-    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, gy), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
+    const uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
+    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, (WIN_MAX_W + WIN_COL_GROUP - 1) / WIN_COL_GROUP, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), stride);
     HIP_TRY(hipGetLastError());

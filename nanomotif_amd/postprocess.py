@@ -36,12 +36,20 @@ class MotifRow:
         return int(self.model._beta - self.model._beta_prior)
 
     def _derived(self):
-        """(motif_iupac, mod_position_iupac), computed once per row (rows are never mutated after creation)."""
+        """(motif_iupac, mod_position_iupac, reverse complement of motif_iupac), computed once per row (rows are never
+        mutated after creation)."""
         d = self.__dict__.get("_cache")
         if d is None:
-            st = Motif(self.motif, self.mod_position).new_stripped_motif()
-            d = self.__dict__["_cache"] = (st.iupac(), int(st.mod_position))
+            st = self.as_motif().new_stripped_motif()
+            iu = st.iupac()
+            d = self.__dict__["_cache"] = (iu, int(st.mod_position), reverse_compliment(iu))
         return d
+
+    def as_motif(self):
+        m = self.__dict__.get("_motif")
+        if m is None:
+            m = self.__dict__["_motif"] = Motif(self.motif, self.mod_position)
+        return m
 
     @property
     def motif_iupac(self):
@@ -75,7 +83,7 @@ def graph_to_rows(graph, best, bin_name, mod_type, padding):
 
 def remove_noisy_motifs(rows):
     """postprocess.py:7-25."""
-    clean = {r.motif for r in rows if not Motif(r.motif, r.mod_position).have_isolated_bases(isolation_size=3)}
+    clean = {r.motif for r in rows if not r.as_motif().have_isolated_bases(isolation_size=3)}
     return rows if not clean else [r for r in rows if r.motif in clean]
 
 
@@ -110,7 +118,7 @@ def _merge_motifs_co(rows, merge_threshold=0.5):
     if not rows:
         return rows
     bin_name, mod_type = rows[0].reference, rows[0].mod_type
-    motifs = [Motif(r.motif, r.mod_position) for r in rows]
+    motifs = [r.as_motif() for r in rows]
     clusters = merge_motifs(motifs)
     # one batch: every merged motif and every pre-merge variant that needs a scan
     need = [(k, c) for k, c in enumerate(clusters) if len(c[3]) > 0]
@@ -150,7 +158,9 @@ def _merge_motifs_co(rows, merge_threshold=0.5):
 
 def remove_sub_motifs(rows):
     """postprocess.py:52-82 for one (reference, mod_type) group."""
-    motifs = [Motif(r.motif, r.mod_position) for r in rows]
+    if len(rows) < 2:
+        return list(rows)
+    motifs = [r.as_motif() for r in rows]
     group = list(rows)
     out = list(rows)
     for parent, child in get_motif_parental_relationship(motifs):
@@ -167,7 +177,7 @@ def join_motif_complements(rows):
     out = []
     for r in rows:
         partners = [o for o in rows if o.reference == r.reference and o.mod_type == r.mod_type
-                    and reverse_compliment(o.motif_iupac) == r.motif_iupac]
+                    and o._derived()[2] == r.motif_iupac]
         if not partners:
             out.append(MotifRow(r.reference, r.motif, r.mod_type, r.mod_position, r.model, r.score, None, True))
             continue
