@@ -102,15 +102,31 @@ class Collective:
     host round trip with gloo — the debugging backend that lets several ranks share one GPU)."""
 
     def __init__(self, kind, eng, world, rank, device, backend):
+        import torch
         import torch.distributed as dist
         self.kind, self.eng, self.dist, self.backend, self.world = kind, eng, dist, backend, world
         self.pending = {}
         if kind == "native":
-            uid = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init(rank, world, uid[0])
+            # every rank must end up on the same path: agree on success before anybody uses the communicator
+            ok = 1
+            try:
+                uid = [eng.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(uid, src=0)
+                eng.comm_init(rank, world, uid[0])
+            except Exception as e:                      # no librccl, duplicate device, ...: torch.distributed carries the tables
+                ok = 0
+                print(f"[bench] rank {rank}: nm_comm_init failed ({e}); falling back to torch.distributed", file=sys.stderr, flush=True)
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag[0])
+            if ok == 0:
+                self.kind = "torch" if world > 1 else "none"
 
     def start(self, slot, tensor):
+        if self.kind == "none":
+            return
         if self.kind == "native":
             self.eng.allreduce_counts_device(tensor.data_ptr(), tensor.numel(), slot)
         elif self.backend == "nccl":
@@ -283,6 +299,7 @@ def main():
     ap.add_argument("--allreduce", choices=["auto", "native", "torch"], default="auto",
                     help="count-table all-reduce: nm_allreduce_counts of the C ABI (RCCL) or torch.distributed; auto = native with nccl")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
+    ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak (auto: all that apply; none)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
@@ -334,7 +351,7 @@ def main():
         return [o.tolist() for o in out]
 
     weak = args.scaling == "weak"
-    reduce_counts = world > 1 and not weak
+    reduce_counts = (world > 1 and not weak) or args.force_allreduce
     seed = 1 + rank if weak else 1
     spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
     mg = synth.make_metagenome(synth.SynthSpec(**spec_kw))
@@ -472,7 +489,8 @@ def main():
     allreduce_ms = None
     if coll:
         torch.cuda.synchronize(device)
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         for k in range(args.steps):
             coll.wait(k & 1)
@@ -531,7 +549,7 @@ def main():
                        "contigs": args.contigs * nw, "bins": args.bins * nw, "mod_types": ["a", "m"],
                        "sharding": ("whole metagenome per GPU, no collective" if weak or world == 1 else
                                     f"contigs over {world} GPUs, longest-first, bins kept whole when small (nanomotif_amd/shard.py); "
-                                    f"count tables summed by {'nm_allreduce_counts (RCCL, C ABI)' if use_native else 'torch.distributed ' + args.dist_backend}"),
+                                    f"count tables summed by {'nm_allreduce_counts (RCCL, C ABI)' if (coll and coll.kind == 'native') else 'torch.distributed ' + args.dist_backend}"),
                        "motif_sites_per_step": sites_per_step * nw},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -540,7 +558,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
-            "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
+            "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
             "allreduce_ms": allreduce_ms,
             "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
                                 int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],

@@ -42,7 +42,7 @@ def test_bench_json_contract():
     assert e["wall_s"] > 0 and e["search_s"] > 0 and e["gpu_busy_s"] >= 0 and e["rounds"] > 0 and e["wall_s"] >= e["search_s"]
     assert d["cfg5_all"]["agrees_with_per_bin_table"] is True and d["cfg5_all"]["value"] > 0
     assert d["roofline_hbm_bound_round"]["frac"] > 0 and "traffic_frac_of_streaming" in d["roofline_hbm_bound_round"]
-    assert d["per_rank"][0]["kernel_ms"] > 0 and d["per_rank"][0]["host_ms_per_step"] > 0
+    assert d["per_rank"][0]["kernel_ms"] > 0 and d["per_rank"][0]["host_call_ms_per_step"] > 0
 
 
 def _bench(extra, nproc=1, launcher=True):
@@ -88,6 +88,15 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and len(d["per_rank"]) == 2
     one = _bench([])
     assert d["counts_checksum"] == one["counts_checksum"]
+
+
+def test_single_rank_step_with_the_c_abi_allreduce():
+    """--force-allreduce: the strong-scaling step (score into table i, nm_allreduce_counts_async on the communication
+    stream, nm_comm_wait before table i is reused) with an RCCL world of one rank — same table, all-reduce timed."""
+    one = _bench([])
+    d = _bench(["--force-allreduce"])
+    assert d["counts_checksum"] == one["counts_checksum"] and d["allreduce_ms"] > 0
+    assert "nm_allreduce_counts" in d["config"]["sharding"] or d["n_gpus"] == 1
 
 
 def test_gpus_flag_must_match_world_size():
