@@ -912,6 +912,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     a.cand_range = reinterpret_cast<uint4 *>(ds + off_range);
     a.out = out;
     a.chunk_rank = c->d_chunk_rank;
+    a.row_base = reinterpret_cast<const uint64_t *>(ds + off_rows);
     for (uint32_t i = 0; i < n_active; ++i) a.active_slot[i] = active[i];
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
