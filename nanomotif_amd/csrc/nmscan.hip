@@ -33,7 +33,8 @@ struct ScoreArgs {
     StatePlanes st[NM_MAX_MOD_SLOTS];
     const uint4 *segments;      // {first chunk, n chunks, bin, 0}
     uint32_t n_segments;
-    uint32_t split_log2;        // every segment is cut into 1 << split_log2 workgroups
+    uint32_t split_log2;        // every segment is cut into 1 << split_log2 pieces
+    uint32_t pieces_per_run, j_big, fine_log2;   // per run of pieces: the first j_big go whole, the rest in 1 << fine_log2 parts
     uint32_t n_bins;
     const uint4 *cand_range;    // [active_slot_index][bin] -> {begin, count, common program or ~0, -} into programs
     const uint32_t *programs;   // [n_prog][2 * (GN + GP) * 8], sorted by (slot, bin)
@@ -461,24 +462,41 @@ __global__ NM_SCORE_BOUNDS void score_kernel(ScoreArgs a) {
     __shared__ uint32_t lds_acc[BMAX * 2 * 64];
     // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), give every XCD a contiguous run
     // of segments so candidate programs and counters of one bin stay in one L2.
-    const uint32_t nb = gridDim.x;
-    const uint32_t per = (nb + 7) / 8;
     // (a light batch streams: there the remap costs 3 % of the read rate, tools/stream_pattern.hip)
-    const uint32_t vseg = K::CF ? blockIdx.x : (blockIdx.x % 8) * per + blockIdx.x / 8;
-    // a small assembly (a shard of a multi-GPU run, a single genome) has too few 16-chunk segments to fill the device
-    // for more than a round or two of workgroups: the host then cuts every segment into 2 or 4 pieces (split_log2)
-    const uint32_t seg = vseg >> a.split_log2;
+    const uint32_t lanes_x = K::CF ? 1u : 8u;                  // runs of pieces: one per XCD, or a single one
+    const uint32_t x = K::CF ? 0u : blockIdx.x % 8, j = K::CF ? blockIdx.x : blockIdx.x / 8;
+    // Pieces: a segment (16 chunks), or a half / quarter of one for assemblies that fill the device for less than two
+    // rounds of workgroups (split_log2).  The workgroups dispatched LAST (j >= j_big in every run) take pieces cut
+    // finer still (fine_log2): the last, partly filled round of workgroups then lasts a quarter as long.
+    uint32_t piece, sub = 0, n_sub = 1;
+    if (j < a.j_big) piece = x * a.pieces_per_run + j;
+    else {
+        const uint32_t k = j - a.j_big;
+        piece = x * a.pieces_per_run + a.j_big + (k >> a.fine_log2);
+        sub = k & ((1u << a.fine_log2) - 1);
+        n_sub = 1u << a.fine_log2;
+        if (a.j_big + (k >> a.fine_log2) >= a.pieces_per_run) return;
+    }
+    (void)lanes_x;
+    const uint32_t seg = piece >> a.split_log2;
     if (seg >= a.n_segments) return;
     uint4 sg = a.segments[seg];
     sg.x = __builtin_amdgcn_readfirstlane(sg.x);   // everything below is wave-uniform: keep it in SGPRs
     sg.y = __builtin_amdgcn_readfirstlane(sg.y);
     sg.z = __builtin_amdgcn_readfirstlane(sg.z);
     if (a.split_log2) {
-        const uint32_t piece = (sg.y + (1u << a.split_log2) - 1) >> a.split_log2;
-        const uint32_t at = (vseg & ((1u << a.split_log2) - 1)) * piece;
+        const uint32_t len = (sg.y + (1u << a.split_log2) - 1) >> a.split_log2;
+        const uint32_t at = (piece & ((1u << a.split_log2) - 1)) * len;
         if (at >= sg.y) return;
         sg.x += at;
-        sg.y = min(piece, sg.y - at);
+        sg.y = min(len, sg.y - at);
+    }
+    if (n_sub > 1) {
+        const uint32_t len = (sg.y + n_sub - 1) / n_sub;
+        const uint32_t at = sub * len;
+        if (at >= sg.y) return;
+        sg.x += at;
+        sg.y = min(len, sg.y - at);
     }
     NM_SLOT_SETUP
     score_piece<K>(a, sg, stp, is_c, lds_acc, lane, wave);
@@ -924,7 +942,18 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     while (split_log2 < 2 && (est_wgs << split_log2) < 2 * resident) ++split_log2;      // measured (tools/gpu_r2f.sh): halves win below ~2 rounds, quarters never
     if (c->opt_split >= 0) split_log2 = (uint32_t)c->opt_split;
     a.split_log2 = split_log2;
-    const uint32_t gx = (((c->n_segments << split_log2) + 7) / 8) * 8;
+    // grid: runs of pieces (8 for the XCD-remapped heavy variants, 1 for the streaming ones); in every run the pieces a
+    // full round of resident workgroups would take LAST are cut finer (down to 4 chunks = one per wave)
+    const bool streaming = light && !c->opt_no_cf;
+    const uint32_t runs = streaming ? 1u : 8u;
+    const uint32_t n_pieces = c->n_segments << split_log2;
+    a.pieces_per_run = (n_pieces + runs - 1) / runs;
+    a.fine_log2 = c->opt_fine >= 0 ? (uint32_t)c->opt_fine : 2u - split_log2;
+    const uint32_t cols = std::max(1u, (streaming && n_active == 2) ? 1u : n_active);
+    uint32_t tail_pieces = (uint32_t)std::min<uint64_t>(a.pieces_per_run, (resident / cols + runs - 1) / runs);
+    if (a.fine_log2 == 0) tail_pieces = 0;
+    a.j_big = a.pieces_per_run - tail_pieces;
+    const uint32_t gx = (a.j_big + (tail_pieces << a.fine_log2)) * runs;
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
     const bool fuse = n_active == 2 && shape.light;
 
@@ -981,6 +1010,7 @@ const char *nm_last_error(void) { return g_err.c_str(); }
 static int ctx_init(nm_ctx *c) {
     c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
     c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
+    if (const char *e = getenv("NM_FINE")) c->opt_fine = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("NM_SPLIT")) c->opt_split = std::max(0, std::min(2, atoi(e)));
     {
         int cus = 0;
