@@ -236,10 +236,7 @@ struct Tile {
 // (prog[g * NP + p], bit r; g counts from the leftmost word-group the variant reads).  Control flow is scalar and
 // wave-uniform (s_ff1 over the SGPR masks), register indices are static.
 template <class K>
-__device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uint32_t (&acc)[T_WORDS]) {
-    uint32_t m[K::PDW];
-#pragma unroll
-    for (int i = 0; i < K::PDW; ++i) m[i] = prog[i];
+__device__ __forceinline__ void eval_masks(const uint32_t (&m)[K::PDW], const Tile<K> &tile, uint32_t (&acc)[T_WORDS]) {
 #pragma unroll
     for (int g = 0; g < K::GN + K::GP; ++g) {            // word pair (t + g, t + g + 1)
 #pragma unroll
@@ -253,6 +250,14 @@ __device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uin
             }
         }
     }
+}
+
+template <class K>
+__device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uint32_t (&acc)[T_WORDS]) {
+    uint32_t m[K::PDW];
+#pragma unroll
+    for (int i = 0; i < K::PDW; ++i) m[i] = prog[i];
+    eval_masks<K>(m, tile, acc);
 }
 
 // acc = base & (the ONE constraint `desc` = (mask index << 5) | r of a strand): the residual of a sibling child once the
@@ -296,6 +301,16 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
         eval_strand<K>(prog, tile, basef);
         eval_strand<K>(prog + K::PDW, tile, baser);
     }
+    // Scalar loads of the masks are software-pipelined at strand granularity: the reverse masks of candidate k are
+    // requested before its forward strand is evaluated, the forward masks of candidate k + 1 before its reverse strand —
+    // two sets of SGPRs like before, but a load's latency hides behind ~40 vector instructions instead of standing in
+    // front of every strand.
+    uint32_t mf[K::PDW], mr[K::PDW];
+    if (!(K::CF && siblings)) {
+        cu32p prog = (cu32p)(a.programs + (size_t)k0 * (2 * K::PDW));
+#pragma unroll
+        for (int i = 0; i < K::PDW; ++i) mf[i] = prog[i];
+    }
     for (uint32_t k = 0; k < nb; ++k) {
         cu32p prog = (cu32p)(a.programs + (size_t)(k0 + k) * (2 * K::PDW));
         uint32_t accf[T_WORDS], accr[T_WORDS];
@@ -305,9 +320,16 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
             apply_single<K>(dr >> 5, dr & 31u, tile, baser, accr);
         } else {
 #pragma unroll
-            for (int t = 0; t < T_WORDS; ++t) { accf[t] = basef[t]; accr[t] = baser[t]; }
-            eval_strand<K>(prog, tile, accf);
-            eval_strand<K>(prog + K::PDW, tile, accr);
+            for (int i = 0; i < K::PDW; ++i) mr[i] = prog[K::PDW + i];
+#pragma unroll
+            for (int t = 0; t < T_WORDS; ++t) accf[t] = basef[t];
+            eval_masks<K>(mf, tile, accf);
+            cu32p next = (cu32p)(a.programs + (size_t)(k0 + min(k + 1, nb - 1)) * (2 * K::PDW));
+#pragma unroll
+            for (int i = 0; i < K::PDW; ++i) mf[i] = next[i];
+#pragma unroll
+            for (int t = 0; t < T_WORDS; ++t) accr[t] = baser[t];
+            eval_masks<K>(mr, tile, accr);
         }
         uint32_t n_mod = 0, n_non = 0;
 #pragma unroll
@@ -747,7 +769,7 @@ void launch_variant(const ScoreArgs &a, uint32_t gx, uint32_t gy, hipStream_t s)
 template <int G, bool COMPACT, bool LIT>
 void launch_by_load(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStream_t s) {
     if (!sh.light) launch_variant<Variant<G, G, COMPACT, 1, LIT, false>>(a, gx, std::max(sh.n_active, 1u), s);
-    else if (sh.n_active == 2) launch_variant<Variant<G, G, COMPACT, 2, LIT, true>>(a, gx, 1, s);
+    else if (sh.n_active == 2 && LIT) launch_variant<Variant<G, G, COMPACT, 2, LIT, true>>(a, gx, 1, s);   // (fusing two slots on the 8-plane tile needs 128 VGPRs)
     else launch_variant<Variant<G, G, COMPACT, 1, LIT, true>>(a, gx, std::max(sh.n_active, 1u), s);
 }
 
@@ -936,7 +958,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
     // workgroups the last, partly filled round is a large share of the launch -> smaller pieces
     uint64_t est_wgs = (uint64_t)c->n_segments * n_groups / std::max<uint32_t>(n_bins, 1);
-    if (light && n_active == 2) est_wgs = (est_wgs + 1) / 2;          // fused slots: one workgroup serves both
+    if (light && n_active == 2 && lit) est_wgs = (est_wgs + 1) / 2;   // fused slots: one workgroup serves both
     const uint64_t resident = (uint64_t)c->n_cus * 6;
     uint32_t split_log2 = 0;
     while (split_log2 < 2 && (est_wgs << split_log2) < 2 * resident) ++split_log2;      // measured (tools/gpu_r2f.sh): halves win below ~2 rounds, quarters never
@@ -949,13 +971,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const uint32_t n_pieces = c->n_segments << split_log2;
     a.pieces_per_run = (n_pieces + runs - 1) / runs;
     a.fine_log2 = c->opt_fine >= 0 ? (uint32_t)c->opt_fine : 2u - split_log2;
-    const uint32_t cols = std::max(1u, (streaming && n_active == 2) ? 1u : n_active);
+    const uint32_t cols = std::max(1u, (streaming && n_active == 2 && lit) ? 1u : n_active);
     uint32_t tail_pieces = (uint32_t)std::min<uint64_t>(a.pieces_per_run, (resident / cols + runs - 1) / runs);
     if (a.fine_log2 == 0) tail_pieces = 0;
     a.j_big = a.pieces_per_run - tail_pieces;
     const uint32_t gx = (a.j_big + (tail_pieces << a.fine_log2)) * runs;
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
-    const bool fuse = n_active == 2 && shape.light;
+    const bool fuse = n_active == 2 && shape.light && lit;
 
     hipEvent_t e0 = c->ev0, e1 = c->ev1;
     if (c->ev_collect) {
