@@ -60,6 +60,25 @@ def test_cfg2_5mbp_contig_200_candidates_bit_exact():
 
 
 @pytest.mark.timeout(2400)
+def test_cfg3_full_loop_every_bin():
+    """cfg 3 (100 Mbp, 1000 contigs, 50 bins, 6mA + 5mC): the whole pipeline on the device, and EVERY bin's motif rows
+    byte-equal to the oracle's pipeline (filters -> search -> post-processing) — 100 searches, none sampled away."""
+    import torch
+    from nanomotif_amd import e2e_synth, postprocess
+    from nanomotif_amd.engine import ScanEngine
+    spec = synth.config("cfg3")
+    mg = synth.make_metagenome(spec)
+    eng = ScanEngine(0)
+    rows, t = e2e_synth.run(mg, eng, torch.device("cuda:0"))
+    eng.close()
+    bins = sorted(set(mg.bin_names))
+    got = postprocess.format_bin_motifs([r for r in rows if r.n_mod + r.n_nomod >= 50])
+    exp = oracle_pipeline_parallel(mg, bins, PROCS)
+    assert got == exp
+    assert got.count("\n") > 50 and t["rounds"] > 20
+
+
+@pytest.mark.timeout(2400)
 def test_cfg5_10k_candidates_1gbp():
     """The exact workload of the default bench.py run: 10 000 seed-2 candidates (20 per bin) on the seed-1 1 Gbp
     metagenome.  >= 32 whole bins against the oracle, the shard-sum invariant the RCCL all-reduce relies on, and the
