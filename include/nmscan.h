@@ -326,6 +326,12 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
  */
 typedef struct nm_bed nm_bed;
 int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
+/* The tabix path of the reference (dataload.py:102-152, find_motifs_bin.py:233-246: the records of a bin's contigs are
+ * fetched through the .tbi index): only the BGZF blocks holding the n_contigs wanted contigs (names back to back,
+ * name_offset[n_contigs + 1]) are inflated and parsed; contigs absent from the index are skipped.  stats (may be NULL):
+ * {bytes inflated, bytes of the compressed file}.  NM_EINVAL "not a tabix index" when tbi_path is not one. */
+int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
+                        uint32_t threads, nm_bed **out, uint64_t stats[2]);
 int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);
 int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
 int nm_bed_mod_code(nm_bed *bed, uint32_t id, const char **code);

@@ -303,6 +303,21 @@ static int load_file(const char *path, unsigned threads, Buffer *buf, const char
     return NM_OK;
 }
 
+// map a file as it is (no inflation)
+static int load_file_raw(const char *path, Buffer *buf) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return nm_set_error(NM_EINVAL, "cannot open '%s'", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return nm_set_error(NM_EINVAL, "cannot stat '%s'", path); }
+    if (st.st_size > 0) {
+        buf->map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        buf->map_size = (size_t)st.st_size;
+        if (buf->map == MAP_FAILED) { buf->map = nullptr; close(fd); return nm_set_error(NM_EINVAL, "cannot map '%s'", path); }
+    }
+    close(fd);
+    return NM_OK;
+}
+
 }  // namespace
 
 struct nm_bed {
@@ -315,32 +330,8 @@ struct nm_bed {
 
 extern "C" {
 
-int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
-    if (!path || !out) return nm_set_error(NM_EINVAL, "NULL argument");
-    *out = nullptr;
-    if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return nm_set_error(NM_EINVAL, "cannot open pileup '%s'", path);
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); return nm_set_error(NM_EINVAL, "cannot stat pileup '%s'", path); }
-    Buffer buf;
-    if (st.st_size > 0) {
-        buf.map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-        buf.map_size = (size_t)st.st_size;
-        if (buf.map == MAP_FAILED) { close(fd); return nm_set_error(NM_EINVAL, "cannot map pileup '%s'", path); }
-    }
-    close(fd);
-    const uint8_t *raw = static_cast<const uint8_t *>(buf.map);
-    std::string err;
-    if (buf.map_size >= 2 && raw[0] == 31 && raw[1] == 139) {
-        if (!load_gzip(raw, buf.map_size, &buf, threads, &err)) {
-            munmap(buf.map, buf.map_size);
-            return nm_set_error(NM_EINVAL, "%s: %s", path, err.c_str());
-        }
-    } else {
-        buf.data = static_cast<const char *>(buf.map);
-        buf.size = buf.map_size;
-    }
+// bedMethyl text (whole file or the tabix-selected regions of it) -> columns
+static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **out) {
     // slabs cut at line ends
     std::vector<size_t> cut(1, 0);
     for (unsigned t = 1; t < threads; ++t) {
@@ -357,6 +348,7 @@ int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
         pool.emplace_back(parse_slab, buf.data + cut[i], buf.data + cut[i + 1], &parts[i]);
     for (auto &th : pool) th.join();
     if (buf.map) munmap(buf.map, buf.map_size);
+    buf.map = nullptr;
     for (auto &p : parts)
         if (!p.error.empty()) return nm_set_error(NM_EINVAL, "%s: %s", path, p.error.c_str());
     nm_bed *b = new (std::nothrow) nm_bed();
@@ -415,6 +407,158 @@ int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
     for (auto &s : a.names) b->name_ptrs.push_back(s.c_str());
     *out = b;
     return NM_OK;
+}
+
+int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
+    if (!path || !out) return nm_set_error(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    Buffer buf;
+    const int rc = load_file(path, threads, &buf, "pileup");
+    if (rc) return rc;
+    return parse_text(path, buf, threads, out);
+}
+
+// Tabix-indexed read (dataload.py:102-152 / find_motifs_bin.py:233-246: the reference fetches the records of a bin's
+// contigs through the .tbi index instead of reading the file): only the BGZF blocks that hold the wanted contigs are
+// inflated and parsed.  The index (tabix format: magic TBI\1, per reference the bins with their chunks of virtual
+// offsets) gives every contig its [begin, end) virtual offsets — from the pseudo-bin 37450 when present, else the
+// hull of its chunks.  NM_EINVAL with "not a tabix index" when the .tbi is not one (the caller may read the whole file).
+int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
+                        uint32_t threads, nm_bed **out, uint64_t stats[2]) {
+    if (!path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return nm_set_error(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    Buffer idx;
+    int rc = load_file(tbi_path, threads, &idx, "tabix index");
+    if (rc) return rc;
+    struct Unmap {
+        Buffer &b;
+        ~Unmap() { if (b.map) munmap(b.map, b.map_size); b.map = nullptr; }
+    } unmap_idx{idx};
+    const uint8_t *t = reinterpret_cast<const uint8_t *>(idx.data);
+    const size_t tn = idx.size;
+    auto bad = [&]() { return nm_set_error(NM_EINVAL, "%s: not a tabix index", tbi_path); };
+    if (tn < 36 || memcmp(t, "TBI\1", 4) != 0) return bad();
+    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, t + o, 4); return v; };
+    auto u64 = [&](size_t o) { uint64_t v; memcpy(&v, t + o, 8); return v; };
+    const int32_t n_ref = i32(4), l_nm = i32(32);
+    if (n_ref < 0 || l_nm < 0 || 36 + (size_t)l_nm > tn) return bad();
+    std::vector<std::string> ref_names;
+    for (size_t o = 36; o < 36 + (size_t)l_nm;) {
+        const char *z = reinterpret_cast<const char *>(t + o);
+        const size_t len = strnlen(z, 36 + (size_t)l_nm - o);
+        ref_names.emplace_back(z, len);
+        o += len + 1;
+    }
+    if ((int32_t)ref_names.size() != n_ref) return bad();
+    std::unordered_map<std::string, uint32_t> want;
+    for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
+    struct Region { uint64_t beg, end; };
+    std::vector<Region> regions;
+    size_t o = 36 + (size_t)l_nm;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (o + 4 > tn) return bad();
+        const int32_t n_bin = i32(o);
+        o += 4;
+        uint64_t lo = ~0ull, hi = 0;
+        bool pseudo = false;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (o + 8 > tn) return bad();
+            uint32_t bin;
+            memcpy(&bin, t + o, 4);
+            const int32_t n_chunk = i32(o + 4);
+            o += 8;
+            if (n_chunk < 0 || o + (size_t)n_chunk * 16 > tn) return bad();
+            if (bin == 37450 && n_chunk >= 1) {              // metadata pseudo-bin: chunk 0 = [begin, end) of the reference
+                lo = u64(o);
+                hi = u64(o + 8);
+                pseudo = true;
+            } else if (!pseudo) {
+                for (int32_t k = 0; k < n_chunk; ++k) {
+                    lo = std::min(lo, u64(o + (size_t)k * 16));
+                    hi = std::max(hi, u64(o + (size_t)k * 16 + 8));
+                }
+            }
+            o += (size_t)n_chunk * 16;
+        }
+        if (o + 4 > tn) return bad();
+        const int32_t n_intv = i32(o);
+        o += 4;
+        if (n_intv < 0 || o + (size_t)n_intv * 8 > tn) return bad();
+        o += (size_t)n_intv * 8;
+        if (want.count(ref_names[r]) && hi > lo) regions.push_back({lo, hi});
+    }
+    std::sort(regions.begin(), regions.end(), [](const Region &x, const Region &y) { return x.beg < y.beg; });
+    // neighbouring contigs: one region
+    std::vector<Region> merged;
+    for (const Region &g : regions) {
+        if (!merged.empty() && g.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, g.end);
+        else merged.push_back(g);
+    }
+    Buffer file;
+    rc = load_file_raw(path, &file);
+    if (rc) return rc;
+    Unmap unmap_file{file};
+    const uint8_t *z = static_cast<const uint8_t *>(file.map);
+    const size_t zn = file.map_size;
+    // the blocks of every region, where their text goes, and which part of it is wanted
+    struct Blk { size_t in_off, in_len, out_len, dst; uint32_t skip, take; };
+    std::vector<Blk> blocks;
+    size_t text_size = 0, inflated = 0;
+    for (const Region &g : merged) {
+        size_t off = (size_t)(g.beg >> 16);
+        const size_t last = (size_t)(g.end >> 16);
+        const uint32_t u_beg = (uint32_t)(g.beg & 0xFFFF), u_end = (uint32_t)(g.end & 0xFFFF);
+        while (off <= last && off + 18 <= zn) {
+            if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return nm_set_error(NM_EINVAL, "%s: the index points outside a BGZF block", path);
+            const size_t xlen = z[off + 10] | (z[off + 11] << 8);
+            size_t x = off + 12, xe = x + xlen, bsize = 0;
+            while (x + 4 <= xe) {
+                const size_t slen = z[x + 2] | (z[x + 3] << 8);
+                if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2) bsize = (size_t)(z[x + 4] | (z[x + 5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize == 0 || off + bsize > zn) return nm_set_error(NM_EINVAL, "%s: corrupt BGZF block", path);
+            const size_t isize = z[off + bsize - 4] | (z[off + bsize - 3] << 8) | (z[off + bsize - 2] << 16) | ((size_t)z[off + bsize - 1] << 24);
+            const uint32_t skip = off == (size_t)(g.beg >> 16) ? u_beg : 0u;
+            const uint32_t stop = off == last ? u_end : (uint32_t)isize;
+            if (skip > isize || stop > isize) return nm_set_error(NM_EINVAL, "%s: the index points beyond a BGZF block", path);
+            if (stop > skip) {
+                blocks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, isize, text_size, skip, stop - skip});
+                text_size += stop - skip;
+                inflated += isize;
+            }
+            off += bsize;
+        }
+    }
+    Buffer text;
+    text.owned.resize(text_size);
+    {
+        std::vector<std::thread> pool;
+        std::vector<int> okv(threads, 1);
+        for (unsigned w = 0; w < threads; ++w)
+            pool.emplace_back([&, w] {
+                std::vector<char> tmp;
+                for (size_t i = w; i < blocks.size(); i += threads) {
+                    const Blk &b = blocks[i];
+                    if (b.skip == 0 && b.take == b.out_len) {
+                        if (!inflate_raw(z + b.in_off, b.in_len, text.owned.data() + b.dst, b.out_len)) okv[w] = 0;
+                    } else {
+                        tmp.resize(b.out_len);
+                        if (!inflate_raw(z + b.in_off, b.in_len, tmp.data(), b.out_len)) okv[w] = 0;
+                        else memcpy(text.owned.data() + b.dst, tmp.data() + b.skip, b.take);
+                    }
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int v : okv)
+            if (!v) return nm_set_error(NM_EINVAL, "%s: corrupt BGZF block", path);
+    }
+    text.data = text.owned.data();
+    text.size = text.owned.size();
+    if (stats) { stats[0] = inflated; stats[1] = zn; }
+    return parse_text(path, text, threads, out);
 }
 
 int nm_bed_shape(nm_bed *b, uint64_t *n_rows, uint32_t *n_contigs) {

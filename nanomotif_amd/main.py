@@ -97,8 +97,12 @@ def find_motifs_bin(args):
     if bgzip and not os.path.exists(cfg.pileup_path + ".tbi"):
         raise FileNotFoundError(f"Tabix index for {cfg.pileup_path} not found.")     # find_motifs_bin.py:383-384
     t0 = time.perf_counter()
-    table = pileup_mod.NativePileup(cfg.pileup_path)                 # native reader, raw rows kept in native memory
-    log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s)")
+    # native reader, raw rows kept in native memory; a bgzip pileup is read through its tabix index: only the blocks
+    # of the contigs that are in a bin and in the assembly (find_motifs_bin.py:233-246 fetches per bin)
+    wanted = [c for c in cfg.bin_contig if c in assembly] if bgzip else None
+    table = pileup_mod.NativePileup(cfg.pileup_path, contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
+    how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
+    log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they
     # balance (independent searches, no collective until the rows are gathered), else the contigs of every bin are

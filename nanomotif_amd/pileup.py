@@ -69,12 +69,28 @@ class NativePileup:
     VIEWS in exactly the types ``ScanEngine.ingest_pileup`` takes (no per-column copies at 1e9 rows); valid until
     ``close()``.  ``contig_names``: first-appearance order of the file = index space of ``lut``."""
 
-    def __init__(self, path: str, threads: int = 0):
+    def __init__(self, path: str, threads: int = 0, contigs=None, index_path=None):
+        """``contigs`` + ``index_path``: read only these contigs through the tabix index (nm_bed_open_indexed — the
+        reference's bgzip path, dataload.py:102-152); ``self.indexed`` tells whether that happened: a file that is not a
+        tabix index falls back to reading everything."""
         import ctypes as C
         from . import _lib
         self._lib, self._check = _lib.load(), _lib.check
         self._h = C.c_void_p()
-        self._check(self._lib.nm_bed_open(os.fsencode(path), int(threads), C.byref(self._h)))
+        self.indexed, self.bytes_inflated, self.bytes_file = False, None, None
+        if contigs is not None and index_path is not None:
+            names = [c.encode() for c in contigs]
+            off = np.zeros(len(names) + 1, dtype=np.uint32)
+            np.cumsum([len(x) for x in names], out=off[1:])
+            stats = (C.c_uint64 * 2)()
+            rc = self._lib.nm_bed_open_indexed(os.fsencode(path), os.fsencode(index_path), len(names), b"".join(names),
+                                               off.ctypes.data_as(C.POINTER(C.c_uint32)), int(threads), C.byref(self._h), stats)
+            if rc == 0:
+                self.indexed, self.bytes_inflated, self.bytes_file = True, int(stats[0]), int(stats[1])
+            elif b"not a tabix index" not in self._lib.nm_last_error():
+                self._check(rc)
+        if not self.indexed:
+            self._check(self._lib.nm_bed_open(os.fsencode(path), int(threads), C.byref(self._h)))
         n, nc = C.c_uint64(0), C.c_uint32(0)
         self._check(self._lib.nm_bed_shape(self._h, C.byref(n), C.byref(nc)))
         self.n = int(n.value)

@@ -119,3 +119,83 @@ def motif_zoo():
         chars[pos] = "AC"[int(rng.integers(2))]
         zoo.append(("".join(chars), pos))
     return zoo
+
+
+# ---------------------------------------------------------------------------------------------
+# bgzip + tabix of a bedMethyl text (what `bgzip p.bed; tabix -p bed p.bed.gz` produce), written from the format
+# specifications (SAM spec §4.1 BGZF; tabix.pdf) — htslib / pysam are not in the image
+# ---------------------------------------------------------------------------------------------
+def write_bgzf_tabix(bed_text: bytes, gz_path: str, block_size: int = 0xFF00):
+    import struct
+    import zlib
+
+    def block(data: bytes) -> bytes:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(data) + c.flush()
+        return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp
+                + struct.pack("<II", zlib.crc32(data), len(data)))
+
+    # blocks cut at arbitrary byte positions (lines straddle blocks, as in real files)
+    blocks, block_coff, coff = [], [], 0
+    for i in range(0, len(bed_text), block_size):
+        b = block(bed_text[i:i + block_size])
+        block_coff.append(coff)
+        blocks.append(b)
+        coff += len(b)
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    with open(gz_path, "wb") as f:
+        f.write(b"".join(blocks) + eof)
+
+    def voff(text_off: int) -> int:
+        if text_off >= len(bed_text):
+            return coff << 16
+        k = text_off // block_size
+        return (block_coff[k] << 16) | (text_off - k * block_size)
+
+    def reg2bin(beg, end):
+        end -= 1
+        for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if beg >> shift == end >> shift:
+                return base + (beg >> shift)
+        return 0
+
+    refs, order = {}, []
+    pos = 0
+    for line in bed_text.split(b"\n"):
+        if line:
+            f = line.split(b"\t")
+            name, beg, end = f[0], int(f[1]), int(f[2])
+            r = refs.get(name)
+            if r is None:
+                r = refs[name] = dict(bins={}, lin={}, first=pos, last=pos)
+                order.append(name)
+            v0, v1 = voff(pos), voff(pos + len(line) + 1)
+            chunks = r["bins"].setdefault(reg2bin(beg, end), [])
+            if chunks and chunks[-1][1] == v0:
+                chunks[-1][1] = v1
+            else:
+                chunks.append([v0, v1])
+            for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+                r["lin"].setdefault(w, v0)
+            r["last"] = pos + len(line) + 1
+        pos += len(line) + 1
+    names = b"".join(n + b"\0" for n in order)
+    out = [b"TBI\1", struct.pack("<iiiiiiii", len(order), 0x10000, 1, 2, 3, ord("#"), 0, len(names)), names]
+    for n in order:
+        r = refs[n]
+        out.append(struct.pack("<i", len(r["bins"]) + 1))
+        for b, chunks in sorted(r["bins"].items()):
+            out.append(struct.pack("<Ii", b, len(chunks)))
+            for v0, v1 in chunks:
+                out.append(struct.pack("<QQ", v0, v1))
+        n_rec = sum(1 for _ in r["bins"])
+        out.append(struct.pack("<IiQQQQ", 37450, 2, voff(r["first"]), voff(r["last"]), n_rec, 0))     # metadata pseudo-bin
+        n_intv = (max(r["lin"]) + 1) if r["lin"] else 0
+        out.append(struct.pack("<i", n_intv))
+        last = 0
+        for w in range(n_intv):
+            last = r["lin"].get(w, last)
+            out.append(struct.pack("<Q", last))
+    idx = b"".join(out)
+    with open(gz_path + ".tbi", "wb") as f:                 # the index is itself BGZF
+        f.write(b"".join(block(idx[i:i + block_size]) for i in range(0, len(idx), block_size)) + eof)

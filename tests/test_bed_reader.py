@@ -139,3 +139,42 @@ def test_native_fasta_matches_the_line_loop(tmp_path):
     bad.write_text(">x\nACGT\n>empty\n>y\nAC\n")
     with pytest.raises(AssertionError, match="must not be empty"):
         fasta.load_fasta(str(bad))
+
+
+def test_tabix_indexed_read_equals_filtered_full_read(tmp_path):
+    """nm_bed_open_indexed: only the blocks of the wanted contigs are inflated; rows equal the full read restricted to
+    those contigs (the reference's bgzip path fetches per bin through the index, dataload.py:102-152)."""
+    from helpers import write_bgzf_tabix
+    spec = synth.SynthSpec(n_contigs=12, total_bp=600_000, n_bins=4, mod_types=("a", "m"), seed=67, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    raw = open(path, "rb").read()
+    gz = path + ".gz"
+    write_bgzf_tabix(raw, gz, block_size=40_000)
+    full = pp.NativePileup(gz)
+    assert not full.indexed
+    cols_full = {k: v.copy() for k, v in full.ingest_columns(np.arange(len(full.contig_names), dtype=np.uint32)).items()}
+    names_full = list(full.contig_names)
+    full.close()
+    for wanted in ([mg.names[3]], [mg.names[0], mg.names[1], mg.names[7]], [mg.names[11], mg.names[5], "not_in_the_file"], list(mg.names)):
+        part = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
+        assert part.indexed and part.bytes_file > 0
+        present = [n for n in names_full if n in set(wanted)]
+        assert part.contig_names == present                                     # file order
+        if len(present) < len(names_full):
+            assert part.bytes_inflated < 0.8 * len(raw)
+        cols = part.ingest_columns(np.arange(len(part.contig_names), dtype=np.uint32))
+        keep = np.isin(cols_full["contig"], [names_full.index(n) for n in present])
+        remap = np.full(len(names_full), -1)
+        for i, n in enumerate(present):
+            remap[names_full.index(n)] = i
+        assert np.array_equal(cols["contig"], remap[cols_full["contig"][keep]])
+        for k in ("position", "mod_type", "strand", "fraction_mod", "nvalid_cov"):
+            assert np.array_equal(cols[k], cols_full[k][keep]), (wanted, k)
+        part.close()
+    # something that is not an index: the caller reads the whole file
+    open(gz + ".bad.tbi", "wb").close()
+    p2 = pp.NativePileup(gz, contigs=[mg.names[0]], index_path=gz + ".bad.tbi")
+    assert not p2.indexed and len(p2) == len(cols_full["position"])
+    p2.close()

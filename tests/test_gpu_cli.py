@@ -132,6 +132,30 @@ def test_cli_5mc_and_4mc_in_one_pileup(tmp_path):
     assert mods == {"m", "21839"}
 
 
+def test_bgzip_pileup_is_read_through_its_tabix_index(tmp_path):
+    """A real .tbi next to the bgzip pileup and a contig-bin table that covers HALF of the bins: only the blocks of those
+    contigs are inflated (find_motifs_bin.py:233-246 fetches a bin's contigs through the index); same bin-motifs.tsv as
+    the oracle's bgzip-order pipeline on those bins."""
+    from helpers import write_bgzf_tabix
+    spec = synth.SynthSpec(n_contigs=8, total_bp=800_000, n_bins=4, mod_types=("a", "m"), seed=66, min_contig_bp=60_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/assembly.fasta")
+    mg.write_bed(tmp + "/pileup.bed")
+    write_bgzf_tabix(open(tmp + "/pileup.bed", "rb").read(), tmp + "/pileup.bed.gz", block_size=50_000)
+    bins = sorted(set(mg.bin_names))[::2]
+    with open(tmp + "/contig_bin.tsv", "w") as f:
+        for n, b in zip(mg.names, mg.bin_names):
+            if b in bins:
+                f.write(f"{n}\t{b}\n")
+    r = _run_cli(tmp, ["assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv", "--out", "out"])
+    assert "tabix-indexed" in r.stdout + r.stderr
+    got = open(tmp + "/out/bin-motifs.tsv").read()
+    assert got == oracle_pipeline(mg, bgzip_order=True, bins=set(bins))
+    assert {l.split("\t")[0] for l in got.strip().split("\n")[1:]} == set(bins)
+
+
 def test_more_ranks_than_contigs(tmp_path):
     """An isolate genome on two ranks with contig sharding: ONE contig, so rank 1 holds nothing — it uploads an empty
     shard, contributes zero tables and empty window sets and still joins every collective (no hang, same output)."""
