@@ -318,7 +318,7 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
 /*
  * Native modkit bedMethyl reader — replaces polars' scan_csv of the 18-column pileup (dataload.py:15-34, 72-100)
  * and the tabix reader of the bgzip path (dataload.py:102-152).  Accepts plain text, gzip and bgzip (BGZF blocks are
- * inflated in parallel; no .tbi needed).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
+ * inflated in parallel; nm_bed_open reads everything, nm_bed_open_indexed only the contigs asked for).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
  * order, names via nm_bed_contig_name), start (col 2), mod code id (col 4: 0 = m, 1 = a, 2 = 21839, other codes
  * numbered 3, 4, ... in first-appearance order, names via nm_bed_mod_code),
  * strand (col 6), fraction_mod = col 11 / 100 (-1 for the null markers "NA" / "null"), Nvalid_cov (col 10, -1 for
