@@ -89,6 +89,16 @@ def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
     return out
 
 
+def _assign(table: dict, contig: str, bin_name: str):
+    """One bin per contig.  The reference keeps a DataFrame and would put a contig that is listed under two bins into both
+    (fasta.py:129-134); here the engine holds every contig once, so the LAST listing wins — loudly."""
+    old = table.get(contig)
+    if old is not None and old != bin_name:
+        log.warning(f"contig {contig} is listed under bins {old} and {bin_name}: it is kept in {bin_name} only "
+                    "(the MI355X engine holds one bin per contig)")
+    table[contig] = bin_name
+
+
 def generate_contig_bin(args) -> dict:
     """fasta.py:122-187 -> ordered dict contig -> bin.  -c: 2-column TSV without header; -f / -d: bin = file stem,
     contig = first header token; with -f/-d the mapping is also written to OUT/temp/contig_bin.tsv."""
@@ -100,7 +110,7 @@ def generate_contig_bin(args) -> dict:
                 if not line:
                     continue
                 parts = line.split("\t")
-                out[str(parts[0])] = str(parts[1])
+                _assign(out, str(parts[0]), str(parts[1]))
         return out
     if getattr(args, "files", None):
         files = list(args.files)
@@ -123,7 +133,7 @@ def generate_contig_bin(args) -> dict:
         stem = Path(fp).stem
         for name in read_fasta_names(fp):
             if name:
-                out[name] = stem
+                _assign(out, name, stem)
     path = os.path.join(args.out, "temp", "contig_bin.tsv")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
