@@ -336,6 +336,11 @@ def main():
         local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # device memory of the library comes out of torch's pool (nm_set_device_allocator): the synthetic inputs are torch
+    # tensors anyway, and a fresh hipMalloc of memory that earlier processes used is scrubbed by the driver at 7-30 GB/s
+    # (tools/alloc_probe.py) — seconds that have nothing to do with the path measured here
+    from nanomotif_amd import _lib as nm_lib
+    nm_lib.use_torch_allocator(True)
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)

@@ -21,6 +21,7 @@
 #ifndef NMSCAN_H
 #define NMSCAN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -50,6 +51,14 @@ typedef enum nm_status {
 
 int nm_abi_version(void);
 const char *nm_last_error(void);
+
+/* Optional, process-wide: take device memory from the host application's pool instead of hipMalloc / hipFree
+ * (alloc returns 0 and sets *ptr; both NULL restores the default).  Set it before the first nm_ctx_create and keep it
+ * until the last ctx is destroyed: a block must be freed by the allocator that made it.  A process that already holds
+ * a caching pool (PyTorch) thereby spares the library the driver's scrubbing of recycled memory. */
+typedef int (*nm_alloc_fn)(void *user, void **ptr, size_t bytes);
+typedef int (*nm_free_fn)(void *user, void *ptr);
+int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user);
 
 /* Create / destroy an engine bound to HIP device `device`. */
 int nm_ctx_create(int device, nm_ctx **out);

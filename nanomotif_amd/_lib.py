@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NM_LIB", os.path.join(_HERE, "libnmscan.so"))   # NM_LIB: A/B kernel experiments
 
 SYMBOLS = [
-    "nm_abi_version", "nm_last_error", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
+    "nm_abi_version", "nm_last_error", "nm_set_device_allocator", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
@@ -28,6 +28,8 @@ class SearchParams(C.Structure):
                 ("remaining_threshold", C.c_double), ("freq_threshold", C.c_double)]
 
 
+ALLOC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.c_size_t)
+FREE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 SEARCH_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_char), C.POINTER(C.c_int64))
 SEARCH_WINDOW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_char),
                                C.POINTER(C.c_int32))
@@ -87,6 +89,7 @@ def load():
     lib.nm_abi_version.restype = C.c_int
     lib.nm_last_error.restype = C.c_char_p
     lib.nm_ctx_create.argtypes = [C.c_int, C.POINTER(p)]
+    lib.nm_set_device_allocator.argtypes = [ALLOC_FN, FREE_FN, p]
     lib.nm_ctx_destroy.argtypes = [p]
     lib.nm_set_stream.argtypes = [p, p]
     lib.nm_upload_contigs.argtypes = [p, C.c_uint32, u64p, u32p, C.c_uint32, u8p]
@@ -157,6 +160,38 @@ def load():
             getattr(lib, s).restype = C.c_int
     _lib = lib
     return lib
+
+
+_torch_pool = None
+
+
+def use_torch_allocator(enable: bool = True):
+    """Serve the library's device allocations from torch's caching allocator (nm_set_device_allocator): for processes
+    that hold a torch pool anyway (bench.py, the synthetic end-to-end runs).  Call before the first engine is created
+    and switch it off only after the last one is closed."""
+    global _torch_pool
+    lib = load()
+    if not enable:
+        check(lib.nm_set_device_allocator(C.cast(None, ALLOC_FN), C.cast(None, FREE_FN), None))
+        _torch_pool = None
+        return
+    import torch
+
+    def _alloc(_user, out, nbytes):
+        try:
+            out[0] = torch.cuda.caching_allocator_alloc(int(nbytes))
+            return 0
+        except Exception:
+            return -4
+
+    def _free(_user, ptr):
+        try:
+            torch.cuda.caching_allocator_delete(ptr)
+            return 0
+        except Exception:
+            return -1
+    _torch_pool = (ALLOC_FN(_alloc), FREE_FN(_free))              # kept alive: the library calls them
+    check(lib.nm_set_device_allocator(_torch_pool[0], _torch_pool[1], None))
 
 
 def check(rc: int):

@@ -208,7 +208,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         drop_slot_ranks(ms);
         if (first) {
             for (auto &p : ms.planes) {
-                if (!p) HIP_TRY(hipMalloc(&p, words * 4));
+                if (!p) HIP_TRY(nmdetail::dev_malloc(&p, words * 4));
                 HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
             }
             ms.present = true;
@@ -249,7 +249,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     }
     // device copies of the raw columns
     std::vector<void *> owned;
-    auto cleanup = [&]() { for (void *p : owned) (void)hipFree(p); };
+    auto cleanup = [&]() { for (void *p : owned) (void)nmdetail::dev_free(p); };
     RawRows r{};
     r.n = n_rows;
     if (rows_on_device) {
@@ -260,7 +260,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         void *dst[6];
         for (int k = 0; k < 6; ++k) {
             dst[k] = nullptr;
-            if (hipMalloc(&dst[k], std::max<size_t>(n_rows * esz[k], 16)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory for the raw pileup"); }
+            if (nmdetail::dev_malloc(&dst[k], std::max<size_t>(n_rows * esz[k], 16)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory for the raw pileup"); }
             owned.push_back(dst[k]);
             if (n_rows && hipMemcpyAsync(dst[k], src[k], n_rows * esz[k], hipMemcpyHostToDevice, c->stream) != hipSuccess) { cleanup(); return fail(NM_EHIP, "H2D copy of the raw pileup failed"); }
         }
@@ -271,7 +271,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     uint8_t *d_ok = nullptr;
     unsigned long long *d_dense = nullptr, *d_scalars = nullptr;
     uint64_t *d_dense_off = nullptr;
-#define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (hipMalloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
+#define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (nmdetail::dev_malloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
     ING_ALLOC(d_cnt, std::max<size_t>(n_groups, 1) * 2 * 4);
     ING_ALLOC(d_kept, std::max<size_t>(n_groups, 1) * 4);
     ING_ALLOC(d_ok, std::max<size_t>(n_groups, 1));

@@ -656,6 +656,23 @@ __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, u
 // ------------------------------------------------------------------------------------------------------
 namespace nmdetail {
 
+static nm_alloc_fn g_alloc = nullptr;
+static nm_free_fn g_free = nullptr;
+static void *g_alloc_user = nullptr;
+
+hipError_t device_alloc(void **p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) return hipSuccess;
+    if (g_alloc) return g_alloc(g_alloc_user, p, bytes) == 0 && *p ? hipSuccess : hipErrorOutOfMemory;
+    return hipMalloc(p, bytes);
+}
+
+hipError_t device_free(void *p) {
+    if (!p) return hipSuccess;
+    if (g_free) return g_free(g_alloc_user, p) == 0 ? hipSuccess : hipErrorInvalidValue;
+    return hipFree(p);
+}
+
 int ensure_stage(nm_ctx *c, size_t bytes) {
     nm_ctx::Stage &st = c->stage[c->stage_next];
     c->stage_next ^= 1;
@@ -666,11 +683,11 @@ int ensure_stage(nm_ctx *c, size_t bytes) {
     }
     if (bytes > st.bytes) {
         const size_t nb = std::max(bytes, st.bytes * 2);
-        if (st.d) (void)hipFree(st.d);
+        if (st.d) (void)nmdetail::dev_free(st.d);
         if (st.h) (void)hipHostFree(st.h);
         st.d = st.h = nullptr;
         st.bytes = 0;
-        HIP_TRY(hipMalloc(&st.d, nb));
+        HIP_TRY(nmdetail::dev_malloc(&st.d, nb));
         HIP_TRY(hipHostMalloc(&st.h, nb, hipHostMallocDefault));
         st.bytes = nb;
     }
@@ -901,10 +918,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
-        if (c->d_programs) (void)hipFree(c->d_programs);
+        if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
         c->d_programs = nullptr;
         c->prog_cap_dw = 0;
-        HIP_TRY(hipMalloc(&c->d_programs, need_dw * 2 * 4 * 2));
+        HIP_TRY(nmdetail::dev_malloc(&c->d_programs, need_dw * 2 * 4 * 2));
         c->prog_cap_dw = need_dw * 2;
     }
     uint32_t *const d_prog = c->d_programs + (size_t)(c->cur_stage - c->stage) * c->prog_cap_dw;
@@ -928,10 +945,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     unsigned long long *out = d_out;
     if (!out) {
         if (c->counts_cap < out_rows) {
-            if (c->d_counts) (void)hipFree(c->d_counts);
+            if (c->d_counts) (void)nmdetail::dev_free(c->d_counts);
             c->d_counts = nullptr;
             c->counts_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_counts, (size_t)out_rows * 2 * sizeof(unsigned long long) * 2));
+            HIP_TRY(nmdetail::dev_malloc(&c->d_counts, (size_t)out_rows * 2 * sizeof(unsigned long long) * 2));
             c->counts_cap = (size_t)out_rows * 2;
         }
         out = c->d_counts;
@@ -1027,6 +1044,14 @@ extern "C" {
 
 int nm_abi_version(void) { return 1; }
 
+int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user) {
+    if ((alloc == nullptr) != (free_fn == nullptr)) return fail(NM_EINVAL, "give both functions or neither");
+    nmdetail::g_alloc = alloc;
+    nmdetail::g_free = free_fn;
+    nmdetail::g_alloc_user = user;
+    return NM_OK;
+}
+
 const char *nm_last_error(void) { return g_err.c_str(); }
 
 static int ctx_init(nm_ctx *c) {
@@ -1045,8 +1070,8 @@ static int ctx_init(nm_ctx *c) {
     HIP_TRY(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipMalloc(&c->d_err, sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(&c->d_other, sizeof(unsigned long long)));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_err, sizeof(unsigned int)));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_other, sizeof(unsigned long long)));
     return NM_OK;
 }
 
@@ -1077,21 +1102,21 @@ static void free_assembly(nm_ctx *c) {
     void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments, c->d_chunk_rank};
     c->d_chunk_rank = nullptr;
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)nmdetail::dev_free(p);
     c->dH = c->dL = c->dV = nullptr;
     c->d_needs_v = nullptr;
     c->d_contig_chunk = nullptr;
     c->d_contig_len = nullptr;
     c->d_segments = nullptr;
     for (int b = 0; b < 4; ++b) {
-        if (c->d_rank[b]) (void)hipFree(c->d_rank[b]);
-        if (c->d_base_total[b]) (void)hipFree(c->d_base_total[b]);
+        if (c->d_rank[b]) (void)nmdetail::dev_free(c->d_rank[b]);
+        if (c->d_base_total[b]) (void)nmdetail::dev_free(c->d_base_total[b]);
         c->d_rank[b] = nullptr;
         c->d_base_total[b] = nullptr;
     }
     for (auto &s : c->slots) {
         for (auto &p : s.planes) {
-            if (p) (void)hipFree(p);
+            if (p) (void)nmdetail::dev_free(p);
             p = nullptr;
         }
         s.present = false;
@@ -1107,17 +1132,17 @@ int nm_ctx_destroy(nm_ctx *c) {
     (void)nm_comm_destroy(c);
     free_assembly(c);
     for (auto &st : c->stage) {
-        if (st.d) (void)hipFree(st.d);
+        if (st.d) (void)nmdetail::dev_free(st.d);
         if (st.h) (void)hipHostFree(st.h);
         if (st.busy) (void)hipEventDestroy(st.busy);
     }
-    if (c->d_counts) (void)hipFree(c->d_counts);
-    if (c->d_programs) (void)hipFree(c->d_programs);
-    if (c->d_win_planes) (void)hipFree(c->d_win_planes);
-    if (c->d_win_alive) (void)hipFree(c->d_win_alive);
-    if (c->d_win_tasks) (void)hipFree(c->d_win_tasks);
-    if (c->d_err) (void)hipFree(c->d_err);
-    if (c->d_other) (void)hipFree(c->d_other);
+    if (c->d_counts) (void)nmdetail::dev_free(c->d_counts);
+    if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
+    if (c->d_win_planes) (void)nmdetail::dev_free(c->d_win_planes);
+    if (c->d_win_alive) (void)nmdetail::dev_free(c->d_win_alive);
+    if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
+    if (c->d_err) (void)nmdetail::dev_free(c->d_err);
+    if (c->d_other) (void)nmdetail::dev_free(c->d_other);
     for (auto &pr : c->ev_pool) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -1157,7 +1182,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         ~Rollback() {
             (void)hipStreamSynchronize(c->stream);          // nothing may still read the temporaries
             for (void *p : tmp)
-                if (p) (void)hipFree(p);
+                if (p) (void)nmdetail::dev_free(p);
             if (!keep) free_assembly(c);
         }
     } guard{c};
@@ -1200,15 +1225,15 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     chunk_contig.push_back(0xFFFFFFFFu);
     c->n_chunks = (uint32_t)(next + 1);
     const size_t words = plane_words(c);
-    HIP_TRY(hipMalloc(&c->dH, words * 4));
-    HIP_TRY(hipMalloc(&c->dL, words * 4));
-    HIP_TRY(hipMalloc(&c->dV, words * 4));
-    HIP_TRY(hipMalloc(&c->d_needs_v, c->n_chunks));
+    HIP_TRY(nmdetail::dev_malloc(&c->dH, words * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->dL, words * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->dV, words * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_needs_v, c->n_chunks));
     HIP_TRY(hipMemsetAsync(c->dH, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->dL, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->dV, 0, words * 4, c->stream));
-    HIP_TRY(hipMalloc(&c->d_contig_chunk, (size_t)std::max(n_contigs, 1u) * 4));
-    HIP_TRY(hipMalloc(&c->d_contig_len, (size_t)std::max(n_contigs, 1u) * 8));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_contig_chunk, (size_t)std::max(n_contigs, 1u) * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_contig_len, (size_t)std::max(n_contigs, 1u) * 8));
     HIP_TRY(hipMemcpyAsync(c->d_contig_chunk, c->contig_chunk.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_contig_len, c->contig_len.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, c->stream));
     // temporaries for the pack pass
@@ -1217,12 +1242,12 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     uint32_t *d_chunk_contig = nullptr;
     if (on_device) d_ascii = const_cast<uint8_t *>(seq_ascii);
     else {
-        HIP_TRY(hipMalloc(&d_ascii, std::max<uint64_t>(c->total_bp, 1)));
+        HIP_TRY(nmdetail::dev_malloc(&d_ascii, std::max<uint64_t>(c->total_bp, 1)));
         guard.tmp[0] = d_ascii;
     }
-    HIP_TRY(hipMalloc(&d_off, (size_t)(n_contigs + 1) * 8));
+    HIP_TRY(nmdetail::dev_malloc(&d_off, (size_t)(n_contigs + 1) * 8));
     guard.tmp[1] = d_off;
-    HIP_TRY(hipMalloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
+    HIP_TRY(nmdetail::dev_malloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
     guard.tmp[2] = d_chunk_contig;
     if (!on_device && c->total_bp) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -1231,7 +1256,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         std::vector<uint32_t> chunk_rank(c->n_chunks, 0);
         for (uint32_t ch = 0; ch < c->n_chunks; ++ch)
             if (chunk_contig[ch] != 0xFFFFFFFFu) chunk_rank[ch] = c->contig_rank[chunk_contig[ch]];
-        HIP_TRY(hipMalloc(&c->d_chunk_rank, (size_t)c->n_chunks * 4));
+        HIP_TRY(nmdetail::dev_malloc(&c->d_chunk_rank, (size_t)c->n_chunks * 4));
         HIP_TRY(hipMemcpy(c->d_chunk_rank, chunk_rank.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemsetAsync(c->d_other, 0, sizeof(unsigned long long), c->stream));
@@ -1246,7 +1271,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         for (uint32_t k = 0; k < c->bin_nchunks[b]; k += c->seg_chunks)
             segs.push_back(make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(c->seg_chunks, c->bin_nchunks[b] - k), b, 0));
     c->n_segments = (uint32_t)segs.size();
-    HIP_TRY(hipMalloc(&c->d_segments, std::max<size_t>(segs.size(), 1) * sizeof(uint4)));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_segments, std::max<size_t>(segs.size(), 1) * sizeof(uint4)));
     if (!segs.empty()) HIP_TRY(hipMemcpyAsync(c->d_segments, segs.data(), segs.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     unsigned long long other = 0;
     HIP_TRY(hipMemcpyAsync(&other, c->d_other, sizeof other, hipMemcpyDeviceToHost, c->stream));
@@ -1271,7 +1296,7 @@ static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_ba
     const size_t words = plane_words(c);
     if (!ms.present || !append) {
         for (auto &p : ms.planes) {
-            if (!p) HIP_TRY(hipMalloc(&p, words * 4));
+            if (!p) HIP_TRY(nmdetail::dev_malloc(&p, words * 4));
             HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
         }
         ms.n_rows = 0;

@@ -26,6 +26,15 @@ int nm_set_error(int code, const char *fmt, ...);
 
 namespace nmdetail {
 
+// Device memory comes from hipMalloc, or from the host application's pool when it registered one
+// (nm_set_device_allocator: a process that already holds a caching pool — torch — hands out blocks it has paid for;
+// fresh hipMallocs of memory other processes used before are scrubbed by the driver at 7-30 GB/s, tools/alloc_probe.py).
+hipError_t device_alloc(void **p, size_t bytes);
+hipError_t device_free(void *p);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return device_alloc(reinterpret_cast<void **>(p), bytes); }
+inline hipError_t dev_free(void *p) { return device_free(p); }
+
 constexpr int T_WORDS = 4;                              // 32-bit words per lane
 constexpr int CHUNK_WORDS = 64 * T_WORDS;               // 256 words
 constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wave-chunk
@@ -160,8 +169,8 @@ inline Planes seq_planes(const nm_ctx *c) {
 
 inline void drop_slot_ranks(ModSlot &ms) {
     for (int k = 0; k < 2; ++k) {
-        if (ms.rank[k]) (void)hipFree(ms.rank[k]);
-        if (ms.rank_total[k]) (void)hipFree(ms.rank_total[k]);
+        if (ms.rank[k]) (void)nmdetail::dev_free(ms.rank[k]);
+        if (ms.rank_total[k]) (void)nmdetail::dev_free(ms.rank_total[k]);
         ms.rank[k] = nullptr;
         ms.rank_total[k] = nullptr;
     }

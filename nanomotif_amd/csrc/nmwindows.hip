@@ -411,10 +411,10 @@ static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uin
     if (used + need_words <= *cap) return NM_OK;
     const uint64_t ncap = std::max<uint64_t>((used + need_words) * 3 / 2, 1u << 20);
     uint32_t *nb = nullptr;
-    HIP_TRY(hipMalloc(&nb, ncap * 4));
+    HIP_TRY(nmdetail::dev_malloc(&nb, ncap * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (*buf && used) HIP_TRY(hipMemcpy(nb, *buf, used * 4, hipMemcpyDeviceToDevice));
-    if (*buf) (void)hipFree(*buf);
+    if (*buf) (void)nmdetail::dev_free(*buf);
     *buf = nb;
     *cap = ncap;
     return NM_OK;
@@ -445,13 +445,13 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
     if (rc) return rc;
     if (n_windows) {
         uint8_t *d_sets = nullptr;
-        HIP_TRY(hipMalloc(&d_sets, (size_t)n_windows * width));
+        HIP_TRY(nmdetail::dev_malloc(&d_sets, (size_t)n_windows * width));
         HIP_TRY(hipMemcpyAsync(d_sets, sets, (size_t)n_windows * width, hipMemcpyHostToDevice, c->stream));
         if (t.nw) hipLaunchKernelGGL(win_pack_kernel, dim3((t.nw + 255) / 256, width), dim3(256), 0, c->stream, t, d_sets,
                            c->d_win_planes, c->d_win_alive);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)hipFree(d_sets);
+        (void)nmdetail::dev_free(d_sets);
     }
     c->win_planes_used += (uint64_t)width * 5 * t.nw;
     c->win_alive_used += t.nw;
@@ -475,10 +475,10 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     }
     if (c->win_tasks_dirty) {
         if (c->d_win_tasks_cap < c->win_tasks.size()) {
-            if (c->d_win_tasks) (void)hipFree(c->d_win_tasks);
+            if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
             c->d_win_tasks = nullptr;
             c->d_win_tasks_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_win_tasks, c->win_tasks.size() * 2 * sizeof(WinTask)));
+            HIP_TRY(nmdetail::dev_malloc(&c->d_win_tasks, c->win_tasks.size() * 2 * sizeof(WinTask)));
             c->d_win_tasks_cap = c->win_tasks.size() * 2;
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -525,8 +525,8 @@ static int base_index(uint8_t base) {
 
 static int ensure_rank(nm_ctx *c, int b) {
     if (c->d_rank[b]) return NM_OK;
-    HIP_TRY(hipMalloc(&c->d_rank[b], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
-    HIP_TRY(hipMalloc(&c->d_base_total[b], (size_t)c->n_contigs * 8));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_rank[b], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->d_base_total[b], (size_t)c->n_contigs * 8));
     if (c->n_contigs) hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
                        static_cast<const uint32_t *>(nullptr), c->d_contig_chunk, c->d_contig_len, b, c->d_rank[b],
                        c->d_base_total[b]);
@@ -551,13 +551,13 @@ int nm_contig_base_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t *out) 
     int rc = ensure_rank(c, b);
     if (rc) return rc;
     uint64_t *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 8));
+    HIP_TRY(nmdetail::dev_malloc(&d_out, (size_t)c->n_contigs * 8));
     if (c->n_contigs) hipLaunchKernelGGL(base_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, seq_planes(c),
                        c->d_contig_chunk, c->d_contig_len, c->n_contigs, b, pad, c->d_base_total[b], d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)c->n_contigs * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_out);
+    (void)nmdetail::dev_free(d_out);
     return NM_OK;
 }
 
@@ -671,8 +671,8 @@ static int ensure_slot_counts(nm_ctx *c, uint32_t slot, uint32_t pad) {
     ModSlot &ms = c->slots[slot];
     if (!ms.rank[0]) {
         for (int k = 0; k < 2; ++k) {
-            HIP_TRY(hipMalloc(&ms.rank[k], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
-            HIP_TRY(hipMalloc(&ms.rank_total[k], (size_t)c->n_contigs * 8));
+            HIP_TRY(nmdetail::dev_malloc(&ms.rank[k], (size_t)c->n_chunks * RANK_PER_CHUNK * 4));
+            HIP_TRY(nmdetail::dev_malloc(&ms.rank_total[k], (size_t)c->n_contigs * 8));
             if (c->n_contigs) hipLaunchKernelGGL(rank_build_kernel, dim3(c->n_contigs), dim3(64), 0, c->stream, seq_planes(c),
                                static_cast<const uint32_t *>(ms.planes[k == 0 ? 2 : 4]), c->d_contig_chunk, c->d_contig_len, -1,
                                ms.rank[k], ms.rank_total[k]);
@@ -682,14 +682,14 @@ static int ensure_slot_counts(nm_ctx *c, uint32_t slot, uint32_t pad) {
     }
     if (ms.meth_pad == pad && ms.meth_counts.size() == (size_t)c->n_contigs * 4) return NM_OK;
     uint64_t *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_out, (size_t)c->n_contigs * 4 * 8));
+    HIP_TRY(nmdetail::dev_malloc(&d_out, (size_t)c->n_contigs * 4 * 8));
     if (c->n_contigs) hipLaunchKernelGGL(meth_count_kernel, dim3((c->n_contigs + 255) / 256), dim3(256), 0, c->stream, ms.planes[2], ms.planes[4],
                        c->d_contig_chunk, c->d_contig_len, c->n_contigs, pad, ms.rank_total[0], ms.rank_total[1], d_out);
     HIP_TRY(hipGetLastError());
     ms.meth_counts.assign((size_t)c->n_contigs * 4, 0);
     HIP_TRY(hipMemcpyAsync(ms.meth_counts.data(), d_out, (size_t)c->n_contigs * 4 * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_out);
+    (void)nmdetail::dev_free(d_out);
     ms.meth_pad = pad;
     return NM_OK;
 }
