@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--allreduce", choices=["auto", "native", "torch"], default="auto",
                     help="count-table all-reduce: nm_allreduce_counts of the C ABI (RCCL) or torch.distributed; auto = native with nccl")
     ap.add_argument("--force-device", type=int, default=-1, help="debug: CUDA device for every rank")
+    ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak (auto: all that apply; none)")
@@ -499,6 +500,9 @@ def main():
         if coll:
             coll.drain()
 
+    if args.cooldown > 0:
+        torch.cuda.synchronize(device)
+        time.sleep(args.cooldown)
     for _ in range(args.warmup):
         step()
     drain()
