@@ -411,25 +411,32 @@ def main():
     # ---- extra: end to end on the same metagenome (generation excluded): whole bins per GPU, no collective.  Runs FIRST, on
     # a fresh device: it is the phase whose wall time depends on allocation speed (1000 window tasks, 9 planes)
     e2e_result = None
-    if "e2e" in extras:
-        sizes = {}
-        for i, b in enumerate(mg.bin_names):
-            sizes[b] = sizes.get(b, 0) + int(mg.lengths[i])
-        my_bins = None if world == 1 else assign_bins(sizes, world, tolerance=float("inf"))[rank]
-        if world > 1:
-            dist.barrier()
-        e_rows, t = run_e2e(mg, local_rank, device, my_bins)
-        planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() if my_bins is None or b in set(my_bins) for m in ms}
-        found = {(r.reference, r.motif_iupac) for r in e_rows}
-        per = gather([t["upload_filter_s"] + t["search_s"], t["search_s"], t["upload_filter_s"], t.get("gpu_busy_s", 0.0), t["rounds"], t["candidates"],
-                      len(e_rows), len(planted), len(planted & found)])
-        if rank == 0:
-            e2e_result = {"what": "motif_discovery on the same metagenome: 1e9 raw pileup rows -> device filters -> windows -> lock-step greedy "
-                                     "search + pruning -> post-processing; synthetic-data generation excluded; N > 1: whole bins per GPU",
-                             "wall_s": max(p[0] for p in per), "search_s": max(p[1] for p in per), "upload_filter_s": max(p[2] for p in per),
-                             "gpu_busy_s": max(p[3] for p in per), "rounds": int(max(p[4] for p in per)), "candidates": int(sum(p[5] for p in per)),
-                             "motif_rows": int(sum(p[6] for p in per)), "planted": int(sum(p[7] for p in per)),
-                             "planted_recovered": int(sum(p[8] for p in per)), "timings_rank0": t}
+    extra_errors = {}
+    try:
+        if "e2e" in extras:
+            sizes = {}
+            for i, b in enumerate(mg.bin_names):
+                sizes[b] = sizes.get(b, 0) + int(mg.lengths[i])
+            my_bins = None if world == 1 else assign_bins(sizes, world, tolerance=float("inf"))[rank]
+            if world > 1:
+                dist.barrier()
+            e_rows, t = run_e2e(mg, local_rank, device, my_bins)
+            planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() if my_bins is None or b in set(my_bins) for m in ms}
+            found = {(r.reference, r.motif_iupac) for r in e_rows}
+            per = gather([t["upload_filter_s"] + t["search_s"], t["search_s"], t["upload_filter_s"], t.get("gpu_busy_s", 0.0), t["rounds"], t["candidates"],
+                          len(e_rows), len(planted), len(planted & found)])
+            if rank == 0:
+                e2e_result = {"what": "motif_discovery on the same metagenome: 1e9 raw pileup rows -> device filters -> windows -> lock-step greedy "
+                                         "search + pruning -> post-processing; synthetic-data generation excluded; N > 1: whole bins per GPU",
+                                 "wall_s": max(p[0] for p in per), "search_s": max(p[1] for p in per), "upload_filter_s": max(p[2] for p in per),
+                                 "gpu_busy_s": max(p[3] for p in per), "rounds": int(max(p[4] for p in per)), "candidates": int(sum(p[5] for p in per)),
+                                 "motif_rows": int(sum(p[6] for p in per)), "planted": int(sum(p[7] for p in per)),
+                                 "planted_recovered": int(sum(p[8] for p in per)), "timings_rank0": t}
+    except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
+        if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
+            raise
+        log(f"extra 'e2e' failed: {exc!r}")
+        extra_errors["e2e"] = repr(exc)
 
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
@@ -546,27 +553,33 @@ def main():
     # ---- the same engine in its HBM-bound regime: one lock-step greedy round (2 sibling children per (bin, mod type),
     # the shape MotifSearcher.run submits), kernel time from HIP events; reported next to the main roofline
     hbm_round = None
-    if args.workload == "cfg5" and args.hbm_round_steps > 0:
-        g_cands = build_candidates(mg, "greedy", 0, 2)
-        g_batch = eng.make_batch(g_cands)
-        g_counts = torch.zeros((len(g_cands), 2), dtype=torch.int64, device=device)
-        g_ms, _ = time_launches(eng, g_batch, g_counts.data_ptr(), args.hbm_round_steps, device)
-        g_groups = {(b, mt) for _, mt, b in g_cands}
-        g_bytes = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in g_groups) + 16 * len(g_cands)
-        g_ms = allmax([g_ms])[0]
-        tr = load_traffic("greedy", args.total_bp, len(g_cands)) if world == 1 else None
-        hbm_round = {"workload": f"greedy round: {len(g_cands)} candidates = 2 sibling children per (bin, mod type)",
-                     "bound": "hbm", "kernel_ms": g_ms, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_launch": g_bytes, "launches": args.hbm_round_steps,
-                     "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                     # the fused two-slot launch reads the sequence planes once for both mod types: real DRAM bytes are
-                     # below the algorithmic 0.5 B/bp/slot; this is the fraction of the device's streaming rate they reach
-                     "traffic_rate_GBs": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 if tr else None,
-                     "traffic_frac_of_spec": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
-                     "traffic_frac_of_streaming": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_STREAM_GBS if tr else None,
-                     "streaming_peak_GBs": HBM_STREAM_GBS,
-                     "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3)}
+    try:
+        if args.workload == "cfg5" and args.hbm_round_steps > 0:
+            g_cands = build_candidates(mg, "greedy", 0, 2)
+            g_batch = eng.make_batch(g_cands)
+            g_counts = torch.zeros((len(g_cands), 2), dtype=torch.int64, device=device)
+            g_ms, _ = time_launches(eng, g_batch, g_counts.data_ptr(), args.hbm_round_steps, device)
+            g_groups = {(b, mt) for _, mt, b in g_cands}
+            g_bytes = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in g_groups) + 16 * len(g_cands)
+            g_ms = allmax([g_ms])[0]
+            tr = load_traffic("greedy", args.total_bp, len(g_cands)) if world == 1 else None
+            hbm_round = {"workload": f"greedy round: {len(g_cands)} candidates = 2 sibling children per (bin, mod type)",
+                         "bound": "hbm", "kernel_ms": g_ms, "achieved": g_bytes / (g_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": g_bytes, "launches": args.hbm_round_steps,
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         # the fused two-slot launch reads the sequence planes once for both mod types: real DRAM bytes are
+                         # below the algorithmic 0.5 B/bp/slot; this is the fraction of the device's streaming rate they reach
+                         "traffic_rate_GBs": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 if tr else None,
+                         "traffic_frac_of_spec": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
+                         "traffic_frac_of_streaming": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_STREAM_GBS if tr else None,
+                         "streaming_peak_GBs": HBM_STREAM_GBS,
+                         "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3)}
+    except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
+        if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
+            raise
+        log(f"extra 'roofline_hbm_bound_round' failed: {exc!r}")
+        extra_errors["roofline_hbm_bound_round"] = repr(exc)
 
     result = None
     tr = load_traffic(args.workload, args.total_bp, n_cand) if world == 1 else None
@@ -616,28 +629,40 @@ def main():
                                        "peak_source": "profiles/r1/valu_peak.txt (alignbit+and stream, 4 cycles per wave64 op per SIMD)"}
 
     # ---- extra: every candidate x every bin (SURVEY §8(d) cfg 5 as 2e13 motif-sites per step), N = 1
-    if "cfg5_all" in extras:
-        a_batch = expand_all_bins(batch)
-        a_counts = torch.zeros((len(a_batch), 2), dtype=torch.int64, device=device)
-        a_ms, a_wall_ms = time_launches(eng, a_batch, a_counts.data_ptr(), 3, device)
-        a_sites = 2 * args.total_bp * len(base)
-        a_bytes = ALGO_BYTES_PER_BP_STEP * args.total_bp * len(mg.spec.mod_types) + 16 * len(a_batch)
-        # every bin must give each candidate the same counts it got in the 20-per-bin table where they coincide
-        a_host = a_counts.cpu().numpy().reshape(len(all_bins), len(base), 2)
-        own = np.array([all_bins.index(c[2]) for c in base])
-        same = bool(np.array_equal(a_host[own, np.arange(len(base))], final))
-        tr_a = load_traffic("cfg5_all", args.total_bp, len(a_batch))
-        result["cfg5_all"] = {"workload": f"{len(base)} candidates x all {len(all_bins)} bins = {len(a_batch)} (candidate, bin) pairs, {a_sites:.3g} motif-sites per step",
-                              "value": a_sites / (a_wall_ms * 1e-3), "unit": "motif-sites/s", "ms_per_step": a_wall_ms, "kernel_ms": a_ms,
-                              "roofline_hbm_frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              "roofline_valu_frac": (tr_a["sq_insts_valu_per_launch"] / (a_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_S) if tr_a and tr_a.get("sq_insts_valu_per_launch") else None,
-                              "agrees_with_per_bin_table": same}
-        del a_counts, a_batch
-        torch.cuda.empty_cache()
+    try:
+        if "cfg5_all" in extras:
+            a_batch = expand_all_bins(batch)
+            a_counts = torch.zeros((len(a_batch), 2), dtype=torch.int64, device=device)
+            a_ms, a_wall_ms = time_launches(eng, a_batch, a_counts.data_ptr(), 3, device)
+            a_sites = 2 * args.total_bp * len(base)
+            a_bytes = ALGO_BYTES_PER_BP_STEP * args.total_bp * len(mg.spec.mod_types) + 16 * len(a_batch)
+            # every bin must give each candidate the same counts it got in the 20-per-bin table where they coincide
+            a_host = a_counts.cpu().numpy().reshape(len(all_bins), len(base), 2)
+            own = np.array([all_bins.index(c[2]) for c in base])
+            same = bool(np.array_equal(a_host[own, np.arange(len(base))], final))
+            tr_a = load_traffic("cfg5_all", args.total_bp, len(a_batch))
+            result["cfg5_all"] = {"workload": f"{len(base)} candidates x all {len(all_bins)} bins = {len(a_batch)} (candidate, bin) pairs, {a_sites:.3g} motif-sites per step",
+                                  "value": a_sites / (a_wall_ms * 1e-3), "unit": "motif-sites/s", "ms_per_step": a_wall_ms, "kernel_ms": a_ms,
+                                  "roofline_hbm_frac": a_bytes / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "roofline_valu_frac": (tr_a["sq_insts_valu_per_launch"] / (a_ms * 1e-3) / VALU_PEAK_WAVE_INSTR_S) if tr_a and tr_a.get("sq_insts_valu_per_launch") else None,
+                                  "agrees_with_per_bin_table": same}
+            del a_counts, a_batch
+            torch.cuda.empty_cache()
+    except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
+        if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
+            raise
+        log(f"extra 'cfg5_all' failed: {exc!r}")
+        extra_errors["cfg5_all"] = repr(exc)
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on a bounded sample of the same workload, and parity
-    if rank == 0 and world == 1 and args.cpu_bins != 0 and cands is not None:
-        cpu_baseline(result, final, cands, mg, spec_kw, args)
+    try:
+        if rank == 0 and world == 1 and args.cpu_bins != 0 and cands is not None:
+            cpu_baseline(result, final, cands, mg, spec_kw, args)
+    except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
+        if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
+            raise
+        log(f"extra 'cpu_baseline' failed: {exc!r}")
+        extra_errors["cpu_baseline"] = repr(exc)
 
     eng.close()
     del counts
@@ -675,6 +700,8 @@ def main():
     if rank == 0:
         if e2e_result is not None:
             result["e2e"] = e2e_result
+        if extra_errors:
+            result["extra_errors"] = extra_errors
         emit(result)
     if world > 1:
         dist.barrier()
