@@ -207,10 +207,8 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         ModSlot &ms = c->slots[slot_of_mod[m]];
         drop_slot_ranks(ms);
         if (first) {
-            for (auto &p : ms.planes) {
-                if (!p) HIP_TRY(nmdetail::dev_malloc(&p, words * 4));
-                HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
-            }
+            HIP_TRY(alloc_slot_planes(ms, words));
+            HIP_TRY(hipMemsetAsync(ms.planes[0], 0, words * 4 * 6, c->stream));
             ms.present = true;
             ms.canonical = canonical_of_mod[m];
             ms.low = low;

@@ -1099,7 +1099,7 @@ int nm_ctx_create(int device, nm_ctx **out) {
 
 static void free_assembly(nm_ctx *c) {
     drop_ingest_rows(c);
-    void *ptrs[] = {c->dH, c->dL, c->dV, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments, c->d_chunk_rank};
+    void *ptrs[] = {c->dH /* owns L and V too */, c->d_needs_v, c->d_contig_chunk, c->d_contig_len, c->d_segments, c->d_chunk_rank};
     c->d_chunk_rank = nullptr;
     for (void *p : ptrs)
         if (p) (void)nmdetail::dev_free(p);
@@ -1115,10 +1115,7 @@ static void free_assembly(nm_ctx *c) {
         c->d_base_total[b] = nullptr;
     }
     for (auto &s : c->slots) {
-        for (auto &p : s.planes) {
-            if (p) (void)nmdetail::dev_free(p);
-            p = nullptr;
-        }
+        free_slot_planes(s);
         s.present = false;
         s.n_rows = 0;
         drop_slot_ranks(s);
@@ -1225,9 +1222,9 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     chunk_contig.push_back(0xFFFFFFFFu);
     c->n_chunks = (uint32_t)(next + 1);
     const size_t words = plane_words(c);
-    HIP_TRY(nmdetail::dev_malloc(&c->dH, words * 4));
-    HIP_TRY(nmdetail::dev_malloc(&c->dL, words * 4));
-    HIP_TRY(nmdetail::dev_malloc(&c->dV, words * 4));
+    HIP_TRY(nmdetail::dev_malloc(&c->dH, words * 4 * 3));          // one block for H, L, V (see alloc_slot_planes)
+    c->dL = c->dH + words;
+    c->dV = c->dL + words;
     HIP_TRY(nmdetail::dev_malloc(&c->d_needs_v, c->n_chunks));
     HIP_TRY(hipMemsetAsync(c->dH, 0, words * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->dL, 0, words * 4, c->stream));
@@ -1295,10 +1292,8 @@ static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_ba
     drop_slot_ranks(ms);
     const size_t words = plane_words(c);
     if (!ms.present || !append) {
-        for (auto &p : ms.planes) {
-            if (!p) HIP_TRY(nmdetail::dev_malloc(&p, words * 4));
-            HIP_TRY(hipMemsetAsync(p, 0, words * 4, c->stream));
-        }
+        HIP_TRY(alloc_slot_planes(ms, words));
+        HIP_TRY(hipMemsetAsync(ms.planes[0], 0, words * 4 * 6, c->stream));
         ms.n_rows = 0;
     } else if (ms.canonical != canonical_base || ms.low != low || ms.high != high) {
         return fail(NM_EINVAL, "append with different canonical base / thresholds than the slot holds");

@@ -178,6 +178,22 @@ inline void drop_slot_ranks(ModSlot &ms) {
     ms.meth_pad = 0xFFFFFFFFu;
 }
 
+// The six state planes of a slot come out of ONE allocation (planes[0] owns it): fewer, larger requests to the driver
+// (a fresh hipMalloc of recycled memory is scrubbed first, tools/alloc_probe.py).
+inline hipError_t alloc_slot_planes(ModSlot &ms, size_t words) {
+    if (ms.planes[0]) return hipSuccess;
+    uint32_t *base = nullptr;
+    const hipError_t e = dev_malloc(&base, words * 4 * 6);
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < 6; ++k) ms.planes[k] = base + (size_t)k * words;
+    return hipSuccess;
+}
+
+inline void free_slot_planes(ModSlot &ms) {
+    if (ms.planes[0]) (void)dev_free(ms.planes[0]);
+    for (auto &p : ms.planes) p = nullptr;
+}
+
 inline void drop_ingest_rows(nm_ctx *c) {
     for (int &x : c->ing_slot_of_mod) x = -1;
     c->ing_nconf = c->ing_total_kept = c->ing_classified = 0;
