@@ -302,7 +302,11 @@ def main():
     ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak (auto: all that apply; none)")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: all that apply; none)")
+    ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
+                    help="scoring lanes (nm_set_score_lanes; 2 = consecutive steps overlap on the device).  0 = auto: both passes "
+                         "run; one GPU: strict order is the headline and the two-lane pass is the key 'two_lanes'; several GPUs: "
+                         "two lanes are the headline, 'strict_order' the other.  1: strict order only.  2: two lanes are the headline")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = ONE metagenome, contigs sharded, count tables all-reduced every step (default, the BASELINE "
                          "configuration); weak = every rank its own --total-bp metagenome, no collective")
@@ -374,7 +378,7 @@ def main():
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
-    extras = {"e2e", "cfg5_all", "weak"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
+    extras = {"e2e", "cfg5_all", "weak", "two_lanes"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
     if args.workload != "cfg5" or weak:
         extras = set()
     if world == 1:
@@ -441,11 +445,11 @@ def main():
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
     rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if (world == 1 or weak) else mine, progress=log)
-    # one explicit side stream carries the engine's launches AND torch's collectives (the legacy default stream has the
-    # handle 0, which nm_set_stream reads as "use the ctx's own stream": never hand it that)
+    # torch's work of this script runs on one explicit side stream; when torch.distributed carries the count tables the
+    # engine's launches go there too (below) (the legacy default stream has the handle 0, which nm_set_stream reads as
+    # "use the ctx's own stream": never hand it that)
     side = torch.cuda.Stream(device)
     assert side.cuda_stream != 0
-    eng.use_stream(side.cuda_stream)
     torch.cuda.set_stream(side)
     st = eng.stats()
     log(f"resident: {st['total_bp']:,} bp ({st['padded_bp']:,} padded), rows {rows}, setup {time.perf_counter() - t0:.1f}s")
@@ -484,8 +488,13 @@ def main():
                                                                   and hasattr(eng, "comm_init")))
     coll = Collective("native" if use_native else "torch", eng, world, rank, device, args.dist_backend) if reduce_counts else None
 
-    # two count tables: the all-reduce of step k (communication stream) overlaps the scoring launch of step k+1
-    counts = [torch.zeros((n_cand, 2), dtype=torch.int64, device=device) for _ in range(2)]
+    if coll is not None and coll.kind == "torch":
+        eng.use_stream(side.cuda_stream)       # torch.distributed orders its collectives on torch's current stream only
+    # (otherwise the engine keeps its own streams: a second scoring lane beside a torch stream shared a hardware queue with
+    #  it on this runtime and did not overlap, tools/gpu_lanes3.sh)
+    # a ring of count tables: the all-reduce of step k (communication stream) overlaps the scoring launches of the next steps
+    N_TABLES = 4
+    counts = [torch.zeros((n_cand, 2), dtype=torch.int64, device=device) for _ in range(N_TABLES)]
     step_no = [0]
     host_s = [0.0]
 
@@ -494,10 +503,10 @@ def main():
         # records (pinned staging ring, copy stream), compile every motif to its constraint program on the device, zero the
         # counters, one scoring launch (async); then the all-reduce of this table is started on the communication stream
         t_in = time.perf_counter()
-        i = step_no[0] & 1
+        i = step_no[0] % N_TABLES
         step_no[0] += 1
         if coll:
-            coll.wait(i)                                    # table i is free again (its all-reduce of step k-2 finished)
+            coll.wait(i)                                    # table i is free again (its all-reduce of step k-4 finished)
         eng.score_into_device(batch, counts[i].data_ptr())
         if coll:
             coll.start(i, counts[i])
@@ -507,31 +516,56 @@ def main():
         if coll:
             coll.drain()
 
+    def timed_region(lanes):
+        """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides.  lanes = 1: every
+        launch in strict stream order (per-launch HIP events = the kernel alone on the device: the roofline's duration);
+        lanes = 2: consecutive steps alternate between two scoring streams of the C ABI (nm_set_score_lanes) and overlap
+        on the device — the counters of a step are the same, only when they are complete moves."""
+        eng.set_score_lanes(lanes)
+        for _ in range(args.warmup):
+            step()
+        drain()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        eng.timing_reset(True)
+        torch.cuda.synchronize(device)
+        host_s[0] = 0.0
+        t_start = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        drain()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        el_local = time.perf_counter() - t_start
+        k_total, n_launch = eng.timing_total()
+        eng.timing_reset(False)
+        eng.set_score_lanes(1)
+        k_local = k_total / max(n_launch, 1)
+        el, k = allmax([el_local, k_local])
+        return {"lanes": lanes, "elapsed": el, "elapsed_local": el_local, "kernel_ms": k, "kernel_ms_local": k_local,
+                "host_ms": host_s[0] / args.steps * 1e3}
+
     if args.cooldown > 0:
         torch.cuda.synchronize(device)
         time.sleep(args.cooldown)
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    eng.timing_reset(True)
-    torch.cuda.synchronize(device)
-    host_s[0] = 0.0
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    elapsed_local = time.perf_counter() - t_start
-    kernel_ms_total, n_launch = eng.timing_total()
-    eng.timing_reset(False)
-    kernel_ms_local = kernel_ms_total / max(n_launch, 1)
-    elapsed, kernel_ms = allmax([elapsed_local, kernel_ms_local])
-    final = counts[(step_no[0] - 1) & 1].cpu().numpy()
+    # Which pass is the headline: with one GPU the strict-order pass (its per-launch events are the roofline's kernel
+    # duration and agree with a rocprofv3 trace of this command); with several GPUs the two-lane pass — a shard's kernel
+    # is so short (~0.08 ms at N = 8) that the ~20 us between two dependent launches and the draining tail of every launch
+    # are a quarter of the step, and consecutive steps are independent.  The other pass is reported next to it.
+    lanes_ok = coll is None or coll.kind in ("native", "none")     # torch.distributed orders itself on torch's stream only
+    want = args.lanes if args.lanes else (2 if world > 1 else 1)
+    if want == 2 and not lanes_ok:
+        log("two scoring lanes need the C ABI's own all-reduce (nm_allreduce_counts_async): staying in strict order")
+        want = 1
+    strict = timed_region(1)
+    piped = timed_region(2) if (lanes_ok and args.lanes != 1 and (want == 2 or "two_lanes" in extras or args.lanes == 2)) else None
+    head = piped if (want == 2 and piped) else strict
+    elapsed, elapsed_local = head["elapsed"], head["elapsed_local"]
+    kernel_ms, kernel_ms_local = strict["kernel_ms"], strict["kernel_ms_local"]
+    host_s[0] = head["host_ms"] * args.steps * 1e-3
+    final = counts[(step_no[0] - 1) % N_TABLES].cpu().numpy()
 
     # the collective alone: K all-reduces of the table back to back, slowest rank
     allreduce_ms = None
@@ -614,9 +648,17 @@ def main():
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
             "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
             "allreduce_ms": allreduce_ms,
+            "pipelining": {"scoring_lanes": head["lanes"], "staging_ring": 4, "count_tables": N_TABLES,
+                           "note": "lanes = 2: consecutive (independent) steps alternate between two scoring streams of the C ABI "
+                                   "and overlap on the device; roofline.kernel_ms is always the strict-order pass of this run"},
             "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
                                 int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],
         }
+        other = strict if head is piped else piped
+        if other:
+            result["strict_order" if head is piped else "two_lanes"] = {
+                "scoring_lanes": other["lanes"], "value": sites_per_step * nw * args.steps / other["elapsed"], "unit": "motif-sites/s",
+                "ms_per_step": other["elapsed"] / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}
         if hbm_round:
             result["roofline_hbm_bound_round"] = hbm_round
         if tr and tr.get("sq_insts_valu_per_launch"):

@@ -67,6 +67,17 @@ int nm_ctx_destroy(nm_ctx *ctx);
 /* Run all subsequent work of this ctx on `hip_stream` (a hipStream_t, e.g. torch's current stream);
  * NULL restores the ctx's own stream. */
 int nm_set_stream(nm_ctx *ctx, void *hip_stream);
+/* Scoring lanes.  lanes = 2 (ctx on its own stream only): consecutive nm_score_batch_device calls alternate between two
+ * streams, so that INDEPENDENT batches submitted back to back overlap on the device — the next launch fills the compute
+ * units the previous one leaves idle while its last workgroups drain, and no launch gap separates them (a shard of a
+ * multi-GPU run scores a 10 000-candidate table in ~0.08 ms: the ~20 us between two dependent launches are a quarter
+ * of that).  The rounds of ONE search depend on each other (find_motifs_bin.py:957-1182) and gain nothing; whole
+ * candidate tables scored step after step, or the tables of different searches, do.  A table is complete after
+ * nm_sync, or — for the all-reduce — nm_allreduce_counts_async orders itself after the launch that produced it.
+ * Every other entry point waits for the second lane first.  lanes = 1 (default) restores strict stream order. */
+int nm_set_score_lanes(nm_ctx *ctx, int lanes);
+/* Wait until all scoring work queued on the ctx (both lanes) has finished. */
+int nm_sync(nm_ctx *ctx);
 
 /*
  * Assembly upload — replaces the per-call `contig_sequence.sequence` strings handed to motif_model_contig

@@ -103,13 +103,14 @@ int nm_comm_init(nm_ctx *c, int rank, int world, const uint8_t id[NM_COMM_ID_BYT
     return NM_OK;
 }
 
-int nm_allreduce_counts_async(nm_ctx *c, int64_t *d_counts, uint64_t n, int buffer_slot) {
+static int allreduce_after(nm_ctx *c, int64_t *d_counts, uint64_t n, int buffer_slot, hipStream_t producer) {
     if (!c || (n && !d_counts)) return fail(NM_EINVAL, "NULL argument");
     if (!c->comm) return fail(NM_ESTATE, "nm_comm_init has not been called on this ctx");
     if (buffer_slot < 0 || buffer_slot >= NM_COMM_SLOTS) return fail(NM_EINVAL, "buffer_slot %d outside 0..%d", buffer_slot, NM_COMM_SLOTS - 1);
     HIP_TRY(hipSetDevice(c->device));
-    // the table is complete once everything queued so far on the scoring stream has run
-    HIP_TRY(hipEventRecord(c->comm_ready, c->stream));
+    // the table is complete once everything queued so far on the scoring stream has run (with two scoring lanes:
+    // on the lane of the most recent launch — the table the caller passes is that launch's)
+    HIP_TRY(hipEventRecord(c->comm_ready, producer));
     HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->comm_ready, 0));
     if (n) RCCL_TRY(rccl().AllReduce(d_counts, d_counts, (size_t)n, NCCL_INT64, NCCL_SUM, static_cast<ncclComm_t>(c->comm), c->comm_stream));
     HIP_TRY(hipEventRecord(c->comm_done[buffer_slot], c->comm_stream));
@@ -117,11 +118,17 @@ int nm_allreduce_counts_async(nm_ctx *c, int64_t *d_counts, uint64_t n, int buff
     return NM_OK;
 }
 
+int nm_allreduce_counts_async(nm_ctx *c, int64_t *d_counts, uint64_t n, int buffer_slot) {
+    if (!c) return fail(NM_EINVAL, "NULL argument");
+    return allreduce_after(c, d_counts, n, buffer_slot, c->last_score_stream ? c->last_score_stream : c->stream);
+}
+
 int nm_comm_wait(nm_ctx *c, int buffer_slot) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (buffer_slot < 0 || buffer_slot >= NM_COMM_SLOTS) return fail(NM_EINVAL, "buffer_slot %d outside 0..%d", buffer_slot, NM_COMM_SLOTS - 1);
     if (!c->comm_pending[buffer_slot]) return NM_OK;
     HIP_TRY(hipStreamWaitEvent(c->stream, c->comm_done[buffer_slot], 0));
+    if (c->lane_stream) HIP_TRY(hipStreamWaitEvent(c->lane_stream, c->comm_done[buffer_slot], 0));
     c->comm_pending[buffer_slot] = false;
     return NM_OK;
 }
@@ -141,7 +148,9 @@ int nm_allreduce_counts_host(nm_ctx *c, int64_t *counts, uint64_t n) {
     if (rc) return rc;
     memcpy(c->h_stage, counts, n * sizeof(int64_t));
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, n * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    rc = nm_allreduce_counts(c, static_cast<int64_t *>(c->d_stage), n);
+    rc = allreduce_after(c, static_cast<int64_t *>(c->d_stage), n, 0, c->stream);
+    if (rc) return rc;
+    rc = nm_comm_wait(c, 0);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_stage, c->d_stage, n * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     rc = nmdetail::release_stage(c);

@@ -195,6 +195,11 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (n_rows && (!contig_id || !position || !mod_code || !strand || !fraction_mod || !nvalid_cov)) return fail(NM_EINVAL, "NULL column");
     if (!(high > low)) return fail(NM_EINVAL, "high threshold must exceed low");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // an asynchronous scoring launch may still read the planes replaced below
+    {
+        const int rcj = nmdetail::join_lanes(c);
+        if (rcj) return rcj;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t words = plane_words(c);
     const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;

@@ -673,9 +673,16 @@ hipError_t device_free(void *p) {
     return hipFree(p);
 }
 
-int ensure_stage(nm_ctx *c, size_t bytes) {
-    nm_ctx::Stage &st = c->stage[c->stage_next];
-    c->stage_next ^= 1;
+int ensure_stage(nm_ctx *c, size_t bytes, bool deep) {
+    int idx;
+    if (deep) {
+        idx = c->stage_next_deep;
+        c->stage_next_deep = (idx + 1) % NM_STAGE_RING;
+    } else {
+        idx = c->stage_next;
+        c->stage_next ^= 1;
+    }
+    nm_ctx::Stage &st = c->stage[idx];
     if (!st.busy) HIP_TRY(hipEventCreateWithFlags(&st.busy, hipEventDisableTiming));
     if (st.pending) {
         HIP_TRY(hipEventSynchronize(st.busy));
@@ -697,9 +704,17 @@ int ensure_stage(nm_ctx *c, size_t bytes) {
     return NM_OK;
 }
 
-int release_stage(nm_ctx *c) {   // call after the last device work that reads the acquired pair was enqueued
-    HIP_TRY(hipEventRecord(c->cur_stage->busy, c->stream));
+int release_stage(nm_ctx *c, hipStream_t s) {   // call after the last device work that reads the acquired pair was enqueued
+    HIP_TRY(hipEventRecord(c->cur_stage->busy, s ? s : c->stream));
     c->cur_stage->pending = true;
+    return NM_OK;
+}
+
+int join_lanes(nm_ctx *c) {
+    if (c->lane_stream && c->lane_pending) {
+        HIP_TRY(hipStreamSynchronize(c->lane_stream));
+        c->lane_pending = false;
+    }
     return NM_OK;
 }
 
@@ -879,8 +894,20 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const size_t range_bytes = (size_t)n_entries * sizeof(uint4);
     const size_t off_rows = (off_range + range_bytes + 15) & ~(size_t)15;          // per-contig mode: row base per sorted candidate
     const size_t total = off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
-    int rc = ensure_stage(c, total);
+    int rc = ensure_stage(c, total, true);
     if (rc) return rc;
+    // scoring lane of this call (nm_set_score_lanes): asynchronous device-output batches take the lane of their staging
+    // pair — a pair, its half of the program table and its stream are reused together; every other call runs on the
+    // ctx stream after the second lane has drained
+    hipStream_t sst = c->stream;
+    const bool laned = c->score_lanes == 2 && d_out && !h_out;
+    if (!laned) {
+        rc = join_lanes(c);
+        if (rc) return rc;
+    } else if ((c->cur_stage - c->stage) & 1) {
+        sst = c->lane_stream;
+        c->lane_pending = true;
+    }
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
     CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
@@ -911,17 +938,19 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // measured crossover (profiles/): up to ~6 candidates per (slot, bin) group the launch is HBM-bound
     const bool light = (uint64_t)n_prog <= 6ull * n_groups && !per_contig;
     const bool cf = light && !c->opt_no_cf;
-    // device-side program buffer: two halves, one per staging pair, so that compiling batch k+1 (on the copy stream)
-    // overlaps the scoring kernel of batch k; reuse of a half is gated like its staging pair (ensure_stage).  A light
+    // device-side program buffer: one part per staging pair, so that compiling the next batches (on the copy stream)
+    // overlaps the scoring kernel of batch k; reuse of a part is gated like its staging pair (ensure_stage).  A light
     // batch appends one common program per (slot, bin) entry.
     const size_t need_dw = ((size_t)std::max(n_prog, 1u) + (cf ? n_entries : 0)) * pdw;
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        rc = join_lanes(c);
+        if (rc) return rc;
         if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
         c->d_programs = nullptr;
         c->prog_cap_dw = 0;
-        HIP_TRY(nmdetail::dev_malloc(&c->d_programs, need_dw * 2 * 4 * 2));
+        HIP_TRY(nmdetail::dev_malloc(&c->d_programs, need_dw * 2 * 4 * NM_STAGE_RING));
         c->prog_cap_dw = need_dw * 2;
     }
     uint32_t *const d_prog = c->d_programs + (size_t)(c->cur_stage - c->stage) * c->prog_cap_dw;
@@ -940,7 +969,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         }
     }
     HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
@@ -953,7 +982,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         }
         out = c->d_counts;
     }
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)out_rows * 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemsetAsync(out, 0, (size_t)out_rows * 2 * sizeof(unsigned long long), sst));
     // ---- launch
     ScoreArgs a{};
     a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
@@ -1009,12 +1038,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         e1 = c->ev_pool[c->ev_used].second;
         c->ev_used += 1;
     }
-    HIP_TRY(hipEventRecord(e0, c->stream));
-    if (n_prog) launch_score(a, gx, shape, c->stream);   // else nothing resident for this batch: the zeroed table is the answer
+    HIP_TRY(hipEventRecord(e0, sst));
+    if (n_prog) launch_score(a, gx, shape, sst);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    rc = release_stage(c);
+    HIP_TRY(hipEventRecord(e1, sst));
+    rc = release_stage(c, sst);
     if (rc) return rc;
+    c->last_score_stream = sst;
     c->timed = !c->ev_collect;
     c->launches += 1;
     c->last_wgs = (uint64_t)gx * (fuse ? 1 : std::max(n_active, 1u));
@@ -1126,6 +1156,7 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (!c) return NM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)join_lanes(c);
     (void)nm_comm_destroy(c);
     free_assembly(c);
     for (auto &st : c->stage) {
@@ -1148,6 +1179,7 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return NM_OK;
@@ -1156,9 +1188,30 @@ int nm_ctx_destroy(nm_ctx *c) {
 int nm_set_stream(nm_ctx *c, void *hip_stream) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = join_lanes(c);
+    if (rc) return rc;
     c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->last_score_stream = nullptr;
     c->timed = false;
     return NM_OK;
+}
+
+int nm_set_score_lanes(nm_ctx *c, int lanes) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (lanes != 1 && lanes != 2) return fail(NM_EINVAL, "lanes must be 1 or 2, got %d", lanes);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = join_lanes(c);
+    if (rc) return rc;
+    if (lanes == 2 && !c->lane_stream) HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
+    c->score_lanes = lanes;
+    return NM_OK;
+}
+
+int nm_sync(nm_ctx *c) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return join_lanes(c);
 }
 
 static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
@@ -1170,6 +1223,10 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     if (offsets[0] != 0) return fail(NM_EINVAL, "offsets[0] must be 0");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rcj = join_lanes(c);
+        if (rcj) return rcj;
+    }
     free_assembly(c);
     // any failure below leaves the ctx WITHOUT an assembly (dH == nullptr, so scoring refuses) and frees the temporaries
     struct Rollback {
@@ -1288,6 +1345,11 @@ static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_ba
     if (!(high > low)) return fail(NM_EINVAL, "high threshold must exceed low (find_motifs_bin.py:117-118)");
     if (n_rows && (!contig_id || !position || !strand || !fraction_mod)) return fail(NM_EINVAL, "NULL column");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));      // an asynchronous scoring launch may still read the planes replaced below
+    {
+        const int rcj = join_lanes(c);
+        if (rcj) return rcj;
+    }
     ModSlot &ms = c->slots[mod_slot];
     drop_slot_ranks(ms);
     const size_t words = plane_words(c);

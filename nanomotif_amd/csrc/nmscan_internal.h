@@ -81,10 +81,22 @@ struct ModSlot {
 
 }  // namespace nmdetail
 
+// Staging pairs (device + pinned host buffer) and parts of the program table.  Scoring walks all of them: the host side,
+// the upload and the compile of batch k+1 ... k+3 run while batch k is scored — on a small shard of a multi-GPU run that
+// chain (~85 us) is as long as the scoring kernel itself, two pairs would hide only one kernel's worth of it.
+#define NM_STAGE_RING 4
+
 struct nm_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
+    // second scoring lane (nm_set_score_lanes): asynchronous device-output batches alternate between the ctx's own
+    // stream and this one, so that consecutive INDEPENDENT batches overlap on the device (the next launch fills the
+    // compute units the previous one leaves idle while it drains, and nothing waits for a launch gap)
+    hipStream_t lane_stream = nullptr;
+    int score_lanes = 1;
+    bool lane_pending = false;                        // work may be in flight on lane_stream
+    hipStream_t last_score_stream = nullptr;          // where the most recent scoring launch went
     std::vector<uint32_t> bucket;                     // per-call host scratch, kept to avoid reallocation
     // window engine
     std::vector<nmdetail::WinTask> win_tasks;
@@ -127,8 +139,9 @@ struct nm_ctx {
         size_t bytes = 0;
         hipEvent_t busy = nullptr;
         bool pending = false;
-    } stage[2];
-    int stage_next = 0;
+    } stage[NM_STAGE_RING];
+    int stage_next = 0;                            // shallow users alternate between pairs 0 and 1
+    int stage_next_deep = 0;                       // scoring walks the whole ring
     void *d_stage = nullptr, *h_stage = nullptr;   // the pair acquired by the current call
     Stage *cur_stage = nullptr;
     unsigned long long *d_counts = nullptr;
@@ -201,7 +214,8 @@ inline void drop_ingest_rows(nm_ctx *c) {
 
 // pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it
 // busy until the work enqueued so far on the ctx stream has run
-int ensure_stage(nm_ctx *c, size_t bytes);
-int release_stage(nm_ctx *c);
+int ensure_stage(nm_ctx *c, size_t bytes, bool deep = false);   // deep: walk all NM_STAGE_RING pairs (scoring), else pairs 0 / 1
+int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
+int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
 
 }  // namespace nmdetail

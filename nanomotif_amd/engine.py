@@ -584,6 +584,15 @@ class ScanEngine:
             _lib.check(self.lib.nm_score_batch_per_contig(self.ctx, *self._batch_args(b), _ptr(rows, C.c_uint64), _ptr(out, C.c_int64)))
         return [(names[int(b.bins[k])], out[int(rows[k]):int(rows[k + 1])]) for k in range(len(b))]
 
+    def set_score_lanes(self, lanes: int):
+        """2: consecutive ``score_into_device`` calls alternate between two streams, so that independent batches
+        overlap on the device (include/nmscan.h: nm_set_score_lanes); 1: strict order (default)."""
+        _lib.check(self.lib.nm_set_score_lanes(self.ctx, int(lanes)))
+
+    def sync(self):
+        """All scoring work queued on this engine has finished (both lanes)."""
+        _lib.check(self.lib.nm_sync(self.ctx))
+
     def score_into_device(self, batch: CandidateBatch, device_ptr: int):
         """Asynchronous variant: counts land in device memory (e.g. a torch int64 tensor) on the engine stream."""
         _lib.check(self.lib.nm_score_batch_device(self.ctx, *self._batch_args(batch), C.c_void_p(device_ptr)))

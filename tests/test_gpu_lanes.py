@@ -1,0 +1,106 @@
+"""nm_set_score_lanes / nm_sync (include/nmscan.h): asynchronous batches alternate between two scoring streams and walk a
+ring of four staging pairs.  Whatever overlaps on the device, every table must hold exactly what the synchronous call
+returns for its batch — also when the batches differ from call to call, when the ring wraps around several times, when
+the all-reduce of the C ABI follows every launch, and when other entry points are called in between."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n_contigs=12, total_bp=3_000_000, n_bins=4, mods=("a", "m"), seed=11):
+    from nanomotif_amd import synth
+    from nanomotif_amd.engine import ScanEngine
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=n_contigs, total_bp=total_bp, n_bins=n_bins, mod_types=mods, seed=seed))
+    eng = ScanEngine(0)
+    eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(n_contigs)], mg.bin_names)
+    for mt in mods:
+        for i in range(n_contigs):
+            p = mg.contig_pileup(i, mt)
+            eng.upload_pileup(mt, np.full(len(p["position"]), i, np.uint32), p["position"], p["strand"],
+                              synth.pct_to_fraction(p["pct_hundredths"]), append=i > 0)
+    return mg, eng
+
+
+def _batches(mg, n_batches):
+    """Different batches: heavy ones (random cfg 5 candidates, 8 per bin and mod type), light sibling rounds, one-candidate ones."""
+    from nanomotif_amd import synth
+    from nanomotif_amd.motif import Motif
+    bins = sorted(set(mg.bin_names))
+    out = []
+    for k in range(n_batches):
+        if k % 3 == 0:
+            raw = synth.random_candidates(16 * len(bins), seed=100 + k, mod_types=mg.spec.mod_types)
+            out.append([(Motif(s, p), mt, bins[(j // 2) % len(bins)]) for j, (s, p, mt) in enumerate(raw)])
+        elif k % 3 == 1:
+            core = list("." * 21)
+            out.append([(Motif("".join(core[:8] + [b] + ["."] + [can] + list("T.G") + core[14:]), 10), mt, bn)
+                        for bn in bins for mt, can in (("a", "A"), ("m", "C")) for b in "ACGT"[: 2 + k % 3]])
+        else:
+            out.append([(Motif("GATC", 1), "a", bins[k % len(bins)])])
+    return out
+
+
+def test_two_lanes_tables_equal_synchronous_scores():
+    import torch
+    mg, eng = _engine()
+    batches = _batches(mg, 11)
+    want = [eng.score(b) for b in batches]
+    made = [eng.make_batch(b) for b in batches]
+    for lanes in (2, 1, 2):
+        tables = [torch.full((len(b), 2), -7, dtype=torch.int64, device="cuda:0") for b in batches]
+        eng.set_score_lanes(lanes)
+        for rep in range(3):                              # 33 launches: the ring of four pairs wraps eight times
+            for k, b in enumerate(made):
+                eng.score_into_device(b, tables[k].data_ptr())
+                if rep == 1 and k == 5:
+                    assert np.array_equal(eng.score(batches[2]), want[2])     # a synchronous call in between joins the lanes
+        eng.sync()
+        for k in range(len(batches)):
+            assert np.array_equal(tables[k].cpu().numpy(), want[k]), (lanes, k)
+    eng.set_score_lanes(1)
+    eng.close()
+
+
+def test_two_lanes_with_the_allreduce_step_and_other_entry_points():
+    import torch
+    from nanomotif_amd import synth
+    mg, eng = _engine(seed=12)
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    batches = _batches(mg, 6)
+    want = [eng.score(b) for b in batches]
+    made = [eng.make_batch(b) for b in batches]
+    tables = [torch.zeros((len(b), 2), dtype=torch.int64, device="cuda:0") for b in batches]
+    eng.set_score_lanes(2)
+    for rep in range(4):
+        for k, b in enumerate(made):
+            slot = k % 4
+            eng.comm_wait(slot)
+            eng.score_into_device(b, tables[k].data_ptr())
+            eng.allreduce_counts_device(tables[k].data_ptr(), tables[k].numel(), slot)
+    eng.comm_sync()
+    eng.sync()
+    for k in range(len(batches)):
+        assert np.array_equal(tables[k].cpu().numpy(), want[k]), k
+    # replacing a classification while launches are in flight: the upload waits for both lanes first
+    for k, b in enumerate(made):
+        eng.score_into_device(b, tables[k].data_ptr())
+    p = mg.contig_pileup(0, "a")
+    eng.upload_pileup("a", np.zeros(len(p["position"]), np.uint32), p["position"], p["strand"], synth.pct_to_fraction(p["pct_hundredths"]))
+    torch.cuda.synchronize()
+    for k in range(len(batches)):
+        assert np.array_equal(tables[k].cpu().numpy(), want[k]), k      # the launches saw the OLD planes
+    assert not np.array_equal(eng.score(batches[0]), want[0])             # the new classification holds contig 0 only
+    eng.close()
+
+
+def test_lanes_argument_is_checked():
+    from nanomotif_amd._lib import NmScanError
+    from nanomotif_amd.engine import ScanEngine
+    eng = ScanEngine(0)
+    with pytest.raises(NmScanError, match="lanes must be 1 or 2"):
+        eng.set_score_lanes(3)
+    eng.set_score_lanes(2)
+    eng.set_score_lanes(1)
+    eng.sync()
+    eng.close()
