@@ -303,6 +303,9 @@ def main():
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: all that apply; none)")
+    ap.add_argument("--prewarm", type=int, default=200,
+                    help="untimed steps BEFORE the W warm-up steps: brings the device clocks to their steady state (a 20-step run is "
+                         "12 ms long, shorter than the clock ramp); reported in the JSON line")
     ap.add_argument("--lanes", type=int, default=0, choices=[0, 1, 2],
                     help="scoring lanes (nm_set_score_lanes; 2 = consecutive steps overlap on the device).  0 = auto: both passes "
                          "run; one GPU: strict order is the headline and the two-lane pass is the key 'two_lanes'; several GPUs: "
@@ -442,6 +445,8 @@ def main():
         log(f"extra 'e2e' failed: {exc!r}")
         extra_errors["e2e"] = repr(exc)
 
+    if os.environ.get("NM_BENCH_EMPTY_CACHE"):
+        torch.cuda.empty_cache()
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
     rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if (world == 1 or weak) else mine, progress=log)
@@ -559,6 +564,9 @@ def main():
     if want == 2 and not lanes_ok:
         log("two scoring lanes need the C ABI's own all-reduce (nm_allreduce_counts_async): staying in strict order")
         want = 1
+    for _ in range(args.prewarm):
+        step()
+    drain()
     strict = timed_region(1)
     piped = timed_region(2) if (lanes_ok and args.lanes != 1 and (want == 2 or "two_lanes" in extras or args.lanes == 2)) else None
     head = piped if (want == 2 and piped) else strict
@@ -648,6 +656,7 @@ def main():
             "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
             "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
             "allreduce_ms": allreduce_ms,
+            "prewarm_steps": args.prewarm,
             "pipelining": {"scoring_lanes": head["lanes"], "staging_ring": 4, "count_tables": N_TABLES,
                            "note": "lanes = 2: consecutive (independent) steps alternate between two scoring streams of the C ABI "
                                    "and overlap on the device; roofline.kernel_ms is always the strict-order pass of this run"},
