@@ -653,7 +653,8 @@ def main():
                          "kernel": "score_kernel (narrow, compact)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
-            "kernel_share_of_step": kernel_ms / (elapsed / args.steps * 1e3),
+            # of the strict-order pass (with two lanes consecutive launches overlap: a step is then SHORTER than one launch)
+            "kernel_share_of_step": kernel_ms / (strict["elapsed"] / args.steps * 1e3),
             "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
             "allreduce_ms": allreduce_ms,
             "prewarm_steps": args.prewarm,
