@@ -1096,6 +1096,9 @@ static int ctx_init(nm_ctx *c) {
     if (const char *e = getenv("NM_SEG_CHUNKS")) c->seg_chunks = (uint32_t)std::max(4, atoi(e));
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    // the second scoring lane is made here, next to the first: the runtime deals its hardware queues to streams in
+    // creation order, and two lanes that share a queue do not overlap (tools/gpu_lanes3.sh)
+    HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev0));
