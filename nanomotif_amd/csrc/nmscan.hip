@@ -1596,6 +1596,10 @@ int nm_stats(nm_ctx *c, uint64_t what[8]) {
 int nm_timing_reset(nm_ctx *c, int enable) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const int rcj = join_lanes(c);          // the event pairs are reused: nothing may still be about to record them
+        if (rcj) return rcj;
+    }
     c->ev_used = 0;
     c->ev_collect = enable != 0;
     c->timed = false;

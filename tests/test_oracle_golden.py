@@ -1,5 +1,6 @@
 """Pin the CPU oracle against vectors recorded from the real reference (tests/golden/gen_golden.py)
 and against the literal known-answer values of the reference's own tests."""
+import os
 import random
 
 import numpy as np
@@ -14,6 +15,8 @@ from oracle import scan as osc
 from oracle import search as ose
 from oracle.model import BetaBernoulliModel, predictive_evaluation_score
 from oracle.motif import Motif
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 # ------------------------------------------------------------------ G1: subseq_indices
@@ -282,3 +285,45 @@ def test_full_chain_runs_and_formats():
     assert lines[0].split("\t") == opp.HEADER
     found = {l.split("\t")[1] for l in lines[1:]}
     assert {"GATC", "ACCCA", "CCAAAT"} <= found and any(m.startswith("G") and m.endswith("GAAGY") for m in found), found
+
+
+def _iupac_to_regex(iupac):
+    sets = {"R": "[AG]", "Y": "[CT]", "S": "[CG]", "W": "[AT]", "K": "[GT]", "M": "[AC]", "B": "[CGT]", "D": "[AGT]", "H": "[ACT]",
+            "V": "[ACG]", "N": "."}
+    return "".join(sets.get(ch, ch) for ch in iupac)
+
+
+def test_bin_motifs_text_equals_a_reference_output_file():
+    """tests/golden/ref_e_coli_bin-motifs.tsv is nanomotif/datasets/e_coli_bin-motifs.tsv — a bin-motifs.tsv the reference
+    wrote (polars write_csv of motif.py:899-926's frame; data, copied as is).  Feeding its own rows — primary and complement
+    as separate search results — through join_motif_complements and the formatter must give the file back byte for byte:
+    pins the header, the column order, the sort key, the null formatting, motif_type and which partner of a
+    complementary pair is kept as the primary.  Both the oracle's chain and the product's."""
+    from nanomotif_amd import postprocess as npp
+    from nanomotif_amd.model import BetaBernoulliModel as ProductModel
+    want = open(os.path.join(GOLDEN, "ref_e_coli_bin-motifs.tsv")).read()
+    if not want.endswith("\n"):
+        want += "\n"                                       # the data set file was saved without the final newline
+    cells = [l.split("\t") for l in want.strip("\n").split("\n")[1:]]
+    found = []                                             # (reference, iupac, pos, mod type, n_mod, n_nomod) as the search finds them
+    for c in cells:
+        found.append((c[0], c[1], int(c[2]), c[3], int(c[4]), int(c[5])))
+        if c[7] and c[7] != c[1]:
+            found.append((c[0], c[7], int(c[8]), c[3], int(c[9]), int(c[10])))
+    for order in (found, found[::-1]):
+        rows = [opp.derive(dict(reference=r, motif=_iupac_to_regex(m), mod_type=mt, mod_position=p, model=_model(a, b), score=1.0))
+                for r, m, p, mt, a, b in order]
+        assert opp.format_bin_motifs(opp.join_motif_complements(rows)) == want
+        prows = [npp.MotifRow(r, _iupac_to_regex(m), mt, p, ProductModel.from_counts(a, b), 1.0) for r, m, p, mt, a, b in order]
+        assert npp.format_bin_motifs(npp.join_motif_complements(prows)) == want
+    # motif_type on the motifs of the reference's other shipped output (older header, same classification)
+    for line in open(os.path.join(GOLDEN, "ref_geobacillus-plasmids.bin-motifs.tsv")).read().strip().split("\n")[1:]:
+        c = line.split("\t")
+        from nanomotif_amd.motif import motif_type as product_motif_type
+        assert opp.motif_type(c[2]) == c[6] and product_motif_type(c[2]) == c[6]
+
+
+def _model(a, b):
+    m = BetaBernoulliModel()
+    m.update(a, b)
+    return m
