@@ -42,6 +42,36 @@ __device__ __forceinline__ void wave_add_keyed(unsigned int *counters, uint32_t 
     }
 }
 
+// OR of `v` over the whole wave, returned wave-uniform: quad butterflies and the two row mirrors through DPP (no LDS
+// traffic), then the four rows of 16 through v_readlane.
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror: 8 lanes
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);     // row_mirror: 16 lanes
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// Set bit `bit` of word `word` (a pointer into one of the state planes) for every lane with `pred`: the rows of a wave lie
+// within two or three words of four planes, so the lanes are grouped by target word (leader election over the ballot, as
+// above) and every distinct word receives ONE atomicOr with the bits of all its lanes — a billion per-row atomics on a
+// few million words were most of the classification pass.  All lanes of the wave must call this together.
+__device__ __forceinline__ void wave_or_keyed(uint32_t *word, uint32_t bit, bool pred) {
+    const uint32_t lane = __lane_id();
+    const uint64_t key = (uint64_t)(uintptr_t)word;
+    unsigned long long todo = __ballot(pred);
+    while (todo) {                                           // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, leader);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), leader);
+        const bool mine = pred && (uint32_t)key == klo && (uint32_t)(key >> 32) == khi;
+        const uint32_t bits = wave_or(mine ? bit : 0u);
+        if ((int)lane == leader) atomicOr(word, bits);
+        todo &= ~__ballot(mine);
+    }
+}
+
 // (1) coverage filter + per (contig, mod code) counts for the frequency filter
 __global__ void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
                                     int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err) {
@@ -81,19 +111,24 @@ __device__ __forceinline__ bool ingest_row_alive(const RawRows &r, uint64_t i, i
     return true;
 }
 
-// (3a) adjacency filter, scatter: per strand the maximal fraction at every position (mod codes mixed, dataload.py:237)
+// (3a) adjacency filter, scatter: per strand the maximal fraction at every position (mod codes mixed, dataload.py:237).
+// Only rows the verdict below tests (fraction >= meth_thr) can decide it — a tested row fails iff a row in its window has
+// a LARGER fraction, and that row is then above the threshold itself — so only those (~1 % of a pileup) are scattered;
+// every other position keeps the 0 the arrays were cleared to.
 __global__ void ingest_scatter_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                       const uint64_t *__restrict__ dense_off, unsigned long long *dense_plus,
-                                      unsigned long long *dense_minus, unsigned int *err) {
+                                      unsigned long long *dense_minus, double meth_thr, unsigned int *err) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= r.n) return;
     uint32_t c;
     bool plus;
     if (!ingest_row_alive(r, i, min_cov, ok, &c, &plus)) return;
     if (dense_off[c] == ~0ull) { atomicOr(err, 8u); return; }          // contig not listed for this part
+    const double f = r.frac[i];
+    if (f < meth_thr) return;
     const uint64_t g = dense_off[c] + r.position[i];
     // fractions are >= 0, so their IEEE bit patterns order like the values
-    atomicMax((plus ? dense_plus : dense_minus) + g, (unsigned long long)__double_as_longlong(r.frac[i]));
+    atomicMax((plus ? dense_plus : dense_minus) + g, (unsigned long long)__double_as_longlong(f));
 }
 
 // (3b) adjacency verdict + classification + confident-row list.  A row survives iff its fraction equals the maximum
@@ -133,15 +168,15 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         my_kept += alive;
         const int slot = alive ? sl.slot_of_mod[m] : -1;
         const bool meth = slot >= 0 && f >= high, non = slot >= 0 && f <= low;
-        if (!meth && !non) continue;
+        const bool cls = meth || non;
         // classified rows are counted; the host compares the total with the population count of the general planes
         // afterwards — a duplicate (contig, position, strand) row sets a bit twice and shows up there, which lets the
         // atomicOr run without a return value.  The compact planes M / U follow from the general ones
         // (compact_planes_kernel), and so does the list of confident rows (nm_ingest_results).
-        my_cls += 1;
-        uint32_t *const *pl = sl.planes[slot];
+        my_cls += cls;
+        uint32_t *const *pl = sl.planes[cls ? slot : 0];
         uint32_t *gen = plus ? (meth ? pl[2] : pl[3]) : (meth ? pl[4] : pl[5]);
-        atomicOr(gen + (g >> 5), 1u << (g & 31));
+        wave_or_keyed(gen + (g >> 5), 1u << (g & 31), cls);                   // all lanes take part
     }
     for (int d = 32; d; d >>= 1) {
         my_kept += __shfl_xor(my_kept, d);
@@ -295,7 +330,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         const dim3 grid((unsigned)((n_rows + 255) / 256));
         hipLaunchKernelGGL(ingest_count_kernel, grid, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
         if (n_groups) hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
-        hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, c->d_err);
+        hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
         hipLaunchKernelGGL(ingest_decide_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)), blk, 0, c->stream, r, 5, d_ok,
                            c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
     }

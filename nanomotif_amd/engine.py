@@ -171,13 +171,20 @@ class DeviceWindowExtractor:
         self.tasks.append((key, base, n_bg, cat(s_contig, np.uint32), cat(s_rank, np.uint32)))
         return True
 
-    def begin_group(self):
+    def begin_group(self, seed=None):
         """Called right after the caller (re)seeded ``random`` for the next task(s): the ``plan_contigs`` calls that follow
         form one generator stream whose draws are DEFERRED to ``finish`` — where the streams of all tasks are drawn on
-        several host threads at once (a thousand tasks x 1 % of a Gbp is 1e7 sequential Mersenne-Twister draws)."""
+        several host threads at once (a thousand tasks x 1 % of a Gbp is 1e7 sequential Mersenne-Twister draws).
+        ``seed``: what ``random.seed`` was just called with — every task of a plain-pileup run starts from the same
+        generator state (find_motifs_bin.py:152-171), read from the interpreter once."""
         import random
-        _, state, _ = random.getstate()
-        self._groups.append((np.array(state, dtype=np.uint32), []))
+        cache = self.__dict__.setdefault("_seed_state", {})
+        state = cache.get(seed) if seed is not None else None
+        if state is None:
+            state = np.array(random.getstate()[1], dtype=np.uint32)
+            if seed is not None:
+                cache[seed] = state
+        self._groups.append((state, []))
 
     def plan_contigs(self, key, names, mod_type: str) -> bool:
         """``plan`` without row lists: the task's windows are all confident rows of the contigs ``names`` (those present

@@ -319,7 +319,7 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
                 random.seed(cfg.seed)
             if extractor is not None:
                 if plus is None and (not bgzip_order or not getattr(extractor, "_bin_open", False)):
-                    extractor.begin_group()              # a fresh generator stream: its draws are made in extractor.finish()
+                    extractor.begin_group(cfg.seed)      # a fresh generator stream: its draws are made in extractor.finish()
                     extractor._bin_open = True
                 windows = None
                 planned_ok = (extractor.plan_contigs((bin_name, mod_type), names, mod_type) if plus is None
