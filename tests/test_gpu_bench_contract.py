@@ -43,6 +43,9 @@ def test_bench_json_contract():
     assert d["cfg5_all"]["agrees_with_per_bin_table"] is True and d["cfg5_all"]["value"] > 0
     assert d["roofline_hbm_bound_round"]["frac"] > 0 and "traffic_frac_of_streaming" in d["roofline_hbm_bound_round"]
     assert d["per_rank"][0]["kernel_ms"] > 0 and d["per_rank"][0]["host_call_ms_per_step"] > 0
+    # one GPU: the strict-order pass is the headline, the two-lane pass of the same steps is reported beside it
+    assert d["pipelining"]["scoring_lanes"] == 1 and d["two_lanes"]["scoring_lanes"] == 2 and d["two_lanes"]["value"] > 0
+    assert d["two_lanes"]["steps"] == 3 and d["prewarm_steps"] == 200
 
 
 def _bench(extra, nproc=1, launcher=True):
@@ -97,6 +100,12 @@ def test_single_rank_step_with_the_c_abi_allreduce():
     d = _bench(["--force-allreduce"])
     assert d["counts_checksum"] == one["counts_checksum"] and d["allreduce_ms"] > 0
     assert "nm_allreduce_counts" in d["config"]["sharding"] or d["n_gpus"] == 1
+    # the same step on two scoring lanes (what several GPUs run as their headline): same table, strict pass beside it
+    two = _bench(["--force-allreduce", "--lanes", "2"])
+    assert two["counts_checksum"] == one["counts_checksum"] and two["pipelining"]["scoring_lanes"] == 2
+    assert two["strict_order"]["scoring_lanes"] == 1 and two["strict_order"]["value"] > 0 and two["roofline"]["kernel_ms"] > 0
+    only = _bench(["--lanes", "1"])
+    assert "two_lanes" not in only and "strict_order" not in only and only["counts_checksum"] == one["counts_checksum"]
 
 
 def test_gpus_flag_must_match_world_size():
