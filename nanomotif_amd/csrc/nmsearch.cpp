@@ -16,7 +16,10 @@
 // The scoring and window back ends are callbacks, so the same state machine runs against the HIP engine
 // (nm_search_run) and, in the CPU tests, against the oracle's scan (nm_search_run_custom).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <queue>
@@ -529,7 +532,13 @@ namespace {
 int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user) {
     auto &tasks = res->tasks;
     const uint32_t W = P.width;
+    // NM_SEARCH_TIMING: where the wall time of the lock-step loop goes (stderr, one line)
+    const bool timing = getenv("NM_SEARCH_TIMING") != nullptr;
+    double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     for (auto &t : tasks) t.resume();
+    t_resume += now() - t0;
     std::vector<uint32_t> s_task, w_task;
     std::vector<char> s_motifs, w_motifs;
     std::vector<uint8_t> w_kind;
@@ -537,6 +546,7 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
     std::vector<int32_t> wout;
     for (;;) {
         s_task.clear(); w_task.clear(); s_motifs.clear(); w_motifs.clear(); w_kind.clear();
+        t0 = now();
         for (uint32_t i = 0; i < tasks.size(); ++i) {
             Task &t = tasks[i];
             if (t.req == REQ_SCORE) {
@@ -550,21 +560,27 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
                 w_motifs.insert(w_motifs.end(), t.req_motifs[0].begin(), t.req_motifs[0].end());
             }
         }
+        t_gather += now() - t0;
         if (s_task.empty() && w_task.empty()) break;
         if (!w_task.empty()) {
+            t0 = now();
             wout.assign(w_task.size() * (size_t)STRIDE, 0);
             const int rc = window_fn(user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
             if (rc) return rc;
             res->window_requests += w_task.size();
+            t_window += now() - t0;
         }
         if (!s_task.empty()) {
+            t0 = now();
             counts.assign(s_task.size() * 2, 0);
             const int rc = score_fn(user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data(), counts.data());
             if (rc) return rc;
             res->rounds += 1;
             res->candidates += s_task.size();
+            t_score += now() - t0;
         }
         // hand the replies back
+        t0 = now();
         size_t si = 0;
         for (size_t k = 0; k < w_task.size(); ++k) {
             Task &t = tasks[w_task[k]];
@@ -580,13 +596,20 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
             t.rep_models.clear();
             for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(counts[2 * si], counts[2 * si + 1]));
         }
+        t_reply += now() - t0;
+        t0 = now();
         for (auto &t : tasks)
             if (t.req != REQ_DONE && t.req != REQ_NONE) {
                 t.req = REQ_NONE;
                 t.resume();
             }
+        t_resume += now() - t0;
     }
     (void)W;
+    if (timing)
+        fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds: resume %.1f ms, request gathering %.1f ms, window batches %.1f ms, "
+                        "scoring batches %.1f ms, replies %.1f ms\n", tasks.size(), (unsigned long long)res->rounds, t_resume * 1e3,
+                t_gather * 1e3, t_window * 1e3, t_score * 1e3, t_reply * 1e3);
     return NM_OK;
 }
 
