@@ -180,3 +180,60 @@ def test_sample_groups_equal_sequential_streams():
     _lib.check(lib.nm_py_random_sample_groups(len(groups), p(np.ascontiguousarray(np.stack(init)), C.c_uint32), p(off, C.c_uint64), p(ns_, C.c_uint64),
                                               p(ks, C.c_uint64), p(out, C.c_uint32), p(final, C.c_uint32)))
     assert out.tolist() == want and np.array_equal(final, final_want)
+
+
+def test_searches_advance_on_several_threads_with_identical_results(monkeypatch):
+    """72 searches (24 copies of three bins) in one nm_search_run_custom call: the state machines advance on a pool of
+    host threads between two batches (NM_SEARCH_THREADS, nmsearch.cpp: Workers).  One thread and eight threads must export
+    the same graphs, node for node and bit for bit, and every copy must equal the first of its bin."""
+    from oracle.scan import score_candidates
+    g4 = load_golden("g4_search.json")
+    base, piles, seqs_by_bin, wins = [], {}, {}, {}
+    for bin_name, gname in (("binA", "gatc_single"), ("binB", "ecoli_like_m"), ("binC", "ecoli_like_a")):
+        g = g4[gname]
+        mg = synth.make_metagenome(spec_from_json(g["spec"]))
+        mt = g["mod_type"]
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        base.append((bin_name, mt))
+        piles[(bin_name, mt)], seqs_by_bin[bin_name] = pile, seqs
+        random.seed(1)
+        wins[(bin_name, mt)] = windows_for(mg, mt, pile)
+    copies = 24
+    keys = [(f"{b}#{c}", mt) for c in range(copies) for b, mt in base]
+    origin = {k: (k[0].split("#")[0], k[1]) for k in keys}
+    cache = {}
+
+    def run(threads):
+        monkeypatch.setenv("NM_SEARCH_THREADS", str(threads))
+        store = ps.HostWindowStore()
+        for k in keys:
+            store.add_task(k, wins[origin[k]][0].copy())
+
+        def score_fn(reqs):
+            out = np.zeros((len(reqs), 2), dtype=np.int64)
+            for i, (t, m) in enumerate(reqs):
+                o = origin[keys[t]]
+                ck = (o, m.string, m.mod_position)
+                if ck not in cache:
+                    cache[ck] = score_candidates(piles[o], seqs_by_bin[o[0]], [(m.string, m.mod_position)])[0]
+                out[i] = cache[ck]
+            return out
+        _, window_fn = _backends(keys, piles, seqs_by_bin, store)
+        res = ns.find_best_candidates_custom([(k, store.totals[k], wins[origin[k]][1]) for k in keys], 20, 0.05, 1.5, score_fn, window_fn)
+        out = []
+        for t in range(len(keys)):
+            r = res.result(t, full_graph=True)
+            if r is None:
+                out.append(None)
+                continue
+            graph, best, _ = r
+            out.append(([(n.string, n.mod_position, graph.nodes[n]["model"].get_raw_counts(), graph.nodes[n]["score"], graph.nodes[n]["priority"],
+                          graph.nodes[n]["depth"], graph.nodes[n]["visited"]) for n in graph.nodes],
+                        sorted((u.string, v.string) for u, v in graph.edges()), [(m.string, m.mod_position) for m in best]))
+        return (res.rounds, res.candidates), out
+    one = run(1)
+    eight = run(8)
+    assert one == eight
+    for t, k in enumerate(keys):
+        assert one[1][t] == one[1][t % len(base)], k
+    assert any(x is not None and len(x[2]) > 0 for x in one[1])
