@@ -225,6 +225,11 @@ int nm_win_add_task_contigs(nm_ctx *ctx, uint32_t mod_slot, uint32_t n_contigs, 
 int nm_contig_base_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t *out);
 int nm_bg_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
                  const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out);
+/* The same with the samples given as RUNS: run r holds run_count[r] consecutive entries of sample_rank, all on contig
+ * run_contig[r] (sample_n_subsequences draws contig after contig, find_motifs_bin.py:640-661); task t owns the runs
+ * [task_run_begin[t], task_run_begin[t + 1]).  The per-sample contig column is written on the device. */
+int nm_bg_counts_runs(nm_ctx *ctx, uint8_t base, uint32_t pad, uint32_t n_runs, const uint32_t *run_contig, const uint32_t *run_count,
+                      const uint32_t *sample_rank, uint32_t n_tasks, const uint32_t *task_run_begin, int64_t *out);
 /* Number of assembly letters that are none of A C G T N (any case) seen by the last nm_upload_contigs. */
 int nm_assembly_other_letters(nm_ctx *ctx, uint64_t *n);
 

@@ -561,16 +561,25 @@ int nm_contig_base_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t *out) 
     return NM_OK;
 }
 
-int nm_bg_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
-                 const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out) {
-    if (!c || !task_begin || !out) return fail(NM_EINVAL, "NULL argument");
-    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+// The samples of nm_bg_counts_runs arrive as RUNS (run r: run_count[r] consecutive samples on contig run_contig[r]); the
+// per-sample contig column the counting kernel reads is written on the device.
+struct BgRun { uint32_t begin_lo, begin_hi, count, contig; };
+
+__global__ __launch_bounds__(256) void bg_expand_runs_kernel(const BgRun *__restrict__ runs, uint32_t *__restrict__ sample_contig) {
+    const BgRun r = runs[blockIdx.x];
+    uint32_t *dst = sample_contig + (((uint64_t)r.begin_hi << 32) | r.begin_lo);
+    for (uint32_t i = threadIdx.x; i < r.count; i += blockDim.x) dst[i] = r.contig;
+}
+
+static int bg_counts_impl(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
+                          const std::vector<BgRun> *runs, const uint32_t *sample_rank, uint32_t n_tasks,
+                          const uint64_t *task_begin, int64_t *out) {
     const int b = base_index(base);
     if (b < 0) return fail(NM_EINVAL, "base must be one of A C G T");
     const uint32_t W = 2 * pad + 1;
     if (W > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", W, WIN_MAX_W);
     if (n_tasks == 0) return NM_OK;
-    if (n_samples && (!sample_contig || !sample_rank)) return fail(NM_EINVAL, "NULL sample column");
+    if (n_samples && !sample_rank) return fail(NM_EINVAL, "NULL sample column");
     if (task_begin[0] != 0 || task_begin[n_tasks] != n_samples) return fail(NM_EINVAL, "task_begin must run from 0 to n_samples");
     constexpr uint32_t SPB = 2048;                       // samples per workgroup
     std::vector<BgBlock> blocks;
@@ -579,25 +588,35 @@ int nm_bg_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, cons
         for (uint64_t s0 = task_begin[t]; s0 < task_begin[t + 1]; s0 += SPB)
             blocks.push_back(BgBlock{t, (uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)std::min<uint64_t>(SPB, task_begin[t + 1] - s0)});
     }
-    for (uint64_t i = 0; i < n_samples; ++i)
-        if (sample_contig[i] >= c->n_contigs) return fail(NM_EINVAL, "sample %llu: contig %u >= %u", (unsigned long long)i, sample_contig[i], c->n_contigs);
+    if (sample_contig)
+        for (uint64_t i = 0; i < n_samples; ++i)
+            if (sample_contig[i] >= c->n_contigs) return fail(NM_EINVAL, "sample %llu: contig %u >= %u", (unsigned long long)i, sample_contig[i], c->n_contigs);
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_rank(c, b);
     if (rc) return rc;
+    const size_t n_runs = runs ? runs->size() : 0;
     const size_t o_rank = (size_t)n_samples * 4, o_blk = (o_rank + (size_t)n_samples * 4 + 15) & ~(size_t)15;
-    const size_t o_out = (o_blk + blocks.size() * sizeof(BgBlock) + 15) & ~(size_t)15;
+    const size_t o_runs = (o_blk + blocks.size() * sizeof(BgBlock) + 15) & ~(size_t)15;
+    const size_t o_out = (o_runs + n_runs * sizeof(BgRun) + 15) & ~(size_t)15;
     const size_t out_bytes = (size_t)n_tasks * 4 * WIN_MAX_W * 8;
     rc = ensure_stage(c, o_out + out_bytes);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_samples) {
-        memcpy(hs, sample_contig, (size_t)n_samples * 4);
+        if (sample_contig) memcpy(hs, sample_contig, (size_t)n_samples * 4);
         memcpy(hs + o_rank, sample_rank, (size_t)n_samples * 4);
     }
     if (!blocks.empty()) memcpy(hs + o_blk, blocks.data(), blocks.size() * sizeof(BgBlock));
-    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
+    if (n_runs) memcpy(hs + o_runs, runs->data(), n_runs * sizeof(BgRun));
+    const size_t up0 = sample_contig ? 0 : o_rank;       // runs: the contig column never crosses the bus
+    HIP_TRY(hipMemcpyAsync(ds + up0, hs + up0, o_out - up0, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, out_bytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
+    if (n_runs) {
+        hipLaunchKernelGGL(bg_expand_runs_kernel, dim3((unsigned)n_runs), dim3(256), 0, c->stream,
+                           reinterpret_cast<const BgRun *>(ds + o_runs), reinterpret_cast<uint32_t *>(ds));
+        HIP_TRY(hipGetLastError());
+    }
     if (!blocks.empty()) {
         hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)blocks.size()), dim3(256), 0, c->stream, seq_planes(c),
                            c->d_rank[b], c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_blk),
@@ -618,6 +637,36 @@ int nm_bg_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, cons
             for (uint32_t col = 0; col < W; ++col)
                 out[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * WIN_MAX_W + col];
     return NM_OK;
+}
+
+int nm_bg_counts(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samples, const uint32_t *sample_contig,
+                 const uint32_t *sample_rank, uint32_t n_tasks, const uint64_t *task_begin, int64_t *out) {
+    if (!c || !task_begin || !out) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (n_samples && !sample_contig) return fail(NM_EINVAL, "NULL sample column");
+    return bg_counts_impl(c, base, pad, n_samples, n_samples ? sample_contig : nullptr, nullptr, sample_rank, n_tasks, task_begin, out);
+}
+
+int nm_bg_counts_runs(nm_ctx *c, uint8_t base, uint32_t pad, uint32_t n_runs, const uint32_t *run_contig, const uint32_t *run_count,
+                      const uint32_t *sample_rank, uint32_t n_tasks, const uint32_t *task_run_begin, int64_t *out) {
+    if (!c || !task_run_begin || !out || (n_runs && (!run_contig || !run_count))) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (task_run_begin[0] != 0 || task_run_begin[n_tasks] != n_runs) return fail(NM_EINVAL, "task_run_begin must run from 0 to n_runs");
+    std::vector<BgRun> runs(n_runs);
+    std::vector<uint64_t> task_begin(n_tasks + 1, 0);
+    uint64_t at = 0;
+    uint32_t t = 0;
+    for (uint32_t r = 0; r < n_runs; ++r) {
+        if (run_contig[r] >= c->n_contigs) return fail(NM_EINVAL, "run %u: contig %u >= %u", r, run_contig[r], c->n_contigs);
+        while (t < n_tasks && task_run_begin[t] <= r) {
+            if (t && task_run_begin[t] < task_run_begin[t - 1]) return fail(NM_EINVAL, "task_run_begin must be non-decreasing");
+            task_begin[t++] = at;
+        }
+        runs[r] = BgRun{(uint32_t)at, (uint32_t)(at >> 32), run_count[r], run_contig[r]};
+        at += run_count[r];
+    }
+    while (t <= n_tasks) task_begin[t++] = at;
+    return bg_counts_impl(c, base, pad, at, nullptr, &runs, sample_rank, n_tasks, task_begin.data(), out);
 }
 
 int nm_win_add_task_rows(nm_ctx *c, uint32_t n_rows, const uint32_t *contig_id, const uint32_t *position,

@@ -225,10 +225,11 @@ class DeviceWindowExtractor:
         mine = [ci for ci in res if ci is not None]
         if deferred:
             keep = [i for i, ci in enumerate(res) if ci is not None]
-            s_contig = np.repeat(np.asarray(mine, dtype=np.uint32), [n_samples[i] for i in keep]) if keep else np.zeros(0, np.uint32)
+            # the samples stay RUNS (contig, count) — nm_bg_counts_runs writes the per-sample contig column on the device
+            runs = (np.asarray(mine, dtype=np.uint32), np.asarray([n_samples[i] for i in keep], dtype=np.uint32))
             self._groups[-1][1].append((len(self.tasks), nv, n_samples, keep))
             self.store.add_task_contigs(key, mod_type, mine, self.pad, total=total)
-            self.tasks.append([key, base, n_bg, s_contig, None])
+            self.tasks.append([key, base, n_bg, runs, None])
             return True
         if len(mine) == len(names):
             s_contig = np.repeat(np.asarray(mine, dtype=np.uint32), n_samples)
@@ -251,22 +252,33 @@ class DeviceWindowExtractor:
         if self._groups:
             self._draw_deferred()
         counts = np.zeros((len(self.tasks), 4, W), dtype=np.int64)
+        n_of = [len(t[4]) for t in self.tasks]                 # samples this rank holds of every task
         for base in sorted({t[1] for t in self.tasks}):
             idx = [i for i, t in enumerate(self.tasks) if t[1] == base]
             lo = 0
             while lo < len(idx):
                 hi, n = lo, 0
-                while hi < len(idx) and (hi == lo or n + len(self.tasks[idx[hi]][3]) <= self.MAX_SAMPLES_PER_CALL):
-                    n += len(self.tasks[idx[hi]][3])
+                while hi < len(idx) and (hi == lo or n + n_of[idx[hi]] <= self.MAX_SAMPLES_PER_CALL):
+                    n += n_of[idx[hi]]
                     hi += 1
                 part = idx[lo:hi]
-                begin = np.zeros(len(part) + 1, dtype=np.uint64)
-                np.cumsum([len(self.tasks[i][3]) for i in part], out=begin[1:])
-                sc = np.concatenate([self.tasks[i][3] for i in part]) if n else np.zeros(0, np.uint32)
                 sr = np.concatenate([self.tasks[i][4] for i in part]) if n else np.zeros(0, np.uint32)
                 out = np.zeros((len(part), 4, W), dtype=np.int64)
-                _lib.check(self.engine.lib.nm_bg_counts(self.engine.ctx, ord(base), self.pad, n, _ptr(sc, C.c_uint32), _ptr(sr, C.c_uint32),
-                                                        len(part), _ptr(begin, C.c_uint64), _ptr(out, C.c_int64)))
+                if all(isinstance(self.tasks[i][3], tuple) for i in part):
+                    run_begin = np.zeros(len(part) + 1, dtype=np.uint32)
+                    np.cumsum([len(self.tasks[i][3][0]) for i in part], out=run_begin[1:])
+                    rc = np.ascontiguousarray(np.concatenate([self.tasks[i][3][0] for i in part]), dtype=np.uint32)
+                    rn = np.ascontiguousarray(np.concatenate([self.tasks[i][3][1] for i in part]), dtype=np.uint32)
+                    _lib.check(self.engine.lib.nm_bg_counts_runs(self.engine.ctx, ord(base), self.pad, len(rc), _ptr(rc, C.c_uint32),
+                                                                 _ptr(rn, C.c_uint32), _ptr(sr, C.c_uint32), len(part),
+                                                                 _ptr(run_begin, C.c_uint32), _ptr(out, C.c_int64)))
+                else:
+                    begin = np.zeros(len(part) + 1, dtype=np.uint64)
+                    np.cumsum([n_of[i] for i in part], out=begin[1:])
+                    sc = np.concatenate([self.tasks[i][3] if not isinstance(self.tasks[i][3], tuple) else np.repeat(*self.tasks[i][3])
+                                         for i in part]) if n else np.zeros(0, np.uint32)
+                    _lib.check(self.engine.lib.nm_bg_counts(self.engine.ctx, ord(base), self.pad, n, _ptr(sc, C.c_uint32), _ptr(sr, C.c_uint32),
+                                                            len(part), _ptr(begin, C.c_uint64), _ptr(out, C.c_int64)))
                 counts[part] = out
                 lo = hi
         if self.allreduce_i64 is not None:
