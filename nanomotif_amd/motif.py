@@ -40,30 +40,34 @@ def set_to_token(m: int) -> str:
     return "[" + "".join(ch for ch in "ACGT" if _BIT[ch] & m) + "]"
 
 
-@lru_cache(maxsize=1 << 16)
-def _parse(s: str):
-    """-> (tokens, sets, is_dot).  ``N`` inside a regex-style motif is kept as its own token (the reference
-    special-cases it in get_parent_scores / isolated-base checks) with set ANY."""
-    toks, sets = [], []
-    i = 0
-    while i < len(s):
-        ch = s[i]
-        if ch == "[":
-            j = s.find("]", i)
-            if j < 0:
-                raise ValueError("Unmatched bracket")
-            tok = s[i:j + 1]
-            m = 0
+_SET_OF_BYTE = bytes(ANY if chr(i) in ".N" else _BIT.get(chr(i), 0) for i in range(256))
+_TOKEN = re.compile(r"\[[^\]]*\]|.", re.S)
+_SET_OF_TOKEN = {".": ANY, "N": ANY, "A": A, "C": C, "G": G, "T": T}
+
+
+def _set_of_token(tok: str) -> int:
+    m = _SET_OF_TOKEN.get(tok)
+    if m is None:
+        if tok == "[":
+            raise ValueError("Unmatched bracket")
+        m = 0
+        if tok[0] == "[":
             for b in tok[1:-1]:
                 m |= _BIT.get(b, 0)
-            i = j + 1
-        else:
-            tok = ch
-            m = ANY if ch in ".N" else _BIT.get(ch, 0)
-            i += 1
-        toks.append(tok)
-        sets.append(m)
-    return tuple(toks), tuple(sets)
+        _SET_OF_TOKEN[tok] = m                  # other single characters: the empty set
+    return m
+
+
+@lru_cache(maxsize=1 << 16)
+def _parse(s: str):
+    """-> (tokens, sets).  ``N`` inside a regex-style motif is kept as its own token (the reference
+    special-cases it in get_parent_scores / isolated-base checks) with set ANY.  Tokenised by one regular expression:
+    a search creates thousands of 41-character strings, a character loop in the interpreter was half of the cold
+    post-processing time."""
+    if "[" not in s:                            # one character per token: both tuples come straight out of C code
+        return tuple(s), tuple(s.encode("latin-1", "replace").translate(_SET_OF_BYTE))
+    toks = tuple(_TOKEN.findall(s))
+    return toks, tuple([_set_of_token(t) for t in toks])
 
 
 def regex_to_iupac(regex_str: str) -> str:
