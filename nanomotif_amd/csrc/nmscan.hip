@@ -969,7 +969,12 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         }
     }
     HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
+    // strict order: the host waits for the compiled programs (tens of microseconds, the previous batch is still being
+    // scored) and the scoring queue carries no cross-stream barrier packet — 5-6 us less between two launches; with two
+    // lanes the host must run ahead instead, so there the stream waits
+    // (a call that returns host counts synchronises at its end anyway: one round trip, not two)
+    if (laned || h_out || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
+    else HIP_TRY(hipEventSynchronize(c->copy_done));
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
@@ -1087,6 +1092,7 @@ const char *nm_last_error(void) { return g_err.c_str(); }
 static int ctx_init(nm_ctx *c) {
     c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
     c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
+    c->opt_stream_wait = getenv("NM_STREAM_WAIT") != nullptr;      // A/B switch: never wait for the compile on the host
     if (const char *e = getenv("NM_FINE")) c->opt_fine = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("NM_SPLIT")) c->opt_split = std::max(0, std::min(2, atoi(e)));
     {
