@@ -496,7 +496,7 @@ def main():
     if coll is not None and coll.kind == "torch":
         eng.use_stream(side.cuda_stream)       # torch.distributed orders its collectives on torch's current stream only
     # (otherwise the engine keeps its own streams: a second scoring lane beside a torch stream shared a hardware queue with
-    #  it on this runtime and did not overlap, tools/gpu_lanes3.sh)
+    #  it on this runtime and did not overlap, profiles/r2/lanes_queue_ab.txt)
     # a ring of count tables: the all-reduce of step k (communication stream) overlaps the scoring launches of the next steps
     N_TABLES = 4
     counts = [torch.zeros((n_cand, 2), dtype=torch.int64, device=device) for _ in range(N_TABLES)]

@@ -1103,7 +1103,7 @@ static int ctx_init(nm_ctx *c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     // the second scoring lane is made here, next to the first: the runtime deals its hardware queues to streams in
-    // creation order, and two lanes that share a queue do not overlap (tools/gpu_lanes3.sh)
+    // creation order, and two lanes that share a queue do not overlap (profiles/r2/lanes_queue_ab.txt)
     HIP_TRY(hipStreamCreateWithFlags(&c->lane_stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));

@@ -166,3 +166,43 @@ def test_other_letters_are_counted():
     eng.upload_assembly(["c1", "c2"], ["ACGTNNRYacgtn" * 700, "ACGT" * 3000 + "W"], ["b", "b"])
     assert eng.other_letters() == 2 * 700 + 1
     eng.close()
+
+
+def test_background_counts_from_runs_equal_counts_from_samples():
+    """nm_bg_counts_runs (samples as (contig, count) runs, contig column written on the device) against nm_bg_counts with
+    the explicit per-sample contig column: three tasks with one, two and no runs; bad arguments come back as errors."""
+    import ctypes as C
+    from nanomotif_amd.engine import ScanEngine
+    rng = np.random.default_rng(17)
+    seqs = _assembly(rng, [30_000, 41_000, 25_000], n_frac=0.01)
+    names = list(seqs)
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, [seqs[n] for n in names], ["b", "b", "c"])
+    u32, u64, i64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+    for base in "AC":
+        nv = eng.contig_base_counts(base, 20)
+        run_contig = np.array([0, 1, 2], dtype=np.uint32)               # task 0: contig 0; task 1: contigs 1, 2; task 2: nothing
+        run_count = np.array([700, 3000, 450], dtype=np.uint32)
+        task_run_begin = np.array([0, 1, 3, 3], dtype=np.uint32)
+        ranks = np.concatenate([rng.choice(int(nv[c]), size=int(k), replace=False) for c, k in zip(run_contig, run_count)]).astype(np.uint32)
+        got = np.zeros((3, 4, 41), dtype=np.int64)
+        rc = eng.lib.nm_bg_counts_runs(eng.ctx, ord(base), 20, 3, run_contig.ctypes.data_as(u32), run_count.ctypes.data_as(u32),
+                                       ranks.ctypes.data_as(u32), 3, task_run_begin.ctypes.data_as(u32), got.ctypes.data_as(i64))
+        assert rc == 0, eng.lib.nm_last_error()
+        want = np.zeros((3, 4, 41), dtype=np.int64)
+        sc = np.repeat(run_contig, run_count).astype(np.uint32)
+        begin = np.array([0, 700, 4150, 4150], dtype=np.uint64)
+        rc = eng.lib.nm_bg_counts(eng.ctx, ord(base), 20, len(sc), sc.ctypes.data_as(u32), ranks.ctypes.data_as(u32), 3,
+                                  begin.ctypes.data_as(u64), want.ctypes.data_as(i64))
+        assert rc == 0, eng.lib.nm_last_error()
+        assert np.array_equal(got, want) and got[0, :, 20].sum() == 700
+        assert got[2].sum() == 0 and got[1, :, 20].sum() == 3450 and got[1][{"A": 0, "C": 3}[base], 20] == 3450
+    bad = np.array([0, 2, 1, 3], dtype=np.uint32)                       # not monotone
+    rc = eng.lib.nm_bg_counts_runs(eng.ctx, ord("A"), 20, 3, run_contig.ctypes.data_as(u32), run_count.ctypes.data_as(u32),
+                                   ranks.ctypes.data_as(u32), 3, bad.ctypes.data_as(u32), got.ctypes.data_as(i64))
+    assert rc != 0
+    far = np.array([0, 1, 9], dtype=np.uint32)                          # contig 9 does not exist
+    rc = eng.lib.nm_bg_counts_runs(eng.ctx, ord("A"), 20, 3, far.ctypes.data_as(u32), run_count.ctypes.data_as(u32),
+                                   ranks.ctypes.data_as(u32), 3, task_run_begin.ctypes.data_as(u32), got.ctypes.data_as(i64))
+    assert rc != 0 and b"contig 9" in eng.lib.nm_last_error()
+    eng.close()
