@@ -22,71 +22,95 @@ struct RawRows {
     const int32_t *nvalid;
 };
 
-// Pileup rows arrive sorted by contig, so the lanes of a wave almost always share their (contig, mod code) key: counters
-// are updated with ONE atomic per distinct key per wave (leader election over the ballot) instead of one per row —
-// a billion same-address atomics were 0.75 s of the 1 Gbp ingest.  All active lanes must call this together.
-__device__ __forceinline__ void wave_add_keyed(unsigned int *counters, uint32_t key, bool pred0, bool pred1, uint32_t stride) {
+// Per-(contig, mod code) counters.  Pileup rows arrive sorted by contig, so (1) the lanes of a wave almost always share
+// their key: the rows of one wave iteration are grouped by key (leader election over the ballot) — a billion same-address
+// atomics were 0.75 s of the 1 Gbp ingest; and (2) a wave that walks a CONTIGUOUS range of rows meets the same two or
+// three keys for thousands of iterations: the sums stay in a four-entry cache of wave-uniform registers and go to memory
+// when a key is evicted or the wave is done — with one atomic per wave iteration every wave of the device was still
+// hammering the same few addresses (3e7 serialised atomics = most of the 24 ms the classification pass took).
+struct KeyCache {
+    uint32_t key[4] = {~0u, ~0u, ~0u, ~0u}, n0[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0};
+    uint32_t next = 0;
+};
+
+__device__ __forceinline__ void cache_flush_entry(const KeyCache &kc, int j, unsigned int *counters, uint32_t stride, uint32_t lane) {
+    if (lane == 0 && kc.key[j] != ~0u) {
+        if (kc.n0[j]) atomicAdd(counters + (size_t)kc.key[j] * stride, kc.n0[j]);
+        if (stride > 1 && kc.n1[j]) atomicAdd(counters + (size_t)kc.key[j] * stride + 1, kc.n1[j]);
+    }
+}
+
+// all arguments but `lane` are wave-uniform
+__device__ __forceinline__ void cache_add(KeyCache &kc, unsigned int *counters, uint32_t stride, uint32_t key, uint32_t a, uint32_t b, uint32_t lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (kc.key[j] == key) {
+            kc.n0[j] += a;
+            kc.n1[j] += b;
+            return;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (kc.next == (uint32_t)j) {
+            cache_flush_entry(kc, j, counters, stride, lane);
+            kc.key[j] = key;
+            kc.n0[j] = a;
+            kc.n1[j] = b;
+        }
+    kc.next = (kc.next + 1) & 3u;
+}
+
+__device__ __forceinline__ void cache_flush(const KeyCache &kc, unsigned int *counters, uint32_t stride, uint32_t lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cache_flush_entry(kc, j, counters, stride, lane);
+}
+
+// counters[key * stride] += lanes with pred0, counters[key * stride + 1] += lanes with pred0 && pred1, through the cache.
+// All active lanes must call this together.
+__device__ __forceinline__ void wave_add_keyed(KeyCache &kc, unsigned int *counters, uint32_t key, bool pred0, bool pred1, uint32_t stride) {
     const uint32_t lane = __lane_id();
     unsigned long long todo = __ballot(pred0);
     while (todo) {                                           // wave-uniform
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k = __shfl(key, leader);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
         const bool mine = pred0 && key == k;
         const unsigned long long same = __ballot(mine);
         const unsigned long long same1 = __ballot(mine && pred1);
-        if ((int)lane == leader) {
-            atomicAdd(counters + (size_t)k * stride, (unsigned int)__popcll(same));
-            if (stride > 1 && same1) atomicAdd(counters + (size_t)k * stride + 1, (unsigned int)__popcll(same1));
-        }
+        cache_add(kc, counters, stride, k, (uint32_t)__popcll(same), (uint32_t)__popcll(same1), lane);
         todo &= ~same;
     }
 }
 
-// OR of `v` over the whole wave, returned wave-uniform: quad butterflies and the two row mirrors through DPP (no LDS
-// traffic), then the four rows of 16 through v_readlane.
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);     // row_half_mirror: 8 lanes
-    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true);     // row_mirror: 16 lanes
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
-           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-}
-
-// Set bit `bit` of word `word` (a pointer into one of the state planes) for every lane with `pred`: the rows of a wave lie
-// within two or three words of four planes, so the lanes are grouped by target word (leader election over the ballot, as
-// above) and every distinct word receives ONE atomicOr with the bits of all its lanes — a billion per-row atomics on a
-// few million words were most of the classification pass.  All lanes of the wave must call this together.
-__device__ __forceinline__ void wave_or_keyed(uint32_t *word, uint32_t bit, bool pred) {
-    const uint32_t lane = __lane_id();
-    const uint64_t key = (uint64_t)(uintptr_t)word;
-    unsigned long long todo = __ballot(pred);
-    while (todo) {                                           // wave-uniform
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, leader);
-        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), leader);
-        const bool mine = pred && (uint32_t)key == klo && (uint32_t)(key >> 32) == khi;
-        const uint32_t bits = wave_or(mine ? bit : 0u);
-        if ((int)lane == leader) atomicOr(word, bits);
-        todo &= ~__ballot(mine);
-    }
+// The rows [row_begin, row_end) one wave walks, 64 at a time: the device's waves cut the pileup into contiguous ranges.
+__device__ __forceinline__ void wave_row_range(uint64_t n, uint64_t *row_begin, uint64_t *row_end) {
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6), id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t per = (((n + waves - 1) / waves) + 63) & ~(uint64_t)63;
+    *row_begin = std::min<uint64_t>(n, id * per);
+    *row_end = std::min<uint64_t>(n, (id + 1) * per);
 }
 
 // (1) coverage filter + per (contig, mod code) counts for the frequency filter
-__global__ void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
+__global__ __launch_bounds__(256) void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
                                     int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= r.n) return;
-    const uint32_t c = r.contig[i];
-    const int m = r.mod[i];
-    bool counted = c != 0xFFFFFFFFu;
-    if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0 || m >= NM_MAX_MOD_CODES)) {
-        atomicOr(err, 1u);
-        counted = false;
+    uint64_t row_begin, row_end;
+    wave_row_range(r.n, &row_begin, &row_end);
+    const uint32_t lane = threadIdx.x & 63;
+    KeyCache kc;
+    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64) {
+        const uint64_t i = i0 + lane;
+        const bool in = i < row_end;
+        const uint32_t c = in ? r.contig[i] : 0xFFFFFFFFu;
+        const int m = in ? r.mod[i] : 0;
+        bool counted = c != 0xFFFFFFFFu;
+        if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0 || m >= NM_MAX_MOD_CODES)) {
+            atomicOr(err, 1u);
+            counted = false;
+        }
+        counted = counted && r.nvalid[i] > min_cov;                              // dataload.py:199: Nvalid_cov > 5
+        const bool is_mod = counted && r.frac[i] > meth_thr;                    // dataload.py:215: fraction_mod > 0.7
+        wave_add_keyed(kc, cnt, counted ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, counted, is_mod, 2);
     }
-    counted = counted && r.nvalid[i] > min_cov;                              // dataload.py:199: Nvalid_cov > 5
-    const bool is_mod = counted && r.frac[i] > meth_thr;                    // dataload.py:215: fraction_mod > 0.7
-    wave_add_keyed(cnt, counted ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, counted, is_mod, 2);
+    cache_flush(kc, cnt, 2, lane);
 }
 
 // (2) frequency filter verdict per (contig, mod code): n_mod / n > 1e-4 and n_mod > 50 (dataload.py:218-219)
@@ -146,25 +170,50 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
                                      double low, double high, IngestSlots sl,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
                                      unsigned long long *n_classified) {
-    // grid-stride over the rows: the two global totals are kept in registers and leave as ONE atomic per wave at the
-    // end (a per-row or even per-wave-iteration atomic on one address was most of this kernel's time at 1e9 rows)
+    // every wave walks a contiguous range of rows: the two global totals are kept in registers and leave as ONE atomic
+    // per wave at the end (a per-row or even per-wave-iteration atomic on one address was most of this kernel's time at
+    // 1e9 rows)
     unsigned long long my_kept = 0, my_cls = 0;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < r.n; i0 += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t i = i0 + threadIdx.x;
+    // Classification bits are collected per wave in LDS before they go to memory: the 64 rows of a wave iteration lie within
+    // a few words of a few planes (rows ascend within a contig), so a table of [plane][word - first word] entries takes one
+    // LDS atomic per row and leaves as ONE global atomicOr per touched word (~10 per 64 rows).  Rows outside the window of
+    // OR_WORDS words (another contig in the same wave, unsorted input) go straight to memory.
+    constexpr uint32_t OR_WORDS = 4, OR_PLANES = NM_MAX_MOD_SLOTS * 4;
+    __shared__ uint32_t or_tab[4][OR_PLANES * OR_WORDS];
+    __shared__ uint32_t *or_plane[OR_PLANES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t e = threadIdx.x; e < 4 * OR_PLANES * OR_WORDS; e += blockDim.x) (&or_tab[0][0])[e] = 0;
+    if (threadIdx.x < OR_PLANES) or_plane[threadIdx.x] = sl.planes[threadIdx.x >> 2][2 + (threadIdx.x & 3)];
+    __syncthreads();
+    uint64_t row_begin, row_end;
+    wave_row_range(r.n, &row_begin, &row_end);
+    KeyCache kc;
+    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64) {
+        const uint64_t i = i0 + lane;
         uint32_t c = 0;
         bool plus = true;
-        bool alive = i < r.n && ingest_row_alive(r, i, min_cov, ok, &c, &plus);
+        bool alive = i < row_end && ingest_row_alive(r, i, min_cov, ok, &c, &plus);
         alive = alive && dense_off[c] != ~0ull;                  // (flagged by the scatter pass)
         const double f = alive ? r.frac[i] : 0.0;
         const uint64_t g = alive ? (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i] : 0;
         if (alive && !(f < meth_thr)) {
             const unsigned long long *d = (plus ? dense_plus : dense_minus) + dense_off[c] + r.position[i];
-            unsigned long long mx = 0;
-            for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[k]);       // >= 64 zero positions around every contig
+            unsigned long long mx = 0;                                              // >= 64 zero positions around every contig
+            if (adjacency == 8) {
+                // the pipeline's distance: all 17 loads are issued before the first is waited for — walked one by one they
+                // were 17 dependent DRAM round trips in two of three wave iterations, and the kernel was bound by exactly that
+                unsigned long long v[17];
+#pragma unroll
+                for (int k = 0; k < 17; ++k) v[k] = d[k - 8];
+#pragma unroll
+                for (int k = 0; k < 17; ++k) mx = max(mx, v[k]);
+            } else {
+                for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[k]);
+            }
             if (mx != (unsigned long long)__double_as_longlong(f)) alive = false;
         }
         const int m = alive ? r.mod[i] : 0;
-        wave_add_keyed(kept, alive ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, alive, false, 1);     // all lanes take part
+        wave_add_keyed(kc, kept, alive ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, alive, false, 1);     // all lanes take part
         my_kept += alive;
         const int slot = alive ? sl.slot_of_mod[m] : -1;
         const bool meth = slot >= 0 && f >= high, non = slot >= 0 && f <= low;
@@ -174,10 +223,33 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         // atomicOr run without a return value.  The compact planes M / U follow from the general ones
         // (compact_planes_kernel), and so does the list of confident rows (nm_ingest_results).
         my_cls += cls;
-        uint32_t *const *pl = sl.planes[cls ? slot : 0];
-        uint32_t *gen = plus ? (meth ? pl[2] : pl[3]) : (meth ? pl[4] : pl[5]);
-        wave_or_keyed(gen + (g >> 5), 1u << (g & 31), cls);                   // all lanes take part
+        const unsigned long long cls_mask = __ballot(cls);
+        if (cls_mask) {                                                        // wave-uniform
+            const uint32_t pid = cls ? (uint32_t)slot * 4u + (plus ? (meth ? 0u : 1u) : (meth ? 2u : 3u)) : 0u;   // MP UP MM UM
+            const uint64_t w = g >> 5;
+            const int first = __ffsll((long long)cls_mask) - 1;
+            const uint64_t w_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), first) << 32) |
+                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, first);
+            const uint64_t rel = w - w_base;                                   // wraps to a huge value for a smaller word
+            const uint32_t bit = 1u << (g & 31);
+            if (cls) {
+                if (rel < OR_WORDS) atomicOr(&or_tab[wave][pid * OR_WORDS + (uint32_t)rel], bit);
+                else atomicOr(or_plane[pid] + w, bit);
+            }
+            // (the LDS unit serves a wave's instructions in order: the reads below see the atomics above; the compiler
+            //  must only keep the order, a fence would also wait for every global access in flight)
+            __asm__ volatile("" ::: "memory");
+            for (uint32_t e = lane; e < OR_PLANES * OR_WORDS; e += 64) {
+                const uint32_t bits = or_tab[wave][e];
+                if (bits) {
+                    atomicOr(or_plane[e / OR_WORDS] + w_base + e % OR_WORDS, bits);
+                    or_tab[wave][e] = 0;
+                }
+            }
+            __asm__ volatile("" ::: "memory");
+        }
     }
+    cache_flush(kc, kept, 1, lane);
     for (int d = 32; d; d >>= 1) {
         my_kept += __shfl_xor(my_kept, d);
         my_cls += __shfl_xor(my_cls, d);
@@ -328,10 +400,11 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     const dim3 blk(256);
     if (n_rows && n_groups) {              // (a shard without contigs ignores every row)
         const dim3 grid((unsigned)((n_rows + 255) / 256));
-        hipLaunchKernelGGL(ingest_count_kernel, grid, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
+        const dim3 walk((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32));      // waves walk contiguous row ranges
+        hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
         if (n_groups) hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
         hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
-        hipLaunchKernelGGL(ingest_decide_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)), blk, 0, c->stream, r, 5, d_ok,
+        hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
                            c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
     }
     // population of the general planes (all parts so far): the confident rows, and the duplicate check — every
