@@ -155,7 +155,9 @@ int nm_ingest_results(nm_ctx *ctx, uint32_t *conf_contig, uint32_t *conf_positio
  *   out_counts[2k] = n_mod, out_counts[2k+1] = n_nomod  (what model.update receives, :1320)
  * nm_score_batch writes host memory and returns when done; nm_score_batch_device writes device memory
  * (e.g. a torch int64 tensor's data_ptr) asynchronously on the ctx stream so the caller can all-reduce it
- * with RCCL before reading.
+ * with RCCL before reading.  (The call returns once its own batch is uploaded and compiled — tens of microseconds on
+ * a side stream while earlier batches are scored; up to four batches are in flight, nm_set_score_lanes lets
+ * consecutive ones overlap.)
  */
 int nm_score_batch(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                    const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
