@@ -303,6 +303,9 @@ def main():
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
     ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: all that apply; none)")
+    ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
+                    help="debug, one GPU: hold the shard rank 0 of an N-rank run would hold (contigs as shard.assign_contigs deals "
+                         "them, the whole candidate table in every call); counts are this shard's only")
     ap.add_argument("--prewarm", type=int, default=200,
                     help="untimed steps BEFORE the W warm-up steps: brings the device clocks to their steady state (a 20-step run is "
                          "12 ms long, shorter than the clock ramp); reported in the JSON line")
@@ -377,7 +380,9 @@ def main():
     seed = 1 + rank if weak else 1
     spec_kw = dict(n_contigs=args.contigs, total_bp=args.total_bp, n_bins=args.bins, mod_types=("a", "m"), seed=seed)
     mg = synth.make_metagenome(synth.SynthSpec(**spec_kw))
-    if weak or world == 1:
+    if world == 1 and args.as_rank_of > 1:
+        mine = assign_contigs(mg.lengths, args.as_rank_of, bins=mg.bin_names)[0]
+    elif weak or world == 1:
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
@@ -449,7 +454,7 @@ def main():
         torch.cuda.empty_cache()
     t0 = time.perf_counter()
     eng = ScanEngine(local_rank)
-    rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if (world == 1 or weak) else mine, progress=log)
+    rows = synth_device.load_engine_from_device(eng, mg, device, contigs=None if ((world == 1 and args.as_rank_of <= 1) or weak) else mine, progress=log)
     # torch's work of this script runs on one explicit side stream; when torch.distributed carries the count tables the
     # engine's launches go there too (below) (the legacy default stream has the handle 0, which nm_set_stream reads as
     # "use the ctx's own stream": never hand it that)
