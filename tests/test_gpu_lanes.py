@@ -29,7 +29,12 @@ def _batches(mg, n_batches):
     bins = sorted(set(mg.bin_names))
     out = []
     for k in range(n_batches):
-        if k % 3 == 0:
+        if k % 5 == 3:            # wide: constraints more than 31 positions from the modified base (the four-word-group kernels)
+            out.append([(Motif("G" + "." * 35 + can + "T." + "C", 36), mt, bn) for bn in bins for mt, can in (("a", "A"), ("m", "C"))] +
+                       [(Motif("GATC", 1), "a", bins[0])])
+        elif k % 5 == 4:          # general state planes: the modified position is not the canonical base of its mod type
+            out.append([(Motif("G[AT]TC", 1), "a", bn) for bn in bins] + [(Motif("CC.GG", 2), "m", bins[-1]), (Motif("TTAA", 0), "a", bins[0])])
+        elif k % 3 == 0:
             raw = synth.random_candidates(16 * len(bins), seed=100 + k, mod_types=mg.spec.mod_types)
             out.append([(Motif(s, p), mt, bins[(j // 2) % len(bins)]) for j, (s, p, mt) in enumerate(raw)])
         elif k % 3 == 1:
