@@ -43,7 +43,11 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 HBM_STREAM_GBS = 6350.0        # what a plain streaming-read kernel reaches on this device (tools/hbm_peak.hip, profiles/r1/hbm_peak.txt)
-VALU_PEAK_WAVE_INSTR_S = 6.1e11   # measured integer-VALU issue peak (tools/valu_peak.hip, profiles/r1/valu_peak.txt)
+VALU_PEAK_WAVE_INSTR_S = 6.1e11   # measured issue rate of THIS kernel's instruction mix (alignbit + and, tools/valu_peak.hip, profiles/r1/valu_peak.txt)
+VALU_ISSUE_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 2   # the chip: 256 CU x 4 SIMD x 2.4 GHz, one wave64 VALU op per 2 cycles (MI355X_MICROARCH.md) = 1.23e12
+# counts_checksum of the N = 1 run of a configuration (workload, total bp, contigs, bins, candidates) — what every N > 1
+# run of the same seeds must reproduce after its all-reduce (BENCH_r02.json, profiles/r2/bench_n1.json)
+N1_CHECKSUMS = {("cfg5", 1_000_000_000, 10_000, 500, 10_000): [5367162, 308740588, 8024022553]}
 ALGO_BYTES_PER_BP_STEP = 0.5   # 2-bit sequence + 2-bit methylation state per bp per mod-type step
 
 
@@ -254,7 +258,19 @@ def time_launches(eng, batch, out_ptr, n, device):
     return ms / max(k, 1), wall * 1e3
 
 
+def kernel_source_sha16():
+    """First 16 hex digits of the sha256 of the scoring kernel's source: ties the stored rocprofv3 counter entries
+    (profiles/traffic.json) to the code they were measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("nmscan.hip", "nmscan_internal.h"):
+        h.update(open(os.path.join(ROOT, "nanomotif_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload, total_bp, n_cand):
+    """The stored rocprofv3 --pmc numbers of this configuration (profiles/summarize.py wrote them), with ``stale`` = the
+    kernel source changed since they were measured."""
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tj):
         return None
@@ -262,8 +278,15 @@ def load_traffic(workload, total_bp, n_cand):
     entries = t if isinstance(t, list) else t.get("entries", [t])
     for e in entries:
         if (e.get("workload"), e.get("total_bp"), e.get("candidates"), e.get("n_gpus", 1)) == (workload, total_bp, n_cand, 1):
+            e = dict(e)
+            e["stale"] = e.get("kernel_source_sha16") != kernel_source_sha16()
             return e
     return None
+
+
+def checksum(table):
+    return [int(table[:, 0].sum()), int(table[:, 1].sum()),
+            int((table * np.arange(1, table.size + 1).reshape(table.shape) % 1000003).sum() % (2**61 - 1))]
 
 
 def run_e2e(mg, eng_device, device, my_bins=None):
@@ -554,8 +577,10 @@ def main():
         eng.set_score_lanes(1)
         k_local = k_total / max(n_launch, 1)
         el, k = allmax([el_local, k_local])
+        # the table the LAST timed step of this pass left (all-reduced at N > 1): what the verification below looks at
+        table = counts[(step_no[0] - 1) % N_TABLES].cpu().numpy().copy()
         return {"lanes": lanes, "elapsed": el, "elapsed_local": el_local, "kernel_ms": k, "kernel_ms_local": k_local,
-                "host_ms": host_s[0] / args.steps * 1e3}
+                "host_ms": host_s[0] / args.steps * 1e3, "table": table}
 
     if args.cooldown > 0:
         torch.cuda.synchronize(device)
@@ -574,14 +599,54 @@ def main():
     drain()
     strict = timed_region(1)
     piped = timed_region(2) if (lanes_ok and args.lanes != 1 and (want == 2 or "two_lanes" in extras or args.lanes == 2)) else None
-    head = piped if (want == 2 and piped) else strict
+    lanes_agree = None if piped is None else bool(np.array_equal(strict["table"], piped["table"]))
+    if lanes_agree is False:
+        log("COUNT MISMATCH between the strict-order and the two-lane pass: the strict-order pass is the headline")
+    head = piped if (want == 2 and piped and lanes_agree) else strict
     elapsed, elapsed_local = head["elapsed"], head["elapsed_local"]
     kernel_ms, kernel_ms_local = strict["kernel_ms"], strict["kernel_ms_local"]
     host_s[0] = head["host_ms"] * args.steps * 1e-3
-    final = counts[(step_no[0] - 1) % N_TABLES].cpu().numpy()
+    final = head["table"]
+
+    # ---- the line proves its own counts (untimed).  (1) independent sum: every rank scores its shard once more in strict
+    # order into a fresh table, the tables travel by all_gather (torch.distributed, not the C ABI's communicator) and are
+    # summed on the host; (2) rank 0 loads ALL contigs of a few sampled bins into a second engine — the single-shard, N = 1
+    # computation of those bins — and compares their rows; (3) the N = 1 checksum of this configuration, when it is known.
+    verification = {"lanes_agree": lanes_agree}
+    if reduce_counts:
+        loc = torch.zeros((n_cand, 2), dtype=torch.int64, device=device)
+        eng.score_into_device(batch, loc.data_ptr())
+        eng.sync()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            src = loc if args.dist_backend == "nccl" else loc.cpu()
+            parts = [torch.zeros_like(src) for _ in range(world)]
+            dist.all_gather(parts, src)
+            indep = np.sum([p_.cpu().numpy() for p_ in parts], axis=0)
+        else:
+            indep = loc.cpu().numpy()
+        verification["allreduced_equals_independent_sum"] = bool(np.array_equal(indep, final))
+        if rank == 0 and cands is not None and (world > 1 or args.as_rank_of > 1):
+            bins_sorted = sorted(set(mg.bin_names))
+            sample_bins = list(dict.fromkeys(bins_sorted[(k * 37) % len(bins_sorted)] for k in range(4)))
+            idx = [i for i, b in enumerate(mg.bin_names) if b in set(sample_bins)]
+            eng1 = ScanEngine(local_rank)
+            synth_device.load_engine_from_device(eng1, mg, device, contigs=idx)
+            whole = eng1.score(eng1.make_batch(cands))
+            eng1.close()
+            rows_ = [k for k, c_ in enumerate(cands) if c_[2] in set(sample_bins)]
+            want_rows = whole[rows_]
+            got_rows = (final if world > 1 else indep)[rows_]      # (--as-rank-of: one shard only, nothing to compare but the path)
+            verification["bin_sample"] = {"bins": len(sample_bins), "candidates": len(rows_),
+                                          "equal_to_single_shard": bool(np.array_equal(want_rows, got_rows)) if world > 1 else None}
+        del loc
+    known = N1_CHECKSUMS.get((args.workload, args.total_bp, args.contigs, args.bins, args.candidates))
+    if known is not None and not weak and args.as_rank_of <= 1 and args.workload == "cfg5":
+        verification["n1_checksum_known"] = known
+        verification["equals_n1_checksum"] = checksum(final) == known
 
     # the collective alone: K all-reduces of the table back to back, slowest rank
-    allreduce_ms = None
+    allreduce_ms, allreduce_ms_local = None, None
     if coll:
         torch.cuda.synchronize(device)
         if world > 1:
@@ -592,10 +657,13 @@ def main():
             coll.start(k & 1, counts[k & 1])
         coll.drain()
         torch.cuda.synchronize(device)
-        allreduce_ms = allmax([(time.perf_counter() - t0) / args.steps * 1e3])[0]
-        # put the tables back: `final` was read above, the all-reduced copies are multiples now
+        allreduce_ms_local = (time.perf_counter() - t0) / args.steps * 1e3
+        allreduce_ms = allmax([allreduce_ms_local])[0]
+        # (the tables are multiples of the counts now: `final` and the verification tables were read before)
+    info = eng.comm_info() if (coll and coll.kind == "native") else {"world": 0, "rank": -1, "device": -1, "rccl_version": 0}
     per_rank = gather([elapsed_local / args.steps * 1e3, kernel_ms_local, host_s[0] / args.steps * 1e3, float(len(mine)),
-                       float(sum(my_bin_bp.values())), algo_bytes_rank])
+                       float(sum(my_bin_bp.values())), algo_bytes_rank, allreduce_ms_local if coll else -1.0,
+                       float(info["world"]), float(info["rank"]), float(info["device"])])
 
     # ---- the same engine in its HBM-bound regime: one lock-step greedy round (2 sibling children per (bin, mod type),
     # the shape MotifSearcher.run submits), kernel time from HIP events; reported next to the main roofline
@@ -652,23 +720,44 @@ def main():
                                     f"contigs over {world} GPUs, longest-first, bins kept whole when small (nanomotif_amd/shard.py); "
                                     f"count tables summed by {'nm_allreduce_counts (RCCL, C ABI)' if (coll and coll.kind == 'native') else 'torch.distributed ' + args.dist_backend}"),
                        "motif_sites_per_step": sites_per_step * nw},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+            # achieved / peak / frac are the HBM roofline of the contract (algorithmic bytes over the kernel's duration);
+            # `bound` names what REALLY limits this launch: a heavy batch (>~ 3 candidates per (bin, mod type)) is bound by
+            # integer-VALU issue, not by HBM — its HBM fraction is also given as hbm_frac, the VALU side in roofline_valu
+            "roofline": {"bound": "hbm" if args.workload == "greedy" else "valu-int",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                          "traffic_source": tr["source"] if tr else "not collected for this configuration (rocprofv3 --pmc runs: profiles/)",
+                         "traffic_measured_by": "rocprofv3 --pmc run of this command kept in profiles/ (replayed here, not collected by this run)" if tr else None,
+                         "traffic_stale": bool(tr["stale"]) if tr else None,
+                         "kernel_source_sha16": kernel_source_sha16(),
                          "kernel": "score_kernel (narrow, compact)", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_rank,
                          "note": "0.5 B/bp per (bin, mod type) step + 16 B per candidate; slowest rank at N>1"},
             # of the strict-order pass (with two lanes consecutive launches overlap: a step is then SHORTER than one launch)
             "kernel_share_of_step": kernel_ms / (strict["elapsed"] / args.steps * 1e3),
-            "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes"], p)) for p in per_rank],
+            "per_rank": [dict(zip(["ms_per_step", "kernel_ms", "host_call_ms_per_step", "contigs", "bp", "algorithmic_bytes", "allreduce_ms",
+                                   "rccl_world", "rccl_rank", "rccl_device"], p)) for p in per_rank],
             "allreduce_ms": allreduce_ms,
             "prewarm_steps": args.prewarm,
             "pipelining": {"scoring_lanes": head["lanes"], "staging_ring": 4, "count_tables": N_TABLES,
                            "note": "lanes = 2: consecutive (independent) steps alternate between two scoring streams of the C ABI "
                                    "and overlap on the device; roofline.kernel_ms is always the strict-order pass of this run"},
-            "counts_checksum": [int(final[:, 0].sum()), int(final[:, 1].sum()),
-                                int((final * np.arange(1, final.size + 1).reshape(final.shape) % 1000003).sum() % (2**61 - 1))],
+            "counts_checksum": checksum(final),
+            "verification": verification,
         }
+        if coll:
+            # what the communicator reports about itself (ncclCommCount / ncclCommUserRank through nm_comm_info), every rank
+            worlds = sorted({int(p[7]) for p in per_rank})
+            result["rccl"] = {"world": worlds[0] if len(worlds) == 1 else worlds, "native": coll.kind == "native",
+                              "all_ranks_report_world": worlds == [world] if coll.kind == "native" else None,
+                              "version_code": info["rccl_version"],
+                              "carrier": "nm_allreduce_counts_async (C ABI, RCCL through dlopen)" if coll.kind == "native"
+                                         else f"torch.distributed {args.dist_backend}"}
+        if reduce_counts or "equals_n1_checksum" in verification:
+            ok_parts = [verification.get("allreduced_equals_independent_sum"), verification.get("equals_n1_checksum"),
+                        (verification.get("bin_sample") or {}).get("equal_to_single_shard")]
+            result["checksum_matches_n1"] = all(x for x in ok_parts if x is not None) if any(x is not None for x in ok_parts) else None
         other = strict if head is piped else piped
         if other:
             result["strict_order" if head is piped else "two_lanes"] = {
@@ -680,10 +769,19 @@ def main():
             # second roofline: the kernel is integer-VALU-issue bound once a (bin, mod type) carries more than ~2
             # candidates; instruction count from rocprofv3 (SQ_INSTS_VALU, profiles/), peak from tools/valu_peak.hip
             rate = tr["sq_insts_valu_per_launch"] / (kernel_ms * 1e-3)
-            result["roofline_valu"] = {"bound": "valu-int", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTR_S,
-                                       "unit": "wave64 integer instr/s", "frac": rate / VALU_PEAK_WAVE_INSTR_S,
+            result["roofline_valu"] = {"bound": "valu-int", "achieved": rate, "unit": "wave64 integer instr/s",
+                                       # the honest denominator: the chip's VALU issue rate (one wave64 op per 2 cycles per SIMD)
+                                       "peak": VALU_ISSUE_PEAK_WAVE_INSTR_S, "frac": rate / VALU_ISSUE_PEAK_WAVE_INSTR_S,
+                                       "peak_source": "MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 VALU op",
+                                       # and the rate THIS instruction mix can issue at (half its ops are the half-rate v_alignbit_b32)
+                                       "peak_measured_mix": VALU_PEAK_WAVE_INSTR_S, "frac_of_measured_mix": rate / VALU_PEAK_WAVE_INSTR_S,
+                                       "peak_measured_mix_source": "tools/valu_peak.hip, profiles/r1/valu_peak.txt (alignbit + and stream)",
                                        "sq_insts_valu_per_launch": tr["sq_insts_valu_per_launch"],
-                                       "peak_source": "profiles/r1/valu_peak.txt (alignbit+and stream, 4 cycles per wave64 op per SIMD)"}
+                                       "sq_insts_salu_per_launch": tr.get("sq_insts_salu_per_launch"),
+                                       "salu_per_valu": (tr["sq_insts_salu_per_launch"] / tr["sq_insts_valu_per_launch"]) if tr.get("sq_insts_salu_per_launch") else None,
+                                       "sq_inst_cycles_salu_per_launch": tr.get("sq_inst_cycles_salu_per_launch"),
+                                       "sq_busy_cycles_per_launch": tr.get("sq_busy_cycles_per_launch"),
+                                       "counters_stale": bool(tr["stale"])}
 
     # ---- extra: every candidate x every bin (SURVEY §8(d) cfg 5 as 2e13 motif-sites per step), N = 1
     try:
@@ -754,15 +852,22 @@ def main():
                                       "value": sum(t[0] for t in tot) * args.steps / el, "unit": "motif-sites/s", "ms_per_step": el / args.steps * 1e3}
         eng_w.close()
 
+    failed = 0
     if rank == 0:
         if e2e_result is not None:
             result["e2e"] = e2e_result
         if extra_errors:
             result["extra_errors"] = extra_errors
         emit(result)
+        if result.get("checksum_matches_n1") is False or (result.get("parity") or {}).get("mismatches"):
+            log("COUNT VERIFICATION FAILED: " + json.dumps(result.get("verification")))
+            failed = 1
     if world > 1:
+        failed = int(allmax([failed])[0])
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)                      # a line whose counts do not verify must not pass for a measurement
 
 
 if __name__ == "__main__":

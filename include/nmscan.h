@@ -126,7 +126,10 @@ int nm_upload_pileup_device(nm_ctx *ctx, uint32_t mod_slot, uint8_t canonical_ba
  * contig, position; valid until a slot is uploaded again).  The device-side window extraction
  * (nm_win_add_task_contigs) never needs the list.
  *   rows: contig_id = engine contig index or 0xFFFFFFFF for contigs this device does not hold (ignored);
- *   mod_code 0..7 (0 = m, 1 = a, 2 = 21839, others as numbered by the reader); nvalid_cov as read (col 10).
+ *   mod_code 0..127 (0 = m, 1 = a, 2 = 21839, others as numbered by the reader: they form their own frequency-filter
+ *   groups and take part in the adjacency maximum like in the reference, but only codes 0..7 can be given a slot or are
+ *   reported by nm_ingest_results); nvalid_cov as read (col 10); fraction_mod < 0 = null percentage (such a row counts
+ *   as a position of its group, dataload.py:216, and is dropped by the adjacency filter).
  *   rows_on_device != 0: the six columns are device pointers.
  */
 int nm_ingest_pileup(nm_ctx *ctx, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
@@ -326,7 +329,10 @@ int nm_search_result_free(nm_search_result *res);
  *   nm_comm_wait(ctx, b) before the ctx stream touches table k's buffer again (device-side wait, returns at once).
  * nm_allreduce_counts_host: host int64[n] in, summed host int64[n] out (staged through the ctx; blocking) — for
  *   hosts that keep the tables in host memory (the Python lock-step scheduler).
- * nm_comm_sync: host waits for every outstanding all-reduce.  nm_comm_destroy: also done by nm_ctx_destroy. */
+ * nm_comm_sync: host waits for every outstanding all-reduce.  nm_comm_destroy: also done by nm_ctx_destroy.
+ * With two scoring lanes a count table may be handed to the next nm_score_batch_device only after nm_comm_wait on the
+ * buffer_slot of its last all-reduce (or after nm_sync when it was not all-reduced): the library orders a launch after
+ * the previous launch that wrote the SAME d_out_counts, but it cannot see a collective still reading it. */
 #define NM_COMM_ID_BYTES 128
 #define NM_COMM_SLOTS 4
 int nm_comm_unique_id(uint8_t id[NM_COMM_ID_BYTES]);
@@ -336,6 +342,10 @@ int nm_allreduce_counts_async(nm_ctx *ctx, int64_t *d_counts, uint64_t n, int bu
 int nm_comm_wait(nm_ctx *ctx, int buffer_slot);
 int nm_allreduce_counts_host(nm_ctx *ctx, int64_t *counts, uint64_t n);
 int nm_comm_sync(nm_ctx *ctx);
+/* What the communicator of this ctx reports about itself: info[0] = number of ranks (ncclCommCount; 0 = no communicator),
+ * info[1] = this rank (ncclCommUserRank), info[2] = its HIP device (ncclCommCuDevice), info[3] = RCCL version code
+ * (ncclGetVersion, 0 = no communicator).  A run can thereby state the world its count tables were REALLY summed over. */
+int nm_comm_info(nm_ctx *ctx, int32_t info[4]);
 int nm_comm_destroy(nm_ctx *ctx);
 
 /* Device time of the last scoring launch(es) in milliseconds, measured with HIP events on the ctx stream
@@ -355,10 +365,13 @@ typedef struct nm_bed nm_bed;
 int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
 /* The tabix path of the reference (dataload.py:102-152, find_motifs_bin.py:233-246: the records of a bin's contigs are
  * fetched through the .tbi index): only the BGZF blocks holding the n_contigs wanted contigs (names back to back,
- * name_offset[n_contigs + 1]) are inflated and parsed; contigs absent from the index are skipped.  stats (may be NULL):
- * {bytes inflated, bytes of the compressed file}.  NM_EINVAL "not a tabix index" when tbi_path is not one. */
+ * name_offset[n_contigs + 1]) are inflated and parsed; contigs absent from the index are skipped and counted.  stats
+ * (may be NULL): {bytes inflated, bytes of the compressed file, wanted contigs without an index entry, 0}.  NM_EINVAL
+ * "not a tabix index" when tbi_path is not one; NM_EINVAL "does not match the pileup" / "index points ..." when the
+ * regions the index names hold rows of other contigs or do not start at BGZF blocks (a stale index): the caller should
+ * then read the whole file (nm_bed_open). */
 int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
-                        uint32_t threads, nm_bed **out, uint64_t stats[2]);
+                        uint32_t threads, nm_bed **out, uint64_t stats[4]);
 int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);
 int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
 int nm_bed_mod_code(nm_bed *bed, uint32_t id, const char **code);
@@ -366,8 +379,8 @@ int nm_bed_columns(nm_bed *bed, const uint32_t **contig_id, const int64_t **posi
                    const uint8_t **strand, const double **fraction_mod, const int64_t **nvalid_cov);
 /* The columns in the exact types nm_ingest_pileup[_part] takes, without further copies: contig ids mapped through
  * contig_lut[n_contigs of the file] (engine contig id, or 0xFFFFFFFF for contigs the engine does not hold), positions
- * as uint32, Nvalid_cov as int32 with -1 for rows whose coverage or percentage is null (they fall to the coverage
- * filter like in the reference).  Releases the 64-bit originals: nm_bed_columns must not be used afterwards. */
+ * as uint32, Nvalid_cov as int32 with -1 for rows whose coverage is null (they fall to the coverage filter like in the
+ * reference; a null percentage stays fraction_mod = -1).  Releases the 64-bit originals: nm_bed_columns must not be used afterwards. */
 int nm_bed_ingest_columns(nm_bed *bed, const uint32_t *contig_lut, uint32_t n_lut, const uint32_t **contig_id,
                           const uint32_t **position, const int8_t **mod_type, const uint8_t **strand,
                           const double **fraction_mod, const int32_t **nvalid_cov);

@@ -17,7 +17,7 @@ SYMBOLS = [
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
-    "nm_comm_sync", "nm_comm_destroy",
+    "nm_comm_sync", "nm_comm_info", "nm_comm_destroy",
     "nm_score_batch_per_contig", "nm_bin_contigs", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_export", "nm_search_result_free",
 ]
 
@@ -156,6 +156,7 @@ def load():
     lib.nm_comm_wait.argtypes = [p, C.c_int]
     lib.nm_allreduce_counts_host.argtypes = [p, i64p, C.c_uint64]
     lib.nm_comm_sync.argtypes = [p]
+    lib.nm_comm_info.argtypes = [p, C.POINTER(C.c_int32)]
     lib.nm_comm_destroy.argtypes = [p]
     lib.nm_timing_total_ms.argtypes = [p, C.POINTER(C.c_double), u64p]
     for s in SYMBOLS:

@@ -425,7 +425,7 @@ int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
 // offsets) gives every contig its [begin, end) virtual offsets — from the pseudo-bin 37450 when present, else the
 // hull of its chunks.  NM_EINVAL with "not a tabix index" when the .tbi is not one (the caller may read the whole file).
 int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
-                        uint32_t threads, nm_bed **out, uint64_t stats[2]) {
+                        uint32_t threads, nm_bed **out, uint64_t stats[4]) {
     if (!path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return nm_set_error(NM_EINVAL, "NULL argument");
     *out = nullptr;
     if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
@@ -456,6 +456,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
     struct Region { uint64_t beg, end; };
     std::vector<Region> regions;
+    uint64_t found_in_index = 0;
     size_t o = 36 + (size_t)l_nm;
     for (int32_t r = 0; r < n_ref; ++r) {
         if (o + 4 > tn) return bad();
@@ -487,7 +488,10 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
         o += 4;
         if (n_intv < 0 || o + (size_t)n_intv * 8 > tn) return bad();
         o += (size_t)n_intv * 8;
-        if (want.count(ref_names[r]) && hi > lo) regions.push_back({lo, hi});
+        if (want.count(ref_names[r])) {
+            found_in_index += 1;
+            if (hi > lo) regions.push_back({lo, hi});
+        }
     }
     std::sort(regions.begin(), regions.end(), [](const Region &x, const Region &y) { return x.beg < y.beg; });
     // neighbouring contigs: one region
@@ -557,8 +561,20 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     }
     text.data = text.owned.data();
     text.size = text.owned.size();
-    if (stats) { stats[0] = inflated; stats[1] = zn; }
-    return parse_text(path, text, threads, out);
+    if (stats) { stats[0] = inflated; stats[1] = zn; stats[2] = n_contigs - std::min<uint64_t>(found_in_index, n_contigs); stats[3] = 0; }
+    rc = parse_text(path, text, threads, out);
+    if (rc) return rc;
+    // the text the index pointed at must belong to the contigs that were asked for: a stale or foreign .tbi otherwise
+    // yields a silently wrong subset of rows
+    for (const std::string &nm : (*out)->all.names)
+        if (!want.count(nm)) {
+            const std::string culprit = nm;
+            delete *out;
+            *out = nullptr;
+            return nm_set_error(NM_EINVAL, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
+                                path, culprit.c_str());
+        }
+    return NM_OK;
 }
 
 int nm_bed_shape(nm_bed *b, uint64_t *n_rows, uint32_t *n_contigs) {
@@ -614,11 +630,13 @@ int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut,
             const int64_t p = b->all.position[i], v = b->all.nvalid[i];
             const int8_t m = b->all.mod_type[i];
             if (p < 0 || p > 0xFFFFFFFEll) bad[t] |= 1;
-            if (m < 0 || m >= 8) bad[t] |= 2;
+            if (m < 0) bad[t] |= 2;
             b->ing_contig[i] = contig_lut[b->all.contig[i]];
             b->ing_position[i] = (uint32_t)p;
-            // a null coverage or percentage can never pass Nvalid_cov > 5: such rows leave through the coverage filter
-            b->ing_nvalid[i] = (v < 0 || b->all.fraction[i] < 0) ? -1 : (int32_t)std::min<int64_t>(v, 0x7FFFFFFF);
+            // a null coverage can never pass Nvalid_cov > 5: such rows leave through the coverage filter; a null PERCENTAGE
+            // with enough coverage keeps its coverage and its fraction of -1: it counts as a position of its
+            // (contig, mod code) group in the frequency filter (pl.count(), dataload.py:216) and leaves at the adjacency filter
+            b->ing_nvalid[i] = v < 0 ? -1 : (int32_t)std::min<int64_t>(v, 0x7FFFFFFF);
         }
     };
     if (threads == 1) {
@@ -631,7 +649,7 @@ int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut,
     int any = 0;
     for (int x : bad) any |= x;
     if (any & 1) return nm_set_error(NM_ERANGE, "pileup position beyond 4 Gbp");
-    if (any & 2) return nm_set_error(NM_ERANGE, "more than 8 distinct modification codes in the pileup");
+    if (any & 2) return nm_set_error(NM_ERANGE, "modification code id out of range");
     Vec<int64_t>().swap(b->all.position);          // the 64-bit originals are no longer needed
     Vec<int64_t>().swap(b->all.nvalid);
     *contig_id = b->ing_contig.data();

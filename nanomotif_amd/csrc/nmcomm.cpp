@@ -25,6 +25,10 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;        // optional: what the communicator itself reports
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     std::string why;
 };
 
@@ -45,6 +49,10 @@ Rccl &rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.handle, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
+    r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.handle, "ncclCommCuDevice"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
         r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
         r.handle = nullptr;
@@ -157,6 +165,36 @@ int nm_allreduce_counts_host(nm_ctx *c, int64_t *counts, uint64_t n) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(counts, c->h_stage, n * sizeof(int64_t));
+    return NM_OK;
+}
+
+int nm_comm_info(nm_ctx *c, int32_t info[4]) {
+    if (!c || !info) return fail(NM_EINVAL, "NULL argument");
+    info[0] = info[3] = 0;
+    info[1] = info[2] = -1;
+    if (!c->comm) return NM_OK;
+    // read back from the communicator, not from what nm_comm_init was told: the run reports the world RCCL really built
+    ncclComm_t comm = static_cast<ncclComm_t>(c->comm);
+    int v = 0;
+    if (rccl().CommCount) {
+        RCCL_TRY(rccl().CommCount(comm, &v));
+        info[0] = v;
+    } else {
+        info[0] = c->comm_world;
+    }
+    if (rccl().CommUserRank) {
+        RCCL_TRY(rccl().CommUserRank(comm, &v));
+        info[1] = v;
+    } else {
+        info[1] = c->comm_rank;
+    }
+    if (rccl().CommCuDevice) {
+        RCCL_TRY(rccl().CommCuDevice(comm, &v));
+        info[2] = v;
+    }
+    v = 0;
+    if (rccl().GetVersion) (void)rccl().GetVersion(&v);
+    info[3] = v > 0 ? v : 1;
     return NM_OK;
 }
 

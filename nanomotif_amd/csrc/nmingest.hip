@@ -16,7 +16,7 @@ struct RawRows {
     uint64_t n;
     const uint32_t *contig;      // engine-local contig id, 0xFFFFFFFF = contig not resident (row ignored)
     const uint32_t *position;
-    const int8_t *mod;           // 0..NM_MAX_MOD_CODES-1
+    const int8_t *mod;           // 0..NM_CODE_STRIDE-1; only codes < NM_MAX_MOD_CODES can have a slot
     const uint8_t *strand;
     const double *frac;
     const int32_t *nvalid;
@@ -102,13 +102,15 @@ __global__ __launch_bounds__(256) void ingest_count_kernel(RawRows r, uint32_t n
         const uint32_t c = in ? r.contig[i] : 0xFFFFFFFFu;
         const int m = in ? r.mod[i] : 0;
         bool counted = c != 0xFFFFFFFFu;
-        if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0 || m >= NM_MAX_MOD_CODES)) {
+        if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0)) {
             atomicOr(err, 1u);
             counted = false;
         }
         counted = counted && r.nvalid[i] > min_cov;                              // dataload.py:199: Nvalid_cov > 5
         const bool is_mod = counted && r.frac[i] > meth_thr;                    // dataload.py:215: fraction_mod > 0.7
-        wave_add_keyed(kc, cnt, counted ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, counted, is_mod, 2);
+        // (a row whose percentage is null — fraction < 0 — counts as a position, never as a modified one: pl.count() vs
+        //  (fraction_mod > thr).sum(), dataload.py:216-217)
+        wave_add_keyed(kc, cnt, counted ? c * NM_CODE_STRIDE + (uint32_t)m : 0u, counted, is_mod, 2);
     }
     cache_flush(kc, cnt, 2, lane);
 }
@@ -126,8 +128,9 @@ __device__ __forceinline__ bool ingest_row_alive(const RawRows &r, uint64_t i, i
                                                  uint32_t *c_out, bool *plus_out) {
     const uint32_t c = r.contig[i];
     const int m = r.mod[i];
-    if (c == 0xFFFFFFFFu || m < 0 || m >= NM_MAX_MOD_CODES || r.nvalid[i] <= min_cov) return false;
-    if (!ok[(size_t)c * NM_MAX_MOD_CODES + m]) return false;
+    if (c == 0xFFFFFFFFu || m < 0 || r.nvalid[i] <= min_cov) return false;
+    if (!ok[(size_t)c * NM_CODE_STRIDE + m]) return false;
+    if (r.frac[i] < 0) return false;               // null percentage: neither `== max` nor `< threshold` holds (dataload.py:244)
     const uint8_t st = r.strand[i];
     if (st != '+' && st != '-') return false;      // other strand labels form groups of their own and are never scored
     *c_out = c;
@@ -213,9 +216,10 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
             if (mx != (unsigned long long)__double_as_longlong(f)) alive = false;
         }
         const int m = alive ? r.mod[i] : 0;
-        wave_add_keyed(kc, kept, alive ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, alive, false, 1);     // all lanes take part
+        const bool listed = alive && m < NM_MAX_MOD_CODES;       // codes beyond the ABI's eight are filtered with the rest, never reported
+        wave_add_keyed(kc, kept, listed ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, listed, false, 1);     // all lanes take part
         my_kept += alive;
-        const int slot = alive ? sl.slot_of_mod[m] : -1;
+        const int slot = listed ? sl.slot_of_mod[m] : -1;
         const bool meth = slot >= 0 && f >= high, non = slot >= 0 && f <= low;
         const bool cls = meth || non;
         // classified rows are counted; the host compares the total with the population count of the general planes
@@ -309,7 +313,8 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t words = plane_words(c);
-    const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;
+    const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;        // reported: kept rows per (contig, code < 8)
+    const size_t n_fgroups = (size_t)c->n_contigs * NM_CODE_STRIDE;         // frequency-filter groups: every code
     IngestSlots sl{};
     for (int m = 0; m < NM_MAX_MOD_CODES; ++m) {
         sl.slot_of_mod[m] = slot_of_mod[m];
@@ -359,7 +364,20 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     }
     // device copies of the raw columns
     std::vector<void *> owned;
-    auto cleanup = [&]() { for (void *p : owned) (void)nmdetail::dev_free(p); };
+    // (a registered pool allocator does not synchronise like hipFree: nothing queued on the stream may still use the blocks)
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        for (void *p : owned) (void)nmdetail::dev_free(p);
+    };
+    // a failed ingest leaves half-written planes behind: the slots go back to "no pileup" so that scoring refuses them
+    auto invalidate = [&]() {
+        for (int m = 0; m < NM_MAX_MOD_CODES; ++m)
+            if (slot_of_mod[m] >= 0 && slot_of_mod[m] < NM_MAX_MOD_SLOTS) {
+                c->slots[slot_of_mod[m]].present = false;
+                c->slots[slot_of_mod[m]].n_rows = 0;
+            }
+        drop_ingest_rows(c);
+    };
     RawRows r{};
     r.n = n_rows;
     if (rows_on_device) {
@@ -382,15 +400,15 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     unsigned long long *d_dense = nullptr, *d_scalars = nullptr;
     uint64_t *d_dense_off = nullptr;
 #define ING_ALLOC(ptr, bytes) do { void *q_ = nullptr; if (nmdetail::dev_malloc(&q_, (bytes)) != hipSuccess) { cleanup(); return fail(NM_ENOMEM, "out of device memory in nm_ingest_pileup (%zu bytes)", (size_t)(bytes)); } owned.push_back(q_); ptr = (decltype(ptr))q_; } while (0)
-    ING_ALLOC(d_cnt, std::max<size_t>(n_groups, 1) * 2 * 4);
+    ING_ALLOC(d_cnt, std::max<size_t>(n_fgroups, 1) * 2 * 4);
     ING_ALLOC(d_kept, std::max<size_t>(n_groups, 1) * 4);
-    ING_ALLOC(d_ok, std::max<size_t>(n_groups, 1));
+    ING_ALLOC(d_ok, std::max<size_t>(n_fgroups, 1));
     ING_ALLOC(d_dense, npos * 8 * 2);
     ING_ALLOC(d_dense_off, (size_t)std::max(c->n_contigs, 1u) * 8);
     ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
-    e = hipMemsetAsync(d_cnt, 0, n_groups * 2 * 4, c->stream);
+    e = hipMemsetAsync(d_cnt, 0, n_fgroups * 2 * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 32, c->stream);
@@ -402,7 +420,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         const dim3 grid((unsigned)((n_rows + 255) / 256));
         const dim3 walk((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32));      // waves walk contiguous row ranges
         hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
-        if (n_groups) hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_groups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_groups, d_cnt, 0.0001, 50u, d_ok);
+        hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_fgroups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_fgroups, d_cnt, 0.0001, 50u, d_ok);
         hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
         hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
                            c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
@@ -421,7 +439,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
                            sl.can_l[slot], pl[0], pl[1], words);
     }
     e = hipGetLastError();
-    if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { cleanup(); invalidate(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
     unsigned long long scal[4] = {0, 0, 0, 0};
     unsigned int err = 0;
     std::vector<uint32_t> part_kept(n_groups);
@@ -430,14 +448,14 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (e == hipSuccess) e = hipMemcpyAsync(part_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     cleanup();
-    if (e != hipSuccess) return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e));
-    if (err & 1u) return fail(NM_EINVAL, "pileup row with contig_id / position / mod code outside the uploaded assembly");
-    if (err & 8u) return fail(NM_EINVAL, "pileup row of a contig that is not listed in part_contigs");
+    if (e != hipSuccess) { invalidate(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
+    if (err & 1u) { invalidate(); return fail(NM_EINVAL, "pileup row with contig_id / position / mod code outside the uploaded assembly"); }
+    if (err & 8u) { invalidate(); return fail(NM_EINVAL, "pileup row of a contig that is not listed in part_contigs"); }
     c->ing_total_kept += scal[0];
     c->ing_classified += scal[1];
     c->ing_nconf = scal[2];
     for (size_t i = 0; i < n_groups; ++i) c->ing_kept[i] += part_kept[i];
-    if ((err & 4u) || c->ing_classified != scal[2] + scal[3]) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
+    if ((err & 4u) || c->ing_classified != scal[2] + scal[3]) { invalidate(); return fail(NM_EINVAL, "duplicate (contig, position, strand) rows within one modification type: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)"); }
     for (int m = 0; m < NM_MAX_MOD_CODES; ++m)
         if (slot_of_mod[m] >= 0) c->slots[slot_of_mod[m]].n_rows = c->ing_total_kept;
     *n_kept = c->ing_total_kept;

@@ -648,6 +648,64 @@ __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, u
     for (int t = 0; t < T_WORDS; ++t) out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & raw.s[0][which][t];
 }
 
+// nm_hit_positions, device-side compaction of the site masks hits_kernel wrote: only the hit INDICES cross PCIe.
+// (1) set bits per chunk (256 words = one workgroup)
+__global__ __launch_bounds__(256) void hits_count_kernel(const uint32_t *__restrict__ masks, uint32_t *__restrict__ chunk_cnt) {
+    __shared__ uint32_t part[4];
+    uint32_t n = __popc(masks[(size_t)blockIdx.x * CHUNK_WORDS + threadIdx.x]);
+    for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// (2) exclusive prefix over the chunks (one workgroup walks them 256 at a time), total in off[n_chunks]
+__global__ __launch_bounds__(256) void hits_scan_kernel(const uint32_t *__restrict__ chunk_cnt, uint32_t n_chunks, unsigned long long *__restrict__ off) {
+    __shared__ unsigned long long buf[256];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n_chunks ? chunk_cnt[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                   // Hillis-Steele inclusive scan
+            const unsigned long long add = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_chunks) off[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += buf[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n_chunks] = carry;
+}
+
+// (3) every word writes the contig-local positions of its bits at its rank (ascending: words, then bits)
+__global__ __launch_bounds__(256) void hits_scatter_kernel(const uint32_t *__restrict__ masks, const unsigned long long *__restrict__ off,
+                                                           long long *__restrict__ out, unsigned long long capacity) {
+    __shared__ uint32_t buf[256];
+    uint32_t m = masks[(size_t)blockIdx.x * CHUNK_WORDS + threadIdx.x];
+    const uint32_t n = __popc(m);
+    buf[threadIdx.x] = n;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)d ? buf[threadIdx.x - d] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long at = off[blockIdx.x] + buf[threadIdx.x] - n;
+    const long long w0 = ((long long)blockIdx.x * CHUNK_WORDS + threadIdx.x) * 32;
+    while (m && at < capacity) {
+        out[at++] = w0 + (__ffs(m) - 1);
+        m &= m - 1;
+    }
+}
+
 }  // namespace
 
 
@@ -659,6 +717,7 @@ namespace nmdetail {
 static nm_alloc_fn g_alloc = nullptr;
 static nm_free_fn g_free = nullptr;
 static void *g_alloc_user = nullptr;
+static int g_live_ctx = 0;          // contexts alive: the allocator pair may only change while there is none
 
 hipError_t device_alloc(void **p, size_t bytes) {
     *p = nullptr;
@@ -908,6 +967,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         sst = c->lane_stream;
         c->lane_pending = true;
     }
+    if (laned) {
+        // two launches that write the same count table are ordered (memset, kernel) only within one stream: when an
+        // earlier launch in flight wrote d_out from the other lane, this lane waits for it (its staging pair's event)
+        for (auto &st : c->stage)
+            if (&st != c->cur_stage && st.pending && st.last_out == d_out && st.last_stream && st.last_stream != sst)
+                HIP_TRY(hipStreamWaitEvent(sst, st.busy, 0));
+    }
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage);
     CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
@@ -1049,6 +1115,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     HIP_TRY(hipEventRecord(e1, sst));
     rc = release_stage(c, sst);
     if (rc) return rc;
+    c->cur_stage->last_out = d_out;
+    c->cur_stage->last_stream = sst;
     c->last_score_stream = sst;
     c->timed = !c->ev_collect;
     c->launches += 1;
@@ -1081,6 +1149,10 @@ int nm_abi_version(void) { return 1; }
 
 int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user) {
     if ((alloc == nullptr) != (free_fn == nullptr)) return fail(NM_EINVAL, "give both functions or neither");
+    // a block must go back to the allocator it came from: with a ctx alive its planes, staging buffers and tables would
+    // be released through the other pair (hipFree on a pool sub-block, the pool's free on a hipMalloc pointer)
+    if (nmdetail::g_live_ctx > 0 && (alloc != nmdetail::g_alloc || free_fn != nmdetail::g_free || user != nmdetail::g_alloc_user))
+        return fail(NM_ESTATE, "nm_set_device_allocator with %d nm_ctx alive: destroy them first", nmdetail::g_live_ctx);
     nmdetail::g_alloc = alloc;
     nmdetail::g_free = free_fn;
     nmdetail::g_alloc_user = user;
@@ -1125,6 +1197,7 @@ int nm_ctx_create(int device, nm_ctx **out) {
     if (!c) return fail(NM_ENOMEM, "out of host memory");
     c->device = device;
     c->stream = nullptr;
+    nmdetail::g_live_ctx += 1;
     const int rc = ctx_init(c);
     if (rc != NM_OK) {                 // nm_ctx_destroy releases whatever was created (the error text is already set)
         const std::string keep = g_err;
@@ -1165,7 +1238,10 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (!c) return NM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    (void)join_lanes(c);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);      // a registered pool's free does not wait like hipFree
+    if (c->lane_stream) (void)hipStreamSynchronize(c->lane_stream);
+    c->lane_pending = false;
     (void)nm_comm_destroy(c);
     free_assembly(c);
     for (auto &st : c->stage) {
@@ -1191,6 +1267,7 @@ int nm_ctx_destroy(nm_ctx *c) {
     if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
+    nmdetail::g_live_ctx -= 1;
     return NM_OK;
 }
 
@@ -1412,7 +1489,14 @@ static int upload_pileup_impl(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_ba
     unsigned int err = 0;
     HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    ms.n_rows += n_rows;
+    if (err) {
+        // the planes already carry part of the bad rows: the slot goes back to "no pileup" (scoring then refuses it with
+        // NM_ESTATE) instead of staying half-written; an append loses what the slot held before, which is corrupt too
+        ms.present = false;
+        ms.n_rows = 0;
+    } else {
+        ms.n_rows += n_rows;
+    }
     if (err & 1u) return fail(NM_EINVAL, "pileup row with contig_id / position outside the uploaded assembly");
     if (err & 2u) return fail(NM_EINVAL, "pileup strand must be '+' or '-'");
     if (err & 4u) return fail(NM_EINVAL, "duplicate (contig, position, strand) rows: the reference's np.isin(assume_unique=True) requires unique positions (find_motifs_bin.py:1258)");
@@ -1503,32 +1587,44 @@ int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t l
     }
     const uint32_t nch = c->contig_nchunks[contig_id];
     const size_t out_words = (size_t)nch * CHUNK_WORDS;
-    rc = ensure_stage(c, sizeof prog + out_words * 4);
+    // scratch: site masks of the contig | set bits per chunk | their exclusive prefix (+ total)
+    const size_t o_cnt = PROG_DW * 4 + out_words * 4, o_off = (o_cnt + (size_t)nch * 4 + 7) & ~(size_t)7;
+    rc = ensure_stage(c, o_off + ((size_t)nch + 1) * 8);
     if (rc) return rc;
     memcpy(c->h_stage, prog, sizeof prog);
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof prog, hipMemcpyHostToDevice, c->stream));
-    uint32_t *d_prog = static_cast<uint32_t *>(c->d_stage);
-    uint32_t *d_out = d_prog + PROG_DW;
+    uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
+    uint32_t *d_prog = reinterpret_cast<uint32_t *>(ds);
+    uint32_t *d_masks = d_prog + PROG_DW;
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(ds + o_cnt);
+    unsigned long long *d_off = reinterpret_cast<unsigned long long *>(ds + o_off);
     const ModSlot &ms = c->slots[mod_slot];
     Planes seq{c->dH, c->dL, c->dV, c->d_needs_v};
     StatePlanes st{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
     dim3 grid((nch + 3) / 4);
-    if (wide) hipLaunchKernelGGL((hits_kernel<2, 2>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_out);
-    else hipLaunchKernelGGL((hits_kernel<1, 1>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_out);
+    if (wide) hipLaunchKernelGGL((hits_kernel<2, 2>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
+    else hipLaunchKernelGGL((hits_kernel<1, 1>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
     HIP_TRY(hipGetLastError());
-    uint32_t *h_out = static_cast<uint32_t *>(c->h_stage) + PROG_DW;
-    HIP_TRY(hipMemcpyAsync(h_out, d_out, out_words * 4, hipMemcpyDeviceToHost, c->stream));
+    // compaction on the device (popcount prefix + scatter): only the hit indices cross PCIe, not the contig's masks
+    hipLaunchKernelGGL(hits_count_kernel, dim3(nch), dim3(256), 0, c->stream, d_masks, d_cnt);
+    hipLaunchKernelGGL(hits_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_cnt, nch, d_off);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_off + nch, sizeof total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    uint64_t n = 0;
-    for (size_t w = 0; w < out_words; ++w) {
-        uint32_t m = h_out[w];
-        while (m) {
-            const int b = __builtin_ctz(m);
-            m &= m - 1;
-            if (out && n < capacity) out[n] = (int64_t)(w * 32 + b);
-            ++n;
-        }
+    const uint64_t n = total, n_write = out ? std::min<uint64_t>(n, capacity) : 0;
+    if (n_write) {
+        long long *d_pos = nullptr;
+        HIP_TRY(nmdetail::dev_malloc(&d_pos, n_write * 8));
+        hipLaunchKernelGGL(hits_scatter_kernel, dim3(nch), dim3(256), 0, c->stream, d_masks, d_off, d_pos, (unsigned long long)n_write);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, d_pos, n_write * 8, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t e2 = hipStreamSynchronize(c->stream);
+        (void)nmdetail::dev_free(d_pos);
+        if (e != hipSuccess || e2 != hipSuccess) return fail(NM_EHIP, "hit compaction failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     }
+    rc = release_stage(c);
+    if (rc) return rc;
     *n_out = n;
     return NM_OK;
 }

@@ -44,7 +44,8 @@ constexpr int BMAX = 32;                                // candidates per LDS ac
 constexpr int PROG_DW = 64;                             // host-side program: [strand 2][word-group 4][plane 8]
 // device-side programs are packed to the word-groups the launched kernel variant reads:
 // narrow (offsets in [-32, 31]) = groups 1..2 -> 32 dwords (128 B), wide = all four -> 64 dwords
-constexpr int NM_MAX_MOD_CODES = 8;
+constexpr int NM_MAX_MOD_CODES = 8;                     // mod codes that can be given a slot / reported (ABI: slot_of_mod[8])
+constexpr int NM_CODE_STRIDE = 128;                     // mod code ids the pre-filters tell apart (int8 ids; the reader numbers unknown codes 3, 4, ...)
 constexpr int WIN_MAX_W = 64;                // window width limit (reference default 41)
 constexpr int RANK_BLOCK_WORDS = 16;                          // 512 bp per rank entry
 constexpr int RANK_PER_CHUNK = CHUNK_WORDS / RANK_BLOCK_WORDS;
@@ -139,6 +140,8 @@ struct nm_ctx {
         size_t bytes = 0;
         hipEvent_t busy = nullptr;
         bool pending = false;
+        const void *last_out = nullptr;        // count table the last scoring launch of this pair wrote, and its stream
+        hipStream_t last_stream = nullptr;
     } stage[NM_STAGE_RING];
     int stage_next = 0;                            // shallow users alternate between pairs 0 and 1
     int stage_next_deep = 0;                       // scoring walks the whole ring

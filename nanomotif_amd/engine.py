@@ -655,6 +655,13 @@ class ScanEngine:
     def comm_sync(self):
         _lib.check(self.lib.nm_comm_sync(self.ctx))
 
+    def comm_info(self) -> dict:
+        """What the RCCL communicator reports about itself (nm_comm_info): world, rank, device, RCCL version code;
+        world 0 = no communicator on this engine."""
+        info = (C.c_int32 * 4)()
+        _lib.check(self.lib.nm_comm_info(self.ctx, info))
+        return {"world": int(info[0]), "rank": int(info[1]), "device": int(info[2]), "rccl_version": int(info[3])}
+
     def allreduce_host(self, counts: np.ndarray) -> np.ndarray:
         """Sum an integer numpy array over all ranks (nm_allreduce_counts_host); returns the same dtype and shape."""
         a = np.ascontiguousarray(counts, dtype=np.int64).copy()

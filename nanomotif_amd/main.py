@@ -127,57 +127,85 @@ def find_motifs_bin(args):
         gather_world = 1
     if world > 1 and dist.get_backend() == "nccl" and os.environ.get("NANOMOTIF_ALLREDUCE", "native") == "native":
         # the per-round count tables travel through the C ABI's own RCCL communicator (nm_allreduce_counts_host);
-        # torch.distributed only carried the 128-byte id to the ranks
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
-        use_native_allreduce(eng)
-        log.info(f"rank {rank}: count tables all-reduced by nm_allreduce_counts (RCCL, {world} ranks)")
-    parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
-    mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
-    all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
-    eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
-    # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
-    # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
-    local_id = {c: i for i, c in enumerate(mine)}
-    lut = np.array([local_id.get(n, 0xFFFFFFFF) for n in table.contig_names], dtype=np.uint32)
-    cols = table.ingest_columns(lut)          # views in the engine's types; refuses > 8 mod codes / positions >= 4 Gbp
-    labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
-    t0 = time.perf_counter()
-    low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
-    # large pileups go to the device in parts of whole contigs (bounds the memory of the raw rows and filter scratch)
-    part_rows = int(os.environ.get("NANOMOTIF_INGEST_PART_ROWS", 250_000_000))
-    res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
-                            cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
-    store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
-    rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
-    if (low, high) == (0.3, 0.7):
-        for mt in pileup_mod.MOD_TYPES:
-            eng.alias_label((mt, "merge"), mt)
-    else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
-        eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
-                          cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
-                          low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows)
-    log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
-    del cols
-    table.close()
-    part = FilteredPileup(mine, *rows_part, res["kept"])
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, part)
-        filtered = FilteredPileup.merge(gathered)
-    else:
-        filtered = part
-    if filtered.kept.sum() == 0:
-        log.info("No pileup data after filtering, skipping")
+        # torch.distributed only carried the 128-byte id to the ranks.  Every rank must end up on the SAME path: a rank
+        # whose bring-up fails (librccl not loadable, ncclCommInitRank error) reports it, all ranks agree with a MIN
+        # all-reduce, and the run falls back to torch.distributed as a whole instead of leaving the others blocked
+        import torch
+
+        def agreed(ok_here: int) -> bool:
+            flag = torch.tensor([ok_here], dtype=torch.int32, device=torch.device("cuda", device))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag[0]) == 1
+
+        ok = 1
+        uid = [None]
+        try:
+            probe = eng.comm_unique_id()            # EVERY rank: proves that librccl loads here before anybody waits in CommInitRank
+            uid = [probe if rank == 0 else None]
+        except NmScanError as e:
+            ok = 0
+            log.warning(f"rank {rank}: nm_comm_unique_id failed ({e})")
+        if agreed(ok):
+            dist.broadcast_object_list(uid, src=0)
+            try:
+                eng.comm_init(rank, world, uid[0])
+            except NmScanError as e:
+                ok = 0
+                log.warning(f"rank {rank}: nm_comm_init failed ({e})")
+        else:
+            ok = 0
+        if agreed(ok):
+            use_native_allreduce(eng)
+            log.info(f"rank {rank}: count tables all-reduced by nm_allreduce_counts (RCCL, {eng.comm_info()['world']} ranks)")
+        else:
+            log.warning(f"rank {rank}: the C ABI's communicator is not up on every rank: count tables go through torch.distributed")
+    try:
+        parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
+        mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
+        all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
+        eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+        # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
+        # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
+        local_id = {c: i for i, c in enumerate(mine)}
+        lut = np.array([local_id.get(n, 0xFFFFFFFF) for n in table.contig_names], dtype=np.uint32)
+        cols = table.ingest_columns(lut)          # views in the engine's types; refuses > 8 mod codes / positions >= 4 Gbp
+        labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
+        t0 = time.perf_counter()
+        low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
+        # large pileups go to the device in parts of whole contigs (bounds the memory of the raw rows and filter scratch)
+        part_rows = int(os.environ.get("NANOMOTIF_INGEST_PART_ROWS", 250_000_000))
+        res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
+                                cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
+        store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
+        rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
+        if (low, high) == (0.3, 0.7):
+            for mt in pileup_mod.MOD_TYPES:
+                eng.alias_label((mt, "merge"), mt)
+        else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
+            eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
+                              cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
+                              low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows)
+        log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
+        del cols
+        table.close()
+        part = FilteredPileup(mine, *rows_part, res["kept"])
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, part)
+            filtered = FilteredPileup.merge(gathered)
+        else:
+            filtered = part
+        if filtered.kept.sum() == 0:
+            log.info("No pileup data after filtering, skipping")
+            return _gather_rows(args, [], rank, gather_world, bin_order) if gather_world > 1 else None
+        scorer = engine_scorer(eng, low, high, use_dist=world > 1)
+        rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
+                                window_store=store, extractor=extractor)
+        return _gather_rows(args, rows, rank, gather_world, bin_order)
+    finally:
+        # also on the early returns and on exceptions: the module-global reducer must not outlive its engine
+        use_native_allreduce(None)
         eng.close()
-        return _gather_rows(args, [], rank, gather_world, bin_order) if gather_world > 1 else None
-    scorer = engine_scorer(eng, low, high, use_dist=world > 1)
-    rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
-                            window_store=store, extractor=extractor)
-    use_native_allreduce(None)
-    eng.close()
-    return _gather_rows(args, rows, rank, gather_world, bin_order)
 
 
 def _gather_rows(args, rows, rank, gather_world, bin_order):

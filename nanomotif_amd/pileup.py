@@ -35,8 +35,9 @@ class PileupTable:
 def load_pileup(path: str, threads: int = 0) -> PileupTable:
     """modkit bedMethyl, 18 tab-separated columns, no header; used: 1 contig, 2 start, 4 mod code, 6 strand,
     10 Nvalid_cov, 11 percent modified; nulls 'NA' / 'null' (dataload.py:72-100).  Parsed natively
-    (libnmscan: nm_bed_open — plain text, gzip or bgzip, multi-threaded); rows whose coverage or percentage is null
-    can never pass ``Nvalid_cov > 5`` in the reference either and are dropped here."""
+    (libnmscan: nm_bed_open — plain text, gzip or bgzip, multi-threaded); rows whose coverage is null can never pass
+    ``Nvalid_cov > 5`` in the reference either and are dropped here; a null percentage becomes NaN (the row still counts
+    as a position of its group in the frequency filter, dataload.py:216, and leaves at the adjacency filter)."""
     import ctypes as C
     from . import _lib
     lib = _lib.load()
@@ -60,7 +61,8 @@ def load_pileup(path: str, threads: int = 0) -> PileupTable:
                         col(3, C.c_uint8, np.uint8), col(4, C.c_double, np.float64), col(5, C.c_int64, np.int64))
     finally:
         lib.nm_bed_close(h)
-    ok = (t.nvalid_cov >= 0) & (t.fraction_mod >= 0)
+    t.fraction_mod[t.fraction_mod < 0] = np.nan
+    ok = t.nvalid_cov >= 0
     return t if ok.all() else t.take(ok)
 
 
@@ -82,13 +84,23 @@ class NativePileup:
             names = [c.encode() for c in contigs]
             off = np.zeros(len(names) + 1, dtype=np.uint32)
             np.cumsum([len(x) for x in names], out=off[1:])
-            stats = (C.c_uint64 * 2)()
+            stats = (C.c_uint64 * 4)()
             rc = self._lib.nm_bed_open_indexed(os.fsencode(path), os.fsencode(index_path), len(names), b"".join(names),
                                                off.ctypes.data_as(C.POINTER(C.c_uint32)), int(threads), C.byref(self._h), stats)
+            self.index_problem, self.contigs_not_indexed = None, 0
             if rc == 0:
                 self.indexed, self.bytes_inflated, self.bytes_file = True, int(stats[0]), int(stats[1])
-            elif b"not a tabix index" not in self._lib.nm_last_error():
-                self._check(rc)
+                self.contigs_not_indexed = int(stats[2])
+                if self.contigs_not_indexed:
+                    import logging
+                    logging.warning(f"{self.contigs_not_indexed} of {len(names)} wanted contigs have no entry in {index_path} (no rows read for them)")
+            else:
+                # not a tabix index, or one that does not fit this file (stale: regions off the BGZF blocks, rows of other
+                # contigs): the whole file is read instead — slower, never a wrong subset of rows
+                import logging
+                self.index_problem = self._lib.nm_last_error().decode()
+                self._h = C.c_void_p()
+                logging.warning(f"tabix index not used ({self.index_problem}): reading the whole pileup")
         if not self.indexed:
             self._check(self._lib.nm_bed_open(os.fsencode(path), int(threads), C.byref(self._h)))
         n, nc = C.c_uint64(0), C.c_uint32(0)
@@ -139,7 +151,7 @@ def filter_pileup_minimummod_frequency(t: PileupTable, methylation_threshold=0.7
     """dataload.py:202-226: keep (contig, mod_type) groups with #(frac > thr) / #rows > 1e-4 and #(frac > thr) > 50."""
     if len(t) == 0:
         return t
-    key = t.contig.astype(np.int64) * 8 + (t.mod_type.astype(np.int64) + 1)
+    key = t.contig.astype(np.int64) * 130 + (t.mod_type.astype(np.int64) + 1)
     n = np.bincount(key)
     n_mod = np.bincount(key, weights=(t.fraction_mod > methylation_threshold)).astype(np.int64)
     ok = np.zeros(len(n), dtype=bool)
@@ -164,9 +176,11 @@ def filter_pileup_adjacency_filter(t: PileupTable, methylation_threshold=0.7, ad
         frac = t.fraction_mod[idx]
         p0 = int(pos[0])
         dense = np.full(int(pos[-1]) - p0 + 1, -np.inf)
-        np.maximum.at(dense, pos - p0, frac)
+        real = ~np.isnan(frac)                               # null percentages: skipped by the maximum, never kept
+        np.maximum.at(dense, pos[real] - p0, frac[real])
         wmax = maximum_filter1d(dense, size=2 * adjacency_distance + 1, mode="constant", cval=-np.inf)[pos - p0]
-        keep[idx] = (frac == wmax) | (frac < methylation_threshold)
+        with np.errstate(invalid="ignore"):
+            keep[idx] = (frac == wmax) | (frac < methylation_threshold)
     return t.take(keep)
 
 

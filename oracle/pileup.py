@@ -4,7 +4,8 @@ restated from source, pinned by the adjacency known-answer cases of tests/test_d
 
 A pileup table is a dict of equal-length numpy columns:
 ``contig`` (any hashable dtype), ``position`` int64, ``strand`` (uint8 ASCII or str), ``mod_type``,
-``fraction_mod`` float64, ``Nvalid_cov`` int.
+``fraction_mod`` float64 (NaN = null percentage: polars keeps such a row in ``pl.count()``, every comparison with it
+is null = not kept), ``Nvalid_cov`` int.
 """
 from __future__ import annotations
 
@@ -51,8 +52,10 @@ def filter_pileup_adjacency_filter(t, methylation_threshold=0.7, adjacency_dista
         frac = t["fraction_mod"][idx]
         lo = np.searchsorted(pos, pos - d, side="left")
         hi = np.searchsorted(pos, pos + d, side="right")
-        wmax = np.array([frac[a:b].max() for a, b in zip(lo, hi)]) if len(idx) else frac
-        keep = (frac == wmax) | (frac < methylation_threshold)
+        # list.max() skips nulls (NaN here); a null row itself satisfies neither comparison
+        with np.errstate(invalid="ignore"):
+            wmax = np.array([np.fmax.reduce(frac[a:b]) for a, b in zip(lo, hi)]) if len(idx) else frac
+            keep = (frac == wmax) | (frac < methylation_threshold)
         keep_idx.append(idx[keep])
     keep_idx = np.concatenate(keep_idx) if keep_idx else np.zeros(0, dtype=np.int64)
     return _take(t, keep_idx)

@@ -57,17 +57,18 @@ def test_reader_edge_cases(tmp_path):
     lines = [
         "c 1\t10\t11\ta\t12\t+\t10\t11\t255,0,0\t12\t70.00\t8\t4\t0\t0\t0\t0\t0",      # name with a space
         "c 1\t11\t12\tm\t3\t-\t11\t12\t255,0,0\tNA\t50.5\t1\t2\t0\t0\t0\t0\t0",        # null coverage -> dropped
-        "c2\t0\t1\t21839\t9\t+\t0\t1\t255,0,0\t9\tnull\t0\t9\t0\t0\t0\t0\t0",           # null percent -> dropped
+        "c2\t0\t1\t21839\t9\t+\t0\t1\t255,0,0\t9\tnull\t0\t9\t0\t0\t0\t0\t0",           # null percent -> kept as NaN (pl.count() counts the row)
         "c2\t5\t6\th\t9\t-\t5\t6\t255,0,0\t9\t33.333333333333336\t3\t6\t0\t0\t0\t0\t0",  # unknown mod code, long float
         "c2\t7\t8\ta\t100\t+\t7\t8\t255,0,0\t100\t1e2\t100\t0\t0\t0\t0\t0\t0",          # exponent form -> strtod path
     ]
     path = str(tmp_path / "e.bed")
     open(path, "w").write("\r\n".join(lines) + "\r\n")
     t = pp.load_pileup(path)
-    assert t.contig_names == ["c 1", "c2"] and len(t) == 3
-    assert t.position.tolist() == [10, 5, 7] and t.mod_type.tolist() == [1, 3, 1]
-    assert t.fraction_mod.tolist() == [70.00 / 100, 33.333333333333336 / 100, 1.0]
-    assert t.strand.tolist() == [ord("+"), ord("-"), ord("+")]
+    assert t.contig_names == ["c 1", "c2"] and len(t) == 4
+    assert t.position.tolist() == [10, 0, 5, 7] and t.mod_type.tolist() == [1, 2, 3, 1]
+    assert np.isnan(t.fraction_mod[1]) and t.nvalid_cov[1] == 9
+    assert t.fraction_mod[[0, 2, 3]].tolist() == [70.00 / 100, 33.333333333333336 / 100, 1.0]
+    assert t.strand.tolist() == [ord("+"), ord("+"), ord("-"), ord("+")]
     from nanomotif_amd._lib import NmScanError
     open(path, "w").write("c\t1\t2\ta\n")
     with pytest.raises(NmScanError):
@@ -85,19 +86,21 @@ def test_native_ingest_columns_match_the_table(tmp_path):
     mg = synth.make_metagenome(synth.SynthSpec(n_contigs=4, total_bp=60_000, n_bins=2, mod_types=("a", "m"), seed=5))
     path = str(tmp_path / "p.bed")
     mg.write_bed(path)
-    with open(path, "a") as f:          # a null percentage and a null coverage: both rows must fall to the coverage filter
+    with open(path, "a") as f:          # a null coverage falls to the coverage filter; a null percentage stays a position (fraction -1 / NaN)
         f.write("contig_0000\t7\t8\ta\t9\t+\t7\t8\t255,0,0\t9\tNA\t0\t9\t0\t0\t0\t0\t0\n")
         f.write("contig_0001\t9\t10\tm\tnull\t-\t9\t10\t255,0,0\tnull\t1.00\t0\t0\t0\t0\t0\t0\t0\n")
-    t = pileup.load_pileup(path)                       # drops the two null rows
+    t = pileup.load_pileup(path)                       # drops the null-coverage row
     nat = pileup.NativePileup(path)
-    assert len(nat) == len(t) + 2 and nat.contig_names[:len(t.contig_names)] == t.contig_names
+    assert len(nat) == len(t) + 1 and nat.contig_names[:len(t.contig_names)] == t.contig_names
     lut = np.arange(len(nat.contig_names), dtype=np.uint32)[::-1].copy()
     lut[0] = 0xFFFFFFFF
     cols = nat.ingest_columns(lut)
     assert [cols[k].dtype for k in ("contig", "position", "mod_type", "strand", "fraction_mod", "nvalid_cov")] == \
         [np.uint32, np.uint32, np.int8, np.uint8, np.float64, np.int32]
     live = cols["nvalid_cov"] >= 0
-    assert int((~live).sum()) == 2
+    assert int((~live).sum()) == 1 and int((cols["fraction_mod"] < 0).sum()) == 1
+    assert cols["nvalid_cov"][cols["fraction_mod"] < 0].tolist() == [9] and np.isnan(t.fraction_mod).sum() == 1
+    t.fraction_mod[np.isnan(t.fraction_mod)] = -1.0
     assert np.array_equal(cols["contig"][live], lut[t.contig])
     assert np.array_equal(cols["position"][live], t.position) and np.array_equal(cols["mod_type"][live], t.mod_type)
     assert np.array_equal(cols["strand"][live], t.strand) and np.array_equal(cols["fraction_mod"][live], t.fraction_mod)
@@ -176,5 +179,20 @@ def test_tabix_indexed_read_equals_filtered_full_read(tmp_path):
     # something that is not an index: the caller reads the whole file
     open(gz + ".bad.tbi", "wb").close()
     p2 = pp.NativePileup(gz, contigs=[mg.names[0]], index_path=gz + ".bad.tbi")
-    assert not p2.indexed and len(p2) == len(cols_full["position"])
+    assert not p2.indexed and len(p2) == len(cols_full["position"]) and "not a tabix index" in p2.index_problem
     p2.close()
+    # a STALE index (the pileup was rewritten with its contigs in another order, the .tbi kept): the regions it names hold
+    # other contigs' rows or start off the BGZF blocks — the whole file is read, never a wrong subset
+    lines = raw.decode().splitlines(True)
+    by_contig = {}
+    for ln in lines:
+        by_contig.setdefault(ln.split("\t", 1)[0], []).append(ln)
+    shuffled = "".join("".join(by_contig[n]) for n in reversed(list(by_contig))).encode()
+    gz2 = str(tmp_path / "q.bed.gz")
+    write_bgzf_tabix(shuffled, gz2, block_size=40_000)
+    import shutil
+    shutil.copy(gz + ".tbi", gz2 + ".tbi")
+    p3 = pp.NativePileup(gz2, contigs=[mg.names[3]], index_path=gz2 + ".tbi")
+    assert not p3.indexed and p3.index_problem and len(p3) == len(cols_full["position"])
+    assert sorted(p3.contig_names) == sorted(names_full)
+    p3.close()

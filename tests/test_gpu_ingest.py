@@ -203,3 +203,61 @@ def test_5mc_and_4mc_rows_share_positions_and_the_adjacency_filter():
             assert np.array_equal(got, expc), (mt, b)
             assert got[0].sum() > 0
     eng.close()
+
+
+def test_many_mod_codes_and_null_percentages_follow_the_reference_filters():
+    """More than eight distinct mod codes (the reference builds no task for unknown codes, find_motifs_bin.py:152-153, but
+    their rows form frequency-filter groups of their own and take part in the adjacency maximum, dataload.py:211-245), and
+    rows with enough coverage but a NULL percentage (counted by pl.count() in n_positions, dataload.py:216, dropped by
+    the adjacency filter): device filters == oracle filters, scoring on the surviving rows == oracle scoring."""
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    from oracle.scan import ContigPileup, score_candidates
+    spec = synth.SynthSpec(n_contigs=4, total_bp=400_000, n_bins=2, mod_types=("a", "m"), seed=85, min_contig_bp=40_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    rng = np.random.default_rng(12)
+    t = _raw_table(mg, rng)
+    n = len(t["position"])
+    # 17 extra codes (ids 3..19) on 6 % of the rows, some strongly "methylated" so that they win adjacency windows
+    idx = rng.choice(n, size=n * 6 // 100, replace=False)
+    t["mod_type"][idx] = rng.integers(3, 20, size=len(idx)).astype(np.int8)
+    hot = idx[: len(idx) // 3]
+    t["fraction_mod"][hot] = rng.choice([0.97, 0.99, 1.0], size=len(hot))
+    # null percentages on 2.5 % of the rows: counted as positions of their group, never kept, never winning a window
+    nul = rng.choice(n, size=n // 40, replace=False)
+    frac = t["fraction_mod"].copy()
+    frac[nul] = np.nan
+    t["fraction_mod"] = frac
+    exp = op.prefilter({k: v.copy() for k, v in t.items()})
+    assert not np.isnan(exp["fraction_mod"]).any()
+    eng = ScanEngine(0)
+    eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(4)], mg.bin_names)
+    dev_frac = np.where(np.isnan(frac), -1.0, frac)                 # the C ABI's null marker
+    res = eng.ingest_pileup(t["contig"].astype(np.uint32), t["position"], t["mod_type"], t["strand"], dev_frac, t["Nvalid_cov"],
+                            {0: ("m", "C"), 1: ("a", "A")})
+    assert res["n_kept"] == len(exp["position"])
+    kept = np.zeros((4, 8), dtype=np.int64)
+    low = exp["mod_type"] < 8
+    np.add.at(kept, (exp["contig"][low], exp["mod_type"][low]), 1)
+    assert np.array_equal(res["kept"].astype(np.int64), kept)
+    assert (exp["mod_type"] >= 8).sum() > 0                        # codes beyond the ABI's eight survived the filters too
+    motifs = [("GATC", 1), ("A", 0), ("CC[AT]GG", 1), ("C", 0)]
+    for code, mt in ((0, "m"), (1, "a")):
+        for b in sorted(set(mg.bin_names)):
+            ids = [i for i, x in enumerate(mg.bin_names) if x == b]
+            pile = {}
+            for i in ids:
+                s = (exp["contig"] == i) & (exp["mod_type"] == code)
+                pile[mg.names[i]] = ContigPileup(exp["position"][s], exp["strand"][s], exp["fraction_mod"][s])
+            these = [(s, p) for s, p in motifs if Motif(s, p).split()[p] == ("A" if mt == "a" else "C")]
+            got = eng.score([(Motif(s, p), mt, b) for s, p in these])
+            assert np.array_equal(got, score_candidates(pile, {mg.names[i]: mg.contig_str(i) for i in ids}, these)), (mt, b)
+    # the ratio test of the frequency filter sees the nulls as positions (oracle only: the device thresholds are fixed)
+    small = dict(contig=np.zeros(100, np.int64), position=np.arange(100, dtype=np.int64), strand=np.full(100, ord("+"), np.uint8),
+                 mod_type=np.ones(100, np.int8), fraction_mod=np.r_[np.full(60, 0.9), np.full(40, np.nan)], Nvalid_cov=np.full(100, 9))
+    f = op.filter_pileup_minimummod_frequency(small, min_mod_frequency=0.6)
+    assert len(f["position"]) == 0                                  # 60 / 100 is not > 0.6: the 40 nulls count as positions
+    f = op.filter_pileup_minimummod_frequency({k: v[:60] for k, v in small.items()}, min_mod_frequency=0.6)
+    assert len(f["position"]) == 60
+    eng.close()

@@ -109,3 +109,28 @@ def test_lanes_argument_is_checked():
     eng.set_score_lanes(1)
     eng.sync()
     eng.close()
+
+
+def test_two_lanes_order_launches_that_share_one_count_table():
+    """Launches that write the SAME d_out are ordered by the library whatever lane they land on (a synchronous call in
+    between flips the lane parity): the table always holds the counts of the LAST batch submitted to it."""
+    import torch
+    mg, eng = _engine(seed=13)
+    batches = _batches(mg, 6)
+    n = max(len(b) for b in batches)
+    padded = [b + [b[0]] * (n - len(b)) for b in batches]            # equal length: one table serves every batch
+    want = [eng.score(b) for b in padded]
+    made = [eng.make_batch(b) for b in padded]
+    table = torch.zeros((n, 2), dtype=torch.int64, device="cuda:0")
+    eng.set_score_lanes(2)
+    for rep in range(5):
+        for k, b in enumerate(made):
+            eng.score_into_device(b, table.data_ptr())
+            if (rep, k) in ((1, 2), (3, 0)):
+                eng.sync()
+                assert np.array_equal(table.cpu().numpy(), want[k]), (rep, k)
+                assert np.array_equal(eng.score(padded[1]), want[1])        # host-output call: advances the ring by one
+    eng.sync()
+    assert np.array_equal(table.cpu().numpy(), want[len(made) - 1])
+    eng.set_score_lanes(1)
+    eng.close()

@@ -216,3 +216,97 @@ def test_fused_slots_with_uneven_groups(engine_cls):
     assert st["last_workgroups"] < 2 * 16 * len(bins) * 2      # fused launch: one workgroup column, not one per slot
     assert np.array_equal(out, np.concatenate(expect))
     eng.close()
+
+
+def test_failed_pileup_upload_leaves_no_half_written_slot():
+    """A row error (duplicate position, bad strand, position outside the contig) is reported AND the slot goes back to
+    'no pileup': scoring against it is refused with NM_ESTATE instead of counting half-written planes."""
+    from nanomotif_amd._lib import NmScanError
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.motif import Motif
+    eng = ScanEngine(0)
+    eng.upload_assembly(["c0"], ["ACGATCGATCGGATCCA" * 40], ["b"])
+    pos = np.array([3, 7, 12], np.uint32)
+    ok = dict(contig_id=np.zeros(3, np.uint32), position=pos, strand=np.frombuffer(b"+++", np.uint8), fraction_mod=np.array([0.9, 0.1, 0.8]))
+    eng.upload_pileup("a", **ok)
+    good = eng.score([(Motif("GATC", 1), "a", "b")])
+    for bad in (dict(ok, position=np.array([3, 3, 12], np.uint32)),                 # duplicate (contig, position, strand)
+                dict(ok, strand=np.frombuffer(b"+x+", np.uint8)),                    # strand label
+                dict(ok, position=np.array([3, 7, 100000], np.uint32))):             # outside the contig
+        for append in (False, True):
+            eng.upload_pileup("a", **ok)
+            with pytest.raises(NmScanError):
+                eng.upload_pileup("a", append=append, **bad)
+            with pytest.raises(NmScanError, match="no pileup uploaded"):
+                eng.score([(Motif("GATC", 1), "a", "b")])
+    eng.upload_pileup("a", **ok)
+    assert np.array_equal(eng.score([(Motif("GATC", 1), "a", "b")]), good)
+    eng.close()
+
+
+_ALLOC = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+from nanomotif_amd import _lib
+from nanomotif_amd.engine import ScanEngine
+eng = ScanEngine(0)
+try:
+    _lib.use_torch_allocator(True)
+    print("SWITCHED-UNDER-LIVE-CTX")
+except _lib.NmScanError as e:
+    assert "nm_ctx alive" in str(e), e
+eng.close()
+_lib.use_torch_allocator(True)          # allowed again once the last ctx is gone
+eng = ScanEngine(0)
+eng.upload_assembly(["c0"], ["ACGT" * 100], ["b"])
+try:
+    _lib.use_torch_allocator(False)
+    print("SWITCHED-UNDER-LIVE-CTX")
+except _lib.NmScanError as e:
+    assert "nm_ctx alive" in str(e), e
+eng.close()
+_lib.use_torch_allocator(False)
+print("ALLOC-OK")
+"""
+
+
+def test_allocator_cannot_change_under_a_live_context(tmp_path):
+    """nm_set_device_allocator is refused (NM_ESTATE) while any nm_ctx is alive: a block must go back to the allocator
+    it came from.  Own process: the allocator pair is process-global."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "alloc.py"
+    script.write_text(_ALLOC)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ALLOC-OK" in r.stdout and "SWITCHED" not in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_hit_positions_compaction_on_a_long_contig():
+    """nm_hit_positions compacts on the device (popcount prefix + scatter): capacity smaller than the number of hits
+    returns the first `capacity` positions and the full count; positions are ascending and equal to the oracle's."""
+    import regex
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.motif import Motif
+    rng = np.random.default_rng(5)
+    seq = "".join(np.array(list("ACGT"))[rng.integers(0, 4, 700_000)])
+    eng = ScanEngine(0)
+    eng.upload_assembly(["c0"], [seq], ["b"])
+    a_pos = np.array([m.start() for m in regex.finditer("A", seq)], np.uint32)
+    frac = np.where(rng.random(len(a_pos)) < 0.5, 0.95, 0.05)
+    eng.upload_pileup("a", np.zeros(len(a_pos), np.uint32), a_pos, np.full(len(a_pos), ord("+"), np.uint8), frac)
+    starts = np.array([m.start() for m in regex.finditer("GA", seq, overlapped=True)], np.int64) + 1
+    meth = set(a_pos[frac > 0.7].tolist())
+    want = np.array([p for p in starts if p in meth], np.int64)
+    got = eng.hit_positions("c0", "a", Motif("GA", 1), 0)             # engine grows the capacity from 65 536
+    assert len(want) > 20_000 and np.array_equal(got, want)
+    import ctypes as C
+    b = eng.make_batch([(Motif("GA", 1), "a", 0)])
+    n = C.c_uint64(0)
+    out = np.full(100, -1, np.int64)
+    from nanomotif_amd import _lib
+    _lib.check(eng.lib.nm_hit_positions(eng.ctx, 0, eng.slot_of_mod["a"], int(b.lens[0]), int(b.modpos[0]), b.masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                        0, out.ctypes.data_as(C.POINTER(C.c_int64)), 100, C.byref(n)))
+    assert n.value == len(want) and np.array_equal(out, want[:100])
+    eng.close()
