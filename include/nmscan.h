@@ -265,6 +265,34 @@ int nm_score_batch_per_contig(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand
 /* resident contigs of a bin (nm_upload_contigs indices) in the order of the per-contig rows */
 int nm_bin_contigs(nm_ctx *ctx, uint32_t bin, uint32_t *contig_ids, uint32_t capacity, uint32_t *n_contigs);
 
+/* ---- per-contig READ methylation of motifs: the table binnary starts from -------------------------
+ * Reference: nanomotif/main.py:142-193 — `contig_methylation = methylation_pattern(pileup, assembly, motifs,
+ * min_valid_read_coverage, min_valid_cov_to_diff_fraction = 0.8, output_type = Median | WeightedMean)` from the
+ * third-party crate epimetheus-py 0.7.5 (setup.py:38; source not in the reference tree: its published behaviour is
+ * restated in oracle/contig_methylation.py, parity UNPINNED), then main.py:193 keeps rows with
+ * n_motif_obs * mean_read_cov >= --methylation_threshold.
+ *
+ * nm_readstats_upload: the pileup records of ONE mod code (bedMethyl columns 1 contig, 2 start, 6 strand, 10 N_valid_cov,
+ *   12 N_mod, 17 N_diff; nm_bed_open_counts reads them) -> read-statistics slot `slot`.  Records with
+ *   n_valid_cov < min_valid_read_coverage or n_valid_cov / (n_valid_cov + n_diff) < min_valid_cov_to_diff_fraction are
+ *   dropped (n_diff NULL: no second filter).  contig_id 0xFFFFFFFF = contig not held by this ctx (ignored).  One call per
+ *   slot replaces its contents; *n_kept (may be NULL) = records kept.  Independent of nm_upload_pileup / nm_ingest_pileup.
+ * nm_contig_methylation: motif m (stripped, masks as for nm_score_batch; motif_slot[m] = read-statistics slot of its mod
+ *   code) against EVERY resident contig i, both strands (forward motif on '+' records, reverse complement on '-'
+ *   records, like motif_model_contig): out[m * n_contigs + i] =
+ *     n_obs          motif sites that carry a kept record (the row exists in the reference's table iff n_obs > 0),
+ *     mean_cov       mean n_valid_cov over those sites,
+ *     median         median of the per-site read fractions n_modified / n_valid_cov (mean of the two middle ones for an
+ *                    even count) — MethylationOutput.Median,
+ *     weighted_mean  sum(n_modified) / sum(n_valid_cov) — MethylationOutput.WeightedMean.
+ *   Host arrays of n_motifs * n_contigs entries each. */
+int nm_readstats_upload(nm_ctx *ctx, uint32_t slot, uint64_t n_rows, const uint32_t *contig_id, const uint32_t *position,
+                        const uint8_t *strand, const int32_t *n_valid_cov, const int32_t *n_modified, const int32_t *n_diff,
+                        int32_t min_valid_read_coverage, double min_valid_cov_to_diff_fraction, int rows_on_device, uint64_t *n_kept);
+int nm_contig_methylation(nm_ctx *ctx, uint32_t n_motifs, const uint8_t *motif_slot, const uint8_t *motif_len, const uint8_t *motif_modpos,
+                          const uint32_t *motif_mask_offset, const uint8_t *motif_masks, uint32_t *out_n_obs, double *out_mean_cov,
+                          double *out_median, double *out_weighted_mean);
+
 /* ---- the greedy candidate search of all (bin, mod type) tasks, in lock-step ---------------------------------------
  * find_best_candidates (find_motifs_bin.py:688-839) with MotifSearcher.run (:1026-1182), the KL child generation
  * (:957-1023), get_parent_scores pruning (:1382-1433), the dead-end / remaining-windows stops and the missed-candidate
@@ -363,6 +391,10 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
  */
 typedef struct nm_bed nm_bed;
 int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
+/* The same, also keeping N_mod (col 12) and N_diff (col 17) as int32 columns (nm_bed_count_columns): the inputs of the
+ * read-methylation table (nm_readstats_upload).  Lines with fewer than 17 columns are an error in this mode. */
+int nm_bed_open_counts(const char *path, uint32_t threads, nm_bed **out);
+int nm_bed_count_columns(nm_bed *bed, const int32_t **n_modified, const int32_t **n_diff);
 /* The tabix path of the reference (dataload.py:102-152, find_motifs_bin.py:233-246: the records of a bin's contigs are
  * fetched through the .tbi index): only the BGZF blocks holding the n_contigs wanted contigs (names back to back,
  * name_offset[n_contigs + 1]) are inflated and parsed; contigs absent from the index are skipped and counted.  stats

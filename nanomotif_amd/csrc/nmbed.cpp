@@ -54,6 +54,8 @@ struct Columns {
     Vec<int8_t> mod_type;
     Vec<uint8_t> strand;
     Vec<double> fraction;
+    Vec<int32_t> n_mod, n_diff;                   // columns 12 / 17, only when the reader was opened with NM_BED_COUNTS
+    bool want_counts = false;
     std::vector<std::string> names;               // local id -> name
     std::vector<std::string> other_mods;          // local mod id 3 + k -> code (anything but m, a, 21839)
     std::string error;
@@ -127,11 +129,12 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
         if (le > p && le[-1] == '\r') --le;
         ++line_no;
         if (le > p) {
-            const char *f[12];
-            const char *fe[12];
+            const char *f[18];
+            const char *fe[18];
             int nf = 0;
             const char *q = p;
-            while (nf < 11) {
+            const int need = c->want_counts ? 17 : 11;
+            while (nf < need) {
                 const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
                 f[nf] = q;
                 fe[nf] = t ? t : le;
@@ -140,6 +143,7 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
                 q = t + 1;
             }
             if (nf < 11) { c->error = "pileup line with fewer than 11 tab-separated columns"; return; }
+            if (nf < need) { c->error = "pileup line with fewer than 17 tab-separated columns (N_mod / N_diff are columns 12 / 17)"; return; }
             // contig
             const size_t nl = (size_t)(fe[0] - f[0]);
             if (!have_last || nl != last_name.size() || memcmp(last_name.data(), f[0], nl) != 0) {
@@ -177,6 +181,15 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
             c->strand.push_back(fe[5] > f[5] ? (uint8_t)f[5][0] : (uint8_t)'?');
             c->nvalid.push_back(cov);
             c->fraction.push_back(pct_null ? -1.0 : pct / 100.0);     // dataload.py:85
+            if (c->want_counts) {
+                int64_t nm = 0, nd = 0;
+                if (!parse_int(f[11], fe[11], &nm) || !parse_int(f[16], fe[16], &nd) || nm < 0 || nd < 0 || nm > 0x7FFFFFFF || nd > 0x7FFFFFFF) {
+                    c->error = "pileup column 12 (N_mod) or 17 (N_diff) is not a non-negative integer";
+                    return;
+                }
+                c->n_mod.push_back((int32_t)nm);
+                c->n_diff.push_back((int32_t)nd);
+            }
         }
         p = eol + 1;
     }
@@ -331,7 +344,7 @@ struct nm_bed {
 extern "C" {
 
 // bedMethyl text (whole file or the tabix-selected regions of it) -> columns
-static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **out) {
+static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **out, bool want_counts = false) {
     // slabs cut at line ends
     std::vector<size_t> cut(1, 0);
     for (unsigned t = 1; t < threads; ++t) {
@@ -343,6 +356,7 @@ static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **
     }
     cut.push_back(buf.size);
     std::vector<Columns> parts(cut.size() - 1);
+    for (auto &p : parts) p.want_counts = want_counts;
     std::vector<std::thread> pool;
     for (size_t i = 0; i + 1 < cut.size(); ++i)
         pool.emplace_back(parse_slab, buf.data + cut[i], buf.data + cut[i + 1], &parts[i]);
@@ -383,6 +397,8 @@ static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **
     }
     const size_t n = at.back();
     a.contig.resize(n); a.position.resize(n); a.nvalid.resize(n); a.mod_type.resize(n); a.strand.resize(n); a.fraction.resize(n);
+    a.want_counts = want_counts;
+    if (want_counts) { a.n_mod.resize(n); a.n_diff.resize(n); }
     {
         std::vector<std::thread> copiers;
         for (size_t k = 0; k < parts.size(); ++k)
@@ -396,6 +412,10 @@ static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **
                     memcpy(a.nvalid.data() + o, p.nvalid.data(), m * sizeof(int64_t));
                     memcpy(a.strand.data() + o, p.strand.data(), m);
                     memcpy(a.fraction.data() + o, p.fraction.data(), m * sizeof(double));
+                    if (a.want_counts) {
+                        memcpy(a.n_mod.data() + o, p.n_mod.data(), m * sizeof(int32_t));
+                        memcpy(a.n_diff.data() + o, p.n_diff.data(), m * sizeof(int32_t));
+                    }
                 }
                 Columns().contig.swap(p.contig);
                 Columns().position.swap(p.position);
@@ -409,14 +429,26 @@ static int parse_text(const char *path, Buffer &buf, uint32_t threads, nm_bed **
     return NM_OK;
 }
 
-int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) {
+static int bed_open_impl(const char *path, uint32_t threads, bool want_counts, nm_bed **out) {
     if (!path || !out) return nm_set_error(NM_EINVAL, "NULL argument");
     *out = nullptr;
     if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     Buffer buf;
     const int rc = load_file(path, threads, &buf, "pileup");
     if (rc) return rc;
-    return parse_text(path, buf, threads, out);
+    return parse_text(path, buf, threads, out, want_counts);
+}
+
+int nm_bed_open(const char *path, uint32_t threads, nm_bed **out) { return bed_open_impl(path, threads, false, out); }
+
+int nm_bed_open_counts(const char *path, uint32_t threads, nm_bed **out) { return bed_open_impl(path, threads, true, out); }
+
+int nm_bed_count_columns(nm_bed *b, const int32_t **n_modified, const int32_t **n_diff) {
+    if (!b || !n_modified || !n_diff) return nm_set_error(NM_EINVAL, "NULL argument");
+    if (!b->all.want_counts) return nm_set_error(NM_ESTATE, "the pileup was not opened with nm_bed_open_counts");
+    *n_modified = b->all.n_mod.data();
+    *n_diff = b->all.n_diff.data();
+    return NM_OK;
 }
 
 // Tabix-indexed read (dataload.py:102-152 / find_motifs_bin.py:233-246: the reference fetches the records of a bin's

@@ -80,6 +80,17 @@ struct ModSlot {
     uint32_t meth_pad = 0xFFFFFFFFu;
 };
 
+// Read statistics of one mod code for the per-contig read-methylation table (nmmeth.hip): presence planes of the records
+// that passed the read filters, rank tables over them, and the records' counts in plane order.
+struct ReadStats {
+    bool present = false;
+    uint32_t *planes = nullptr;                   // P+ | P-  (2 x plane words)
+    uint32_t *rank[2] = {nullptr, nullptr};       // per 512-bp block: records of the contig before the block
+    uint64_t *base[2] = {nullptr, nullptr};       // per contig: index of its first record in val[]
+    uint2 *val[2] = {nullptr, nullptr};           // (n_valid_cov, n_modified) per record, position order
+    uint64_t n_rows[2] = {0, 0};
+};
+
 }  // namespace nmdetail
 
 // Staging pairs (device + pinned host buffer) and parts of the program table.  Scoring walks all of them: the host side,
@@ -133,6 +144,8 @@ struct nm_ctx {
     uint4 *d_segments = nullptr;
     uint32_t n_segments = 0;
     nmdetail::ModSlot slots[NM_MAX_MOD_SLOTS];
+    nmdetail::ReadStats readstats[NM_MAX_MOD_SLOTS];   // nm_readstats_upload (per-contig read methylation, nmmeth.hip)
+    uint32_t *d_chunk_contig = nullptr;                // per chunk: its contig, ~0 for pad chunks (built on first use)
     // per-call staging: ring of two (device, pinned host) buffer pairs so that compiling the next batch on the
     // host overlaps the previous launch; `busy` marks the last device work that read the pair.
     struct Stage {
@@ -221,5 +234,6 @@ inline void drop_ingest_rows(nm_ctx *c) {
 int ensure_stage(nm_ctx *c, size_t bytes, bool deep = false);   // deep: walk all NM_STAGE_RING pairs (scoring), else pairs 0 / 1
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
+void free_readstats(nm_ctx *c);                          // nmmeth.hip: read statistics are tied to the resident assembly
 
 }  // namespace nmdetail

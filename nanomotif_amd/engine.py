@@ -541,9 +541,10 @@ class ScanEngine:
         self.slot_of_mod[label] = self.slot_of_mod[existing]
 
     # ------------------------------------------------------------------ scoring
-    def make_batch(self, candidates) -> CandidateBatch:
+    def make_batch(self, candidates, slot_of=None) -> CandidateBatch:
         """candidates: sequence of (Motif, mod_type, bin name or id).  Parsing / stripping is done natively
-        (nm_parse_motifs); Python only joins the strings."""
+        (nm_parse_motifs); Python only joins the strings.  ``slot_of``: mod type -> slot number, default the resident
+        classifications (``slot_of_mod``)."""
         n = len(candidates)
         strings = [c[0].string for c in candidates]
         text = "".join(strings).encode("ascii")
@@ -552,7 +553,7 @@ class ScanEngine:
         modpos_in = np.fromiter((c[0].mod_position for c in candidates), dtype=np.int32, count=n)
         bi, so = self.bin_index, self.slot_of_mod
         bins = np.fromiter((bi[c[2]] if isinstance(c[2], str) else c[2] for c in candidates), dtype=np.uint32, count=n)
-        slots = np.fromiter((so[c[1]] for c in candidates), dtype=np.uint8, count=n)
+        slots = np.fromiter(((so[c[1]] if slot_of is None else slot_of(c[1])) for c in candidates), dtype=np.uint8, count=n)
         lens = np.empty(n, dtype=np.uint8)
         modpos = np.empty(n, dtype=np.uint8)
         moff = np.empty(n, dtype=np.uint32)

@@ -31,7 +31,7 @@ def test_bench_json_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and d["data"] == "synthetic"
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert rf["bound"] in ("hbm", "mfma", "valu-int") and rf["unit"] == "GB/s" and abs(rf["hbm_frac"] - rf["frac"]) < 1e-12 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "traffic" in rf and rf["kernel_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]

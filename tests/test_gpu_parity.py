@@ -230,7 +230,7 @@ def test_failed_pileup_upload_leaves_no_half_written_slot():
     ok = dict(contig_id=np.zeros(3, np.uint32), position=pos, strand=np.frombuffer(b"+++", np.uint8), fraction_mod=np.array([0.9, 0.1, 0.8]))
     eng.upload_pileup("a", **ok)
     good = eng.score([(Motif("GATC", 1), "a", "b")])
-    for bad in (dict(ok, position=np.array([3, 3, 12], np.uint32)),                 # duplicate (contig, position, strand)
+    for bad in (dict(ok, position=np.array([3, 7, 3], np.uint32)),                  # duplicate (contig, position, strand) among the methylated rows
                 dict(ok, strand=np.frombuffer(b"+x+", np.uint8)),                    # strand label
                 dict(ok, position=np.array([3, 7, 100000], np.uint32))):             # outside the contig
         for append in (False, True):

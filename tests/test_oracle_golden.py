@@ -327,3 +327,23 @@ def _model(a, b):
     m = BetaBernoulliModel()
     m.update(a, b)
     return m
+
+
+def test_read_methylation_restatement_on_a_hand_worked_case():
+    """oracle/contig_methylation.read_methylation (epimetheus' methylation_pattern restated; parity unpinned — there is no
+    reference vector): a case small enough to work by hand.  GATC@1 on GATCAGATCTGATC: '+' sites 1, 6, 11 (the A), '-'
+    sites 2, 7, 12 (the T opposite the A of the reverse-complement GATC)."""
+    from oracle.contig_methylation import read_methylation
+    seq = "GATCAGATCTGATC"
+    rec = {("c", "a"): dict(position=np.array([1, 6, 11, 2, 7, 12, 4]), strand=np.frombuffer(b"+++---+", np.uint8).copy(),
+                            n_valid=np.array([10, 20, 2, 8, 10, 40, 50]), n_mod=np.array([9, 10, 2, 8, 1, 30, 50]),
+                            n_diff=np.array([0, 0, 0, 0, 3, 0, 0]))}
+    # kept: pos 1 (0.9, cov 10), 6 (0.5, cov 20), 2 (1.0, cov 8), 12 (0.75, cov 40); dropped: 11 (coverage 2 < 3), 7 (10 / 13 < 0.8);
+    # position 4 is no GATC site
+    rows = read_methylation(rec, {"c": seq}, [("GATC", "a", 1)], 3, 0.8, "median")
+    assert rows == [dict(contig="c", motif=0, n_motif_obs=4, mean_read_cov=(10 + 20 + 8 + 40) / 4, methylation_value=(0.75 + 0.9) / 2)]
+    rows = read_methylation(rec, {"c": seq}, [("GATC", "a", 1)], 3, 0.8, "weighted-mean")
+    assert rows[0]["methylation_value"] == (9 + 10 + 8 + 30) / (10 + 20 + 8 + 40)
+    assert read_methylation(rec, {"c": seq}, [("GATC", "m", 3)], 3, 0.8) == []        # no record of that mod code
+    rows = read_methylation(rec, {"c": seq}, [("GATC", "a", 1)], 3, 0.0, "median")    # odd count: the middle value
+    assert rows[0]["n_motif_obs"] == 5 and rows[0]["methylation_value"] == 0.75
