@@ -440,7 +440,7 @@ class ScanEngine:
                                              _ptr(fr, C.c_double), 1 if append else 0))
 
     def ingest_pileup(self, contig_local, position, mod_code, strand, fraction_mod, nvalid_cov, labels, low=0.3, high=0.7,
-                      want_rows=True, max_part_rows=None):
+                      want_rows=True, max_part_rows=None, extra_parts=()):
         """RAW pileup rows -> device-side pre-filters (dataload.py:191-247) -> state planes.
         contig_local: engine contig index per row, 0xFFFFFFFF for contigs this engine does not hold;
         mod_code: int8 ids as numbered by the reader (0 = m, 1 = a, 2 = 21839, 3.. = others, which only take part in
@@ -451,7 +451,9 @@ class ScanEngine:
         kept=uint32[n_contigs, 8] surviving rows per (contig, mod code)).
         ``max_part_rows``: ingest a pileup whose rows are grouped by contig (modkit output is) in parts of about that many
         rows, cut at contig boundaries (nm_ingest_pileup_part) — bounds the device memory of the raw rows and of the
-        dense adjacency arrays; the result is the same."""
+        dense adjacency arrays; the result is the same.  ``extra_parts``: further parts as dicts of the six columns
+        (contig, position, mod_type, strand, fraction_mod, nvalid_cov), each holding whole contigs that appear in no other
+        part (the rows of a contig that is a member of a second bin, under that placement's contig index)."""
         cid = np.ascontiguousarray(contig_local, dtype=np.uint32)
         pos = np.ascontiguousarray(position, dtype=np.uint32)
         mod = np.ascontiguousarray(mod_code, dtype=np.int8)
@@ -492,6 +494,16 @@ class ScanEngine:
             _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, b - a, sl(cid), sl(pos), sl(mod), sl(st), sl(fr), sl(nv), slot_of, canon,
                                                       float(low), float(high), 0, 1 if k == 0 else 0, len(ids), _ptr(ids, C.c_uint32),
                                                       C.byref(n_kept), C.byref(n_conf)))
+        for x in extra_parts:
+            xc = np.ascontiguousarray(x["contig"], dtype=np.uint32)
+            cols_x = [xc, np.ascontiguousarray(x["position"], dtype=np.uint32), np.ascontiguousarray(x["mod_type"], dtype=np.int8),
+                      np.ascontiguousarray(x["strand"], dtype=np.uint8), np.ascontiguousarray(x["fraction_mod"], dtype=np.float64),
+                      np.ascontiguousarray(x["nvalid_cov"], dtype=np.int32)]
+            ids = np.ascontiguousarray(np.unique(xc[xc != 0xFFFFFFFF]), dtype=np.uint32)
+            if len(xc) == 0:
+                continue
+            _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, len(xc), *[vp(a) for a in cols_x], slot_of, canon, float(low), float(high), 0,
+                                                      0, len(ids), _ptr(ids, C.c_uint32), C.byref(n_kept), C.byref(n_conf)))
         self._n_confident = int(n_conf.value)
         kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
         _lib.check(self.lib.nm_ingest_results(self.ctx, None, None, None, None, 0, _ptr(kept, C.c_uint32)))

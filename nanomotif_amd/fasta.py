@@ -89,14 +89,35 @@ def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
     return out
 
 
+ALIAS_SEP = "\x00"       # a contig listed under several bins: its further placements are named  contig + ALIAS_SEP + bin
+
+
+def original_name(name: str) -> str:
+    """The contig a (possibly aliased) placement stands for."""
+    return name.split(ALIAS_SEP, 1)[0]
+
+
 def _assign(table: dict, contig: str, bin_name: str):
-    """One bin per contig.  The reference keeps a DataFrame and would put a contig that is listed under two bins into both
-    (fasta.py:129-134); here the engine holds every contig once, so the LAST listing wins — loudly."""
+    """The reference keeps a (contig, bin) DataFrame: a contig listed under two bins is a member of BOTH — its pileup rows are
+    joined to each (find_motifs_bin.py:416-418) and each bin's assembly holds it (fasta.py:122-187).  The engine holds a
+    contig once per bin, so every further placement becomes a contig of its own, named  contig + ALIAS_SEP + bin  (it sorts
+    right after the contig's own name: the window-extraction order inside the other bin is that of the original name)."""
     old = table.get(contig)
-    if old is not None and old != bin_name:
-        log.warning(f"contig {contig} is listed under bins {old} and {bin_name}: it is kept in {bin_name} only "
-                    "(the MI355X engine holds one bin per contig)")
-    table[contig] = bin_name
+    if old is None:
+        table[contig] = bin_name
+        return
+    if old == bin_name or table.get(contig + ALIAS_SEP + bin_name) == bin_name:
+        log.warning(f"contig {contig} is listed under bin {bin_name} more than once: the repeated line is ignored")
+        return
+    log.warning(f"contig {contig} is listed under bins {old} and {bin_name}: it is scored in both, like in the reference")
+    table[contig + ALIAS_SEP + bin_name] = bin_name
+
+
+def add_alias_sequences(assembly: dict, bin_contig: dict):
+    """Every aliased placement gets its contig's sequence (the same array, no copy)."""
+    for name in bin_contig:
+        if ALIAS_SEP in name and original_name(name) in assembly:
+            assembly[name] = assembly[original_name(name)]
 
 
 def generate_contig_bin(args) -> dict:
@@ -138,5 +159,5 @@ def generate_contig_bin(args) -> dict:
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         for c, b in out.items():
-            f.write(f"{c}\t{b}\n")
+            f.write(f"{original_name(c)}\t{b}\n")
     return out

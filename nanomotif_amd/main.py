@@ -87,6 +87,7 @@ def find_motifs_bin(args):
         return None
     log.info("Loading assembly")
     assembly = fasta.load_fasta(args.assembly)
+    fasta.add_alias_sequences(assembly, bin_contig)          # a contig listed under several bins is a member of each
     log.info("Identifying motifs")
     cfg = ProcessorConfig(assembly=assembly, pileup_path=args.pileup, bin_contig=bin_contig, threads=args.threads,
                           search_frame_size=args.search_frame_size, methylation_threshold_low=args.methylation_threshold_low,
@@ -99,7 +100,7 @@ def find_motifs_bin(args):
     t0 = time.perf_counter()
     # native reader, raw rows kept in native memory; a bgzip pileup is read through its tabix index: only the blocks
     # of the contigs that are in a bin and in the assembly (find_motifs_bin.py:233-246 fetches per bin)
-    wanted = [c for c in cfg.bin_contig if c in assembly] if bgzip else None
+    wanted = list(dict.fromkeys(fasta.original_name(c) for c in cfg.bin_contig if c in assembly)) if bgzip else None
     table = pileup_mod.NativePileup(cfg.pileup_path, contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
     how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
     log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
@@ -168,14 +169,23 @@ def find_motifs_bin(args):
         # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
         local_id = {c: i for i, c in enumerate(mine)}
         lut = np.array([local_id.get(n, 0xFFFFFFFF) for n in table.contig_names], dtype=np.uint32)
-        cols = table.ingest_columns(lut)          # views in the engine's types; refuses > 8 mod codes / positions >= 4 Gbp
+        # further placements of a contig listed under several bins: the contig's rows once more per placement
+        file_id = {n: i for i, n in enumerate(table.contig_names)}
+        placements = [(file_id[fasta.original_name(c)], local_id[c]) for c in mine
+                      if fasta.ALIAS_SEP in c and fasta.original_name(c) in file_id]
+        file_contig = table.file_contig_column().copy() if placements else None
+        cols = table.ingest_columns(lut)          # views in the engine's types; refuses positions >= 4 Gbp
         labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
         t0 = time.perf_counter()
         low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
         # large pileups go to the device in parts of whole contigs (bounds the memory of the raw rows and filter scratch)
         part_rows = int(os.environ.get("NANOMOTIF_INGEST_PART_ROWS", 250_000_000))
+        extra = []
+        for fid, local in placements:
+            sel = np.flatnonzero(file_contig == fid)
+            extra.append(dict(contig=np.full(len(sel), local, np.uint32), **{k: cols[k][sel] for k in ("position", "mod_type", "strand", "fraction_mod", "nvalid_cov")}))
         res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
-                                cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows)
+                                cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
         store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
         rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
         if (low, high) == (0.3, 0.7):
@@ -184,7 +194,7 @@ def find_motifs_bin(args):
         else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
             eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
                               cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
-                              low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows)
+                              low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
         log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
         del cols
         table.close()

@@ -118,6 +118,13 @@ class NativePileup:
     def __len__(self):
         return self.n
 
+    def file_contig_column(self) -> np.ndarray:
+        """uint32 view: per row the index into ``contig_names`` (valid until ``close()``)."""
+        import ctypes as C
+        ptr = [C.c_void_p() for _ in range(6)]
+        self._check(self._lib.nm_bed_columns(self._h, *[C.byref(x) for x in ptr]))
+        return np.ctypeslib.as_array(C.cast(ptr[0], C.POINTER(C.c_uint32)), shape=(self.n,))
+
     def ingest_columns(self, lut: np.ndarray) -> dict:
         import ctypes as C
         lut = np.ascontiguousarray(lut, dtype=np.uint32)

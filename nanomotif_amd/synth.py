@@ -120,6 +120,7 @@ class SynthMetagenome:
     bin_gc: dict
     bin_motifs: dict                     # bin -> [(iupac, pos, modtype)]
     _seq_cache: dict = field(default_factory=dict)
+    key_index: dict = field(default_factory=dict)   # contig index -> index whose hash key it shares (a second placement of a contig)
 
     # ---------------------------------------------------------------- sequences
     def contig_codes(self, i: int) -> np.ndarray:
@@ -160,7 +161,7 @@ class SynthMetagenome:
         """
         codes = self.contig_codes(i)
         L = len(codes)
-        key = contig_key(self.spec.seed, i)
+        key = contig_key(self.spec.seed, self.key_index.get(i, i))
         can = "ACGT".index(MOD_CANONICAL[mod_type])
         comp = 3 - can
         stream_base = 16 * (1 + ["a", "m", "21839"].index(mod_type))
@@ -317,6 +318,22 @@ def make_metagenome(spec: SynthSpec) -> SynthMetagenome:
             t += 1
         bin_motifs[b] = chosen
     return SynthMetagenome(spec, names, bin_names, lengths, bin_gc, bin_motifs)
+
+
+def from_sequences(names, sequences, bin_names, motifs, seed: int = 1, mod_types=("a",), methylated_fraction: float = 0.97) -> SynthMetagenome:
+    """A synthetic PILEUP on GIVEN contigs (e.g. the reference's packaged geobacillus plasmids, whose own pileup is not
+    distributable — SURVEY §8(d) cfg 1): the sequences are taken as they are, the rows and the planted motifs
+    ``[(iupac, pos, mod_type), ...]`` come from the same counter-based hash as in make_metagenome."""
+    seqs = [s if isinstance(s, str) else bytes(s).decode("ascii") for s in sequences]
+    lengths = np.array([len(s) for s in seqs], dtype=np.int64)
+    spec = SynthSpec(n_contigs=len(names), total_bp=int(lengths.sum()), n_bins=len(set(bin_names)), mod_types=tuple(mod_types), seed=seed,
+                     fixed_motifs=tuple(tuple(m) for m in motifs), methylated_fraction=methylated_fraction)
+    bins = sorted(set(bin_names))
+    mg = SynthMetagenome(spec, list(names), list(bin_names), lengths, {b: 0.5 for b in bins},
+                         {b: [tuple(m) for m in motifs if m[2] in mod_types] for b in bins})
+    for i, s in enumerate(seqs):                       # contig_codes() serves these instead of generating
+        mg._seq_cache[i] = CODE_OF_ASCII[np.frombuffer(s.upper().encode("ascii"), dtype=np.uint8)]
+    return mg
 
 
 # named configurations of BASELINE.json ("configs")

@@ -67,6 +67,65 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     assert os.path.exists(tmp + "/out_gz/temp/contig_bin.tsv")
 
 
+def test_cfg1_packaged_geobacillus_assembly(tmp_path):
+    """BASELINE cfg 1 / SURVEY §8(d): the reference's check_installation data set — the packaged
+    geobacillus-plasmids.assembly.fasta (2 contigs, 176 kbp) and geobacillus-contig-bin.tsv, copied as data fixtures — with
+    the modkit pileup (a missing blob in the reference) synthesized ON THOSE contigs, planting the four motifs of the
+    packaged expected output (geobacillus-plasmids.bin-motifs.tsv:2-5); `-t 1`.  bin-motifs.tsv must equal the oracle
+    pipeline byte for byte and hold those four motifs."""
+    import shutil
+    from helpers import GOLDEN
+    from nanomotif_amd import fasta
+    tmp = str(tmp_path)
+    shutil.copy(os.path.join(GOLDEN, "data_geobacillus-plasmids.assembly.fasta"), tmp + "/geobacillus-plasmids.assembly.fasta")
+    shutil.copy(os.path.join(GOLDEN, "data_geobacillus-contig-bin.tsv"), tmp + "/geobacillus-contig-bin.tsv")
+    names, seqs = zip(*fasta.read_fasta_names_and_seqs(tmp + "/geobacillus-plasmids.assembly.fasta"))
+    assert list(names) == ["contig_3", "contig_2"] and [len(s) for s in seqs] == [82915, 93311]          # SURVEY §2
+    bin_of = dict(line.split("\t") for line in open(tmp + "/geobacillus-contig-bin.tsv").read().split("\n") if line)
+    planted = [("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCAAAT", 4, "a"), ("GRNGAAGY", 5, "a")]
+    mg = synth.from_sequences(names, seqs, [bin_of[n] for n in names], planted, seed=1, mod_types=("a",))
+    mg.write_bed(tmp + "/geobacillus-plasmids.pileup.bed")
+    _run_cli(tmp, ["geobacillus-plasmids.assembly.fasta", "geobacillus-plasmids.pileup.bed", "-c", "geobacillus-contig-bin.tsv",
+                   "--out", "out", "-t", "1"])
+    got = open(tmp + "/out/bin-motifs.tsv").read()
+    expect = oracle_pipeline(mg)
+    assert got == expect, f"\n--- gpu ---\n{got}\n--- oracle ---\n{expect}"
+    rows = [l.split("\t") for l in got.strip().split("\n")[1:]]
+    assert {(r[0], r[1], int(r[2]), r[3]) for r in rows} >= {("bin1", m, p, "a") for m, p, _ in planted[:3]}
+    # (on these 176 kbp the search settles on GRNGAAGC, the commoner half of the planted GRNGAAGY — like the oracle)
+    assert any(r[1].startswith("GRNGAAG") and int(r[2]) == 5 for r in rows)
+    gatc = next(r for r in rows if r[1] == "GATC")
+    assert gatc[6] == "palindrome" and int(gatc[4]) > 600                 # the packaged output lists 679 methylated GATC sites
+
+
+def test_contig_listed_under_two_bins_is_scored_in_both(tmp_path):
+    """The reference's contig-bin table is a DataFrame: a contig listed under two bins is a member of both (its pileup rows
+    are joined to each bin, find_motifs_bin.py:416-418; fasta.py:122-187).  Expected output: the oracle pipeline on a
+    metagenome that holds the contig twice, once per bin, with the same sequence and the same pileup rows."""
+    from nanomotif_amd.fasta import ALIAS_SEP
+    base = synth.make_metagenome(synth.SynthSpec(n_contigs=5, total_bp=600_000, n_bins=2, mod_types=("a", "m"), seed=71, min_contig_bp=60_000))
+    seqs = [base.contig_str(i) for i in range(5)]
+    planted = [("GATC", 1, "a"), ("CCWGG", 1, "m"), ("GAATTC", 2, "a")]
+    shared = next(i for i, b in enumerate(base.bin_names) if b == "bin_000")
+    mg = synth.from_sequences(base.names, seqs, base.bin_names, planted, seed=71, mod_types=("a", "m"))
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    with open(tmp + "/cb.tsv", "w") as f:
+        for n, b in zip(mg.names, mg.bin_names):
+            f.write(f"{n}\t{b}\n")
+        f.write(f"{mg.names[shared]}\tbin_001\n")                        # the second listing
+        f.write(f"{mg.names[shared]}\tbin_001\n")                        # an exact repeat: ignored with a warning
+    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o"])
+    assert "it is scored in both" in r.stdout + r.stderr
+    twice = synth.from_sequences(list(mg.names) + [mg.names[shared] + ALIAS_SEP + "bin_001"], seqs + [seqs[shared]],
+                                 list(mg.bin_names) + ["bin_001"], planted, seed=71, mod_types=("a", "m"))
+    twice.key_index = {5: shared}
+    got = open(tmp + "/o/bin-motifs.tsv").read()
+    assert got == oracle_pipeline(twice)
+    assert got != oracle_pipeline(mg)                                     # the extra member changed bin_001's counts
+
+
 def test_non_default_thresholds_search_and_merge_stage(tmp_path):
     """--methylation_threshold_low/high drive the search; the merge stage stays at 0.3 / 0.7 like the reference."""
     spec = synth.SynthSpec(n_contigs=2, total_bp=400_000, n_bins=1, mod_types=("a",), seed=43, min_contig_bp=150_000,
