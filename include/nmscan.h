@@ -235,6 +235,23 @@ int nm_bg_counts(nm_ctx *ctx, uint8_t base, uint32_t pad, uint64_t n_samples, co
  * [task_run_begin[t], task_run_begin[t + 1]).  The per-sample contig column is written on the device. */
 int nm_bg_counts_runs(nm_ctx *ctx, uint8_t base, uint32_t pad, uint32_t n_runs, const uint32_t *run_contig, const uint32_t *run_count,
                       const uint32_t *sample_rank, uint32_t n_tasks, const uint32_t *task_run_begin, int64_t *out);
+/* Window extraction of ALL (bin, mod type) tasks in one call — find_motifs_bin.py:625-686 for every task.  Task t walks the
+ * resident contigs contig_id[task_contig_begin[t] .. task_contig_begin[t + 1]) in the order given (the reference's order:
+ * sorted contig name); per contig the background sample is drawn first (n = max(ceil(len * freq), 50) of the valid
+ * starts with the canonical base task_base[t] in the middle, CPython's random.sample bit for bit) and then the
+ * methylation windows are taken around the confident rows of classification task_slot[t]; the task ends as "None" at the
+ * first contig without a window (the contigs up to and including that one have consumed random numbers).  Tasks with the
+ * same task_group[t] (non-decreasing) share one generator stream in task order; group g starts from
+ * group_init_state[g][625] (shared_init != 0: every group from group_init_state[0] — the reference reseeds every task of
+ * a plain pileup alike, find_motifs_bin.py:152-171); final_state = where the last group's stream ends.
+ * Outputs per task: task_status 0 = windows made / 1 = None; task_window = window-engine task id; task_n_windows;
+ * task_n_bg = background samples; bg_counts int64[n_tasks][4][2*pad+1], rows A, T, G, C (pssm = counts / task_n_bg).
+ * One gather launch serves the windows of every task; the draws run on host threads meanwhile.  The reference's two
+ * ValueErrors come back as NM_EINVAL with their text ("Too many samples requested ...", "Not enough subsequences ..."). */
+int nm_plan_windows(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_slot, const uint8_t *task_base, const uint32_t *task_group,
+                    const uint32_t *task_contig_begin, const uint32_t *contig_id, uint32_t pad, double freq, uint32_t n_groups,
+                    const uint32_t *group_init_state, int shared_init, uint8_t *task_status, uint32_t *task_window,
+                    uint64_t *task_n_windows, uint64_t *task_n_bg, int64_t *bg_counts, uint32_t final_state[625]);
 /* Number of assembly letters that are none of A C G T N (any case) seen by the last nm_upload_contigs. */
 int nm_assembly_other_letters(nm_ctx *ctx, uint64_t *n);
 

@@ -1,6 +1,9 @@
 // libnmscan — window engine and window extraction: the per-expansion work of the greedy search on bit planes over
 // windows, the gather of those windows from the resident planes and the background sample (C ABI: nm_win_*,
 // nm_contig_base_counts, nm_bg_counts, nm_methylated_row_counts; include/nmscan.h).
+#include <cmath>
+#include <thread>
+
 #include "nmscan_internal.h"
 
 using namespace nmdetail;
@@ -393,6 +396,47 @@ __global__ __launch_bounds__(256) void win_gather_contigs_kernel(WinTask t, Plan
         const uint32_t c0 = contig_chunk[sg.contig];
         const uint32_t nblk = (uint32_t)((contig_len[sg.contig] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
         centre = select_kth(s, minus ? MM : MP, -1, (minus ? rank_m : rank_p) + (size_t)c0 * RANK_PER_CHUNK, c0, nblk,
+                            (uint32_t)i - sg.dst_start + sg.head);
+        if (centre == ~0ull) {
+            atomicOr(err, 8u);
+            on = false;
+        }
+    }
+    pack_windows(t, s, wave, lane, on, centre, minus, pad, planes, alive);
+}
+
+// The methylation windows of ALL tasks in one launch (nm_plan_windows): workgroup b serves the 256 windows
+// [first, first + 256) of task blocks[b].task; the task's (contig, strand) segments are segs[seg_begin .. seg_begin + n_seg).
+struct WinBlock { uint32_t task, first, seg_begin, n_seg, slot; };
+struct SlotRows { const uint32_t *MP, *MM, *rank_p, *rank_m; };
+struct AllSlotRows { SlotRows s[NM_MAX_MOD_SLOTS]; };
+
+__global__ __launch_bounds__(256) void win_gather_all_kernel(const WinTask *__restrict__ tasks, const WinBlock *__restrict__ blocks,
+                                                             Planes s, AllSlotRows rows, const uint32_t *__restrict__ contig_chunk,
+                                                             const uint64_t *__restrict__ contig_len, const WinSegment *__restrict__ segs,
+                                                             uint32_t pad, uint32_t *__restrict__ planes, uint32_t *__restrict__ alive,
+                                                             unsigned int *err) {
+    const WinBlock blk = blocks[blockIdx.x];
+    const WinTask t = tasks[blk.task];
+    const SlotRows sr = rows.s[blk.slot];
+    const WinSegment *seg = segs + blk.seg_begin;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blk.first / 64 + (threadIdx.x >> 6);
+    const uint64_t i = (uint64_t)wave * 64 + lane;
+    if ((uint64_t)wave * 64 >= t.n) return;
+    bool on = i < t.n, minus = false;
+    uint64_t centre = 0;
+    if (on) {
+        uint32_t lo = 0, hi = blk.n_seg - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (seg[mid].dst_start <= (uint32_t)i) lo = mid; else hi = mid - 1;
+        }
+        const WinSegment sg = seg[lo];
+        minus = sg.minus != 0;
+        const uint32_t c0 = contig_chunk[sg.contig];
+        const uint32_t nblk = (uint32_t)((contig_len[sg.contig] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
+        centre = select_kth(s, minus ? sr.MM : sr.MP, -1, (minus ? sr.rank_m : sr.rank_p) + (size_t)c0 * RANK_PER_CHUNK, c0, nblk,
                             (uint32_t)i - sg.dst_start + sg.head);
         if (centre == ~0ull) {
             atomicOr(err, 8u);
@@ -814,6 +858,229 @@ int nm_win_add_task_contigs(nm_ctx *c, uint32_t mod_slot, uint32_t n_contigs, co
     *n_windows = total;
     c->win_tasks.push_back(t);
     c->win_tasks_dirty = true;
+    return NM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// nm_plan_windows: window extraction of ALL (bin, mod type) tasks in one call (find_motifs_bin.py:625-686 per task): the
+// reference walks the task's contigs in order; per contig it draws the background sample (random.sample of the valid
+// starts, seq.py:202-225) and then gathers the methylation windows, and gives the task up (None) at the first contig
+// without a window — the contigs up to and including that one have consumed random numbers.  Here: the plan on the host
+// (counts come from the rank tables), ONE gather launch for the windows of every task, the draws of all generator
+// streams on host threads while that kernel runs, written straight into the pinned staging buffer, one counting launch
+// per canonical base.
+// ------------------------------------------------------------------------------------------------------
+int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, const uint8_t *task_base, const uint32_t *task_group,
+                    const uint32_t *task_contig_begin, const uint32_t *contig_id, uint32_t pad, double freq, uint32_t n_groups,
+                    const uint32_t *group_init_state, int shared_init, uint8_t *task_status, uint32_t *task_window,
+                    uint64_t *task_n_windows, uint64_t *task_n_bg, int64_t *bg_counts, uint32_t final_state[625]) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs must come first");
+    if (n_tasks == 0) return NM_OK;
+    if (!task_slot || !task_base || !task_group || !task_contig_begin || !task_status || !task_window || !task_n_windows || !task_n_bg ||
+        !bg_counts || !group_init_state || !final_state || (task_contig_begin[n_tasks] && !contig_id))
+        return fail(NM_EINVAL, "NULL argument");
+    const uint32_t W = 2 * pad + 1;
+    if (W > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", W, WIN_MAX_W);
+    HIP_TRY(hipSetDevice(c->device));
+    // ---- counts the plan needs: valid sample starts per contig and base, confident rows per contig and slot
+    std::vector<uint64_t> n_valid[4];
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        const int b = base_index(task_base[t]);
+        if (b < 0) return fail(NM_EINVAL, "task %u: base must be one of A C G T", t);
+        if (task_slot[t] >= NM_MAX_MOD_SLOTS || !c->slots[task_slot[t]].present) return fail(NM_ESTATE, "task %u: mod slot %u holds no pileup", t, task_slot[t]);
+        if (task_group[t] >= n_groups || (t && task_group[t] < task_group[t - 1])) return fail(NM_EINVAL, "task_group must be non-decreasing and < n_groups");
+        if (n_valid[b].empty()) {
+            n_valid[b].assign(c->n_contigs, 0);
+            const int rc = nm_contig_base_counts(c, task_base[t], pad, n_valid[b].data());
+            if (rc) return rc;
+        }
+        const int rc = ensure_slot_counts(c, task_slot[t], pad);
+        if (rc) return rc;
+    }
+    // ---- the plan
+    struct Call { uint64_t n, k, out; };                   // random.sample(range(n), k); out: first rank in the staging buffer or ~0 (discarded)
+    std::vector<std::vector<Call>> group_calls(n_groups);
+    std::vector<WinSegment> segs;
+    std::vector<WinBlock> blocks;
+    std::vector<WinTask> new_tasks;
+    std::vector<BgRun> runs;
+    std::vector<BgBlock> bg_blocks[4];
+    uint64_t n_samples = 0, planes_used = c->win_planes_used, alive_used = c->win_alive_used;
+    constexpr uint32_t SPB = 2048;
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        const uint32_t a = task_contig_begin[t], e = task_contig_begin[t + 1];
+        if (e < a) return fail(NM_EINVAL, "task_contig_begin must be non-decreasing");
+        const int b = base_index(task_base[t]);
+        const ModSlot &ms = c->slots[task_slot[t]];
+        task_status[t] = 1;
+        task_window[t] = 0xFFFFFFFFu;
+        task_n_windows[t] = task_n_bg[t] = 0;
+        uint32_t stop = e;
+        for (uint32_t k = a; k < e; ++k) {
+            const uint32_t ci = contig_id[k];
+            if (ci >= c->n_contigs) return fail(NM_EINVAL, "task %u: contig %u >= %u", t, ci, c->n_contigs);
+            if (ms.meth_counts[4 * (size_t)ci] + ms.meth_counts[4 * (size_t)ci + 1] == 0) { stop = k; break; }
+        }
+        const uint32_t drawn_end = std::min(stop + 1, e);
+        uint64_t total = 0, n_bg = 0;
+        const size_t seg0 = segs.size(), run0 = runs.size();
+        const uint64_t samples0 = n_samples;
+        for (uint32_t k = a; k < drawn_end; ++k) {
+            const uint32_t ci = contig_id[k];
+            const uint64_t len = c->contig_len[ci];
+            const uint64_t want = std::max<uint64_t>((uint64_t)std::ceil((double)len * freq), 50);       // find_motifs_bin.py:633
+            if (len < W || want > len - W + 1) return fail(NM_EINVAL, "Too many samples requested for unique subsequences");
+            if (n_valid[b][ci] < want)
+                return fail(NM_EINVAL, "Not enough subsequences with '%c' in the middle (found %llu, need %llu)", task_base[t],
+                            (unsigned long long)n_valid[b][ci], (unsigned long long)want);
+            const bool keep = stop == e;
+            group_calls[task_group[t]].push_back(Call{n_valid[b][ci], want, keep ? n_samples : ~0ull});
+            if (!keep) continue;
+            runs.push_back(BgRun{(uint32_t)n_samples, (uint32_t)(n_samples >> 32), (uint32_t)want, ci});
+            n_samples += want;
+            n_bg += want;
+            for (uint32_t strand = 0; strand < 2; ++strand) {       // plus rows, then minus rows (find_motifs_bin.py:640-659)
+                const uint64_t n = ms.meth_counts[4 * (size_t)ci + strand];
+                if (!n) continue;
+                segs.push_back(WinSegment{(uint32_t)total, ci, strand, (uint32_t)ms.meth_counts[4 * (size_t)ci + 2 + strand]});
+                total += n;
+            }
+        }
+        if (stop != e || total == 0 || n_bg == 0) {                  // None: no methylation windows (find_motifs_bin.py:662-664)
+            segs.resize(seg0);
+            runs.resize(run0);
+            n_samples = samples0;
+            for (Call &cl : group_calls[task_group[t]])
+                if (cl.out != ~0ull && cl.out >= samples0) cl.out = ~0ull;
+            continue;
+        }
+        if (total >= 0xFFFFFFFFull) return fail(NM_ERANGE, "more than 4G windows in one task");
+        WinTask wt{};
+        wt.n = (uint32_t)total;
+        wt.nw = (wt.n + 31) / 32;
+        wt.width = W;
+        wt.plane_off = planes_used;
+        wt.alive_off = alive_used;
+        planes_used += (uint64_t)W * 5 * wt.nw;
+        alive_used += wt.nw;
+        const uint32_t tid = (uint32_t)(c->win_tasks.size() + new_tasks.size());
+        new_tasks.push_back(wt);
+        for (uint32_t first = 0; first < wt.n; first += 256)
+            blocks.push_back(WinBlock{tid, first, (uint32_t)seg0, (uint32_t)(segs.size() - seg0), task_slot[t]});
+        for (uint64_t s0 = samples0; s0 < n_samples; s0 += SPB)
+            bg_blocks[b].push_back(BgBlock{t, (uint32_t)s0, (uint32_t)(s0 >> 32), (uint32_t)std::min<uint64_t>(SPB, n_samples - s0)});
+        task_status[t] = 0;
+        task_window[t] = tid;
+        task_n_windows[t] = total;
+        task_n_bg[t] = n_bg;
+    }
+    // ---- window pools and the task table
+    int rc = win_grow(c, &c->d_win_planes, &c->win_planes_cap, c->win_planes_used, planes_used - c->win_planes_used);
+    if (rc) return rc;
+    rc = win_grow(c, &c->d_win_alive, &c->win_alive_cap, c->win_alive_used, alive_used - c->win_alive_used);
+    if (rc) return rc;
+    c->win_tasks.insert(c->win_tasks.end(), new_tasks.begin(), new_tasks.end());
+    c->win_planes_used = planes_used;
+    c->win_alive_used = alive_used;
+    if (c->d_win_tasks_cap < c->win_tasks.size()) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
+        c->d_win_tasks = nullptr;
+        c->d_win_tasks_cap = 0;
+        HIP_TRY(nmdetail::dev_malloc(&c->d_win_tasks, c->win_tasks.size() * 2 * sizeof(WinTask)));
+        c->d_win_tasks_cap = c->win_tasks.size() * 2;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_win_tasks, c->win_tasks.data(), c->win_tasks.size() * sizeof(WinTask), hipMemcpyHostToDevice, c->stream));
+    c->win_tasks_dirty = false;
+    // ---- staging: ranks | sample contig column (device only) | segments | window blocks | runs | bg blocks (4 lists) | counts
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_rank = 0, o_contig = up16((size_t)n_samples * 4), o_seg = up16(o_contig + (size_t)n_samples * 4);
+    const size_t o_blk = up16(o_seg + segs.size() * sizeof(WinSegment)), o_runs = up16(o_blk + blocks.size() * sizeof(WinBlock));
+    size_t o_bg[4], at = up16(o_runs + runs.size() * sizeof(BgRun));
+    for (int b = 0; b < 4; ++b) { o_bg[b] = at; at = up16(at + bg_blocks[b].size() * sizeof(BgBlock)); }
+    const size_t o_out = at, out_bytes = (size_t)n_tasks * 4 * WIN_MAX_W * 8;
+    rc = ensure_stage(c, o_out + out_bytes);
+    if (rc) return rc;
+    uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    if (!segs.empty()) memcpy(hs + o_seg, segs.data(), segs.size() * sizeof(WinSegment));
+    if (!blocks.empty()) memcpy(hs + o_blk, blocks.data(), blocks.size() * sizeof(WinBlock));
+    if (!runs.empty()) memcpy(hs + o_runs, runs.data(), runs.size() * sizeof(BgRun));
+    for (int b = 0; b < 4; ++b)
+        if (!bg_blocks[b].empty()) memcpy(hs + o_bg[b], bg_blocks[b].data(), bg_blocks[b].size() * sizeof(BgBlock));
+    HIP_TRY(hipMemcpyAsync(ds + o_seg, hs + o_seg, o_out - o_seg, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(ds + o_out, 0, out_bytes, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream));
+    if (!blocks.empty()) {
+        AllSlotRows rows{};
+        for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) {
+            const ModSlot &ms = c->slots[sl];
+            rows.s[sl] = SlotRows{ms.planes[2], ms.planes[4], ms.rank[0], ms.rank[1]};
+        }
+        hipLaunchKernelGGL(win_gather_all_kernel, dim3((unsigned)blocks.size()), dim3(256), 0, c->stream, c->d_win_tasks,
+                           reinterpret_cast<const WinBlock *>(ds + o_blk), seq_planes(c), rows, c->d_contig_chunk, c->d_contig_len,
+                           reinterpret_cast<const WinSegment *>(ds + o_seg), pad, c->d_win_planes, c->d_win_alive, c->d_err);
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- the draws: every group its own generator stream, on host threads, while the gather kernel runs
+    {
+        uint32_t *ranks = reinterpret_cast<uint32_t *>(hs + o_rank);
+        std::vector<int> rcs(n_groups, NM_OK);
+        std::vector<std::string> errs(n_groups);
+        const unsigned threads = std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), n_groups}));
+        std::vector<std::vector<uint32_t>> last(threads);
+        auto work = [&](unsigned th) {
+            std::vector<uint32_t> st(625), scratch;
+            for (uint32_t g = th; g < n_groups; g += threads) {
+                memcpy(st.data(), group_init_state + (shared_init ? 0 : (size_t)g * 625), 625 * 4);
+                for (const Call &cl : group_calls[g]) {
+                    uint32_t *dst = cl.out == ~0ull ? (scratch.resize(cl.k), scratch.data()) : ranks + cl.out;
+                    rcs[g] = nm_py_random_sample(st.data(), cl.n, cl.k, dst);
+                    if (rcs[g] != NM_OK) { errs[g] = nm_last_error(); break; }
+                }
+                if (g == n_groups - 1) last[th] = st;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned th = 1; th < threads; ++th) pool.emplace_back(work, th);
+        work(0);
+        for (auto &th : pool) th.join();
+        for (uint32_t g = 0; g < n_groups; ++g)
+            if (rcs[g] != NM_OK) {
+                (void)hipStreamSynchronize(c->stream);
+                return fail(rcs[g], "%s", errs[g].c_str());
+            }
+        for (unsigned th = 0; th < threads; ++th)
+            if (!last[th].empty()) memcpy(final_state, last[th].data(), 625 * 4);
+    }
+    if (n_samples) {
+        HIP_TRY(hipMemcpyAsync(ds + o_rank, hs + o_rank, (size_t)n_samples * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bg_expand_runs_kernel, dim3((unsigned)runs.size()), dim3(256), 0, c->stream,
+                           reinterpret_cast<const BgRun *>(ds + o_runs), reinterpret_cast<uint32_t *>(ds + o_contig));
+        HIP_TRY(hipGetLastError());
+        for (int b = 0; b < 4; ++b) {
+            if (bg_blocks[b].empty()) continue;
+            hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)bg_blocks[b].size()), dim3(256), 0, c->stream, seq_planes(c), c->d_rank[b],
+                               c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_bg[b]),
+                               reinterpret_cast<const uint32_t *>(ds + o_contig), reinterpret_cast<const uint32_t *>(ds + o_rank), b, pad,
+                               reinterpret_cast<unsigned long long *>(ds + o_out), c->d_err);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    unsigned int err = 0;
+    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost, c->stream));
+    rc = release_stage(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (err & 8u) return fail(NM_ESTATE, "a window's row rank is beyond the rows of its contig (the slot's planes changed?)");
+    if (err) return fail(NM_EINVAL, "a sample rank is not below the contig's number of valid starts");
+    const uint64_t *ho = reinterpret_cast<const uint64_t *>(hs + o_out);
+    for (uint32_t t = 0; t < n_tasks; ++t)
+        for (uint32_t r = 0; r < 4; ++r)
+            for (uint32_t col = 0; col < W; ++col)
+                bg_counts[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * WIN_MAX_W + col];
     return NM_OK;
 }
 

@@ -246,6 +246,64 @@ class DeviceWindowExtractor:
     def _draw_deferred(self):
         _draw_deferred_impl(self)
 
+    def plan_all(self, tasks, seed, one_stream_per_bin=False) -> dict:
+        """Every task of a single-GPU run in ONE native call (nm_plan_windows): ``tasks`` = [(key, contig names present in
+        the filtered pileup of the task's mod type, mod_type)] in task order; ``seed``: what the reference seeds ``random``
+        with before a task (plain pileup, find_motifs_bin.py:152-171) or before a bin's tasks (``one_stream_per_bin``: the
+        bgzip path, :219-248 — consecutive tasks of one bin share a stream).  Windows are gathered, backgrounds drawn and
+        counted on the device / on native threads; the interpreter's generator ends where the sequential run would leave it.
+        Returns {key: background PSSM float64[4, W]} for the tasks that have methylation windows (the others are the
+        reference's "No methylation sequences found")."""
+        import random
+        if not tasks:
+            return {}
+        n = len(tasks)
+        slot = np.fromiter((self.engine.slot_of_mod[t[2]] for t in tasks), dtype=np.uint32, count=n)
+        base = np.fromiter((ord(MOD_TYPE_TO_CANONICAL[t[2]]) for t in tasks), dtype=np.uint8, count=n)
+        begin = np.zeros(n + 1, dtype=np.uint32)
+        ids = []
+        res = self.resident
+        for k, (_, names, _) in enumerate(tasks):
+            ids += [res[x] for x in sorted(names)]
+            begin[k + 1] = len(ids)
+        ids = np.asarray(ids, dtype=np.uint32)
+        if one_stream_per_bin:
+            group = np.zeros(n, dtype=np.uint32)
+            g, last_bin = -1, object()
+            for k, (key, _, _) in enumerate(tasks):
+                if key[0] != last_bin:
+                    g, last_bin = g + 1, key[0]
+                group[k] = g
+            n_groups = g + 1
+        else:
+            group, n_groups = np.arange(n, dtype=np.uint32), n
+        version, _, gauss = random.getstate()
+        random.seed(seed)
+        init = np.array(random.getstate()[1], dtype=np.uint32)
+        W = 2 * self.pad + 1
+        status = np.zeros(n, dtype=np.uint8)
+        window = np.zeros(n, dtype=np.uint32)
+        n_win, n_bg = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        counts = np.zeros((n, 4, W), dtype=np.int64)
+        final = np.zeros(625, dtype=np.uint32)
+        rc = self.engine.lib.nm_plan_windows(self.engine.ctx, n, _ptr(slot, C.c_uint32), _ptr(base, C.c_uint8), _ptr(group, C.c_uint32),
+                                             _ptr(begin, C.c_uint32), _ptr(ids, C.c_uint32), self.pad, float(self.freq), n_groups,
+                                             _ptr(init, C.c_uint32), 1, _ptr(status, C.c_uint8), _ptr(window, C.c_uint32),
+                                             _ptr(n_win, C.c_uint64), _ptr(n_bg, C.c_uint64), _ptr(counts, C.c_int64), _ptr(final, C.c_uint32))
+        if rc:
+            msg = self.engine.lib.nm_last_error().decode()
+            if msg.startswith("Too many samples") or msg.startswith("Not enough subsequences"):
+                raise ValueError(msg)                       # seq.py:208-219 raises these
+            _lib.check(rc)
+        random.setstate((version, tuple(final.tolist()), gauss))
+        out = {}
+        for k, (key, _, _) in enumerate(tasks):
+            if status[k]:
+                continue
+            self.store.task_id[key], self.store.width[key], self.store.totals[key] = int(window[k]), W, int(n_win[k])
+            out[key] = counts[k] / float(n_bg[k])
+        return out
+
     def finish(self) -> dict:
         """Background PSSM (``background_sequences.pssm()``, float64[4, W]) of every planned task."""
         W = 2 * self.pad + 1

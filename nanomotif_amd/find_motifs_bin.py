@@ -313,6 +313,12 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
         bins.setdefault(b, []).append(c)
     tasks = {}
     out_dir = cfg.output_dir
+    # single GPU, windows on the device: the plan of every task goes to libnmscan in ONE call (nm_plan_windows: one gather
+    # launch for all windows, the background draws on native threads meanwhile); contig-sharded multi-GPU runs and host
+    # windows keep the per-task path below
+    plan_natively = (extractor is not None and extractor.row_counts is not None and extractor.allreduce_i64 is None
+                     and os.environ.get("NANOMOTIF_PLAN_PER_TASK") != "1")
+    native_tasks = []
     # task order and seeding follow the reference: plain pileup = one task per (bin, mod type), each seeded afresh
     # (find_motifs_bin.py:152-171); bgzip = one task per bin, seeded once, mod types in constants order (:219-222, 248)
     for bin_name in bins:
@@ -325,6 +331,9 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                 plus = minus = None
                 names = filtered.present(bins[bin_name], mt_id)
                 if not names:
+                    continue
+                if plan_natively:
+                    native_tasks.append(((bin_name, mod_type), names, mod_type))
                     continue
             else:
                 plus, minus = filtered.positions(bins[bin_name], mt_id)
@@ -361,7 +370,21 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
             tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
     lap("plan_s")
     if extractor is not None:
-        pssms = extractor.finish()
+        if plan_natively:
+            pssms = extractor.plan_all(native_tasks, cfg.seed, one_stream_per_bin=bgzip_order)
+            for key, _, _ in native_tasks:
+                if key not in pssms:
+                    log.info(f"[{key[0]} {key[1]}] No methylation sequences found")
+                    continue
+                stage_writer = temp_dir = None
+                if out_dir and rank == 0:
+                    pre = os.path.join(out_dir, "precleanup-motifs", f"{key[0]}-{key[1]}")
+                    os.makedirs(pre, exist_ok=True)
+                    stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
+                    temp_dir = os.path.join(out_dir, "temp", key[0])
+                planned.append((key, stage_writer, temp_dir))
+        else:
+            pssms = extractor.finish()
         lap("background_s")
         engine = getattr(store, "engine", None)
         if engine is not None and os.environ.get("NANOMOTIF_PY_SEARCH") != "1":
