@@ -90,72 +90,119 @@ __device__ __forceinline__ void wave_row_range(uint64_t n, uint64_t *row_begin, 
 }
 
 // (1) coverage filter + per (contig, mod code) counts for the frequency filter
+// Also establishes, for free, whether the rows come the way modkit writes them — every contig's rows in ONE run, positions
+// non-decreasing inside it (order bit 1 = a position decreases, runs[contig] = number of runs): the classification pass
+// then assembles complete plane words and writes them with plain stores instead of read-modify-write atomics.
 __global__ __launch_bounds__(256) void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
-                                    int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err) {
+                                    int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err,
+                                    unsigned int *order /*[0]: flags*/, unsigned int *runs /*[contig]*/) {
     uint64_t row_begin, row_end;
     wave_row_range(r.n, &row_begin, &row_end);
     const uint32_t lane = threadIdx.x & 63;
     KeyCache kc;
-    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64) {
-        const uint64_t i = i0 + lane;
-        const bool in = i < row_end;
-        const uint32_t c = in ? r.contig[i] : 0xFFFFFFFFu;
-        const int m = in ? r.mod[i] : 0;
-        bool counted = c != 0xFFFFFFFFu;
-        if (counted && (c >= n_contigs || r.position[i] >= contig_len[c] || m < 0)) {
-            atomicOr(err, 1u);
-            counted = false;
+    // 256 rows per turn: the loads of four consecutive 64-row pieces are all issued before the first value is looked at —
+    // no test sits between two loads (the short-circuit tests used to make three dependent round trips of them), and a
+    // wave asks memory for 1 KB of consecutive addresses per column at a time instead of 256 B
+    constexpr int U = 4;
+    uint32_t prev_c = 0xFFFFFFFEu, prev_p = 0;                       // the row before this wave's first (0xFFFFFFFE: none)
+    if (row_begin > 0 && row_begin < row_end) {
+        prev_c = r.contig[row_begin - 1];
+        prev_p = r.position[row_begin - 1];
+    }
+    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64 * U) {
+        uint32_t c[U], p[U];
+        int m[U], nv[U];
+        double f[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+            in[u] = i < row_end;
+            const uint64_t ii = in[u] ? i : row_begin;
+            c[u] = r.contig[ii];
+            p[u] = r.position[ii];
+            m[u] = r.mod[ii];
+            nv[u] = r.nvalid[ii];
+            f[u] = r.frac[ii];
         }
-        counted = counted && r.nvalid[i] > min_cov;                              // dataload.py:199: Nvalid_cov > 5
-        const bool is_mod = counted && r.frac[i] > meth_thr;                    // dataload.py:215: fraction_mod > 0.7
-        // (a row whose percentage is null — fraction < 0 — counts as a position, never as a modified one: pl.count() vs
-        //  (fraction_mod > thr).sum(), dataload.py:216-217)
-        wave_add_keyed(kc, cnt, counted ? c * NM_CODE_STRIDE + (uint32_t)m : 0u, counted, is_mod, 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + (uint64_t)u * 64 >= row_end) break;             // wave-uniform
+            const uint32_t cc = in[u] ? c[u] : 0xFFFFFFFFu;
+            uint32_t pc = __shfl_up(cc, 1), pp = __shfl_up(p[u], 1);
+            if (lane == 0) { pc = prev_c; pp = prev_p; }
+            if (in[u] && cc != 0xFFFFFFFFu && cc < n_contigs) {
+                if (pc == cc) { if (p[u] < pp) atomicOr(order, 1u); }
+                else atomicAdd(runs + cc, 1u);
+            }
+            prev_c = __shfl(cc, 63);                                 // (beyond the wave's last row: never used again)
+            prev_p = __shfl(p[u], 63);
+            bool counted = cc != 0xFFFFFFFFu;
+            if (counted && (cc >= n_contigs || p[u] >= contig_len[cc] || m[u] < 0)) {
+                atomicOr(err, 1u);
+                counted = false;
+            }
+            counted = counted && nv[u] > min_cov;                    // dataload.py:199: Nvalid_cov > 5
+            const bool is_mod = counted && f[u] > meth_thr;          // dataload.py:215: fraction_mod > 0.7
+            // (a row whose percentage is null — fraction < 0 — counts as a position, never as a modified one: pl.count() vs
+            //  (fraction_mod > thr).sum(), dataload.py:216-217)
+            wave_add_keyed(kc, cnt, counted ? cc * NM_CODE_STRIDE + (uint32_t)m[u] : 0u, counted, is_mod, 2);
+        }
     }
     cache_flush(kc, cnt, 2, lane);
 }
 
 // (2) frequency filter verdict per (contig, mod code): n_mod / n > 1e-4 and n_mod > 50 (dataload.py:218-219)
 __global__ void ingest_group_kernel(uint32_t n_groups, const unsigned int *__restrict__ cnt, double min_freq,
-                                    unsigned int min_mods, uint8_t *ok) {
+                                    unsigned int min_mods, uint8_t *ok, const unsigned int *__restrict__ runs, unsigned int *order) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
+    if (g % NM_CODE_STRIDE == 0 && runs[g / NM_CODE_STRIDE] > 1) atomicOr(order, 2u);       // a contig's rows in several places
     const unsigned int n = cnt[g * 2], nm = cnt[g * 2 + 1];
     ok[g] = n > 0 && ((double)nm / (double)n) > min_freq && nm > min_mods;
-}
-
-__device__ __forceinline__ bool ingest_row_alive(const RawRows &r, uint64_t i, int min_cov, const uint8_t *ok,
-                                                 uint32_t *c_out, bool *plus_out) {
-    const uint32_t c = r.contig[i];
-    const int m = r.mod[i];
-    if (c == 0xFFFFFFFFu || m < 0 || r.nvalid[i] <= min_cov) return false;
-    if (!ok[(size_t)c * NM_CODE_STRIDE + m]) return false;
-    if (r.frac[i] < 0) return false;               // null percentage: neither `== max` nor `< threshold` holds (dataload.py:244)
-    const uint8_t st = r.strand[i];
-    if (st != '+' && st != '-') return false;      // other strand labels form groups of their own and are never scored
-    *c_out = c;
-    *plus_out = st == '+';
-    return true;
 }
 
 // (3a) adjacency filter, scatter: per strand the maximal fraction at every position (mod codes mixed, dataload.py:237).
 // Only rows the verdict below tests (fraction >= meth_thr) can decide it — a tested row fails iff a row in its window has
 // a LARGER fraction, and that row is then above the threshold itself — so only those (~1 % of a pileup) are scattered;
 // every other position keeps the 0 the arrays were cleared to.
-__global__ void ingest_scatter_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
+__global__ __launch_bounds__(256) void ingest_scatter_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                       const uint64_t *__restrict__ dense_off, unsigned long long *dense_plus,
                                       unsigned long long *dense_minus, double meth_thr, unsigned int *err) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= r.n) return;
-    uint32_t c;
-    bool plus;
-    if (!ingest_row_alive(r, i, min_cov, ok, &c, &plus)) return;
-    if (dense_off[c] == ~0ull) { atomicOr(err, 8u); return; }          // contig not listed for this part
-    const double f = r.frac[i];
-    if (f < meth_thr) return;
-    const uint64_t g = dense_off[c] + r.position[i];
-    // fractions are >= 0, so their IEEE bit patterns order like the values
-    atomicMax((plus ? dense_plus : dense_minus) + g, (unsigned long long)__double_as_longlong(f));
+    // waves walk contiguous row ranges, 256 rows per turn with every load issued before the first value is looked at
+    // (with early returns between the loads the kernel ran at a third of the rate the 18 bytes per row allow)
+    uint64_t row_begin, row_end;
+    wave_row_range(r.n, &row_begin, &row_end);
+    const uint32_t lane = threadIdx.x & 63;
+    constexpr int U = 4;
+    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64 * U) {
+        double f[U];
+        uint32_t c[U];
+        int m[U], nv[U];
+        uint8_t st[U];
+        uint64_t idx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+            idx[u] = i < row_end ? i : ~0ull;
+            const uint64_t ii = i < row_end ? i : row_begin;
+            f[u] = r.frac[ii];
+            c[u] = r.contig[ii];
+            m[u] = r.mod[ii];
+            nv[u] = r.nvalid[ii];
+            st[u] = r.strand[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (idx[u] == ~0ull || !(f[u] >= meth_thr) || c[u] == 0xFFFFFFFFu || m[u] < 0 || nv[u] <= min_cov) continue;   // (~1 % of the rows go on)
+            if (!ok[(size_t)c[u] * NM_CODE_STRIDE + m[u]]) continue;
+            if (st[u] != '+' && st[u] != '-') continue;
+            const uint64_t off = dense_off[c[u]];
+            if (off == ~0ull) { atomicOr(err, 8u); continue; }        // contig not listed for this part
+            // fractions are >= 0, so their IEEE bit patterns order like the values
+            atomicMax((st[u] == '+' ? dense_plus : dense_minus) + off + r.position[idx[u]], (unsigned long long)__double_as_longlong(f[u]));
+        }
+    }
 }
 
 // (3b) adjacency verdict + classification + confident-row list.  A row survives iff its fraction equals the maximum
@@ -166,46 +213,99 @@ struct IngestSlots {
     uint32_t can_l[NM_MAX_MOD_SLOTS];         // canonical base C (1) or A (0)
 };
 
+// One row's columns, as loaded (nothing tested yet).
+struct RowCols {
+    uint32_t c, pos;
+    int m, nv;
+    uint8_t st;
+    double f;
+};
+
+__device__ __forceinline__ RowCols load_row(const RawRows &r, uint64_t i) {
+    RowCols x;
+    x.c = r.contig[i];
+    x.pos = r.position[i];
+    x.m = r.mod[i];
+    x.nv = r.nvalid[i];
+    x.st = r.strand[i];
+    x.f = r.frac[i];
+    return x;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+
+// Every wave walks a contiguous range of rows, 64 per iteration.
+//  * No test sits between two loads of a row, and four iterations' columns are requested at once (the kernel was bound by
+//    the round trip of its own loads: 8 waves per SIMD x one dependent chain each, 256 B per request).
+//  * Rows at or above the adjacency threshold (~1.5 % of a pileup) need 17 scattered loads of the dense maxima: they are
+//    QUEUED (row index, LDS) and judged 64 at a time — one dependent round trip per 64 candidates instead of one in two
+//    of three iterations.  Their classification bits (the methylated planes: sparse) go to memory as atomicOr.
+//  * The bits of all other classified rows (the unmethylated planes: nearly every row) are collected per wave in a circular
+//    LDS window of 32 plane words per (slot, strand).  When the input is in modkit's order (order[0] == 0: verified by the
+//    counting pass) a word is COMPLETE once the wave has moved past it, and leaves as a plain store, whole runs of
+//    consecutive words per plane at a time; only the first word a wave touches and what it holds at its end can be shared
+//    with a neighbouring wave and go out as atomicOr.  Unordered input: the window is flushed with atomicOr every iteration.
 __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                      const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ dense_off,
                                      const unsigned long long *__restrict__ dense_plus,
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
-                                     double low, double high, IngestSlots sl,
+                                     double low, double high, IngestSlots sl, const unsigned int *__restrict__ order,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
                                      unsigned long long *n_classified) {
-    // every wave walks a contiguous range of rows: the two global totals are kept in registers and leave as ONE atomic
-    // per wave at the end (a per-row or even per-wave-iteration atomic on one address was most of this kernel's time at
-    // 1e9 rows)
-    unsigned long long my_kept = 0, my_cls = 0;
-    // Classification bits are collected per wave in LDS before they go to memory: the 64 rows of a wave iteration lie within
-    // a few words of a few planes (rows ascend within a contig), so a table of [plane][word - first word] entries takes one
-    // LDS atomic per row and leaves as ONE global atomicOr per touched word (~10 per 64 rows).  Rows outside the window of
-    // OR_WORDS words (another contig in the same wave, unsorted input) go straight to memory.
-    constexpr uint32_t OR_WORDS = 4, OR_PLANES = NM_MAX_MOD_SLOTS * 4;
-    __shared__ uint32_t or_tab[4][OR_PLANES * OR_WORDS];
-    __shared__ uint32_t *or_plane[OR_PLANES];
+    constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = 64 + 4 * 64;
+    __shared__ uint32_t tab[4][UP_PLANES * WIN];          // [slot * 2 + minus][word & 31]
+    __shared__ uint32_t *u_plane[UP_PLANES];
+    __shared__ unsigned long long queue[4][QCAP];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t e = threadIdx.x; e < 4 * OR_PLANES * OR_WORDS; e += blockDim.x) (&or_tab[0][0])[e] = 0;
-    if (threadIdx.x < OR_PLANES) or_plane[threadIdx.x] = sl.planes[threadIdx.x >> 2][2 + (threadIdx.x & 3)];
+    for (uint32_t e = threadIdx.x; e < 4 * UP_PLANES * WIN; e += blockDim.x) (&tab[0][0])[e] = 0;
+    if (threadIdx.x < UP_PLANES) u_plane[threadIdx.x] = sl.planes[threadIdx.x >> 1][(threadIdx.x & 1) ? 5 : 3];   // UP / UM
     __syncthreads();
+    // plain stores need ordered input AND candidates that can never set an unmethylated bit later (low < the adjacency threshold)
+    const bool sorted = __builtin_amdgcn_readfirstlane(order[0]) == 0 && low < meth_thr;
     uint64_t row_begin, row_end;
     wave_row_range(r.n, &row_begin, &row_end);
+    unsigned long long my_kept = 0, my_cls = 0;
     KeyCache kc;
-    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64) {
-        const uint64_t i = i0 + lane;
-        uint32_t c = 0;
-        bool plus = true;
-        bool alive = i < row_end && ingest_row_alive(r, i, min_cov, ok, &c, &plus);
-        alive = alive && dense_off[c] != ~0ull;                  // (flagged by the scatter pass)
-        const double f = alive ? r.frac[i] : 0.0;
-        const uint64_t g = alive ? (uint64_t)contig_chunk[c] * CHUNK_BP + r.position[i] : 0;
-        if (alive && !(f < meth_thr)) {
-            const unsigned long long *d = (plus ? dense_plus : dense_minus) + dense_off[c] + r.position[i];
-            unsigned long long mx = 0;                                              // >= 64 zero positions around every contig
+    uint32_t *const mytab = tab[wave];
+    unsigned long long *const myq = queue[wave];
+    uint32_t qn = 0;                                      // wave-uniform
+    uint64_t w_base = 0, first_word = ~0ull;              // wave-uniform
+    uint32_t cur_contig = 0xFFFFFFFFu;
+    bool have = false;
+
+    // words [lo, hi) of the window -> memory.  Lanes run along the words of one plane: consecutive stores.
+    auto flush_range = [&](uint64_t lo, uint64_t hi, bool all_atomic) {
+        if (!have || hi <= lo) return;
+        const uint32_t nw = (uint32_t)(hi - lo);
+        __asm__ volatile("" ::: "memory");
+        for (uint32_t e = lane; e < UP_PLANES * nw; e += 64) {
+            const uint32_t pid = e / nw;
+            const uint64_t w = lo + e % nw;
+            const uint32_t bits = mytab[pid * WIN + (uint32_t)(w & (WIN - 1))];
+            if (bits) {
+                if (all_atomic || w == first_word) atomicOr(u_plane[pid] + w, bits);
+                else u_plane[pid][w] = bits;
+                mytab[pid * WIN + (uint32_t)(w & (WIN - 1))] = 0;
+            }
+        }
+        __asm__ volatile("" ::: "memory");
+    };
+
+    // the adjacency verdict of up to 64 queued rows, one per lane (n <= 64 of them)
+    auto judge = [&](uint32_t n) {
+        const bool on = lane < n;
+        const uint64_t i = on ? myq[lane] : row_begin;
+        const RowCols x = load_row(r, i);
+        const bool plus = x.st == '+';
+        const uint64_t doff = on ? dense_off[x.c] : 0ull;
+        const unsigned long long *d = (plus ? dense_plus : dense_minus) + doff + x.pos;
+        unsigned long long mx = 0;                        // >= 64 zero positions around every contig
+        if (on) {
             if (adjacency == 8) {
-                // the pipeline's distance: all 17 loads are issued before the first is waited for — walked one by one they
-                // were 17 dependent DRAM round trips in two of three wave iterations, and the kernel was bound by exactly that
-                unsigned long long v[17];
+                unsigned long long v[17];                 // all 17 loads are issued before the first is waited for
 #pragma unroll
                 for (int k = 0; k < 17; ++k) v[k] = d[k - 8];
 #pragma unroll
@@ -213,46 +313,124 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
             } else {
                 for (int k = -adjacency; k <= adjacency; ++k) mx = max(mx, d[k]);
             }
-            if (mx != (unsigned long long)__double_as_longlong(f)) alive = false;
         }
-        const int m = alive ? r.mod[i] : 0;
-        const bool listed = alive && m < NM_MAX_MOD_CODES;       // codes beyond the ABI's eight are filtered with the rest, never reported
-        wave_add_keyed(kc, kept, listed ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, listed, false, 1);     // all lanes take part
+        const bool alive = on && mx == (unsigned long long)__double_as_longlong(x.f);
+        const bool listed = alive && x.m < NM_MAX_MOD_CODES;
+        wave_add_keyed(kc, kept, listed ? x.c * NM_MAX_MOD_CODES + (uint32_t)x.m : 0u, listed, false, 1);
         my_kept += alive;
-        const int slot = listed ? sl.slot_of_mod[m] : -1;
-        const bool meth = slot >= 0 && f >= high, non = slot >= 0 && f <= low;
-        const bool cls = meth || non;
-        // classified rows are counted; the host compares the total with the population count of the general planes
-        // afterwards — a duplicate (contig, position, strand) row sets a bit twice and shows up there, which lets the
-        // atomicOr run without a return value.  The compact planes M / U follow from the general ones
-        // (compact_planes_kernel), and so does the list of confident rows (nm_ingest_results).
-        my_cls += cls;
-        const unsigned long long cls_mask = __ballot(cls);
-        if (cls_mask) {                                                        // wave-uniform
-            const uint32_t pid = cls ? (uint32_t)slot * 4u + (plus ? (meth ? 0u : 1u) : (meth ? 2u : 3u)) : 0u;   // MP UP MM UM
-            const uint64_t w = g >> 5;
-            const int first = __ffsll((long long)cls_mask) - 1;
-            const uint64_t w_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), first) << 32) |
-                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, first);
-            const uint64_t rel = w - w_base;                                   // wraps to a huge value for a smaller word
-            const uint32_t bit = 1u << (g & 31);
-            if (cls) {
-                if (rel < OR_WORDS) atomicOr(&or_tab[wave][pid * OR_WORDS + (uint32_t)rel], bit);
-                else atomicOr(or_plane[pid] + w, bit);
-            }
-            // (the LDS unit serves a wave's instructions in order: the reads below see the atomics above; the compiler
-            //  must only keep the order, a fence would also wait for every global access in flight)
-            __asm__ volatile("" ::: "memory");
-            for (uint32_t e = lane; e < OR_PLANES * OR_WORDS; e += 64) {
-                const uint32_t bits = or_tab[wave][e];
-                if (bits) {
-                    atomicOr(or_plane[e / OR_WORDS] + w_base + e % OR_WORDS, bits);
-                    or_tab[wave][e] = 0;
-                }
-            }
-            __asm__ volatile("" ::: "memory");
+        const int slot = listed ? sl.slot_of_mod[x.m] : -1;
+        const bool meth = slot >= 0 && x.f >= high, non = slot >= 0 && x.f <= low;
+        my_cls += meth || non;
+        if (meth || non) {
+            const uint64_t g = (uint64_t)contig_chunk[x.c] * CHUNK_BP + x.pos;
+            // M U MP UP MM UM: methylated plus / minus = 2 / 4, unmethylated = 3 / 5 (non only with low >= the threshold:
+            // then the kernel runs unordered, every unmethylated bit is an atomicOr)
+            atomicOr(sl.planes[slot][(plus ? 2 : 4) + (meth ? 0 : 1)] + (g >> 5), 1u << (g & 31));
         }
+    };
+
+    // 256 rows per turn: the columns of four consecutive 64-row pieces are requested together (1 KB of consecutive addresses
+    // per column and wave — the counting pass reaches the streaming rate of the device this way), then the pieces are
+    // worked on one after the other
+    constexpr int U = 4;
+    for (uint64_t i00 = row_begin; i00 < row_end; i00 += 64 * U) {
+      RowCols cols[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cols[u] = load_row(r, min(i00 + (uint64_t)u * 64 + lane, row_end - 1));
+      // what hangs on the contig / mod code of a row (frequency-filter verdict, dense offset, first chunk) is fetched for
+      // all four pieces together: one dependent round trip per 256 rows, not one per 64
+      bool pre[U];
+      uint8_t okv[U];
+      uint64_t doffv[U];
+      uint32_t chunkv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const RowCols &x = cols[u];
+        pre[u] = i00 + (uint64_t)u * 64 + lane < row_end && x.c != 0xFFFFFFFFu && x.m >= 0 && x.nv > min_cov && (x.st == '+' || x.st == '-') && !(x.f < 0);
+        const uint32_t c = pre[u] ? x.c : 0u;
+        okv[u] = ok[(size_t)c * NM_CODE_STRIDE + (pre[u] ? x.m : 0)];
+        doffv[u] = dense_off[c];
+        chunkv[u] = contig_chunk[c];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t i0 = i00 + (uint64_t)u * 64;
+        if (i0 >= row_end) break;                                // wave-uniform
+        const uint64_t i = i0 + lane;
+        const RowCols x = cols[u];
+        const bool alive = pre[u] && okv[u] && doffv[u] != ~0ull;      // (doff == ~0: flagged by the scatter pass)
+        const uint32_t c = alive ? x.c : 0u;
+        const bool plus = x.st == '+';
+        // candidates for the adjacency test are queued; everybody else survives the filter
+        const bool cand = alive && !(x.f < meth_thr);
+        const unsigned long long cmask = __ballot(cand);
+        if (cmask) {                                             // (judged after the four pieces: at most 63 + 256 are waiting)
+            if (cand) myq[qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull))] = i;
+            qn += (uint32_t)__popcll(cmask);
+        }
+        const bool pass = alive && !cand;
+        const int m = pass ? x.m : 0;
+        const bool listed = pass && m < NM_MAX_MOD_CODES;        // codes beyond the ABI's eight are filtered with the rest, never reported
+        wave_add_keyed(kc, kept, listed ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, listed, false, 1);     // all lanes take part
+        my_kept += pass;
+        const int slot = listed ? sl.slot_of_mod[m] : -1;
+        const bool non = slot >= 0 && x.f <= low;                // (below the adjacency threshold: never methylated unless high < threshold)
+        const bool meth = slot >= 0 && x.f >= high;
+        // classified rows are counted; the host compares the total with the population count of the general planes
+        // afterwards — a duplicate (contig, position, strand) row sets a bit twice and shows up there
+        my_cls += meth || non;
+        const uint64_t g = (meth || non) ? (uint64_t)chunkv[u] * CHUNK_BP + x.pos : 0;
+        if (meth && !non) atomicOr(sl.planes[slot][plus ? 2 : 4] + (g >> 5), 1u << (g & 31));      // only with high < threshold
+        unsigned long long todo = __ballot(non);
+        const uint64_t w = g >> 5;
+        const uint32_t pid = non ? (uint32_t)slot * 2u + (plus ? 0u : 1u) : 0u;
+        const uint32_t bit = 1u << (g & 31);
+        while (todo) {                                           // wave-uniform; one turn unless a contig ends in this iteration
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lc = (uint32_t)__builtin_amdgcn_readlane((int)c, leader);
+            const uint64_t lw = readlane64(w, leader);
+            if (!have || lc != cur_contig || lw < w_base) {      // (lw < w_base: unordered input only)
+                flush_range(w_base, w_base + WIN, !sorted);
+                cur_contig = lc;
+                w_base = lw;
+                have = true;
+                if (first_word == ~0ull) first_word = lw;
+            } else if (lw >= w_base + WIN / 2) {                 // the words before the leader's are complete
+                flush_range(w_base, min(lw, w_base + WIN), !sorted);
+                w_base = lw;
+            }
+            const bool mine = non && c == lc && w >= w_base && w - w_base < WIN;
+            if (mine) atomicOr(&mytab[pid * WIN + (uint32_t)(w & (WIN - 1))], bit);
+            const unsigned long long done = __ballot(mine);
+            todo &= ~done;
+            if (!sorted) {                                       // unordered: whatever does not fit this window goes straight to memory
+                if (non && !mine && ((todo >> lane) & 1)) atomicOr(u_plane[pid] + w, bit);
+                todo = 0;
+            }
+        }
+        if (!sorted) flush_range(w_base, w_base + WIN, true);
+      }
+      while (qn >= 64) {                                         // wave-uniform
+        __asm__ volatile("" ::: "memory");
+        judge(64);
+        for (uint32_t k = lane; k + 64 < qn; k += 64) {          // the rest moves down (reads of a turn before its writes)
+            const unsigned long long moved = myq[k + 64];
+            __asm__ volatile("" ::: "memory");
+            myq[k] = moved;
+        }
+        qn -= 64;
+      }
     }
+    while (qn) {                                                 // the rest of the queue
+        const uint32_t n = min(qn, 64u);
+        __asm__ volatile("" ::: "memory");
+        judge(n);
+        const unsigned long long moved = lane + 64 < qn ? myq[lane + 64] : 0ull;
+        __asm__ volatile("" ::: "memory");
+        if (lane + 64 < qn) myq[lane] = moved;
+        qn -= n;
+    }
+    flush_range(w_base, w_base + WIN, true);                     // what is left may share its words with the next wave
     cache_flush(kc, kept, 1, lane);
     for (int d = 32; d; d >>= 1) {
         my_kept += __shfl_xor(my_kept, d);
@@ -405,6 +583,8 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     ING_ALLOC(d_ok, std::max<size_t>(n_fgroups, 1));
     ING_ALLOC(d_dense, npos * 8 * 2);
     ING_ALLOC(d_dense_off, (size_t)std::max(c->n_contigs, 1u) * 8);
+    unsigned int *d_order = nullptr;   // [0]: order flags of the rows (1: a position decreases inside a run, 2: a contig in several runs); [1..]: runs per contig
+    ING_ALLOC(d_order, ((size_t)c->n_contigs + 1) * 4);
     ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
@@ -412,6 +592,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 32, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_order, 0, ((size_t)c->n_contigs + 1) * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dense_off, dense_off.data(), (size_t)c->n_contigs * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
@@ -419,11 +600,12 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (n_rows && n_groups) {              // (a shard without contigs ignores every row)
         const dim3 grid((unsigned)((n_rows + 255) / 256));
         const dim3 walk((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32));      // waves walk contiguous row ranges
-        hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err);
-        hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_fgroups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_fgroups, d_cnt, 0.0001, 50u, d_ok);
-        hipLaunchKernelGGL(ingest_scatter_kernel, grid, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
+        hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err, d_order, d_order + 1);
+        hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_fgroups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_fgroups, d_cnt, 0.0001, 50u, d_ok, d_order + 1, d_order);
+        hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
+        if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
         hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
-                           c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_kept, d_scalars, d_scalars + 1);
+                           c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
     }
     // population of the general planes (all parts so far): the confident rows, and the duplicate check — every
     // classified row must have set its own bit; then the compact planes

@@ -15,11 +15,9 @@ from .motif import MOD_TYPE_TO_CANONICAL
 from .pileup import MOD_TYPES
 
 
-def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
-    """Generate (a shard of) ``mg`` on ``device`` and ingest it through the device-side filters.
-    Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
-    t = {}
-    t0 = time.perf_counter()
+def generate_raw(mg: synth.SynthMetagenome, device, contigs=None):
+    """(mine, lengths, offsets, bins, ASCII of the contigs back to back, raw pileup columns) of (a shard of) ``mg``, all
+    on ``device``: the inputs of nm_upload_contigs_device / nm_ingest_pileup."""
     mine = list(range(len(mg.names))) if contigs is None else sorted(int(i) for i in contigs)
     lengths = np.asarray([int(mg.lengths[i]) for i in mine], dtype=np.uint64)
     offsets = np.zeros(len(mine) + 1, dtype=np.uint64)
@@ -41,15 +39,31 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
         for k, i in enumerate(db.contigs):
             o = int(offsets[local_of[i]])
             ascii_all[o:o + int(mg.lengths[i])] = db.ascii_cat[st[k]:st[k] + int(mg.lengths[i])]
+        # the rows of a bin in modkit's order: sorted by (contig, position), mod codes and strands interleaved
+        part = {k: [] for k in cols}
         for mt in mg.spec.mod_types:
             p = db.pileups[mt]
-            cols["contig"].append(lut[p["contig_id"].to(torch.int64)].to(torch.int32))
-            cols["position"].append(p["position"])
-            cols["mod"].append(torch.full_like(p["strand"], MOD_TYPES.index(mt)).to(torch.int8))
-            cols["strand"].append(p["strand"])
-            cols["frac"].append(p["fraction_mod"])
-            cols["nvalid"].append(p["nvalid"].to(torch.int32))
+            part["contig"].append(lut[p["contig_id"].to(torch.int64)].to(torch.int32))
+            part["position"].append(p["position"])
+            part["mod"].append(torch.full_like(p["strand"], MOD_TYPES.index(mt)).to(torch.int8))
+            part["strand"].append(p["strand"])
+            part["frac"].append(p["fraction_mod"])
+            part["nvalid"].append(p["nvalid"].to(torch.int32))
+        part = {k: torch.cat(v) for k, v in part.items()}
+        key = (part["contig"].to(torch.int64) << 34) | (part["position"].to(torch.int64) << 2) | part["mod"].to(torch.int64)
+        order = torch.argsort(key)
+        for k in cols:
+            cols[k].append(part[k][order])
     cat = {k: torch.cat(v).contiguous() for k, v in cols.items()}
+    return mine, lengths, offsets, bins, ascii_all, cat
+
+
+def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
+    """Generate (a shard of) ``mg`` on ``device`` and ingest it through the device-side filters.
+    Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
+    t = {}
+    t0 = time.perf_counter()
+    mine, lengths, offsets, bins, ascii_all, cat = generate_raw(mg, device, contigs)
     # what the ingest will ask the allocator for (16 B per bp of dense maxima, the planes) is taken and given back to
     # torch's pool HERE, with the generation: a fresh hipMalloc of memory that another process used before is scrubbed
     # by the driver at 7-30 GB/s (DESIGN §7) — 0.4 s for this block right after the test suite, none on a fresh box —

@@ -3,6 +3,7 @@
 plus profiles/traffic.json (read by bench.py).   usage: python profiles/summarize.py gpurun_out/prof_<tag> <round>"""
 import collections
 import csv
+import hashlib
 import json
 import os
 import shutil
@@ -12,6 +13,11 @@ src, rnd = sys.argv[1], sys.argv[2]
 sub = sys.argv[3] if len(sys.argv) > 3 else ""          # optional sub-directory / workload tag (e.g. "greedy2")
 dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd, sub)
 os.makedirs(dst, exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("nmscan.hip", "nmscan_internal.h"):
+    _h.update(open(os.path.join(ROOT, "nanomotif_amd", "csrc", _f), "rb").read())
+KERNEL_SHA = _h.hexdigest()[:16]
 KEEP = ("score_kernel", "compile_kernel", "pack_kernel", "state_kernel", "needs_v_kernel")
 
 
@@ -70,6 +76,11 @@ out = {
     "correction": "gfx950: FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced streaming reads -> doubled "
                   "(MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
     "hbm_bytes_per_launch": traffic, "sq_insts_valu_per_launch": c["SQ_INSTS_VALU"], "sq_insts_salu_per_launch": c["SQ_INSTS_SALU"],
+    # the scalar side as numbers: cycles the scalar ALU spent on instructions, and cycles the sequencers were busy
+    "sq_inst_cycles_salu_per_launch": c.get("SQ_INST_CYCLES_SALU"), "sq_busy_cycles_per_launch": c.get("SQ_BUSY_CYCLES"),
+    "sq_wave_cycles_per_launch": c.get("SQ_WAVE_CYCLES"), "sq_active_inst_valu_per_launch": c.get("SQ_ACTIVE_INST_VALU"),
+    # ties the entry to the kernel source it was measured on (bench.py: roofline.traffic_stale)
+    "kernel_source_sha16": KERNEL_SHA,
     "source": [f"profiles/{rnd}/{sub + '/' if sub else ''}pmc_FETCH_SIZE.csv", f"profiles/{rnd}/{sub + '/' if sub else ''}pmc_WRITE_SIZE.csv",
                f"profiles/{rnd}/{sub + '/' if sub else ''}pmc_sq_insts.csv"],
 }
@@ -97,7 +108,8 @@ here hold the rows of this repository's kernels only.  Generated by `profiles/su
 | HBM traffic per launch | **{traffic:.4e} B = {traffic/algo:.2f} x algorithmic** (chunk padding 4.2 %, halo words, V plane of boundary chunks, programs) | `../traffic.json` |
 | TCC_EA0_RDREQ_sum | {c.get('TCC_EA0_RDREQ_sum', 0):.3e} requests (x 128 B = {c.get('TCC_EA0_RDREQ_sum', 0)*128:.3e} B); TCC hit {c.get('TCC_HIT_sum', 0):.3e} / miss {c.get('TCC_MISS_sum', 0):.3e} | `pmc_tcc.csv` |
 | SQ_INSTS_VALU / SALU / SMEM / LDS | {c['SQ_INSTS_VALU']/1e6:.1f} M / {c['SQ_INSTS_SALU']/1e6:.1f} M / {c['SQ_INSTS_SMEM']/1e6:.2f} M / {c['SQ_INSTS_LDS']/1e6:.2f} M wave-instructions per launch | `pmc_sq_insts.csv` |
-| integer-VALU rate | {c['SQ_INSTS_VALU']/(avg_us*1e-6)/1e11:.2f}e11 wave-instr/s = **{c['SQ_INSTS_VALU']/(avg_us*1e-6)/6.1e11*100:.0f} % of the 6.1e11 measured by `tools/valu_peak.hip`** (alignbit+and stream, one wave64 integer op per 4 cycles per SIMD) | see DESIGN.md §4 |
+| integer-VALU rate | {c['SQ_INSTS_VALU']/(avg_us*1e-6)/1e11:.2f}e11 wave-instr/s = **{c['SQ_INSTS_VALU']/(avg_us*1e-6)/1.2288e12*100:.0f} % of the chip's issue peak** (256 CU x 4 SIMD x 2.4 GHz / 2 cycles per wave64 op = 1.23e12) = {c['SQ_INSTS_VALU']/(avg_us*1e-6)/6.1e11*100:.0f} % of the 6.1e11 this instruction mix reaches in `tools/valu_peak.hip` (half its ops are the half-rate v_alignbit_b32) | see DESIGN.md §4 |
+| scalar side | SQ_INST_CYCLES_SALU {c.get('SQ_INST_CYCLES_SALU', 0)/1e6:.1f} M, SQ_BUSY_CYCLES {c.get('SQ_BUSY_CYCLES', 0)/1e6:.1f} M, SALU / VALU instructions {c['SQ_INSTS_SALU']/c['SQ_INSTS_VALU']:.2f} | `pmc_sq_insts.csv`, `pmc_sq_wait.csv` |
 | wave time split | ACTIVE_INST_ANY {c['SQ_ACTIVE_INST_ANY']/c['SQ_WAVE_CYCLES']*100:.0f} %, WAIT_INST_ANY {c['SQ_WAIT_INST_ANY']/c['SQ_WAVE_CYCLES']*100:.0f} %, WAIT_ANY {c['SQ_WAIT_ANY']/c['SQ_WAVE_CYCLES']*100:.0f} % of SQ_WAVE_CYCLES | `pmc_sq_wait.csv` |
 """
 open(os.path.join(dst, "SUMMARY.md"), "w").write(md)

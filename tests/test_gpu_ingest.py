@@ -261,3 +261,45 @@ def test_many_mod_codes_and_null_percentages_follow_the_reference_filters():
     f = op.filter_pileup_minimummod_frequency({k: v[:60] for k, v in small.items()}, min_mod_frequency=0.6)
     assert len(f["position"]) == 60
     eng.close()
+
+
+def test_modkit_order_takes_the_store_path_and_equals_any_other_order():
+    """Rows in modkit's order (every contig in one run, positions non-decreasing, mod codes and strands interleaved) let the
+    classification pass write complete plane words with plain stores; any other order (a contig in two runs, a position
+    going down) falls back to atomicOr.  Same kept counts, same confident rows, same scores either way — and equal to the
+    oracle filters."""
+    import os
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    spec = synth.SynthSpec(n_contigs=7, total_bp=900_000, n_bins=3, mod_types=("a", "m"), seed=87, min_contig_bp=30_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    t = _raw_table(mg, np.random.default_rng(8))
+    exp = op.prefilter({k: v.copy() for k, v in t.items()})
+    labels = {0: ("m", "C"), 1: ("a", "A")}
+    motifs = [(Motif("GATC", 1), "a"), (Motif("A", 0), "a"), (Motif("CC[AT]GG", 1), "m"), (Motif("C", 0), "m"), (Motif("T", 0), "a")]
+    cands = [(m, mt, b) for b in sorted(set(mg.bin_names)) for m, mt in motifs]
+    modkit = np.lexsort((t["mod_type"], t["position"], t["contig"]))
+    rng = np.random.default_rng(1)
+    two_runs = np.concatenate([modkit[: len(modkit) // 3], modkit[len(modkit) // 3:][::-1]])        # reversed tail: positions go down
+    orders = {"modkit": modkit, "contigs in another order": modkit[np.argsort(-t["contig"][modkit], kind="stable")],
+              "as generated (two runs per contig)": np.arange(len(modkit)), "reversed tail": two_runs, "shuffled": rng.permutation(len(modkit))}
+    out = {}
+    for name, o in orders.items():
+        for env in ((None, "1") if name == "modkit" else (None,)):
+            if env:
+                os.environ["NM_INGEST_ATOMIC"] = env
+            try:
+                eng = ScanEngine(0)
+                eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(len(mg.names))], mg.bin_names)
+                res = eng.ingest_pileup(t["contig"][o].astype(np.uint32), t["position"][o], t["mod_type"][o], t["strand"][o],
+                                        t["fraction_mod"][o], t["Nvalid_cov"][o], labels)
+                rows = sorted(zip(*[x.tolist() for x in res["confident"]]))
+                out[(name, env)] = (res["n_kept"], res["n_confident"], res["kept"].tolist(), rows, eng.score(cands).tolist())
+                eng.close()
+            finally:
+                os.environ.pop("NM_INGEST_ATOMIC", None)
+    first = out[("modkit", None)]
+    assert first[0] == len(exp["position"]) and first[1] > 0
+    for k, v in out.items():
+        assert v == first, k
