@@ -436,6 +436,33 @@ int nm_bed_ingest_columns(nm_bed *bed, const uint32_t *contig_lut, uint32_t n_lu
 int nm_bed_close(nm_bed *bed);
 
 /*
+ * Device-side bedMethyl parser — the same six columns as nm_bed_open, parsed ON THE GPU for plain-text pileups
+ * (dataload.py:15-34, 72-100): the host moves the file through pinned slabs into HBM; kernels find the lines, split the
+ * fields and convert the numbers with the host parser's own rules (integers digit by digit; the percentage through the
+ * correctly rounded fast path, anything else is handed to the host parser's routines and patched in), contig names
+ * become ids through a per-row hash and the runs of equal names (first-appearance order, like nm_bed_contig_name).
+ * Every row equals nm_bed_open's bit for bit.  The columns stay in device memory in the types nm_ingest_pileup takes with
+ * rows_on_device = 1.  Compressed input is refused (NM_EINVAL "compressed input": use nm_bed_open).
+ *   nm_bedcols_shape           rows, contigs, runs of equal contig names; times = {seconds in total, seconds copying the file}
+ *   nm_bedcols_runs            run_row[n_runs + 1] (first row of each run, then n_rows), run_contig[n_runs] (file contig id)
+ *   nm_bedcols_map_contigs     contig column = contig_lut[file contig id] (engine contig id or 0xFFFFFFFF)
+ *   nm_bedcols_device_columns  DEVICE pointers; contig_id is valid after nm_bedcols_map_contigs
+ */
+typedef struct nm_bedcols nm_bedcols;
+int nm_bed_parse_device(nm_ctx *ctx, const char *path, uint32_t threads, nm_bedcols **out);
+int nm_bedcols_shape(nm_bedcols *cols, uint64_t *n_rows, uint32_t *n_contigs, uint32_t *n_runs, double times[2]);
+int nm_bedcols_contig_name(nm_bedcols *cols, uint32_t i, const char **name);
+int nm_bedcols_mod_code(nm_bedcols *cols, uint32_t id, const char **code);
+int nm_bedcols_runs(nm_bedcols *cols, uint64_t *run_row, uint32_t *run_contig);
+int nm_bedcols_map_contigs(nm_bedcols *cols, const uint32_t *contig_lut, uint32_t n_lut);
+int nm_bedcols_device_columns(nm_bedcols *cols, const uint32_t **contig_id, const uint32_t **file_contig_id, const uint32_t **position,
+                              const int8_t **mod_type, const uint8_t **strand, const double **fraction_mod, const int32_t **nvalid_cov);
+int nm_bedcols_close(nm_bedcols *cols);
+/* Copy `bytes` from device memory the library handed out (e.g. the columns above) to host memory, after the work queued on
+ * the ctx stream. */
+int nm_device_read(nm_ctx *ctx, void *host_dst, const void *device_src, uint64_t bytes);
+
+/*
  * Native FASTA reader — replaces pyfastx / the line loop of fasta.py:35-49 plus DNAsequence's checks (seq.py:53-71):
  * plain or gzip / bgzip files; record name = first whitespace-delimited token of the header; sequences upper-cased,
  * all records back to back in nm_fasta_sequence; an empty record or a letter outside ATGCRYSWKMBDHVN is an error (the

@@ -1,0 +1,742 @@
+// libnmscan — device-side bedMethyl parser (C ABI: nm_bed_parse_device / nm_bedcols_*, include/nmscan.h).
+//
+// Replaces, for plain-text pileups, the host parser of nmbed.cpp on the ingestion side of the hot path (reference:
+// polars' scan_csv of the 18-column modkit pileup, nanomotif/dataload.py:15-34, 72-100).  At 1 Gbp the text is ~80 GB:
+// a host parser needs every core of the box for tens of seconds where the search itself takes a fraction of one.  Here the
+// host only moves bytes: file -> pinned slabs (threads) -> HBM (one stream), and the GPU does the rest per slab:
+//   line starts   popcount of "first byte of a non-empty line" per 16 KB block, prefix sum, one offset per line;
+//   fields        one thread per line: the six columns the reference keeps (1 contig, 2 start, 4 mod code, 6 strand,
+//                 10 N_valid_cov, 11 percent) with the host parser's own rules — integers digit by digit, the percentage
+//                 through Clinger's fast path (mantissa < 2^53, <= 22 decimals: ONE correctly rounded division, the same
+//                 bits as strtod), nulls "NA" / "null" / empty -> -1;
+//   contigs       a 64-bit hash of the name per row; a row whose hash differs from the row before starts a RUN — only the
+//                 runs (one per contig in a modkit file) go back to the host, which reads their names from the mapped file
+//                 and numbers them in first-appearance order;
+//   leftovers     rows the kernel will not decide (a mod code other than m / a / 21839, a number outside the fast path)
+//                 are listed and parsed by the host parser's routines (nmbed_parse.h), then patched in.
+// The columns stay in HBM in exactly the types nm_ingest_pileup takes (rows_on_device = 1): no pileup row ever exists
+// as a host array.  nmbed.cpp's parser is the bit-exactness oracle for every row (tests/test_gpu_bed_device.py).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include "nmbed_parse.h"
+#include "nmscan_internal.h"
+
+using namespace nmdetail;
+
+namespace {
+
+constexpr uint32_t BLOCK_BYTES = 16384;           // bytes per workgroup in the line-start passes (256 threads x 64 B)
+constexpr uint64_t SLAB_BYTES = 64ull << 20;            // per slab: 3 pinned + 2 device buffers of this size (pinning memory costs ~0.2 ms per MB)
+constexpr uint32_t PATCH_CAP = 1u << 22;
+
+enum RowError : uint32_t { E_NONE = 0, E_COLUMNS = 1, E_START = 2, E_COV = 3, E_PCT = 4, E_POS_RANGE = 5 };
+
+// bit k of the result = byte k of the 64 bytes at `base` is the first byte of a non-empty line.  The 64 bytes come as four
+// 16-byte loads (the text buffers are 16-byte aligned and padded); the bytes before and after them decide the edges.
+__device__ __forceinline__ unsigned long long line_start_mask(const uint8_t *__restrict__ b, uint64_t base, uint64_t n) {
+    if (base >= n) return 0;
+    unsigned long long nl = 0, cr = 0;                                  // bit k: byte k is '\n' / '\r'
+    const uint4 *v = reinterpret_cast<const uint4 *>(b + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 x = v[q];
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t c = (w[j] >> (8 * k)) & 0xFFu;
+                nl |= (unsigned long long)(c == '\n') << (q * 16 + j * 4 + k);
+                cr |= (unsigned long long)(c == '\r') << (q * 16 + j * 4 + k);
+            }
+    }
+    const uint64_t left = n - base;                                     // valid bytes here
+    const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+    const bool prev_nl = base == 0 || b[base - 1] == '\n';
+    const unsigned long long after_nl = (nl << 1) | (prev_nl ? 1ull : 0ull);           // byte k follows a newline (or starts the text)
+    // "\r\n" alone is an empty line: a '\r' whose next byte is '\n' or the end of the text
+    const bool next_nl = left <= 64 ? true : b[base + 64] == '\n';
+    const unsigned long long before_nl = (nl >> 1) | ((left <= 64 ? (1ull << (left - 1)) : 0ull)) | (next_nl && left >= 64 ? (1ull << 63) : 0ull);
+    return after_nl & ~nl & ~(cr & before_nl) & valid;
+}
+
+// (1) non-empty line starts per 16 KB block
+__global__ __launch_bounds__(256) void bed_count_kernel(const uint8_t *__restrict__ b, uint64_t n, uint32_t *__restrict__ block_cnt) {
+    __shared__ uint32_t part[4];
+    const uint64_t base = (uint64_t)blockIdx.x * BLOCK_BYTES + (uint64_t)threadIdx.x * 64;
+    uint32_t cnt = (uint32_t)__popcll(line_start_mask(b, base, n));
+    for (int o = 32; o; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+// (2) the offsets of those starts, in order
+__global__ __launch_bounds__(256) void bed_starts_kernel(const uint8_t *__restrict__ b, uint64_t n, const uint32_t *__restrict__ block_off,
+                                                         uint32_t *__restrict__ line_start) {
+    __shared__ uint32_t scan[256];
+    const uint64_t base = (uint64_t)blockIdx.x * BLOCK_BYTES + (uint64_t)threadIdx.x * 64;
+    unsigned long long mask = line_start_mask(b, base, n);
+    const uint32_t mine = (uint32_t)__popcll(mask);
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)d ? scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t at = block_off[blockIdx.x] + scan[threadIdx.x] - mine;
+    while (mask) {
+        const int k = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        line_start[at++] = (uint32_t)(base + k);
+    }
+}
+
+struct BedOut {
+    uint64_t *hash;             // [row] name hash
+    uint64_t *line_off;         // [row] file offset of the row's line
+    uint32_t *position;
+    int8_t *mod;
+    uint8_t *strand;
+    double *frac;
+    int32_t *nvalid;
+    unsigned long long *first_error;   // min over (row << 8 | code)
+    unsigned int *n_patch;
+    uint2 *patch;               // (row, flags) — a pileup holds fewer than 2^32 rows (checked)
+};
+
+__device__ __forceinline__ bool field_is_null(const uint8_t *p, uint32_t n) {
+    return n == 0 || (n == 2 && p[0] == 'N' && p[1] == 'A') || (n == 4 && p[0] == 'n' && p[1] == 'u' && p[2] == 'l' && p[3] == 'l');
+}
+
+__device__ __forceinline__ bool dev_parse_int(const uint8_t *p, uint32_t n, long long *out) {
+    if (n == 0) return false;
+    bool neg = false;
+    uint32_t i = 0;
+    if (p[0] == '-') { neg = true; i = 1; }
+    long long v = 0;
+    for (; i < n; ++i) {
+        const uint32_t d = (uint32_t)p[i] - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// (3) one thread per line
+__global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restrict__ b, uint64_t n, const uint32_t *__restrict__ line_start,
+                                                        uint32_t n_lines, uint64_t row0, uint64_t slab_file_off, BedOut o) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lines) return;
+    const uint64_t row = row0 + li;
+    const uint8_t *p = b + line_start[li];
+    const uint8_t *end = b + n;
+    // the line is walked once; the bounds of the six fields that matter are kept in registers (fields count from 0)
+    uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0, b3 = 0, e3 = 0, b5 = 0, e5 = 0, b9 = 0, e9 = 0, b10 = 0, e10 = 0;
+    uint32_t nf = 0, at = 0, start = 0;
+    bool ended = false;                                                 // the line ended (newline / end of text) inside field nf - 1
+    for (;;) {
+        const bool stop = p + at >= end || p[at] == '\n';
+        if (stop || p[at] == '\t') {
+            switch (nf) {
+                case 0: b0 = start; e0 = at; break;
+                case 1: b1 = start; e1 = at; break;
+                case 3: b3 = start; e3 = at; break;
+                case 5: b5 = start; e5 = at; break;
+                case 9: b9 = start; e9 = at; break;
+                case 10: b10 = start; e10 = at; break;
+                default: break;
+            }
+            ++nf;
+            if (stop) { ended = true; break; }
+            if (nf >= 11) break;
+            start = at + 1;
+        }
+        ++at;
+    }
+    uint32_t err = E_NONE;
+    if (nf < 11) err = E_COLUMNS;
+    // "\r\n" line ends: the host parser strips the '\r' before it splits the line; it can only sit in the last field
+    if (nf == 11 && ended && e10 > b10 && p[e10 - 1] == '\r') e10 -= 1;
+    if (nf < 11 && ended) {                                              // (a short line whose last field is "\r"-terminated is short either way)
+    }
+    // contig name: FNV-1a over the bytes, the length folded in
+    unsigned long long h = 1469598103934665603ull;
+    if (!err) {
+        for (uint32_t k = b0; k < e0; ++k) h = (h ^ p[k]) * 1099511628211ull;
+        h = (h ^ (unsigned long long)(e0 - b0)) * 1099511628211ull;
+    }
+    long long pos = 0, cov = -1;
+    double frac = -1.0;
+    uint32_t flags = 0;                                                 // 1: mod code for the host, 2: percentage for the host
+    int8_t mt = -1;
+    uint8_t st = '?';
+    if (!err) {
+        if (!dev_parse_int(p + b1, e1 - b1, &pos)) err = E_START;
+        else if (pos < 0 || pos > 0xFFFFFFFEll) err = E_POS_RANGE;
+    }
+    if (!err && !field_is_null(p + b9, e9 - b9) && !dev_parse_int(p + b9, e9 - b9, &cov)) err = E_COV;
+    if (!err) {
+        const uint8_t *q = p + b10;
+        const uint32_t ln = e10 - b10;
+        if (!field_is_null(q, ln)) {
+            // Clinger's fast path, exactly as nmbedparse::parse_double takes it; everything else is the host's
+            uint32_t i = 0;
+            bool neg = false, dot = false, ok = true;
+            if (q[0] == '-' || q[0] == '+') { neg = q[0] == '-'; i = 1; }
+            unsigned long long mant = 0;
+            int ndig = 0, dec = 0;
+            for (; i < ln; ++i) {
+                const uint32_t d = (uint32_t)q[i] - '0';
+                if (d <= 9) {
+                    if (mant > (0xFFFFFFFFFFFFFFFFull - 9) / 10) { ok = false; break; }
+                    mant = mant * 10 + d;
+                    dec += dot;
+                    ++ndig;
+                } else if (q[i] == '.' && !dot) {
+                    dot = true;
+                } else { ok = false; break; }
+            }
+            ok = ok && ndig > 0 && mant < (1ull << 53) && dec <= 22;
+            if (ok) {
+                double p10 = 1.0;
+                for (int k = 0; k < dec; ++k) p10 *= 10.0;               // exact up to 1e22
+                const double v = (double)mant / p10;
+                frac = (neg ? -v : v) / 100.0;                           // dataload.py:85
+            } else {
+                flags |= 2u;
+            }
+        }
+        const uint32_t ml = e3 - b3;
+        const uint8_t *m = p + b3;
+        if (ml == 1 && m[0] == 'm') mt = 0;
+        else if (ml == 1 && m[0] == 'a') mt = 1;
+        else if (ml == 5 && m[0] == '2' && m[1] == '1' && m[2] == '8' && m[3] == '3' && m[4] == '9') mt = 2;
+        else flags |= 1u;
+        st = e5 > b5 ? p[b5] : (uint8_t)'?';
+    }
+    if (err) {
+        atomicMin(o.first_error, ((unsigned long long)row << 8) | err);
+        o.hash[row] = 0;
+        return;
+    }
+    o.hash[row] = h;
+    o.line_off[row] = slab_file_off + line_start[li];
+    o.position[row] = (uint32_t)pos;
+    o.mod[row] = mt;
+    o.strand[row] = st;
+    o.frac[row] = frac;
+    o.nvalid[row] = cov < 0 ? -1 : (int32_t)(cov > 0x7FFFFFFF ? 0x7FFFFFFF : cov);
+    if (flags) {
+        const unsigned int k = atomicAdd(o.n_patch, 1u);
+        if (k < PATCH_CAP) o.patch[k] = make_uint2((uint32_t)row, flags);
+    }
+}
+
+// (4) rows whose contig name differs from the row before: the starts of the runs
+__global__ void bed_runs_kernel(const uint64_t *__restrict__ hash, uint64_t n_rows, unsigned int *n_runs, unsigned long long *run_row, uint32_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    if (i == 0 || hash[i] != hash[i - 1]) {
+        const unsigned int k = atomicAdd(n_runs, 1u);
+        if (k < cap) run_row[k] = i;
+    }
+}
+
+// (5) contig column from the run table (ascending run starts): id of the last run that starts at or before the row
+__global__ void bed_fill_contig_kernel(uint64_t n_rows, const unsigned long long *__restrict__ run_row, const uint32_t *__restrict__ run_id,
+                                       uint32_t n_runs, uint32_t *__restrict__ contig) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    uint32_t lo = 0, hi = n_runs - 1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (run_row[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    contig[i] = run_id[lo];
+}
+
+__global__ void bed_gather_off_kernel(uint32_t n, const unsigned long long *__restrict__ rows, const uint64_t *__restrict__ line_off,
+                                      unsigned long long *__restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = line_off[rows[k]];
+}
+
+__global__ void bed_patch_kernel(uint32_t n, const unsigned long long *__restrict__ row, const int8_t *__restrict__ mod, const double *__restrict__ frac,
+                                 const uint8_t *__restrict__ what, int8_t *__restrict__ out_mod, double *__restrict__ out_frac) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (what[k] & 1) out_mod[row[k]] = mod[k];
+    if (what[k] & 2) out_frac[row[k]] = frac[k];
+}
+
+__global__ void bed_map_contigs_kernel(uint64_t n_rows, const uint32_t *__restrict__ lut, const uint32_t *__restrict__ file_id, uint32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) out[i] = lut[file_id[i]];
+}
+
+}  // namespace
+
+struct nm_bedcols {
+    nm_ctx *ctx = nullptr;
+    uint64_t n_rows = 0, cap = 0;
+    uint32_t *d_file_contig = nullptr, *d_contig = nullptr, *d_position = nullptr;
+    int8_t *d_mod = nullptr;
+    uint8_t *d_strand = nullptr;
+    double *d_frac = nullptr;
+    int32_t *d_nvalid = nullptr;
+    uint64_t *d_hash = nullptr, *d_line_off = nullptr;      // scratch of the parse: released when it is done
+    std::vector<std::string> names, other_mods;
+    std::vector<const char *> name_ptrs;
+    std::vector<uint64_t> run_row;          // ascending, + n_rows at the end
+    std::vector<uint32_t> run_contig;
+    double t_read = 0, t_total = 0;
+};
+
+namespace {
+
+void free_cols(nm_bedcols *b) {
+    void *ptrs[] = {b->d_file_contig, b->d_contig, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, b->d_hash, b->d_line_off};
+    for (void *p : ptrs)
+        if (p) (void)dev_free(p);
+    b->d_file_contig = b->d_contig = b->d_position = nullptr;
+    b->d_mod = nullptr; b->d_strand = nullptr; b->d_frac = nullptr; b->d_nvalid = nullptr; b->d_hash = b->d_line_off = nullptr;
+}
+
+// grow the six output columns (+ hash) to hold `rows`; device-to-device copies of what is there
+int grow(nm_bedcols *b, uint64_t rows, hipStream_t s) {
+    if (rows <= b->cap) return NM_OK;
+    const uint64_t ncap = std::max<uint64_t>(rows, b->cap + b->cap / 2);
+    auto regrow = [&](void **p, size_t esz) -> int {
+        void *q = nullptr;
+        HIP_TRY(device_alloc(&q, ncap * esz));
+        if (*p && b->n_rows) HIP_TRY(hipMemcpyAsync(q, *p, b->n_rows * esz, hipMemcpyDeviceToDevice, s));
+        if (*p) {
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)dev_free(*p);
+        }
+        *p = q;
+        return NM_OK;
+    };
+    int rc;
+    if ((rc = regrow((void **)&b->d_position, 4)) || (rc = regrow((void **)&b->d_mod, 1)) || (rc = regrow((void **)&b->d_strand, 1)) ||
+        (rc = regrow((void **)&b->d_frac, 8)) || (rc = regrow((void **)&b->d_nvalid, 4)) || (rc = regrow((void **)&b->d_hash, 8)) ||
+        (rc = regrow((void **)&b->d_line_off, 8)))
+        return rc;
+    b->cap = ncap;
+    return NM_OK;
+}
+
+const char *row_error_text(uint32_t code) {
+    switch (code) {
+        case E_COLUMNS: return "pileup line with fewer than 11 tab-separated columns";
+        case E_START: return "pileup column 2 (start) is not an integer";
+        case E_COV: return "pileup column 10 (Nvalid_cov) is not an integer";
+        case E_PCT: return "pileup column 11 (percent modified) is not a number";
+        case E_POS_RANGE: return "pileup position beyond 4 Gbp";
+        default: return "malformed pileup line";
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_bedcols_close(nm_bedcols *b) {
+    if (!b) return NM_OK;
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    free_cols(b);
+    delete b;
+    return NM_OK;
+}
+
+int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcols **out) {
+    if (!c || !path || !out) return fail(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    HIP_TRY(hipSetDevice(c->device));
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(NM_EINVAL, "cannot open pileup '%s'", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(NM_EINVAL, "cannot stat pileup '%s'", path); }
+    const uint64_t n = (uint64_t)st.st_size;
+    const uint8_t *file = nullptr;
+    if (n) {
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return fail(NM_EINVAL, "cannot map pileup '%s'", path); }
+        file = static_cast<const uint8_t *>(m);
+    }
+    close(fd);
+    struct Unmap {
+        const uint8_t *p; uint64_t n;
+        ~Unmap() { if (p) munmap(const_cast<uint8_t *>(p), n); }
+    } unmap{file, n};
+    if (n >= 2 && file[0] == 31 && file[1] == 139) return fail(NM_EINVAL, "%s: compressed input: the device parser reads plain text (use nm_bed_open)", path);
+    nm_bedcols *b = new (std::nothrow) nm_bedcols();
+    if (!b) return fail(NM_ENOMEM, "out of host memory");
+    b->ctx = c;
+    struct Fail { nm_bedcols *b; bool keep = false; ~Fail() { if (!keep) (void)nm_bedcols_close(b); } } guard{b};
+    // slabs of whole lines
+    std::vector<uint64_t> cut(1, 0);
+    while (cut.back() < n) {
+        uint64_t e = std::min<uint64_t>(n, cut.back() + SLAB_BYTES);
+        if (e < n) {
+            const uint64_t lo = cut.back();
+            while (e > lo && file[e - 1] != '\n') --e;
+            if (e == lo) return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)SLAB_BYTES);
+        }
+        cut.push_back(e);
+    }
+    const size_t n_slabs = cut.size() - 1;
+    // pinned ring + producer thread: file -> pinned, several copy threads per slab
+    constexpr int RING = 3;
+    uint8_t *h_ring[RING] = {nullptr, nullptr, nullptr};
+    uint8_t *d_slab[2] = {nullptr, nullptr};
+    uint32_t *d_line_start = nullptr, *d_block_cnt = nullptr, *d_block_off = nullptr;
+    unsigned long long *d_first_error = nullptr, *d_run_row = nullptr;
+    unsigned int *d_counters = nullptr;           // [0] patches, [1] runs
+    uint2 *d_patch = nullptr;
+    void *d_scan_tmp = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t h2d_done[RING] = {nullptr, nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
+    std::vector<void *> dev_tmp;
+    struct Cleanup {
+        uint8_t **h; uint8_t **d; std::vector<void *> &tmp; hipStream_t &cs; hipEvent_t *e1; hipEvent_t *e2; nm_ctx *c;
+        ~Cleanup() {
+            (void)hipStreamSynchronize(c->stream);
+            if (cs) (void)hipStreamSynchronize(cs);
+            for (int i = 0; i < RING; ++i) { if (h[i]) (void)hipHostFree(h[i]); if (e1[i]) (void)hipEventDestroy(e1[i]); }
+            for (int i = 0; i < 2; ++i) { if (d[i]) (void)dev_free(d[i]); if (e2[i]) (void)hipEventDestroy(e2[i]); }
+            for (void *p : tmp) (void)dev_free(p);
+            if (cs) (void)hipStreamDestroy(cs);
+        }
+    } cleanup{h_ring, d_slab, dev_tmp, copy_stream, h2d_done, parsed, c};
+    const uint64_t slab_cap = std::min<uint64_t>(SLAB_BYTES, std::max<uint64_t>(n, 1));
+    const uint32_t max_blocks = (uint32_t)((slab_cap + BLOCK_BYTES - 1) / BLOCK_BYTES);
+    const uint64_t max_lines = slab_cap / 2 + 1;                          // a non-empty line and its '\n'
+    if (n_slabs) {
+        for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(hipHostMalloc((void **)&h_ring[i], slab_cap, hipHostMallocDefault));
+        for (int i = 0; i < 2 && (size_t)i < n_slabs; ++i) HIP_TRY(dev_malloc(&d_slab[i], slab_cap + 128));
+        for (int i = 0; i < RING; ++i) HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&parsed[i], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    }
+    auto tmp_alloc = [&](void **p, size_t bytes) -> hipError_t {
+        const hipError_t e = device_alloc(p, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) dev_tmp.push_back(*p);
+        return e;
+    };
+    // (line starts of a slab: worst case one per two bytes is absurd for a pileup; sized for lines of >= 16 bytes, checked)
+    const uint64_t line_cap = std::min<uint64_t>(max_lines, slab_cap / 16 + 1024);
+    HIP_TRY(tmp_alloc((void **)&d_line_start, line_cap * 4));
+    HIP_TRY(tmp_alloc((void **)&d_block_cnt, ((size_t)max_blocks + 1) * 4));
+    HIP_TRY(tmp_alloc((void **)&d_block_off, ((size_t)max_blocks + 1) * 4));
+    HIP_TRY(tmp_alloc((void **)&d_first_error, 8));
+    HIP_TRY(tmp_alloc((void **)&d_counters, 8));
+    HIP_TRY(tmp_alloc((void **)&d_patch, (size_t)PATCH_CAP * sizeof(uint2)));
+    size_t scan_bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)max_blocks + 1, rocprim::plus<unsigned int>(), c->stream));
+    HIP_TRY(tmp_alloc(&d_scan_tmp, scan_bytes));
+    HIP_TRY(hipMemsetAsync(d_first_error, 0xFF, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(d_counters, 0, 8, c->stream));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t filled = 0, consumed = 0;              // slabs copied into the ring / slabs whose H2D has been waited for
+    bool stop = false;
+    double t_read = 0;
+    std::thread producer([&] {
+        for (size_t k = 0; k < n_slabs; ++k) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || k < consumed + RING; });
+                if (stop) return;
+            }
+            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            const uint64_t lo = cut[k], len = cut[k + 1] - cut[k];
+            uint8_t *dst = h_ring[k % RING];
+            std::vector<std::thread> pool;
+            const unsigned nt = std::max(1u, threads - 1);
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&, t] {
+                    const uint64_t a = len * t / nt, e = len * (t + 1) / nt;
+                    memcpy(dst + a, file + lo + a, e - a);
+                });
+            for (auto &th : pool) th.join();
+            t_read += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                filled = k + 1;
+            }
+            cv.notify_all();
+        }
+    });
+    struct Join {
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; bool &stop;
+        ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+    } join{producer, mu, cv, stop};
+
+    for (size_t k = 0; k < n_slabs; ++k) {
+        const uint64_t len = cut[k + 1] - cut[k];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return filled > k; });
+        }
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(copy_stream, parsed[k % 2], 0));       // the device slab is free again
+        HIP_TRY(hipMemcpyAsync(d_slab[k % 2], h_ring[k % RING], len, hipMemcpyHostToDevice, copy_stream));
+        HIP_TRY(hipEventRecord(h2d_done[k % RING], copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, h2d_done[k % RING], 0));
+        const uint32_t nblk = (uint32_t)((len + BLOCK_BYTES - 1) / BLOCK_BYTES);
+        hipLaunchKernelGGL(bed_count_kernel, dim3(nblk), dim3(256), 0, c->stream, d_slab[k % 2], len, d_block_cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(d_block_cnt + nblk, 0, 4, c->stream));
+        HIP_TRY(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)nblk + 1, rocprim::plus<unsigned int>(), c->stream));
+        uint32_t n_lines = 0;
+        HIP_TRY(hipMemcpyAsync(&n_lines, d_block_off + nblk, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        {   // the pinned buffer of this slab may be refilled once its H2D is done (it is: the count kernel ran after it)
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = k + 1;
+        }
+        cv.notify_all();
+        if (n_lines > line_cap) return fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path);
+        if (b->n_rows + n_lines >= 0xFFFFFFFFull) return fail(NM_ERANGE, "%s: more than 4G rows in one pileup", path);
+        // the columns are sized ONCE, from the line density of the first slab (+ 3 % and one slab's worth of slack): every
+        // regrow is a fresh allocation (scrubbed by the driver when the memory was used before) plus a copy
+        uint64_t want = b->n_rows + n_lines;
+        if (k == 0 && n_slabs > 1) want = std::max<uint64_t>(want, (uint64_t)((double)n_lines * ((double)n / (double)len) * 1.03) + n_lines);
+        int rc = grow(b, want, c->stream);
+        if (rc) return rc;
+        if (n_lines) {
+            hipLaunchKernelGGL(bed_starts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_slab[k % 2], len, d_block_off, d_line_start);
+            BedOut o{b->d_hash, b->d_line_off, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
+            hipLaunchKernelGGL(bed_parse_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_slab[k % 2], len, d_line_start, n_lines, b->n_rows,
+                               cut[k], o);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
+        b->n_rows += n_lines;
+    }
+    unsigned long long first_error = ~0ull;
+    HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (first_error != ~0ull) return fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF)));
+    // file offsets of the lines of a list of rows (ascending rows in, offsets out)
+    auto offsets_of = [&](const std::vector<unsigned long long> &rows, std::vector<unsigned long long> &offs) -> int {
+        offs.resize(rows.size());
+        if (rows.empty()) return NM_OK;
+        unsigned long long *d_rows = nullptr, *d_offs = nullptr;
+        HIP_TRY(tmp_alloc((void **)&d_rows, rows.size() * 8));
+        HIP_TRY(tmp_alloc((void **)&d_offs, rows.size() * 8));
+        HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bed_gather_off_kernel, dim3((unsigned)((rows.size() + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)rows.size(), d_rows,
+                           b->d_line_off, d_offs);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(offs.data(), d_offs, rows.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NM_OK;
+    };
+    auto field = [&](uint64_t line, int k, const char **fb, const char **fe) {     // k-th tab-separated field of the line at `line`
+        const char *p = reinterpret_cast<const char *>(file) + line, *end = reinterpret_cast<const char *>(file) + n;
+        const char *le = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+        if (!le) le = end;
+        if (le > p && le[-1] == '\r') --le;
+        for (int i = 0; i < k; ++i) {
+            const char *t = static_cast<const char *>(memchr(p, '\t', (size_t)(le - p)));
+            p = t ? t + 1 : le;
+        }
+        const char *t = static_cast<const char *>(memchr(p, '\t', (size_t)(le - p)));
+        *fb = p;
+        *fe = t ? t : le;
+    };
+    // ---- runs of equal contig names -> names, ids, the contig column
+    if (b->n_rows) {
+        const uint32_t run_cap = 1u << 22;
+        HIP_TRY(tmp_alloc((void **)&d_run_row, (size_t)run_cap * 8));
+        hipLaunchKernelGGL(bed_runs_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->d_hash, b->n_rows, d_counters + 1, d_run_row, run_cap);
+        HIP_TRY(hipGetLastError());
+        unsigned int n_runs = 0;
+        HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (n_runs > run_cap) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, run_cap);
+        std::vector<unsigned long long> rows(n_runs), offs;
+        HIP_TRY(hipMemcpy(rows.data(), d_run_row, (size_t)n_runs * 8, hipMemcpyDeviceToHost));
+        std::sort(rows.begin(), rows.end());
+        int rc = offsets_of(rows, offs);
+        if (rc) return rc;
+        std::unordered_map<std::string, uint32_t> ids;
+        b->run_row.assign(rows.begin(), rows.end());
+        b->run_contig.resize(n_runs);
+        for (unsigned int r = 0; r < n_runs; ++r) {
+            const char *fb, *fe;
+            field(offs[r], 0, &fb, &fe);
+            std::string name(fb, fe);
+            auto it = ids.find(name);
+            if (it == ids.end()) {
+                it = ids.emplace(name, (uint32_t)b->names.size()).first;
+                b->names.push_back(name);
+            }
+            b->run_contig[r] = it->second;
+        }
+        b->run_row.push_back(b->n_rows);
+        uint32_t *d_run_id = nullptr;
+        HIP_TRY(tmp_alloc((void **)&d_run_id, (size_t)n_runs * 4));
+        HIP_TRY(dev_malloc(&b->d_file_contig, b->n_rows * 4));
+        HIP_TRY(dev_malloc(&b->d_contig, b->n_rows * 4));
+        HIP_TRY(hipMemcpyAsync(d_run_row, rows.data(), (size_t)n_runs * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_run_id, b->run_contig.data(), (size_t)n_runs * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(bed_fill_contig_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->n_rows, d_run_row, d_run_id, n_runs,
+                           b->d_file_contig);
+        HIP_TRY(hipGetLastError());
+        // ---- the rows left to the host parser's routines: other mod codes (numbered in first-appearance order, like the
+        // host reader does), percentages outside the fast path
+        unsigned int np = 0;
+        HIP_TRY(hipMemcpyAsync(&np, d_counters, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (np > PATCH_CAP) return fail(NM_ERANGE, "%s: more than %u rows need the host parser (unusual mod codes / number formats): use nm_bed_open", path, PATCH_CAP);
+        if (np) {
+            std::vector<uint2> patch(np);
+            HIP_TRY(hipMemcpy(patch.data(), d_patch, (size_t)np * sizeof(uint2), hipMemcpyDeviceToHost));
+            std::sort(patch.begin(), patch.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
+            std::vector<unsigned long long> prow(np), poff;
+            for (unsigned int i = 0; i < np; ++i) prow[i] = patch[i].x;
+            rc = offsets_of(prow, poff);
+            if (rc) return rc;
+            std::vector<int8_t> pmod(np, 0);
+            std::vector<double> pfrac(np, 0.0);
+            std::vector<uint8_t> pwhat(np, 0);
+            for (unsigned int i = 0; i < np; ++i) {
+                pwhat[i] = (uint8_t)patch[i].y;
+                const char *fb, *fe;
+                if (patch[i].y & 1u) {
+                    field(poff[i], 3, &fb, &fe);
+                    const std::string code(fb, fe);
+                    size_t k = 0;
+                    for (; k < b->other_mods.size(); ++k)
+                        if (b->other_mods[k] == code) break;
+                    if (k == b->other_mods.size()) b->other_mods.push_back(code);
+                    if (k > 100) return fail(NM_EINVAL, "%s: more than 100 distinct modification codes in column 4", path);
+                    pmod[i] = (int8_t)(3 + k);
+                }
+                if (patch[i].y & 2u) {
+                    field(poff[i], 10, &fb, &fe);
+                    double pct = 0;
+                    if (!nmbedparse::parse_double(fb, fe, &pct)) return fail(NM_EINVAL, "%s: pileup column 11 (percent modified) is not a number", path);
+                    pfrac[i] = pct / 100.0;
+                }
+            }
+            unsigned long long *d_prow = nullptr;
+            int8_t *d_pmod = nullptr;
+            double *d_pfrac = nullptr;
+            uint8_t *d_pwhat = nullptr;
+            HIP_TRY(tmp_alloc((void **)&d_prow, (size_t)np * 8));
+            HIP_TRY(tmp_alloc((void **)&d_pmod, np));
+            HIP_TRY(tmp_alloc((void **)&d_pfrac, (size_t)np * 8));
+            HIP_TRY(tmp_alloc((void **)&d_pwhat, np));
+            HIP_TRY(hipMemcpyAsync(d_prow, prow.data(), (size_t)np * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_pmod, pmod.data(), np, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_pfrac, pfrac.data(), (size_t)np * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_pwhat, pwhat.data(), np, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(bed_patch_kernel, dim3((np + 255) / 256), dim3(256), 0, c->stream, np, d_prow, d_pmod, d_pfrac, d_pwhat, b->d_mod, b->d_frac);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)dev_free(b->d_hash);
+        (void)dev_free(b->d_line_off);
+        b->d_hash = b->d_line_off = nullptr;
+    }
+    for (auto &s_ : b->names) b->name_ptrs.push_back(s_.c_str());
+    b->t_read = t_read;
+    b->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin;
+    guard.keep = true;
+    *out = b;
+    return NM_OK;
+}
+
+int nm_bedcols_shape(nm_bedcols *b, uint64_t *n_rows, uint32_t *n_contigs, uint32_t *n_runs, double times[2]) {
+    if (!b || !n_rows || !n_contigs) return fail(NM_EINVAL, "NULL argument");
+    *n_rows = b->n_rows;
+    *n_contigs = (uint32_t)b->names.size();
+    if (n_runs) *n_runs = (uint32_t)b->run_contig.size();
+    if (times) { times[0] = b->t_total; times[1] = b->t_read; }
+    return NM_OK;
+}
+
+int nm_bedcols_contig_name(nm_bedcols *b, uint32_t i, const char **name) {
+    if (!b || !name || i >= b->name_ptrs.size()) return fail(NM_EINVAL, "bad contig index");
+    *name = b->name_ptrs[i];
+    return NM_OK;
+}
+
+int nm_bedcols_mod_code(nm_bedcols *b, uint32_t id, const char **code) {
+    static const char *known[3] = {"m", "a", "21839"};
+    if (!b || !code) return fail(NM_EINVAL, "NULL argument");
+    if (id < 3) { *code = known[id]; return NM_OK; }
+    if (id - 3 >= b->other_mods.size()) return fail(NM_EINVAL, "mod id %u not present", id);
+    *code = b->other_mods[id - 3].c_str();
+    return NM_OK;
+}
+
+int nm_bedcols_runs(nm_bedcols *b, uint64_t *run_row, uint32_t *run_contig) {
+    if (!b || !run_row || !run_contig) return fail(NM_EINVAL, "NULL argument");
+    memcpy(run_row, b->run_row.data(), b->run_row.size() * 8);
+    memcpy(run_contig, b->run_contig.data(), b->run_contig.size() * 4);
+    return NM_OK;
+}
+
+int nm_bedcols_map_contigs(nm_bedcols *b, const uint32_t *contig_lut, uint32_t n_lut) {
+    if (!b || !contig_lut) return fail(NM_EINVAL, "NULL argument");
+    if (n_lut != b->names.size()) return fail(NM_EINVAL, "contig_lut has %u entries, the pileup names %zu contigs", n_lut, b->names.size());
+    if (b->n_rows == 0) return NM_OK;
+    nm_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t *d_lut = nullptr;
+    HIP_TRY(dev_malloc(&d_lut, (size_t)std::max(n_lut, 1u) * 4));
+    HIP_TRY(hipMemcpyAsync(d_lut, contig_lut, (size_t)n_lut * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bed_map_contigs_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->n_rows, d_lut, b->d_file_contig, b->d_contig);
+    const hipError_t e = hipGetLastError();
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)dev_free(d_lut);
+    if (e != hipSuccess || e2 != hipSuccess) return fail(NM_EHIP, "contig mapping failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return NM_OK;
+}
+
+int nm_device_read(nm_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) {
+    if (!c || (bytes && (!host_dst || !device_src))) return fail(NM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NM_OK;
+}
+
+int nm_bedcols_device_columns(nm_bedcols *b, const uint32_t **contig_id, const uint32_t **file_contig_id, const uint32_t **position, const int8_t **mod_type,
+                              const uint8_t **strand, const double **fraction_mod, const int32_t **nvalid_cov) {
+    if (!b) return fail(NM_EINVAL, "NULL argument");
+    if (contig_id) *contig_id = b->d_contig;
+    if (file_contig_id) *file_contig_id = b->d_file_contig;
+    if (position) *position = b->d_position;
+    if (mod_type) *mod_type = b->d_mod;
+    if (strand) *strand = b->d_strand;
+    if (fraction_mod) *fraction_mod = b->d_frac;
+    if (nvalid_cov) *nvalid_cov = b->d_nvalid;
+    return NM_OK;
+}
+
+}  // extern "C"

@@ -568,6 +568,52 @@ class ScanEngine:
         return dict(n_kept=int(n_kept.value), n_confident=self._n_confident,
                     confident=self.confident_rows() if want_rows else None, kept=kept)
 
+    def ingest_device_pileup(self, table, lut, labels, low=0.3, high=0.7, max_part_rows=None):
+        """``ingest_pileup`` for a ``pileup.DevicePileup`` (columns already in device memory, parsed there): ``lut`` maps
+        the file's contig ids to engine contig indices (0xFFFFFFFF: not held here).  Parts are cut at the runs of equal
+        contig names the parser reports.  Returns dict(n_kept, n_confident, kept)."""
+        lut = np.ascontiguousarray(lut, dtype=np.uint32)
+        table.map_contigs(lut)
+        ptr = table.device_pointers()
+        esz = {"contig": 4, "position": 4, "mod_type": 1, "strand": 1, "fraction_mod": 8, "nvalid_cov": 4}
+        slot_of = (C.c_int32 * 8)(*([-1] * 8))
+        canon = (C.c_uint8 * 8)(*([0] * 8))
+        for code, (label, base) in labels.items():
+            if label not in self.slot_of_mod:
+                n_slots = len(set(self.slot_of_mod.values()))
+                if n_slots >= 8:
+                    raise ValueError("at most 8 pileup classifications resident")
+                self.slot_of_mod[label] = n_slots
+            slot_of[int(code)] = self.slot_of_mod[label]
+            canon[int(code)] = ord(base)
+        run_eng = lut[table.run_contig]                                   # engine contig of every run
+        real = run_eng[run_eng != 0xFFFFFFFF]
+        one_run_each = len(np.unique(real)) == len(real)
+        n = len(table)
+        bounds = [0]
+        if one_run_each and max_part_rows and n > max_part_rows:
+            at = 0
+            for e in table.run_row[1:].tolist():
+                if e - at >= max_part_rows:
+                    bounds.append(int(e))
+                    at = e
+        if bounds[-1] != n:
+            bounds.append(n)
+        n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
+        for k in range(len(bounds) - 1):
+            a, b = bounds[k], bounds[k + 1]
+            in_part = (table.run_row[:-1] >= a) & (table.run_row[:-1] < b)
+            ids = np.unique(run_eng[in_part])
+            ids = np.ascontiguousarray(ids[ids != 0xFFFFFFFF], dtype=np.uint32)
+            col = lambda name: C.c_void_p(ptr[name] + a * esz[name])
+            _lib.check(self.lib.nm_ingest_pileup_part(self.ctx, b - a, col("contig"), col("position"), col("mod_type"), col("strand"),
+                                                      col("fraction_mod"), col("nvalid_cov"), slot_of, canon, float(low), float(high), 1,
+                                                      1 if k == 0 else 0, len(ids), _ptr(ids, C.c_uint32), C.byref(n_kept), C.byref(n_conf)))
+        self._n_confident = int(n_conf.value)
+        kept = np.zeros((len(self.contig_names), 8), dtype=np.uint32)
+        _lib.check(self.lib.nm_ingest_results(self.ctx, None, None, None, None, 0, _ptr(kept, C.c_uint32)))
+        return dict(n_kept=int(n_kept.value), n_confident=self._n_confident, confident=None, kept=kept)
+
     @staticmethod
     def _pileup_parts(cid: np.ndarray, max_rows: int):
         """[(begin, end)] row ranges of about ``max_rows`` rows cut where the contig id changes, or None when some contig's

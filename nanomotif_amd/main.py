@@ -101,9 +101,24 @@ def find_motifs_bin(args):
     # native reader, raw rows kept in native memory; a bgzip pileup is read through its tabix index: only the blocks
     # of the contigs that are in a bin and in the assembly (find_motifs_bin.py:233-246 fetches per bin)
     wanted = list(dict.fromkeys(fasta.original_name(c) for c in cfg.bin_contig if c in assembly)) if bgzip else None
-    table = pileup_mod.NativePileup(cfg.pileup_path, contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
-    how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
-    log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
+    # plain text is parsed ON THE GPU (nm_bed_parse_device: the host only moves the file through pinned slabs; every row
+    # equals the host parser's bit for bit); compressed input, a contig listed under several bins (its rows are needed
+    # twice) and NANOMOTIF_HOST_PARSER=1 take the host parser
+    table = None
+    if not bgzip and os.environ.get("NANOMOTIF_HOST_PARSER") != "1" and not any(fasta.ALIAS_SEP in c for c in cfg.bin_contig):
+        try:
+            table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0)
+            log.info(f"pileup: {len(table):,} rows parsed on the device ({time.perf_counter() - t0:.1f}s, {table.seconds_reading:.1f}s of it "
+                     f"moving the file)")
+        except NmScanError as e:
+            if "use nm_bed_open" not in str(e):
+                raise
+            log.info(f"pileup: the device parser declined ({e}); using the host parser")
+    if table is None:
+        table = pileup_mod.NativePileup(cfg.pileup_path, contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
+        how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
+        log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
+    on_device = isinstance(table, pileup_mod.DevicePileup)
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they
     # balance (independent searches, no collective until the rows are gathered), else the contigs of every bin are
@@ -174,7 +189,7 @@ def find_motifs_bin(args):
         placements = [(file_id[fasta.original_name(c)], local_id[c]) for c in mine
                       if fasta.ALIAS_SEP in c and fasta.original_name(c) in file_id]
         file_contig = table.file_contig_column().copy() if placements else None
-        cols = table.ingest_columns(lut)          # views in the engine's types; refuses positions >= 4 Gbp
+        cols = None if on_device else table.ingest_columns(lut)          # views in the engine's types; refuses positions >= 4 Gbp
         labels = {i: (mt, MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)}
         t0 = time.perf_counter()
         low, high = cfg.methylation_threshold_low, cfg.methylation_threshold_high
@@ -184,14 +199,20 @@ def find_motifs_bin(args):
         for fid, local in placements:
             sel = np.flatnonzero(file_contig == fid)
             extra.append(dict(contig=np.full(len(sel), local, np.uint32), **{k: cols[k][sel] for k in ("position", "mod_type", "strand", "fraction_mod", "nvalid_cov")}))
-        res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
-                                cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
+        if on_device:
+            res = eng.ingest_device_pileup(table, lut, labels, low=low, high=high, max_part_rows=part_rows)
+        else:
+            res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
+                                    cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
         store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
         rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
         if (low, high) == (0.3, 0.7):
             for mt in pileup_mod.MOD_TYPES:
                 eng.alias_label((mt, "merge"), mt)
-        else:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
+        elif on_device:   # the merge stage always runs at 0.3 / 0.7 (find_motifs_bin.py:569, 1436): a second classification
+            eng.ingest_device_pileup(table, lut, {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
+                                     low=0.3, high=0.7, max_part_rows=part_rows)
+        else:
             eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
                               cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
                               low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows, extra_parts=extra)

@@ -147,6 +147,82 @@ class NativePileup:
             pass
 
 
+class DevicePileup:
+    """A plain-text bedMethyl file parsed ON THE GPU (nm_bed_parse_device): the six columns live in device memory in the
+    types ``nm_ingest_pileup`` takes, no row ever becomes a host array.  ``contig_names``: first-appearance order of the
+    file = index space of the ``lut`` given to ``map_contigs``; ``run_row`` / ``run_contig``: the runs of equal contig
+    names (a modkit file has one per contig).  Raises NmScanError for compressed input (use ``NativePileup``)."""
+
+    COLUMNS = (("contig", np.uint32), ("file_contig", np.uint32), ("position", np.uint32), ("mod_type", np.int8), ("strand", np.uint8),
+               ("fraction_mod", np.float64), ("nvalid_cov", np.int32))
+
+    def __init__(self, engine, path: str, threads: int = 0):
+        import ctypes as C
+        from . import _lib
+        self.engine, self._lib, self._check = engine, _lib.load(), _lib.check
+        self._h = C.c_void_p()
+        self._check(self._lib.nm_bed_parse_device(engine.ctx, os.fsencode(path), int(threads), C.byref(self._h)))
+        n, nc, nr = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        times = (C.c_double * 2)()
+        self._check(self._lib.nm_bedcols_shape(self._h, C.byref(n), C.byref(nc), C.byref(nr), times))
+        self.n, self.seconds, self.seconds_reading = int(n.value), float(times[0]), float(times[1])
+        if self.n == 0:
+            self.close()
+            raise SystemExit("Pileup is empty after initial load")      # dataload.py:89-91 exits with status 1
+        self.contig_names = []
+        for i in range(nc.value):
+            s = C.c_char_p()
+            self._check(self._lib.nm_bedcols_contig_name(self._h, i, C.byref(s)))
+            self.contig_names.append(s.value.decode())
+        self.run_row = np.zeros(nr.value + 1, dtype=np.uint64)
+        self.run_contig = np.zeros(max(nr.value, 1), dtype=np.uint32)
+        self._check(self._lib.nm_bedcols_runs(self._h, self.run_row.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              self.run_contig.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.run_contig = self.run_contig[:nr.value]
+
+    def __len__(self):
+        return self.n
+
+    def mod_code(self, i: int) -> str:
+        import ctypes as C
+        s = C.c_char_p()
+        self._check(self._lib.nm_bedcols_mod_code(self._h, int(i), C.byref(s)))
+        return s.value.decode()
+
+    def map_contigs(self, lut: np.ndarray):
+        import ctypes as C
+        lut = np.ascontiguousarray(lut, dtype=np.uint32)
+        self._check(self._lib.nm_bedcols_map_contigs(self._h, lut.ctypes.data_as(C.POINTER(C.c_uint32)), len(lut)))
+
+    def device_pointers(self) -> dict:
+        import ctypes as C
+        ptr = [C.c_void_p() for _ in range(7)]
+        self._check(self._lib.nm_bedcols_device_columns(self._h, *[C.byref(x) for x in ptr]))
+        return {name: int(p.value or 0) for (name, _), p in zip(self.COLUMNS, ptr)}
+
+    def to_host(self) -> dict:
+        """The columns copied to numpy arrays (tests, debugging)."""
+        import ctypes as C
+        out = {}
+        for (name, dt), addr in zip(self.COLUMNS, self.device_pointers().values()):
+            a = np.empty(self.n, dtype=dt)
+            if addr:
+                self._check(self._lib.nm_device_read(self.engine.ctx, a.ctypes.data_as(C.c_void_p), C.c_void_p(addr), a.nbytes))
+                out[name] = a
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.nm_bedcols_close(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def filter_pileup(t: PileupTable, min_coverage: int = 5) -> PileupTable:
     """dataload.py:191-200: strict Nvalid_cov > 5 (the CLI's --threshold_valid_coverage is parsed but never
     forwarded by the reference, argparser.py:126-129 vs main.py:69-83 — same here)."""

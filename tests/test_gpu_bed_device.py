@@ -1,0 +1,135 @@
+"""nm_bed_parse_device (csrc/nmbedgpu.hip): the bedMethyl text parsed ON THE GPU against the host parser (nm_bed_open,
+csrc/nmbed.cpp — the bit-exactness oracle of every row) and through the CLI against the host-parser run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from nanomotif_amd import pileup as pp
+from nanomotif_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same_as_host(eng, path):
+    host = pp.NativePileup(path)
+    cols_h = {k: v.copy() for k, v in host.ingest_columns(np.arange(len(host.contig_names), dtype=np.uint32)).items()}
+    names_h = list(host.contig_names)
+    host.close()
+    dev = pp.DevicePileup(eng, path)
+    assert dev.contig_names == names_h and len(dev) == len(cols_h["position"])
+    dev.map_contigs(np.arange(len(names_h), dtype=np.uint32))
+    cols_d = dev.to_host()
+    assert np.array_equal(cols_d["file_contig"], cols_h["contig"]) and np.array_equal(cols_d["contig"], cols_h["contig"])
+    for k in ("position", "mod_type", "strand", "nvalid_cov"):
+        assert np.array_equal(cols_d[k], cols_h[k]), k
+    assert np.array_equal(cols_d["fraction_mod"].view(np.uint64), cols_h["fraction_mod"].view(np.uint64))      # the same bits
+    # the runs: every run is one contig, ascending rows, the last entry = number of rows
+    assert dev.run_row[0] == 0 and dev.run_row[-1] == len(dev) and (np.diff(dev.run_row.astype(np.int64)) > 0).all()
+    for r in range(len(dev.run_contig)):
+        a, b = int(dev.run_row[r]), int(dev.run_row[r + 1])
+        assert (cols_h["contig"][a:b] == dev.run_contig[r]).all()
+    return dev
+
+
+def test_device_parser_equals_host_parser(tmp_path):
+    from nanomotif_amd.engine import ScanEngine
+    eng = ScanEngine(0)
+    spec = synth.SynthSpec(n_contigs=6, total_bp=500_000, n_bins=2, mod_types=("a", "m"), seed=91, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    dev = _same_as_host(eng, path)
+    assert len(dev) == 500_000 and len(dev.run_contig) == 6
+    dev.close()
+    # edge cases of the format: CRLF, empty lines, nulls, names with spaces, other mod codes, numbers outside the fast
+    # path (exponent, 20 digits), a contig that comes back later (two runs), no newline at the end, 11 columns only
+    lines = [
+        "c 1\t10\t11\ta\t12\t+\t10\t11\t255,0,0\t12\t70.00\t8\t4\t0\t0\t0\t0\t0",
+        "c 1\t11\t12\tm\t3\t-\t11\t12\t255,0,0\tNA\t50.5\t1\t2\t0\t0\t0\t0\t0",
+        "",
+        "c2\t0\t1\t21839\t9\t+\t0\t1\t255,0,0\t9\tnull\t0\t9\t0\t0\t0\t0\t0",
+        "c2\t5\t6\th\t9\t-\t5\t6\t255,0,0\t9\t33.333333333333336\t3\t6\t0\t0\t0\t0\t0",
+        "c2\t7\t8\ta\t100\t+\t7\t8\t255,0,0\t100\t1e2\t100\t0\t0\t0\t0\t0\t0",
+        "c2\t8\t9\t17596\t100\t\t8\t9\t255,0,0\tnull\t\t100\t0\t0\t0\t0\t0\t0",
+        "c2\t9\t10\th\t7\t+\t9\t10\t255,0,0\t7\t12345678901234567890.5\t1\t1\t0\t0\t0\t0\t0",
+        "c 1\t99\t100\ta\t12\t+\t99\t100\t255,0,0\t4000000000\t0.01\t8\t4\t0\t0\t0\t0\t0",
+        "c3\t4294967294\t4294967295\tm\t1\t-\t0\t0\t0\t6\t100.00",
+    ]
+    for eol, tail in (("\n", "\n"), ("\r\n", "\r\n"), ("\n", "")):
+        with open(path, "w", newline="") as f:
+            f.write(eol.join(lines) + tail)
+        dev = _same_as_host(eng, path)
+        assert dev.contig_names == ["c 1", "c2", "c3"] and len(dev.run_contig) == 4 and len(dev) == 9
+        assert [dev.mod_code(i) for i in range(5)] == ["m", "a", "21839", "h", "17596"]
+        dev.close()
+    # error texts of the host parser
+    from nanomotif_amd._lib import NmScanError
+    for bad, what in (("c\t1\t2\ta\n", "fewer than 11"), ("c\tx\t2\ta\t1\t+\t1\t2\t0\t9\t1.0\n", "column 2"),
+                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9x\t1.0\n", "column 10"), ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0.0\n", "column 11"),
+                      ("c\t5000000000\t2\ta\t1\t+\t1\t2\t0\t9\t1.0\n", "beyond 4 Gbp")):
+        open(path, "w").write("c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n" * 3 + bad)
+        with pytest.raises(NmScanError, match=what):
+            pp.DevicePileup(eng, path)
+    open(path, "w").write("")
+    with pytest.raises(SystemExit):
+        pp.DevicePileup(eng, path)
+    import gzip
+    with gzip.open(path + ".gz", "wb") as g:
+        g.write(b"c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")
+    with pytest.raises(NmScanError, match="compressed input"):
+        pp.DevicePileup(eng, path + ".gz")
+    eng.close()
+
+
+def test_several_slabs_and_ingest_from_device_columns(tmp_path):
+    """A file of several 256 MB slabs is out of reach for a unit test; the slab logic is exercised by the CLI test below on
+    a multi-contig file, and here the ingest of device columns (parts cut at the runs) against the host-column ingest."""
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.motif import Motif
+    spec = synth.SynthSpec(n_contigs=7, total_bp=900_000, n_bins=3, mod_types=("a", "m"), seed=92, min_contig_bp=30_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    labels = {0: ("m", "C"), 1: ("a", "A")}
+    cands = [(Motif(s, p), mt, b) for b in sorted(set(mg.bin_names)) for s, p, mt in (("GATC", 1, "a"), ("A", 0, "a"), ("CC[AT]GG", 1, "m"))]
+    out = []
+    for mode in ("host", "device", "device-parts"):
+        eng = ScanEngine(0)
+        eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(len(mg.names))], mg.bin_names)
+        if mode == "host":
+            t = pp.NativePileup(path)
+            lut = np.array([mg.names.index(n) for n in t.contig_names], dtype=np.uint32)
+            c = t.ingest_columns(lut)
+            res = eng.ingest_pileup(c["contig"], c["position"], c["mod_type"], c["strand"], c["fraction_mod"], c["nvalid_cov"], labels, want_rows=False)
+        else:
+            t = pp.DevicePileup(eng, path)
+            lut = np.array([mg.names.index(n) for n in t.contig_names], dtype=np.uint32)
+            res = eng.ingest_device_pileup(t, lut, labels, max_part_rows=150_000 if mode == "device-parts" else None)
+        out.append((res["n_kept"], res["n_confident"], res["kept"].tolist(), eng.score(cands).tolist(), eng.methylated_row_counts("a", 20).tolist()))
+        t.close()
+        eng.close()
+    assert out[0] == out[1] == out[2] and out[0][0] > 0
+
+
+def test_cli_on_the_device_parser_equals_the_host_parser_run(tmp_path):
+    spec = synth.SynthSpec(n_contigs=4, total_bp=500_000, n_bins=2, mod_types=("a", "m"), seed=61, min_contig_bp=60_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    tmp = str(tmp_path)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    mg.write_contig_bin(tmp + "/cb.tsv")
+    outs = []
+    for env_extra, out in (({}, "o_dev"), ({"NANOMOTIF_HOST_PARSER": "1"}, "o_host")):
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **env_extra)
+        r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "a.fasta", "p.bed", "-c", "cb.tsv", "--out", out],
+                           cwd=tmp, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert ("parsed on the device" in r.stdout + r.stderr) == (not env_extra)
+        outs.append(open(f"{tmp}/{out}/bin-motifs.tsv").read())
+    assert outs[0] == outs[1] and "GATC" in outs[0]

@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 from nanomotif_amd import synth
 total_bp = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # replicate the data set under renamed contigs / bins
-tmp = "/tmp/cli_probe"
+tmp = ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp") + "/cli_probe"
 shutil.rmtree(tmp, ignore_errors=True); os.makedirs(tmp)
 mg = synth.make_metagenome(synth.SynthSpec(n_contigs=max(8, total_bp // 100_000), total_bp=total_bp, n_bins=max(2, total_bp // 2_000_000), mod_types=("a", "m"), seed=3))
 t0 = time.perf_counter()
@@ -20,13 +20,15 @@ if copies > 1:
     del fa, bed, cb
 print(f"wrote inputs in {time.perf_counter() - t0:.1f}s: bed {os.path.getsize(tmp + '/pileup.bed') / 1e9:.2f} GB", flush=True)
 env = dict(os.environ, PYTHONPATH=os.getcwd())
+if len(sys.argv) > 3 and sys.argv[3] == "host":
+    env["NANOMOTIF_HOST_PARSER"] = "1"
 t0 = time.perf_counter()
 r = subprocess.run([sys.executable, "-X", "importtime", "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out"],
                    cwd=tmp, env=env, capture_output=True, text=True)
 wall = time.perf_counter() - t0
 log = [l for l in r.stdout.splitlines() if " - INFO - " in l]
 print("\n".join(log[:4] + log[-8:]))
-print(json.dumps({"total_bp": total_bp * copies, "cli_wall_s": wall, "rc": r.returncode}))
+print(json.dumps({"total_bp": total_bp * copies, "cli_wall_s": wall, "rc": r.returncode, "parser": "host" if "NANOMOTIF_HOST_PARSER" in env else "device"}))
 if r.returncode:
     print(r.stderr[-2000:])
 shutil.rmtree(tmp)
