@@ -304,6 +304,55 @@ def run_e2e(mg, eng_device, device, my_bins=None):
     return [r for r in rows if r.n_mod + r.n_nomod >= 50], t
 
 
+def run_cli_extra(device, log_fn, total_bp=100_000_000):
+    """File to bin-motifs.tsv: BASELINE cfg 3 (100 Mbp, 1000 contigs, 50 bins, 6mA + 5mC) as FILES on a tmpfs — FASTA, modkit
+    bedMethyl TEXT (7.8 GB, 1e8 rows), contig-bin TSV — through `python -m nanomotif_amd motif_discovery`, wall clock of the
+    whole process, with the split the CLI records itself (parse / device filters / search / write), once with the
+    device-side parser (the default) and once with the host parser."""
+    import shutil
+    import tempfile
+    from nanomotif_amd import e2e_synth, synth
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tmp = tempfile.mkdtemp(prefix="nm_bench_cli_", dir=base)
+    try:
+        spec = synth.config("cfg3") if total_bp == 100_000_000 else synth.SynthSpec(
+            n_contigs=max(8, total_bp // 100_000), total_bp=total_bp, n_bins=max(2, total_bp // 2_000_000), mod_types=("a", "m"), seed=1)
+        mg3 = synth.make_metagenome(spec)
+        t0 = time.perf_counter()
+        sizes = e2e_synth.write_text_inputs(mg3, tmp, device)
+        log_fn(f"cli extra: wrote {sizes['bed_bytes'] / 1e9:.2f} GB of bedMethyl text ({sizes['rows']:,} rows) in {time.perf_counter() - t0:.1f}s to {tmp}")
+        out = {"what": f"python -m nanomotif_amd motif_discovery on FILES: {total_bp:,} bp FASTA + {sizes['bed_bytes'] / 1e9:.2f} GB modkit bedMethyl text "
+                       f"({sizes['rows']:,} rows) on a tmpfs -> bin-motifs.tsv; wall clock of the whole process",
+               "bed_bytes": sizes["bed_bytes"], "rows": sizes["rows"], "total_bp": total_bp}
+        texts = {}
+        for parser in ("device", "host"):
+            env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            if parser == "host":
+                env["NANOMOTIF_HOST_PARSER"] = "1"
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv",
+                                "--out", "out_" + parser], cwd=tmp, env=env, capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode:
+                out[parser] = {"error": (r.stdout + r.stderr)[-500:]}
+                continue
+            tj = os.path.join(tmp, "out_" + parser, "logs", "timings.motif_discovery.json")
+            t = json.load(open(tj)) if os.path.exists(tj) else {}
+            texts[parser] = open(os.path.join(tmp, "out_" + parser, "bin-motifs.tsv")).read()
+            out[parser] = {"wall_s": wall, "pileup_parse_s": t.get("pileup_parse_s"), "upload_filter_s": t.get("upload_filter_s"),
+                           "search_s": t.get("search_s"), "assembly_s": t.get("assembly_s"), "engine_start_s": t.get("engine_start_s"),
+                           "write_s": t.get("write_s"), "in_find_motifs_bin_s": t.get("find_motifs_bin_s"),
+                           "text_GB_per_s_of_parse": sizes["bed_bytes"] / 1e9 / t["pileup_parse_s"] if t.get("pileup_parse_s") else None,
+                           "motif_rows": max(len(texts[parser].splitlines()) - 1, 0)}
+        if len(texts) == 2:
+            out["outputs_byte_equal"] = texts["device"] == texts["host"]
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,7 +374,8 @@ def main():
     ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: all that apply; none)")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes,cli (auto: all that apply; none)")
+    ap.add_argument("--cli-bp", type=int, default=100_000_000, help="size of the file-to-bin-motifs.tsv extra (cfg 3: 100 Mbp = 7.8 GB of bedMethyl text)")
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
                     help="debug, one GPU: hold the shard rank 0 of an N-rank run would hold (contigs as shard.assign_contigs deals "
                          "them, the whole candidate table in every call); counts are this shard's only")
@@ -409,13 +459,14 @@ def main():
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
-    extras = {"e2e", "cfg5_all", "weak", "two_lanes"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
+    extras = {"e2e", "cfg5_all", "weak", "two_lanes", "cli"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
     if args.workload != "cfg5" or weak:
         extras = set()
     if world == 1:
         extras.discard("weak")
     else:
         extras.discard("cfg5_all")
+        extras.discard("cli")
 
     if args.workload == "e2e":
         sizes = {}
@@ -466,7 +517,11 @@ def main():
                                  "wall_s": max(p[0] for p in per), "search_s": max(p[1] for p in per), "upload_filter_s": max(p[2] for p in per),
                                  "gpu_busy_s": max(p[3] for p in per), "rounds": int(max(p[4] for p in per)), "candidates": int(sum(p[5] for p in per)),
                                  "motif_rows": int(sum(p[6] for p in per)), "planted": int(sum(p[7] for p in per)),
-                                 "planted_recovered": int(sum(p[8] for p in per)), "timings_rank0": t}
+                                 "planted_recovered": int(sum(p[8] for p in per)),
+                                 "gpu_busy_over_wall": max(p[3] for p in per) / max(p[0] for p in per),
+                                 "gpu_busy_covers": "every device phase of the run (pre-filter kernels, window gathers and batches, background counts, scoring launches), HIP events on the ctx stream",
+                                 "not_in_wall_s": {"generate_s": t.get("generate_s"), "allocator_prewarm_s": t.get("allocator_prewarm_s")},
+                                 "timings_rank0": t}
     except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
         if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
             raise
@@ -851,6 +906,13 @@ def main():
             result["weak_scaling"] = {"what": f"{world} x (own {args.total_bp:,} bp metagenome, seed 1 + rank, own {len(c_w)}-candidate table), no collective",
                                       "value": sum(t[0] for t in tot) * args.steps / el, "unit": "motif-sites/s", "ms_per_step": el / args.steps * 1e3}
         eng_w.close()
+
+    try:
+        if "cli" in extras and rank == 0:
+            result["cli"] = run_cli_extra(device, log, args.cli_bp)
+    except Exception as exc:
+        log(f"extra 'cli' failed: {exc!r}")
+        extra_errors["cli"] = repr(exc)
 
     failed = 0
     if rank == 0:

@@ -492,12 +492,21 @@ int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t 
  * group ends in (where the interpreter's generator stands after a sequential run of the same calls) */
 int nm_py_random_sample_groups(uint32_t n_groups, const uint32_t *init_state, const uint64_t *group_off, const uint64_t *n,
                                const uint64_t *k, uint32_t *out_indices, uint32_t final_state[625]);
+/* Synthetic-data tooling (no GPU involved): rows -> modkit bedMethyl text, 18 tab-separated columns as
+ * synth.SynthMetagenome.write_bed writes them (N_mod = round(N_valid_cov * percent / 100), N_canonical the rest), formatted
+ * on several threads.  names / name_offset: contig names back to back; mod_type 0 = m, 1 = a, 2 = 21839;
+ * pct_hundredths = percent modified in hundredths of a percent. */
+int nm_synth_write_bed(const char *path, uint64_t n_rows, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
+                       const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_type, const uint8_t *strand,
+                       const int32_t *nvalid_cov, const int32_t *pct_hundredths, uint32_t threads);
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows,
                             uint32_t width, int64_t *counts);
 
 /* Per-launch timing over a region: nm_timing_reset(ctx, 1) starts collecting one HIP event pair per scoring
  * launch (no synchronisation per launch); nm_timing_total_ms sums the kernel durations recorded since then and
- * reports how many launches they cover; nm_timing_reset(ctx, 0) stops collecting. */
+ * reports how many launches they cover; nm_timing_reset(ctx, 0) stops collecting.  enable = 2 also brackets the other
+ * device phases of the library on the ctx stream (the pre-filter kernels of nm_ingest_pileup, the launches of
+ * nm_plan_windows, every nm_win_batch): the sum is then the time the GPU was busy for this ctx. */
 int nm_timing_reset(nm_ctx *ctx, int enable);
 int nm_timing_total_ms(nm_ctx *ctx, double *total_ms, uint64_t *n_launches);
 

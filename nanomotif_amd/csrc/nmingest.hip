@@ -588,6 +588,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
 #undef ING_ALLOC
     hipError_t e = hipSuccess;
+    nmdetail::busy_begin(c);
     e = hipMemsetAsync(d_cnt, 0, n_fgroups * 2 * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
@@ -621,6 +622,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
                            sl.can_l[slot], pl[0], pl[1], words);
     }
     e = hipGetLastError();
+    nmdetail::busy_end(c);
     if (e != hipSuccess) { cleanup(); invalidate(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
     unsigned long long scal[4] = {0, 0, 0, 0};
     unsigned int err = 0;

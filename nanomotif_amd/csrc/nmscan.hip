@@ -637,6 +637,25 @@ int release_stage(nm_ctx *c, hipStream_t s) {   // call after the last device wo
     return NM_OK;
 }
 
+void busy_begin(nm_ctx *c) {
+    if (!c->ev_collect_all) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 65536) return;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        c->ev_pool.emplace_back(a, b);
+    }
+    (void)hipEventRecord(c->ev_pool[c->ev_used].first, c->stream);
+    c->busy_open = true;
+}
+
+void busy_end(nm_ctx *c) {
+    if (!c->ev_collect_all || !c->busy_open) return;
+    (void)hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    c->ev_used += 1;
+    c->busy_open = false;
+}
+
 int join_lanes(nm_ctx *c) {
     if (c->lane_stream && c->lane_pending) {
         HIP_TRY(hipStreamSynchronize(c->lane_stream));
@@ -1512,6 +1531,8 @@ int nm_timing_reset(nm_ctx *c, int enable) {
     }
     c->ev_used = 0;
     c->ev_collect = enable != 0;
+    c->ev_collect_all = enable == 2;
+    c->busy_open = false;
     c->timed = false;
     return NM_OK;
 }

@@ -130,6 +130,8 @@ struct nm_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     bool ev_collect = false;
+    bool busy_open = false;
+    bool ev_collect_all = false;                      // nm_timing_reset(ctx, 2): also the ingest / window / background phases
     // assembly
     uint32_t n_contigs = 0, n_bins = 0, n_chunks = 0;
     uint64_t total_bp = 0;
@@ -234,6 +236,10 @@ inline void drop_ingest_rows(nm_ctx *c) {
 int ensure_stage(nm_ctx *c, size_t bytes, bool deep = false);   // deep: walk all NM_STAGE_RING pairs (scoring), else pairs 0 / 1
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
-void free_readstats(nm_ctx *c);                          // nmmeth.hip: read statistics are tied to the resident assembly
+void free_readstats(nm_ctx *c);
+// nm_timing_reset(ctx, 2): one event pair around a device phase of the library on the ctx stream (no-ops otherwise); the
+// pairs are summed by nm_timing_total_ms together with the scoring launches
+void busy_begin(nm_ctx *c);
+void busy_end(nm_ctx *c);                          // nmmeth.hip: read statistics are tied to the resident assembly
 
 }  // namespace nmdetail

@@ -542,9 +542,11 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
     const uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
+    nmdetail::busy_begin(c);
     hipLaunchKernelGGL(win_request_kernel, dim3(n_req, (WIN_MAX_W + WIN_COL_GROUP - 1) / WIN_COL_GROUP, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), stride);
+    nmdetail::busy_end(c);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, c->stream));
     rc = release_stage(c);
@@ -1018,9 +1020,11 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
             const ModSlot &ms = c->slots[sl];
             rows.s[sl] = SlotRows{ms.planes[2], ms.planes[4], ms.rank[0], ms.rank[1]};
         }
+        nmdetail::busy_begin(c);
         hipLaunchKernelGGL(win_gather_all_kernel, dim3((unsigned)blocks.size()), dim3(256), 0, c->stream, c->d_win_tasks,
                            reinterpret_cast<const WinBlock *>(ds + o_blk), seq_planes(c), rows, c->d_contig_chunk, c->d_contig_len,
                            reinterpret_cast<const WinSegment *>(ds + o_seg), pad, c->d_win_planes, c->d_win_alive, c->d_err);
+        nmdetail::busy_end(c);
         HIP_TRY(hipGetLastError());
     }
     // ---- the draws: every group its own generator stream, on host threads, while the gather kernel runs
@@ -1056,6 +1060,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     }
     if (n_samples) {
         HIP_TRY(hipMemcpyAsync(ds + o_rank, hs + o_rank, (size_t)n_samples * 4, hipMemcpyHostToDevice, c->stream));
+        nmdetail::busy_begin(c);
         hipLaunchKernelGGL(bg_expand_runs_kernel, dim3((unsigned)runs.size()), dim3(256), 0, c->stream,
                            reinterpret_cast<const BgRun *>(ds + o_runs), reinterpret_cast<uint32_t *>(ds + o_contig));
         HIP_TRY(hipGetLastError());
@@ -1067,6 +1072,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
                                reinterpret_cast<unsigned long long *>(ds + o_out), c->d_err);
             HIP_TRY(hipGetLastError());
         }
+        nmdetail::busy_end(c);
     }
     unsigned int err = 0;
     HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -58,7 +58,39 @@ def generate_raw(mg: synth.SynthMetagenome, device, contigs=None):
     return mine, lengths, offsets, bins, ascii_all, cat
 
 
-def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
+def write_text_inputs(mg: synth.SynthMetagenome, out_dir: str, device, threads: int = 0) -> dict:
+    """The metagenome as the FILES the CLI takes — assembly.fasta, pileup.bed (modkit bedMethyl text, rows in modkit's
+    order), contig_bin.tsv — generated on ``device`` and written by the native writer (nm_synth_write_bed: the Python
+    row loop of ``write_bed`` takes ~1 us per row, a 100 Mbp pileup has 1e8).  Byte-identical to ``mg.write_bed`` /
+    ``write_contig_bin``; the FASTA holds every contig on one line.  Returns sizes."""
+    import os
+    mine, lengths, offsets, bins, ascii_all, cat = generate_raw(mg, device)
+    torch.cuda.synchronize(device)
+    host = {k: v.cpu().numpy() for k, v in cat.items()}
+    pct = np.rint(host["frac"] * 10000.0).astype(np.int32)               # hundredths of a percent (synth.pct_to_fraction inverted)
+    assert np.array_equal(synth.pct_to_fraction(pct), host["frac"])
+    names = "".join(mg.names).encode()
+    off = np.zeros(len(mg.names) + 1, dtype=np.uint32)
+    np.cumsum([len(x) for x in mg.names], out=off[1:])
+    lib = _lib.load()
+    p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(t))
+    cid, pos = np.ascontiguousarray(host["contig"], dtype=np.uint32), np.ascontiguousarray(host["position"], dtype=np.uint32)
+    mod, st = np.ascontiguousarray(host["mod"], dtype=np.int8), np.ascontiguousarray(host["strand"], dtype=np.uint8)
+    nv = np.ascontiguousarray(host["nvalid"], dtype=np.int32)
+    bed = os.path.join(out_dir, "pileup.bed")
+    _lib.check(lib.nm_synth_write_bed(bed.encode(), len(cid), len(mg.names), names, p(off, C.c_uint32), p(cid, C.c_uint32), p(pos, C.c_uint32),
+                                      p(mod, C.c_int8), p(st, C.c_uint8), p(nv, C.c_int32), p(pct, C.c_int32), int(threads)))
+    seq = ascii_all.cpu().numpy()
+    with open(os.path.join(out_dir, "assembly.fasta"), "wb") as f:
+        for j, i in enumerate(mine):
+            f.write(b">" + mg.names[i].encode() + b"\n")
+            f.write(seq[int(offsets[j]):int(offsets[j + 1])].tobytes())
+            f.write(b"\n")
+    mg.write_contig_bin(os.path.join(out_dir, "contig_bin.tsv"))
+    return {"rows": int(len(cid)), "bed_bytes": os.path.getsize(bed), "assembly_bp": int(lengths.sum())}
+
+
+def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, host_assembly=True):
     """Generate (a shard of) ``mg`` on ``device`` and ingest it through the device-side filters.
     Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
     t = {}
@@ -68,10 +100,14 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
     # torch's pool HERE, with the generation: a fresh hipMalloc of memory that another process used before is scrubbed
     # by the driver at 7-30 GB/s — 0.4 s for this block right after the test suite, none on a fresh box —
     # and that is no more part of the pipeline than the generation of the synthetic rows is
+    torch.cuda.synchronize(device)
+    t_warm = time.perf_counter()
     warm = torch.empty(int(lengths.sum()) * 20, dtype=torch.uint8, device=device)
     del warm
     torch.cuda.synchronize(device)
+    t["allocator_prewarm_s"] = time.perf_counter() - t_warm        # reported, not part of wall_s (like the generation)
     t["generate_s"] = time.perf_counter() - t0
+    engine.timing_reset(2)                                         # every device phase from here on counts as GPU-busy time
     t0 = time.perf_counter()
     engine.upload_assembly_device([mg.names[i] for i in mine], lengths, [mg.bin_names[i] for i in mine], ascii_all.data_ptr(),
                                   bin_names=bins)
@@ -98,8 +134,14 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None):
     t["upload_filter_s"] = time.perf_counter() - t0
     t["rows_raw"], t["rows_kept"], t["rows_confident"] = n, int(n_kept.value), int(k)
     t0 = time.perf_counter()
-    host_ascii = ascii_all.cpu().numpy()
-    assembly = {mg.names[i]: host_ascii[int(offsets[j]):int(offsets[j + 1])] for j, i in enumerate(mine)}
+    if host_assembly:
+        host_ascii = ascii_all.cpu().numpy()
+        assembly = {mg.names[i]: host_ascii[int(offsets[j]):int(offsets[j + 1])] for j, i in enumerate(mine)}
+    else:
+        # the sequences never have to exist on the host: windows are gathered and backgrounds counted from the resident
+        # planes (a run from files has them on the host to begin with and pays the upload instead: 1 Gbp = 0.03 s of PCIe)
+        empty = np.zeros(0, dtype=np.uint8)
+        assembly = {mg.names[i]: empty for i in mine}
     t["assembly_to_host_s"] = time.perf_counter() - t0
     return assembly, FilteredPileup(engine.contig_names, cc, cp, cs, cm, kept), t
 
@@ -111,7 +153,7 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
     if bins is not None:
         keep = set(bins)
         contigs = [i for i, b in enumerate(mg.bin_names) if b in keep]
-    assembly, filtered, t = load_and_filter(engine, mg, device, contigs=contigs)
+    assembly, filtered, t = load_and_filter(engine, mg, device, contigs=contigs, host_assembly=False)
     names = mg.names if contigs is None else [mg.names[i] for i in contigs]
     bin_of = mg.bin_names if contigs is None else [mg.bin_names[i] for i in contigs]
     lengths = [int(mg.lengths[i]) for i in (range(len(mg.names)) if contigs is None else contigs)]
@@ -121,7 +163,6 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
     t0 = time.perf_counter()
     scorer = engine_scorer(engine, 0.3, 0.7)
     from .main import device_window_pipeline
-    engine.timing_reset(True)
     t1 = time.perf_counter()
     store, extractor = device_window_pipeline(engine, dict(zip(names, lengths)), list(names), cfg.padding)
     t["window_pipeline_s"] = time.perf_counter() - t1
@@ -130,7 +171,7 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
     t.update(getattr(scorer, "timings", {}))
     ms, n = engine.timing_total()
     engine.timing_reset(False)
-    t["gpu_busy_s"] = ms * 1e-3              # scoring launches of the search (HIP events on the launch stream)
-    t["score_launches"] = n
+    t["gpu_busy_s"] = ms * 1e-3              # every device phase: pre-filters, window gathers and batches, background counts, scoring launches (HIP events on the ctx stream)
+    t["device_phases"] = n
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
     return rows, t

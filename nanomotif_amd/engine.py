@@ -794,8 +794,10 @@ class ScanEngine:
                 "last_compact", "last_general"]
         return dict(zip(keys, [int(x) for x in w]))
 
-    def timing_reset(self, enable: bool = True):
-        _lib.check(self.lib.nm_timing_reset(self.ctx, 1 if enable else 0))
+    def timing_reset(self, enable=True):
+        """True / 1: collect the scoring launches; 2: every device phase of the library (pre-filters, window gathers, window
+        batches, background counts); False / 0: stop."""
+        _lib.check(self.lib.nm_timing_reset(self.ctx, int(enable)))
 
     def timing_total(self):
         """(sum of scoring-kernel durations in ms, number of launches) since ``timing_reset(True)``."""

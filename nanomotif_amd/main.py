@@ -52,8 +52,18 @@ def shared_setup(args, working_dir, rank=0):
     set_seed(args.seed)
 
 
+TIMINGS = {}          # seconds per phase of the last find_motifs_bin call in this process (written to OUT/logs/timings.*.json)
+
+
 def find_motifs_bin(args):
     """main.py:46-104."""
+    TIMINGS.clear()
+    t_phase = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        TIMINGS[name] = TIMINGS.get(name, 0.0) + now - t_phase[0]
+        t_phase[0] = now
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,6 +90,7 @@ def find_motifs_bin(args):
     except NmScanError as e:
         raise RuntimeError(f"nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback ({e})") from e
 
+    lap("engine_start_s")
     log.info("Starting nanomotif motif finder")
     bin_contig = fasta.generate_contig_bin(args)
     if not bin_contig:
@@ -88,6 +99,7 @@ def find_motifs_bin(args):
     log.info("Loading assembly")
     assembly = fasta.load_fasta(args.assembly)
     fasta.add_alias_sequences(assembly, bin_contig)          # a contig listed under several bins is a member of each
+    lap("assembly_s")
     log.info("Identifying motifs")
     cfg = ProcessorConfig(assembly=assembly, pileup_path=args.pileup, bin_contig=bin_contig, threads=args.threads,
                           search_frame_size=args.search_frame_size, methylation_threshold_low=args.methylation_threshold_low,
@@ -119,6 +131,9 @@ def find_motifs_bin(args):
         how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
         log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
     on_device = isinstance(table, pileup_mod.DevicePileup)
+    lap("pileup_parse_s")
+    TIMINGS["pileup_parser"] = "device" if on_device else "host"
+    TIMINGS["pileup_rows"] = len(table)
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they
     # balance (independent searches, no collective until the rows are gathered), else the contigs of every bin are
@@ -217,6 +232,7 @@ def find_motifs_bin(args):
                               cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
                               low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
         log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
+        lap("upload_filter_s")
         del cols
         table.close()
         part = FilteredPileup(mine, *rows_part, res["kept"])
@@ -232,7 +248,11 @@ def find_motifs_bin(args):
         scorer = engine_scorer(eng, low, high, use_dist=world > 1)
         rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
                                 window_store=store, extractor=extractor)
-        return _gather_rows(args, rows, rank, gather_world, bin_order)
+        lap("search_s")
+        TIMINGS.update({"search_" + k: v for k, v in getattr(scorer, "timings", {}).items()})
+        out = _gather_rows(args, rows, rank, gather_world, bin_order)
+        lap("write_s")
+        return out
     finally:
         # also on the early returns and on exceptions: the module-global reducer must not outlive its engine
         use_native_allreduce(None)
@@ -329,7 +349,15 @@ def main(argv=None):
     if args.command == "motif_discovery":
         rank = int(os.environ.get("RANK", "0"))
         shared_setup(args, args.out, rank=rank)
+        t_main = time.perf_counter()
         result = find_motifs_bin(args)
+        if rank == 0:
+            try:
+                TIMINGS["find_motifs_bin_s"] = time.perf_counter() - t_main
+                with open(os.path.join(args.out, "logs", "timings.motif_discovery.json"), "w") as f:
+                    json.dump(TIMINGS, f, indent=1)
+            except OSError:
+                pass
         if result is None and rank == 0:
             with open(os.path.join(args.out, "bin-motifs.tsv"), "w") as f:     # main.py:317-321
                 f.write(HEADER)
