@@ -199,6 +199,17 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
             for (int t = 0; t < T_WORDS; ++t) accr[t] = baser[t];
             eval_masks<K>(mr, tile, accr);
         }
+#ifdef NM_EXP_SKIP_EMPTY
+        {   // experiment (round 3): skip the count stage when no lane of the wave holds a site of this candidate.  Same-device
+            // A/B, three rounds (profiles/r3/ab_skip_empty_count_stage.txt): cfg 5 kernel 0.514 -> 0.530 ms (3 % SLOWER: a
+            // 5.5-constraint candidate has ~8 sites per 8192-bp chunk, the wave is almost never empty and pays the test),
+            // greedy rounds +1-2 %.  Not compiled in.
+            uint32_t any = 0;
+#pragma unroll
+            for (int t = 0; t < T_WORDS; ++t) any |= accf[t] | accr[t];
+            if (__ballot(any != 0) == 0) continue;
+        }
+#endif
         uint32_t n_mod = 0, n_non = 0;
 #pragma unroll
         for (int t = 0; t < T_WORDS; ++t) {
