@@ -39,7 +39,7 @@ typedef enum nm_status {
     NM_ERANGE = -5       /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
 } nm_status;
 
-#define NM_MAX_MOTIF_LEN 64   /* stripped motif length; offsets relative to the modified base in [-64, 63] */
+#define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base (nm_hit_positions, nm_contig_methylation: 63) */
 #define NM_MAX_MOD_SLOTS 8    /* pileup classifications resident at once: the reference's 3 mod types (m, a, 21839 — constants.py:29-33), each possibly under two threshold pairs */
 
 /* motif position sets are 4-bit masks: bit0 = A, bit1 = C, bit2 = G, bit3 = T; 15 = '.'/N (any character,
@@ -183,9 +183,10 @@ int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, c
  * Window engine — the per-expansion work of the greedy search on the device.  The windows around the confidently
  * methylated sites of one (bin, mod type) search (find_motifs_bin.py:635-677) are kept as bit planes over windows;
  * a request then replaces DNAarray.filter_sequence_matches (seq.py:499-524) + DNAarray.pssm (seq.py:526-537):
- *   nm_win_add_task  windows as base-set bytes [n][width] (bit0 A, bit1 C, bit2 G, bit3 T, 15 = N), width <= 64;
+ *   nm_win_add_task  windows as base-set bytes [n][width] (bit0 A, bit1 C, bit2 G, bit3 T, 15 = N), width <= NM_WIN_MAX_WIDTH
+ *                    (the reference accepts any --search_frame_size; here 2 * (frame // 2) + 1 <= 191);
  *                    returns the task id.  nm_win_clear drops all tasks.
- *   nm_win_batch     n_req requests (task, kind, motif as one base-set byte per column in a 64-byte slot):
+ *   nm_win_batch     n_req requests (task, kind, motif as one base-set byte per column in a slot of NM_WIN_MAX_WIDTH bytes):
  *                    kind 0: out = { n_active, 0, counts[4][64] } — number of not-yet-removed windows that match the
  *                            motif and, per column, how many of them carry A / T / G / C (rows in the reference's
  *                            A, T, G, C order; an N window counts for all four) => pssm = counts / n_active;
@@ -193,12 +194,17 @@ int nm_parse_motifs(uint32_t n, const char *text, const uint32_t *text_offset, c
  *                            find_motifs_bin.py:803); out = { alive before, alive after, ... }.
  *                    out is int32[n_req][2 + 4*64].  Requests of one batch must not mix kinds on one task.
  */
-#define NM_WIN_MAX_WIDTH 64
+#define NM_WIN_MAX_WIDTH 192
 #define NM_WIN_OUT_STRIDE (2 + 4 * NM_WIN_MAX_WIDTH)
 int nm_win_clear(nm_ctx *ctx);
 int nm_win_add_task(nm_ctx *ctx, uint32_t n_windows, uint32_t width, const uint8_t *sets, uint32_t *task_id);
 int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind,
                  const uint8_t *req_sets, int32_t *out);
+/* The same with a caller-chosen width stride ws (>= the width of every task asked about, <= NM_WIN_MAX_WIDTH): req_sets is
+ * uint8[n_req][ws], out is int32[n_req][2 + 4 * ws] (counts row r, column j at 2 + r * ws + j) — the default 41-column
+ * search moves 258 ints per request instead of 770. */
+int nm_win_batch_w(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind,
+                   const uint8_t *req_sets, uint32_t ws, int32_t *out);
 
 /*
  * Window extraction on the device (find_motifs_bin.py:625-686) — the windows never exist as bytes on the host.
@@ -324,7 +330,8 @@ int nm_contig_methylation(nm_ctx *ctx, uint32_t n_motifs, const uint8_t *motif_s
  * reduce (may be NULL): sums an int64 array over the ranks of a contig-sharded run, called once per batch.
  * nm_search_run_custom runs the same state machine on caller-supplied back ends (the CPU tests drive it with the
  * oracle): score_fn gets n motifs of W characters (A C G T .) with their task index and fills int64[n][2];
- * window_fn gets n requests (kind 0 = pssm, 1 = remove) and fills int32[n][NM_WIN_OUT_STRIDE] like nm_win_batch.
+ * window_fn gets n requests (kind 0 = pssm, 1 = remove) and fills int32[n][2 + 4 * ws] like nm_win_batch_w, with
+ * ws = W rounded up to a multiple of 64 (64 for the default frame).
  *
  * Results (nm_search_result_sizes / _export, then _free): per task either "none" (no graph) or the graph in insertion
  * order — motif characters, raw counts, score, priority, depth, visited, edges as task-local node index pairs — and

@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     }
 }
 
-// needs_v[c] = 0 iff chunk c is entirely valid and so are the two words either side of it.
+// needs_v[c] = 0 iff chunk c is entirely valid and so are the three words either side of it (the widest halo a variant reads).
 __global__ void needs_v_kernel(const uint32_t *__restrict__ V, uint8_t *__restrict__ needs_v, uint32_t n_chunks) {
     const uint32_t c = blockIdx.x;
     __shared__ uint32_t all_and;
     if (threadIdx.x == 0) all_and = 0xFFFFFFFFu;
     __syncthreads();
     uint32_t v = V[(size_t)c * CHUNK_WORDS + threadIdx.x];
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 3) {
         if (c > 0) v &= V[(size_t)c * CHUNK_WORDS - 1 - threadIdx.x];
         else v = 0;
         if (c + 1 < n_chunks) v &= V[(size_t)(c + 1) * CHUNK_WORDS + threadIdx.x];
@@ -421,7 +421,7 @@ __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
                                uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_prog) return;
-    const int groups = wide ? 4 : 2, g0 = wide ? 0 : 1;
+    const int groups = 2 + 2 * wide, g0 = 1 - wide;        // wide: 0 narrow (word-groups 1..2), 1 wide (0..3), 2 extra wide (-1..4)
     const int pdw = 2 * groups * np;
     uint32_t *prog = programs + (size_t)k * pdw;
     for (int i = 0; i < pdw; ++i) prog[i] = 0;
@@ -684,7 +684,8 @@ namespace {
 // light (<= 6 candidates per (slot, bin) group on average — a round of the greedy search): HBM-bound, groups share their
 // common constraints (CF), two classifications (the usual 6mA + 5mC batch) share one pass over the sequence planes.
 struct LaunchShape {
-    bool wide, compact, lit, light;
+    int wide;                 // 0: offsets in [-32, 31], 1: [-64, 63], 2: [-96, 95]
+    bool compact, lit, light;
     uint32_t n_active;
     bool per_contig = false;
 };
@@ -704,13 +705,18 @@ void launch_by_load(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipS
 void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStream_t s) {
     if (sh.per_contig) {      // (candidate, contig) counters: the plain one-slot-per-column kernels with the other reduction key
         const uint32_t gy = std::max(sh.n_active, 1u);
-        if (!sh.wide && sh.compact) launch_variant<Variant<1, 1, true, 1, false, false, true>>(a, gx, gy, s);
+        if (sh.wide == 2 && sh.compact) launch_variant<Variant<3, 3, true, 1, false, false, true>>(a, gx, gy, s);
+        else if (sh.wide == 2) launch_variant<Variant<3, 3, false, 1, false, false, true>>(a, gx, gy, s);
+        else if (!sh.wide && sh.compact) launch_variant<Variant<1, 1, true, 1, false, false, true>>(a, gx, gy, s);
         else if (!sh.wide) launch_variant<Variant<1, 1, false, 1, false, false, true>>(a, gx, gy, s);
         else if (sh.compact) launch_variant<Variant<2, 2, true, 1, false, false, true>>(a, gx, gy, s);
         else launch_variant<Variant<2, 2, false, 1, false, false, true>>(a, gx, gy, s);
         return;
     }
-    if (!sh.wide && sh.compact) {
+    if (sh.wide == 2) {       // motifs that reach more than 63 positions from the modified base (search frames above 127)
+        if (sh.compact) launch_by_load<3, true, false>(a, gx, sh, s);
+        else launch_by_load<3, false, false>(a, gx, sh, s);
+    } else if (!sh.wide && sh.compact) {
         if (sh.lit) launch_by_load<1, true, true>(a, gx, sh, s);
         else launch_by_load<1, true, false>(a, gx, sh, s);
     } else if (!sh.wide) launch_by_load<1, false, false>(a, gx, sh, s);
@@ -730,7 +736,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const uint32_t n_bins = c->n_bins;
     std::vector<uint32_t> &bucket = c->bucket;          // counting sort by (slot, bin)
     bucket.assign((size_t)NM_MAX_MOD_SLOTS * n_bins + 1, 0);
-    bool any_wide = false, all_compact = true, all_literal = true;
+    int any_wide = 0;                                    // widest offset class of the batch: 0 / 1 / 2 (see LaunchShape)
+    bool all_compact = true, all_literal = true;
     uint32_t n_prog = 0;
     uint64_t mask_bytes = 0, mask_lo = ~0ull;   // byte range of cand_masks the resident candidates reference
     bool slot_used[NM_MAX_MOD_SLOTS] = {};
@@ -757,7 +764,11 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         mask_lo = std::min<uint64_t>(mask_lo, cand_mask_offset[k]);
         mask_bytes = std::max<uint64_t>(mask_bytes, (uint64_t)cand_mask_offset[k] + len);
         // offsets relative to the modified base span [-mp, len-1-mp] forward and the mirror image in reverse
-        if (mp > 31 || len - 1 - mp > 31) any_wide = true;
+        {
+            const uint32_t reach = std::max(mp, len - 1 - mp);
+            if (reach > 95) return fail(NM_ERANGE, "candidate %u: a position %u away from the modified base (the engine reaches 95)", k, reach);
+            any_wide = std::max(any_wide, reach > 63 ? 2 : reach > 31 ? 1 : 0);
+        }
         const uint32_t can_mask = c->slots[slot].canonical == 'A' ? NM_BASE_A : NM_BASE_C;
         if ((m[mp] & 15u) != can_mask) all_compact = false;
         bucket[(size_t)slot * n_bins + bin + 1] += 1;
@@ -781,7 +792,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
                             (unsigned long long)(row_offset[k + 1] - row_offset[k]), c->bin_ncontigs[cand_bin[k]]);
     const bool lit = all_literal && all_compact && !any_wide && !c->opt_no_lit && !per_contig;   // literal-only tiles exist for the narrow compact kernels
     const uint32_t np = lit ? 4u : 8u;
-    const uint32_t pdw = 2u * (any_wide ? 4u : 2u) * np;         // dwords per program: [strand][word-group][plane]
+    const uint32_t pdw = 2u * (2u + 2u * (uint32_t)any_wide) * np;         // dwords per program: [strand][word-group][plane]
     const size_t rec_bytes = (size_t)n_prog * sizeof(CandRec);
     const size_t off_orig = (rec_bytes + 15) & ~(size_t)15;
     const size_t off_masks = (off_orig + (size_t)n_prog * 4 + 15) & ~(size_t)15;
@@ -862,7 +873,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_prog) {
         hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->copy_stream, n_prog,
-                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide ? 1 : 0, (int)np,
+                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide, (int)np,
                            all_compact ? 1 : 0);
         HIP_TRY(hipGetLastError());
         if (cf) {

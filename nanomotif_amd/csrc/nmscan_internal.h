@@ -38,7 +38,7 @@ inline hipError_t dev_free(void *p) { return device_free(p); }
 constexpr int T_WORDS = 4;                              // 32-bit words per lane
 constexpr int CHUNK_WORDS = 64 * T_WORDS;               // 256 words
 constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wave-chunk
-constexpr int GAP_BP = 64;                              // invalid positions guaranteed after every contig
+constexpr int GAP_BP = 96;                              // invalid positions guaranteed after every contig (>= the widest offset a motif reaches: no match straddles contigs)
 constexpr int SEG_CHUNKS = 16;                          // chunks per workgroup segment (128 Kbp)
 constexpr int BMAX = 32;                                // candidates per LDS accumulation pass
 constexpr int PROG_DW = 64;                             // host-side program: [strand 2][word-group 4][plane 8]
@@ -46,7 +46,7 @@ constexpr int PROG_DW = 64;                             // host-side program: [s
 // narrow (offsets in [-32, 31]) = groups 1..2 -> 32 dwords (128 B), wide = all four -> 64 dwords
 constexpr int NM_MAX_MOD_CODES = 8;                     // mod codes that can be given a slot / reported (ABI: slot_of_mod[8])
 constexpr int NM_CODE_STRIDE = 128;                     // mod code ids the pre-filters tell apart (int8 ids; the reader numbers unknown codes 3, 4, ...)
-constexpr int WIN_MAX_W = 64;                // window width limit (reference default 41)
+constexpr int WIN_MAX_W = NM_WIN_MAX_WIDTH;   // window width limit (reference default 41)
 constexpr int RANK_BLOCK_WORDS = 16;                          // 512 bp per rank entry
 constexpr int RANK_PER_CHUNK = CHUNK_WORDS / RANK_BLOCK_WORDS;
 

@@ -38,8 +38,8 @@ int nm_set_error(int code, const char *fmt, ...);
 
 namespace {
 
-constexpr int STRIDE = NM_WIN_OUT_STRIDE;
 constexpr int MAXW = NM_WIN_MAX_WIDTH;
+inline uint32_t width_stride(uint32_t W) { return (W + 63u) / 64u * 64u; }      // columns per row of window sets / counts
 
 // scipy.special.psi for positive integers (Cephes psi: exact harmonic sum for x <= 10, asymptotic series beyond)
 double psi_int(double x) {
@@ -611,7 +611,7 @@ private:
 
 int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user) {
     auto &tasks = res->tasks;
-    const uint32_t W = P.width;
+    const uint32_t W = P.width, WS = width_stride(W);
     // NM_SEARCH_TIMING: where the wall time of the lock-step loop goes (stderr, one line)
     const bool timing = getenv("NM_SEARCH_TIMING") != nullptr;
     double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
@@ -651,7 +651,7 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
         if (s_task.empty() && w_task.empty()) break;
         if (!w_task.empty()) {
             t0 = now();
-            wout.assign(w_task.size() * (size_t)STRIDE, 0);
+            wout.assign(w_task.size() * (size_t)(2 + 4 * WS), 0);
             const int rc = window_fn(user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
             if (rc) return rc;
             res->window_requests += w_task.size();
@@ -671,12 +671,12 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
         size_t si = 0;
         for (size_t k = 0; k < w_task.size(); ++k) {
             Task &t = tasks[w_task[k]];
-            const int32_t *o = wout.data() + k * (size_t)STRIDE;
+            const int32_t *o = wout.data() + k * (size_t)(2 + 4 * WS);
             t.rep_a = o[0];
             t.rep_b = o[1];
             if (w_kind[k] == 0)
                 for (int r = 0; r < 4; ++r)
-                    for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * MAXW + j];
+                    for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * WS + j];
         }
         while (si < s_task.size()) {
             Task &t = tasks[s_task[si]];
@@ -754,15 +754,16 @@ int engine_window(void *user, uint32_t n, const uint32_t *task, const uint8_t *k
     EngineUser &u = *static_cast<EngineUser *>(user);
     const uint32_t W = u.width;
     u.wtask.resize(n);
-    u.sets.assign((size_t)n * MAXW, 15);
+    const uint32_t WS = width_stride(W);
+    u.sets.assign((size_t)n * WS, 15);
     for (uint32_t i = 0; i < n; ++i) {
         u.wtask[i] = u.task_win[task[i]];
-        for (uint32_t j = 0; j < W; ++j) u.sets[(size_t)i * MAXW + j] = set_of(motifs[(size_t)i * W + j]);
+        for (uint32_t j = 0; j < W; ++j) u.sets[(size_t)i * WS + j] = set_of(motifs[(size_t)i * W + j]);
     }
-    int rc = nm_win_batch(u.ctx, n, u.wtask.data(), kind, u.sets.data(), out);
+    int rc = nm_win_batch_w(u.ctx, n, u.wtask.data(), kind, u.sets.data(), WS, out);
     if (rc) return rc;
     if (u.reduce) {                                  // contig-sharded run: every rank holds the windows of its contigs
-        const size_t m = (size_t)n * STRIDE;
+        const size_t m = (size_t)n * (2 + 4 * WS);
         u.tmp64.resize(m);
         for (size_t i = 0; i < m; ++i) u.tmp64[i] = out[i];
         rc = u.reduce(u.reduce_user, u.tmp64.data(), m);

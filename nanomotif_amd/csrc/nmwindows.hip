@@ -57,14 +57,15 @@ __global__ __launch_bounds__(256) void win_request_kernel(const WinTask *__restr
                                                           const uint8_t *__restrict__ req_kind,
                                                           const uint8_t *__restrict__ req_sets /*[n_req][WIN_MAX_W]*/,
                                                           const uint32_t *__restrict__ planes, uint32_t *alive,
-                                                          int *__restrict__ out, uint32_t out_stride) {
+                                                          int *__restrict__ out, uint32_t ws /*columns per row of sets / counts*/) {
     __shared__ uint8_t mset[WIN_MAX_W];
     const uint32_t r = blockIdx.x;
     const WinTask t = tasks[req_task[r]];
     const uint32_t kind = req_kind[r];
     const uint32_t col0 = blockIdx.y * WIN_COL_GROUP;
     if (col0 >= t.width || (kind == 1 && blockIdx.y != 0)) return;
-    if (threadIdx.x < WIN_MAX_W) mset[threadIdx.x] = threadIdx.x < t.width ? req_sets[(size_t)r * WIN_MAX_W + threadIdx.x] : 15;
+    const uint32_t out_stride = 2 + 4 * ws;
+    if (threadIdx.x < WIN_MAX_W) mset[threadIdx.x] = threadIdx.x < t.width ? req_sets[(size_t)r * ws + threadIdx.x] : 15;
     __syncthreads();
     const uint32_t *pl = planes + t.plane_off;
     uint32_t *al = alive + t.alive_off;
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(256) void win_request_kernel(const WinTask *__restr
         if (col0 + c >= t.width) break;
         const int ca = wave_sum(cnt[c][0]), cc = wave_sum(cnt[c][1]), cg = wave_sum(cnt[c][2]), ct = wave_sum(cnt[c][3]);
         if (lane == 0) {                                               // row order A, T, G, C (constants.py:1)
-            if (ca) atomicAdd(&o[2 + 0 * WIN_MAX_W + col0 + c], ca);
-            if (ct) atomicAdd(&o[2 + 1 * WIN_MAX_W + col0 + c], ct);
-            if (cg) atomicAdd(&o[2 + 2 * WIN_MAX_W + col0 + c], cg);
-            if (cc) atomicAdd(&o[2 + 3 * WIN_MAX_W + col0 + c], cc);
+            if (ca) atomicAdd(&o[2 + 0 * ws + col0 + c], ca);
+            if (ct) atomicAdd(&o[2 + 1 * ws + col0 + c], ct);
+            if (cg) atomicAdd(&o[2 + 2 * ws + col0 + c], cg);
+            if (cc) atomicAdd(&o[2 + 3 * ws + col0 + c], cc);
         }
     }
 }
@@ -158,6 +159,39 @@ __device__ __forceinline__ uint64_t plane_field(const uint32_t *__restrict__ P, 
     x >>= sh;
     if (sh + n > 64) x |= (uint64_t)P[w0 + 2] << (64 - sh);
     return n >= 64 ? x : (x & ((1ull << n) - 1));
+}
+
+// W <= 192 bits starting at global bit g, as three 64-bit pieces
+struct Field3 { uint64_t w[3]; };
+
+__device__ __forceinline__ Field3 plane_field3(const uint32_t *__restrict__ P, uint64_t g, uint32_t n) {
+    Field3 f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f.w[k] = n > 64u * k ? plane_field(P, g + 64u * k, min(64u, n - 64u * k)) : 0ull;
+    return f;
+}
+
+__device__ __forceinline__ uint32_t field_bit(const Field3 &f, uint32_t j) {
+    const uint64_t w = j < 64 ? f.w[0] : (j < 128 ? f.w[1] : f.w[2]);
+    return (uint32_t)(w >> (j & 63)) & 1u;
+}
+
+// set bits among the n (<= 192) bits of a plane from bit g on
+__device__ __forceinline__ uint32_t plane_popc(const uint32_t *__restrict__ P, uint64_t g, uint32_t n) {
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < n; k += 64) c += (uint32_t)__popcll(plane_field(P, g + k, min(64u, n - k)));
+    return c;
+}
+
+// positions among the n (<= 192) from bit g on whose base is b
+__device__ __forceinline__ uint32_t base_popc(const Planes &s, uint64_t g, uint32_t n, int b) {
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < n; k += 64) {
+        const uint32_t m = min(64u, n - k);
+        const uint64_t h = plane_field(s.H, g + k, m), l = plane_field(s.L, g + k, m), v = plane_field(s.V, g + k, m);
+        c += (uint32_t)__popcll(v & ((b >= 2) ? h : ~h) & ((b == 1 || b == 2) ? l : ~l));
+    }
+    return c;
 }
 
 // one wave per contig: rank[block] = number of positions with base b in the contig before the block
@@ -198,14 +232,7 @@ __global__ void base_count_kernel(Planes s, const uint32_t *__restrict__ contig_
     const uint64_t len = contig_len[ci], g0 = (uint64_t)contig_chunk[ci] * CHUNK_BP;
     if (len < 2ull * pad + 1) { out[ci] = 0; return; }
     uint64_t n = total[ci];
-    if (pad) {
-        const uint64_t hh = plane_field(s.H, g0, pad), hl = plane_field(s.L, g0, pad), hv = plane_field(s.V, g0, pad);
-        const uint64_t th = plane_field(s.H, g0 + len - pad, pad), tl = plane_field(s.L, g0 + len - pad, pad),
-                       tv = plane_field(s.V, g0 + len - pad, pad);
-        const uint64_t head = hv & ((b >= 2) ? hh : ~hh) & ((b == 1 || b == 2) ? hl : ~hl);
-        const uint64_t tail = tv & ((b >= 2) ? th : ~th) & ((b == 1 || b == 2) ? tl : ~tl);
-        n -= __popcll(head) + __popcll(tail);
-    }
+    if (pad) n -= base_popc(s, g0, pad, b) + base_popc(s, g0 + len - pad, pad, b);
     out[ci] = n;
 }
 
@@ -243,9 +270,9 @@ __global__ void meth_count_kernel(const uint32_t *__restrict__ MP, const uint32_
     const uint64_t len = contig_len[ci], g0 = (uint64_t)contig_chunk[ci] * CHUNK_BP;
     uint64_t *o = out + (size_t)ci * 4;
     if (len < 2ull * pad + 2) { o[0] = o[1] = o[2] = o[3] = 0; return; }
-    const uint64_t hp = __popcll(plane_field(MP, g0, pad + 1)), hm = __popcll(plane_field(MM, g0, pad + 1));
-    const uint64_t tp = pad ? __popcll(plane_field(MP, g0 + len - pad, pad)) : 0;
-    const uint64_t tm = pad ? __popcll(plane_field(MM, g0 + len - pad, pad)) : 0;
+    const uint64_t hp = plane_popc(MP, g0, pad + 1), hm = plane_popc(MM, g0, pad + 1);
+    const uint64_t tp = pad ? plane_popc(MP, g0 + len - pad, pad) : 0;
+    const uint64_t tm = pad ? plane_popc(MM, g0 + len - pad, pad) : 0;
     o[0] = total_p[ci] - hp - tp;
     o[1] = total_m[ci] - hm - tm;
     o[2] = hp;
@@ -263,7 +290,8 @@ __global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t
                                                         const BgBlock *__restrict__ blocks,
                                                         const uint32_t *__restrict__ sample_contig,
                                                         const uint32_t *__restrict__ sample_rank, int b, uint32_t pad,
-                                                        unsigned long long *__restrict__ out, unsigned int *err) {
+                                                        unsigned long long *__restrict__ out, uint32_t ws /*columns per output row*/,
+                                                        unsigned int *err) {
     __shared__ uint32_t cnt[4 * WIN_MAX_W];
     const BgBlock blk = blocks[blockIdx.x];
     const uint64_t begin = ((uint64_t)blk.begin_hi << 32) | blk.begin_lo;
@@ -273,29 +301,26 @@ __global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t
     for (uint32_t i0 = 0; i0 < blk.count; i0 += blockDim.x) {
         const uint32_t i = i0 + threadIdx.x;
         bool on = i < blk.count;
-        uint64_t fh = 0, fl = 0, fv = 0;
+        Field3 fh{}, fl{}, fv{};
         if (on) {
             const uint32_t ci = sample_contig[begin + i];
             const uint32_t c0 = contig_chunk[ci];
             const uint64_t g0 = (uint64_t)c0 * CHUNK_BP;
             const uint32_t nblk = (uint32_t)((contig_len[ci] + GAP_BP + CHUNK_BP - 1) / CHUNK_BP) * RANK_PER_CHUNK;
             uint32_t k = sample_rank[begin + i];
-            if (pad) {
-                const uint64_t hh = plane_field(s.H, g0, pad), hl = plane_field(s.L, g0, pad), hv = plane_field(s.V, g0, pad);
-                k += __popcll(hv & ((b >= 2) ? hh : ~hh) & ((b == 1 || b == 2) ? hl : ~hl));
-            }
+            if (pad) k += base_popc(s, g0, pad, b);
             const uint64_t centre = select_kth(s, nullptr, b, rank + (size_t)c0 * RANK_PER_CHUNK, c0, nblk, k);
             if (centre == ~0ull || centre < g0 + pad) {
                 atomicOr(err, 4u);                       // rank beyond the contig's valid starts
                 on = false;
             } else {
-                fh = plane_field(s.H, centre - pad, W);
-                fl = plane_field(s.L, centre - pad, W);
-                fv = plane_field(s.V, centre - pad, W);
+                fh = plane_field3(s.H, centre - pad, W);
+                fl = plane_field3(s.L, centre - pad, W);
+                fv = plane_field3(s.V, centre - pad, W);
             }
         }
         for (uint32_t col = 0; col < W; ++col) {
-            const bool v = on && ((fv >> col) & 1), h = (fh >> col) & 1, l = (fl >> col) & 1;
+            const bool v = on && field_bit(fv, col), h = field_bit(fh, col), l = field_bit(fl, col);
             const unsigned long long ba = __ballot(v && !h && !l), bt = __ballot(v && h && !l);
             const unsigned long long bg = __ballot(v && h && l), bc = __ballot(v && !h && l);
             if (lane == 0) {                              // rows A, T, G, C (constants.py:1)
@@ -307,9 +332,9 @@ __global__ __launch_bounds__(256) void bg_counts_kernel(Planes s, const uint32_t
         }
     }
     __syncthreads();
-    unsigned long long *o = out + (size_t)blk.task * 4 * WIN_MAX_W;
+    unsigned long long *o = out + (size_t)blk.task * 4 * ws;
     for (uint32_t i = threadIdx.x; i < 4 * WIN_MAX_W; i += blockDim.x)
-        if (cnt[i]) atomicAdd(&o[i], (unsigned long long)cnt[i]);
+        if (cnt[i]) atomicAdd(&o[(i / WIN_MAX_W) * ws + i % WIN_MAX_W], (unsigned long long)cnt[i]);
 }
 
 // Methylation windows of one task from the sequence planes: a wave packs 64 windows; per column it ballots the five
@@ -319,24 +344,21 @@ __device__ __forceinline__ void pack_windows(const WinTask &t, const Planes &s, 
                                              uint64_t centre, bool minus, uint32_t pad, uint32_t *__restrict__ planes,
                                              uint32_t *__restrict__ alive) {
     const uint32_t W = t.width;
-    uint64_t fh = 0, fl = 0, fv = 0;
+    Field3 fh{}, fl{}, fv{};
     if (on) {
         const uint64_t g = centre - pad;
-        fh = plane_field(s.H, g, W);
-        fl = plane_field(s.L, g, W);
-        fv = plane_field(s.V, g, W);
-        if (minus) {
-            fh = __brevll(fh) >> (64 - W);
-            fl = __brevll(fl) >> (64 - W);
-            fv = __brevll(fv) >> (64 - W);
-            fh = ~fh & fv;
-        }
+        fh = plane_field3(s.H, g, W);
+        fl = plane_field3(s.L, g, W);
+        fv = plane_field3(s.V, g, W);
     }
     const uint32_t w = wave * 2 + lane;                   // word written by lanes 0 and 1
     const bool writer = lane < 2 && w < t.nw;
     const uint32_t shift = 32 * (lane & 1);
     for (uint32_t col = 0; col < W; ++col) {
-        const bool v = (fv >> col) & 1, h = (fh >> col) & 1, l = (fl >> col) & 1;
+        // minus rows: the window is read backwards and complemented (flip H in the (H, L) code; N stays N)
+        const uint32_t j = minus ? W - 1 - col : col;
+        const bool v = field_bit(fv, j), l = field_bit(fl, j);
+        const bool h = (field_bit(fh, j) != 0) != (minus && v);
         const unsigned long long ba = __ballot(on && v && !h && !l), bc = __ballot(on && v && !h && l);
         const unsigned long long bg = __ballot(on && v && h && l), bt = __ballot(on && v && h && !l);
         const unsigned long long bn = __ballot(on && !v);
@@ -505,17 +527,20 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
     return NM_OK;
 }
 
-int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
-                 int32_t *out) {
+int nm_win_batch_w(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                   uint32_t ws, int32_t *out) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (n_req == 0) return NM_OK;
     if (!req_task || !req_kind || !req_sets || !out) return fail(NM_EINVAL, "NULL argument");
+    if (ws == 0 || ws > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "width stride %u outside 1..%d", ws, WIN_MAX_W);
     HIP_TRY(hipSetDevice(c->device));
-    uint32_t max_nw = 1;
+    uint32_t max_nw = 1, max_w = 1;
     for (uint32_t r = 0; r < n_req; ++r) {
         if (req_task[r] >= c->win_tasks.size()) return fail(NM_EINVAL, "request %u: window task %u does not exist", r, req_task[r]);
         if (req_kind[r] > 1) return fail(NM_EINVAL, "request %u: kind must be 0 (pssm) or 1 (remove)", r);
         max_nw = std::max(max_nw, c->win_tasks[req_task[r]].nw);
+        max_w = std::max(max_w, c->win_tasks[req_task[r]].width);
+        if (c->win_tasks[req_task[r]].width > ws) return fail(NM_EINVAL, "request %u: window task of width %u, width stride %u", r, c->win_tasks[req_task[r]].width, ws);
     }
     if (c->win_tasks_dirty) {
         if (c->d_win_tasks_cap < c->win_tasks.size()) {
@@ -529,23 +554,23 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
         HIP_TRY(hipMemcpy(c->d_win_tasks, c->win_tasks.data(), c->win_tasks.size() * sizeof(WinTask), hipMemcpyHostToDevice));
         c->win_tasks_dirty = false;
     }
-    const uint32_t stride = 2 + 4 * WIN_MAX_W;
+    const uint32_t stride = 2 + 4 * ws;
     const size_t o_kind = (size_t)n_req * 4, o_sets = (o_kind + n_req + 15) & ~(size_t)15;
-    const size_t o_out = (o_sets + (size_t)n_req * WIN_MAX_W + 15) & ~(size_t)15;
+    const size_t o_out = (o_sets + (size_t)n_req * ws + 15) & ~(size_t)15;
     const size_t total = o_out + (size_t)n_req * stride * 4;
     int rc = ensure_stage(c, total);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
     memcpy(hs, req_task, (size_t)n_req * 4);
     memcpy(hs + o_kind, req_kind, n_req);
-    memcpy(hs + o_sets, req_sets, (size_t)n_req * WIN_MAX_W);
+    memcpy(hs + o_sets, req_sets, (size_t)n_req * ws);
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
     const uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
     nmdetail::busy_begin(c);
-    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, (WIN_MAX_W + WIN_COL_GROUP - 1) / WIN_COL_GROUP, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
+    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, (max_w + WIN_COL_GROUP - 1) / WIN_COL_GROUP, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
-                       reinterpret_cast<int *>(ds + o_out), stride);
+                       reinterpret_cast<int *>(ds + o_out), ws);
     nmdetail::busy_end(c);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, c->stream));
@@ -554,6 +579,11 @@ int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(out, hs + o_out, (size_t)n_req * stride * 4);
     return NM_OK;
+}
+
+int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                 int32_t *out) {
+    return nm_win_batch_w(c, n_req, req_task, req_kind, req_sets, NM_WIN_MAX_WIDTH, out);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -644,7 +674,8 @@ static int bg_counts_impl(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samp
     const size_t o_rank = (size_t)n_samples * 4, o_blk = (o_rank + (size_t)n_samples * 4 + 15) & ~(size_t)15;
     const size_t o_runs = (o_blk + blocks.size() * sizeof(BgBlock) + 15) & ~(size_t)15;
     const size_t o_out = (o_runs + n_runs * sizeof(BgRun) + 15) & ~(size_t)15;
-    const size_t out_bytes = (size_t)n_tasks * 4 * WIN_MAX_W * 8;
+    const uint32_t ws = (W + 7u) & ~7u;                       // columns per output row
+    const size_t out_bytes = (size_t)n_tasks * 4 * ws * 8;
     rc = ensure_stage(c, o_out + out_bytes);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
@@ -667,7 +698,7 @@ static int bg_counts_impl(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samp
         hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)blocks.size()), dim3(256), 0, c->stream, seq_planes(c),
                            c->d_rank[b], c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_blk),
                            reinterpret_cast<const uint32_t *>(ds), reinterpret_cast<const uint32_t *>(ds + o_rank), b, pad,
-                           reinterpret_cast<unsigned long long *>(ds + o_out), c->d_err);
+                           reinterpret_cast<unsigned long long *>(ds + o_out), ws, c->d_err);
         HIP_TRY(hipGetLastError());
     }
     unsigned int err = 0;
@@ -681,7 +712,7 @@ static int bg_counts_impl(nm_ctx *c, uint8_t base, uint32_t pad, uint64_t n_samp
     for (uint32_t t = 0; t < n_tasks; ++t)
         for (uint32_t r = 0; r < 4; ++r)
             for (uint32_t col = 0; col < W; ++col)
-                out[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * WIN_MAX_W + col];
+                out[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * ws + col];
     return NM_OK;
 }
 
@@ -1002,7 +1033,8 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     const size_t o_blk = up16(o_seg + segs.size() * sizeof(WinSegment)), o_runs = up16(o_blk + blocks.size() * sizeof(WinBlock));
     size_t o_bg[4], at = up16(o_runs + runs.size() * sizeof(BgRun));
     for (int b = 0; b < 4; ++b) { o_bg[b] = at; at = up16(at + bg_blocks[b].size() * sizeof(BgBlock)); }
-    const size_t o_out = at, out_bytes = (size_t)n_tasks * 4 * WIN_MAX_W * 8;
+    const uint32_t ws = (W + 7u) & ~7u;                       // columns per row of the background counts
+    const size_t o_out = at, out_bytes = (size_t)n_tasks * 4 * ws * 8;
     rc = ensure_stage(c, o_out + out_bytes);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
@@ -1069,7 +1101,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
             hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)bg_blocks[b].size()), dim3(256), 0, c->stream, seq_planes(c), c->d_rank[b],
                                c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_bg[b]),
                                reinterpret_cast<const uint32_t *>(ds + o_contig), reinterpret_cast<const uint32_t *>(ds + o_rank), b, pad,
-                               reinterpret_cast<unsigned long long *>(ds + o_out), c->d_err);
+                               reinterpret_cast<unsigned long long *>(ds + o_out), ws, c->d_err);
             HIP_TRY(hipGetLastError());
         }
         nmdetail::busy_end(c);
@@ -1086,7 +1118,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     for (uint32_t t = 0; t < n_tasks; ++t)
         for (uint32_t r = 0; r < 4; ++r)
             for (uint32_t col = 0; col < W; ++col)
-                bg_counts[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * WIN_MAX_W + col];
+                bg_counts[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * ws + col];
     return NM_OK;
 }
 

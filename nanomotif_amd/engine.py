@@ -31,8 +31,6 @@ class DeviceWindowStore:
     search.HostWindowStore.  Windows are bit planes over windows in HBM; a ``pssm`` request returns integer counts,
     a ``remove`` request clears the matching windows from the task's alive mask."""
 
-    STRIDE = 2 + 4 * 64
-
     def __init__(self, engine, allreduce=None):
         """``allreduce``: callable summing an int32 numpy array over the ranks of a multi-GPU run, in which every rank
         holds only the windows of its own contigs (tasks added with ``add_task_rows``)."""
@@ -83,12 +81,13 @@ class DeviceWindowStore:
             n = len(dev)
             task = np.fromiter((self.task_id[k] for _, k, _ in dev), dtype=np.uint32, count=n)
             kind = np.fromiter((1 if r.kind == "remove" else 0 for _, _, r in dev), dtype=np.uint8, count=n)
-            sets = np.full((n, 64), 15, dtype=np.uint8)
+            ws = (max(self.width[k] for _, k, _ in dev) + 63) // 64 * 64        # columns per row of sets / counts (nm_win_batch_w)
+            sets = np.full((n, ws), 15, dtype=np.uint8)
             for j, (_, k, r) in enumerate(dev):
                 sets[j, :self.width[k]] = r.motif.sets
-            res = np.zeros((n, self.STRIDE), dtype=np.int32)
-            _lib.check(self.engine.lib.nm_win_batch(self.engine.ctx, n, _ptr(task, C.c_uint32), _ptr(kind, C.c_uint8),
-                                                    _ptr(sets, C.c_uint8), res.ctypes.data_as(C.POINTER(C.c_int32))))
+            res = np.zeros((n, 2 + 4 * ws), dtype=np.int32)
+            _lib.check(self.engine.lib.nm_win_batch_w(self.engine.ctx, n, _ptr(task, C.c_uint32), _ptr(kind, C.c_uint8),
+                                                      _ptr(sets, C.c_uint8), ws, res.ctypes.data_as(C.POINTER(C.c_int32))))
             if self.allreduce is not None:
                 res = self.allreduce(res)
             for j, (i, k, r) in enumerate(dev):
@@ -96,7 +95,7 @@ class DeviceWindowStore:
                     out[i] = (int(res[j, 0]), int(res[j, 1]))
                 else:
                     w = self.width[k]
-                    out[i] = (int(res[j, 0]), res[j, 2:].reshape(4, 64)[:, :w].astype(np.int64))
+                    out[i] = (int(res[j, 0]), res[j, 2:].reshape(4, ws)[:, :w].astype(np.int64))
         return out
 
 

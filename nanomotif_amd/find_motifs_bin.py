@@ -25,7 +25,7 @@ from .pileup import MOD_TYPES, PileupTable
 from .search import HostWindowStore, extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
 
 IUPAC_LETTERS = set("ATGCRYSWKMBDHVN")
-MAX_WINDOW_WIDTH = 64          # include/nmscan.h: NM_WIN_MAX_WIDTH
+MAX_WINDOW_WIDTH = 191         # include/nmscan.h: NM_WIN_MAX_WIDTH 192 columns, scoring offsets within 95 of the modified base
 
 
 # ------------------------------------------------------------------------------------------------ config
@@ -65,8 +65,8 @@ class ProcessorConfig:
         if self.search_frame_size <= 1:
             raise ValueError("search_frame_size must be greater than 1")
         if 2 * (self.search_frame_size // 2) + 1 > MAX_WINDOW_WIDTH:
-            # the reference takes any frame (find_motifs_bin.py:128-130); the engine's window planes and motif offsets
-            # are 64 positions wide (include/nmscan.h: NM_WIN_MAX_WIDTH, NM_MAX_MOTIF_LEN)
+            # the reference takes any frame (find_motifs_bin.py:128-130; default 40); the engine's window planes hold 192
+            # columns and its scoring kernels reach 95 positions either side of the modified base (include/nmscan.h)
             raise ValueError(f"search_frame_size must be at most {MAX_WINDOW_WIDTH - 1} on the MI355X engine "
                              f"(windows of 2 * (search_frame_size // 2) + 1 <= {MAX_WINDOW_WIDTH} positions)")
         if not (0 <= self.methylation_threshold_high <= 1):

@@ -148,7 +148,7 @@ def find_best_candidates_custom(tasks, padding, min_kl, score_threshold, score_f
             text = C.string_at(motifs, cnt * W).decode("ascii")
             res = np.asarray(window_fn([(int(task[i]), "remove" if kind[i] else "pssm", Motif(text[i * W:(i + 1) * W], int(padding)))
                                         for i in range(cnt)]), dtype=np.int32)
-            np.ctypeslib.as_array(out, shape=(cnt, 2 + 4 * 64))[:] = res
+            np.ctypeslib.as_array(out, shape=(cnt, 2 + 4 * ((W + 63) // 64 * 64)))[:] = res
             return 0
         except Exception as e:
             err.append(e)

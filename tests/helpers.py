@@ -44,7 +44,7 @@ def oracle_bin_inputs(mg, mod_type, contigs=None, min_cov=5):
     return pile, seqs
 
 
-def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, high=0.7, bins=None):
+def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, high=0.7, bins=None, padding=20):
     """bin-motifs.tsv text computed end to end by the CPU oracle (filters -> search -> post-processing),
     following the task order / seeding of the reference's plain (or bgzip) strategy.  ``bins``: restrict to these
     bins (bins are independent tasks, find_motifs_bin.py:152-171)."""
@@ -56,7 +56,7 @@ def oracle_pipeline(mg, min_motifs_bin=50, seed=1, bgzip_order=False, low=0.3, h
             order.append(b)
     rows = []
     for b in order:
-        rows += opl.bin_rows(mg, b, seed=seed, bgzip_order=bgzip_order, low=low, high=high)
+        rows += opl.bin_rows(mg, b, seed=seed, bgzip_order=bgzip_order, low=low, high=high, padding=padding)
     return opp.format_bin_motifs(rows, min_motifs_bin=min_motifs_bin)
 
 

@@ -231,17 +231,24 @@ def test_more_ranks_than_contigs(tmp_path):
     assert open(tmp + "/out2/bin-motifs.tsv").read() == one
 
 
-def test_search_frame_size_beyond_the_engine_limit_is_refused(tmp_path):
-    """The reference takes any --search_frame_size (find_motifs_bin.py:128-130); the engine's windows are 64 wide."""
-    spec = synth.SynthSpec(n_contigs=1, total_bp=60_000, n_bins=1, mod_types=("a",), seed=62, fixed_motifs=())
+def test_wide_search_frames_equal_the_oracle_and_the_limit_is_refused(tmp_path):
+    """The reference takes any --search_frame_size (find_motifs_bin.py:128-130).  Frames above 63 use the three-word window
+    fields and, once a child reaches more than 63 positions from the modified base, the extra-wide scoring kernels
+    (offsets in [-96, 95]); the engine stops at 191 (windows of 191 columns)."""
+    spec = synth.SynthSpec(n_contigs=3, total_bp=300_000, n_bins=1, mod_types=("a", "m"), seed=64, min_contig_bp=60_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("GCACNNNNNNGTT", 2, "a"), ("CCWGG", 1, "m")))
     mg = synth.make_metagenome(spec)
     tmp = str(tmp_path)
     mg.write_fasta(tmp + "/a.fasta")
     mg.write_bed(tmp + "/p.bed")
     mg.write_contig_bin(tmp + "/cb.tsv")
-    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "64"], check=False)
-    assert r.returncode != 0 and "search_frame_size must be at most 63" in r.stdout + r.stderr
-    _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o63", "--search_frame_size", "62"])
+    for frame in (62, 100, 128, 191):
+        _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", f"o{frame}", "--search_frame_size", str(frame)])
+        got = open(f"{tmp}/o{frame}/bin-motifs.tsv").read()
+        assert got == oracle_pipeline(mg, padding=frame // 2), frame
+        assert "GATC" in got
+    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "192"], check=False)
+    assert r.returncode != 0 and "search_frame_size must be at most 190" in r.stdout + r.stderr
 
 
 def test_assembly_with_other_iupac_letters_takes_the_host_window_path(tmp_path):

@@ -310,3 +310,31 @@ def test_hit_positions_compaction_on_a_long_contig():
                                         0, out.ctypes.data_as(C.POINTER(C.c_int64)), 100, C.byref(n)))
     assert n.value == len(want) and np.array_equal(out, want[:100])
     eng.close()
+
+
+def test_extra_wide_motifs_reach_95_positions_from_the_modified_base(engine_cls):
+    """Search frames above 127 make children that reach up to 95 positions from the modified base: the extra-wide kernels
+    (three halo words either side, offsets in [-96, 95]) against the oracle scan, compact and general state, plus the
+    per-contig counters; one position further is refused."""
+    from nanomotif_amd._lib import NmScanError
+    from oracle.scan import score_candidates
+    spec = synth.SynthSpec(n_contigs=5, total_bp=400_000, n_bins=2, mod_types=("a", "m"), seed=77, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    eng = engine_cls()
+    _upload_metagenome(eng, mg, ("a", "m"))
+    zoo = {"a": [("T" + "." * 70 + "A", 71), ("A" + "." * 90 + "G", 0), ("C" + "." * 94 + "A" + "." * 94 + "G", 95), ("G.." + "A" + "." * 64 + "[CT]", 3),
+                 ("GATC", 1), ("[AG]" + "." * 80 + "T" + "." * 10 + "A", 92), ("T" + "." * 94 + "A", 0)],
+           "m": [("C" + "." * 64 + "G", 0), ("A" + "." * 94 + "C", 95), ("G" + "." * 70 + "C" + "." * 70 + "[AT]", 71)]}
+    for mt, motifs in zoo.items():
+        for b in sorted(set(mg.bin_names)):
+            idx = [i for i, x in enumerate(mg.bin_names) if x == b]
+            pile, seqs = oracle_bin_inputs(mg, mt, contigs=idx)
+            want = score_candidates(pile, seqs, motifs)
+            got = eng.score([(Motif(s, p), mt, b) for s, p in motifs])
+            assert np.array_equal(got, want), (mt, b, got.tolist(), want.tolist())
+            per = eng.score_per_contig([(Motif(s, p), mt, b) for s, p in motifs])
+            assert np.array_equal(np.array([t.sum(axis=0) for _, t in per]), want)
+    assert eng.score([(Motif("T" + "." * 70 + "A", 71), "a", "bin_000")]).sum() > 0
+    with pytest.raises(NmScanError, match="the engine reaches 95"):
+        eng.score([(Motif("A" + "." * 95 + "G", 0), "a", "bin_000")])
+    eng.close()
