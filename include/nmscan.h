@@ -363,6 +363,9 @@ int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uin
                             char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,
                             uint8_t *node_visited, int32_t *edges, int32_t *best);
 int nm_search_result_free(nm_search_result *res);
+/* digamma of a positive integer, the value scipy.special.psi returns bit for bit (Cephes psi; model.py:82-83 only ever
+ * evaluates it at alpha, beta, alpha + beta = 5 + counts) — what the native search uses, for hosts that score without SciPy. */
+int nm_psi_posint(int64_t n, double *out);
 
 /* ---- multi-GPU exchange: sum of the per-rank count tables ------------------------------------------------------
  * One process per GPU; contigs are sharded over the ranks and counts are sums over contigs

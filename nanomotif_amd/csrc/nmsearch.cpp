@@ -875,6 +875,13 @@ int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uin
     return NM_OK;
 }
 
+int nm_psi_posint(int64_t n, double *out) {
+    if (!out) return nm_set_error(NM_EINVAL, "out is NULL");
+    if (n < 1) return nm_set_error(NM_EINVAL, "nm_psi_posint needs n >= 1, got %lld", (long long)n);
+    *out = psi_int((double)n);
+    return NM_OK;
+}
+
 int nm_search_result_free(nm_search_result *res) {
     delete res;
     return NM_OK;

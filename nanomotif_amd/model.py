@@ -3,8 +3,30 @@ nanomotif/model.py:11-92 and find_motifs_bin.py:1360-1379 (same names and argume
 Scores never run on the GPU: they need digamma in float64 and are O(1) per candidate."""
 from __future__ import annotations
 
+import ctypes as _C
+
 import numpy as np
-from scipy.special import psi
+
+_native_psi = None
+_scipy_psi = None
+
+
+def psi(x):
+    """digamma.  The model only ever asks for it at positive integers (alpha, beta, alpha + beta = prior + counts): those
+    go to libnmscan's nm_psi_posint — scipy.special.psi's value bit for bit (tests/test_native_search.py checks the two
+    against each other) without importing SciPy at CLI start-up (0.1-0.3 s); anything else falls back to SciPy."""
+    global _native_psi, _scipy_psi
+    if isinstance(x, (int, np.integer)) and x >= 1:
+        if _native_psi is None:
+            from . import _lib
+            _native_psi = _lib.load().nm_psi_posint
+        out = _C.c_double(0.0)
+        if _native_psi(int(x), _C.byref(out)) == 0:
+            return out.value
+    if _scipy_psi is None:
+        from scipy.special import psi as _p
+        _scipy_psi = _p
+    return _scipy_psi(x)
 
 DEFAULT_PRIOR_ALPHA = 5
 DEFAULT_PRIOR_BETA = 5

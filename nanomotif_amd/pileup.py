@@ -9,7 +9,6 @@ import os
 from dataclasses import dataclass
 
 import numpy as np
-from scipy.ndimage import maximum_filter1d
 
 MOD_TYPES = ["m", "a", "21839"]      # constants.py MOD_CODE_TO_PRETTY order = task order (find_motifs_bin.py:152-153)
 
@@ -249,6 +248,7 @@ def filter_pileup_adjacency_filter(t: PileupTable, methylation_threshold=0.7, ad
     per contig and strand (exact: max of float64 values)."""
     if len(t) == 0:
         return t
+    from scipy.ndimage import maximum_filter1d          # (imported here: the CLI filters on the device and never needs it)
     keep = np.zeros(len(t), dtype=bool)
     order = np.lexsort((t.position, t.strand, t.contig))
     grp = t.contig[order].astype(np.int64) * 2 + (t.strand[order] == ord("-"))

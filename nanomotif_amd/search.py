@@ -19,7 +19,6 @@ import math
 import random
 
 import numpy as np
-from scipy.special import rel_entr
 
 from .model import BetaBernoulliModel, predictive_evaluation_score
 from .motif import BASES, MOD_TYPE_TO_CANONICAL, Motif
@@ -319,6 +318,7 @@ def kl_divergence_columns(pk: np.ndarray, qk: np.ndarray) -> np.ndarray:
     with np.errstate(invalid="ignore", divide="ignore"):
         pk = 1.0 * pk / np.sum(pk, axis=0, keepdims=True)
         qk = 1.0 * qk / np.sum(qk, axis=0, keepdims=True)
+    from scipy.special import rel_entr                  # (lazy: the native search path never gets here)
     return np.sum(rel_entr(pk, qk), axis=0)
 
 
