@@ -263,7 +263,7 @@ def kernel_source_sha16():
     (profiles/traffic.json) to the code they were measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("nmscan.hip", "nmscan_internal.h"):       # (profiles/summarize.py hashes the same two files)
+    for f in ("nmscan.hip", "nmscan_device.h", "nmscan_internal.h"):       # (profiles/summarize.py hashes the same two files)
         h.update(open(os.path.join(ROOT, "nanomotif_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -157,10 +157,20 @@ class Motif(str):
         return lo, hi
 
     def new_stripped_motif(self, character="."):
+        cached = self.__dict__.get("_stripped")            # (motifs are immutable; post-processing asks thousands of times)
+        if cached is not None:
+            return cached
         lo, hi = self._dot_bounds()
         if lo == len(self.tokens):
-            return self
-        return Motif("".join(self.tokens[lo:hi]), self.mod_position - lo)
+            out = self
+        elif lo == 0 and hi == len(self.tokens):
+            out = Motif(self.string, self.mod_position)
+            out.__dict__["_stripped"] = out
+        else:
+            out = Motif("".join(self.tokens[lo:hi]), self.mod_position - lo)
+            out.__dict__["_stripped"] = out
+        self.__dict__["_stripped"] = out
+        return out
 
     def stripped_sets(self):
         """(sets of the stripped motif as uint8 array, stripped mod_position) — the engine's candidate form."""

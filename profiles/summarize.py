@@ -15,7 +15,7 @@ dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), rnd, sub)
 os.makedirs(dst, exist_ok=True)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("nmscan.hip", "nmscan_internal.h"):
+for _f in ("nmscan.hip", "nmscan_device.h", "nmscan_internal.h"):
     _h.update(open(os.path.join(ROOT, "nanomotif_amd", "csrc", _f), "rb").read())
 KERNEL_SHA = _h.hexdigest()[:16]
 KEEP = ("score_kernel", "compile_kernel", "pack_kernel", "state_kernel", "needs_v_kernel")
