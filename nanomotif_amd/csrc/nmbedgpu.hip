@@ -36,7 +36,7 @@ using namespace nmdetail;
 namespace {
 
 constexpr uint32_t BLOCK_BYTES = 16384;           // bytes per workgroup in the line-start passes (256 threads x 64 B)
-constexpr uint64_t SLAB_BYTES = 64ull << 20;            // per slab: 3 pinned + 2 device buffers of this size (pinning memory costs ~0.2 ms per MB)
+constexpr uint64_t SLAB_BYTES = 32ull << 20;            // per slab: 3 pinned + 2 device buffers of this size (pinning memory costs ~0.2 ms per MB)
 constexpr uint32_t PATCH_CAP = 1u << 22;
 
 enum RowError : uint32_t { E_NONE = 0, E_COLUMNS = 1, E_START = 2, E_COV = 3, E_PCT = 4, E_POS_RANGE = 5 };
@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256) void bed_starts_kernel(const uint8_t *__restri
 }
 
 struct BedOut {
-    uint64_t *hash;             // [row] name hash
-    uint64_t *line_off;         // [row] file offset of the row's line
+    uint64_t *hash;             // [line of the slab] name hash (scratch of one slab)
     uint32_t *position;
     int8_t *mod;
     uint8_t *strand;
@@ -114,7 +113,7 @@ struct BedOut {
     int32_t *nvalid;
     unsigned long long *first_error;   // min over (row << 8 | code)
     unsigned int *n_patch;
-    uint2 *patch;               // (row, flags) — a pileup holds fewer than 2^32 rows (checked)
+    uint4 *patch;               // (row, flags, file offset lo, hi) — a pileup holds fewer than 2^32 rows (checked)
 };
 
 __device__ __forceinline__ bool field_is_null(const uint8_t *p, uint32_t n) {
@@ -230,11 +229,10 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
     }
     if (err) {
         atomicMin(o.first_error, ((unsigned long long)row << 8) | err);
-        o.hash[row] = 0;
+        o.hash[li] = 0;
         return;
     }
-    o.hash[row] = h;
-    o.line_off[row] = slab_file_off + line_start[li];
+    o.hash[li] = h;
     o.position[row] = (uint32_t)pos;
     o.mod[row] = mt;
     o.strand[row] = st;
@@ -242,18 +240,26 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
     o.nvalid[row] = cov < 0 ? -1 : (int32_t)(cov > 0x7FFFFFFF ? 0x7FFFFFFF : cov);
     if (flags) {
         const unsigned int k = atomicAdd(o.n_patch, 1u);
-        if (k < PATCH_CAP) o.patch[k] = make_uint2((uint32_t)row, flags);
+        const uint64_t off = slab_file_off + line_start[li];
+        if (k < PATCH_CAP) o.patch[k] = make_uint4((uint32_t)row, flags, (uint32_t)off, (uint32_t)(off >> 32));
     }
 }
 
-// (4) rows whose contig name differs from the row before: the starts of the runs
-__global__ void bed_runs_kernel(const uint64_t *__restrict__ hash, uint64_t n_rows, unsigned int *n_runs, unsigned long long *run_row, uint32_t cap) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    if (i == 0 || hash[i] != hash[i - 1]) {
+// (4) rows whose contig name differs from the row before: the starts of the runs, found slab by slab (the hashes and the
+// line starts of a slab are scratch).  prev_in / prev_out: the hash of the last row of the previous / of this slab.
+struct BedRun { unsigned long long row, off; };
+
+__global__ void bed_runs_kernel(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ line_start, uint32_t n_lines, uint64_t row0,
+                                uint64_t slab_file_off, int first_slab, const unsigned long long *__restrict__ prev_in,
+                                unsigned long long *__restrict__ prev_out, unsigned int *n_runs, BedRun *runs, uint32_t cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lines) return;
+    const unsigned long long before = i ? hash[i - 1] : *prev_in;
+    if ((i == 0 && first_slab) || hash[i] != before) {
         const unsigned int k = atomicAdd(n_runs, 1u);
-        if (k < cap) run_row[k] = i;
+        if (k < cap) runs[k] = BedRun{row0 + i, slab_file_off + line_start[i]};
     }
+    if (i == n_lines - 1) *prev_out = hash[i];
 }
 
 // (5) contig column from the run table (ascending run starts): id of the last run that starts at or before the row
@@ -267,12 +273,6 @@ __global__ void bed_fill_contig_kernel(uint64_t n_rows, const unsigned long long
         if (run_row[mid] <= i) lo = mid; else hi = mid - 1;
     }
     contig[i] = run_id[lo];
-}
-
-__global__ void bed_gather_off_kernel(uint32_t n, const unsigned long long *__restrict__ rows, const uint64_t *__restrict__ line_off,
-                                      unsigned long long *__restrict__ out) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = line_off[rows[k]];
 }
 
 __global__ void bed_patch_kernel(uint32_t n, const unsigned long long *__restrict__ row, const int8_t *__restrict__ mod, const double *__restrict__ frac,
@@ -298,7 +298,6 @@ struct nm_bedcols {
     uint8_t *d_strand = nullptr;
     double *d_frac = nullptr;
     int32_t *d_nvalid = nullptr;
-    uint64_t *d_hash = nullptr, *d_line_off = nullptr;      // scratch of the parse: released when it is done
     std::vector<std::string> names, other_mods;
     std::vector<const char *> name_ptrs;
     std::vector<uint64_t> run_row;          // ascending, + n_rows at the end
@@ -309,11 +308,11 @@ struct nm_bedcols {
 namespace {
 
 void free_cols(nm_bedcols *b) {
-    void *ptrs[] = {b->d_file_contig, b->d_contig, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, b->d_hash, b->d_line_off};
+    void *ptrs[] = {b->d_file_contig, b->d_contig, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid};
     for (void *p : ptrs)
         if (p) (void)dev_free(p);
     b->d_file_contig = b->d_contig = b->d_position = nullptr;
-    b->d_mod = nullptr; b->d_strand = nullptr; b->d_frac = nullptr; b->d_nvalid = nullptr; b->d_hash = b->d_line_off = nullptr;
+    b->d_mod = nullptr; b->d_strand = nullptr; b->d_frac = nullptr; b->d_nvalid = nullptr;
 }
 
 // grow the six output columns (+ hash) to hold `rows`; device-to-device copies of what is there
@@ -333,8 +332,7 @@ int grow(nm_bedcols *b, uint64_t rows, hipStream_t s) {
     };
     int rc;
     if ((rc = regrow((void **)&b->d_position, 4)) || (rc = regrow((void **)&b->d_mod, 1)) || (rc = regrow((void **)&b->d_strand, 1)) ||
-        (rc = regrow((void **)&b->d_frac, 8)) || (rc = regrow((void **)&b->d_nvalid, 4)) || (rc = regrow((void **)&b->d_hash, 8)) ||
-        (rc = regrow((void **)&b->d_line_off, 8)))
+        (rc = regrow((void **)&b->d_frac, 8)) || (rc = regrow((void **)&b->d_nvalid, 4)))
         return rc;
     b->cap = ncap;
     return NM_OK;
@@ -410,9 +408,12 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     uint8_t *h_ring[RING] = {nullptr, nullptr, nullptr};
     uint8_t *d_slab[2] = {nullptr, nullptr};
     uint32_t *d_line_start = nullptr, *d_block_cnt = nullptr, *d_block_off = nullptr;
-    unsigned long long *d_first_error = nullptr, *d_run_row = nullptr;
+    unsigned long long *d_first_error = nullptr, *d_run_row = nullptr, *d_prev = nullptr;
+    uint64_t *d_hash = nullptr;
+    BedRun *d_runs = nullptr;
+    constexpr uint32_t RUN_CAP = 1u << 22;
     unsigned int *d_counters = nullptr;           // [0] patches, [1] runs
-    uint2 *d_patch = nullptr;
+    uint4 *d_patch = nullptr;
     void *d_scan_tmp = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t h2d_done[RING] = {nullptr, nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
@@ -450,7 +451,10 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     HIP_TRY(tmp_alloc((void **)&d_block_off, ((size_t)max_blocks + 1) * 4));
     HIP_TRY(tmp_alloc((void **)&d_first_error, 8));
     HIP_TRY(tmp_alloc((void **)&d_counters, 8));
-    HIP_TRY(tmp_alloc((void **)&d_patch, (size_t)PATCH_CAP * sizeof(uint2)));
+    HIP_TRY(tmp_alloc((void **)&d_patch, (size_t)PATCH_CAP * sizeof(uint4)));
+    HIP_TRY(tmp_alloc((void **)&d_hash, line_cap * 8));
+    HIP_TRY(tmp_alloc((void **)&d_runs, (size_t)RUN_CAP * sizeof(BedRun)));
+    HIP_TRY(tmp_alloc((void **)&d_prev, 16));
     size_t scan_bytes = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)max_blocks + 1, rocprim::plus<unsigned int>(), c->stream));
     HIP_TRY(tmp_alloc(&d_scan_tmp, scan_bytes));
@@ -493,6 +497,8 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         ~Join() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
     } join{producer, mu, cv, stop};
 
+    bool first_rows = true;                 // the next slab with rows holds row 0
+    size_t n_parsed = 0;                    // slabs with rows so far (ping-pong of the "hash of the row before")
     for (size_t k = 0; k < n_slabs; ++k) {
         const uint64_t len = cut[k + 1] - cut[k];
         {
@@ -526,10 +532,14 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         if (rc) return rc;
         if (n_lines) {
             hipLaunchKernelGGL(bed_starts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_slab[k % 2], len, d_block_off, d_line_start);
-            BedOut o{b->d_hash, b->d_line_off, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
+            BedOut o{d_hash, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
             hipLaunchKernelGGL(bed_parse_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_slab[k % 2], len, d_line_start, n_lines, b->n_rows,
                                cut[k], o);
+            hipLaunchKernelGGL(bed_runs_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_hash, d_line_start, n_lines, b->n_rows, cut[k],
+                               first_rows ? 1 : 0, d_prev + (n_parsed & 1), d_prev + ((n_parsed + 1) & 1), d_counters + 1, d_runs, RUN_CAP);
             HIP_TRY(hipGetLastError());
+            first_rows = false;
+            n_parsed += 1;
         }
         HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
         b->n_rows += n_lines;
@@ -538,21 +548,6 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first_error != ~0ull) return fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF)));
-    // file offsets of the lines of a list of rows (ascending rows in, offsets out)
-    auto offsets_of = [&](const std::vector<unsigned long long> &rows, std::vector<unsigned long long> &offs) -> int {
-        offs.resize(rows.size());
-        if (rows.empty()) return NM_OK;
-        unsigned long long *d_rows = nullptr, *d_offs = nullptr;
-        HIP_TRY(tmp_alloc((void **)&d_rows, rows.size() * 8));
-        HIP_TRY(tmp_alloc((void **)&d_offs, rows.size() * 8));
-        HIP_TRY(hipMemcpyAsync(d_rows, rows.data(), rows.size() * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(bed_gather_off_kernel, dim3((unsigned)((rows.size() + 255) / 256)), dim3(256), 0, c->stream, (uint32_t)rows.size(), d_rows,
-                           b->d_line_off, d_offs);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(offs.data(), d_offs, rows.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        return NM_OK;
-    };
     auto field = [&](uint64_t line, int k, const char **fb, const char **fe) {     // k-th tab-separated field of the line at `line`
         const char *p = reinterpret_cast<const char *>(file) + line, *end = reinterpret_cast<const char *>(file) + n;
         const char *le = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
@@ -568,19 +563,16 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     };
     // ---- runs of equal contig names -> names, ids, the contig column
     if (b->n_rows) {
-        const uint32_t run_cap = 1u << 22;
-        HIP_TRY(tmp_alloc((void **)&d_run_row, (size_t)run_cap * 8));
-        hipLaunchKernelGGL(bed_runs_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->d_hash, b->n_rows, d_counters + 1, d_run_row, run_cap);
-        HIP_TRY(hipGetLastError());
         unsigned int n_runs = 0;
         HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (n_runs > run_cap) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, run_cap);
-        std::vector<unsigned long long> rows(n_runs), offs;
-        HIP_TRY(hipMemcpy(rows.data(), d_run_row, (size_t)n_runs * 8, hipMemcpyDeviceToHost));
-        std::sort(rows.begin(), rows.end());
-        int rc = offsets_of(rows, offs);
-        if (rc) return rc;
+        if (n_runs > RUN_CAP) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, RUN_CAP);
+        std::vector<BedRun> runs(n_runs);
+        HIP_TRY(hipMemcpy(runs.data(), d_runs, (size_t)n_runs * sizeof(BedRun), hipMemcpyDeviceToHost));
+        std::sort(runs.begin(), runs.end(), [](const BedRun &x, const BedRun &y) { return x.row < y.row; });
+        std::vector<unsigned long long> rows(n_runs), offs(n_runs);
+        for (unsigned int r = 0; r < n_runs; ++r) { rows[r] = runs[r].row; offs[r] = runs[r].off; }
+        int rc = NM_OK;
         std::unordered_map<std::string, uint32_t> ids;
         b->run_row.assign(rows.begin(), rows.end());
         b->run_contig.resize(n_runs);
@@ -600,6 +592,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         HIP_TRY(tmp_alloc((void **)&d_run_id, (size_t)n_runs * 4));
         HIP_TRY(dev_malloc(&b->d_file_contig, b->n_rows * 4));
         HIP_TRY(dev_malloc(&b->d_contig, b->n_rows * 4));
+        HIP_TRY(tmp_alloc((void **)&d_run_row, (size_t)n_runs * 8));
         HIP_TRY(hipMemcpyAsync(d_run_row, rows.data(), (size_t)n_runs * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_run_id, b->run_contig.data(), (size_t)n_runs * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(bed_fill_contig_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->n_rows, d_run_row, d_run_id, n_runs,
@@ -612,13 +605,11 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (np > PATCH_CAP) return fail(NM_ERANGE, "%s: more than %u rows need the host parser (unusual mod codes / number formats): use nm_bed_open", path, PATCH_CAP);
         if (np) {
-            std::vector<uint2> patch(np);
-            HIP_TRY(hipMemcpy(patch.data(), d_patch, (size_t)np * sizeof(uint2), hipMemcpyDeviceToHost));
-            std::sort(patch.begin(), patch.end(), [](const uint2 &x, const uint2 &y) { return x.x < y.x; });
-            std::vector<unsigned long long> prow(np), poff;
-            for (unsigned int i = 0; i < np; ++i) prow[i] = patch[i].x;
-            rc = offsets_of(prow, poff);
-            if (rc) return rc;
+            std::vector<uint4> patch(np);
+            HIP_TRY(hipMemcpy(patch.data(), d_patch, (size_t)np * sizeof(uint4), hipMemcpyDeviceToHost));
+            std::sort(patch.begin(), patch.end(), [](const uint4 &x, const uint4 &y) { return x.x < y.x; });
+            std::vector<unsigned long long> prow(np), poff(np);
+            for (unsigned int i = 0; i < np; ++i) { prow[i] = patch[i].x; poff[i] = ((unsigned long long)patch[i].w << 32) | patch[i].z; }
             std::vector<int8_t> pmod(np, 0);
             std::vector<double> pfrac(np, 0.0);
             std::vector<uint8_t> pwhat(np, 0);
@@ -658,9 +649,6 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
-        (void)dev_free(b->d_hash);
-        (void)dev_free(b->d_line_off);
-        b->d_hash = b->d_line_off = nullptr;
     }
     for (auto &s_ : b->names) b->name_ptrs.push_back(s_.c_str());
     b->t_read = t_read;
