@@ -17,10 +17,10 @@
 // The columns stay in HBM in exactly the types nm_ingest_pileup takes (rows_on_device = 1): no pileup row ever exists
 // as a host array.  nmbed.cpp's parser is the bit-exactness oracle for every row (tests/test_gpu_bed_device.py).
 #include <fcntl.h>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -375,18 +375,23 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return fail(NM_EINVAL, "cannot stat pileup '%s'", path); }
     const uint64_t n = (uint64_t)st.st_size;
-    const uint8_t *file = nullptr;
-    if (n) {
-        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { close(fd); return fail(NM_EINVAL, "cannot map pileup '%s'", path); }
-        file = static_cast<const uint8_t *>(m);
+    // the file is READ (pread straight into the pinned slabs), not mapped: mapping 8 GB costs two million page faults on the
+    // way in and as many page-table entries on the way out
+    struct CloseFd { int fd; ~CloseFd() { close(fd); } } close_fd{fd};
+    auto read_at = [&](uint64_t off, void *dst, uint64_t len) -> bool {
+        uint8_t *d = static_cast<uint8_t *>(dst);
+        while (len) {
+            const ssize_t k = pread(fd, d, (size_t)std::min<uint64_t>(len, 1u << 30), (off_t)off);
+            if (k <= 0) return false;
+            d += k; off += (uint64_t)k; len -= (uint64_t)k;
+        }
+        return true;
+    };
+    {
+        uint8_t magic[2] = {0, 0};
+        if (n >= 2 && !read_at(0, magic, 2)) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
+        if (n >= 2 && magic[0] == 31 && magic[1] == 139) return fail(NM_EINVAL, "%s: compressed input: the device parser reads plain text (use nm_bed_open)", path);
     }
-    close(fd);
-    struct Unmap {
-        const uint8_t *p; uint64_t n;
-        ~Unmap() { if (p) munmap(const_cast<uint8_t *>(p), n); }
-    } unmap{file, n};
-    if (n >= 2 && file[0] == 31 && file[1] == 139) return fail(NM_EINVAL, "%s: compressed input: the device parser reads plain text (use nm_bed_open)", path);
     nm_bedcols *b = new (std::nothrow) nm_bedcols();
     if (!b) return fail(NM_ENOMEM, "out of host memory");
     b->ctx = c;
@@ -395,10 +400,19 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     std::vector<uint64_t> cut(1, 0);
     while (cut.back() < n) {
         uint64_t e = std::min<uint64_t>(n, cut.back() + SLAB_BYTES);
-        if (e < n) {
+        if (e < n) {                                       // back to the end of the last whole line (the tail of the slab is read in pieces)
             const uint64_t lo = cut.back();
-            while (e > lo && file[e - 1] != '\n') --e;
-            if (e == lo) return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)SLAB_BYTES);
+            std::vector<uint8_t> win(1u << 16);
+            bool found = false;
+            while (e > lo && !found) {
+                const uint64_t w0 = e - lo > win.size() ? e - win.size() : lo;
+                if (!read_at(w0, win.data(), e - w0)) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
+                uint64_t k = e;
+                while (k > w0 && win[k - 1 - w0] != '\n') --k;
+                if (k > w0) { e = k; found = true; }
+                else e = w0;
+            }
+            if (!found) return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)SLAB_BYTES);
         }
         cut.push_back(e);
     }
@@ -461,6 +475,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     HIP_TRY(hipMemsetAsync(d_first_error, 0xFF, 8, c->stream));
     HIP_TRY(hipMemsetAsync(d_counters, 0, 8, c->stream));
 
+    std::atomic<bool> read_failed{false};
     std::mutex mu;
     std::condition_variable cv;
     size_t filled = 0, consumed = 0;              // slabs copied into the ring / slabs whose H2D has been waited for
@@ -481,7 +496,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
             for (unsigned t = 0; t < nt; ++t)
                 pool.emplace_back([&, t] {
                     const uint64_t a = len * t / nt, e = len * (t + 1) / nt;
-                    memcpy(dst + a, file + lo + a, e - a);
+                    if (!read_at(lo + a, dst + a, e - a)) read_failed = true;
                 });
             for (auto &th : pool) th.join();
             t_read += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
@@ -544,12 +559,16 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
         b->n_rows += n_lines;
     }
+    if (read_failed) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
     unsigned long long first_error = ~0ull;
     HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first_error != ~0ull) return fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF)));
+    std::vector<char> line_buf(1u << 16);
     auto field = [&](uint64_t line, int k, const char **fb, const char **fe) {     // k-th tab-separated field of the line at `line`
-        const char *p = reinterpret_cast<const char *>(file) + line, *end = reinterpret_cast<const char *>(file) + n;
+        const uint64_t got = std::min<uint64_t>(line_buf.size(), n - line);
+        if (!read_at(line, line_buf.data(), got)) { *fb = *fe = line_buf.data(); return; }
+        const char *p = line_buf.data(), *end = line_buf.data() + got;
         const char *le = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
         if (!le) le = end;
         if (le > p && le[-1] == '\r') --le;
