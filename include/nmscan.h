@@ -363,6 +363,36 @@ int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uin
                             char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,
                             uint8_t *node_visited, int32_t *edges, int32_t *best);
 int nm_search_result_free(nm_search_result *res);
+/* ---- post-processing of the searches' best candidates, natively -----------------------------------------------------
+ * process_subpileup after the search (find_motifs_bin.py:537-596) for EVERY task of a finished nm_search_run at once:
+ * graph nodes that are best candidates (score-descending) -> remove_noisy_motifs (postprocess.py:7-25) -> the clique
+ * merge of merge_motifs_in_df (find_motifs_bin.py:1436-1537, motif.py:484-560) -> remove_sub_motifs (postprocess.py:
+ * 41-82) -> join_motif_complements (:85-109), with the reference's de-duplication after each of the last three.  The
+ * merge stage scores, for all tasks together, (1) every merged motif with its exploded pre-merge variants and (2) every
+ * accepted merged motif with its parents: two scoring batches on classification task_merge_slot[i] of bin task_bin[i]
+ * (the reference evaluates this stage at 0.3 / 0.7 whatever the CLI thresholds are).  reduce: as in nm_search_run.
+ * nm_post_run_custom: the same on a caller-supplied scorer (CPU tests); it gets n motifs as regex-style text
+ * (letters, '.', sorted "[..]" groups; text_off[n + 1]) with their mod positions and task indices.
+ *
+ * Export: one record per (task, stage, row), tasks ascending, stages 0..4 = motifs, -noise, -merge, -sub, -complement
+ * (the precleanup tables; a task ends at the first stage that leaves no row), rows in the reference's order.  text holds
+ * for record i the motif at [text_off[2i], text_off[2i+1]) and its IUPAC form at [text_off[2i+1], text_off[2i+2]);
+ * counts = int64[n][2] (n_mod, n_nomod); complement = record index of the complement row (a stage-3 record of the same
+ * task) or -1.  stats[2] = scoring batches, candidates scored. */
+typedef struct nm_post_result nm_post_result;
+typedef int (*nm_post_score_fn)(void *user, uint32_t n, const uint32_t *task, const char *text, const uint32_t *text_off,
+                                const int32_t *mod_position, int64_t *out_counts);
+int nm_post_run(nm_ctx *ctx, const nm_search_result *res, const uint32_t *task_bin, const uint32_t *task_merge_slot,
+                nm_search_reduce_fn reduce, void *reduce_user, nm_post_result **out);
+int nm_post_run_custom(const nm_search_result *res, nm_post_score_fn score_fn, void *user, nm_post_result **out);
+/* the same from explicit rows instead of a search result (tests): task t holds rows [row_off[t], row_off[t + 1]) in graph
+ * node order — motifs = width characters each (A C G T ., modified base in the middle), counts = int64[n][2], score */
+int nm_post_run_rows_custom(uint32_t n_tasks, uint32_t width, const uint64_t *row_off, const char *motifs, const int64_t *counts,
+                            const double *score, nm_post_score_fn score_fn, void *user, nm_post_result **out);
+int nm_post_sizes(const nm_post_result *post, uint64_t *n_rows, uint64_t *text_bytes, uint64_t stats[2]);
+int nm_post_export(const nm_post_result *post, uint32_t *row_task, uint8_t *row_stage, uint64_t *text_off, char *text,
+                   int32_t *mod_position, int32_t *mod_position_iupac, int64_t *counts, double *score, int64_t *complement);
+int nm_post_free(nm_post_result *post);
 /* digamma of a positive integer, the value scipy.special.psi returns bit for bit (Cephes psi; model.py:82-83 only ever
  * evaluates it at alpha, beta, alpha + beta = 5 + counts) — what the native search uses, for hosts that score without SciPy. */
 int nm_psi_posint(int64_t n, double *out);

@@ -185,17 +185,26 @@ def task_coroutine(bin_name, mod_type, bin_pssm, cfg: ProcessorConfig, stage_wri
     return (yield from post_coroutine(bin_name, mod_type, res, cfg, stage_writer, temp_dir))
 
 
-def post_coroutine(bin_name, mod_type, res, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
-    """The part of process_subpileup after the search (find_motifs_bin.py:537-596): ``res`` = what
-    find_best_candidates returned — (graph, best candidates, background PSSM) or None."""
+def write_search_artifacts(bin_name, mod_type, res, temp_dir=None):
+    """What process_subpileup leaves next to the tables (find_motifs_bin.py:521-535): the "no motifs" log line, the
+    background PSSM and the search graph under ``temp_dir``.  Returns False when the search found nothing."""
     if res is None:
         log.info(f"[{bin_name} {mod_type}] No motifs found")
-        return None
+        return False
     graph, best, bin_pssm = res
     if temp_dir:
         os.makedirs(temp_dir, exist_ok=True)
         np.savetxt(os.path.join(temp_dir, "background_pssm.txt"), bin_pssm, fmt="%.4f")
         graph.export_graph_gml(os.path.join(temp_dir, f"motif_graph_{mod_type}.gml"))
+    return True
+
+
+def post_coroutine(bin_name, mod_type, res, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+    """The part of process_subpileup after the search (find_motifs_bin.py:537-596): ``res`` = what
+    find_best_candidates returned — (graph, best candidates, background PSSM) or None."""
+    if not write_search_artifacts(bin_name, mod_type, res, temp_dir):
+        return None
+    graph, best, bin_pssm = res
     rows = yield from postprocess.postprocess_co(graph, best, bin_name, mod_type, cfg.padding, on_stage=stage_writer)
     return rows
 
@@ -312,6 +321,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)
     tasks = {}
+    native_rows = {}
     out_dir = cfg.output_dir
     # single GPU, windows on the device: the plan of every task goes to libnmscan in ONE call (nm_plan_windows: one gather
     # launch for all windows, the background draws on native threads meanwhile); contig-sharded multi-GPU runs and host
@@ -398,8 +408,25 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
             scorer.rounds += found.rounds
             scorer.candidates += found.candidates
             lap("native_search_s")
-            for t, (key, stage_writer, temp_dir) in enumerate(planned):
-                tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir)
+            if os.environ.get("NANOMOTIF_PY_POST") == "1":
+                for t, (key, stage_writer, temp_dir) in enumerate(planned):
+                    tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir)
+            else:
+                # post-processing of all tasks inside libnmscan as well (nm_post_run: noise -> clique merge in two scoring
+                # batches on the merge stage's 0.3 / 0.7 classification -> sub-motifs -> complements); postprocess.py is its twin
+                post = found.postprocess(engine, (engine.bin_index[key[0]] for key, _, _ in planned),
+                                         (engine.slot_of_mod[state_label(key[1], "merge")] for key, _, _ in planned), reduce=reduce)
+                scorer.rounds += post.batches
+                scorer.candidates += post.candidates
+                for t, (key, stage_writer, temp_dir) in enumerate(planned):
+                    if temp_dir or found.none[t]:
+                        write_search_artifacts(key[0], key[1], found.result(t, full_graph=True), temp_dir)
+                    if stage_writer:
+                        for s in range(post.n_stages(t)):
+                            stage_writer(post.STAGES[s], post.rows(t, s))
+                    native_rows[key] = post.final(t)
+                lap("postprocess_s")
+            found.close()
         else:
             for key, stage_writer, temp_dir in planned:
                 tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
@@ -407,9 +434,10 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
     lap("coroutines_s")
     scorer.timings = timings
     rows = []
-    for key in tasks:
-        if results.get(key):
-            rows += results[key]
+    for key in list(tasks) + list(native_rows):
+        r = results.get(key) or native_rows.get(key)
+        if r:
+            rows += r
     log.info(f"scoring rounds: {scorer.rounds}, candidates scored: {scorer.candidates}")
     return rows, scorer
 

@@ -50,9 +50,47 @@ class SearchResults:
                                                p(self.none, C.c_uint8), self.motif.ctypes.data_as(C.c_char_p), p(self.counts, C.c_int64),
                                                p(self.score, C.c_double), p(self.priority, C.c_double), p(self.depth, C.c_int32),
                                                p(self.visited, C.c_uint8), p(self.edges, C.c_int32), p(self.best, C.c_int32)))
-        lib.nm_search_result_free(handle)
+        self._lib, self._handle = lib, handle              # kept for post-processing (nm_post_run reads the graphs); close() frees it
         self.W = W
         self._text = self.motif.tobytes().decode("ascii") if nn.value else ""
+
+    def close(self):
+        if self._handle is not None:
+            self._lib.nm_search_result_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def postprocess(self, engine, task_bins, merge_slots, reduce=None):
+        """process_subpileup after the search for every task (nm_post_run): ``task_bins`` / ``merge_slots`` = engine bin
+        index and the classification the merge stage is scored on, per task.  Returns PostResults."""
+        n = len(self.keys)
+        bins = np.ascontiguousarray(np.fromiter(task_bins, dtype=np.uint32, count=n)) if n else np.zeros(1, np.uint32)
+        slots = np.ascontiguousarray(np.fromiter(merge_slots, dtype=np.uint32, count=n)) if n else np.zeros(1, np.uint32)
+        err = []
+        cb = _reduce_callback(reduce, err)
+        handle = C.c_void_p()
+        rc = self._lib.nm_post_run(engine.ctx, self._handle, bins.ctypes.data_as(C.POINTER(C.c_uint32)), slots.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                   cb, None, C.byref(handle))
+        if err:
+            raise err[0]
+        _lib.check(rc)
+        return PostResults(self._lib, handle, self.keys)
+
+    def postprocess_custom(self, score_fn):
+        """The same on a Python scorer (CPU tests): ``score_fn(list of (task index, Motif)) -> int64[n, 2]``, every request
+        on the merge stage's 0.3 / 0.7 classification."""
+        err = []
+        handle = C.c_void_p()
+        rc = self._lib.nm_post_run_custom(self._handle, _post_score_callback(score_fn, err), None, C.byref(handle))
+        if err:
+            raise err[0]
+        _lib.check(rc)
+        return PostResults(self._lib, handle, self.keys)
 
     def _node(self, t, k):
         i = int(self.node_off[t]) + k
@@ -81,6 +119,120 @@ class SearchResults:
         return g, [made[k] for k in best_idx], self.pssms[t]
 
 
+def _reduce_callback(reduce, err):
+    if reduce is None:
+        return C.cast(None, _lib.SEARCH_REDUCE_FN)
+
+    def _reduce(_user, ptr, count):
+        try:
+            a = np.ctypeslib.as_array(ptr, shape=(int(count),))
+            a[:] = reduce(a.copy())
+            return 0
+        except Exception as e:          # a Python exception cannot cross the C frames
+            err.append(e)
+            return -3
+    return _lib.SEARCH_REDUCE_FN(_reduce)
+
+
+def _post_score_callback(score_fn, err):
+    def _score(_user, cnt, task, text, off, modpos, out):
+        try:
+            s = C.string_at(text, off[cnt]).decode("ascii") if cnt else ""
+            res = np.asarray(score_fn([(int(task[i]), Motif(s[off[i]:off[i + 1]], int(modpos[i]))) for i in range(cnt)]), dtype=np.int64)
+            np.ctypeslib.as_array(out, shape=(cnt, 2))[:] = res
+            return 0
+        except Exception as e:
+            err.append(e)
+            return -3
+    return _lib.POST_SCORE_FN(_score)
+
+
+def postprocess_rows_custom(keys, rows_per_task, padding, score_fn):
+    """Native post-processing of explicit rows (tests): ``rows_per_task[t]`` = list of (motif string of 2 * padding + 1
+    characters, n_mod, n_nomod, score) in graph node order.  Returns PostResults."""
+    lib = _lib.load()
+    W = 2 * int(padding) + 1
+    off = np.zeros(len(keys) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in rows_per_task], out=off[1:])
+    flat = [r for rows in rows_per_task for r in rows]
+    text = "".join(r[0] for r in flat).encode("ascii")
+    assert len(text) == len(flat) * W
+    counts = np.ascontiguousarray(np.array([[r[1], r[2]] for r in flat], dtype=np.int64).reshape(-1, 2))
+    score = np.ascontiguousarray(np.array([r[3] for r in flat], dtype=np.float64))
+    err = []
+    handle = C.c_void_p()
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = lib.nm_post_run_rows_custom(len(keys), W, p(off, C.c_uint64), text, p(counts, C.c_int64) if len(flat) else None,
+                                     p(score, C.c_double) if len(flat) else None, _post_score_callback(score_fn, err), None, C.byref(handle))
+    if err:
+        raise err[0]
+    _lib.check(rc)
+    return PostResults(lib, handle, keys)
+
+
+class PostResults:
+    """Rows of every (task, stage) of one native post-processing run (include/nmscan.h: nm_post_*), as the MotifRow
+    records postprocess.postprocess_co produces; built on demand (a run without --out only reads the last stage)."""
+    STAGES = ("motifs", "motifs-noise", "motifs-noise-merge", "motifs-noise-merge-sub", "motifs-noise-merge-sub-complement")
+
+    def __init__(self, lib, handle, keys):
+        self.keys = list(keys)
+        nr, nb = C.c_uint64(0), C.c_uint64(0)
+        stats = (C.c_uint64 * 2)()
+        _lib.check(lib.nm_post_sizes(handle, C.byref(nr), C.byref(nb), stats))
+        self.batches, self.candidates = int(stats[0]), int(stats[1])
+        n = int(nr.value)
+        self.task = np.zeros(max(n, 1), dtype=np.uint32)
+        self.stage = np.zeros(max(n, 1), dtype=np.uint8)
+        self.text_off = np.zeros(2 * n + 1, dtype=np.uint64)
+        text = np.zeros(max(int(nb.value), 1), dtype=np.uint8)
+        self.mod_position = np.zeros(max(n, 1), dtype=np.int32)
+        self.mod_position_iupac = np.zeros(max(n, 1), dtype=np.int32)
+        self.counts = np.zeros((max(n, 1), 2), dtype=np.int64)
+        self.score = np.zeros(max(n, 1), dtype=np.float64)
+        self.complement = np.zeros(max(n, 1), dtype=np.int64)
+        p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        _lib.check(lib.nm_post_export(handle, p(self.task, C.c_uint32), p(self.stage, C.c_uint8), p(self.text_off, C.c_uint64),
+                                      text.ctypes.data_as(C.c_char_p), p(self.mod_position, C.c_int32), p(self.mod_position_iupac, C.c_int32),
+                                      p(self.counts, C.c_int64), p(self.score, C.c_double), p(self.complement, C.c_int64)))
+        lib.nm_post_free(handle)
+        self.n = n
+        self._text = text.tobytes().decode("ascii")
+        key = self.task[:n].astype(np.int64) * 8 + self.stage[:n]
+        self._first = np.searchsorted(key, np.arange(len(self.keys) * 8 + 1))       # records are sorted by (task, stage)
+        self._off = self.text_off.tolist()
+        self._made = {}
+
+    def _row(self, i):
+        from .motif import reverse_compliment
+        from .postprocess import MotifRow
+        r = self._made.get(i)
+        if r is None:
+            k = self.keys[int(self.task[i])]
+            o = self._off
+            comp = int(self.complement[i])
+            r = MotifRow(k[0], self._text[o[2 * i]:o[2 * i + 1]], k[1], int(self.mod_position[i]),
+                         BetaBernoulliModel.from_counts(int(self.counts[i, 0]), int(self.counts[i, 1])), float(self.score[i]),
+                         None if comp < 0 else self._row(comp), int(self.stage[i]) == 4)
+            iu = self._text[o[2 * i + 1]:o[2 * i + 2]]
+            r.__dict__["_cache"] = (iu, int(self.mod_position_iupac[i]), reverse_compliment(iu))
+            self._made[i] = r
+        return r
+
+    def n_stages(self, t):
+        """Stages of task ``t`` that hold rows (the reference stops a task at the first empty one)."""
+        f = self._first
+        return sum(1 for s in range(5) if f[t * 8 + s + 1] > f[t * 8 + s])
+
+    def rows(self, t, stage):
+        f = self._first
+        return [self._row(i) for i in range(int(f[t * 8 + stage]), int(f[t * 8 + stage + 1]))]
+
+    def final(self, t):
+        """What postprocess_co returns for task ``t``: the rows of the last stage, or None."""
+        return self.rows(t, 4) or None
+
+
 def find_best_candidates_all(engine, tasks, padding, min_kl, score_threshold, reduce=None, **kw):
     """tasks: list of (key=(bin name, mod type), window-store task id, total windows, background PSSM float64[4, W]).
     Runs every search on ``engine`` (nm_search_run); ``reduce``: callable summing an int64 numpy array over the ranks of a
@@ -98,16 +250,7 @@ def find_best_candidates_all(engine, tasks, padding, min_kl, score_threshold, re
     canon = np.frombuffer("".join(MOD_TYPE_TO_CANONICAL[m] for m in mods).encode("ascii"), dtype=np.uint8).copy() if n else np.zeros(1, np.uint8)
     pssm = np.ascontiguousarray(np.stack([np.asarray(t[3], dtype=np.float64).reshape(4, W) for t in tasks])) if n else np.zeros((1, 4, W))
     err = []
-
-    def _reduce(_user, ptr, count):
-        try:
-            a = np.ctypeslib.as_array(ptr, shape=(int(count),))
-            a[:] = reduce(a.copy())
-            return 0
-        except Exception as e:          # a Python exception cannot cross the C frames
-            err.append(e)
-            return -3
-    cb = _lib.SEARCH_REDUCE_FN(_reduce) if reduce is not None else C.cast(None, _lib.SEARCH_REDUCE_FN)
+    cb = _reduce_callback(reduce, err)
     params = _params(padding, min_kl, score_threshold, **kw)
     handle = C.c_void_p()
     p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
