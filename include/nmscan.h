@@ -168,6 +168,14 @@ int nm_score_batch(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const
 int nm_score_batch_device(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                           const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
                           const uint8_t *cand_masks, int64_t *d_out_counts);
+/* nm_score_batch in two halves, for a caller with host work to do while the batch runs (the native search resumes the
+ * tasks of a round's window batch under the scoring kernel): _begin returns with the upload, the program compile and
+ * the scoring launch enqueued; _end waits for the counts (pinned staging, then out_counts) and must be called before the
+ * next _begin (out_counts NULL: wait and drop the batch).  Other calls on the ctx may come in between. */
+int nm_score_batch_begin(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                         const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                         const uint8_t *cand_masks);
+int nm_score_batch_end(nm_ctx *ctx, int64_t *out_counts);
 
 /*
  * Parse n regex-style motif strings (characters A C G T . and [..] sets, the form the reference keeps in
@@ -205,6 +213,10 @@ int nm_win_batch(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const ui
  * search moves 258 ints per request instead of 770. */
 int nm_win_batch_w(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind,
                    const uint8_t *req_sets, uint32_t ws, int32_t *out);
+/* the same in two halves (see nm_score_batch_begin): _begin enqueues the batch on its own staging pair, _end collects */
+int nm_win_batch_w_begin(nm_ctx *ctx, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                         uint32_t width_stride);
+int nm_win_batch_w_end(nm_ctx *ctx, int32_t *out);
 
 /*
  * Window extraction on the device (find_motifs_bin.py:625-686) — the windows never exist as bytes on the host.

@@ -611,9 +611,10 @@ hipError_t device_free(void *p) {
     return hipFree(p);
 }
 
-int ensure_stage(nm_ctx *c, size_t bytes, bool deep) {
+int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
     int idx;
-    if (deep) {
+    if (mode == 2) idx = NM_STAGE_RING;
+    else if (mode == 1) {
         idx = c->stage_next_deep;
         c->stage_next_deep = (idx + 1) % NM_STAGE_RING;
     } else {
@@ -726,9 +727,15 @@ void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStr
 
 int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
-               const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out, const uint64_t *row_offset = nullptr) {
+               const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out, const uint64_t *row_offset = nullptr,
+               bool defer = false) {
+    // defer: host counts, collected later by nm_score_batch_end (the call returns with everything enqueued)
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    if (defer) {
+        if (c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
+        c->score_wait = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+    }
     if (n_cand == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
     // ---- one pass over the candidates: validate, classify the batch, count per (slot, bin) bucket.
@@ -801,7 +808,12 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const size_t range_bytes = (size_t)n_entries * sizeof(uint4);
     const size_t off_rows = (off_range + range_bytes + 15) & ~(size_t)15;          // per-contig mode: row base per sorted candidate
     const size_t total = off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
-    int rc = ensure_stage(c, total, true);
+    // host counts come back through the pinned half of the staging pair (a copy into pageable memory is staged by the
+    // runtime and costs tens of microseconds more per round of the search); tables too large for that go directly
+    const size_t out_bytes = (size_t)out_rows * 2 * sizeof(int64_t);
+    const bool via_stage = defer || (h_out && out_bytes <= ((size_t)4 << 20));
+    const size_t off_counts = (total + 15) & ~(size_t)15;
+    int rc = ensure_stage(c, via_stage ? off_counts + out_bytes : total, 1);
     if (rc) return rc;
     // scoring lane of this call (nm_set_score_lanes): asynchronous device-output batches take the lane of their staging
     // pair — a pair, its half of the program table and its stream are reused together; every other call runs on the
@@ -887,7 +899,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // scored) and the scoring queue carries no cross-stream barrier packet — 5-6 us less between two launches; with two
     // lanes the host must run ahead instead, so there the stream waits
     // (a call that returns host counts synchronises at its end anyway: one round trip, not two)
-    if (laned || h_out || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
+    if (laned || h_out || defer || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
     else HIP_TRY(hipEventSynchronize(c->copy_done));
     // ---- output counters
     unsigned long long *out = d_out;
@@ -961,6 +973,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (n_prog) launch_score(a, gx, shape, sst);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e1, sst));
+    if (via_stage) HIP_TRY(hipMemcpyAsync(hs + off_counts, out, out_bytes, hipMemcpyDeviceToHost, sst));
     rc = release_stage(c, sst);
     if (rc) return rc;
     c->cur_stage->last_out = d_out;
@@ -971,8 +984,13 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     c->last_wgs = (uint64_t)gx * (fuse ? 1 : std::max(n_active, 1u));
     c->last_compact = all_compact ? n_prog : 0;
     c->last_general = all_compact ? 0 : n_prog;
-    if (h_out) {
-        HIP_TRY(hipMemcpyAsync(h_out, out, (size_t)out_rows * 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    if (defer) {
+        c->score_wait = nm_ctx::Waiting{hs + off_counts, out_bytes, c->cur_stage, true};
+    } else if (via_stage) {
+        HIP_TRY(hipEventSynchronize(c->cur_stage->busy));
+        memcpy(h_out, hs + off_counts, out_bytes);
+    } else if (h_out) {
+        HIP_TRY(hipMemcpyAsync(h_out, out, out_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return NM_OK;
@@ -1382,6 +1400,28 @@ int nm_score_batch(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const u
     if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !out_counts))
         return fail(NM_EINVAL, "NULL argument");
     return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, out_counts);
+}
+
+int nm_score_batch_begin(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                         const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
+                         const uint8_t *cand_masks) {
+    if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks))
+        return fail(NM_EINVAL, "NULL argument");
+    const int rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, nullptr, nullptr, true);
+    if (rc && c) c->score_wait.open = false;
+    return rc;
+}
+
+int nm_score_batch_end(nm_ctx *c, int64_t *out_counts) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (!c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_end without nm_score_batch_begin");
+    const nm_ctx::Waiting w = c->score_wait;
+    c->score_wait.open = false;
+    if (w.bytes == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(w.stage->busy));
+    if (out_counts) memcpy(out_counts, w.h, w.bytes);           // NULL: the batch is dropped
+    return NM_OK;
 }
 
 int nm_score_batch_device(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,

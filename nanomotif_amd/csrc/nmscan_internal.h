@@ -97,6 +97,7 @@ struct ReadStats {
 // the upload and the compile of batch k+1 ... k+3 run while batch k is scored — on a small shard of a multi-GPU run that
 // chain (~85 us) is as long as the scoring kernel itself, two pairs would hide only one kernel's worth of it.
 #define NM_STAGE_RING 4
+#define NM_STAGE_SLOTS (NM_STAGE_RING + 1)     /* + the pair of the asynchronous window batch (nm_win_batch_w_begin) */
 
 struct nm_ctx {
     int device = 0;
@@ -157,11 +158,18 @@ struct nm_ctx {
         bool pending = false;
         const void *last_out = nullptr;        // count table the last scoring launch of this pair wrote, and its stream
         hipStream_t last_stream = nullptr;
-    } stage[NM_STAGE_RING];
+    } stage[NM_STAGE_SLOTS];
     int stage_next = 0;                            // shallow users alternate between pairs 0 and 1
     int stage_next_deep = 0;                       // scoring walks the whole ring
     void *d_stage = nullptr, *h_stage = nullptr;   // the pair acquired by the current call
     Stage *cur_stage = nullptr;
+    // a batch begun and not yet collected (nm_score_batch_begin / nm_win_batch_w_begin): where its results land in pinned memory
+    struct Waiting {
+        const void *h = nullptr;
+        size_t bytes = 0;
+        Stage *stage = nullptr;
+        bool open = false;
+    } score_wait, win_wait;
     unsigned long long *d_counts = nullptr;
     size_t counts_cap = 0;
     unsigned int *d_err = nullptr;
@@ -233,7 +241,7 @@ inline void drop_ingest_rows(nm_ctx *c) {
 
 // pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it
 // busy until the work enqueued so far on the ctx stream has run
-int ensure_stage(nm_ctx *c, size_t bytes, bool deep = false);   // deep: walk all NM_STAGE_RING pairs (scoring), else pairs 0 / 1
+int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2: the asynchronous window batch's own pair
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
 void free_readstats(nm_ctx *c);

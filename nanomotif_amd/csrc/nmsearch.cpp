@@ -157,6 +157,9 @@ struct Task {
     // pending request
     ReqKind req = REQ_NONE;
     std::vector<std::string> req_motifs;            // REQ_SCORE: motifs; REQ_PSSM / REQ_REMOVE: one motif
+    std::vector<std::string> ask_all;               // REQ_SCORE: the whole request (req_motifs = the part not in the memo)
+    std::unordered_map<std::string, Model> memo;    // every motif this task has had scored
+    bool use_memo = true;
     // replies
     std::vector<Model> rep_models;
     int64_t rep_a = 0, rep_b = 0;                   // pssm: n_active ; remove: before, left
@@ -189,6 +192,7 @@ struct Task {
         root.assign(p->width, '.');
         root[p->padding] = canonical_;
         result_none = false;
+        use_memo = getenv("NM_SEARCH_NO_MEMO") == nullptr;
     }
 
     // ---- MotifSearcher._motif_child_nodes_kl_dist_max (find_motifs_bin.py:957-1023)
@@ -227,11 +231,35 @@ struct Task {
         }
     }
 
-    void request_score(std::vector<std::string> motifs) { req = REQ_SCORE; req_motifs = std::move(motifs); }
+    // Counts are a pure function of (task, motif): what this task has had scanned before — the root at the start of
+    // every outer iteration, the guess and the parents on its search path when pruning starts — is answered from the
+    // memo, and a request that is answered completely costs no lock-step round at all.  Returns whether a round is needed.
+    bool request_score(std::vector<std::string> motifs) {
+        std::vector<std::string> missing;
+        for (const auto &m : motifs)
+            if ((!use_memo || !memo.count(m)) && std::find(missing.begin(), missing.end(), m) == missing.end()) missing.push_back(m);
+        ask_all = std::move(motifs);
+        req_motifs = std::move(missing);
+        if (req_motifs.empty()) {
+            rep_models.clear();
+            absorb();
+            return false;
+        }
+        req = REQ_SCORE;
+        return true;
+    }
+    void absorb() {                                 // replies of the pending request -> memo; rep_models = the full request's models
+        for (size_t k = 0; k < req_motifs.size() && k < rep_models.size(); ++k) memo[req_motifs[k]] = rep_models[k];
+        std::vector<Model> full;
+        full.reserve(ask_all.size());
+        for (const auto &m : ask_all) full.push_back(memo[m]);
+        rep_models.swap(full);
+        ask_all.clear();
+    }
     void request_win(ReqKind k, const std::string &m) { req = k; req_motifs.assign(1, m); }
 
     // get_parent_scores_co request for `temp` (find_motifs_bin.py:1382-1433)
-    void request_parents() {
+    bool request_parents() {
         parent_pos.clear();
         parent_motifs.clear();
         for (int i = 0; i < (int)temp.size(); ++i) {
@@ -244,7 +272,7 @@ struct Task {
         std::vector<std::string> r;
         r.push_back(temp);
         r.insert(r.end(), parent_motifs.begin(), parent_motifs.end());
-        request_score(std::move(r));
+        return request_score(std::move(r));
     }
 
     void finish() {
@@ -281,6 +309,7 @@ struct Task {
     }
 
     void resume() {
+        if (!ask_all.empty()) absorb();
         switch (state) {
             case 0: goto OUTER;
             case 1: goto ROOT_SCORED;
@@ -294,9 +323,10 @@ struct Task {
         if (dead_ends >= P->max_dead_ends) { finish(); return; }
         // ---- MotifSearcher.run (find_motifs_bin.py:1026-1182); the graph persists across outer iterations
         best_guess = root;
-        request_score({root});
-        state = 1;
-        return;
+        if (request_score({root})) {
+            state = 1;
+            return;
+        }
     ROOT_SCORED:
         root_model = rep_models[0];
         best_score = evaluation_score(root_model, root_model);
@@ -332,12 +362,11 @@ struct Task {
             fresh.clear();
             for (const auto &m : neighbors)
                 if (g.find(m) < 0) fresh.push_back(m);
-            if (!fresh.empty()) {
-                request_score(fresh);
+            if (fresh.empty()) rep_models.clear();
+            else if (request_score(fresh)) {
                 state = 3;
                 return;
             }
-            rep_models.clear();
         CHILDREN_SCORED:
             {
                 const Model cur_model = g.nodes[cur_id].model;
@@ -384,9 +413,10 @@ struct Task {
         to_prune.clear();
         single = false;
     PRUNE:
-        request_parents();
-        state = 4;
-        return;
+        if (request_parents()) {
+            state = 4;
+            return;
+        }
     PARENTS_SCORED:
         {
             child_model = rep_models[0];
@@ -529,7 +559,20 @@ private:
     bool stop_ = false;
 };
 
-int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user) {
+// The two back ends of a lock-step round.  Callbacks (nm_search_run_custom) answer at once; the engine's halves
+// (nm_*_begin / _end) let a round enqueue its window batch and its scoring batch back to back, collect the windows,
+// advance the tasks that asked for them WHILE the scoring kernel runs, and only then wait for the counts.
+struct Backend {
+    nm_search_score_fn score = nullptr;
+    nm_search_window_fn window = nullptr;
+    int (*score_begin)(void *user, uint32_t n, const uint32_t *task, const char *motifs) = nullptr;
+    int (*score_end)(void *user, uint32_t n, int64_t *out) = nullptr;
+    int (*window_begin)(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) = nullptr;
+    int (*window_end)(void *user, uint32_t n, int32_t *out) = nullptr;
+    void *user = nullptr;
+};
+
+int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     auto &tasks = res->tasks;
     const uint32_t W = P.width, WS = width_stride(W);
     // NM_SEARCH_TIMING: where the wall time of the lock-step loop goes (stderr, one line)
@@ -546,17 +589,27 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
     double t0 = now();
     workers.run(tasks.size(), [&](size_t i) { tasks[i].resume(); });
     t_resume += now() - t0;
-    std::vector<uint32_t> s_task, w_task;
+    std::vector<uint32_t> s_task, w_task, s_owner;
     std::vector<char> s_motifs, w_motifs;
     std::vector<uint8_t> w_kind;
     std::vector<int64_t> counts;
     std::vector<int32_t> wout;
+    auto resume_these = [&](const std::vector<uint32_t> &which) {
+        const double t1 = now();
+        workers.run(which.size(), [&](size_t k) {
+            Task &t = tasks[which[k]];
+            t.req = REQ_NONE;
+            t.resume();
+        });
+        t_resume += now() - t1;
+    };
     for (;;) {
-        s_task.clear(); w_task.clear(); s_motifs.clear(); w_motifs.clear(); w_kind.clear();
+        s_task.clear(); w_task.clear(); s_motifs.clear(); w_motifs.clear(); w_kind.clear(); s_owner.clear();
         t0 = now();
         for (uint32_t i = 0; i < tasks.size(); ++i) {
             Task &t = tasks[i];
             if (t.req == REQ_SCORE) {
+                s_owner.push_back(i);
                 for (const auto &m : t.req_motifs) {
                     s_task.push_back(i);
                     s_motifs.insert(s_motifs.end(), m.begin(), m.end());
@@ -569,10 +622,12 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
         }
         t_gather += now() - t0;
         if (s_task.empty() && w_task.empty()) break;
+        // ---- both batches go out
         if (!w_task.empty()) {
             t0 = now();
             wout.assign(w_task.size() * (size_t)(2 + 4 * WS), 0);
-            const int rc = window_fn(user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
+            const int rc = B.window_begin ? B.window_begin(B.user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data())
+                                          : B.window(B.user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
             if (rc) return rc;
             res->window_requests += w_task.size();
             t_window += now() - t0;
@@ -580,41 +635,52 @@ int run_tasks(nm_search_result *res, const Params &P, nm_search_score_fn score_f
         if (!s_task.empty()) {
             t0 = now();
             counts.assign(s_task.size() * 2, 0);
-            const int rc = score_fn(user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data(), counts.data());
+            const int rc = B.score_begin ? B.score_begin(B.user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data())
+                                         : B.score(B.user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data(), counts.data());
             if (rc) return rc;
             res->rounds += 1;
             res->candidates += s_task.size();
             t_score += now() - t0;
         }
-        // hand the replies back
-        t0 = now();
-        size_t si = 0;
-        for (size_t k = 0; k < w_task.size(); ++k) {
-            Task &t = tasks[w_task[k]];
-            const int32_t *o = wout.data() + k * (size_t)(2 + 4 * WS);
-            t.rep_a = o[0];
-            t.rep_b = o[1];
-            if (w_kind[k] == 0)
-                for (int r = 0; r < 4; ++r)
-                    for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * WS + j];
-        }
-        while (si < s_task.size()) {
-            Task &t = tasks[s_task[si]];
-            t.rep_models.clear();
-            for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(counts[2 * si], counts[2 * si + 1]));
-        }
-        t_reply += now() - t0;
-        t0 = now();
-        workers.run(tasks.size(), [&](size_t i) {
-            Task &t = tasks[i];
-            if (t.req != REQ_DONE && t.req != REQ_NONE) {
-                t.req = REQ_NONE;
-                t.resume();
+        // ---- the windows come back first; their tasks advance while the scoring kernel is still running
+        if (!w_task.empty()) {
+            t0 = now();
+            if (B.window_end) {
+                const int rc = B.window_end(B.user, (uint32_t)w_task.size(), wout.data());
+                if (rc) return rc;
             }
-        });
-        t_resume += now() - t0;
+            t_window += now() - t0;
+            t0 = now();
+            for (size_t k = 0; k < w_task.size(); ++k) {
+                Task &t = tasks[w_task[k]];
+                const int32_t *o = wout.data() + k * (size_t)(2 + 4 * WS);
+                t.rep_a = o[0];
+                t.rep_b = o[1];
+                if (w_kind[k] == 0)
+                    for (int r = 0; r < 4; ++r)
+                        for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * WS + j];
+            }
+            t_reply += now() - t0;
+            resume_these(w_task);
+        }
+        if (!s_task.empty()) {
+            t0 = now();
+            if (B.score_end) {
+                const int rc = B.score_end(B.user, (uint32_t)s_task.size(), counts.data());
+                if (rc) return rc;
+            }
+            t_score += now() - t0;
+            t0 = now();
+            size_t si = 0;
+            while (si < s_task.size()) {
+                Task &t = tasks[s_task[si]];
+                t.rep_models.clear();
+                for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(counts[2 * si], counts[2 * si + 1]));
+            }
+            t_reply += now() - t0;
+            resume_these(s_owner);
+        }
     }
-    (void)W;
     if (timing)
         fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds: resume %.1f ms, request gathering %.1f ms, window batches %.1f ms, "
                         "scoring batches %.1f ms, replies %.1f ms\n", tasks.size(), (unsigned long long)res->rounds, t_resume * 1e3,
@@ -647,7 +713,7 @@ struct EngineUser {
 
 inline uint8_t set_of(char ch) { return ch == 'A' ? NM_BASE_A : ch == 'C' ? NM_BASE_C : ch == 'G' ? NM_BASE_G : ch == 'T' ? NM_BASE_T : 15; }
 
-int engine_score(void *user, uint32_t n, const uint32_t *task, const char *motifs, int64_t *out) {
+int engine_score_begin(void *user, uint32_t n, const uint32_t *task, const char *motifs) {
     EngineUser &u = *static_cast<EngineUser *>(user);
     const uint32_t W = u.width;
     u.bins.resize(n); u.offs.resize(n); u.slots.resize(n); u.lens.resize(n); u.modpos.resize(n);
@@ -664,13 +730,18 @@ int engine_score(void *user, uint32_t n, const uint32_t *task, const char *motif
         u.offs[i] = (uint32_t)u.masks.size();
         for (uint32_t j = lo; j < hi; ++j) u.masks.push_back(set_of(m[j]));
     }
-    int rc = nm_score_batch(u.ctx, n, u.bins.data(), u.slots.data(), u.lens.data(), u.modpos.data(), u.offs.data(), u.masks.data(), out);
+    return nm_score_batch_begin(u.ctx, n, u.bins.data(), u.slots.data(), u.lens.data(), u.modpos.data(), u.offs.data(), u.masks.data());
+}
+
+int engine_score_end(void *user, uint32_t n, int64_t *out) {
+    EngineUser &u = *static_cast<EngineUser *>(user);
+    int rc = nm_score_batch_end(u.ctx, out);
     if (rc) return rc;
     if (u.reduce) rc = u.reduce(u.reduce_user, out, (uint64_t)n * 2);
     return rc;
 }
 
-int engine_window(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs, int32_t *out) {
+int engine_window_begin(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) {
     EngineUser &u = *static_cast<EngineUser *>(user);
     const uint32_t W = u.width;
     u.wtask.resize(n);
@@ -680,10 +751,15 @@ int engine_window(void *user, uint32_t n, const uint32_t *task, const uint8_t *k
         u.wtask[i] = u.task_win[task[i]];
         for (uint32_t j = 0; j < W; ++j) u.sets[(size_t)i * WS + j] = set_of(motifs[(size_t)i * W + j]);
     }
-    int rc = nm_win_batch_w(u.ctx, n, u.wtask.data(), kind, u.sets.data(), WS, out);
+    return nm_win_batch_w_begin(u.ctx, n, u.wtask.data(), kind, u.sets.data(), WS);
+}
+
+int engine_window_end(void *user, uint32_t n, int32_t *out) {
+    EngineUser &u = *static_cast<EngineUser *>(user);
+    int rc = nm_win_batch_w_end(u.ctx, out);
     if (rc) return rc;
     if (u.reduce) {                                  // contig-sharded run: every rank holds the windows of its contigs
-        const size_t m = (size_t)n * (2 + 4 * WS);
+        const size_t m = (size_t)n * (2 + 4 * width_stride(u.width));
         u.tmp64.resize(m);
         for (size_t i = 0; i < m; ++i) u.tmp64[i] = out[i];
         rc = u.reduce(u.reduce_user, u.tmp64.data(), m);
@@ -717,6 +793,24 @@ int start(uint32_t n_tasks, const nm_search_params *p, const double *bg_pssm, co
 
 }  // namespace
 
+namespace {
+
+int run_search(uint32_t n_tasks, const nm_search_params *params, const double *bg_pssm, const uint64_t *total_windows, const uint8_t *canonical,
+               const Backend &B, nm_search_result **out) {
+    Params P;
+    int rc = start(n_tasks, params, bg_pssm, total_windows, canonical, out, P);
+    if (rc) return rc;
+    rc = run_tasks(*out, P, B);
+    for (auto &t : (*out)->tasks) t.P = nullptr;
+    if (rc) {
+        delete *out;
+        *out = nullptr;
+    }
+    return rc;
+}
+
+}  // namespace
+
 bool nm_search_task_best(const nm_search_result *res, uint32_t t, std::vector<nmsearch::BestRow> &out) {
     out.clear();
     const Task &T = res->tasks[t];
@@ -740,16 +834,11 @@ int nm_search_run_custom(uint32_t n_tasks, const nm_search_params *params, const
                          const uint8_t *canonical, nm_search_score_fn score_fn, nm_search_window_fn window_fn, void *user,
                          nm_search_result **out) {
     if (!score_fn || !window_fn) return nm_set_error(NM_EINVAL, "NULL callback");
-    Params P;
-    int rc = start(n_tasks, params, bg_pssm, total_windows, canonical, out, P);
-    if (rc) return rc;
-    rc = run_tasks(*out, P, score_fn, window_fn, user);
-    for (auto &t : (*out)->tasks) t.P = nullptr;
-    if (rc) {
-        delete *out;
-        *out = nullptr;
-    }
-    return rc;
+    Backend B;
+    B.score = score_fn;
+    B.window = window_fn;
+    B.user = user;
+    return run_search(n_tasks, params, bg_pssm, total_windows, canonical, B, out);
 }
 
 int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const uint32_t *task_slot, const uint32_t *task_window,
@@ -759,7 +848,18 @@ int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const
     int rc = check_params(params);
     if (rc) return rc;
     EngineUser u{ctx, task_bin, task_slot, task_window, 2 * params->padding + 1, params->padding, reduce, reduce_user, {}, {}, {}, {}, {}, {}, {}, {}, {}};
-    return nm_search_run_custom(n_tasks, params, bg_pssm, total_windows, canonical, engine_score, engine_window, &u, out);
+    Backend B;
+    B.score_begin = engine_score_begin;
+    B.score_end = engine_score_end;
+    B.window_begin = engine_window_begin;
+    B.window_end = engine_window_end;
+    B.user = &u;
+    rc = run_search(n_tasks, params, bg_pssm, total_windows, canonical, B, out);
+    if (rc) {                                        // a round that failed half way: nothing stays open on the ctx
+        (void)nm_win_batch_w_end(ctx, nullptr);
+        (void)nm_score_batch_end(ctx, nullptr);
+    }
+    return rc;
 }
 
 int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_best, uint64_t stats[3]) {

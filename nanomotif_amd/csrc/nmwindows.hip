@@ -527,11 +527,15 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
     return NM_OK;
 }
 
-int nm_win_batch_w(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
-                   uint32_t ws, int32_t *out) {
+int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                         uint32_t ws) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
-    if (n_req == 0) return NM_OK;
-    if (!req_task || !req_kind || !req_sets || !out) return fail(NM_EINVAL, "NULL argument");
+    if (c->win_wait.open) return fail(NM_ESTATE, "nm_win_batch_w_begin: the previous batch has not been collected (nm_win_batch_w_end)");
+    if (n_req == 0) {
+        c->win_wait = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+        return NM_OK;
+    }
+    if (!req_task || !req_kind || !req_sets) return fail(NM_EINVAL, "NULL argument");
     if (ws == 0 || ws > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "width stride %u outside 1..%d", ws, WIN_MAX_W);
     HIP_TRY(hipSetDevice(c->device));
     uint32_t max_nw = 1, max_w = 1;
@@ -558,7 +562,7 @@ int nm_win_batch_w(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const ui
     const size_t o_kind = (size_t)n_req * 4, o_sets = (o_kind + n_req + 15) & ~(size_t)15;
     const size_t o_out = (o_sets + (size_t)n_req * ws + 15) & ~(size_t)15;
     const size_t total = o_out + (size_t)n_req * stride * 4;
-    int rc = ensure_stage(c, total);
+    int rc = ensure_stage(c, total, 2);          // its own pair: a scoring batch enqueued behind this one never waits for it on the host
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
     memcpy(hs, req_task, (size_t)n_req * 4);
@@ -576,9 +580,27 @@ int nm_win_batch_w(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const ui
     HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, c->stream));
     rc = release_stage(c);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    memcpy(out, hs + o_out, (size_t)n_req * stride * 4);
+    c->win_wait = nm_ctx::Waiting{hs + o_out, (size_t)n_req * stride * 4, c->cur_stage, true};
     return NM_OK;
+}
+
+int nm_win_batch_w_end(nm_ctx *c, int32_t *out) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (!c->win_wait.open) return fail(NM_ESTATE, "nm_win_batch_w_end without nm_win_batch_w_begin");
+    const nm_ctx::Waiting w = c->win_wait;
+    c->win_wait.open = false;
+    if (w.bytes == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(w.stage->busy));
+    if (out) memcpy(out, w.h, w.bytes);                         // NULL: the batch is dropped
+    return NM_OK;
+}
+
+int nm_win_batch_w(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                   uint32_t ws, int32_t *out) {
+    if (n_req && !out) return fail(NM_EINVAL, "NULL argument");
+    const int rc = nm_win_batch_w_begin(c, n_req, req_task, req_kind, req_sets, ws);
+    return rc ? rc : nm_win_batch_w_end(c, out);
 }
 
 int nm_win_batch(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,

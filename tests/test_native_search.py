@@ -78,9 +78,13 @@ def _fresh_backends(mg, mt, pile, seqs, P, key):
     return _backends([key], {key: pile}, {"bin0": seqs}, store)
 
 
-def test_native_lockstep_equals_python_coroutines_bit_for_bit():
+@pytest.mark.parametrize("memo", [False, True])
+def test_native_lockstep_equals_python_coroutines_bit_for_bit(memo, monkeypatch):
     """Three tasks advanced together: graphs (node order, counts, depth, visited), best lists, and every score and
-    priority EXACTLY equal to the Python coroutine path's float64 values; same number of rounds and candidates."""
+    priority EXACTLY equal to the Python coroutine path's float64 values.  Without the per-task memo of scored motifs
+    (NM_SEARCH_NO_MEMO) also the same number of rounds and candidates; with it (the default) fewer of both."""
+    if not memo:
+        monkeypatch.setenv("NM_SEARCH_NO_MEMO", "1")
     g4 = load_golden("g4_search.json")
     keys, piles, seqs_by_bin, wins = [], {}, {}, {}
     for bin_name, gname in (("binA", "geobacillus_like"), ("binB", "ecoli_like_m"), ("binC", "ecoli_like_a")):
@@ -107,7 +111,10 @@ def test_native_lockstep_equals_python_coroutines_bit_for_bit():
         store2.add_task(key, wins[key][0].copy())
     score_fn, window_fn = _backends(keys, piles, seqs_by_bin, store2)
     res = ns.find_best_candidates_custom([(k, store2.totals[k], wins[k][1]) for k in keys], 20, 0.05, 1.5, score_fn, window_fn)
-    assert (res.rounds, res.candidates) == (scorer.rounds, scorer.candidates)
+    if memo:
+        assert res.rounds < scorer.rounds and res.candidates < scorer.candidates
+    else:
+        assert (res.rounds, res.candidates) == (scorer.rounds, scorer.candidates)
     for t, key in enumerate(keys):
         graph, best, _ = res.result(t, full_graph=True)
         wg, wbest, _ = want[key]
