@@ -417,10 +417,8 @@ struct CandRec {
 // batch, is-X planes; np = 8); bit r of a word = offset 32 g + r.
 // fold_modpos: the modified position's own constraint is left out (compact batches start the accumulator from the
 // canonical plane instead).
-__global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
-                               uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_prog) return;
+__device__ __forceinline__ void compile_one(uint32_t k, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
+                                            uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
     const int groups = 2 + 2 * wide, g0 = 1 - wide;        // wide: 0 narrow (word-groups 1..2), 1 wide (0..3), 2 extra wide (-1..4)
     const int pdw = 2 * groups * np;
     uint32_t *prog = programs + (size_t)k * pdw;
@@ -450,14 +448,18 @@ __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
     }
 }
 
+__global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
+                               uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_prog) compile_one(k, rec, masks, programs, wide, np, fold_modpos);
+}
+
 // Light batches (a round of the greedy search): the constraints shared by ALL candidates of a (slot, bin) group — the
 // parent of sibling children (find_motifs_bin.py:1116-1135), the motif under its parents in a pruning round
 // (:1408-1432) — become the group's COMMON program (index n_prog + group), evaluated once per tile; the candidates keep
 // the rest.  One thread per group; groups of 1 or of more than max_group candidates are left alone (range.z = ~0).
-__global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
-                              uint32_t n_prog, uint32_t max_group) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_entries) return;
+__device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
+                                           uint32_t n_prog, uint32_t max_group) {
     uint4 r = range[g];
     r.z = 0xFFFFFFFFu;
     r.w = 0;
@@ -502,6 +504,24 @@ __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uin
         }
     }
     range[g] = r;
+}
+
+__global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
+                              uint32_t n_prog, uint32_t max_group) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n_entries) common_one(g, range, programs, pdw, n_prog, max_group);
+}
+
+// Both steps in ONE launch for the small light batches of the search's long tail (a few dozen candidates, where a round
+// is a chain of launch latencies): a single workgroup compiles, synchronises, and factors the groups.
+__global__ __launch_bounds__(1024) void compile_common_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
+                                                               const uint8_t *__restrict__ masks, uint32_t *__restrict__ programs, int wide,
+                                                               int np, int fold_modpos, uint32_t n_entries, uint4 *__restrict__ range,
+                                                               uint32_t pdw, uint32_t max_group) {
+    for (uint32_t k = threadIdx.x; k < n_prog; k += blockDim.x) compile_one(k, rec, masks, programs, wide, np, fold_modpos);
+    __threadfence_block();
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_entries; g += blockDim.x) common_one(g, range, programs, pdw, n_prog, max_group);
 }
 
 // Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
@@ -881,26 +901,38 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     }
     uint32_t *const d_prog = c->d_programs + (size_t)(c->cur_stage - c->stage) * c->prog_cap_dw;
     // staged tables travel and are compiled on the copy stream; the scoring stream waits for the compiled programs
-    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, c->copy_stream));
+    // a call that returns host counts has nothing to overlap the compile with (the caller waits for this very batch):
+    // it prepares on the scoring stream itself — no event, no cross-stream wait in its chain of launch latencies
+    const bool inline_prep = (h_out || defer) && !c->opt_no_inline;
+    hipStream_t pst = inline_prep ? sst : c->copy_stream;
+    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, pst));
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_prog) {
-        hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, c->copy_stream, n_prog,
-                           reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide, (int)np,
-                           all_compact ? 1 : 0);
-        HIP_TRY(hipGetLastError());
-        if (cf) {
-            hipLaunchKernelGGL(common_kernel, dim3((n_entries + 63) / 64), dim3(64), 0, c->copy_stream, n_entries,
-                               reinterpret_cast<uint4 *>(ds + off_range), d_prog, pdw, n_prog, 8u);
+        if (cf && n_prog <= 2048 && n_entries <= 8192 && !c->opt_no_inline) {
+            hipLaunchKernelGGL(compile_common_kernel, dim3(1), dim3(1024), 0, pst, n_prog, reinterpret_cast<const CandRec *>(ds),
+                               ds + off_masks, d_prog, any_wide, (int)np, all_compact ? 1 : 0, n_entries,
+                               reinterpret_cast<uint4 *>(ds + off_range), pdw, 8u);
             HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, pst, n_prog,
+                               reinterpret_cast<const CandRec *>(ds), ds + off_masks, d_prog, any_wide, (int)np,
+                               all_compact ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+            if (cf) {
+                hipLaunchKernelGGL(common_kernel, dim3((n_entries + 63) / 64), dim3(64), 0, pst, n_entries,
+                                   reinterpret_cast<uint4 *>(ds + off_range), d_prog, pdw, n_prog, 8u);
+                HIP_TRY(hipGetLastError());
+            }
         }
     }
-    HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
-    // strict order: the host waits for the compiled programs (tens of microseconds, the previous batch is still being
-    // scored) and the scoring queue carries no cross-stream barrier packet — 5-6 us less between two launches; with two
-    // lanes the host must run ahead instead, so there the stream waits
-    // (a call that returns host counts synchronises at its end anyway: one round trip, not two)
-    if (laned || h_out || defer || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
-    else HIP_TRY(hipEventSynchronize(c->copy_done));
+    if (!inline_prep) {
+        HIP_TRY(hipEventRecord(c->copy_done, c->copy_stream));
+        // strict order: the host waits for the compiled programs (tens of microseconds, the previous batch is still being
+        // scored) and the scoring queue carries no cross-stream barrier packet — 5-6 us less between two launches; with two
+        // lanes the host must run ahead instead, so there the stream waits
+        if (laned || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
+        else HIP_TRY(hipEventSynchronize(c->copy_done));
+    }
     // ---- output counters
     unsigned long long *out = d_out;
     if (!out) {
@@ -1030,6 +1062,7 @@ const char *nm_last_error(void) { return g_err.c_str(); }
 static int ctx_init(nm_ctx *c) {
     c->opt_no_lit = getenv("NM_NO_LIT") != nullptr;
     c->opt_no_cf = getenv("NM_NO_CF") != nullptr;
+    c->opt_no_inline = getenv("NM_NO_INLINE_PREP") != nullptr;
     c->opt_stream_wait = getenv("NM_STREAM_WAIT") != nullptr;      // A/B switch: never wait for the compile on the host
     if (const char *e = getenv("NM_FINE")) c->opt_fine = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("NM_SPLIT")) c->opt_split = std::max(0, std::min(2, atoi(e)));

@@ -188,6 +188,7 @@ struct nm_ctx {
     // kernel-variant switches for A/B runs (environment: NM_NO_LIT, NM_NO_CF, NM_PREFETCH), read at nm_ctx_create
     bool opt_no_lit = false, opt_no_cf = false;
     bool opt_stream_wait = false;
+    bool opt_no_inline = false;         // NM_NO_INLINE_PREP: host-count batches prepare on the copy stream with two launches, as before round 3
     int opt_fine = -1;                  // NM_FINE: log2 of the extra cut of the last-dispatched pieces, -1 = 2 - split
     int opt_split = -1;                 // NM_SPLIT: force the segment split (log2), -1 = by size
     uint32_t n_cus = 256;
