@@ -104,6 +104,10 @@ def load():
                                             C.c_int]
     for name in ("nm_score_batch", "nm_score_batch_device"):
         getattr(lib, name).argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p, p]
+    lib.nm_score_batch_begin.argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p]
+    lib.nm_score_batch_end.argtypes = [p, i64p]
+    lib.nm_win_batch_w_begin.argtypes = [p, C.c_uint32, u32p, u8p, u8p, C.c_uint32]
+    lib.nm_win_batch_w_end.argtypes = [p, C.POINTER(C.c_int32)]
     lib.nm_score_batch_per_contig.argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p, u64p, i64p]
     lib.nm_bin_contigs.argtypes = [p, C.c_uint32, u32p, C.c_uint32, u32p]
     lib.nm_readstats_upload.argtypes = [p, C.c_uint32, C.c_uint64, p, p, p, p, p, p, C.c_int32, C.c_double, C.c_int, u64p]

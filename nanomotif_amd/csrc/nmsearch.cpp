@@ -79,27 +79,97 @@ bool sub_motif_of(const std::string &self, const std::string &other, int modpos)
     return true;
 }
 
+// motif string -> small integer.  Open addressing with the key INLINE — the motif packed at 3 bits per position (two words
+// for the default 41-column frame) next to its value: a lookup is one probe sequence in one array.  The std::unordered_map
+// of strings this replaces took three dependent cache misses per find (bucket, node, the string's heap block), and with a
+// thousand searches taking turns nothing of a task is in cache when its turn comes: 45 % of the state machines' time.
+class MotifIndex {
+public:
+    int find(const std::string &s) const {
+        if (cap_ == 0) return -1;
+        uint64_t key[MAXK];
+        const uint32_t K = pack(s, key);
+        const uint64_t *slots = slots_.data();
+        for (uint32_t i = (uint32_t)hash(key, K) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
+            const uint64_t *e = slots + (size_t)i * (K + 1);
+            if (e[K] == 0) return -1;
+            bool same = true;
+            for (uint32_t k = 0; k < K; ++k) same &= e[k] == key[k];
+            if (same) return (int)(e[K] - 1);
+        }
+    }
+    void insert(const std::string &s, int value) {          // s must not be present
+        uint64_t key[MAXK];
+        const uint32_t K = pack(s, key);
+        if (cap_ == 0 || (n_ + 1) * 2 > cap_) grow(K);
+        place(key, K, (uint64_t)value + 1);
+        n_ += 1;
+    }
+    void clear() { slots_.clear(); cap_ = 0; n_ = 0; }
+
+private:
+    static constexpr uint32_t MAXK = (NM_WIN_MAX_WIDTH * 3 + 63) / 64;
+    static uint32_t pack(const std::string &s, uint64_t *key) {
+        const uint32_t K = ((uint32_t)s.size() * 3 + 63) / 64;
+        for (uint32_t k = 0; k < K; ++k) key[k] = 0;
+        for (uint32_t j = 0; j < s.size(); ++j) {
+            const char ch = s[j];
+            const uint64_t code = ch == '.' ? 0 : ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : ch == 'T' ? 4 : 5;
+            const uint32_t bit = j * 3;
+            key[bit >> 6] |= code << (bit & 63);
+            if ((bit & 63) > 61) key[(bit >> 6) + 1] |= code >> (64 - (bit & 63));
+        }
+        return K;
+    }
+    static uint64_t hash(const uint64_t *key, uint32_t K) {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (uint32_t k = 0; k < K; ++k) h = (h ^ key[k]) * 0xD6E8FEB86659FD93ull, h ^= h >> 32;
+        return h;
+    }
+    void place(const uint64_t *key, uint32_t K, uint64_t stored) {
+        for (uint32_t i = (uint32_t)hash(key, K) & (cap_ - 1);; i = (i + 1) & (cap_ - 1)) {
+            uint64_t *e = slots_.data() + (size_t)i * (K + 1);
+            if (e[K] == 0) {
+                for (uint32_t k = 0; k < K; ++k) e[k] = key[k];
+                e[K] = stored;
+                return;
+            }
+        }
+    }
+    void grow(uint32_t K) {
+        std::vector<uint64_t> old;
+        old.swap(slots_);
+        const uint32_t old_cap = cap_;
+        cap_ = cap_ ? cap_ * 2 : 64;
+        slots_.assign((size_t)cap_ * (K + 1), 0);
+        for (uint32_t i = 0; i < old_cap; ++i) {
+            const uint64_t *e = old.data() + (size_t)i * (K + 1);
+            if (e[K]) place(e, K, e[K]);
+        }
+    }
+    std::vector<uint64_t> slots_;                        // cap_ entries of K key words + (value + 1), 0 = empty
+    uint32_t cap_ = 0, n_ = 0;
+};
+
 struct Node {
     std::string motif;
     Model model;
     double score = 0, priority = 0;
     int depth = 0;
     bool visited = false;
+    uint32_t seen_epoch = 0;                            // MotifSearcher.run's `visited` set of the current outer iteration
     std::vector<int> succ, pred;
 };
 
 struct Graph {                                      // MotifTree (motif.py:577-607): insertion-ordered nodes
     std::vector<Node> nodes;
-    std::unordered_map<std::string, int> index;
-    int find(const std::string &m) const {
-        auto it = index.find(m);
-        return it == index.end() ? -1 : it->second;
-    }
+    MotifIndex index;
+    int find(const std::string &m) const { return index.find(m); }
     int add(const std::string &m) {
         const int id = (int)nodes.size();
         nodes.emplace_back();
         nodes.back().motif = m;
-        index.emplace(m, id);
+        index.insert(m, id);
         return id;
     }
     bool has_edge(int u, int v) const { return std::find(nodes[u].succ.begin(), nodes[u].succ.end(), v) != nodes[u].succ.end(); }
@@ -134,6 +204,7 @@ struct HeapEntry {
     double priority;
     int depth;
     std::string motif;
+    int id;                                             // graph node of the motif (not part of the order)
 };
 struct HeapCmp {                                    // min-heap on the Python tuple (priority, depth, motif)
     bool operator()(const HeapEntry &x, const HeapEntry &y) const {
@@ -158,7 +229,8 @@ struct Task {
     ReqKind req = REQ_NONE;
     std::vector<std::string> req_motifs;            // REQ_SCORE: motifs; REQ_PSSM / REQ_REMOVE: one motif
     std::vector<std::string> ask_all;               // REQ_SCORE: the whole request (req_motifs = the part not in the memo)
-    std::unordered_map<std::string, Model> memo;    // every motif this task has had scored
+    MotifIndex memo;                                // every motif this task has had scored -> memo_models
+    std::vector<Model> memo_models;
     bool use_memo = true;
     // replies
     std::vector<Model> rep_models;
@@ -169,7 +241,7 @@ struct Task {
     uint32_t dead_ends = 0;
     // MotifSearcher.run
     std::priority_queue<HeapEntry, std::vector<HeapEntry>, HeapCmp> pq;
-    std::unordered_map<std::string, char> visited;
+    uint32_t epoch = 0;                             // `visited` of MotifSearcher.run = nodes whose seen_epoch is this
     Model root_model;
     double best_score = 0;
     std::string best_guess;
@@ -177,6 +249,7 @@ struct Task {
     std::string cur;
     int cur_id = -1;
     std::vector<std::string> neighbors, fresh;
+    std::vector<int> neighbor_ids;                  // graph nodes of `neighbors` when the children were requested, -1 = new
     // pruning
     std::string guess, temp;
     std::vector<int> to_prune;                      // cumulative set of positions
@@ -204,13 +277,17 @@ struct Task {
             for (int j = 0; j < W; ++j) meth[r][j] = (double)rep_counts[r][j] / (double)n_active;
         bool any_dot = false;
         for (int j = 0; j < W; ++j) {
+            if (motif[j] != '.') {                  // specified positions are zeroed out of the KL vector (find_motifs_bin.py:976-980)
+                kl[j] = 0.0;
+                continue;
+            }
+            any_dot = true;
             const double sp = ((meth[0][j] + meth[1][j]) + meth[2][j]) + meth[3][j];
             const double sq = ((bg[0 * W + j] + bg[1 * W + j]) + bg[2 * W + j]) + bg[3 * W + j];
             double e[4];
             for (int r = 0; r < 4; ++r) e[r] = rel_entr(meth[r][j] / sp, bg[r * W + j] / sq);
             const double v = ((e[0] + e[1]) + e[2]) + e[3];
-            kl[j] = motif[j] == '.' ? v : 0.0;
-            any_dot |= motif[j] == '.';
+            kl[j] = v;
         }
         if (!any_dot) return;
         // np.max / np.argmax: NaN propagates and wins, otherwise the first maximum
@@ -237,7 +314,7 @@ struct Task {
     bool request_score(std::vector<std::string> motifs) {
         std::vector<std::string> missing;
         for (const auto &m : motifs)
-            if ((!use_memo || !memo.count(m)) && std::find(missing.begin(), missing.end(), m) == missing.end()) missing.push_back(m);
+            if ((!use_memo || memo.find(m) < 0) && std::find(missing.begin(), missing.end(), m) == missing.end()) missing.push_back(m);
         ask_all = std::move(motifs);
         req_motifs = std::move(missing);
         if (req_motifs.empty()) {
@@ -249,10 +326,17 @@ struct Task {
         return true;
     }
     void absorb() {                                 // replies of the pending request -> memo; rep_models = the full request's models
-        for (size_t k = 0; k < req_motifs.size() && k < rep_models.size(); ++k) memo[req_motifs[k]] = rep_models[k];
+        for (size_t k = 0; k < req_motifs.size() && k < rep_models.size(); ++k) {
+            const int at = memo.find(req_motifs[k]);
+            if (at >= 0) memo_models[at] = rep_models[k];
+            else {
+                memo.insert(req_motifs[k], (int)memo_models.size());
+                memo_models.push_back(rep_models[k]);
+            }
+        }
         std::vector<Model> full;
         full.reserve(ask_all.size());
-        for (const auto &m : ask_all) full.push_back(memo[m]);
+        for (const auto &m : ask_all) full.push_back(memo_models[memo.find(m)]);
         rep_models.swap(full);
         ask_all.clear();
     }
@@ -331,7 +415,7 @@ struct Task {
         root_model = rep_models[0];
         best_score = evaluation_score(root_model, root_model);
         rounds = 0;
-        visited.clear();
+        epoch += 1;
         graph_made = true;
         if (g.find(root) < 0) {
             const int id = g.add(root);
@@ -339,18 +423,21 @@ struct Task {
             g.nodes[id].score = best_score;
         }
         pq = decltype(pq)();
-        pq.push(HeapEntry{0.0, 0, root});
+        pq.push(HeapEntry{0.0, 0, root, g.find(root)});
         while (!pq.empty()) {
+            cur_id = pq.top().id;
+            if (g.nodes[cur_id].seen_epoch == epoch) {
+                pq.pop();
+                continue;
+            }
             cur = pq.top().motif;
             pq.pop();
-            if (visited.count(cur)) continue;
-            cur_id = g.find(cur);
             {
                 const Node &n = g.nodes[cur_id];
                 if (n.model.n_mod() + n.model.n_nomod() < 10) continue;
                 if (stripped_length(cur) > P->max_motif_length) continue;
             }
-            visited.emplace(cur, 1);
+            g.nodes[cur_id].seen_epoch = epoch;
             g.nodes[cur_id].visited = true;
             rounds += 1;
             request_win(REQ_PSSM, cur);
@@ -360,8 +447,11 @@ struct Task {
             if (rep_a == 0) continue;
             children_of(cur, rep_a);
             fresh.clear();
-            for (const auto &m : neighbors)
-                if (g.find(m) < 0) fresh.push_back(m);
+            neighbor_ids.clear();
+            for (const auto &m : neighbors) {
+                neighbor_ids.push_back(g.find(m));
+                if (neighbor_ids.back() < 0) fresh.push_back(m);
+            }
             if (fresh.empty()) rep_models.clear();
             else if (request_score(fresh)) {
                 state = 3;
@@ -371,8 +461,9 @@ struct Task {
             {
                 const Model cur_model = g.nodes[cur_id].model;
                 const int cur_depth = g.nodes[cur_id].depth;
-                for (const auto &nxt : neighbors) {
-                    int id = g.find(nxt);
+                for (size_t ni = 0; ni < neighbors.size(); ++ni) {
+                    const std::string &nxt = neighbors[ni];
+                    int id = neighbor_ids[ni];
                     Model nm;
                     if (id >= 0) nm = g.nodes[id].model;
                     else {
@@ -396,7 +487,7 @@ struct Task {
                         n.depth = cur_depth + 1;
                     }
                     if (!g.has_edge(cur_id, id)) g.add_edge(cur_id, id);
-                    if (!visited.count(nxt)) pq.push(HeapEntry{g.nodes[id].priority, g.nodes[id].depth, nxt});
+                    if (g.nodes[id].seen_epoch != epoch) pq.push(HeapEntry{g.nodes[id].priority, g.nodes[id].depth, nxt, id});
                     if (score > best_score) {
                         best_score = score;
                         best_guess = nxt;
@@ -495,68 +586,82 @@ public:
     ~Workers() {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-            gen_ += 1;
+            stop_.store(true);
+            gen_.fetch_add(1);
         }
         cv_.notify_all();
         for (auto &t : pool_) t.join();
     }
-    // fn(i) for i in [0, n): the calling thread takes part; returns when all indices are done
+    // fn(i) for i in [0, n): the calling thread takes part; returns when all indices are done.  Two batches of a search
+    // are some hundred microseconds apart: a worker spins that long for the next one before it goes to sleep on the
+    // condition variable (a futex wake-up per phase cost as much as the phase's work).
     void run(size_t n, const std::function<void(size_t)> &fn) {
-        if (pool_.empty() || n < 64) {
+        if (pool_.empty() || n < min_parallel_) {
             for (size_t i = 0; i < n; ++i) fn(i);
             return;
         }
-        {
+        fn_ = &fn;
+        n_ = n;
+        chunk_ = std::max<size_t>(1, std::min<size_t>(16, n / ((pool_.size() + 1) * 3)));
+        next_.store(0, std::memory_order_relaxed);
+        busy_.store((unsigned)pool_.size());
+        gen_.fetch_add(1);                                   // publishes fn_, n_, next_, busy_
+        if (asleep_.load() > 0) {
             std::lock_guard<std::mutex> lk(m_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0, std::memory_order_relaxed);
-            busy_ = (unsigned)pool_.size();
-            gen_ += 1;
+            cv_.notify_all();
         }
-        cv_.notify_all();
         drain();
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return busy_ == 0; });
+        while (busy_.load(std::memory_order_acquire) != 0) relax();
         fn_ = nullptr;
     }
 
 private:
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void drain() {
         for (;;) {
-            const size_t lo = next_.fetch_add(16, std::memory_order_relaxed);
+            const size_t lo = next_.fetch_add(chunk_, std::memory_order_relaxed);
             if (lo >= n_) return;
-            const size_t hi = std::min(n_, lo + 16);
+            const size_t hi = std::min(n_, lo + chunk_);
             for (size_t i = lo; i < hi; ++i) (*fn_)(i);
         }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (stop_) return;
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (gen_.load() == seen) {
+                relax();
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    asleep_.fetch_add(1);
+                    cv_.wait(lk, [&] { return gen_.load() != seen; });
+                    asleep_.fetch_sub(1);
+                    break;
+                }
             }
+            seen = gen_.load();
+            if (stop_.load()) return;
             drain();
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                busy_ -= 1;
-            }
-            done_.notify_one();
+            busy_.fetch_sub(1, std::memory_order_release);
         }
     }
     std::vector<std::thread> pool_;
     std::mutex m_;
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_ = 0;
+    size_t n_ = 0, chunk_ = 16;
+    size_t min_parallel_ = getenv("NM_SEARCH_MIN_PARALLEL") ? (size_t)std::max(1, atoi(getenv("NM_SEARCH_MIN_PARALLEL"))) : 16;
     std::atomic<size_t> next_{0};
-    unsigned busy_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    std::atomic<unsigned> busy_{0}, asleep_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> stop_{false};
 };
 
 // The two back ends of a lock-step round.  Callbacks (nm_search_run_custom) answer at once; the engine's halves
@@ -579,12 +684,12 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     const bool timing = getenv("NM_SEARCH_TIMING") != nullptr;
     double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    // NM_SEARCH_THREADS: host threads that advance the searches between two batches.  Default 4: a round of 1 000 searches
-    // is ~0.1 ms of state-machine work, more threads spend it waking up (1 Gbp run: 22 ms on one thread, 12-15 on four,
-    // 15-29 on eight)
+    // NM_SEARCH_THREADS: host threads that advance the searches between two batches (default 4; a phase with fewer than
+    // NM_SEARCH_MIN_PARALLEL = 16 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
+    // of children_of (164 logarithms per expansion, bit-exact with scipy): 24 ms on one thread, 16-17 on four, 14-15 on eight
     unsigned n_threads = std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("NM_SEARCH_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, atoi(e)));
-    if (tasks.size() < 64) n_threads = 1;
+    if (tasks.size() < 16) n_threads = 1;
     Workers workers(n_threads);
     double t0 = now();
     workers.run(tasks.size(), [&](size_t i) { tasks[i].resume(); });

@@ -134,3 +134,50 @@ def test_two_lanes_order_launches_that_share_one_count_table():
     assert np.array_equal(table.cpu().numpy(), want[len(made) - 1])
     eng.set_score_lanes(1)
     eng.close()
+
+
+def test_begin_end_halves_equal_the_synchronous_calls():
+    """nm_score_batch_begin / _end and nm_win_batch_w_begin / _end (what a round of nm_search_run keeps in flight together):
+    same counts as the one-call forms, with other calls on the ctx in between; a second _begin before _end and an _end
+    without _begin are NM_ESTATE; _end(NULL) drops the batch."""
+    import ctypes as C
+    from nanomotif_amd import _lib
+    NM_ESTATE = -3
+    mg, eng = _engine()
+    lib = eng.lib
+    batches = _batches(mg, 7)
+    want = [eng.score(b) for b in batches]
+    # a window task to run requests on while scoring batches are open
+    rng = np.random.default_rng(3)
+    sets = rng.choice(np.array([1, 2, 4, 8], dtype=np.uint8), size=(500, 41))
+    tid = C.c_uint32(0)
+    _lib.check(lib.nm_win_add_task(eng.ctx, 500, 41, sets.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(tid)))
+    req_task = np.array([tid.value, tid.value], dtype=np.uint32)
+    req_kind = np.zeros(2, dtype=np.uint8)
+    req_sets = np.full((2, 64), 15, dtype=np.uint8)
+    req_sets[1, 20] = 1
+    p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    win_want = np.zeros((2, 2 + 4 * 64), dtype=np.int32)
+    _lib.check(lib.nm_win_batch_w(eng.ctx, 2, p(req_task, C.c_uint32), p(req_kind, C.c_uint8), p(req_sets, C.c_uint8), 64, p(win_want, C.c_int32)))
+    assert win_want[0, 0] == 500 and 0 < win_want[1, 0] < 500
+    for k, b in enumerate(batches):
+        made = eng.make_batch(b)
+        args = eng._batch_args(made)
+        _lib.check(lib.nm_win_batch_w_begin(eng.ctx, 2, p(req_task, C.c_uint32), p(req_kind, C.c_uint8), p(req_sets, C.c_uint8), 64))
+        _lib.check(lib.nm_score_batch_begin(eng.ctx, *args))
+        assert lib.nm_score_batch_begin(eng.ctx, *args) == NM_ESTATE
+        assert lib.nm_win_batch_w_begin(eng.ctx, 2, p(req_task, C.c_uint32), p(req_kind, C.c_uint8), p(req_sets, C.c_uint8), 64) == NM_ESTATE
+        win_got = np.zeros_like(win_want)
+        _lib.check(lib.nm_win_batch_w_end(eng.ctx, p(win_got, C.c_int32)))
+        assert np.array_equal(win_got, win_want)
+        if k % 2:
+            assert np.array_equal(eng.score(batches[0]), want[0])           # another scoring call while the batch is open
+        got = np.full((len(b), 2), -1, dtype=np.int64)
+        _lib.check(lib.nm_score_batch_end(eng.ctx, p(got, C.c_int64)))
+        assert np.array_equal(got, want[k]), k
+    assert lib.nm_score_batch_end(eng.ctx, None) == NM_ESTATE
+    assert lib.nm_win_batch_w_end(eng.ctx, None) == NM_ESTATE
+    _lib.check(lib.nm_score_batch_begin(eng.ctx, *eng._batch_args(eng.make_batch(batches[1]))))
+    _lib.check(lib.nm_score_batch_end(eng.ctx, None))                       # dropped
+    assert np.array_equal(eng.score(batches[1]), want[1])
+    eng.close()

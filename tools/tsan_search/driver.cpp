@@ -20,8 +20,11 @@ int nm_set_error(int code, const char *fmt, ...) {
     return code;
 }
 extern "C" {
-int nm_score_batch(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, const uint8_t *, const uint32_t *, const uint8_t *, int64_t *) { return NM_ESTATE; }
-int nm_win_batch(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, int32_t *) { return NM_ESTATE; }
+// the engine entry points nm_search_run links against (never called here: the driver runs on callbacks)
+int nm_score_batch_begin(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, const uint8_t *, const uint32_t *, const uint8_t *) { return NM_ESTATE; }
+int nm_score_batch_end(nm_ctx *, int64_t *) { return NM_ESTATE; }
+int nm_win_batch_w_begin(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, uint32_t) { return NM_ESTATE; }
+int nm_win_batch_w_end(nm_ctx *, int32_t *) { return NM_ESTATE; }
 }
 
 static uint64_t mix(uint64_t x) {
@@ -113,6 +116,10 @@ static Export run(uint32_t n_tasks, const char *threads) {
 
 int main(int argc, char **argv) {
     const uint32_t n = argc > 1 ? (uint32_t)atoi(argv[1]) : 300;
+    if (argc > 2) {                      // timing mode: <n> <threads> [<threads> ...], NM_SEARCH_TIMING=1 prints the split
+        for (int k = 2; k < argc; ++k) run(n, argv[k]);
+        return 0;
+    }
     const Export a = run(n, "1"), b = run(n, "8"), c = run(n, "3");
     if (!(a == b) || !(a == c)) { printf("MISMATCH between thread counts\n"); return 1; }
     printf("identical exports\n");
