@@ -85,21 +85,48 @@ def find_motifs_bin(args):
                 dist.init_process_group(backend)
     from ._lib import NmScanError
     from .engine import ScanEngine
-    try:
-        eng = ScanEngine(device)                 # fails loudly without a GPU: there is no CPU fallback
-    except NmScanError as e:
-        raise RuntimeError(f"nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback ({e})") from e
+    # The HIP runtime takes 0.1-0.3 s to come up in a fresh process: it does so on a side thread while this one reads the
+    # contig-bin table and parses the assembly (native code, the interpreter lock is released).  Fails loudly without a
+    # GPU: there is no CPU fallback.
+    import threading
+    started = {}
 
-    lap("engine_start_s")
+    def start_engine():
+        try:
+            started["eng"] = ScanEngine(device)
+        except BaseException as e:               # re-raised on the main thread below
+            started["error"] = e
+    starter = threading.Thread(target=start_engine, name="nm-engine-start")
+    starter.start()
+
+    def engine():
+        starter.join()
+        if "error" in started:
+            e = started["error"]
+            if isinstance(e, NmScanError):
+                raise RuntimeError(f"nanomotif_amd needs an AMD GPU (MI355X); there is no CPU fallback ({e})") from e
+            raise e
+        return started["eng"]
+
     log.info("Starting nanomotif motif finder")
     bin_contig = fasta.generate_contig_bin(args)
     if not bin_contig:
         log.error("No bin contig mapping found")
+        eng = engine()
+        eng.close()
         return None
     log.info("Loading assembly")
-    assembly = fasta.load_fasta(args.assembly)
-    fasta.add_alias_sequences(assembly, bin_contig)          # a contig listed under several bins is a member of each
+    try:
+        assembly = fasta.load_fasta(args.assembly)
+        fasta.add_alias_sequences(assembly, bin_contig)      # a contig listed under several bins is a member of each
+    except BaseException:
+        starter.join()
+        if "eng" in started:
+            started["eng"].close()
+        raise
     lap("assembly_s")
+    eng = engine()
+    lap("engine_start_s")                        # what the assembly did not hide
     log.info("Identifying motifs")
     cfg = ProcessorConfig(assembly=assembly, pileup_path=args.pileup, bin_contig=bin_contig, threads=args.threads,
                           search_frame_size=args.search_frame_size, methylation_threshold_low=args.methylation_threshold_low,
