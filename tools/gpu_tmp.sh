@@ -1,9 +1,10 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
-for cfg in "4 64" "4 16" "4 8" "8 16" "8 8" "4 64" "4 16" "8 16"; do
-set -- $cfg
-NM_SEARCH_THREADS=$1 NM_SEARCH_MIN_PARALLEL=$2 NM_SEARCH_TIMING=1 timeout 900 python bench.py --workload e2e --steps 1 --warmup 0 --cpu-bins 0 > gpurun_out/e2e_z.json 2> gpurun_out/e2e_z.err
-echo "threads $1 min_parallel $2: $(grep 'nm_search. 1000' gpurun_out/e2e_z.err | cut -c1-120) $(python -c "
-import json; d=json.loads(open('gpurun_out/e2e_z.json').read().strip().splitlines()[-1]); t=d['timings_rank0']; print(round(d['value'],4), round(t['native_search_s'],4))")"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_lanes.py -x -q 2>&1 | tail -3
+for mode in desc mask desc mask; do
+if [ $mode = mask ]; then export NM_NO_DESC=1; else unset NM_NO_DESC; fi
+timeout 600 python bench.py --cpu-bins 0 --extras none --hbm-round-steps 0 --steps 20 --warmup 5 > gpurun_out/b_$mode.json 2>/dev/null
+python -c "
+import json; d=json.loads(open('gpurun_out/b_$mode.json').read().strip().splitlines()[-1]); print('$mode', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline'].get('kernel'))"
 done
