@@ -59,6 +59,16 @@ struct MT {                       // MT19937 exactly as CPython's _randommodule.
 
 }  // namespace
 
+// n_draws outputs of genrand_uint32 from mt_state (advanced in place); out may be NULL.  For the device-side draws of
+// nm_plan_windows: the raw sequence every generator stream reads, and the state a stream is left in.
+void nm_mt_outputs(uint32_t mt_state[625], uint64_t n_draws, uint32_t *out) {
+    MT g{mt_state, mt_state + 624};
+    if (out)
+        for (uint64_t i = 0; i < n_draws; ++i) out[i] = g.next();
+    else
+        for (uint64_t i = 0; i < n_draws; ++i) (void)g.next();
+}
+
 extern "C" {
 
 int nm_py_random_sample(uint32_t mt_state[625], uint64_t n, uint64_t k, uint32_t *out_indices) {

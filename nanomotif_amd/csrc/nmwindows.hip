@@ -1,12 +1,15 @@
 // libnmscan — window engine and window extraction: the per-expansion work of the greedy search on bit planes over
 // windows, the gather of those windows from the resident planes and the background sample (C ABI: nm_win_*,
 // nm_contig_base_counts, nm_bg_counts, nm_methylated_row_counts; include/nmscan.h).
+#include <chrono>
 #include <cmath>
 #include <thread>
 
 #include "nmscan_internal.h"
 
 using namespace nmdetail;
+
+void nm_mt_outputs(uint32_t mt_state[625], uint64_t n_draws, uint32_t *out);   // nmhost.cpp: genrand_uint32 outputs, state advanced in place
 
 namespace {
 
@@ -918,6 +921,120 @@ int nm_win_add_task_contigs(nm_ctx *c, uint32_t mod_slot, uint32_t n_contigs, co
 
 
 // ------------------------------------------------------------------------------------------------------
+// random.sample(range(n), k) of every generator stream ON THE DEVICE.  When all streams start from the same state (the
+// reference seeds every (bin, mod type) task afresh, find_motifs_bin.py:152-171) they all read ONE sequence of MT19937
+// outputs, which the host generates once; what differs per stream is how the sequence is CONSUMED, and that is a scan:
+// a draw r = raw >> (32 - bits(n)) is rejected when r >= n (Random._randbelow_with_getrandbits), skipped when r was
+// selected before (the `while j in selected` loop of random.sample's set branch, random.py:449-466), selected otherwise,
+// until k are selected.  One wave per stream walks its calls in order, 64 raw draws at a time: range test per lane,
+// membership of earlier tiles in a bitmap (one word array per stream, bits cleared again at the end of the call), first
+// occurrence inside the tile by a leader loop over the distinct values, cut at the k-th selection.  The pool branch
+// (n <= setsize: tiny contigs) is replayed by lane 0.
+// ------------------------------------------------------------------------------------------------------
+struct DrawCall { uint32_t n, k, out_lo, out_hi; };      // out: first rank in `ranks` (kept samples) or, bit 63 set, in the discard area
+
+// A stream's scratch and outputs are touched by ONE wave only: what its lanes hand each other through global memory has to
+// be ordered, not made visible to the other dies.  Atomics and write-through stores are performed at the L2 of the wave's
+// own XCD; "all my earlier memory operations have been performed" (s_waitcnt) plus loads that bypass the L1 is all it takes
+// — an agent-scope fence writes back and invalidates caches and cost 10+ us per 64 draws.
+__device__ __forceinline__ uint32_t load_coherent(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wave_mem_sync() { __asm__ volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(64) void bg_draw_kernel(const uint32_t *__restrict__ raw, uint32_t raw_len, const DrawCall *__restrict__ calls,
+                                                     const uint32_t *__restrict__ group_call_off, const uint64_t *__restrict__ group_scratch_off,
+                                                     uint32_t *scratch, uint32_t *ranks, uint32_t *discard, uint32_t *consumed /*[n_groups]*/) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    uint32_t *bm = scratch + group_scratch_off[g];
+    uint32_t p = 0;                                       // raw draws consumed so far (wave-uniform)
+    bool overflow = false;
+    for (uint32_t ci = group_call_off[g]; ci < group_call_off[g + 1] && !overflow; ++ci) {
+        const DrawCall cl = calls[ci];
+        const uint64_t out_at = ((uint64_t)(cl.out_hi & 0x7FFFFFFFu) << 32) | cl.out_lo;
+        uint32_t *out = ((cl.out_hi >> 31) ? discard : ranks) + out_at;
+        const uint32_t n = cl.n, k = cl.k;
+        if (k == 0) continue;
+        // random.py:449-453: setsize = 21, + 4 ** ceil(log(3 k, 4)) for k > 5 — the smallest power of four >= 3 k
+        uint64_t setsize = 21;
+        if (k > 5) {
+            uint64_t p4 = 1;
+            while (p4 < 3ull * k) p4 *= 4;
+            setsize += p4;
+        }
+        if ((uint64_t)n <= setsize) {
+            // pool branch: j = randbelow(n - i); result[i] = pool[j]; pool[j] = pool[n - i - 1]
+            for (uint32_t i = lane; i < n; i += 64) bm[i] = i;
+            wave_mem_sync();
+            if (lane == 0) {
+                for (uint32_t i = 0; i < k && !overflow; ++i) {
+                    const uint32_t m = n - i, sh = (uint32_t)__clz((int)m);
+                    uint32_t r = 0xFFFFFFFFu;
+                    while (r >= m) {
+                        if (p >= raw_len) { overflow = true; break; }
+                        r = raw[p++] >> sh;
+                    }
+                    if (overflow) break;
+                    out[i] = load_coherent(bm + r);
+                    __hip_atomic_store(bm + r, load_coherent(bm + m - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+            overflow = __builtin_amdgcn_readfirstlane((int)overflow) != 0;
+            wave_mem_sync();
+            for (uint32_t i = lane; i < n; i += 64) bm[i] = 0;       // the scratch goes back to all zero
+            wave_mem_sync();
+            continue;
+        }
+        const uint32_t sh = (uint32_t)__clz((int)n);         // 32 - n.bit_length()
+        uint32_t selected = 0;
+        while (selected < k) {
+            if (p >= raw_len) { overflow = true; break; }
+            const uint32_t idx = p + lane;
+            const bool in_range = idx < raw_len;
+            const uint32_t r = in_range ? raw[idx] >> sh : 0xFFFFFFFFu;
+            const bool valid = in_range && r < n;
+            const uint32_t word = valid ? r >> 5 : 0u, bit = 1u << (r & 31u);
+            const bool cand = valid && !(load_coherent(bm + word) & bit);
+            bool keep = cand;
+            unsigned long long todo = __ballot(cand);
+            while (todo) {                                   // wave-uniform: one turn per distinct value of the tile
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
+                const unsigned long long same = __ballot(cand && r == v);
+                if (cand && r == v && (int)lane != leader) keep = false;
+                todo &= ~same;
+            }
+            unsigned long long sel = __ballot(keep);
+            uint32_t advance = 64;
+            if (selected + (uint32_t)__popcll(sel) >= k) {   // the call ends inside this tile: at its (k - selected)-th selection
+                unsigned long long m = sel;
+                for (uint32_t skip = k - selected - 1; skip; --skip) m &= m - 1;
+                const int last = __ffsll((long long)m) - 1;
+                if (last < 63) sel &= (2ull << last) - 1ull;
+                keep = keep && (int)lane <= last;
+                advance = (uint32_t)last + 1u;
+            }
+            if (keep) {
+                out[selected + (uint32_t)__popcll(sel & ((1ull << lane) - 1ull))] = r;
+                atomicOr(bm + word, bit);
+            }
+            selected += (uint32_t)__popcll(sel);
+            p += advance;
+            wave_mem_sync();                                 // this tile's bits before the next tile's membership loads
+        }
+        // clear the bits of this call: the bitmap is all zero between calls
+        wave_mem_sync();
+        for (uint32_t i = lane; i < selected; i += 64) {
+            const uint32_t v = load_coherent(out + i);
+            atomicAnd(bm + (v >> 5), ~(1u << (v & 31u)));
+        }
+        wave_mem_sync();
+    }
+    if (lane == 0) consumed[g] = overflow ? 0xFFFFFFFFu : p;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // nm_plan_windows: window extraction of ALL (bin, mod type) tasks in one call (find_motifs_bin.py:625-686 per task): the
 // reference walks the task's contigs in order; per contig it draws the background sample (random.sample of the valid
 // starts, seq.py:202-225) and then gathers the methylation windows, and gives the task up (None) at the first contig
@@ -939,6 +1056,11 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     const uint32_t W = 2 * pad + 1;
     if (W > (uint32_t)WIN_MAX_W) return fail(NM_ERANGE, "window width %u outside 1..%d", W, WIN_MAX_W);
     HIP_TRY(hipSetDevice(c->device));
+    // NM_PLAN_TIMING: where the wall time of this call goes (stderr, one line)
+    const bool timing = getenv("NM_PLAN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now(), t_counts = 0, t_plan = 0, t_stage = 0, t_draws = 0, t_tail = 0;
+    auto lap = [&](double &acc) { const double t = now(); acc += t - t_mark; t_mark = t; };
     // ---- counts the plan needs: valid sample starts per contig and base, confident rows per contig and slot
     std::vector<uint64_t> n_valid[4];
     for (uint32_t t = 0; t < n_tasks; ++t) {
@@ -954,6 +1076,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
         const int rc = ensure_slot_counts(c, task_slot[t], pad);
         if (rc) return rc;
     }
+    lap(t_counts);
     // ---- the plan
     struct Call { uint64_t n, k, out; };                   // random.sample(range(n), k); out: first rank in the staging buffer or ~0 (discarded)
     std::vector<std::vector<Call>> group_calls(n_groups);
@@ -1031,6 +1154,40 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
         task_n_windows[t] = total;
         task_n_bg[t] = n_bg;
     }
+    lap(t_plan);
+    // device draws: flat call table, a bound on the raw draws any stream consumes, scratch words per stream
+    bool device_draws = shared_init && n_groups >= 32 && n_samples && getenv("NM_HOST_DRAWS") == nullptr;
+    std::vector<DrawCall> flat;
+    std::vector<uint32_t> call_off(n_groups + 1, 0);
+    std::vector<uint64_t> scratch_off(n_groups + 1, 0);
+    uint64_t raw_len = 0, n_discard = 0;
+    if (device_draws) {
+        for (uint32_t g = 0; g < n_groups && device_draws; ++g) {
+            double expect = 0;
+            uint64_t words = 1;
+            for (const Call &cl : group_calls[g]) {
+                uint64_t setsize = 21;
+                if (cl.k > 5) {
+                    uint64_t p4 = 1;
+                    while (p4 < 3 * cl.k) p4 *= 4;
+                    setsize += p4;
+                }
+                const bool pool = cl.n <= setsize;
+                if (cl.n >= 0xFFFFFFFFull || (pool && cl.k > 4096)) { device_draws = false; break; }   // (a long pool replay is serial: host)
+                const int bits = 64 - __builtin_clzll(cl.n | 1);
+                // a draw is in range with probability n / 2^bits (> 1/2) and new with probability >= 1 - k / n
+                expect += (double)cl.k * ((double)(1ull << bits) / (double)cl.n) / std::max(0.05, 1.0 - (double)cl.k / (double)cl.n) + 64.0;
+                words = std::max<uint64_t>(words, pool ? cl.n : (cl.n + 31) / 32);
+                const uint64_t out = cl.out == ~0ull ? ((1ull << 63) | n_discard) : cl.out;
+                if (cl.out == ~0ull) n_discard += cl.k;
+                flat.push_back(DrawCall{(uint32_t)cl.n, (uint32_t)cl.k, (uint32_t)out, (uint32_t)(out >> 32)});
+            }
+            call_off[g + 1] = (uint32_t)flat.size();
+            scratch_off[g + 1] = scratch_off[g] + words;
+            raw_len = std::max<uint64_t>(raw_len, (uint64_t)(expect * 1.3) + 4096);
+        }
+        if (raw_len > (8ull << 20) || scratch_off[n_groups] > (1ull << 30)) device_draws = false;   // one very long stream: nothing to run in parallel
+    }
     // ---- window pools and the task table
     int rc = win_grow(c, &c->d_win_planes, &c->win_planes_cap, c->win_planes_used, planes_used - c->win_planes_used);
     if (rc) return rc;
@@ -1049,9 +1206,19 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     }
     HIP_TRY(hipMemcpyAsync(c->d_win_tasks, c->win_tasks.data(), c->win_tasks.size() * sizeof(WinTask), hipMemcpyHostToDevice, c->stream));
     c->win_tasks_dirty = false;
-    // ---- staging: ranks | sample contig column (device only) | segments | window blocks | runs | bg blocks (4 lists) | counts
+    // ---- staging: [ranks | sample contig column (device only)] | segments | window blocks | runs | bg blocks (4 lists) | counts.
+    // With device draws the two sample columns never exist on the host: they get a device buffer of their own and the pinned
+    // staging pair stays small (pinning 160 MB for a 1 Gbp plan was 10 ms of this call).
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t o_rank = 0, o_contig = up16((size_t)n_samples * 4), o_seg = up16(o_contig + (size_t)n_samples * 4);
+    struct DeviceBuffer {
+        uint8_t *p = nullptr;
+        ~DeviceBuffer() {                                    // (error paths leave kernels in flight: wait before the memory goes back)
+            if (p) { (void)hipDeviceSynchronize(); (void)nmdetail::dev_free(p); }
+        }
+    } d_samples;
+    const size_t col_bytes = up16((size_t)n_samples * 4);
+    if (device_draws) HIP_TRY(nmdetail::dev_malloc(&d_samples.p, 2 * col_bytes + 16));
+    const size_t o_rank = 0, o_contig = device_draws ? 0 : col_bytes, o_seg = device_draws ? 0 : up16(o_contig + (size_t)n_samples * 4);
     const size_t o_blk = up16(o_seg + segs.size() * sizeof(WinSegment)), o_runs = up16(o_blk + blocks.size() * sizeof(WinBlock));
     size_t o_bg[4], at = up16(o_runs + runs.size() * sizeof(BgRun));
     for (int b = 0; b < 4; ++b) { o_bg[b] = at; at = up16(at + bg_blocks[b].size() * sizeof(BgBlock)); }
@@ -1060,6 +1227,8 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     rc = ensure_stage(c, o_out + out_bytes);
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    uint32_t *const d_rank_col = reinterpret_cast<uint32_t *>(device_draws ? d_samples.p : ds + o_rank);
+    uint32_t *const d_contig_col = reinterpret_cast<uint32_t *>(device_draws ? d_samples.p + col_bytes : ds + o_contig);
     if (!segs.empty()) memcpy(hs + o_seg, segs.data(), segs.size() * sizeof(WinSegment));
     if (!blocks.empty()) memcpy(hs + o_blk, blocks.data(), blocks.size() * sizeof(WinBlock));
     if (!runs.empty()) memcpy(hs + o_runs, runs.data(), runs.size() * sizeof(BgRun));
@@ -1081,9 +1250,13 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
         nmdetail::busy_end(c);
         HIP_TRY(hipGetLastError());
     }
-    // ---- the draws: every group its own generator stream, on host threads, while the gather kernel runs
-    {
-        uint32_t *ranks = reinterpret_cast<uint32_t *>(hs + o_rank);
+    lap(t_stage);
+    // ---- the draws.  Streams that all start from one state (the plain-pileup task order) are consumed on the device
+    // (bg_draw_kernel); otherwise, or when a stream is too long for that to pay, on host threads while the gather kernel runs.
+    auto host_draws = [&]() -> int {
+        std::vector<uint32_t> unpinned;                      // (only when the device draws were tried first: no pinned column then)
+        if (device_draws) unpinned.resize(n_samples + 1);
+        uint32_t *ranks = device_draws ? unpinned.data() : reinterpret_cast<uint32_t *>(hs + o_rank);
         std::vector<int> rcs(n_groups, NM_OK);
         std::vector<std::string> errs(n_groups);
         const unsigned threads = std::max(1u, std::min<unsigned>({16u, std::thread::hardware_concurrency(), n_groups}));
@@ -1111,18 +1284,65 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
             }
         for (unsigned th = 0; th < threads; ++th)
             if (!last[th].empty()) memcpy(final_state, last[th].data(), 625 * 4);
+        if (n_samples) HIP_TRY(hipMemcpyAsync(d_rank_col, ranks, (size_t)n_samples * 4, hipMemcpyHostToDevice, c->stream));
+        if (device_draws) HIP_TRY(hipStreamSynchronize(c->stream));
+        return NM_OK;
+    };
+    bool drew_on_device = false;
+    if (device_draws) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t q_calls = 0, q_coff = up(q_calls + flat.size() * sizeof(DrawCall)), q_soff = up(q_coff + call_off.size() * 4);
+        const size_t q_raw = up(q_soff + scratch_off.size() * 8), q_cons = up(q_raw + raw_len * 4), q_scr = up(q_cons + (size_t)n_groups * 4);
+        const size_t q_disc = up(q_scr + scratch_off[n_groups] * 4), q_end = up(q_disc + (n_discard + 1) * 4);
+        uint8_t *d_draw = nullptr;
+        HIP_TRY(nmdetail::dev_malloc(&d_draw, q_end));
+        std::vector<uint8_t> hbuf(q_cons, 0);
+        memcpy(hbuf.data() + q_calls, flat.data(), flat.size() * sizeof(DrawCall));
+        memcpy(hbuf.data() + q_coff, call_off.data(), call_off.size() * 4);
+        memcpy(hbuf.data() + q_soff, scratch_off.data(), scratch_off.size() * 8);
+        uint32_t st[625];
+        memcpy(st, group_init_state, sizeof st);
+        nm_mt_outputs(st, raw_len, reinterpret_cast<uint32_t *>(hbuf.data() + q_raw));
+        std::vector<uint32_t> consumed(n_groups, 0);
+        hipError_t e = hipMemcpyAsync(d_draw, hbuf.data(), q_cons, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_draw + q_scr, 0, scratch_off[n_groups] * 4, c->stream);
+        if (e == hipSuccess) {
+            nmdetail::busy_begin(c);
+            hipLaunchKernelGGL(bg_draw_kernel, dim3(n_groups), dim3(64), 0, c->stream, reinterpret_cast<const uint32_t *>(d_draw + q_raw),
+                               (uint32_t)raw_len, reinterpret_cast<const DrawCall *>(d_draw + q_calls),
+                               reinterpret_cast<const uint32_t *>(d_draw + q_coff), reinterpret_cast<const uint64_t *>(d_draw + q_soff),
+                               reinterpret_cast<uint32_t *>(d_draw + q_scr), d_rank_col,
+                               reinterpret_cast<uint32_t *>(d_draw + q_disc), reinterpret_cast<uint32_t *>(d_draw + q_cons));
+            nmdetail::busy_end(c);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(consumed.data(), d_draw + q_cons, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)nmdetail::dev_free(d_draw);
+        if (e != hipSuccess) return fail(NM_EHIP, "device draws: %s", hipGetErrorString(e));
+        drew_on_device = true;
+        for (uint32_t g = 0; g < n_groups; ++g)
+            if (consumed[g] == 0xFFFFFFFFu) drew_on_device = false;       // a stream outran the generated sequence (1.3 x its expectation): host replay
+        if (drew_on_device) {
+            memcpy(st, group_init_state, sizeof st);
+            nm_mt_outputs(st, consumed[n_groups - 1], nullptr);
+            memcpy(final_state, st, sizeof st);
+        }
     }
+    if (!drew_on_device) {
+        rc = host_draws();
+        if (rc) return rc;
+    }
+    lap(t_draws);
     if (n_samples) {
-        HIP_TRY(hipMemcpyAsync(ds + o_rank, hs + o_rank, (size_t)n_samples * 4, hipMemcpyHostToDevice, c->stream));
         nmdetail::busy_begin(c);
         hipLaunchKernelGGL(bg_expand_runs_kernel, dim3((unsigned)runs.size()), dim3(256), 0, c->stream,
-                           reinterpret_cast<const BgRun *>(ds + o_runs), reinterpret_cast<uint32_t *>(ds + o_contig));
+                           reinterpret_cast<const BgRun *>(ds + o_runs), d_contig_col);
         HIP_TRY(hipGetLastError());
         for (int b = 0; b < 4; ++b) {
             if (bg_blocks[b].empty()) continue;
             hipLaunchKernelGGL(bg_counts_kernel, dim3((unsigned)bg_blocks[b].size()), dim3(256), 0, c->stream, seq_planes(c), c->d_rank[b],
-                               c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_bg[b]),
-                               reinterpret_cast<const uint32_t *>(ds + o_contig), reinterpret_cast<const uint32_t *>(ds + o_rank), b, pad,
+                               c->d_contig_chunk, c->d_contig_len, reinterpret_cast<const BgBlock *>(ds + o_bg[b]), d_contig_col, d_rank_col, b, pad,
                                reinterpret_cast<unsigned long long *>(ds + o_out), ws, c->d_err);
             HIP_TRY(hipGetLastError());
         }
@@ -1141,6 +1361,11 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
         for (uint32_t r = 0; r < 4; ++r)
             for (uint32_t col = 0; col < W; ++col)
                 bg_counts[((size_t)t * 4 + r) * W + col] = (int64_t)ho[((size_t)t * 4 + r) * ws + col];
+    lap(t_tail);
+    if (timing)
+        fprintf(stderr, "[nm_plan_windows] %u tasks, %llu samples (%s draws): base / row counts %.1f ms, plan %.1f ms, pools + staging + gather launch "
+                        "%.1f ms, draws %.1f ms, background counts + wait %.1f ms\n", n_tasks, (unsigned long long)n_samples,
+                drew_on_device ? "device" : "host", t_counts * 1e3, t_plan * 1e3, t_stage * 1e3, t_draws * 1e3, t_tail * 1e3);
     return NM_OK;
 }
 

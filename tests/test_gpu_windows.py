@@ -206,3 +206,49 @@ def test_background_counts_from_runs_equal_counts_from_samples():
                                    ranks.ctypes.data_as(u32), 3, task_run_begin.ctypes.data_as(u32), got.ctypes.data_as(i64))
     assert rc != 0 and b"contig 9" in eng.lib.nm_last_error()
     eng.close()
+
+
+@pytest.mark.parametrize("freq", [0.01, 0.05])
+def test_device_draws_equal_host_draws(freq, monkeypatch):
+    """nm_plan_windows consumes the generator streams of all tasks on the device (bg_draw_kernel: one wave per stream over
+    ONE sequence of MT19937 outputs) when they start from the same state: background PSSMs, window counts and the state
+    the interpreter's generator is left in must equal the host-thread replay (NM_HOST_DRAWS=1) exactly.  freq 0.01: the
+    set branch of random.sample; freq 0.05: samples so large that n <= setsize for most contigs, the pool branch."""
+    import random
+    from nanomotif_amd import synth
+    from nanomotif_amd.e2e_synth import load_and_filter
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.main import device_window_pipeline
+    from nanomotif_amd.pileup import MOD_TYPES
+    import torch
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=300, total_bp=6_000_000, n_bins=24, mod_types=("a", "m"), seed=5))
+    results = []
+    for host in (True, False):
+        if host:
+            monkeypatch.setenv("NM_HOST_DRAWS", "1")
+        else:
+            monkeypatch.delenv("NM_HOST_DRAWS", raising=False)
+        eng = ScanEngine(0)
+        assembly, filtered, _ = load_and_filter(eng, mg, torch.device("cuda:0"), host_assembly=False)
+        lengths = dict(zip(mg.names, (int(x) for x in mg.lengths)))
+        store, extractor = device_window_pipeline(eng, lengths, list(mg.names), 20)
+        extractor.freq = freq
+        bins = {}
+        for c, b in zip(mg.names, mg.bin_names):
+            bins.setdefault(b, []).append(c)
+        tasks = []
+        for b in bins:
+            for mt in ("a", "m"):
+                names = filtered.present(bins[b], MOD_TYPES.index(mt))
+                if names:
+                    tasks.append(((b, mt), names, mt))
+        assert len(tasks) >= 32
+        random.seed(99)
+        pssms = extractor.plan_all(tasks, seed=1)
+        results.append((pssms, random.getstate(), dict(store.totals)))
+        eng.close()
+    (p_host, s_host, t_host), (p_dev, s_dev, t_dev) = results
+    assert s_host == s_dev and t_host == t_dev
+    assert list(p_host) == list(p_dev) and len(p_host) >= 32
+    for k in p_host:
+        assert np.array_equal(p_host[k], p_dev[k]), k

@@ -1,10 +1,11 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_lanes.py -x -q 2>&1 | tail -3
-for mode in desc mask desc mask; do
-if [ $mode = mask ]; then export NM_NO_DESC=1; else unset NM_NO_DESC; fi
-timeout 600 python bench.py --cpu-bins 0 --extras none --hbm-round-steps 0 --steps 20 --warmup 5 > gpurun_out/b_$mode.json 2>/dev/null
+timeout 900 python -m pytest tests/test_gpu_windows.py tests/test_gpu_cli.py -x -q 2>&1 | tail -3
+for mode in dev host dev; do
+if [ $mode = host ]; then export NM_HOST_DRAWS=1; else unset NM_HOST_DRAWS; fi
+NM_PLAN_TIMING=1 timeout 600 python bench.py --workload e2e --steps 1 --warmup 0 --cpu-bins 0 > gpurun_out/e2e_d.json 2> gpurun_out/e2e_d.err
+grep nm_plan gpurun_out/e2e_d.err
 python -c "
-import json; d=json.loads(open('gpurun_out/b_$mode.json').read().strip().splitlines()[-1]); print('$mode', d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline'].get('kernel'))"
+import json; d=json.loads(open('gpurun_out/e2e_d.json').read().strip().splitlines()[-1]); t=d['timings_rank0']; print('$mode', round(d['value'],4), d['per_rank'][0]['motif_rows'], d['per_rank'][0]['planted_recovered'], {k: round(v,4) for k,v in t.items() if k in ('plan_s','background_s','native_search_s','gpu_busy_s')})"
 done
