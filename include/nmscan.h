@@ -264,7 +264,9 @@ int nm_bg_counts_runs(nm_ctx *ctx, uint8_t base, uint32_t pad, uint32_t n_runs, 
  * a plain pileup alike, find_motifs_bin.py:152-171); final_state = where the last group's stream ends.
  * Outputs per task: task_status 0 = windows made / 1 = None; task_window = window-engine task id; task_n_windows;
  * task_n_bg = background samples; bg_counts int64[n_tasks][4][2*pad+1], rows A, T, G, C (pssm = counts / task_n_bg).
- * One gather launch serves the windows of every task; the draws run on host threads meanwhile.  The reference's two
+ * One gather launch serves the windows of every task.  With shared_init and at least 32 streams the draws are consumed
+ * on the device (one wave per stream over one shared sequence of MT19937 outputs, bit-identical to random.sample's set
+ * and pool branches); otherwise on host threads while the gather kernel runs (NM_HOST_DRAWS=1 forces that).  The reference's two
  * ValueErrors come back as NM_EINVAL with their text ("Too many samples requested ...", "Not enough subsequences ..."). */
 int nm_plan_windows(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_slot, const uint8_t *task_base, const uint32_t *task_group,
                     const uint32_t *task_contig_begin, const uint32_t *contig_id, uint32_t pad, double freq, uint32_t n_groups,
