@@ -95,11 +95,13 @@ __device__ __forceinline__ void wave_row_range(uint64_t n, uint64_t *row_begin, 
 // then assembles complete plane words and writes them with plain stores instead of read-modify-write atomics.
 __global__ __launch_bounds__(256) void ingest_count_kernel(RawRows r, uint32_t n_contigs, const uint64_t *__restrict__ contig_len,
                                     int min_cov, double meth_thr, unsigned int *cnt /*[contig][mod][2]*/, unsigned int *err,
-                                    unsigned int *order /*[0]: flags*/, unsigned int *runs /*[contig]*/) {
+                                    unsigned int *order /*[0]: flags*/, unsigned int *runs /*[contig]*/,
+                                    unsigned int *wave_cand /*[waves]: rows that can enter the adjacency test (upper bound)*/) {
     uint64_t row_begin, row_end;
     wave_row_range(r.n, &row_begin, &row_end);
     const uint32_t lane = threadIdx.x & 63;
     KeyCache kc;
+    uint32_t n_cand = 0;                                             // wave-uniform
     // 256 rows per turn: the loads of four consecutive 64-row pieces are all issued before the first value is looked at —
     // no test sits between two loads (the short-circuit tests used to make three dependent round trips of them), and a
     // wave asks memory for 1 KB of consecutive addresses per column at a time instead of 256 B
@@ -147,9 +149,111 @@ __global__ __launch_bounds__(256) void ingest_count_kernel(RawRows r, uint32_t n
             // (a row whose percentage is null — fraction < 0 — counts as a position, never as a modified one: pl.count() vs
             //  (fraction_mod > thr).sum(), dataload.py:216-217)
             wave_add_keyed(kc, cnt, counted ? cc * NM_CODE_STRIDE + (uint32_t)m[u] : 0u, counted, is_mod, 2);
+            n_cand += (uint32_t)__popcll(__ballot(counted && f[u] >= meth_thr));
         }
     }
     cache_flush(kc, cnt, 2, lane);
+    if (lane == 0) wave_cand[(size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = n_cand;
+}
+
+// exclusive prefix of n <= 2^20 counters by ONE workgroup: out[i] = sum of in[0 .. i), out[n] = the total
+__global__ __launch_bounds__(1024) void ingest_scan_kernel(const unsigned int *__restrict__ in, uint32_t n, unsigned long long *out) {
+    __shared__ unsigned long long part[1024];
+    const uint32_t per = (n + 1023) / 1024, a = threadIdx.x * per, b = min(n, a + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = a; i < b; ++i) sum += in[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+        out[n] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (uint32_t i = a; i < b; ++i) { out[i] = run; run += in[i]; }
+}
+
+// (3a') adjacency filter on rows in modkit's order: the rows that can decide a verdict (the ones ingest_scatter_kernel
+// would scatter) are COMPACTED IN ROW ORDER instead — contig, position, strand, fraction of ~1.5 % of a pileup — and a
+// tested row looks its window up in that list (binary search + the few entries within 8 positions).  No table of one
+// maximum per position and strand: at 1 Gbp that table is 16 GB, 98.5 % of it the zeros it was cleared to.
+// Every wave compacts the candidates of its row range into the block the counting pass sized for it (an upper bound: the
+// frequency verdicts were not known then); ingest_pack_kernel closes the gaps.
+struct CandList {
+    unsigned long long *key;       // contig << 32 | position: ascending inside a contig's run (the runs come in file order)
+    unsigned long long *fbits;     // IEEE bits of the fraction (>= 0: they order like the values)
+    uint8_t *strand;
+    unsigned long long *range;     // [contig][2]: the contig's entries are [first, end)
+};
+
+__global__ __launch_bounds__(256) void ingest_compact_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
+                                      const uint64_t *__restrict__ dense_off, double meth_thr, const unsigned long long *__restrict__ wave_first,
+                                      CandList out, unsigned int *wave_n, unsigned int *err) {
+    uint64_t row_begin, row_end;
+    wave_row_range(r.n, &row_begin, &row_end);
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wid = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned long long base = wave_first[wid];
+    uint32_t n = 0;                                                  // wave-uniform
+    constexpr int U = 4;
+    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64 * U) {
+        double f[U];
+        uint32_t c[U], p[U];
+        int m[U], nv[U];
+        uint8_t st[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * 64 + lane;
+            in[u] = i < row_end;
+            const uint64_t ii = in[u] ? i : row_begin;
+            f[u] = r.frac[ii];
+            c[u] = r.contig[ii];
+            p[u] = r.position[ii];
+            m[u] = r.mod[ii];
+            nv[u] = r.nvalid[ii];
+            st[u] = r.strand[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bool take = in[u] && f[u] >= meth_thr && c[u] != 0xFFFFFFFFu && m[u] >= 0 && nv[u] > min_cov && (st[u] == '+' || st[u] == '-');
+            take = take && ok[(size_t)c[u] * NM_CODE_STRIDE + m[u]];
+            if (take && dense_off[c[u]] == ~0ull) { atomicOr(err, 8u); take = false; }      // contig not listed for this part
+            const unsigned long long mask = __ballot(take);
+            if (take) {
+                const unsigned long long at = base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                out.key[at] = ((unsigned long long)c[u] << 32) | p[u];
+                out.fbits[at] = (unsigned long long)__double_as_longlong(f[u]);
+                out.strand[at] = st[u];
+            }
+            n += (uint32_t)__popcll(mask);
+        }
+    }
+    if (lane == 0) wave_n[wid] = n;
+}
+
+// where every contig's entries begin and end in the packed list (a contig without candidates keeps the cleared 0, 0)
+__global__ __launch_bounds__(256) void ingest_ranges_kernel(CandList list, const unsigned long long *__restrict__ list_n) {
+    const unsigned long long n = list_n[0];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t c = (uint32_t)(list.key[i] >> 32);
+        if (i == 0 || (uint32_t)(list.key[i - 1] >> 32) != c) list.range[2 * (size_t)c] = i;
+        if (i + 1 == n || (uint32_t)(list.key[i + 1] >> 32) != c) list.range[2 * (size_t)c + 1] = i + 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void ingest_pack_kernel(uint32_t n_waves, const unsigned long long *__restrict__ wave_first,
+                                   const unsigned int *__restrict__ wave_n, const unsigned long long *__restrict__ packed_first,
+                                   CandList src, CandList dst) {
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n_waves) return;
+    const unsigned long long a = wave_first[w], b = packed_first[w];
+    for (uint32_t i = lane; i < wave_n[w]; i += 64) {
+        dst.key[b + i] = src.key[a + i];
+        dst.fbits[b + i] = src.fbits[a + i];
+        dst.strand[b + i] = src.strand[a + i];
+    }
 }
 
 // (2) frequency filter verdict per (contig, mod code): n_mod / n > 1e-4 and n_mod > 50 (dataload.py:218-219)
@@ -254,7 +358,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
                                      double low, double high, IngestSlots sl, const unsigned int *__restrict__ order,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
-                                     unsigned long long *n_classified) {
+                                     unsigned long long *n_classified, CandList list, const unsigned long long *__restrict__ list_n) {
     constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = 64 + 4 * 64;
     __shared__ uint32_t tab[4][UP_PLANES * WIN];          // [slot * 2 + minus][word & 31]
     __shared__ uint32_t *u_plane[UP_PLANES];
@@ -300,10 +404,26 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const uint64_t i = on ? myq[lane] : row_begin;
         const RowCols x = load_row(r, i);
         const bool plus = x.st == '+';
-        const uint64_t doff = on ? dense_off[x.c] : 0ull;
-        const unsigned long long *d = (plus ? dense_plus : dense_minus) + doff + x.pos;
         unsigned long long mx = 0;                        // >= 64 zero positions around every contig
-        if (on) {
+        if (list.key) {
+            // ordered input: the rows that can beat this one are its neighbours in the compacted candidate list
+            if (on) {
+                const unsigned long long hi_c = (unsigned long long)x.c << 32, c_end = list.range[2 * (size_t)x.c + 1];
+                const unsigned long long kmin = hi_c | (x.pos > (uint32_t)adjacency ? x.pos - (uint32_t)adjacency : 0u);
+                const unsigned long long kmax = hi_c | (unsigned long long)min((unsigned long long)x.pos + (unsigned long long)adjacency, 0xFFFFFFFFull);
+                unsigned long long lo = list.range[2 * (size_t)x.c], hi = c_end;
+                while (lo < hi) {
+                    const unsigned long long mid = (lo + hi) >> 1;
+                    if (list.key[mid] < kmin) lo = mid + 1;
+                    else hi = mid;
+                }
+                for (unsigned long long sx = lo; sx < c_end && list.key[sx] <= kmax; ++sx)
+                    if (list.strand[sx] == x.st) mx = max(mx, list.fbits[sx]);
+                (void)list_n;
+            }
+        } else if (on) {
+            const uint64_t doff = dense_off[x.c];
+            const unsigned long long *d = (plus ? dense_plus : dense_minus) + doff + x.pos;
             if (adjacency == 8) {
                 unsigned long long v[17];                 // all 17 loads are issued before the first is waited for
 #pragma unroll
@@ -581,33 +701,75 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     ING_ALLOC(d_cnt, std::max<size_t>(n_fgroups, 1) * 2 * 4);
     ING_ALLOC(d_kept, std::max<size_t>(n_groups, 1) * 4);
     ING_ALLOC(d_ok, std::max<size_t>(n_fgroups, 1));
-    ING_ALLOC(d_dense, npos * 8 * 2);
     ING_ALLOC(d_dense_off, (size_t)std::max(c->n_contigs, 1u) * 8);
     unsigned int *d_order = nullptr;   // [0]: order flags of the rows (1: a position decreases inside a run, 2: a contig in several runs); [1..]: runs per contig
     ING_ALLOC(d_order, ((size_t)c->n_contigs + 1) * 4);
     ING_ALLOC(d_scalars, 32);          // n_kept, n_classified (this part), population of the methylated / unmethylated general planes (all parts)
-#undef ING_ALLOC
+    const dim3 blk(256);
+    const dim3 walk((unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_rows + 255) / 256, 256 * 32)));      // waves walk contiguous row ranges
+    const uint32_t n_waves = walk.x * 4;
+    unsigned int *d_wave_cand = nullptr, *d_wave_n = nullptr;
+    unsigned long long *d_wave_first = nullptr, *d_packed_first = nullptr;
+    ING_ALLOC(d_wave_cand, (size_t)n_waves * 4);
+    ING_ALLOC(d_wave_n, (size_t)n_waves * 4);
+    ING_ALLOC(d_wave_first, ((size_t)n_waves + 1) * 8);
+    ING_ALLOC(d_packed_first, ((size_t)n_waves + 1) * 8);
     hipError_t e = hipSuccess;
     nmdetail::busy_begin(c);
     e = hipMemsetAsync(d_cnt, 0, n_fgroups * 2 * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_scalars, 0, 32, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_order, 0, ((size_t)c->n_contigs + 1) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_wave_first, 0, ((size_t)n_waves + 1) * 8, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_err, 0, sizeof(unsigned int), c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dense_off, dense_off.data(), (size_t)c->n_contigs * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { cleanup(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
-    const dim3 blk(256);
     if (n_rows && n_groups) {              // (a shard without contigs ignores every row)
-        const dim3 grid((unsigned)((n_rows + 255) / 256));
-        const dim3 walk((unsigned)std::min<uint64_t>((n_rows + 255) / 256, 256 * 32));      // waves walk contiguous row ranges
-        hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err, d_order, d_order + 1);
+        hipLaunchKernelGGL(ingest_count_kernel, walk, blk, 0, c->stream, r, c->n_contigs, c->d_contig_len, 5, 0.7, d_cnt, c->d_err, d_order, d_order + 1,
+                           d_wave_cand);
         hipLaunchKernelGGL(ingest_group_kernel, dim3((unsigned)((n_fgroups + 255) / 256)), blk, 0, c->stream, (uint32_t)n_fgroups, d_cnt, 0.0001, 50u, d_ok, d_order + 1, d_order);
-        hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
-        if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
-        hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
-                           c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
+        // Rows in modkit's order (verified by the counting pass) and thresholds the way the reference has them: the adjacency
+        // test runs on the compacted list of candidates.  Otherwise (or NM_INGEST_DENSE=1): one maximum per position and strand.
+        bool use_list = low < 0.7 && getenv("NM_INGEST_DENSE") == nullptr && getenv("NM_INGEST_ATOMIC") == nullptr;
+        unsigned long long cap = 0;
+        if (use_list) {
+            hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_wave_cand, n_waves, d_wave_first);
+            unsigned int order_flags = 0;
+            e = hipMemcpyAsync(&order_flags, d_order, 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&cap, d_wave_first + n_waves, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
+            use_list = order_flags == 0;
+        }
+        CandList lists[2] = {};
+        if (use_list) {
+            for (int k = 0; k < 2; ++k) {
+                ING_ALLOC(lists[k].key, (size_t)(cap + 2) * 8);
+                ING_ALLOC(lists[k].fbits, (size_t)(cap + 2) * 8);
+                ING_ALLOC(lists[k].strand, (size_t)(cap + 16));
+            }
+            hipLaunchKernelGGL(ingest_compact_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, 0.7, d_wave_first, lists[0], d_wave_n, c->d_err);
+            hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_wave_n, n_waves, d_packed_first);
+            hipLaunchKernelGGL(ingest_pack_kernel, dim3((n_waves + 3) / 4), blk, 0, c->stream, n_waves, d_wave_first, d_wave_n, d_packed_first, lists[0], lists[1]);
+            ING_ALLOC(lists[1].range, (size_t)std::max(c->n_contigs, 1u) * 16);
+            e = hipMemsetAsync(lists[1].range, 0, (size_t)std::max(c->n_contigs, 1u) * 16, c->stream);
+            if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(ingest_ranges_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
+                               c->stream, lists[1], d_packed_first + n_waves);
+            hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
+                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1, lists[1], d_packed_first + n_waves);
+        } else {
+            ING_ALLOC(d_dense, npos * 8 * 2);
+            e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
+            if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
+            if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
+            hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
+                               c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1,
+                               CandList{}, nullptr);
+        }
     }
+#undef ING_ALLOC
     // population of the general planes (all parts so far): the confident rows, and the duplicate check — every
     // classified row must have set its own bit; then the compact planes
     bool seen[NM_MAX_MOD_SLOTS] = {};
