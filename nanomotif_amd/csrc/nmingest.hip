@@ -358,11 +358,12 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
                                      double low, double high, IngestSlots sl, const unsigned int *__restrict__ order,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
-                                     unsigned long long *n_classified, CandList list, const unsigned long long *__restrict__ list_n) {
+                                     unsigned long long *n_classified, CandList list, const unsigned long long *__restrict__ list_first /*[waves]*/) {
     constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = 64 + 4 * 64;
     __shared__ uint32_t tab[4][UP_PLANES * WIN];          // [slot * 2 + minus][word & 31]
     __shared__ uint32_t *u_plane[UP_PLANES];
     __shared__ unsigned long long queue[4][QCAP];
+    __shared__ unsigned long long queue_slot[4][QCAP];      // list branch: where a queued row sits in the candidate list
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t e = threadIdx.x; e < 4 * UP_PLANES * WIN; e += blockDim.x) (&tab[0][0])[e] = 0;
     if (threadIdx.x < UP_PLANES) u_plane[threadIdx.x] = sl.planes[threadIdx.x >> 1][(threadIdx.x & 1) ? 5 : 3];   // UP / UM
@@ -375,6 +376,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
     KeyCache kc;
     uint32_t *const mytab = tab[wave];
     unsigned long long *const myq = queue[wave];
+    unsigned long long *const myslot = queue_slot[wave];
+    // this wave walks the row range the compaction pass walked: its k-th list row is entry list_first[wave] + k
+    unsigned long long next_slot = list.key ? list_first[(size_t)blockIdx.x * (blockDim.x >> 6) + wave] : 0ull;   // wave-uniform
     uint32_t qn = 0;                                      // wave-uniform
     uint64_t w_base = 0, first_word = ~0ull;              // wave-uniform
     uint32_t cur_contig = 0xFFFFFFFFu;
@@ -406,20 +410,19 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const bool plus = x.st == '+';
         unsigned long long mx = 0;                        // >= 64 zero positions around every contig
         if (list.key) {
-            // ordered input: the rows that can beat this one are its neighbours in the compacted candidate list
-            if (on) {
-                const unsigned long long hi_c = (unsigned long long)x.c << 32, c_end = list.range[2 * (size_t)x.c + 1];
+            // ordered input: the rows that can beat this one are its neighbours in the compacted candidate list — it knows
+            // its own entry (queued with the row), the window is the few entries on either side within `adjacency` positions
+            const unsigned long long sl0 = on ? myslot[lane] : ~0ull;
+            if (on && sl0 != ~0ull) {
+                const unsigned long long hi_c = (unsigned long long)x.c << 32;
+                const unsigned long long c_first = list.range[2 * (size_t)x.c], c_end = list.range[2 * (size_t)x.c + 1];
                 const unsigned long long kmin = hi_c | (x.pos > (uint32_t)adjacency ? x.pos - (uint32_t)adjacency : 0u);
                 const unsigned long long kmax = hi_c | (unsigned long long)min((unsigned long long)x.pos + (unsigned long long)adjacency, 0xFFFFFFFFull);
-                unsigned long long lo = list.range[2 * (size_t)x.c], hi = c_end;
-                while (lo < hi) {
-                    const unsigned long long mid = (lo + hi) >> 1;
-                    if (list.key[mid] < kmin) lo = mid + 1;
-                    else hi = mid;
-                }
-                for (unsigned long long sx = lo; sx < c_end && list.key[sx] <= kmax; ++sx)
+                mx = list.fbits[sl0];
+                for (unsigned long long sx = sl0; sx > c_first && list.key[sx - 1] >= kmin; --sx)
+                    if (list.strand[sx - 1] == x.st) mx = max(mx, list.fbits[sx - 1]);
+                for (unsigned long long sx = sl0 + 1; sx < c_end && list.key[sx] <= kmax; ++sx)
                     if (list.strand[sx] == x.st) mx = max(mx, list.fbits[sx]);
-                (void)list_n;
             }
         } else if (on) {
             const uint64_t doff = dense_off[x.c];
@@ -485,7 +488,16 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const bool cand = alive && !(x.f < meth_thr);
         const unsigned long long cmask = __ballot(cand);
         if (cmask) {                                             // (judged after the four pieces: at most 63 + 256 are waiting)
-            if (cand) myq[qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull))] = i;
+            // (the compaction pass took exactly the rows with fraction >= threshold: a NaN fraction is queued, has no entry
+            //  and fails the test like it does against the dense maxima)
+            const bool listed_row = cand && x.f >= meth_thr;
+            const unsigned long long lmask = __ballot(listed_row);
+            if (cand) {
+                const uint32_t qa = qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull));
+                myq[qa] = i;
+                myslot[qa] = listed_row ? next_slot + (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull)) : ~0ull;
+            }
+            next_slot += (uint32_t)__popcll(lmask);
             qn += (uint32_t)__popcll(cmask);
         }
         const bool pass = alive && !cand;
@@ -534,9 +546,10 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         __asm__ volatile("" ::: "memory");
         judge(64);
         for (uint32_t k = lane; k + 64 < qn; k += 64) {          // the rest moves down (reads of a turn before its writes)
-            const unsigned long long moved = myq[k + 64];
+            const unsigned long long moved = myq[k + 64], moved_slot = myslot[k + 64];
             __asm__ volatile("" ::: "memory");
             myq[k] = moved;
+            myslot[k] = moved_slot;
         }
         qn -= 64;
       }
@@ -545,9 +558,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const uint32_t n = min(qn, 64u);
         __asm__ volatile("" ::: "memory");
         judge(n);
-        const unsigned long long moved = lane + 64 < qn ? myq[lane + 64] : 0ull;
+        const unsigned long long moved = lane + 64 < qn ? myq[lane + 64] : 0ull, moved_slot = lane + 64 < qn ? myslot[lane + 64] : 0ull;
         __asm__ volatile("" ::: "memory");
-        if (lane + 64 < qn) myq[lane] = moved;
+        if (lane + 64 < qn) { myq[lane] = moved; myslot[lane] = moved_slot; }
         qn -= n;
     }
     flush_range(w_base, w_base + WIN, true);                     // what is left may share its words with the next wave
@@ -757,7 +770,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             hipLaunchKernelGGL(ingest_ranges_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
                                c->stream, lists[1], d_packed_first + n_waves);
             hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
-                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1, lists[1], d_packed_first + n_waves);
+                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1, lists[1], d_packed_first);
         } else {
             ING_ALLOC(d_dense, npos * 8 * 2);
             e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
