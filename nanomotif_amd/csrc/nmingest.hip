@@ -184,6 +184,7 @@ struct CandList {
     unsigned long long *key;       // contig << 32 | position: ascending inside a contig's run (the runs come in file order)
     unsigned long long *fbits;     // IEEE bits of the fraction (>= 0: they order like the values)
     uint8_t *strand;
+    int8_t *mod;
     unsigned long long *range;     // [contig][2]: the contig's entries are [first, end)
 };
 
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256) void ingest_compact_kernel(RawRows r, int min_
                 out.key[at] = ((unsigned long long)c[u] << 32) | p[u];
                 out.fbits[at] = (unsigned long long)__double_as_longlong(f[u]);
                 out.strand[at] = st[u];
+                out.mod[at] = (int8_t)m[u];
             }
             n += (uint32_t)__popcll(mask);
         }
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void ingest_pack_kernel(uint32_t n_waves, cons
         dst.key[b + i] = src.key[a + i];
         dst.fbits[b + i] = src.fbits[a + i];
         dst.strand[b + i] = src.strand[a + i];
+        dst.mod[b + i] = src.mod[a + i];
     }
 }
 
@@ -352,18 +355,18 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
 //    counting pass) a word is COMPLETE once the wave has moved past it, and leaves as a plain store, whole runs of
 //    consecutive words per plane at a time; only the first word a wave touches and what it holds at its end can be shared
 //    with a neighbouring wave and go out as atomicOr.  Unordered input: the window is flushed with atomicOr every iteration.
+template <bool LIST>      // LIST: the candidate rows are ingest_judge_kernel's — skipped here, no queue
 __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                      const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ dense_off,
                                      const unsigned long long *__restrict__ dense_plus,
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
                                      double low, double high, IngestSlots sl, const unsigned int *__restrict__ order,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
-                                     unsigned long long *n_classified, CandList list, const unsigned long long *__restrict__ list_first /*[waves]*/) {
-    constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = 64 + 4 * 64;
+                                     unsigned long long *n_classified) {
+    constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = LIST ? 1 : 64 + 4 * 64;
     __shared__ uint32_t tab[4][UP_PLANES * WIN];          // [slot * 2 + minus][word & 31]
     __shared__ uint32_t *u_plane[UP_PLANES];
     __shared__ unsigned long long queue[4][QCAP];
-    __shared__ unsigned long long queue_slot[4][QCAP];      // list branch: where a queued row sits in the candidate list
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t e = threadIdx.x; e < 4 * UP_PLANES * WIN; e += blockDim.x) (&tab[0][0])[e] = 0;
     if (threadIdx.x < UP_PLANES) u_plane[threadIdx.x] = sl.planes[threadIdx.x >> 1][(threadIdx.x & 1) ? 5 : 3];   // UP / UM
@@ -376,9 +379,6 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
     KeyCache kc;
     uint32_t *const mytab = tab[wave];
     unsigned long long *const myq = queue[wave];
-    unsigned long long *const myslot = queue_slot[wave];
-    // this wave walks the row range the compaction pass walked: its k-th list row is entry list_first[wave] + k
-    unsigned long long next_slot = list.key ? list_first[(size_t)blockIdx.x * (blockDim.x >> 6) + wave] : 0ull;   // wave-uniform
     uint32_t qn = 0;                                      // wave-uniform
     uint64_t w_base = 0, first_word = ~0ull;              // wave-uniform
     uint32_t cur_contig = 0xFFFFFFFFu;
@@ -409,22 +409,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const RowCols x = load_row(r, i);
         const bool plus = x.st == '+';
         unsigned long long mx = 0;                        // >= 64 zero positions around every contig
-        if (list.key) {
-            // ordered input: the rows that can beat this one are its neighbours in the compacted candidate list — it knows
-            // its own entry (queued with the row), the window is the few entries on either side within `adjacency` positions
-            const unsigned long long sl0 = on ? myslot[lane] : ~0ull;
-            if (on && sl0 != ~0ull) {
-                const unsigned long long hi_c = (unsigned long long)x.c << 32;
-                const unsigned long long c_first = list.range[2 * (size_t)x.c], c_end = list.range[2 * (size_t)x.c + 1];
-                const unsigned long long kmin = hi_c | (x.pos > (uint32_t)adjacency ? x.pos - (uint32_t)adjacency : 0u);
-                const unsigned long long kmax = hi_c | (unsigned long long)min((unsigned long long)x.pos + (unsigned long long)adjacency, 0xFFFFFFFFull);
-                mx = list.fbits[sl0];
-                for (unsigned long long sx = sl0; sx > c_first && list.key[sx - 1] >= kmin; --sx)
-                    if (list.strand[sx - 1] == x.st) mx = max(mx, list.fbits[sx - 1]);
-                for (unsigned long long sx = sl0 + 1; sx < c_end && list.key[sx] <= kmax; ++sx)
-                    if (list.strand[sx] == x.st) mx = max(mx, list.fbits[sx]);
-            }
-        } else if (on) {
+        if (on) {
             const uint64_t doff = dense_off[x.c];
             const unsigned long long *d = (plus ? dense_plus : dense_minus) + doff + x.pos;
             if (adjacency == 8) {
@@ -487,17 +472,8 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         // candidates for the adjacency test are queued; everybody else survives the filter
         const bool cand = alive && !(x.f < meth_thr);
         const unsigned long long cmask = __ballot(cand);
-        if (cmask) {                                             // (judged after the four pieces: at most 63 + 256 are waiting)
-            // (the compaction pass took exactly the rows with fraction >= threshold: a NaN fraction is queued, has no entry
-            //  and fails the test like it does against the dense maxima)
-            const bool listed_row = cand && x.f >= meth_thr;
-            const unsigned long long lmask = __ballot(listed_row);
-            if (cand) {
-                const uint32_t qa = qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull));
-                myq[qa] = i;
-                myslot[qa] = listed_row ? next_slot + (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull)) : ~0ull;
-            }
-            next_slot += (uint32_t)__popcll(lmask);
+        if (!LIST && cmask) {                                    // (judged after the four pieces: at most 63 + 256 are waiting)
+            if (cand) myq[qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull))] = i;
             qn += (uint32_t)__popcll(cmask);
         }
         const bool pass = alive && !cand;
@@ -546,10 +522,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         __asm__ volatile("" ::: "memory");
         judge(64);
         for (uint32_t k = lane; k + 64 < qn; k += 64) {          // the rest moves down (reads of a turn before its writes)
-            const unsigned long long moved = myq[k + 64], moved_slot = myslot[k + 64];
+            const unsigned long long moved = myq[k + 64];
             __asm__ volatile("" ::: "memory");
             myq[k] = moved;
-            myslot[k] = moved_slot;
         }
         qn -= 64;
       }
@@ -558,9 +533,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         const uint32_t n = min(qn, 64u);
         __asm__ volatile("" ::: "memory");
         judge(n);
-        const unsigned long long moved = lane + 64 < qn ? myq[lane + 64] : 0ull, moved_slot = lane + 64 < qn ? myslot[lane + 64] : 0ull;
+        const unsigned long long moved = lane + 64 < qn ? myq[lane + 64] : 0ull;
         __asm__ volatile("" ::: "memory");
-        if (lane + 64 < qn) { myq[lane] = moved; myslot[lane] = moved_slot; }
+        if (lane + 64 < qn) myq[lane] = moved;
         qn -= n;
     }
     flush_range(w_base, w_base + WIN, true);                     // what is left may share its words with the next wave
@@ -570,6 +545,67 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         my_cls += __shfl_xor(my_cls, d);
     }
     if ((threadIdx.x & 63) == 0) {
+        if (my_kept) atomicAdd(n_kept, my_kept);
+        if (my_cls) atomicAdd(n_classified, my_cls);
+    }
+}
+
+// (3b') the candidate rows of an ordered pileup, judged where they sit in the list: an entry survives iff no entry of its
+// strand within `adjacency` positions has a larger fraction (its neighbours are the entries next to it), and a survivor is
+// what ingest_decide_kernel makes of a passing row — counted as kept, its bit set in the methylated plane when its fraction
+// reaches `high` (it cannot be unmethylated: the list path needs low < the adjacency threshold).  The classification pass
+// then skips these rows altogether: no queue, no scattered loads there.
+__global__ __launch_bounds__(256) void ingest_judge_kernel(CandList list, const unsigned long long *__restrict__ list_n, int adjacency, double high,
+                                    const uint32_t *__restrict__ contig_chunk, IngestSlots sl, unsigned int *kept /*[contig][mod]*/,
+                                    unsigned long long *n_kept, unsigned long long *n_classified) {
+    uint64_t e_begin, e_end;
+    wave_row_range(list_n[0], &e_begin, &e_end);
+    const uint32_t lane = threadIdx.x & 63;
+    unsigned long long my_kept = 0, my_cls = 0;
+    KeyCache kc;
+    for (uint64_t e0 = e_begin; e0 < e_end; e0 += 64) {
+        const uint64_t e = e0 + lane;
+        const bool on = e < e_end;
+        bool alive = false;
+        uint32_t c = 0, pos = 0;
+        int m = 0;
+        uint8_t st = 0;
+        unsigned long long fb = 0;
+        if (on) {
+            const unsigned long long key = list.key[e];
+            c = (uint32_t)(key >> 32);
+            pos = (uint32_t)key;
+            st = list.strand[e];
+            m = list.mod[e];
+            fb = list.fbits[e];
+            const unsigned long long hi_c = key & 0xFFFFFFFF00000000ull;
+            const unsigned long long c_first = list.range[2 * (size_t)c], c_end = list.range[2 * (size_t)c + 1];
+            const unsigned long long kmin = hi_c | (pos > (uint32_t)adjacency ? pos - (uint32_t)adjacency : 0u);
+            const unsigned long long kmax = hi_c | (unsigned long long)min((unsigned long long)pos + (unsigned long long)adjacency, 0xFFFFFFFFull);
+            unsigned long long mx = fb;
+            for (unsigned long long sx = e; sx > c_first && list.key[sx - 1] >= kmin; --sx)
+                if (list.strand[sx - 1] == st) mx = max(mx, list.fbits[sx - 1]);
+            for (unsigned long long sx = e + 1; sx < c_end && list.key[sx] <= kmax; ++sx)
+                if (list.strand[sx] == st) mx = max(mx, list.fbits[sx]);
+            alive = mx == fb;
+        }
+        const bool listed = alive && m < NM_MAX_MOD_CODES;
+        wave_add_keyed(kc, kept, listed ? c * NM_MAX_MOD_CODES + (uint32_t)m : 0u, listed, false, 1);
+        my_kept += alive;
+        const int slot = listed ? sl.slot_of_mod[m] : -1;
+        const bool meth = slot >= 0 && __longlong_as_double((long long)fb) >= high;
+        my_cls += meth;
+        if (meth) {
+            const uint64_t g = (uint64_t)contig_chunk[c] * CHUNK_BP + pos;
+            atomicOr(sl.planes[slot][st == '+' ? 2 : 4] + (g >> 5), 1u << (g & 31));
+        }
+    }
+    cache_flush(kc, kept, 1, lane);
+    for (int d = 32; d; d >>= 1) {
+        my_kept += __shfl_xor(my_kept, d);
+        my_cls += __shfl_xor(my_cls, d);
+    }
+    if (lane == 0) {
         if (my_kept) atomicAdd(n_kept, my_kept);
         if (my_cls) atomicAdd(n_classified, my_cls);
     }
@@ -760,6 +796,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
                 ING_ALLOC(lists[k].key, (size_t)(cap + 2) * 8);
                 ING_ALLOC(lists[k].fbits, (size_t)(cap + 2) * 8);
                 ING_ALLOC(lists[k].strand, (size_t)(cap + 16));
+                ING_ALLOC(lists[k].mod, (size_t)(cap + 16));
             }
             hipLaunchKernelGGL(ingest_compact_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, 0.7, d_wave_first, lists[0], d_wave_n, c->d_err);
             hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_wave_n, n_waves, d_packed_first);
@@ -769,17 +806,18 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
             hipLaunchKernelGGL(ingest_ranges_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
                                c->stream, lists[1], d_packed_first + n_waves);
-            hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
-                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1, lists[1], d_packed_first);
+            hipLaunchKernelGGL(ingest_judge_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
+                               c->stream, lists[1], d_packed_first + n_waves, 8, high, c->d_contig_chunk, sl, d_kept, d_scalars, d_scalars + 1);
+            hipLaunchKernelGGL(ingest_decide_kernel<true>, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
+                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
         } else {
             ING_ALLOC(d_dense, npos * 8 * 2);
             e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
             if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
             hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
             if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
-            hipLaunchKernelGGL(ingest_decide_kernel, walk, blk, 0, c->stream, r, 5, d_ok,
-                               c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1,
-                               CandList{}, nullptr);
+            hipLaunchKernelGGL(ingest_decide_kernel<false>, walk, blk, 0, c->stream, r, 5, d_ok,
+                               c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
         }
     }
 #undef ING_ALLOC
