@@ -178,8 +178,8 @@ __global__ __launch_bounds__(1024) void ingest_scan_kernel(const unsigned int *_
 // would scatter) are COMPACTED IN ROW ORDER instead — contig, position, strand, fraction of ~1.5 % of a pileup — and a
 // tested row looks its window up in that list (binary search + the few entries within 8 positions).  No table of one
 // maximum per position and strand: at 1 Gbp that table is 16 GB, 98.5 % of it the zeros it was cleared to.
-// Every wave compacts the candidates of its row range into the block the counting pass sized for it (an upper bound: the
-// frequency verdicts were not known then); ingest_pack_kernel closes the gaps.
+// The classification pass (ingest_decide_kernel<true>) compacts the candidates of every wave's row range into the block the
+// counting pass sized for it (an upper bound: the frequency verdicts were not known then); ingest_pack_kernel closes the gaps.
 struct CandList {
     unsigned long long *key;       // contig << 32 | position: ascending inside a contig's run (the runs come in file order)
     unsigned long long *fbits;     // IEEE bits of the fraction (>= 0: they order like the values)
@@ -187,53 +187,6 @@ struct CandList {
     int8_t *mod;
     unsigned long long *range;     // [contig][2]: the contig's entries are [first, end)
 };
-
-__global__ __launch_bounds__(256) void ingest_compact_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
-                                      const uint64_t *__restrict__ dense_off, double meth_thr, const unsigned long long *__restrict__ wave_first,
-                                      CandList out, unsigned int *wave_n, unsigned int *err) {
-    uint64_t row_begin, row_end;
-    wave_row_range(r.n, &row_begin, &row_end);
-    const uint32_t lane = threadIdx.x & 63;
-    const size_t wid = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const unsigned long long base = wave_first[wid];
-    uint32_t n = 0;                                                  // wave-uniform
-    constexpr int U = 4;
-    for (uint64_t i0 = row_begin; i0 < row_end; i0 += 64 * U) {
-        double f[U];
-        uint32_t c[U], p[U];
-        int m[U], nv[U];
-        uint8_t st[U];
-        bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t i = i0 + (uint64_t)u * 64 + lane;
-            in[u] = i < row_end;
-            const uint64_t ii = in[u] ? i : row_begin;
-            f[u] = r.frac[ii];
-            c[u] = r.contig[ii];
-            p[u] = r.position[ii];
-            m[u] = r.mod[ii];
-            nv[u] = r.nvalid[ii];
-            st[u] = r.strand[ii];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            bool take = in[u] && f[u] >= meth_thr && c[u] != 0xFFFFFFFFu && m[u] >= 0 && nv[u] > min_cov && (st[u] == '+' || st[u] == '-');
-            take = take && ok[(size_t)c[u] * NM_CODE_STRIDE + m[u]];
-            if (take && dense_off[c[u]] == ~0ull) { atomicOr(err, 8u); take = false; }      // contig not listed for this part
-            const unsigned long long mask = __ballot(take);
-            if (take) {
-                const unsigned long long at = base + n + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                out.key[at] = ((unsigned long long)c[u] << 32) | p[u];
-                out.fbits[at] = (unsigned long long)__double_as_longlong(f[u]);
-                out.strand[at] = st[u];
-                out.mod[at] = (int8_t)m[u];
-            }
-            n += (uint32_t)__popcll(mask);
-        }
-    }
-    if (lane == 0) wave_n[wid] = n;
-}
 
 // where every contig's entries begin and end in the packed list (a contig without candidates keeps the cleared 0, 0)
 __global__ __launch_bounds__(256) void ingest_ranges_kernel(CandList list, const unsigned long long *__restrict__ list_n) {
@@ -362,7 +315,10 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
                                      const unsigned long long *__restrict__ dense_minus, int adjacency, double meth_thr,
                                      double low, double high, IngestSlots sl, const unsigned int *__restrict__ order,
                                      unsigned int *kept /*[contig][mod]*/, unsigned long long *n_kept,
-                                     unsigned long long *n_classified) {
+                                     unsigned long long *n_classified, const unsigned long long *__restrict__ wave_first, CandList out,
+                                     unsigned int *wave_n, unsigned int *err) {
+    // LIST: this pass also COMPACTS the candidate rows, in row order, into the block the counting pass sized for the wave
+    // (an upper bound: the frequency verdicts were not known then; ingest_pack_kernel closes the gaps)
     constexpr uint32_t WIN = 32, UP_PLANES = NM_MAX_MOD_SLOTS * 2, QCAP = LIST ? 1 : 64 + 4 * 64;
     __shared__ uint32_t tab[4][UP_PLANES * WIN];          // [slot * 2 + minus][word & 31]
     __shared__ uint32_t *u_plane[UP_PLANES];
@@ -379,6 +335,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
     KeyCache kc;
     uint32_t *const mytab = tab[wave];
     unsigned long long *const myq = queue[wave];
+    const size_t wid = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const unsigned long long list_base = LIST ? wave_first[wid] : 0ull;
+    uint32_t list_n = 0;                                  // wave-uniform
     uint32_t qn = 0;                                      // wave-uniform
     uint64_t w_base = 0, first_word = ~0ull;              // wave-uniform
     uint32_t cur_contig = 0xFFFFFFFFu;
@@ -476,6 +435,19 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
             if (cand) myq[qn + (uint32_t)__popcll(cmask & ((1ull << lane) - 1ull))] = i;
             qn += (uint32_t)__popcll(cmask);
         }
+        if (LIST) {
+            if (pre[u] && okv[u] && doffv[u] == ~0ull && x.f >= meth_thr) atomicOr(err, 8u);     // contig not listed for this part
+            const bool take = cand && x.f >= meth_thr;           // (a NaN fraction is a candidate without an entry: it fails like against the table)
+            const unsigned long long tmask = __ballot(take);
+            if (take) {
+                const unsigned long long at = list_base + list_n + (uint32_t)__popcll(tmask & ((1ull << lane) - 1ull));
+                out.key[at] = ((unsigned long long)x.c << 32) | x.pos;
+                out.fbits[at] = (unsigned long long)__double_as_longlong(x.f);
+                out.strand[at] = x.st;
+                out.mod[at] = (int8_t)x.m;
+            }
+            list_n += (uint32_t)__popcll(tmask);
+        }
         const bool pass = alive && !cand;
         const int m = pass ? x.m : 0;
         const bool listed = pass && m < NM_MAX_MOD_CODES;        // codes beyond the ABI's eight are filtered with the rest, never reported
@@ -539,6 +511,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         qn -= n;
     }
     flush_range(w_base, w_base + WIN, true);                     // what is left may share its words with the next wave
+    if (LIST && lane == 0) wave_n[wid] = list_n;
     cache_flush(kc, kept, 1, lane);
     for (int d = 32; d; d >>= 1) {
         my_kept += __shfl_xor(my_kept, d);
@@ -798,18 +771,19 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
                 ING_ALLOC(lists[k].strand, (size_t)(cap + 16));
                 ING_ALLOC(lists[k].mod, (size_t)(cap + 16));
             }
-            hipLaunchKernelGGL(ingest_compact_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, 0.7, d_wave_first, lists[0], d_wave_n, c->d_err);
+            // one pass over the rows classifies everything below the adjacency threshold and compacts the rest; the list is
+            // then packed, indexed per contig and judged
+            hipLaunchKernelGGL(ingest_decide_kernel<true>, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
+                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1, d_wave_first, lists[0], d_wave_n, c->d_err);
             hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_wave_n, n_waves, d_packed_first);
             hipLaunchKernelGGL(ingest_pack_kernel, dim3((n_waves + 3) / 4), blk, 0, c->stream, n_waves, d_wave_first, d_wave_n, d_packed_first, lists[0], lists[1]);
             ING_ALLOC(lists[1].range, (size_t)std::max(c->n_contigs, 1u) * 16);
             e = hipMemsetAsync(lists[1].range, 0, (size_t)std::max(c->n_contigs, 1u) * 16, c->stream);
             if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
-            hipLaunchKernelGGL(ingest_ranges_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
-                               c->stream, lists[1], d_packed_first + n_waves);
-            hipLaunchKernelGGL(ingest_judge_kernel, dim3((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192))), blk, 0,
-                               c->stream, lists[1], d_packed_first + n_waves, 8, high, c->d_contig_chunk, sl, d_kept, d_scalars, d_scalars + 1);
-            hipLaunchKernelGGL(ingest_decide_kernel<true>, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
-                               high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
+            const dim3 over_list((unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>((cap + 255) / 256, 8192)));
+            hipLaunchKernelGGL(ingest_ranges_kernel, over_list, blk, 0, c->stream, lists[1], d_packed_first + n_waves);
+            hipLaunchKernelGGL(ingest_judge_kernel, over_list, blk, 0, c->stream, lists[1], d_packed_first + n_waves, 8, high, c->d_contig_chunk, sl, d_kept,
+                               d_scalars, d_scalars + 1);
         } else {
             ING_ALLOC(d_dense, npos * 8 * 2);
             e = hipMemsetAsync(d_dense, 0, npos * 8 * 2, c->stream);
@@ -817,7 +791,8 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
             if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
             hipLaunchKernelGGL(ingest_decide_kernel<false>, walk, blk, 0, c->stream, r, 5, d_ok,
-                               c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1);
+                               c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1,
+                               nullptr, CandList{}, nullptr, c->d_err);
         }
     }
 #undef ING_ALLOC
