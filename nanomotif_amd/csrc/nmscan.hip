@@ -1440,8 +1440,9 @@ int nm_score_batch_begin(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, c
                          const uint8_t *cand_masks) {
     if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks))
         return fail(NM_EINVAL, "NULL argument");
+    if (c && c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
     const int rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, nullptr, nullptr, true);
-    if (rc && c) c->score_wait.open = false;
+    if (rc && c) c->score_wait.open = false;         // (a batch that failed half way is not open)
     return rc;
 }
 
