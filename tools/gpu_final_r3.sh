@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|ERROR" | tail -6
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 1500 python bench.py > gpurun_out/bench_default_r3.json 2> gpurun_out/bench_default_r3.err; echo "bench rc $?"
 python - <<'PY'
