@@ -208,12 +208,13 @@ def test_background_counts_from_runs_equal_counts_from_samples():
     eng.close()
 
 
-@pytest.mark.parametrize("freq", [0.01, 0.05])
-def test_device_draws_equal_host_draws(freq, monkeypatch):
+@pytest.mark.parametrize("freq,per_bin", [(0.01, False), (0.05, False), (0.01, True)])
+def test_device_draws_equal_host_draws(freq, per_bin, monkeypatch):
     """nm_plan_windows consumes the generator streams of all tasks on the device (bg_draw_kernel: one wave per stream over
     ONE sequence of MT19937 outputs) when they start from the same state: background PSSMs, window counts and the state
     the interpreter's generator is left in must equal the host-thread replay (NM_HOST_DRAWS=1) exactly.  freq 0.01: the
-    set branch of random.sample; freq 0.05: samples so large that n <= setsize for most contigs, the pool branch."""
+    set branch of random.sample; freq 0.05: samples so large that n <= setsize for most contigs, the pool branch;
+    per_bin: the bgzip task order, where the tasks of a bin share one stream."""
     import random
     from nanomotif_amd import synth
     from nanomotif_amd.e2e_synth import load_and_filter
@@ -221,7 +222,7 @@ def test_device_draws_equal_host_draws(freq, monkeypatch):
     from nanomotif_amd.main import device_window_pipeline
     from nanomotif_amd.pileup import MOD_TYPES
     import torch
-    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=300, total_bp=6_000_000, n_bins=24, mod_types=("a", "m"), seed=5))
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=400, total_bp=8_000_000, n_bins=40, mod_types=("a", "m"), seed=5))
     results = []
     for host in (True, False):
         if host:
@@ -244,7 +245,7 @@ def test_device_draws_equal_host_draws(freq, monkeypatch):
                     tasks.append(((b, mt), names, mt))
         assert len(tasks) >= 32
         random.seed(99)
-        pssms = extractor.plan_all(tasks, seed=1)
+        pssms = extractor.plan_all(tasks, seed=1, one_stream_per_bin=per_bin)
         results.append((pssms, random.getstate(), dict(store.totals)))
         eng.close()
     (p_host, s_host, t_host), (p_dev, s_dev, t_dev) = results
