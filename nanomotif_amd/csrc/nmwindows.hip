@@ -573,9 +573,17 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
     memcpy(hs + o_sets, req_sets, (size_t)n_req * ws);
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
-    const uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));   // >= 1: tasks of an empty shard have no windows
+    // slices of a task's words per request (blockIdx.z): one workgroup per 256 words when the batch is small, fewer and
+    // fatter ones when a thousand requests already fill the device several times over (a workgroup's fixed cost — the match
+    // mask set-up, the reduction of its 34 counters, its atomics — is most of what it does)
+    const uint32_t n_col_groups = (max_w + WIN_COL_GROUP - 1) / WIN_COL_GROUP;
+    uint32_t gz = std::max<uint32_t>(1, std::min<uint32_t>(64, (max_nw + 255) / 256));         // >= 1: tasks of an empty shard have no windows
+    if (getenv("NM_WIN_THIN") == nullptr) {
+        const uint64_t want = std::max<uint64_t>(1, (uint64_t)c->n_cus * 8 / std::max<uint64_t>(1, (uint64_t)n_req * n_col_groups));
+        gz = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gz, want));
+    }
     nmdetail::busy_begin(c);
-    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, (max_w + WIN_COL_GROUP - 1) / WIN_COL_GROUP, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
+    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, n_col_groups, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), ws);
     nmdetail::busy_end(c);
