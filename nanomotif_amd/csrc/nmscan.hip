@@ -827,7 +827,23 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const uint32_t n_entries = std::max(n_active, 1u) * n_bins;
     const size_t range_bytes = (size_t)n_entries * sizeof(uint4);
     const size_t off_rows = (off_range + range_bytes + 15) & ~(size_t)15;          // per-contig mode: row base per sorted candidate
-    const size_t total = off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
+    // The static segment table covers every bin; a batch whose candidates sit in a few bins only — the long tail of the
+    // search: a handful of tasks still open among hundreds of bins — would launch thousands of workgroups that find no
+    // candidate range and leave.  Such a batch brings its own table: the segments of the bins it has candidates for.
+    std::vector<uint8_t> bin_active(n_bins, 0);
+    uint32_t n_active_bins = 0;
+    size_t n_active_segs = 0;
+    for (uint32_t b = 0; b < n_bins; ++b) {
+        bool act = false;
+        for (int sl = 0; sl < NM_MAX_MOD_SLOTS && !act; ++sl) act = slot_used[sl] && bucket[(size_t)sl * n_bins + b + 1] > 0;
+        if (!act) continue;
+        bin_active[b] = 1;
+        n_active_bins += 1;
+        n_active_segs += (c->bin_nchunks[b] + c->seg_chunks - 1) / c->seg_chunks;
+    }
+    const bool own_segments = n_prog && n_active_segs * 4 <= (size_t)c->n_segments * 3 && getenv("NM_ALL_SEGMENTS") == nullptr;
+    const size_t off_segs = (off_rows + (per_contig ? (size_t)n_prog * 8 : 0) + 15) & ~(size_t)15;
+    const size_t total = own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
     // host counts come back through the pinned half of the staging pair (a copy into pageable memory is staged by the
     // runtime and costs tens of microseconds more per round of the search); tables too large for that go directly
     const size_t out_bytes = (size_t)out_rows * 2 * sizeof(int64_t);
@@ -860,6 +876,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     uint4 *h_range = reinterpret_cast<uint4 *>(hs + off_range);
     memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
     memset(h_range, 0, range_bytes);
+    if (own_segments) {
+        uint4 *h_segs = reinterpret_cast<uint4 *>(hs + off_segs);
+        size_t at = 0;
+        for (uint32_t b = 0; b < n_bins; ++b)
+            if (bin_active[b])
+                for (uint32_t k = 0; k < c->bin_nchunks[b]; k += c->seg_chunks)
+                    h_segs[at++] = make_uint4(c->bin_chunk0[b] + k, std::min<uint32_t>(c->seg_chunks, c->bin_nchunks[b] - k), b, 0);
+    }
     uint32_t n_groups = 0;
     // exclusive prefix over the buckets -> first sorted index of each (slot, bin); stable within a bucket
     for (size_t i = 1; i < bucket.size(); ++i) bucket[i] += bucket[i - 1];
@@ -953,8 +977,8 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         const ModSlot &ms = c->slots[s];
         a.st[s] = StatePlanes{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
     }
-    a.segments = c->d_segments;
-    a.n_segments = c->n_segments;
+    a.segments = own_segments ? reinterpret_cast<const uint4 *>(ds + off_segs) : c->d_segments;
+    a.n_segments = own_segments ? (uint32_t)n_active_segs : c->n_segments;
     a.n_bins = c->n_bins;
     a.programs = d_prog;
     a.orig_index = reinterpret_cast<uint32_t *>(ds + off_orig);
@@ -966,7 +990,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     for (int sl = 0; sl < NM_MAX_MOD_SLOTS; ++sl) a.slot_is_c[sl] = c->slots[sl].canonical == 'C';
     // workgroups that will find candidates, against what the device runs at once (~6 per CU): below ~2 rounds of
     // workgroups the last, partly filled round is a large share of the launch -> smaller pieces
-    uint64_t est_wgs = (uint64_t)c->n_segments * n_groups / std::max<uint32_t>(n_bins, 1);
+    uint64_t est_wgs = (uint64_t)a.n_segments * n_groups / std::max<uint32_t>(own_segments ? n_active_bins : n_bins, 1);
     if (light && n_active == 2 && lit) est_wgs = (est_wgs + 1) / 2;   // fused slots: one workgroup serves both
     const uint64_t resident = (uint64_t)c->n_cus * 6;
     uint32_t split_log2 = 0;
@@ -977,7 +1001,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // full round of resident workgroups would take LAST are cut finer (down to 4 chunks = one per wave)
     const bool streaming = light && !c->opt_no_cf;
     const uint32_t runs = streaming ? 1u : 8u;
-    const uint32_t n_pieces = c->n_segments << split_log2;
+    const uint32_t n_pieces = a.n_segments << split_log2;
     a.pieces_per_run = (n_pieces + runs - 1) / runs;
     a.fine_log2 = c->opt_fine >= 0 ? (uint32_t)c->opt_fine : 2u - split_log2;
     const uint32_t cols = std::max(1u, (streaming && n_active == 2 && lit) ? 1u : n_active);
