@@ -458,13 +458,15 @@ __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
 // parent of sibling children (find_motifs_bin.py:1116-1135), the motif under its parents in a pruning round
 // (:1408-1432) — become the group's COMMON program (index n_prog + group), evaluated once per tile; the candidates keep
 // the rest.  One thread per group; groups of 1 or of more than max_group candidates are left alone (range.z = ~0).
-__device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
+// programs: the candidates' programs (global memory, or the LDS copy compile_common_kernel works on); commons: where the
+// common program of entry g goes (global memory, program index n_prog + g)
+__device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range, uint32_t *programs, uint32_t *commons, uint32_t pdw,
                                            uint32_t n_prog, uint32_t max_group) {
     uint4 r = range[g];
     r.z = 0xFFFFFFFFu;
     r.w = 0;
     if (r.y >= 2 && r.y <= max_group) {
-        uint32_t *common = programs + (size_t)(n_prog + g) * pdw;
+        uint32_t *common = commons + (size_t)g * pdw;
         uint32_t any = 0;
         for (uint32_t i = 0; i < pdw; ++i) {
             uint32_t c = programs[(size_t)r.x * pdw + i];
@@ -509,7 +511,7 @@ __device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range
 __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
                               uint32_t n_prog, uint32_t max_group) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < n_entries) common_one(g, range, programs, pdw, n_prog, max_group);
+    if (g < n_entries) common_one(g, range, programs, programs + (size_t)n_prog * pdw, pdw, n_prog, max_group);
 }
 
 // Both steps in ONE launch for the small light batches of the search's long tail (a few dozen candidates, where a round
@@ -517,11 +519,19 @@ __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uin
 __global__ __launch_bounds__(1024) void compile_common_kernel(uint32_t n_prog, const CandRec *__restrict__ rec,
                                                                const uint8_t *__restrict__ masks, uint32_t *__restrict__ programs, int wide,
                                                                int np, int fold_modpos, uint32_t n_entries, uint4 *__restrict__ range,
-                                                               uint32_t pdw, uint32_t max_group) {
-    for (uint32_t k = threadIdx.x; k < n_prog; k += blockDim.x) compile_one(k, rec, masks, programs, wide, np, fold_modpos);
+                                                               uint32_t pdw, uint32_t max_group, uint32_t lds_words) {
+    // the candidates' programs are built and factored in LDS (a program is a chain of read-modify-writes: one dependent
+    // round trip each in global memory) and leave in one coalesced copy; a batch too large for that works in place
+    extern __shared__ uint32_t lds_programs[];
+    uint32_t *work = lds_words ? lds_programs : programs;
+    for (uint32_t k = threadIdx.x; k < n_prog; k += blockDim.x) compile_one(k, rec, masks, work, wide, np, fold_modpos);
     __threadfence_block();
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < n_entries; g += blockDim.x) common_one(g, range, programs, pdw, n_prog, max_group);
+    for (uint32_t g = threadIdx.x; g < n_entries; g += blockDim.x) common_one(g, range, work, programs + (size_t)n_prog * pdw, pdw, n_prog, max_group);
+    if (lds_words) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_prog * pdw; i += blockDim.x) programs[i] = lds_programs[i];
+    }
 }
 
 // Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
@@ -933,9 +943,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     if (n_prog) {
         if (cf && n_prog <= 2048 && n_entries <= 8192 && !c->opt_no_inline) {
-            hipLaunchKernelGGL(compile_common_kernel, dim3(1), dim3(1024), 0, pst, n_prog, reinterpret_cast<const CandRec *>(ds),
+            const size_t lds_bytes = (size_t)n_prog * pdw * 4 <= 48 * 1024 ? (size_t)n_prog * pdw * 4 : 0;
+            hipLaunchKernelGGL(compile_common_kernel, dim3(1), dim3(1024), lds_bytes, pst, n_prog, reinterpret_cast<const CandRec *>(ds),
                                ds + off_masks, d_prog, any_wide, (int)np, all_compact ? 1 : 0, n_entries,
-                               reinterpret_cast<uint4 *>(ds + off_range), pdw, 8u);
+                               reinterpret_cast<uint4 *>(ds + off_range), pdw, 8u, (uint32_t)(lds_bytes / 4));
             HIP_TRY(hipGetLastError());
         } else {
             hipLaunchKernelGGL(compile_kernel, dim3((n_prog + 255) / 256), dim3(256), 0, pst, n_prog,
