@@ -698,7 +698,7 @@ private:
     std::condition_variable cv_;
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_ = 0, chunk_ = 16;
-    size_t min_parallel_ = getenv("NM_SEARCH_MIN_PARALLEL") ? (size_t)std::max(1, atoi(getenv("NM_SEARCH_MIN_PARALLEL"))) : 16;
+    size_t min_parallel_ = getenv("NM_SEARCH_MIN_PARALLEL") ? (size_t)std::max(1, atoi(getenv("NM_SEARCH_MIN_PARALLEL"))) : 8;
     std::atomic<size_t> next_{0};
     std::atomic<unsigned> busy_{0}, asleep_{0};
     std::atomic<uint64_t> gen_{0};
@@ -725,12 +725,12 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     const bool timing = getenv("NM_SEARCH_TIMING") != nullptr;
     double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    // NM_SEARCH_THREADS: host threads that advance the searches between two batches (default 4; a phase with fewer than
-    // NM_SEARCH_MIN_PARALLEL = 16 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
+    // NM_SEARCH_THREADS: host threads that advance the searches between two batches (default: half the hardware threads, at
+    // most 8; a phase with fewer than NM_SEARCH_MIN_PARALLEL = 8 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
     // of children_of (164 logarithms per expansion, bit-exact with scipy): 24 ms on one thread, 16-17 on four, 14-15 on eight
-    unsigned n_threads = std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
     if (const char *e = getenv("NM_SEARCH_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, atoi(e)));
-    if (tasks.size() < 16) n_threads = 1;
+    if (tasks.size() < 8) n_threads = 1;
     Workers workers(n_threads);
     double t0 = now();
     workers.run(tasks.size(), [&](size_t i) { tasks[i].resume(); });
