@@ -199,23 +199,24 @@ class PostResults:
         self.n = n
         self._text = text.tobytes().decode("ascii")
         key = self.task[:n].astype(np.int64) * 8 + self.stage[:n]
-        self._first = np.searchsorted(key, np.arange(len(self.keys) * 8 + 1))       # records are sorted by (task, stage)
+        self._first = np.searchsorted(key, np.arange(len(self.keys) * 8 + 1)).tolist()       # records are sorted by (task, stage)
         self._off = self.text_off.tolist()
+        # plain lists: a row is built from a dozen scalars, and numpy scalars cost more to unwrap than the row costs to make
+        self._cols = (self.task[:n].tolist(), self.stage[:n].tolist(), self.mod_position[:n].tolist(), self.mod_position_iupac[:n].tolist(),
+                      self.counts[:n].tolist(), self.score[:n].tolist(), self.complement[:n].tolist())
         self._made = {}
 
     def _row(self, i):
-        from .motif import reverse_compliment
         from .postprocess import MotifRow
         r = self._made.get(i)
         if r is None:
-            k = self.keys[int(self.task[i])]
-            o = self._off
-            comp = int(self.complement[i])
-            r = MotifRow(k[0], self._text[o[2 * i]:o[2 * i + 1]], k[1], int(self.mod_position[i]),
-                         BetaBernoulliModel.from_counts(int(self.counts[i, 0]), int(self.counts[i, 1])), float(self.score[i]),
-                         None if comp < 0 else self._row(comp), int(self.stage[i]) == 4)
-            iu = self._text[o[2 * i + 1]:o[2 * i + 2]]
-            r.__dict__["_cache"] = (iu, int(self.mod_position_iupac[i]), reverse_compliment(iu))
+            task, stage, modpos, modpos_iu, counts, score, complement = self._cols
+            k = self.keys[task[i]]
+            o, text = self._off, self._text
+            comp = complement[i]
+            r = MotifRow(k[0], text[o[2 * i]:o[2 * i + 1]], k[1], modpos[i], BetaBernoulliModel.from_counts(counts[i][0], counts[i][1]), score[i],
+                         None if comp < 0 else self._row(comp), stage[i] == 4)
+            r.__dict__["_cache"] = (text[o[2 * i + 1]:o[2 * i + 2]], modpos_iu[i], None)      # (the reverse complement on first use)
             self._made[i] = r
         return r
 
@@ -226,7 +227,7 @@ class PostResults:
 
     def rows(self, t, stage):
         f = self._first
-        return [self._row(i) for i in range(int(f[t * 8 + stage]), int(f[t * 8 + stage + 1]))]
+        return [self._row(i) for i in range(f[t * 8 + stage], f[t * 8 + stage + 1])]
 
     def final(self, t):
         """What postprocess_co returns for task ``t``: the rows of the last stage, or None."""

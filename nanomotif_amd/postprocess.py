@@ -37,12 +37,14 @@ class MotifRow:
 
     def _derived(self):
         """(motif_iupac, mod_position_iupac, reverse complement of motif_iupac), computed once per row (rows are never
-        mutated after creation)."""
+        mutated after creation; the native post-processing hands the first two over and leaves the third for the first use)."""
         d = self.__dict__.get("_cache")
         if d is None:
             st = self.as_motif().new_stripped_motif()
             iu = st.iupac()
             d = self.__dict__["_cache"] = (iu, int(st.mod_position), reverse_compliment(iu))
+        elif d[2] is None:
+            d = self.__dict__["_cache"] = (d[0], d[1], reverse_compliment(d[0]))
         return d
 
     def as_motif(self):
@@ -53,11 +55,13 @@ class MotifRow:
 
     @property
     def motif_iupac(self):
-        return self._derived()[0]
+        d = self.__dict__.get("_cache")
+        return d[0] if d is not None else self._derived()[0]
 
     @property
     def mod_position_iupac(self):
-        return self._derived()[1]
+        d = self.__dict__.get("_cache")
+        return d[1] if d is not None else self._derived()[1]
 
     def key(self):
         return (self.reference, self.motif, self.mod_type, self.mod_position, self.n_mod, self.n_nomod, self.score,
