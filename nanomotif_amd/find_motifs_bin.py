@@ -261,10 +261,12 @@ class FilteredPileup:
         """The listed contigs that have at least one surviving row of this mod type (find_motifs_bin.py:629)."""
         if getattr(self, "_name_index", None) is None:
             self._name_index = {n: i for i, n in enumerate(self.contig_names)}
+            self._kept_rows = (np.asarray(self.kept) != 0).tolist()        # plain lists: this runs once per (bin, mod type)
+        index, kept = self._name_index, self._kept_rows
         out = []
         for name in contig_names:
-            i = self._name_index.get(name)
-            if i is not None and self.kept[i, mod_id] != 0:
+            i = index.get(name)
+            if i is not None and kept[i][mod_id]:
                 out.append(name)
         return out
 
@@ -426,7 +428,9 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                             stage_writer(post.STAGES[s], post.rows(t, s))
                     native_rows[key] = post.final(t)
                 lap("postprocess_s")
-            found.close()
+            # (a thousand search graphs take 3 ms to free: off the critical path, on a thread of their own)
+            import threading
+            threading.Thread(target=found.close, name="nm-search-free", daemon=False).start()
         else:
             for key, stage_writer, temp_dir in planned:
                 tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)

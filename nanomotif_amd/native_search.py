@@ -51,13 +51,16 @@ class SearchResults:
                                                p(self.score, C.c_double), p(self.priority, C.c_double), p(self.depth, C.c_int32),
                                                p(self.visited, C.c_uint8), p(self.edges, C.c_int32), p(self.best, C.c_int32)))
         self._lib, self._handle = lib, handle              # kept for post-processing (nm_post_run reads the graphs); close() frees it
+        import threading
+        self._close_lock = threading.Lock()
         self.W = W
         self._text = self.motif.tobytes().decode("ascii") if nn.value else ""
 
     def close(self):
-        if self._handle is not None:
-            self._lib.nm_search_result_free(self._handle)
-            self._handle = None
+        with self._close_lock:                      # (discover() frees the graphs on a side thread; __del__ may come from another)
+            handle, self._handle = self._handle, None
+        if handle is not None:
+            self._lib.nm_search_result_free(handle)
 
     def __del__(self):
         try:
