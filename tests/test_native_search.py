@@ -244,3 +244,50 @@ def test_searches_advance_on_several_threads_with_identical_results(monkeypatch)
     for t, k in enumerate(keys):
         assert one[1][t] == one[1][t % len(base)], k
     assert any(x is not None and len(x[2]) > 0 for x in one[1])
+
+
+@pytest.mark.parametrize("pad", [31, 64, 95])
+def test_native_search_on_wide_frames_equals_python_coroutines(pad):
+    """Search frames of 63, 129 and 191 columns (the packed motif keys take 3, 7 and 9 words, the window rows 64 / 192 /
+    192 columns): the native state machine against the Python coroutines, graphs and scores with ==."""
+    g = load_golden("g4_search.json")["ecoli_like_a"]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    mt = g["mod_type"]
+    pile, seqs = oracle_bin_inputs(mg, mt)
+    key = ("bin0", mt)
+    random.seed(1)
+    wins = windows_for(mg, mt, pile, 0.7, pad)
+    store = ps.HostWindowStore()
+    store.add_task(key, wins[0].copy())
+    scorer = LockstepScorer(oracle_backend({key: pile}, {"bin0": seqs}))
+    want = ps.run_lockstep({key: ps.find_best_candidates_co(wins[1], mt, pad, min_kl=0.05, score_threshold=1.5)}, scorer, store.execute)[key]
+    store2 = ps.HostWindowStore()
+    store2.add_task(key, wins[0].copy())
+    from oracle.scan import score_candidates
+    W = 2 * pad + 1
+    ws = (W + 63) // 64 * 64
+
+    def score_fn(reqs):
+        return np.array([score_candidates(pile, seqs, [(m.string, m.mod_position)])[0] for _, m in reqs], dtype=np.int64).reshape(-1, 2)
+
+    def window_fn(reqs):
+        res = store2.execute([(key, ps.WinReq(kind, m)) for _, kind, m in reqs])
+        out = np.zeros((len(reqs), 2 + 4 * ws), dtype=np.int32)
+        for i, ((_, kind, m), r) in enumerate(zip(reqs, res)):
+            if kind == "remove":
+                out[i, 0], out[i, 1] = r
+            else:
+                out[i, 0] = r[0]
+                if r[1] is not None:
+                    out[i, 2:].reshape(4, ws)[:, :r[1].shape[1]] = r[1]
+        return out
+    res = ns.find_best_candidates_custom([(key, store2.totals[key], wins[1])], pad, 0.05, 1.5, score_fn, window_fn)
+    got = res.result(0, full_graph=True)
+    assert (got is None) == (want is None)
+    if want is not None:
+        graph, best, _ = got
+        wg, wbest, _ = want
+        assert list(graph.nodes) == list(wg.nodes) and best == wbest and len(graph.nodes) > 3
+        for n in graph.nodes:
+            a, b = graph.nodes[n], wg.nodes[n]
+            assert a["model"].get_raw_counts() == b["model"].get_raw_counts() and a["score"] == b["score"] and a["priority"] == b["priority"]
