@@ -642,15 +642,24 @@ hipError_t device_free(void *p) {
 }
 
 int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
+    // A pair whose pinned half still holds the results of an open begin / end batch (nm_score_batch_begin,
+    // nm_win_batch_w_begin) is never handed out: the next user would copy over — or, growing the pair, free — what
+    // nm_*_end has yet to read.  At most two pairs are held at a time, so the walk always finds a free one.
+    auto held = [&](int i) {
+        return (c->score_wait.open && c->score_wait.stage == &c->stage[i]) || (c->win_wait.open && c->win_wait.stage == &c->stage[i]);
+    };
     int idx;
     if (mode == 2) idx = NM_STAGE_RING;
     else if (mode == 1) {
         idx = c->stage_next_deep;
+        for (int tries = 0; tries < NM_STAGE_RING && held(idx); ++tries) idx = (idx + 1) % NM_STAGE_RING;
         c->stage_next_deep = (idx + 1) % NM_STAGE_RING;
     } else {
         idx = c->stage_next;
-        c->stage_next ^= 1;
+        if (held(idx)) idx ^= 1;
+        c->stage_next = idx ^ 1;
     }
+    if (held(idx)) return fail(NM_ESTATE, "staging ring: every pair is held by an uncollected batch");
     nm_ctx::Stage &st = c->stage[idx];
     if (!st.busy) HIP_TRY(hipEventCreateWithFlags(&st.busy, hipEventDisableTiming));
     if (st.pending) {

@@ -146,9 +146,10 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, hos
     return assembly, FilteredPileup(engine.contig_names, cc, cp, cs, cm, kept), t
 
 
-def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
+def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None, use_dist=False):
     """End-to-end run on one GPU; ``bins``: only these bins (whole-bin sharding of a multi-GPU run: every rank runs the
-    searches of its own bins alone, find_motifs_bin.py:152-171).  Returns (rows, timings)."""
+    searches of its own bins alone, find_motifs_bin.py:152-171); ``use_dist``: every round's count and window tables go
+    through ``allreduce_counts`` like in a contig-sharded run (the caller has a communicator up).  Returns (rows, timings)."""
     contigs = None
     if bins is not None:
         keep = set(bins)
@@ -161,7 +162,7 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None):
                           search_frame_size=40, methylation_threshold_low=0.3, methylation_threshold_high=0.7,
                           minimum_kl_divergence=0.05, score_threshold=1.5, log_dir=None, seed=1, output_dir=None)
     t0 = time.perf_counter()
-    scorer = engine_scorer(engine, 0.3, 0.7)
+    scorer = engine_scorer(engine, 0.3, 0.7, use_dist=use_dist)
     from .main import device_window_pipeline
     t1 = time.perf_counter()
     store, extractor = device_window_pipeline(engine, dict(zip(names, lengths)), list(names), cfg.padding)

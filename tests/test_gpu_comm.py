@@ -52,6 +52,35 @@ def test_single_rank_communicator_orders_allreduce_after_scoring():
     eng.close()
 
 
+def test_native_search_reduces_through_the_c_abi_with_batches_in_flight():
+    """nm_search_run with a reduce callback that lands in nm_allreduce_counts_host (what a contig-sharded run with the
+    native communicator does every round), RCCL world of one: a lock-step round has its window batch AND its scoring batch
+    open (nm_*_begin) when the window counts are reduced, so the reduction must not take the staging pair the open
+    scoring batch's counts sit in (round-3 advisor finding).  Same motif rows as the run without a collective."""
+    import torch
+    from nanomotif_amd import e2e_synth, postprocess, synth
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.find_motifs_bin import use_native_allreduce
+    mg = synth.make_metagenome(synth.SynthSpec(n_contigs=40, total_bp=12_000_000, n_bins=8, mod_types=("a", "m"), seed=5))
+    eng = ScanEngine(0)
+    rows0, t0 = e2e_synth.run(mg, eng, torch.device("cuda:0"))
+    eng.close()
+    eng = ScanEngine(0)
+    eng.comm_init(0, 1, eng.comm_unique_id())
+    calls = []
+    inner = eng.allreduce_host
+    eng.allreduce_host = lambda a: (calls.append(a.size), inner(a))[1]
+    use_native_allreduce(eng)
+    try:
+        rows1, t1 = e2e_synth.run(mg, eng, torch.device("cuda:0"), use_dist=True)
+    finally:
+        use_native_allreduce(None)
+        eng.close()
+    assert len(rows0) > 8 and t0["rounds"] > 20
+    assert postprocess.format_bin_motifs(rows1) == postprocess.format_bin_motifs(rows0)
+    assert t1["rounds"] == t0["rounds"] and len(calls) > 2 * t0["rounds"] - 10      # window AND count tables, every round
+
+
 _TWO_RANKS = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4: the LDS-staged transposed tile prototype (tools/lds_proto.hip): correctness on a small input, then the 1 Gbp shape
+cd ${GRAFT_REPO_ROOT:-.}
+mkdir -p gpurun_out/lds_proto
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-int-to-pointer-cast -o /tmp/lds_proto tools/lds_proto.hip || exit 1
+{
+timeout 300 /tmp/lds_proto 66 10 1
+timeout 300 /tmp/lds_proto 122072 10 0
+timeout 300 /tmp/lds_proto 122072 4 0
+timeout 300 /tmp/lds_proto 122072 16 0
+} 2>&1 | tee gpurun_out/lds_proto/out.txt
