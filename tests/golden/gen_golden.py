@@ -16,6 +16,10 @@ Vectors:
   G5  Motif algebra                                            -> g5_motif_algebra.json
   G6  background window starts (random.sample, seed 1)         -> g6_background.json
   G7  get_parent_scores / merge_motifs                         -> g7_parents_merge.json
+  G8  remove_noisy_motifs / merge_motifs_in_df / remove_sub_motifs / join_motif_complements on motif families built to fire
+      every branch (the REAL functions on the row-list frame of refframe.py)   -> g8_postprocess_glue.json
+  G9  process_subpileup end to end: every stage table + the final rows          -> g9_process_subpileup.json
+  G10 dataload.filter_pileup + filter_pileup_minimummod_frequency               -> g10_frequency_filter.json
 """
 from __future__ import annotations
 
@@ -333,6 +337,207 @@ def g7(nm):
     dump("g7_parents_merge.json", out)
 
 
+# ---------------------------------------------------------------------------------------------------- g8 - g10
+POST_BINS = dict(SEARCH_BINS)
+# two planted motifs at distance 2 whose cross variants (GCAAGC, GTAAGT) are NOT planted: a merge that must be rejected
+POST_BINS["two_planted"] = (dict(n_contigs=2, total_bp=400_000, n_bins=1, mod_types=("a",), seed=45, min_contig_bp=150_000,
+                                 fixed_motifs=(("GCAAGT", 3, "a"), ("GTAAGC", 3, "a"), ("GATC", 1, "a"))), "a")
+
+
+def _wide(nm, core, pos, pad=20):
+    from nanomotif.motif import Motif
+    left = pad - pos
+    return Motif("." * left + core + "." * (2 * pad + 1 - left - len(core)), pad)
+
+
+def _post_bin(nm, name, mod_types=None):
+    """Reference-side inputs of one bin: pileup frame (all requested mod types, coverage filter only), sequences."""
+    from nanomotif.seq import DNAsequence
+    kw, mt = POST_BINS[name]
+    mod_types = mod_types or (mt,)
+    mg = synth.make_metagenome(synth.SynthSpec(**kw))
+    parts = []
+    for m in mod_types:
+        cols = filtered_bin_pileup(mg, m)
+        names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+        parts.append(refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()],
+                                         cols["fraction_mod"], mod_type=[m] * len(names)))
+    pile = parts[0] if len(parts) == 1 else refstub.refframe.concat(parts)
+    seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+    return kw, mg, pile, seqs
+
+
+def _table(df):
+    """A stage table as sorted plain rows (models as counts); complement columns when present."""
+    comp = "motif_complement" in df.columns
+    out = []
+    for r in df.rows():
+        row = [r["reference"], r["motif"], r["mod_type"], int(r["mod_position"]), int(r["n_mod"]), int(r["n_nomod"]),
+               float(r["score"]), r["motif_iupac"], int(r["mod_position_iupac"])]
+        if comp:
+            none = r["motif_complement"] is None
+            row += [None if none else r["motif_complement"], None if none else int(r["mod_position_complement"]),
+                    None if none else int(r["n_mod_complement"]), None if none else int(r["n_nomod_complement"]),
+                    None if none else r["motif_iupac_complement"], None if none else int(r["mod_position_iupac_complement"])]
+        out.append(row)
+    return sorted(out, key=lambda x: [("" if v is None else str(v)) for v in x])
+
+
+def _has_duplicate_motifs(df):
+    keys = [(r["reference"], r["mod_type"], r["motif"], r["mod_position"]) for r in df.rows()]
+    return len(set(keys)) != len(keys)
+
+
+G8_CASES = [
+    # name, bin, mod types of the frame, [(core, mod position of the core, mod type)]
+    ("degenerate_all_variants_present", "geobacillus_like", [("GA.GAAGC", 5, "a"), ("GG.GAAGC", 5, "a"), ("GA.GAAGT", 5, "a"), ("GG.GAAGT", 5, "a"), ("GATC", 1, "a")]),
+    ("degenerate_accepted_by_score", "geobacillus_like", [("GA.GAAGC", 5, "a"), ("GG.GAAGC", 5, "a"), ("GA.GAAGT", 5, "a"), ("ACCCA", 4, "a")]),
+    ("merge_rejected_unmethylated_partner", "geobacillus_like", [("CCAAAT", 4, "a"), ("CGAATT", 4, "a"), ("GATC", 1, "a")]),
+    ("merges_to_stripped_forms_then_join", "geobacillus_like", [("GATC", 1, "a"), ("GATCA", 1, "a"), ("TGATC", 2, "a"), ("ACCCA", 4, "a"), ("ACCCAG", 4, "a"), ("CCAAAT", 4, "a"), ("CAAAT", 3, "a")]),
+    ("noisy_motifs_dropped", "geobacillus_like", [("GATC", 1, "a"), ("G...ATC", 5, "a"), ("A....GATC", 6, "a")]),
+    ("all_noisy_frame_unchanged", "geobacillus_like", [("G...ATC", 5, "a"), ("A....GATC", 6, "a")]),
+    ("sub_motif_children_dropped", "geobacillus_like", [("GATC", 1, "a"), ("TGATCA", 2, "a"), ("AGATCT", 2, "a"), ("GATCGG", 1, "a")]),
+    ("sub_motif_parent_dropped", "geobacillus_like", [("A", 0, "a"), ("GATC", 1, "a"), ("ACCCA", 4, "a"), ("CCCA", 3, "a")]),
+    ("short_motifs_never_merge", "geobacillus_like", [("GATC", 1, "a"), ("GATG", 1, "a"), ("AATC", 1, "a")]),
+    ("merge_rejected_both_methylated", "two_planted", [("GCAAGT", 3, "a"), ("GTAAGC", 3, "a"), ("GATC", 1, "a")]),
+    ("two_mod_types_in_one_frame", "ecoli_like_a", [("GATC", 1, "a"), ("CCAGG", 1, "m"), ("CCTGG", 1, "m"), ("GCAC......GTT", 2, "a"), ("AAC......GTGC", 1, "a"),
+                                                      ("GATCA", 1, "a"), ("TGATC", 2, "a")]),
+    ("palindromes_and_complement_pairs", "ecoli_like_a", [("GATC", 1, "a"), ("GCAC......GTT", 2, "a"), ("AAC......GTGC", 1, "a"), ("CC[AT]GG", 1, "m")]),
+]
+
+
+def g8(nm):
+    from nanomotif.model import BetaBernoulliModel
+    fmb = nm.find_motifs_bin
+    pl = sys.modules["polars"]
+    out = {"bins": {}, "cases": [], "stand_in": "tests/golden/refframe.py"}
+    cache = {}
+    for name, bin_name, members in G8_CASES:
+        mts = tuple(sorted({m[2] for m in members}))
+        if (bin_name, mts) not in cache:
+            cache[(bin_name, mts)] = _post_bin(nm, bin_name, mts)
+        kw, mg, pile, seqs = cache[(bin_name, mts)]
+        out["bins"][bin_name] = {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v))
+                                 for k, v in kw.items()}
+        data = {"reference": [], "motif": [], "mod_type": [], "mod_position": [], "model": [], "score": []}
+        rec_in = []
+        for k, (core, pos, mt) in enumerate(members):
+            m = _wide(nm, core, pos)
+            sub = pile.filter(pl.col("mod_type") == mt)
+            model = fmb.motif_model_bin(sub, seqs, m, BetaBernoulliModel(), 0.3, 0.7)
+            score = 2.0 + 0.25 * k                   # the stages carry the search's score along; any value does
+            for key, v in zip(data, ("bin0", m.string, mt, int(m.mod_position), model, score)):
+                data[key].append(v)
+            rec_in.append([m.string, int(m.mod_position), mt, model_counts(model), score])
+        df = nm.motif.MotifSearchResult(pl.DataFrame(data))
+        stages = {}
+        dup = False
+        a = nm.postprocess.remove_noisy_motifs(df)
+        stages["noise"] = _table(a)
+        b = fmb.merge_motifs_in_df(a, pile, seqs, {"bin0": list(seqs)}).unique()
+        stages["merge"] = _table(b)
+        dup |= _has_duplicate_motifs(b)
+        c = nm.postprocess.remove_sub_motifs(b).unique()
+        stages["sub"] = _table(c)
+        dup |= _has_duplicate_motifs(c)
+        d = nm.postprocess.join_motif_complements(c).unique()
+        stages["complement"] = _table(d)
+        out["cases"].append({"name": name, "bin": bin_name, "mod_types": list(mts), "input": rec_in, "stages": stages,
+                             "a_stage_held_one_motif_twice": bool(dup)})
+        print(name, {k: len(v) for k, v in stages.items()})
+    dump("g8_postprocess_glue.json", out)
+
+
+def g9(nm):
+    fmb = nm.find_motifs_bin
+    out = {}
+    for name, (kw, mt) in POST_BINS.items():
+        kw, mg, pile, seqs = _post_bin(nm, name)
+        tmp = tempfile.mkdtemp()
+        rec = []
+        refstub.refframe.DataFrame.recorder = rec
+        random.seed(1)
+        try:
+            res = fmb.process_subpileup({"bin0": list(seqs)}, mt, pile, seqs, 0.05, 20, 0.3, 0.7, 1.5, output_dir=tmp)
+        finally:
+            refstub.refframe.DataFrame.recorder = None
+        stages = {os.path.basename(path)[:-4]: _table(refstub.refframe.DataFrame({k: [r[k] for r in rows] for k in rows[0]}) if rows else
+                                                       refstub.refframe.DataFrame())
+                  for path, rows in rec}
+        out[name] = {"spec": {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v)) for k, v in kw.items()},
+                     "mod_type": mt, "params": dict(low=0.3, high=0.7, padding=20, min_kl=0.05, score_threshold=1.5, seed=1),
+                     "stages": stages, "final": None if res is None else _table(res)}
+        print(name, {k: len(v) for k, v in stages.items()}, "final:", None if res is None else len(res))
+    dump("g9_process_subpileup.json", out)
+
+
+def g10(nm):
+    import importlib
+    dl = importlib.import_module("nanomotif.dataload")
+    rng = np.random.default_rng(77)
+    groups = [
+        # contig, mod type, rows, rows with fraction > 0.7, note
+        ("c_ok", "a", 20_000, 60, "passes both"),
+        ("c_ok", "m", 20_000, 50, "exactly 50 modified: fails > 50"),
+        ("c_51", "a", 20_000, 51, "51 modified: passes"),
+        ("c_ratio_eq", "a", 510_000, 51, "51 / 510000 = 1e-4 exactly: fails > 1e-4"),
+        ("c_ratio_gt", "a", 509_999, 51, "just above 1e-4: passes"),
+        ("c_none", "m", 5_000, 0, "no modified row"),
+        ("c_null", "a", 1_000, 60, "nulls among the rest: a null counts as a position, not as modified"),
+        ("c_null_tip", "m", 600_001, 60, "60 / 600001 < 1e-4: fails; the same group without its 100002 nulls would pass"),
+        ("c_21839", "21839", 3_000, 70, "4mC code"),
+    ]
+    cols = {"contig": [], "mod_type": [], "fraction_mod": [], "Nvalid_cov": [], "position": [], "strand": []}
+    for contig, mt, n, n_mod, _ in groups:
+        frac = rng.integers(0, 7000, n).astype(np.float64) / 10000.0          # <= 0.6999
+        frac[rng.choice(n, n_mod, replace=False)] = rng.integers(7001, 10001, n_mod) / 10000.0
+        if contig == "c_ok" and mt == "a":
+            low = np.flatnonzero(frac <= 0.7)[:5]
+            frac[low] = 0.7                                                      # exactly 0.7 is not > 0.7
+        if contig.startswith("c_null"):
+            k = 100 if contig == "c_null" else 100_002
+            low = np.flatnonzero(frac <= 0.7)[:k]
+            frac[low] = np.nan
+        cov = rng.integers(6, 60, n)
+        cols["contig"] += [contig] * n
+        cols["mod_type"] += [mt] * n
+        cols["fraction_mod"].append(frac)
+        cols["Nvalid_cov"].append(cov)
+        cols["position"].append(np.arange(n, dtype=np.int64))
+        cols["strand"] += ["+"] * n
+    # rows at or under the coverage bound: 5 is dropped (strict >), and dropping them moves c_cov across the 50 bound
+    n = 10_000
+    frac = rng.integers(0, 7000, n).astype(np.float64) / 10000.0
+    hot = rng.choice(n, 55, replace=False)
+    frac[hot] = 0.9
+    cov = rng.integers(6, 60, n)
+    cov[hot[:5]] = 5
+    cov[hot[5:8]] = 6
+    cols["contig"] += ["c_cov"] * n
+    cols["mod_type"] += ["a"] * n
+    cols["fraction_mod"].append(frac)
+    cols["Nvalid_cov"].append(cov)
+    cols["position"].append(np.arange(n, dtype=np.int64))
+    cols["strand"] += ["+"] * n
+    df = refstub.refframe.DataFrame()
+    df._cols = {"contig": np.array(cols["contig"], dtype=object), "mod_type": np.array(cols["mod_type"], dtype=object),
+                "fraction_mod": np.concatenate(cols["fraction_mod"]), "Nvalid_cov": np.concatenate(cols["Nvalid_cov"]).astype(np.int64),
+                "position": np.concatenate(cols["position"]), "strand": np.array(cols["strand"], dtype=object)}
+    df._cols["row"] = np.arange(len(df), dtype=np.int64)
+    a = dl.filter_pileup(df)
+    b = dl.filter_pileup_minimummod_frequency(a)
+    assert "contig_mod" not in b.columns
+    kept = {}
+    for (c, m), sub in b.group_by("contig", "mod_type"):
+        kept[f"{c}|{m}"] = int(len(sub))
+    out = {"seed": 77, "groups": [[c, m, n, k, note] for c, m, n, k, note in groups] + [["c_cov", "a", 10_000, 55, "5 of the 55 at coverage 5: 50 left, fails"]],
+           "input_sha1": {k: sha1(v if v.dtype != object else np.array([str(x) for x in v]).astype("S")) for k, v in df._cols.items() if k != "row"},
+           "n_rows": int(len(df)), "after_coverage": int(len(a)), "after_coverage_rows_sha1": sha1(a._cols["row"]),
+           "after_frequency": int(len(b)), "after_frequency_rows_sha1": sha1(b._cols["row"]), "kept_groups": kept}
+    print("g10:", out["n_rows"], "->", out["after_coverage"], "->", out["after_frequency"], kept)
+    dump("g10_frequency_filter.json", out)
+
+
 if __name__ == "__main__":
     if os.environ.get("PYTHONHASHSEED") != "0":
         # the reference appends missed candidates in SET order (find_motifs_bin.py:826-833): pin the hash seed so that
@@ -340,6 +545,6 @@ if __name__ == "__main__":
         os.environ["PYTHONHASHSEED"] = "0"
         os.execv(sys.executable, [sys.executable] + sys.argv)
     nm = refstub.load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w](nm)

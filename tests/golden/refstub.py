@@ -28,115 +28,12 @@ REFERENCE_ROOT = os.environ.get("NANOMOTIF_REFERENCE", "/root/reference")
 
 
 # --------------------------------------------------------------------------
-# minimal polars stand-in
+# polars stand-in: tests/golden/refframe.py (numpy columns; filters, group_by, join, concat, ... — see its docstring)
 # --------------------------------------------------------------------------
-class _Expr:
-    def __init__(self, fn):
-        self.fn = fn
+import refframe  # noqa: E402
+from refframe import DataFrame, Series, col  # noqa: E402,F401
 
-    def __call__(self, df):
-        return self.fn(df)
-
-    def _bin(self, other, op):
-        if isinstance(other, _Expr):
-            return _Expr(lambda df: op(self(df), other(df)))
-        return _Expr(lambda df: op(self(df), other))
-
-    def __ge__(self, o):
-        return self._bin(o, lambda a, b: a >= b)
-
-    def __le__(self, o):
-        return self._bin(o, lambda a, b: a <= b)
-
-    def __gt__(self, o):
-        return self._bin(o, lambda a, b: a > b)
-
-    def __lt__(self, o):
-        return self._bin(o, lambda a, b: a < b)
-
-    def __eq__(self, o):  # type: ignore[override]
-        return self._bin(o, lambda a, b: a == b)
-
-    def __and__(self, o):
-        return self._bin(o, lambda a, b: a & b)
-
-    def __or__(self, o):
-        return self._bin(o, lambda a, b: a | b)
-
-    def eq(self, o):
-        return self == o
-
-    def is_in(self, values):
-        vals = list(values)
-        return _Expr(lambda df: np.isin(self(df), np.array(vals, dtype=object)
-                                         if vals and isinstance(vals[0], str) else np.array(vals)))
-
-    def not_(self):
-        return _Expr(lambda df: ~self(df))
-
-
-def col(name):
-    return _Expr(lambda df: df._cols[name])
-
-
-class Series:
-    def __init__(self, name, values):
-        self.name = name
-        self.values = np.asarray(values)
-
-    def to_numpy(self):
-        return self.values
-
-    def to_list(self):
-        return self.values.tolist()
-
-    def unique(self):
-        # polars' unique() order is unspecified; the fixtures pin "sorted"
-        return Series(self.name, np.unique(self.values))
-
-    def __iter__(self):
-        return iter(self.values.tolist())
-
-    def __len__(self):
-        return len(self.values)
-
-    def __getitem__(self, i):
-        return self.values[i]
-
-
-class DataFrame:
-    def __init__(self, data=None, schema=None):
-        data = data or {}
-        self._cols = {k: (np.asarray(v, dtype=object) if len(v) and isinstance(v[0], str) else np.asarray(v))
-                      for k, v in data.items()}
-
-    @property
-    def columns(self):
-        return list(self._cols)
-
-    def filter(self, expr):
-        mask = np.asarray(expr(self), dtype=bool)
-        out = DataFrame()
-        out._cols = {k: v[mask] for k, v in self._cols.items()}
-        return out
-
-    def get_column(self, name):
-        return Series(name, self._cols[name])
-
-    def __getitem__(self, name):
-        return Series(name, self._cols[name])
-
-    def is_empty(self):
-        return len(self) == 0
-
-    def __len__(self):
-        if not self._cols:
-            return 0
-        return len(next(iter(self._cols.values())))
-
-    @property
-    def height(self):
-        return len(self)
+_Expr = refframe.Expr
 
 
 def _make_polars():
@@ -148,7 +45,11 @@ def _make_polars():
     for n in ("Utf8", "String", "Int64", "Float64", "Object", "Null", "Boolean"):
         setattr(pl, n, n)
     pl.set_random_seed = lambda seed: None
-    pl.lit = lambda v: _Expr(lambda df: np.full(len(df), v))
+    pl.lit = refframe.lit
+    pl.count = refframe.count
+    pl.len = refframe.count
+    pl.when = refframe.when
+    pl.concat = refframe.concat
     testing = types.ModuleType("polars.testing")
     pl.testing = testing
     return pl, testing
@@ -183,6 +84,9 @@ def load_reference():
                 "postprocess", "find_motifs_bin"):
         m = importlib.import_module(f"nanomotif.{mod}")
         setattr(pkg, mod, m)
+    # MotifSearchResult subclasses the REAL polars frame and reaches into its internals (motif.py:654-880): replaced by a
+    # pass-through with the same column contract (refframe.make_motif_search_result)
+    pkg.motif.MotifSearchResult = refframe.make_motif_search_result(pkg.motif.Motif)
     _loaded = pkg
     return pkg
 

@@ -347,3 +347,178 @@ def test_read_methylation_restatement_on_a_hand_worked_case():
     assert read_methylation(rec, {"c": seq}, [("GATC", "m", 3)], 3, 0.8) == []        # no record of that mod code
     rows = read_methylation(rec, {"c": seq}, [("GATC", "a", 1)], 3, 0.0, "median")    # odd count: the middle value
     assert rows[0]["n_motif_obs"] == 5 and rows[0]["methylation_value"] == 0.75
+
+
+# ------------------------------------------------------------------ G8 - G10: post-processing glue and pre-filters, recorded from the
+# reference's OWN functions run on the row-list frame of tests/golden/refframe.py (round 4)
+def post_table(rows):
+    """Oracle / product rows -> the sorted plain table g8 / g9 record (tests/golden/gen_golden.py: _table)."""
+    comp = any("motif_complement" in r for r in rows)
+    out = []
+    for r in rows:
+        row = [r["reference"], r["motif"], r["mod_type"], int(r["mod_position"]), int(r["n_mod"]), int(r["n_nomod"]),
+               float(r["score"]), r["motif_iupac"], int(r["mod_position_iupac"])]
+        if comp:
+            none = r.get("motif_complement") is None
+            row += [None if none else r["motif_complement"], None if none else int(r["mod_position_complement"]),
+                    None if none else int(r["n_mod_complement"]), None if none else int(r["n_nomod_complement"]),
+                    None if none else r["motif_iupac_complement"], None if none else int(r["mod_position_iupac_complement"])]
+        out.append(row)
+    return sorted(out, key=lambda x: [("" if v is None else str(v)) for v in x])
+
+
+def assert_tables_equal(got, exp, what):
+    assert len(got) == len(exp), (what, got, exp)
+    for g, e in zip(got, exp):
+        assert len(g) == len(e), (what, g, e)
+        for i, (a, b) in enumerate(zip(g, e)):
+            if i == 6:                                        # the score: float64, same operation order
+                assert a == pytest.approx(b, rel=0, abs=1e-9), (what, g, e)
+            else:
+                assert a == b, (what, g, e)
+
+
+def g8_case_inputs(g, case):
+    """(oracle pileups per mod type, sequences, input rows) of one g8 case."""
+    mg = synth.make_metagenome(spec_from_json(g["bins"][case["bin"]]))
+    piles, seqs = {}, None
+    for mt in case["mod_types"]:
+        piles[mt], seqs = oracle_bin_inputs(mg, mt)
+    rows = []
+    for motif, pos, mt, counts, score in case["input"]:
+        model = BetaBernoulliModel()
+        model.update(*counts)
+        rows.append(opp.derive(dict(reference="bin0", motif=motif, mod_type=mt, mod_position=pos, model=model, score=score)))
+    return piles, seqs, rows
+
+
+def oracle_post_stages(rows, piles, seqs):
+    """The chain of find_motifs_bin.py:555-593 on a frame that may hold several (reference, mod_type) groups."""
+    stages = {}
+    rows = opp.remove_noisy_motifs(rows)
+    stages["noise"] = rows
+    groups = {}
+    for r in rows:
+        groups.setdefault((r["reference"], r["mod_type"]), []).append(r)
+    merged = []
+    for (_, mt), grp in groups.items():
+        merged += opp.merge_motifs_in_rows(grp, piles[mt], seqs)
+    rows = opp.unique_rows(merged)
+    stages["merge"] = rows
+    groups = {}
+    for r in rows:
+        groups.setdefault((r["reference"], r["mod_type"]), []).append(r)
+    kept = []
+    for grp in groups.values():
+        kept += opp.remove_sub_motifs(grp)
+    rows = opp.unique_rows(kept)
+    stages["sub"] = rows
+    stages["complement"] = opp.join_motif_complements(rows)
+    return stages
+
+
+def test_g8_postprocess_glue_equals_the_reference_functions():
+    g = load_golden("g8_postprocess_glue.json")
+    assert len(g["cases"]) >= 12
+    fired = set()
+    for case in g["cases"]:
+        assert not case["a_stage_held_one_motif_twice"]      # no recorded value rests on polars' Object-cell equality
+        piles, seqs, rows = g8_case_inputs(g, case)
+        # the input counts themselves were computed by the reference's motif_model_bin
+        for r, (motif, pos, mt, counts, _) in zip(rows, case["input"]):
+            m = osc.motif_model_bin(piles[mt], seqs, Motif(motif, pos), BetaBernoulliModel(), 0.3, 0.7)
+            assert list(m.get_raw_counts()) == counts, (case["name"], motif)
+        stages = oracle_post_stages(rows, piles, seqs)
+        for name in ("noise", "merge", "sub", "complement"):
+            assert_tables_equal(post_table(stages[name]), case["stages"][name], (case["name"], name))
+        n_in, n_noise, n_merge, n_sub = len(case["input"]), len(case["stages"]["noise"]), len(case["stages"]["merge"]), len(case["stages"]["sub"])
+        if n_noise < n_in:
+            fired.add("noise")
+        if any("[" in r[1] for r in case["stages"]["merge"]):
+            fired.add("degenerate merge")
+        if n_merge == n_noise and "rejected" in case["name"]:
+            fired.add("rejected merge")
+        if n_sub < n_merge:
+            fired.add("sub-motif")
+        if len(case["stages"]["complement"]) != n_sub:
+            fired.add("complement join changes the row count")
+    assert fired == {"noise", "degenerate merge", "rejected merge", "sub-motif", "complement join changes the row count"}
+
+
+def test_g9_process_subpileup_stage_tables():
+    """process_subpileup itself (find_motifs_bin.py:468-596) run from the reference on six bins: every stage table it writes
+    and its return value against the oracle's search + post-processing chain."""
+    g = load_golden("g9_process_subpileup.json")
+    for name, rec in g.items():
+        mg = synth.make_metagenome(spec_from_json(rec["spec"]))
+        pile, seqs = oracle_bin_inputs(mg, rec["mod_type"])
+        p = rec["params"]
+        random.seed(p["seed"])
+        res = ose.find_best_candidates(pile, seqs, rec["mod_type"], p["low"], p["high"], p["padding"], min_kl=p["min_kl"],
+                                       score_threshold=p["score_threshold"])
+        if rec["final"] is None and not rec["stages"]:
+            assert res is None or not opp.graph_to_rows(res[0], res[1], "bin0", rec["mod_type"], p["padding"]), name
+            continue
+        rows = opp.graph_to_rows(res[0], res[1], "bin0", rec["mod_type"], p["padding"])
+        assert_tables_equal(post_table(rows), rec["stages"]["motifs"], (name, "motifs"))
+        stages = oracle_post_stages(rows, {rec["mod_type"]: pile}, seqs)
+        for ours, theirs in (("noise", "motifs-noise"), ("merge", "motifs-noise-merge"), ("sub", "motifs-noise-merge-sub"),
+                             ("complement", "motifs-noise-merge-sub-complement")):
+            assert_tables_equal(post_table(stages[ours]), rec["stages"][theirs], (name, theirs))
+        final = opp.process_bin(pile, seqs, "bin0", rec["mod_type"], res[0], res[1], p["padding"])
+        assert_tables_equal(post_table(final or []), rec["final"] or [], (name, "final"))
+
+
+def g10_table(g):
+    """The input table of g10, rebuilt from its seed (tests/golden/gen_golden.py: g10) as an oracle.pileup table."""
+    rng = np.random.default_rng(g["seed"])
+    cols = {"contig": [], "mod_type": [], "fraction_mod": [], "Nvalid_cov": [], "position": []}
+    for contig, mt, n, n_mod, _ in g["groups"][:-1]:
+        frac = rng.integers(0, 7000, n).astype(np.float64) / 10000.0
+        frac[rng.choice(n, n_mod, replace=False)] = rng.integers(7001, 10001, n_mod) / 10000.0
+        if contig == "c_ok" and mt == "a":
+            frac[np.flatnonzero(frac <= 0.7)[:5]] = 0.7
+        if contig.startswith("c_null"):
+            frac[np.flatnonzero(frac <= 0.7)[:100 if contig == "c_null" else 100_002]] = np.nan
+        cols["contig"] += [contig] * n
+        cols["mod_type"] += [mt] * n
+        cols["fraction_mod"].append(frac)
+        cols["Nvalid_cov"].append(rng.integers(6, 60, n))
+        cols["position"].append(np.arange(n, dtype=np.int64))
+    n = 10_000
+    frac = rng.integers(0, 7000, n).astype(np.float64) / 10000.0
+    hot = rng.choice(n, 55, replace=False)
+    frac[hot] = 0.9
+    cov = rng.integers(6, 60, n)
+    cov[hot[:5]] = 5
+    cov[hot[5:8]] = 6
+    cols["contig"] += ["c_cov"] * n
+    cols["mod_type"] += ["a"] * n
+    cols["fraction_mod"].append(frac)
+    cols["Nvalid_cov"].append(cov)
+    cols["position"].append(np.arange(n, dtype=np.int64))
+    t = dict(contig=np.array(cols["contig"], dtype=object), mod_type=np.array(cols["mod_type"], dtype=object),
+             fraction_mod=np.concatenate(cols["fraction_mod"]), Nvalid_cov=np.concatenate(cols["Nvalid_cov"]).astype(np.int64),
+             position=np.concatenate(cols["position"]))
+    t["strand"] = np.full(len(t["position"]), ord("+"), dtype=np.uint8)
+    assert len(t["position"]) == g["n_rows"]
+    for k in ("fraction_mod", "Nvalid_cov", "position"):
+        assert sha1(t[k]) == g["input_sha1"][k], f"g10 input column {k} drifted"
+    t["row"] = np.arange(len(t["position"]), dtype=np.int64)
+    return t
+
+
+def test_g10_coverage_and_frequency_filters():
+    """dataload.filter_pileup + filter_pileup_minimummod_frequency (dataload.py:191-226) run from the reference: the strict
+    bounds (> 5, > 50, > 1e-4, fraction > 0.7) and a null percentage counting as a position of its group."""
+    g = load_golden("g10_frequency_filter.json")
+    t = g10_table(g)
+    a = op.filter_pileup(t)
+    assert len(a["row"]) == g["after_coverage"] and sha1(a["row"]) == g["after_coverage_rows_sha1"]
+    b = op.filter_pileup_minimummod_frequency(a)
+    assert len(b["row"]) == g["after_frequency"] and sha1(b["row"]) == g["after_frequency_rows_sha1"]
+    kept = {}
+    for c, m in zip(b["contig"].tolist(), b["mod_type"].tolist()):
+        kept[f"{c}|{m}"] = kept.get(f"{c}|{m}", 0) + 1
+    assert kept == g["kept_groups"]
+    assert "c_null_tip|m" not in kept and "c_ratio_eq|a" not in kept and "c_ok|m" not in kept and "c_cov|a" not in kept

@@ -5,7 +5,9 @@ mkdir -p gpurun_out/lds_proto
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -Wno-int-to-pointer-cast -o /tmp/lds_proto tools/lds_proto.hip || exit 1
 {
 timeout 300 /tmp/lds_proto 66 10 1
-timeout 300 /tmp/lds_proto 122072 10 0
-timeout 300 /tmp/lds_proto 122072 4 0
-timeout 300 /tmp/lds_proto 122072 16 0
+for f in 0 1 2 3; do
+for c in 0 4 10 16; do
+timeout 300 /tmp/lds_proto 122072 $c 0 $f
+done
+done
 } 2>&1 | tee gpurun_out/lds_proto/out.txt
