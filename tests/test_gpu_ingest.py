@@ -303,3 +303,46 @@ def test_modkit_order_takes_the_store_path_and_equals_any_other_order():
     assert first[0] == len(exp["position"]) and first[1] > 0
     for k, v in out.items():
         assert v == first, k
+
+
+def test_g10_frequency_and_coverage_bounds_recorded_from_the_reference():
+    """The table of fixture g10 (strict bounds > 5 / > 50 / > 1e-4 / fraction > 0.7, nulls counting as positions) through the
+    device filters: the (contig, mod code) groups the REFERENCE's filter_pileup + filter_pileup_minimummod_frequency keep
+    (recorded by tests/golden/gen_golden.py from dataload.py:191-226) are the groups with surviving rows, and each holds
+    what the adjacency filter leaves of it."""
+    from helpers import load_golden
+    from nanomotif_amd.engine import ScanEngine
+    from oracle import pileup as op
+    from test_oracle_golden import g10_table
+    from helpers import sha1
+    g = load_golden("g10_frequency_filter.json")
+    t = g10_table(g)
+    ref = op.filter_pileup_minimummod_frequency(op.filter_pileup(t))
+    assert sha1(ref["row"]) == g["after_frequency_rows_sha1"]           # the restatement reproduces the reference's rows ...
+    exp = op.filter_pileup_adjacency_filter(ref)                        # ... and the KAT-pinned adjacency filter follows
+    names = sorted(set(t["contig"].tolist()))
+    codes = {"m": 0, "a": 1, "21839": 2}
+    rng = np.random.default_rng(3)
+    lengths = {c: int(t["position"][t["contig"] == c].max()) + 1 for c in names}
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, ["".join(rng.choice(list("ACGT"), size=lengths[c])) for c in names], ["b"] * len(names))
+    cid = np.array([names.index(c) for c in t["contig"].tolist()], dtype=np.uint32)
+    mod = np.array([codes[m] for m in t["mod_type"].tolist()], dtype=np.int8)
+    frac = np.where(np.isnan(t["fraction_mod"]), -0.01, t["fraction_mod"])       # the reader's null: percentage -1
+    for order in ("grouped", "shuffled"):                                # modkit order (store path) and any other order
+        idx = np.arange(len(cid))
+        if order == "grouped":
+            idx = np.lexsort((t["position"], mod, cid))
+        else:
+            np.random.default_rng(5).shuffle(idx)
+        res = eng.ingest_pileup(cid[idx], t["position"][idx], mod[idx], t["strand"][idx], frac[idx], t["Nvalid_cov"][idx],
+                                {0: ("m", "C"), 1: ("a", "A"), 2: ("21839", "C")}, want_rows=False)
+        kept = {}
+        for c, m in zip(exp["contig"].tolist(), exp["mod_type"].tolist()):
+            kept[(names.index(c), codes[m])] = kept.get((names.index(c), codes[m]), 0) + 1
+        want = np.zeros((len(names), 8), dtype=np.int64)
+        for (c, m), n in kept.items():
+            want[c, m] = n
+        assert np.array_equal(res["kept"].astype(np.int64), want), order
+        assert {f"{names[c]}|{[k for k, v in codes.items() if v == m][0]}" for c, m in kept} == set(g["kept_groups"])
+    eng.close()

@@ -1,0 +1,108 @@
+"""The product's post-processing — the Python coroutines (nanomotif_amd/postprocess.py) and the native nm_post_run
+(csrc/nmpost.cpp) — against tables recorded from the reference's OWN functions (fixtures g8 / g9: remove_noisy_motifs,
+merge_motifs_in_df, remove_sub_motifs, join_motif_complements and process_subpileup run from /root/reference on the
+row-list frame of tests/golden/refframe.py).  Scoring requests are answered by the CPU oracle's scan (the checker)."""
+import numpy as np
+import pytest
+
+from helpers import load_golden, oracle_bin_inputs, spec_from_json
+from nanomotif_amd import native_search as ns
+from nanomotif_amd import postprocess as pp
+from nanomotif_amd import search as ps
+from nanomotif_amd import synth
+from nanomotif_amd.model import BetaBernoulliModel
+from nanomotif_amd.motif import Motif
+from test_oracle_golden import assert_tables_equal
+
+PAD = 20
+STAGES = ns.PostResults.STAGES
+
+
+def table(rows):
+    comp = any(r.has_complement_columns for r in rows)
+    out = []
+    for r in rows:
+        row = [r.reference, r.motif, r.mod_type, int(r.mod_position), int(r.n_mod), int(r.n_nomod), float(r.score), r.motif_iupac,
+               int(r.mod_position_iupac)]
+        if comp:
+            c = r.complement
+            row += [None] * 6 if c is None else [c.motif, int(c.mod_position), int(c.n_mod), int(c.n_nomod), c.motif_iupac, int(c.mod_position_iupac)]
+        out.append(row)
+    return sorted(out, key=lambda x: [("" if v is None else str(v)) for v in x])
+
+
+def oracle_scorer(keys, piles, seqs):
+    from oracle import scan as osc
+    from oracle.model import BetaBernoulliModel as OModel
+    from oracle.motif import Motif as OMotif
+
+    def score(reqs):
+        out = np.zeros((len(reqs), 2), dtype=np.int64)
+        for i, (t, m) in enumerate(reqs):
+            model = osc.motif_model_bin(piles[keys[t][1]], seqs, OMotif(m.string, int(m.mod_position)), OModel(), 0.3, 0.7)
+            out[i] = model.get_raw_counts()
+        return out
+    return score
+
+
+def both_implementations(keys, rows_per_task, score_fn):
+    """{stage name: rows of all tasks} from the Python twin and from the native library."""
+    stages = {k: {} for k in keys}
+    tasks = {}
+    for key, rows in zip(keys, rows_per_task):
+        g, best = ps.MotifTree(), []
+        for s, n_mod, n_nomod, sc in rows:
+            m = Motif(s, PAD)
+            g.add_node(m, model=BetaBernoulliModel.from_counts(n_mod, n_nomod), score=sc)
+            best.append(m)
+        tasks[key] = pp.postprocess_co(g, best, key[0], key[1], PAD, on_stage=lambda name, r, key=key: stages[key].__setitem__(name, list(r)))
+    final = ps.run_lockstep(tasks, lambda flat: score_fn([(keys.index(k), m) for k, m, _ in flat]))
+    py = {name: [r for k in keys for r in stages[k].get(name, [])] for name in STAGES}
+    post = ns.postprocess_rows_custom(keys, rows_per_task, PAD, score_fn)
+    native = {name: [r for t in range(len(keys)) for r in post.rows(t, s)] for s, name in enumerate(STAGES)}
+    py_final = [r for k in keys for r in (final.get(k) or [])]
+    native_final = [r for t in range(len(keys)) for r in (post.final(t) or [])]
+    return py, native, py_final, native_final
+
+
+def test_g8_both_implementations_equal_the_reference_stage_tables():
+    g = load_golden("g8_postprocess_glue.json")
+    for case in g["cases"]:
+        mg = synth.make_metagenome(spec_from_json(g["bins"][case["bin"]]))
+        piles, seqs = {}, None
+        for mt in case["mod_types"]:
+            piles[mt], seqs = oracle_bin_inputs(mg, mt)
+        keys = [("bin0", mt) for mt in case["mod_types"]]
+        rows = [[(m, c[0], c[1], sc) for m, pos, mt2, c, sc in case["input"] if mt2 == mt] for mt in case["mod_types"]]
+        assert all(pos == PAD for _, pos, _, _, _ in case["input"])
+        py, native, _, _ = both_implementations(keys, rows, oracle_scorer(keys, piles, seqs))
+        for ours, theirs in zip(STAGES[1:], ("noise", "merge", "sub", "complement")):
+            exp = case["stages"][theirs]
+            if not exp:
+                continue
+            assert_tables_equal(table(py[ours]), exp, (case["name"], theirs, "python twin"))
+            assert_tables_equal(table(native[ours]), exp, (case["name"], theirs, "nm_post_run"))
+
+
+def test_g9_both_implementations_equal_process_subpileup():
+    """Input: the graph rows process_subpileup starts from (its first stage table, in the reference's score-descending
+    order); every later table and the return value must come out of both implementations."""
+    g = load_golden("g9_process_subpileup.json")
+    seen = 0
+    for name, rec in g.items():
+        if not rec["stages"]:
+            continue
+        mg = synth.make_metagenome(spec_from_json(rec["spec"]))
+        mt = rec["mod_type"]
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        keys = [("bin0", mt)]
+        first = sorted(rec["stages"]["motifs"], key=lambda r: -r[6])
+        rows = [[(r[1], r[4], r[5], r[6]) for r in first]]
+        py, native, py_final, native_final = both_implementations(keys, rows, oracle_scorer(keys, {mt: pile}, seqs))
+        for stage in STAGES:
+            assert_tables_equal(table(py[stage]), rec["stages"][stage], (name, stage, "python twin"))
+            assert_tables_equal(table(native[stage]), rec["stages"][stage], (name, stage, "nm_post_run"))
+        assert_tables_equal(table(py_final), rec["final"] or [], (name, "final", "python twin"))
+        assert_tables_equal(table(native_final), rec["final"] or [], (name, "final", "nm_post_run"))
+        seen += 1
+    assert seen >= 5

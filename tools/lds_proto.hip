@@ -18,17 +18,25 @@
 
 typedef const uint32_t __attribute__((address_space(4))) *cu32p;
 
-constexpr int ENT = 128;            // entries per chunk and plane
-constexpr int HALO = 32;            // extension entries either side (offsets in [-32, 31])
+constexpr int ENT = 64;             // entries (128 bits each) per chunk and plane: entry i, bit b <-> offset i + 64 b
+#ifndef HALO
+#define HALO 32                     // extension entries either side (offsets in [-HALO, HALO - 1])
+#endif
+#ifndef BOTH
+#define BOTH 0                      // 1: the reads of both strands are issued before the first is consumed
+#endif
+#ifndef WAVES
+#define WAVES 5
+#endif
 constexpr int ROW = ENT + 2 * HALO; // entries of one plane row in LDS
-constexpr int ROW_B = ROW * 8;
+constexpr int ROW_B = ROW * 16;
 constexpr int TILE_B = 4 * ROW_B;   // four is-X planes
 constexpr int SEG = 16;             // chunks per workgroup
 constexpr int MAXC = 16;            // candidates per pass
 constexpr int PROG_DW = 32;         // [0] n_f, [1] n_r, [2..15] forward byte offsets, [18..31] reverse
 
 struct Args {
-    const uint2 *H, *L, *M, *U;     // transposed planes, 128 uint2 per chunk (M / U per slot: slot s at + s * plane stride)
+    const uint4 *H, *L, *M, *U;     // transposed planes, 64 uint4 per chunk (M / U per slot: slot s at + s * plane stride)
     size_t state_stride;            // entries between the slots' state planes
     uint32_t n_chunks;              // scored chunks are [1, n_chunks - 1)
     const uint32_t *prog;           // [n_cand][PROG_DW]
@@ -38,71 +46,76 @@ struct Args {
 };
 
 struct Raw {
-    uint2 h0, h1, l0, l1, m0, m1, u0, u1, hn, ln;
+    uint4 h, l, m, u, hn, ln;
 };
 
 __device__ __forceinline__ Raw load_raw(const Args &a, uint32_t chunk, uint32_t slot, int lane) {
     Raw r;
     const size_t b = (size_t)chunk * ENT + lane;
-    r.h0 = a.H[b]; r.h1 = a.H[b + 64];
-    r.l0 = a.L[b]; r.l1 = a.L[b + 64];
+    r.h = a.H[b];
+    r.l = a.L[b];
     const size_t sb = b + slot * a.state_stride;
-    r.m0 = a.M[sb]; r.m1 = a.M[sb + 64];
-    r.u0 = a.U[sb]; r.u1 = a.U[sb + 64];
-    // lanes 0..31: entry `lane` of the NEXT chunk; lanes 32..63: entry 64 + lane of the PREVIOUS chunk
-    const size_t nb = lane < 32 ? b + ENT : b - ENT + 64;
-    r.hn = a.H[nb]; r.ln = a.L[nb];
+    r.m = a.M[sb];
+    r.u = a.U[sb];
+    // lanes 0..HALO-1: entry `lane` of the NEXT chunk; lanes 64-HALO..63: entry `lane` of the PREVIOUS chunk
+    r.hn = r.ln = make_uint4(0, 0, 0, 0);
+    if (lane < HALO || lane >= 64 - HALO) {
+        const size_t nb = lane < HALO ? b + ENT : b - ENT;
+        r.hn = a.H[nb];
+        r.ln = a.L[nb];
+    }
     return r;
 }
 
-__device__ __forceinline__ uint2 plane_of(int p, uint2 h, uint2 l) {
-    uint2 r;
-    switch (p) {
-    case 0: r.x = ~h.x & ~l.x; r.y = ~h.y & ~l.y; break;   // A = 00
-    case 1: r.x = ~h.x & l.x;  r.y = ~h.y & l.y;  break;   // C = 01
-    case 2: r.x = h.x & l.x;   r.y = h.y & l.y;   break;   // G = 11
-    default: r.x = h.x & ~l.x; r.y = h.y & ~l.y; break;    // T = 10
-    }
-    return r;
+__device__ __forceinline__ uint32_t plane1(int p, uint32_t h, uint32_t l) {
+    return p == 0 ? ~h & ~l : p == 1 ? ~h & l : p == 2 ? h & l : h & ~l;      // A = 00, C = 01, G = 11, T = 10
+}
+__device__ __forceinline__ uint4 plane_of(int p, uint4 h, uint4 l) {
+    return make_uint4(plane1(p, h.x, l.x), plane1(p, h.y, l.y), plane1(p, h.z, l.z), plane1(p, h.w, l.w));
 }
 
 __device__ __forceinline__ void build_tile(char *tile, const Raw &r, int lane) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const uint2 e0 = plane_of(p, r.h0, r.l0), e1 = plane_of(p, r.h1, r.l1), en = plane_of(p, r.hn, r.ln);
-        *(uint2 *)(tile + p * ROW_B + (HALO + lane) * 8) = e0;
-        *(uint2 *)(tile + p * ROW_B + (HALO + 64 + lane) * 8) = e1;
-        // extension: lanes 0..31 -> entry ENT + lane = own entry `lane` one bit down, top bit from the next chunk;
-        //            lanes 32..63 -> entry lane - 64 (row index lane - 32) = own entry 64 + lane one bit up, low bit from the previous chunk
-        uint2 x;
-        if (lane < 32) {
-            x.x = (e0.x >> 1) | (e0.y << 31);
-            x.y = (e0.y >> 1) | (en.x << 31);
-        } else {
-            x.y = (e1.y << 1) | (e1.x >> 31);
-            x.x = (e1.x << 1) | (en.y >> 31);
+        const uint4 e = plane_of(p, r.h, r.l), en = plane_of(p, r.hn, r.ln);
+        *(uint4 *)(tile + p * ROW_B + (HALO + lane) * 16) = e;
+        // extension: lanes 0..HALO-1 -> entry ENT + lane = own entry one bit down, top bit from the next chunk;
+        //            lanes 64-HALO..63 -> entry lane - 64 = own entry one bit up, low bit from the previous chunk
+        if (lane < HALO) {
+            uint4 x;
+            x.x = __builtin_amdgcn_alignbit(e.y, e.x, 1);
+            x.y = __builtin_amdgcn_alignbit(e.z, e.y, 1);
+            x.z = __builtin_amdgcn_alignbit(e.w, e.z, 1);
+            x.w = __builtin_amdgcn_alignbit(en.x, e.w, 1);
+            *(uint4 *)(tile + p * ROW_B + (HALO + ENT + lane) * 16) = x;
+        } else if (lane >= 64 - HALO) {
+            uint4 x;
+            x.w = __builtin_amdgcn_alignbit(e.w, e.z, 31);
+            x.z = __builtin_amdgcn_alignbit(e.z, e.y, 31);
+            x.y = __builtin_amdgcn_alignbit(e.y, e.x, 31);
+            x.x = __builtin_amdgcn_alignbit(e.x, en.w, 31);
+            *(uint4 *)(tile + p * ROW_B + (lane - (64 - HALO)) * 16) = x;
         }
-        const int row_idx = lane < 32 ? HALO + ENT + lane : lane - 32;
-        *(uint2 *)(tile + p * ROW_B + row_idx * 8) = x;
     }
 }
 
-typedef const volatile unsigned long long __attribute__((address_space(3))) *lds64p;
-#define RD(i) { const unsigned long long q0_ = *(lds64p)(row + off[i]); const unsigned long long q1_ = *(lds64p)(row + off[i] + 512); r0[i] = make_uint2((uint32_t)q0_, (uint32_t)(q0_ >> 32)); r1[i] = make_uint2((uint32_t)q1_, (uint32_t)(q1_ >> 32)); }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const volatile u32x4 __attribute__((address_space(3))) *lds128p;
+#define RD(i) { const u32x4 q_ = *(lds128p)(row + off[i]); r[i] = make_uint4(q_.x, q_.y, q_.z, q_.w); }
 #define B3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x80)
-#define AN2(i, j) { a0.x = B3(a0.x, r0[i].x, r0[j].x); a0.y = B3(a0.y, r0[i].y, r0[j].y); a1.x = B3(a1.x, r1[i].x, r1[j].x); a1.y = B3(a1.y, r1[i].y, r1[j].y); }
-#define AN1(i) { a0.x &= r0[i].x; a0.y &= r0[i].y; a1.x &= r1[i].x; a1.y &= r1[i].y; }
+#define AN2(i, j) { acc.x = B3(acc.x, r[i].x, r[j].x); acc.y = B3(acc.y, r[i].y, r[j].y); acc.z = B3(acc.z, r[i].z, r[j].z); acc.w = B3(acc.w, r[i].w, r[j].w); }
+#define AN1(i) { acc.x &= r[i].x; acc.y &= r[i].y; acc.z &= r[i].z; acc.w &= r[i].w; }
 
-// acc &= every constraint of one strand; off[] = byte offsets into the tile (plane row + entry shift), n wave-uniform
-__device__ __forceinline__ void eval_strand(const uint32_t row, const uint32_t (&off)[8], uint32_t n, uint2 &a0, uint2 &a1) {
-    // off[0]: the single constraint when n is odd; then pairs.  Every step is a plain wave-uniform `if`: reads of all
-    // constraints first (16 ds_read_b64 in flight at most), then one three-input AND per pair and half-row.
-    uint2 r0[8], r1[8];
+// off[0]: the single constraint when n is odd; then pairs.  Every step is a plain wave-uniform `if`.
+__device__ __forceinline__ void issue_strand(const uint32_t row, const uint32_t (&off)[8], uint32_t n, uint4 (&r)[8]) {
     const uint32_t odd = n & 1u, np = n >> 1;
     if (odd) RD(0)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         if (np > (uint32_t)i) { RD(1 + 2 * i) RD(2 + 2 * i) }
+}
+__device__ __forceinline__ void consume_strand(uint32_t n, const uint4 (&r)[8], uint4 &acc) {
+    const uint32_t odd = n & 1u, np = n >> 1;
     if (odd) AN1(0)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -110,28 +123,37 @@ __device__ __forceinline__ void eval_strand(const uint32_t row, const uint32_t (
 }
 
 template <int CAN>
-__device__ __forceinline__ void score_chunk(const Args &a, const char *tile, const Raw &r, uint32_t *cnt, int lane) {
+__device__ __forceinline__ void score_chunk(const Args &a, const char *tile, const Raw &raw, uint32_t *cnt, int lane) {
     // canonical plane / its complement at offset 0 start the accumulators (the modified base's own constraint)
-    const uint2 f0 = plane_of(CAN ? 1 : 0, r.h0, r.l0), f1 = plane_of(CAN ? 1 : 0, r.h1, r.l1);
-    const uint2 g0 = plane_of(CAN ? 2 : 3, r.h0, r.l0), g1 = plane_of(CAN ? 2 : 3, r.h1, r.l1);
-    const uint32_t row = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)tile + (HALO + lane) * 8;
+    const uint4 f0 = plane_of(CAN ? 1 : 0, raw.h, raw.l), g0 = plane_of(CAN ? 2 : 3, raw.h, raw.l);
+    const uint32_t row = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)tile + (HALO + lane) * 16;
     for (uint32_t k = 0; k < a.n_cand; ++k) {
         cu32p prog = (cu32p)(a.prog + (size_t)k * PROG_DW);
         const uint32_t nf = prog[0], nr = prog[1];
         uint32_t of[8], orv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { of[i] = prog[2 + i]; orv[i] = prog[18 + i]; }
-        uint2 af0 = f0, af1 = f1, ar0 = g0, ar1 = g1;
-        eval_strand(row, of, nf, af0, af1);
-        eval_strand(row, orv, nr, ar0, ar1);
-        const uint32_t s0 = af0.x | ar0.x, s1 = af0.y | ar0.y, s2 = af1.x | ar1.x, s3 = af1.y | ar1.y;
-        const uint32_t n_mod = __popc(s0 & r.m0.x) + __popc(s1 & r.m0.y) + __popc(s2 & r.m1.x) + __popc(s3 & r.m1.y);
-        const uint32_t n_non = __popc(s0 & r.u0.x) + __popc(s1 & r.u0.y) + __popc(s2 & r.u1.x) + __popc(s3 & r.u1.y);
+        uint4 af = f0, ar = g0;
+        uint4 rf[8], rr[8];
+        if (BOTH) {
+            issue_strand(row, of, nf, rf);
+            issue_strand(row, orv, nr, rr);
+            consume_strand(nf, rf, af);
+            consume_strand(nr, rr, ar);
+        } else {
+            issue_strand(row, of, nf, rf);
+            consume_strand(nf, rf, af);
+            issue_strand(row, orv, nr, rr);
+            consume_strand(nr, rr, ar);
+        }
+        const uint32_t s0 = af.x | ar.x, s1 = af.y | ar.y, s2 = af.z | ar.z, s3 = af.w | ar.w;
+        const uint32_t n_mod = __popc(s0 & raw.m.x) + __popc(s1 & raw.m.y) + __popc(s2 & raw.m.z) + __popc(s3 & raw.m.w);
+        const uint32_t n_non = __popc(s0 & raw.u.x) + __popc(s1 & raw.u.y) + __popc(s2 & raw.u.z) + __popc(s3 & raw.u.w);
         atomicAdd(&cnt[k * 64 + lane], n_mod | (n_non << 16));
     }
 }
 
-__global__ __launch_bounds__(256) void score_t_kernel(Args a) {
+__global__ __launch_bounds__(256, WAVES) void score_t_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *cnt = (uint32_t *)smem;                              // [MAXC][64] packed n_mod | n_non << 16
     const int lane = threadIdx.x & 63;
@@ -142,18 +164,14 @@ __global__ __launch_bounds__(256) void score_t_kernel(Args a) {
     const uint32_t c1 = min(c0 + SEG, a.n_chunks - 1);
     for (uint32_t i = threadIdx.x; i < MAXC * 64; i += 256) cnt[i] = 0;
     __syncthreads();
-    uint32_t ck = c0 + wave;
-    if (ck < c1) {
-        Raw cur = load_raw(a, ck, slot, lane);
-        for (; ck < c1; ck += 4) {
-            Raw nxt;
-            const bool more = ck + 4 < c1;
-            if (more && !(a.flags & 2)) nxt = load_raw(a, ck + 4, slot, lane);
-            if (!(a.flags & 1)) build_tile(tile, cur, lane);
-            if (slot) score_chunk<1>(a, tile, cur, cnt, lane);
-            else score_chunk<0>(a, tile, cur, cnt, lane);
-            if (more && !(a.flags & 2)) cur = nxt;
-        }
+    Raw cur;
+    bool have = false;
+    for (uint32_t ck = c0 + wave; ck < c1; ck += 4) {
+        if (!have || !(a.flags & 2)) cur = load_raw(a, ck, slot, lane);
+        have = true;
+        if (!(a.flags & 1)) build_tile(tile, cur, lane);
+        if (slot) score_chunk<1>(a, tile, cur, cnt, lane);
+        else score_chunk<0>(a, tile, cur, cnt, lane);
     }
     __syncthreads();
     for (uint32_t idx = threadIdx.x; idx < a.n_cand * 2; idx += 256) {
@@ -199,29 +217,33 @@ int main(int argc, char **argv) {
             mean_reads += 2.0 * c.off.size();
             const size_t shift = (c.off.size() & 1) ? 0 : 1;     // even: slot 0 (the single) stays unused
             for (size_t j = 0; j < c.off.size(); ++j) {
-                p[2 + shift + j] = (uint32_t)(c.base[j] * ROW_B + c.off[j] * 8);                 // forward: base at +off
-                p[18 + shift + j] = (uint32_t)((3 - c.base[j]) * ROW_B + (-c.off[j]) * 8);       // reverse: complement (A<->T, C<->G = 3 - b) at -off
+                p[2 + shift + j] = (uint32_t)(c.base[j] * ROW_B + c.off[j] * 16);                 // forward: base at +off
+                p[18 + shift + j] = (uint32_t)((3 - c.base[j]) * ROW_B + (-c.off[j]) * 16);       // reverse: complement (A<->T, C<->G = 3 - b) at -off
             }
         }
     mean_reads /= 2.0 * n_cand;
     // data
-    std::vector<uint64_t> H((size_t)n_chunks * ENT), L(H.size()), M(2 * H.size()), U(2 * H.size());
+    // an entry is 128 bits = two uint64 halves: entry i, bit b <-> offset i + 64 b
+    const size_t NE = (size_t)n_chunks * ENT * 2;
+    std::vector<uint64_t> H(NE), L(NE), M(2 * NE), U(2 * NE);
     std::vector<uint8_t> seq;
     if (check) seq.resize(n_pos);
     for (size_t c = 0; c < n_chunks; ++c)
-        for (int i = 0; i < ENT; ++i) {
-            const uint64_t h = rng(), l = rng(), m = rng() & rng(), u = rng() & ~m;
-            H[c * ENT + i] = h; L[c * ENT + i] = l;
-            // slot 0 (6mA): rows on A (fwd) and T (rev): h=0,l=0 / h=1,l=0 -> ~l ; slot 1 (5mC): C and G -> l
-            M[c * ENT + i] = m & ~l; U[c * ENT + i] = u & ~l;
-            M[H.size() + c * ENT + i] = m & l; U[H.size() + c * ENT + i] = u & l;
-            if (check)
-                for (int b = 0; b < 64; ++b) {
-                    const int hb = (h >> b) & 1, lb = (l >> b) & 1;
-                    seq[c * 8192 + i + 128 * b] = (uint8_t)(hb == 0 ? (lb ? 1 : 0) : (lb ? 2 : 3));
-                }
-        }
-    uint2 *dH, *dL, *dM, *dU; uint32_t *dprog; unsigned long long *dout;
+        for (int i = 0; i < ENT; ++i)
+            for (int half = 0; half < 2; ++half) {
+                const uint64_t h = rng(), l = rng(), m = rng() & rng(), u = rng() & ~m;
+                const size_t w = (c * ENT + i) * 2 + half;
+                H[w] = h; L[w] = l;
+                // slot 0 (6mA): rows on A (fwd) and T (rev): l = 0; slot 1 (5mC): C and G: l = 1
+                M[w] = m & ~l; U[w] = u & ~l;
+                M[NE + w] = m & l; U[NE + w] = u & l;
+                if (check)
+                    for (int b = 0; b < 64; ++b) {
+                        const int hb = (h >> b) & 1, lb = (l >> b) & 1;
+                        seq[c * 8192 + i + 64 * (64 * half + b)] = (uint8_t)(hb == 0 ? (lb ? 1 : 0) : (lb ? 2 : 3));
+                    }
+            }
+    uint4 *dH, *dL, *dM, *dU; uint32_t *dprog; unsigned long long *dout;
     CHK(hipMalloc(&dH, H.size() * 8)); CHK(hipMalloc(&dL, H.size() * 8)); CHK(hipMalloc(&dM, M.size() * 8)); CHK(hipMalloc(&dU, U.size() * 8));
     CHK(hipMalloc(&dprog, prog.size() * 4)); CHK(hipMalloc(&dout, 2 * (size_t)n_cand * 2 * 8));
     CHK(hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice)); CHK(hipMemcpy(dL, L.data(), H.size() * 8, hipMemcpyHostToDevice));
@@ -229,7 +251,7 @@ int main(int argc, char **argv) {
     CHK(hipMemcpy(dprog, prog.data(), prog.size() * 4, hipMemcpyHostToDevice));
     CHK(hipMemset(dout, 0, 2 * (size_t)n_cand * 2 * 8));
     const uint32_t flags = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
-    Args a{dH, dL, dM, dU, H.size(), n_chunks, dprog, n_cand, dout, flags};
+    Args a{dH, dL, dM, dU, NE / 2, n_chunks, dprog, n_cand, dout, flags};
     const uint32_t n_seg = (n_chunks - 2 + SEG - 1) / SEG;
     const size_t lds = MAXC * 64 * 4 + 4 * TILE_B;
     CHK(hipFuncSetAttribute((const void *)score_t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -259,10 +281,10 @@ int main(int argc, char **argv) {
                         if (r && seq[p - c.off[j]] != 3 - c.base[j]) r = false;
                     }
                     if (!f && !r) continue;
-                    const size_t ch = p / 8192, o = p % 8192, e = ch * ENT + (o & 127), b = o >> 7;
-                    const size_t so = slot * H.size();
-                    nm += (M[so + e] >> b) & 1;
-                    nn += (U[so + e] >> b) & 1;
+                    const size_t ch = p / 8192, o = p % 8192, bit = o >> 6, w = (ch * ENT + (o & 63)) * 2 + (bit >> 6);
+                    const size_t so = slot * NE;
+                    nm += (M[so + w] >> (bit & 63)) & 1;
+                    nn += (U[so + w] >> (bit & 63)) & 1;
                 }
                 const unsigned long long gm = out[((size_t)slot * n_cand + k) * 2], gn = out[((size_t)slot * n_cand + k) * 2 + 1];
                 if (gm != nm || gn != nn) { ++bad; printf("MISMATCH slot %d cand %u: gpu %llu %llu cpu %llu %llu (n=%zu)\n", slot, k, gm, gn, nm, nn, c.off.size()); }
