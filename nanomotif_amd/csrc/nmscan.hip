@@ -199,17 +199,6 @@ __device__ __forceinline__ void score_candidates(const ScoreArgs &a, const Tile<
             for (int t = 0; t < T_WORDS; ++t) accr[t] = baser[t];
             eval_masks<K>(mr, tile, accr);
         }
-#ifdef NM_EXP_SKIP_EMPTY
-        {   // experiment (round 3): skip the count stage when no lane of the wave holds a site of this candidate.  Same-device
-            // A/B, three rounds (profiles/r3/ab_skip_empty_count_stage.txt): cfg 5 kernel 0.514 -> 0.530 ms (3 % SLOWER: a
-            // 5.5-constraint candidate has ~8 sites per 8192-bp chunk, the wave is almost never empty and pays the test),
-            // greedy rounds +1-2 %.  Not compiled in.
-            uint32_t any = 0;
-#pragma unroll
-            for (int t = 0; t < T_WORDS; ++t) any |= accf[t] | accr[t];
-            if (__ballot(any != 0) == 0) continue;
-        }
-#endif
         uint32_t n_mod = 0, n_non = 0;
 #pragma unroll
         for (int t = 0; t < T_WORDS; ++t) {
@@ -278,15 +267,21 @@ __device__ __forceinline__ void score_piece(const ScoreArgs &a, const uint4 sg, 
         Tile<K> tile;
         tile.expand(cur);
         const uint32_t rank = K::PC ? ((cu32p)a.chunk_rank)[chunk] : 0u;
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-            if (range[j].y <= pass0) continue;                       // wave-uniform
+        // one slot at a time with the slot index a compile-time constant: left to `#pragma unroll`, the optimizer gave up on
+        // the NS = 2 non-literal bodies ("loop not unrolled") and indexed cur.s[j] / range[j] / is_c[j] through private
+        // memory — 192-288 bytes of scratch per lane in five variants (round-3 review)
+        auto one_slot = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (range[j].y <= pass0) return;                         // wave-uniform
             const uint32_t nbj = min(H, range[j].y - pass0);
             if (K::COMPACT && is_c[j])
                 score_candidates<K, 1>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane, rank);
             else
                 score_candidates<K, 0>(a, tile, cur.s[j], range[j].x + pass0, nbj, range[j].z, range[j].w != 0, lds_acc, j, lane, rank);
-        }
+        };
+        one_slot(std::integral_constant<int, 0>{});
+        if constexpr (NS > 1) one_slot(std::integral_constant<int, 1>{});
+        static_assert(NS <= 2, "slot fusion is written for one or two slots");
     };
     auto clear_rows = [&](uint32_t rows_hi) {
         if (K::PC) return;

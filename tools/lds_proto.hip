@@ -33,7 +33,7 @@ constexpr int ROW_B = ROW * 16;
 constexpr int TILE_B = 4 * ROW_B;   // four is-X planes
 constexpr int SEG = 16;             // chunks per workgroup
 constexpr int MAXC = 16;            // candidates per pass
-constexpr int PROG_DW = 32;         // [0] n_f, [1] n_r, [2..15] forward byte offsets, [18..31] reverse
+constexpr int PROG_DW = 32;         // [0] n_f, [1] n_r, [2..9] forward byte offsets, [10..17] reverse
 
 struct Args {
     const uint4 *H, *L, *M, *U;     // transposed planes, 64 uint4 per chunk (M / U per slot: slot s at + s * plane stride)
@@ -106,20 +106,26 @@ typedef const volatile u32x4 __attribute__((address_space(3))) *lds128p;
 #define AN2(i, j) { acc.x = B3(acc.x, r[i].x, r[j].x); acc.y = B3(acc.y, r[i].y, r[j].y); acc.z = B3(acc.z, r[i].z, r[j].z); acc.w = B3(acc.w, r[i].w, r[j].w); }
 #define AN1(i) { acc.x &= r[i].x; acc.y &= r[i].y; acc.z &= r[i].z; acc.w &= r[i].w; }
 
-// off[0]: the single constraint when n is odd; then pairs.  Every step is a plain wave-uniform `if`.
-__device__ __forceinline__ void issue_strand(const uint32_t row, const uint32_t (&off)[8], uint32_t n, uint4 (&r)[8]) {
-    const uint32_t odd = n & 1u, np = n >> 1;
-    if (odd) RD(0)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (np > (uint32_t)i) { RD(1 + 2 * i) RD(2 + 2 * i) }
-}
-__device__ __forceinline__ void consume_strand(uint32_t n, const uint4 (&r)[8], uint4 &acc) {
-    const uint32_t odd = n & 1u, np = n >> 1;
-    if (odd) AN1(0)
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        if (np > (uint32_t)i) AN2(1 + 2 * i, 2 + 2 * i)
+// One strand: acc = init & every constraint.  A straight-line body per constraint count behind ONE multi-way branch (a compare
+// tree on the wave-uniform n): all reads of the strand in flight together, one three-input AND per pair of constraints and
+// dword, no flags, no copies (the if-chains of the first version cost 48 scalar and 71 vector instructions per candidate
+// and chunk, profiles of round 4).
+#define RDN(i) const u32x4 q##i = *(lds128p)(row + off[i]);
+#define A2(i, j, src) acc.x = B3(src.x, q##i.x, q##j.x); acc.y = B3(src.y, q##i.y, q##j.y); acc.z = B3(src.z, q##i.z, q##j.z); acc.w = B3(src.w, q##i.w, q##j.w);
+#define A1(i, src) acc.x = src.x & q##i.x; acc.y = src.y & q##i.y; acc.z = src.z & q##i.z; acc.w = src.w & q##i.w;
+__device__ __forceinline__ uint4 eval_strand(const uint32_t row, const uint32_t (&off)[8], uint32_t n, const uint4 init) {
+    uint4 acc = init;
+    switch (n) {
+    case 0: break;
+    case 1: { RDN(0) A1(0, init) } break;
+    case 2: { RDN(0) RDN(1) A2(0, 1, init) } break;
+    case 3: { RDN(0) RDN(1) RDN(2) A2(0, 1, init) A1(2, acc) } break;
+    case 4: { RDN(0) RDN(1) RDN(2) RDN(3) A2(0, 1, init) A2(2, 3, acc) } break;
+    case 5: { RDN(0) RDN(1) RDN(2) RDN(3) RDN(4) A2(0, 1, init) A2(2, 3, acc) A1(4, acc) } break;
+    case 6: { RDN(0) RDN(1) RDN(2) RDN(3) RDN(4) RDN(5) A2(0, 1, init) A2(2, 3, acc) A2(4, 5, acc) } break;
+    default: { RDN(0) RDN(1) RDN(2) RDN(3) RDN(4) RDN(5) RDN(6) A2(0, 1, init) A2(2, 3, acc) A2(4, 5, acc) A1(6, acc) } break;
+    }
+    return acc;
 }
 
 template <int CAN>
@@ -127,29 +133,29 @@ __device__ __forceinline__ void score_chunk(const Args &a, const char *tile, con
     // canonical plane / its complement at offset 0 start the accumulators (the modified base's own constraint)
     const uint4 f0 = plane_of(CAN ? 1 : 0, raw.h, raw.l), g0 = plane_of(CAN ? 2 : 3, raw.h, raw.l);
     const uint32_t row = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)tile + (HALO + lane) * 16;
-    for (uint32_t k = 0; k < a.n_cand; ++k) {
-        cu32p prog = (cu32p)(a.prog + (size_t)k * PROG_DW);
-        const uint32_t nf = prog[0], nr = prog[1];
-        uint32_t of[8], orv[8];
+    // the next candidate's program is requested (scalar loads) before the current one is evaluated
+    uint32_t nf, nr, of[8], orv[8];
+    {
+        cu32p prog = (cu32p)a.prog;
+        nf = prog[0]; nr = prog[1];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { of[i] = prog[2 + i]; orv[i] = prog[18 + i]; }
-        uint4 af = f0, ar = g0;
-        uint4 rf[8], rr[8];
-        if (BOTH) {
-            issue_strand(row, of, nf, rf);
-            issue_strand(row, orv, nr, rr);
-            consume_strand(nf, rf, af);
-            consume_strand(nr, rr, ar);
-        } else {
-            issue_strand(row, of, nf, rf);
-            consume_strand(nf, rf, af);
-            issue_strand(row, orv, nr, rr);
-            consume_strand(nr, rr, ar);
-        }
+        for (int i = 0; i < 8; ++i) { of[i] = prog[2 + i]; orv[i] = prog[10 + i]; }
+    }
+    for (uint32_t k = 0; k < a.n_cand; ++k) {
+        cu32p nxt = (cu32p)(a.prog + (size_t)min(k + 1, a.n_cand - 1) * PROG_DW);
+        const uint32_t nf2 = nxt[0], nr2 = nxt[1];
+        uint32_t of2[8], orv2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { of2[i] = nxt[2 + i]; orv2[i] = nxt[10 + i]; }
+        const uint4 af = eval_strand(row, of, nf, f0);
+        const uint4 ar = eval_strand(row, orv, nr, g0);
         const uint32_t s0 = af.x | ar.x, s1 = af.y | ar.y, s2 = af.z | ar.z, s3 = af.w | ar.w;
         const uint32_t n_mod = __popc(s0 & raw.m.x) + __popc(s1 & raw.m.y) + __popc(s2 & raw.m.z) + __popc(s3 & raw.m.w);
         const uint32_t n_non = __popc(s0 & raw.u.x) + __popc(s1 & raw.u.y) + __popc(s2 & raw.u.z) + __popc(s3 & raw.u.w);
         atomicAdd(&cnt[k * 64 + lane], n_mod | (n_non << 16));
+        nf = nf2; nr = nr2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { of[i] = of2[i]; orv[i] = orv2[i]; }
     }
 }
 
@@ -215,10 +221,10 @@ int main(int argc, char **argv) {
             uint32_t *p = prog.data() + ((size_t)slot * n_cand + k) * PROG_DW;
             p[0] = p[1] = (uint32_t)c.off.size();
             mean_reads += 2.0 * c.off.size();
-            const size_t shift = (c.off.size() & 1) ? 0 : 1;     // even: slot 0 (the single) stays unused
+            const size_t shift = 0;
             for (size_t j = 0; j < c.off.size(); ++j) {
                 p[2 + shift + j] = (uint32_t)(c.base[j] * ROW_B + c.off[j] * 16);                 // forward: base at +off
-                p[18 + shift + j] = (uint32_t)((3 - c.base[j]) * ROW_B + (-c.off[j]) * 16);       // reverse: complement (A<->T, C<->G = 3 - b) at -off
+                p[10 + shift + j] = (uint32_t)((3 - c.base[j]) * ROW_B + (-c.off[j]) * 16);       // reverse: complement (A<->T, C<->G = 3 - b) at -off
             }
         }
     mean_reads /= 2.0 * n_cand;
@@ -292,9 +298,9 @@ int main(int argc, char **argv) {
         printf("check: %s (%u candidates x 2 slots, %u chunks)\n", bad ? "FAILED" : "ok", n_cand, n_chunks);
     }
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) launch();
+    const int iters = argc > 5 ? atoi(argv[5]) : 50;
+    for (int i = 0; i < (iters < 20 ? iters : 20); ++i) launch();
     CHK(hipDeviceSynchronize());
-    const int iters = 50;
     CHK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) launch();
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
