@@ -26,6 +26,7 @@
 
 #include "../../include/nmscan.h"
 #include "nmbed_parse.h"
+#include "nmbgzf.h"
 
 int nm_set_error(int code, const char *fmt, ...);   // defined in nmscan.hip
 
@@ -153,49 +154,20 @@ struct Buffer {
     std::vector<char> owned;
 };
 
-bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n) {
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) return false;
-    zs.next_in = const_cast<Bytef *>(src);
-    zs.avail_in = (uInt)n;
-    zs.next_out = reinterpret_cast<Bytef *>(dst);
-    zs.avail_out = (uInt)dst_n;
-    const int rc = inflate(&zs, Z_FINISH);
-    inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
-}
+using nmbgzf::inflate_raw;
 
 bool load_gzip(const uint8_t *z, size_t zn, Buffer *b, unsigned threads, std::string *err) {
-    // BGZF: every member is a gzip block with FEXTRA 'B','C' subfield holding the block size
-    struct Blk { size_t in_off, in_len, out_off, out_len; };
-    std::vector<Blk> blocks;
-    size_t off = 0, out = 0;
-    bool bgzf = true;
-    while (off + 18 <= zn) {
-        if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) { bgzf = false; break; }
-        const size_t xlen = z[off + 10] | (z[off + 11] << 8);
-        size_t x = off + 12, xe = x + xlen, bsize = 0;
-        while (x + 4 <= xe) {
-            const size_t slen = z[x + 2] | (z[x + 3] << 8);
-            if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2) bsize = (size_t)(z[x + 4] | (z[x + 5] << 8)) + 1;
-            x += 4 + slen;
-        }
-        if (bsize == 0 || off + bsize > zn) { bgzf = false; break; }
-        const size_t isize = z[off + bsize - 4] | (z[off + bsize - 3] << 8) | (z[off + bsize - 2] << 16) | ((size_t)z[off + bsize - 1] << 24);
-        blocks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, out, isize});
-        out += isize;
-        off += bsize;
-    }
-    if (bgzf && off == zn && !blocks.empty()) {
+    // BGZF: every member is a gzip block with FEXTRA 'B','C' subfield holding the block size (nmbgzf.h)
+    std::vector<nmbgzf::Piece> blocks;
+    uint64_t out = 0;
+    if (nmbgzf::whole_file(z, zn, &blocks, &out)) {
         b->owned.resize(out);
         std::vector<std::thread> pool;
         std::vector<int> okv(threads, 1);
         for (unsigned t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
                 for (size_t i = t; i < blocks.size(); i += threads)
-                    if (blocks[i].out_len && !inflate_raw(z + blocks[i].in_off, blocks[i].in_len, b->owned.data() + blocks[i].out_off, blocks[i].out_len))
-                        okv[t] = 0;
+                    if (!inflate_raw(z + blocks[i].in_off, blocks[i].in_len, b->owned.data() + blocks[i].text_off, blocks[i].out_len)) okv[t] = 0;
             });
         for (auto &th : pool) th.join();
         for (int v : okv)
@@ -417,69 +389,13 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
         Buffer &b;
         ~Unmap() { if (b.map) munmap(b.map, b.map_size); b.map = nullptr; }
     } unmap_idx{idx};
-    const uint8_t *t = reinterpret_cast<const uint8_t *>(idx.data);
-    const size_t tn = idx.size;
-    auto bad = [&]() { return nm_set_error(NM_EINVAL, "%s: not a tabix index", tbi_path); };
-    if (tn < 36 || memcmp(t, "TBI\1", 4) != 0) return bad();
-    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, t + o, 4); return v; };
-    auto u64 = [&](size_t o) { uint64_t v; memcpy(&v, t + o, 8); return v; };
-    const int32_t n_ref = i32(4), l_nm = i32(32);
-    if (n_ref < 0 || l_nm < 0 || 36 + (size_t)l_nm > tn) return bad();
-    std::vector<std::string> ref_names;
-    for (size_t o = 36; o < 36 + (size_t)l_nm;) {
-        const char *z = reinterpret_cast<const char *>(t + o);
-        const size_t len = strnlen(z, 36 + (size_t)l_nm - o);
-        ref_names.emplace_back(z, len);
-        o += len + 1;
-    }
-    if ((int32_t)ref_names.size() != n_ref) return bad();
     std::unordered_map<std::string, uint32_t> want;
     for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
-    struct Region { uint64_t beg, end; };
-    std::vector<Region> regions;
+    std::vector<nmbgzf::Region> merged;
     uint64_t found_in_index = 0;
-    size_t o = 36 + (size_t)l_nm;
-    for (int32_t r = 0; r < n_ref; ++r) {
-        if (o + 4 > tn) return bad();
-        const int32_t n_bin = i32(o);
-        o += 4;
-        uint64_t lo = ~0ull, hi = 0;
-        bool pseudo = false;
-        for (int32_t b = 0; b < n_bin; ++b) {
-            if (o + 8 > tn) return bad();
-            uint32_t bin;
-            memcpy(&bin, t + o, 4);
-            const int32_t n_chunk = i32(o + 4);
-            o += 8;
-            if (n_chunk < 0 || o + (size_t)n_chunk * 16 > tn) return bad();
-            if (bin == 37450 && n_chunk >= 1) {              // metadata pseudo-bin: chunk 0 = [begin, end) of the reference
-                lo = u64(o);
-                hi = u64(o + 8);
-                pseudo = true;
-            } else if (!pseudo) {
-                for (int32_t k = 0; k < n_chunk; ++k) {
-                    lo = std::min(lo, u64(o + (size_t)k * 16));
-                    hi = std::max(hi, u64(o + (size_t)k * 16 + 8));
-                }
-            }
-            o += (size_t)n_chunk * 16;
-        }
-        if (o + 4 > tn) return bad();
-        const int32_t n_intv = i32(o);
-        o += 4;
-        if (n_intv < 0 || o + (size_t)n_intv * 8 > tn) return bad();
-        o += (size_t)n_intv * 8;
-        if (want.count(ref_names[r])) {
-            found_in_index += 1;
-            if (hi > lo) regions.push_back({lo, hi});
-        }
-    }
-    std::sort(regions.begin(), regions.end(), [](const Region &x, const Region &y) { return x.beg < y.beg; });
-    // neighbouring contigs: one region
-    std::vector<Region> merged;
-    for (const Region &g : regions) {
-        if (!merged.empty() && g.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, g.end);
-        else merged.push_back(g);
+    {
+        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(idx.data), idx.size, want, &merged, &found_in_index);
+        if (!what.empty()) return nm_set_error(NM_EINVAL, "%s: %s", tbi_path, what.c_str());
     }
     Buffer file;
     rc = load_file_raw(path, &file);
@@ -488,34 +404,11 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     const uint8_t *z = static_cast<const uint8_t *>(file.map);
     const size_t zn = file.map_size;
     // the blocks of every region, where their text goes, and which part of it is wanted
-    struct Blk { size_t in_off, in_len, out_len, dst; uint32_t skip, take; };
-    std::vector<Blk> blocks;
-    size_t text_size = 0, inflated = 0;
-    for (const Region &g : merged) {
-        size_t off = (size_t)(g.beg >> 16);
-        const size_t last = (size_t)(g.end >> 16);
-        const uint32_t u_beg = (uint32_t)(g.beg & 0xFFFF), u_end = (uint32_t)(g.end & 0xFFFF);
-        while (off <= last && off + 18 <= zn) {
-            if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return nm_set_error(NM_EINVAL, "%s: the index points outside a BGZF block", path);
-            const size_t xlen = z[off + 10] | (z[off + 11] << 8);
-            size_t x = off + 12, xe = x + xlen, bsize = 0;
-            while (x + 4 <= xe) {
-                const size_t slen = z[x + 2] | (z[x + 3] << 8);
-                if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2) bsize = (size_t)(z[x + 4] | (z[x + 5] << 8)) + 1;
-                x += 4 + slen;
-            }
-            if (bsize == 0 || off + bsize > zn) return nm_set_error(NM_EINVAL, "%s: corrupt BGZF block", path);
-            const size_t isize = z[off + bsize - 4] | (z[off + bsize - 3] << 8) | (z[off + bsize - 2] << 16) | ((size_t)z[off + bsize - 1] << 24);
-            const uint32_t skip = off == (size_t)(g.beg >> 16) ? u_beg : 0u;
-            const uint32_t stop = off == last ? u_end : (uint32_t)isize;
-            if (skip > isize || stop > isize) return nm_set_error(NM_EINVAL, "%s: the index points beyond a BGZF block", path);
-            if (stop > skip) {
-                blocks.push_back({off + 12 + xlen, bsize - 12 - xlen - 8, isize, text_size, skip, stop - skip});
-                text_size += stop - skip;
-                inflated += isize;
-            }
-            off += bsize;
-        }
+    std::vector<nmbgzf::Piece> blocks;
+    uint64_t text_size = 0, inflated = 0;
+    {
+        const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated);
+        if (!what.empty()) return nm_set_error(NM_EINVAL, "%s: %s", path, what.c_str());
     }
     Buffer text;
     text.owned.resize(text_size);
@@ -525,16 +418,8 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
         for (unsigned w = 0; w < threads; ++w)
             pool.emplace_back([&, w] {
                 std::vector<char> tmp;
-                for (size_t i = w; i < blocks.size(); i += threads) {
-                    const Blk &b = blocks[i];
-                    if (b.skip == 0 && b.take == b.out_len) {
-                        if (!inflate_raw(z + b.in_off, b.in_len, text.owned.data() + b.dst, b.out_len)) okv[w] = 0;
-                    } else {
-                        tmp.resize(b.out_len);
-                        if (!inflate_raw(z + b.in_off, b.in_len, tmp.data(), b.out_len)) okv[w] = 0;
-                        else memcpy(text.owned.data() + b.dst, tmp.data() + b.skip, b.take);
-                    }
-                }
+                for (size_t i = w; i < blocks.size(); i += threads)
+                    if (!nmbgzf::inflate_piece(z, blocks[i], text.owned.data() + blocks[i].text_off, tmp)) okv[w] = 0;
             });
         for (auto &th : pool) th.join();
         for (int v : okv)

@@ -1,0 +1,182 @@
+// BGZF blocks and tabix indexes, shared by the host bedMethyl reader (nmbed.cpp) and the device-side parser
+// (nmbedgpu.hip).  Internal: not part of the C ABI.
+//
+// A bgzip file is a sequence of gzip members ("blocks", <= 64 KiB of text each) whose FEXTRA 'B','C' subfield holds the
+// block size; a tabix index (.tbi) gives, per reference sequence, virtual offsets (file offset of a block << 16 | offset
+// inside its text) — the reference reads a bin's contigs through it (dataload.py:102-152, find_motifs_bin.py:233-246).
+// Here the text that has to be parsed is described as a list of PIECES: a block and the part of its text that is wanted.
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace nmbgzf {
+
+struct Piece {
+    size_t in_off, in_len;      // the raw deflate stream of the block inside the file
+    size_t out_len;             // text bytes of the whole block
+    uint32_t skip, take;        // the wanted part of that text
+    uint64_t text_off;          // where the wanted part starts in the concatenated text
+};
+
+inline bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)n;
+    zs.next_out = reinterpret_cast<Bytef *>(dst);
+    zs.avail_out = (uInt)dst_n;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
+// header of the block at `off`: its size in the file, where its deflate stream sits, its text size.  false: not a BGZF block
+inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, size_t *in_off, size_t *in_len, size_t *isize) {
+    if (off + 18 > zn) return false;
+    if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return false;
+    const size_t xlen = z[off + 10] | (z[off + 11] << 8);
+    size_t x = off + 12, xe = x + xlen, bs = 0;
+    if (xe > zn) return false;
+    while (x + 4 <= xe) {
+        const size_t slen = z[x + 2] | (z[x + 3] << 8);
+        if (z[x] == 'B' && z[x + 1] == 'C' && slen == 2 && x + 6 <= xe) bs = (size_t)(z[x + 4] | (z[x + 5] << 8)) + 1;
+        x += 4 + slen;
+    }
+    if (bs < 12 + xlen + 8 || off + bs > zn) return false;
+    *bsize = bs;
+    *in_off = off + 12 + xlen;
+    *in_len = bs - 12 - xlen - 8;
+    *isize = z[off + bs - 4] | (z[off + bs - 3] << 8) | (z[off + bs - 2] << 16) | ((size_t)z[off + bs - 1] << 24);
+    return true;
+}
+
+// every block of the file, whole.  false when the file is not BGZF from the first to the last byte (a plain gzip stream)
+inline bool whole_file(const uint8_t *z, size_t zn, std::vector<Piece> *pieces, uint64_t *text_size) {
+    pieces->clear();
+    size_t off = 0;
+    uint64_t out = 0;
+    while (off < zn) {
+        size_t bsize, in_off, in_len, isize;
+        if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize)) return false;
+        if (isize) pieces->push_back({in_off, in_len, isize, 0u, (uint32_t)isize, out});
+        out += isize;
+        off += bsize;
+    }
+    *text_size = out;
+    return !pieces->empty() || zn == 0 || out == 0;
+}
+
+struct Region { uint64_t beg, end; };    // virtual offsets
+
+// The [begin, end) virtual offsets of the wanted reference sequences of a tabix index held in memory (already inflated):
+// from the metadata pseudo-bin 37450 when present, else the hull of the sequence's chunks; regions sorted, neighbours
+// merged.  *found = wanted names the index knows.  Returns an empty string, or what is wrong with the index.
+inline std::string tabix_regions(const uint8_t *t, size_t tn, const std::unordered_map<std::string, uint32_t> &want,
+                                 std::vector<Region> *merged, uint64_t *found) {
+    const std::string bad = "not a tabix index";
+    if (tn < 36 || memcmp(t, "TBI\1", 4) != 0) return bad;
+    auto i32 = [&](size_t o) { int32_t v; memcpy(&v, t + o, 4); return v; };
+    auto u64 = [&](size_t o) { uint64_t v; memcpy(&v, t + o, 8); return v; };
+    const int32_t n_ref = i32(4), l_nm = i32(32);
+    if (n_ref < 0 || l_nm < 0 || 36 + (size_t)l_nm > tn) return bad;
+    std::vector<std::string> ref_names;
+    for (size_t o = 36; o < 36 + (size_t)l_nm;) {
+        const char *z = reinterpret_cast<const char *>(t + o);
+        const size_t len = strnlen(z, 36 + (size_t)l_nm - o);
+        ref_names.emplace_back(z, len);
+        o += len + 1;
+    }
+    if ((int32_t)ref_names.size() != n_ref) return bad;
+    std::vector<Region> regions;
+    *found = 0;
+    size_t o = 36 + (size_t)l_nm;
+    for (int32_t r = 0; r < n_ref; ++r) {
+        if (o + 4 > tn) return bad;
+        const int32_t n_bin = i32(o);
+        o += 4;
+        uint64_t lo = ~0ull, hi = 0;
+        bool pseudo = false;
+        for (int32_t b = 0; b < n_bin; ++b) {
+            if (o + 8 > tn) return bad;
+            uint32_t bin;
+            memcpy(&bin, t + o, 4);
+            const int32_t n_chunk = i32(o + 4);
+            o += 8;
+            if (n_chunk < 0 || o + (size_t)n_chunk * 16 > tn) return bad;
+            if (bin == 37450 && n_chunk >= 1) {              // metadata pseudo-bin: chunk 0 = [begin, end) of the reference
+                lo = u64(o);
+                hi = u64(o + 8);
+                pseudo = true;
+            } else if (!pseudo) {
+                for (int32_t k = 0; k < n_chunk; ++k) {
+                    lo = std::min(lo, u64(o + (size_t)k * 16));
+                    hi = std::max(hi, u64(o + (size_t)k * 16 + 8));
+                }
+            }
+            o += (size_t)n_chunk * 16;
+        }
+        if (o + 4 > tn) return bad;
+        const int32_t n_intv = i32(o);
+        o += 4;
+        if (n_intv < 0 || o + (size_t)n_intv * 8 > tn) return bad;
+        o += (size_t)n_intv * 8;
+        if (want.count(ref_names[r])) {
+            *found += 1;
+            if (hi > lo) regions.push_back({lo, hi});
+        }
+    }
+    std::sort(regions.begin(), regions.end(), [](const Region &x, const Region &y) { return x.beg < y.beg; });
+    merged->clear();
+    for (const Region &g : regions) {
+        if (!merged->empty() && g.beg <= merged->back().end) merged->back().end = std::max(merged->back().end, g.end);
+        else merged->push_back(g);
+    }
+    return std::string();
+}
+
+// the pieces of the regions' text.  Returns an empty string, or the error
+inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<Region> &merged, std::vector<Piece> *pieces,
+                                 uint64_t *text_size, uint64_t *inflated) {
+    pieces->clear();
+    uint64_t text = 0, infl = 0;
+    for (const Region &g : merged) {
+        size_t off = (size_t)(g.beg >> 16);
+        const size_t last = (size_t)(g.end >> 16);
+        const uint32_t u_beg = (uint32_t)(g.beg & 0xFFFF), u_end = (uint32_t)(g.end & 0xFFFF);
+        while (off <= last && off + 18 <= zn) {
+            size_t bsize, in_off, in_len, isize;
+            if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return "the index points outside a BGZF block";
+            if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize)) return "corrupt BGZF block";
+            const uint32_t skip = off == (size_t)(g.beg >> 16) ? u_beg : 0u;
+            const uint32_t stop = off == last ? u_end : (uint32_t)isize;
+            if (skip > isize || stop > isize) return "the index points beyond a BGZF block";
+            if (stop > skip) {
+                pieces->push_back({in_off, in_len, isize, skip, stop - skip, text});
+                text += stop - skip;
+                infl += isize;
+            }
+            off += bsize;
+        }
+    }
+    *text_size = text;
+    *inflated = infl;
+    return std::string();
+}
+
+// the wanted text of one piece -> dst (take bytes); tmp is scratch for pieces that are not taken whole
+inline bool inflate_piece(const uint8_t *z, const Piece &p, char *dst, std::vector<char> &tmp) {
+    if (p.skip == 0 && p.take == p.out_len) return inflate_raw(z + p.in_off, p.in_len, dst, p.out_len);
+    tmp.resize(p.out_len);
+    if (!inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len)) return false;
+    memcpy(dst, tmp.data() + p.skip, p.take);
+    return true;
+}
+
+}  // namespace nmbgzf
