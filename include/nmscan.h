@@ -496,7 +496,11 @@ int nm_bed_close(nm_bed *bed);
  * correctly rounded fast path, anything else is handed to the host parser's routines and patched in), contig names
  * become ids through a per-row hash and the runs of equal names (first-appearance order, like nm_bed_contig_name).
  * Every row equals nm_bed_open's bit for bit.  The columns stay in device memory in the types nm_ingest_pileup takes with
- * rows_on_device = 1.  Compressed input is refused (NM_EINVAL "compressed input": use nm_bed_open).
+ * rows_on_device = 1.  A bgzip file (what the reference recommends, docs/source/required_files.md:21) takes the same path:
+ * the copy threads inflate its BGZF blocks straight into the pinned slabs.  nm_bed_parse_device_indexed reads only the
+ * blocks a tabix index names for the wanted contigs (dataload.py:102-152, find_motifs_bin.py:192-312: the reference fetches a
+ * bin's contigs through the .tbi) — arguments, stats and errors as nm_bed_open_indexed; rows equal to it bit for bit.
+ * Any other gzip stream is refused (NM_EINVAL "compressed input ...": use nm_bed_open).
  *   nm_bedcols_shape           rows, contigs, runs of equal contig names; times = {seconds in total, seconds copying the file}
  *   nm_bedcols_runs            run_row[n_runs + 1] (first row of each run, then n_rows), run_contig[n_runs] (file contig id)
  *   nm_bedcols_map_contigs     contig column = contig_lut[file contig id] (engine contig id or 0xFFFFFFFF)
@@ -504,6 +508,8 @@ int nm_bed_close(nm_bed *bed);
  */
 typedef struct nm_bedcols nm_bedcols;
 int nm_bed_parse_device(nm_ctx *ctx, const char *path, uint32_t threads, nm_bedcols **out);
+int nm_bed_parse_device_indexed(nm_ctx *ctx, const char *path, const char *tbi_path, uint32_t n_contigs, const char *names,
+                                const uint32_t *name_offset, uint32_t threads, nm_bedcols **out, uint64_t stats[4]);
 int nm_bedcols_shape(nm_bedcols *cols, uint64_t *n_rows, uint32_t *n_contigs, uint32_t *n_runs, double times[2]);
 int nm_bedcols_contig_name(nm_bedcols *cols, uint32_t i, const char **name);
 int nm_bedcols_mod_code(nm_bedcols *cols, uint32_t id, const char **code);
@@ -546,13 +552,6 @@ int nm_py_random_sample_many(uint32_t mt_state[625], uint32_t m, const uint64_t 
  * group ends in (where the interpreter's generator stands after a sequential run of the same calls) */
 int nm_py_random_sample_groups(uint32_t n_groups, const uint32_t *init_state, const uint64_t *group_off, const uint64_t *n,
                                const uint64_t *k, uint32_t *out_indices, uint32_t final_state[625]);
-/* Synthetic-data tooling (no GPU involved): rows -> modkit bedMethyl text, 18 tab-separated columns as
- * synth.SynthMetagenome.write_bed writes them (N_mod = round(N_valid_cov * percent / 100), N_canonical the rest), formatted
- * on several threads.  names / name_offset: contig names back to back; mod_type 0 = m, 1 = a, 2 = 21839;
- * pct_hundredths = percent modified in hundredths of a percent. */
-int nm_synth_write_bed(const char *path, uint64_t n_rows, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
-                       const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_type, const uint8_t *strand,
-                       const int32_t *nvalid_cov, const int32_t *pct_hundredths, uint32_t threads);
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows,
                             uint32_t width, int64_t *counts);
 

@@ -15,10 +15,10 @@ SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_set_device_allocator", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_set_score_lanes", "nm_sync", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
-    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_synth_write_bed", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
+    "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
     "nm_comm_sync", "nm_comm_info", "nm_comm_destroy",
-    "nm_score_batch_per_contig", "nm_bin_contigs", "nm_readstats_upload", "nm_contig_methylation", "nm_bed_open_counts", "nm_bed_count_columns", "nm_bed_parse_device", "nm_bedcols_shape", "nm_bedcols_contig_name", "nm_bedcols_mod_code", "nm_bedcols_runs", "nm_bedcols_map_contigs", "nm_bedcols_device_columns", "nm_bedcols_close", "nm_device_read", "nm_score_batch_begin", "nm_score_batch_end", "nm_win_batch_w_begin", "nm_win_batch_w_end", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_export", "nm_search_result_free", "nm_post_run", "nm_post_run_custom", "nm_post_run_rows_custom", "nm_post_sizes", "nm_post_export", "nm_post_free", "nm_psi_posint",
+    "nm_score_batch_per_contig", "nm_bin_contigs", "nm_readstats_upload", "nm_contig_methylation", "nm_bed_open_counts", "nm_bed_count_columns", "nm_bed_parse_device", "nm_bed_parse_device_indexed", "nm_bedcols_shape", "nm_bedcols_contig_name", "nm_bedcols_mod_code", "nm_bedcols_runs", "nm_bedcols_map_contigs", "nm_bedcols_device_columns", "nm_bedcols_close", "nm_device_read", "nm_score_batch_begin", "nm_score_batch_end", "nm_win_batch_w_begin", "nm_win_batch_w_end", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_export", "nm_search_result_free", "nm_post_run", "nm_post_run_custom", "nm_post_run_rows_custom", "nm_post_sizes", "nm_post_export", "nm_post_free", "nm_psi_posint",
 ]
 
 class SearchParams(C.Structure):
@@ -115,6 +115,7 @@ def load():
     lib.nm_bed_open_counts.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(p)]
     lib.nm_bed_count_columns.argtypes = [p, C.POINTER(p), C.POINTER(p)]
     lib.nm_bed_parse_device.argtypes = [p, C.c_char_p, C.c_uint32, C.POINTER(p)]
+    lib.nm_bed_parse_device_indexed.argtypes = [p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(p), C.POINTER(C.c_uint64)]
     lib.nm_bedcols_shape.argtypes = [p, u64p, u32p, u32p, f64p]
     lib.nm_bedcols_contig_name.argtypes = [p, C.c_uint32, C.POINTER(C.c_char_p)]
     lib.nm_bedcols_mod_code.argtypes = [p, C.c_uint32, C.POINTER(C.c_char_p)]
@@ -150,8 +151,6 @@ def load():
     lib.nm_py_random_sample.argtypes = [u32p, C.c_uint64, C.c_uint64, u32p]
     lib.nm_py_random_sample_many.argtypes = [u32p, C.c_uint32, u64p, u64p, u32p]
     lib.nm_py_random_sample_groups.argtypes = [C.c_uint32, u32p, u64p, u64p, u64p, u32p, u32p]
-    lib.nm_synth_write_bed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_char_p, u32p, u32p, u32p, C.POINTER(C.c_int8), u8p, C.POINTER(C.c_int32),
-                                       C.POINTER(C.c_int32), C.c_uint32]
     lib.nm_window_letter_counts.argtypes = [u8p, C.c_uint64, i64p, C.c_uint64, C.c_uint32, i64p]
     lib.nm_bed_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(p)]
     lib.nm_bed_open_indexed.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, u32p, C.c_uint32, C.POINTER(p), u64p]

@@ -13,6 +13,10 @@ _CSRC = os.path.join(_HERE, "csrc")
 SRC_HIP = [os.path.join(_CSRC, f) for f in ("nmscan.hip", "nmscore.hip", "nmingest.hip", "nmwindows.hip", "nmmeth.hip", "nmbedgpu.hip")]
 SRC_HOST = [os.path.join(_CSRC, f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp", "nmsearch.cpp", "nmpost.cpp")]
 OUT = os.path.join(_HERE, "libnmscan.so")
+# synthetic-data tooling of bench.py and the tests (a bedMethyl text writer, a bgzip + tabix writer): its own small library,
+# not part of the product's C ABI
+SYNTH_SRC = os.path.join(_CSRC, "bench", "nmsynth.cpp")
+SYNTH_OUT = os.path.join(_HERE, "libnmsynth.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "nmscan.h")
 OBJ_DIR = os.path.join(_CSRC, "_build")
 
@@ -25,7 +29,14 @@ def sources():
     return [s for s in SRC_HIP + SRC_HOST if os.path.exists(s)]
 
 
+def build_synth(force: bool = False) -> str:
+    if force or not os.path.exists(SYNTH_OUT) or os.path.getmtime(SYNTH_OUT) < os.path.getmtime(SYNTH_SRC):
+        subprocess.run([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-o", SYNTH_OUT, SYNTH_SRC, "-lz", "-lpthread"], check=True)
+    return SYNTH_OUT
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_synth(force)
     srcs = sources()
     hdr_time = max(os.path.getmtime(h) for h in _headers())
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

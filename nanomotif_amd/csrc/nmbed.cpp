@@ -484,7 +484,19 @@ int nm_bed_ingest_columns(nm_bed *b, const uint32_t *contig_lut, uint32_t n_lut,
         return nm_set_error(NM_EINVAL, "NULL argument");
     if (n_lut != b->all.names.size()) return nm_set_error(NM_EINVAL, "contig_lut has %u entries, the pileup names %zu contigs", n_lut, b->all.names.size());
     const size_t n = b->all.contig.size();
+    // a second call (another lut) only maps the contigs again: the 64-bit originals were given up by the first
+    const bool again = n > 0 && b->all.position.size() != n && b->ing_position.size() == n;
     b->ing_contig.resize(n);
+    if (again) {
+        for (size_t i = 0; i < n; ++i) b->ing_contig[i] = contig_lut[b->all.contig[i]];
+        *contig_id = b->ing_contig.data();
+        *position = b->ing_position.data();
+        *mod_type = b->all.mod_type.data();
+        *strand = b->all.strand.data();
+        *fraction_mod = b->all.fraction.data();
+        *nvalid_cov = b->ing_nvalid.data();
+        return NM_OK;
+    }
     b->ing_position.resize(n);
     b->ing_nvalid.resize(n);
     unsigned threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));

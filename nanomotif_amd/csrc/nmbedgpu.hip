@@ -28,7 +28,10 @@
 
 #include <rocprim/device/device_scan.hpp>
 
+#include <sys/mman.h>
+
 #include "nmbed_parse.h"
+#include "nmbgzf.h"
 #include "nmscan_internal.h"
 
 using namespace nmdetail;
@@ -364,34 +367,184 @@ int nm_bedcols_close(nm_bedcols *b) {
     return NM_OK;
 }
 
-int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcols **out) {
-    if (!c || !path || !out) return fail(NM_EINVAL, "NULL argument");
-    *out = nullptr;
-    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    HIP_TRY(hipSetDevice(c->device));
-    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}  // extern "C"
+
+namespace {
+
+// Where the bedMethyl TEXT comes from: a plain file (pread) or the wanted parts of the BGZF blocks of a bgzip file
+// (nmbgzf.h: every block, or the blocks a tabix index names), inflated by the copy threads straight into the pinned slabs.
+// Offsets are offsets into the text either way.
+struct TextSource {
+    int fd = -1;
+    uint64_t n = 0;                               // bytes of text
+    bool bgzf = false;
+    const uint8_t *z = nullptr;                   // the mapped bgzip file
+    size_t zn = 0;
+    std::vector<nmbgzf::Piece> pieces;            // sorted by text_off, contiguous in the text
+    ~TextSource() {
+        if (z) munmap(const_cast<uint8_t *>(z), zn);
+        if (fd >= 0) close(fd);
+    }
+    size_t piece_at(uint64_t off) const {          // the piece that holds text offset `off`
+        size_t lo = 0, hi = pieces.size();
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (pieces[mid].text_off <= off) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    }
+    // pieces first, first + step, ... that overlap the text range [off, off + len) -> dst (which holds the range)
+    bool read_pieces(uint64_t off, uint64_t len, size_t first, size_t step, uint8_t *dst, std::vector<char> &tmp) const {
+        for (size_t i = first; i < pieces.size() && pieces[i].text_off < off + len; i += step) {
+            const nmbgzf::Piece &p = pieces[i];
+            const uint64_t a = std::max<uint64_t>(off, p.text_off), e = std::min<uint64_t>(off + len, p.text_off + p.take);
+            if (e <= a) continue;
+            if (a == p.text_off && e == p.text_off + p.take) {
+                if (!nmbgzf::inflate_piece(z, p, reinterpret_cast<char *>(dst + (a - off)), tmp)) return false;
+            } else {                              // a piece cut by the range's end: its text through tmp
+                tmp.resize(p.out_len);
+                if (!nmbgzf::inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len)) return false;
+                memcpy(dst + (a - off), tmp.data() + p.skip + (a - p.text_off), (size_t)(e - a));
+            }
+        }
+        return true;
+    }
+    bool read_at(uint64_t off, void *dst, uint64_t len) const {
+        if (!bgzf) {
+            uint8_t *d = static_cast<uint8_t *>(dst);
+            while (len) {
+                const ssize_t k = pread(fd, d, (size_t)std::min<uint64_t>(len, 1u << 30), (off_t)off);
+                if (k <= 0) return false;
+                d += k; off += (uint64_t)k; len -= (uint64_t)k;
+            }
+            return true;
+        }
+        if (len == 0) return true;
+        if (off + len > n) return false;
+        std::vector<char> tmp;
+        return read_pieces(off, len, piece_at(off), 1, static_cast<uint8_t *>(dst), tmp);
+    }
+    // share t of nt of the range -> dst: a byte range of a plain file, every nt-th block of a bgzip file
+    bool fill(uint64_t off, uint64_t len, unsigned t, unsigned nt, uint8_t *dst, std::vector<char> &tmp) const {
+        if (!bgzf) {
+            const uint64_t a = len * t / nt, e = len * (t + 1) / nt;
+            return e <= a || read_at(off + a, dst + a, e - a);
+        }
+        if (len == 0) return true;
+        return read_pieces(off, len, piece_at(off) + t, nt, dst, tmp);
+    }
+};
+
+int map_file(const char *path, TextSource *src) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(NM_EINVAL, "cannot open pileup '%s'", path);
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return fail(NM_EINVAL, "cannot stat pileup '%s'", path); }
-    const uint64_t n = (uint64_t)st.st_size;
+    src->zn = (size_t)st.st_size;
+    if (src->zn) {
+        void *m = mmap(nullptr, src->zn, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); src->zn = 0; return fail(NM_EINVAL, "cannot map pileup '%s'", path); }
+        src->z = static_cast<const uint8_t *>(m);
+    }
+    close(fd);
+    return NM_OK;
+}
+
+int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out);
+
+}  // namespace
+
+extern "C" {
+
+int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcols **out) {
+    if (!c || !path || !out) return fail(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    TextSource src;
+    src.fd = open(path, O_RDONLY);
+    if (src.fd < 0) return fail(NM_EINVAL, "cannot open pileup '%s'", path);
+    struct stat st;
+    if (fstat(src.fd, &st) != 0) return fail(NM_EINVAL, "cannot stat pileup '%s'", path);
+    src.n = (uint64_t)st.st_size;
     // the file is READ (pread straight into the pinned slabs), not mapped: mapping 8 GB costs two million page faults on the
     // way in and as many page-table entries on the way out
-    struct CloseFd { int fd; ~CloseFd() { close(fd); } } close_fd{fd};
-    auto read_at = [&](uint64_t off, void *dst, uint64_t len) -> bool {
-        uint8_t *d = static_cast<uint8_t *>(dst);
-        while (len) {
-            const ssize_t k = pread(fd, d, (size_t)std::min<uint64_t>(len, 1u << 30), (off_t)off);
-            if (k <= 0) return false;
-            d += k; off += (uint64_t)k; len -= (uint64_t)k;
-        }
-        return true;
-    };
-    {
-        uint8_t magic[2] = {0, 0};
-        if (n >= 2 && !read_at(0, magic, 2)) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
-        if (n >= 2 && magic[0] == 31 && magic[1] == 139) return fail(NM_EINVAL, "%s: compressed input: the device parser reads plain text (use nm_bed_open)", path);
+    uint8_t magic[2] = {0, 0};
+    if (src.n >= 2 && !src.read_at(0, magic, 2)) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
+    if (src.n >= 2 && magic[0] == 31 && magic[1] == 139) {
+        // bgzip (what the reference recommends, docs/source/required_files.md:21): the blocks are inflated by the copy threads
+        // into the same pinned slabs; any other gzip stream has no block structure to inflate in parallel
+        close(src.fd);
+        src.fd = -1;
+        int rc = map_file(path, &src);
+        if (rc) return rc;
+        if (!nmbgzf::whole_file(src.z, src.zn, &src.pieces, &src.n))
+            return fail(NM_EINVAL, "%s: compressed input that is not bgzip: the device parser reads plain text and BGZF (use nm_bed_open)", path);
+        src.bgzf = true;
     }
+    return parse_device_impl(c, path, src, threads, out);
+}
+
+int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
+                                uint32_t threads, nm_bedcols **out, uint64_t stats[4]) {
+    if (!c || !path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return fail(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    // the index: a small bgzip file itself
+    std::vector<char> index;
+    {
+        TextSource idx;
+        int rc = map_file(tbi_path, &idx);
+        if (rc) return fail(NM_EINVAL, "cannot open tabix index '%s'", tbi_path);
+        if (idx.zn >= 2 && idx.z[0] == 31 && idx.z[1] == 139) {
+            if (!nmbgzf::whole_file(idx.z, idx.zn, &idx.pieces, &idx.n)) return fail(NM_EINVAL, "%s: not a tabix index", tbi_path);
+            idx.bgzf = true;
+            index.resize(idx.n);
+            if (idx.n && !idx.read_at(0, index.data(), idx.n)) return fail(NM_EINVAL, "%s: corrupt BGZF block", tbi_path);
+        } else {
+            index.assign(reinterpret_cast<const char *>(idx.z), reinterpret_cast<const char *>(idx.z) + idx.zn);
+        }
+    }
+    std::unordered_map<std::string, uint32_t> want;
+    for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
+    std::vector<nmbgzf::Region> merged;
+    uint64_t found = 0, inflated = 0;
+    {
+        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), want, &merged, &found);
+        if (!what.empty()) return fail(NM_EINVAL, "%s: %s", tbi_path, what.c_str());
+    }
+    TextSource src;
+    int rc = map_file(path, &src);
+    if (rc) return rc;
+    {
+        const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated);
+        if (!what.empty()) return fail(NM_EINVAL, "%s: %s", path, what.c_str());
+    }
+    src.bgzf = true;
+    if (stats) { stats[0] = inflated; stats[1] = src.zn; stats[2] = n_contigs - std::min<uint64_t>(found, n_contigs); stats[3] = 0; }
+    rc = parse_device_impl(c, path, src, threads, out);
+    if (rc) return rc;
+    // the text the index pointed at must belong to the contigs that were asked for: a stale or foreign .tbi otherwise
+    // yields a silently wrong subset of rows
+    for (const std::string &nm : (*out)->names)
+        if (!want.count(nm)) {
+            const std::string culprit = nm;
+            (void)nm_bedcols_close(*out);
+            *out = nullptr;
+            return fail(NM_EINVAL, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
+                        path, culprit.c_str());
+        }
+    return NM_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out) {
+    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    HIP_TRY(hipSetDevice(c->device));
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const uint64_t n = src.n;
+    auto read_at = [&](uint64_t off, void *dst, uint64_t len) -> bool { return src.read_at(off, dst, len); };
     nm_bedcols *b = new (std::nothrow) nm_bedcols();
     if (!b) return fail(NM_ENOMEM, "out of host memory");
     b->ctx = c;
@@ -489,6 +642,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     std::vector<std::thread> producers;
     for (unsigned t = 0; t < nt; ++t)
         producers.emplace_back([&, t] {
+            std::vector<char> inflate_tmp;
             for (size_t k = 0; k < n_slabs; ++k) {
                 {
                     std::unique_lock<std::mutex> lk(mu);
@@ -497,9 +651,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
                 }
                 const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
                 const uint64_t lo = cut[k], len = cut[k + 1] - cut[k];
-                uint8_t *dst = h_ring[k % RING];
-                const uint64_t a = len * t / nt, e = len * (t + 1) / nt;
-                if (e > a && !read_at(lo + a, dst + a, e - a)) read_failed = true;
+                if (!src.fill(lo, len, t, nt, h_ring[k % RING], inflate_tmp)) read_failed = true;
                 const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
                 {
                     std::lock_guard<std::mutex> lk(mu);
@@ -526,6 +678,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return filled > k; });
         }
+        if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block" : "cannot read pileup '%s'", path);
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(copy_stream, parsed[k % 2], 0));       // the device slab is free again
         HIP_TRY(hipMemcpyAsync(d_slab[k % 2], h_ring[k % RING], len, hipMemcpyHostToDevice, copy_stream));
         HIP_TRY(hipEventRecord(h2d_done[k % RING], copy_stream));
@@ -565,7 +718,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
         b->n_rows += n_lines;
     }
-    if (read_failed) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
+    if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block" : "cannot read pileup '%s'", path);
     unsigned long long first_error = ~0ull;
     HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -682,6 +835,10 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     *out = b;
     return NM_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int nm_bedcols_shape(nm_bedcols *b, uint64_t *n_rows, uint32_t *n_contigs, uint32_t *n_runs, double times[2]) {
     if (!b || !n_rows || !n_contigs) return fail(NM_EINVAL, "NULL argument");

@@ -147,51 +147,6 @@ int nm_py_random_sample_groups(uint32_t n_groups, const uint32_t *init_state /*[
     return NM_OK;
 }
 
-// Synthetic-data tooling: rows -> modkit bedMethyl text (18 tab-separated columns, what synth.SynthMetagenome.write_bed
-// writes row by row in Python), formatted on several threads.  pct_hundredths = percent modified in 1/100 %.
-int nm_synth_write_bed(const char *path, uint64_t n_rows, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
-                       const uint32_t *contig_id, const uint32_t *position, const int8_t *mod_type, const uint8_t *strand,
-                       const int32_t *nvalid_cov, const int32_t *pct_hundredths, uint32_t threads) {
-    if (!path || (n_rows && (!names || !name_offset || !contig_id || !position || !mod_type || !strand || !nvalid_cov || !pct_hundredths)))
-        return nm_set_error(NM_EINVAL, "NULL argument");
-    if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    static const char *codes[3] = {"m", "a", "21839"};
-    FILE *f = fopen(path, "wb");
-    if (!f) return nm_set_error(NM_EINVAL, "cannot create '%s'", path);
-    const uint64_t piece = 1u << 20;                                   // rows per round and thread (~80 MB of text each)
-    std::vector<std::string> buf(threads);
-    int bad = 0;
-    for (uint64_t r0 = 0; r0 < n_rows; r0 += piece * threads) {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; ++t)
-            pool.emplace_back([&, t] {
-                std::string &o = buf[t];
-                o.clear();
-                const uint64_t a = std::min<uint64_t>(n_rows, r0 + piece * t), e = std::min<uint64_t>(n_rows, a + piece);
-                char tmp[256];
-                for (uint64_t i = a; i < e; ++i) {
-                    const uint32_t c = contig_id[i];
-                    const int m = mod_type[i];
-                    if (c >= n_contigs || m < 0 || m > 2) { bad = 1; return; }
-                    const long long cov = nvalid_cov[i], pct = pct_hundredths[i], pos = position[i];
-                    const long long nmod = (long long)std::nearbyint((double)(cov * pct) / 10000.0);    // Python's round(): half to even
-                    o.append(names + name_offset[c], name_offset[c + 1] - name_offset[c]);
-                    const int k = snprintf(tmp, sizeof tmp, "\t%lld\t%lld\t%s\t%lld\t%c\t%lld\t%lld\t255,0,0\t%lld\t%lld.%02lld\t%lld\t%lld\t0\t0\t0\t0\t0\n",
-                                           pos, pos + 1, codes[m], cov, (char)strand[i], pos, pos + 1, cov, pct / 100, pct % 100, nmod, cov - nmod);
-                    o.append(tmp, (size_t)k);
-                }
-            });
-        for (auto &th : pool) th.join();
-        if (bad) break;
-        for (unsigned t = 0; t < threads; ++t)
-            if (!buf[t].empty() && fwrite(buf[t].data(), 1, buf[t].size(), f) != buf[t].size()) bad = 2;
-    }
-    fclose(f);
-    if (bad == 1) return nm_set_error(NM_EINVAL, "row with a contig id / mod code outside the tables");
-    if (bad == 2) return nm_set_error(NM_EINVAL, "short write to '%s'", path);
-    return NM_OK;
-}
-
 int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t *starts, uint64_t n_windows, uint32_t width,
                             int64_t *counts /*[4][width], rows A,T,G,C*/) {
     if (!seq || !counts || (n_windows && !starts)) return nm_set_error(NM_EINVAL, "NULL argument");

@@ -58,9 +58,34 @@ def generate_raw(mg: synth.SynthMetagenome, device, contigs=None):
     return mine, lengths, offsets, bins, ascii_all, cat
 
 
+_synth = None
+
+
+def synth_lib():
+    """libnmsynth.so (csrc/bench/nmsynth.cpp): the synthetic-data writers of the bench and the tests — not the product library."""
+    global _synth
+    if _synth is None:
+        from . import build
+        lib = C.CDLL(build.build_synth())
+        u32p = C.POINTER(C.c_uint32)
+        lib.nm_synth_last_error.restype = C.c_char_p
+        lib.nm_synth_write_bed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_char_p, u32p, u32p, u32p, C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32]
+        lib.nm_synth_bgzip.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32]
+        _synth = lib
+    return _synth
+
+
+def bgzip_tabix(text_path: str, gz_path: str, threads: int = 0, level: int = 6, block_size: int = 0xFF00):
+    """``bgzip`` + ``tabix -p bed`` of a bedMethyl text file, natively on several threads (writes gz_path and gz_path + '.tbi')."""
+    lib = synth_lib()
+    if lib.nm_synth_bgzip(text_path.encode(), gz_path.encode(), int(threads), int(level), int(block_size)):
+        raise RuntimeError(lib.nm_synth_last_error().decode())
+
+
 def write_text_inputs(mg: synth.SynthMetagenome, out_dir: str, device, threads: int = 0) -> dict:
     """The metagenome as the FILES the CLI takes — assembly.fasta, pileup.bed (modkit bedMethyl text, rows in modkit's
-    order), contig_bin.tsv — generated on ``device`` and written by the native writer (nm_synth_write_bed: the Python
+    order), contig_bin.tsv — generated on ``device`` and written by the native writer (nm_synth_write_bed of libnmsynth.so: the Python
     row loop of ``write_bed`` takes ~1 us per row, a 100 Mbp pileup has 1e8).  Byte-identical to ``mg.write_bed`` /
     ``write_contig_bin``; the FASTA holds every contig on one line.  Returns sizes."""
     import os
@@ -72,14 +97,15 @@ def write_text_inputs(mg: synth.SynthMetagenome, out_dir: str, device, threads: 
     names = "".join(mg.names).encode()
     off = np.zeros(len(mg.names) + 1, dtype=np.uint32)
     np.cumsum([len(x) for x in mg.names], out=off[1:])
-    lib = _lib.load()
+    lib = synth_lib()
     p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(t))
     cid, pos = np.ascontiguousarray(host["contig"], dtype=np.uint32), np.ascontiguousarray(host["position"], dtype=np.uint32)
     mod, st = np.ascontiguousarray(host["mod"], dtype=np.int8), np.ascontiguousarray(host["strand"], dtype=np.uint8)
     nv = np.ascontiguousarray(host["nvalid"], dtype=np.int32)
     bed = os.path.join(out_dir, "pileup.bed")
-    _lib.check(lib.nm_synth_write_bed(bed.encode(), len(cid), len(mg.names), names, p(off, C.c_uint32), p(cid, C.c_uint32), p(pos, C.c_uint32),
-                                      p(mod, C.c_int8), p(st, C.c_uint8), p(nv, C.c_int32), p(pct, C.c_int32), int(threads)))
+    if lib.nm_synth_write_bed(bed.encode(), len(cid), len(mg.names), names, p(off, C.c_uint32), p(cid, C.c_uint32), p(pos, C.c_uint32),
+                              p(mod, C.c_int8), p(st, C.c_uint8), p(nv, C.c_int32), p(pct, C.c_int32), int(threads)):
+        raise RuntimeError(lib.nm_synth_last_error().decode())
     seq = ascii_all.cpu().numpy()
     with open(os.path.join(out_dir, "assembly.fasta"), "wb") as f:
         for j, i in enumerate(mine):

@@ -140,15 +140,18 @@ def find_motifs_bin(args):
     # native reader, raw rows kept in native memory; a bgzip pileup is read through its tabix index: only the blocks
     # of the contigs that are in a bin and in the assembly (find_motifs_bin.py:233-246 fetches per bin)
     wanted = list(dict.fromkeys(fasta.original_name(c) for c in cfg.bin_contig if c in assembly)) if bgzip else None
-    # plain text is parsed ON THE GPU (nm_bed_parse_device: the host only moves the file through pinned slabs; every row
-    # equals the host parser's bit for bit); compressed input, a contig listed under several bins (its rows are needed
-    # twice) and NANOMOTIF_HOST_PARSER=1 take the host parser
+    # the pileup is parsed ON THE GPU (nm_bed_parse_device: the host only moves the file through pinned slabs — the BGZF
+    # blocks of a bgzip file are inflated into them by the copy threads, the tabix subset alike; every row equals the host
+    # parser's bit for bit); a gzip stream that is not bgzip, a contig listed under several bins (its rows are needed twice)
+    # and NANOMOTIF_HOST_PARSER=1 take the host parser
     table = None
-    if not bgzip and os.environ.get("NANOMOTIF_HOST_PARSER") != "1" and not any(fasta.ALIAS_SEP in c for c in cfg.bin_contig):
+    if os.environ.get("NANOMOTIF_HOST_PARSER") != "1" and not any(fasta.ALIAS_SEP in c for c in cfg.bin_contig):
         try:
-            table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0)
+            table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0,
+                                            contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
+            how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
             log.info(f"pileup: {len(table):,} rows parsed on the device ({time.perf_counter() - t0:.1f}s, {table.seconds_reading:.1f}s of it "
-                     f"moving the file)")
+                     f"moving the file{how})")
         except NmScanError as e:
             if "use nm_bed_open" not in str(e):
                 raise

@@ -147,20 +147,45 @@ class NativePileup:
 
 
 class DevicePileup:
-    """A plain-text bedMethyl file parsed ON THE GPU (nm_bed_parse_device): the six columns live in device memory in the
-    types ``nm_ingest_pileup`` takes, no row ever becomes a host array.  ``contig_names``: first-appearance order of the
-    file = index space of the ``lut`` given to ``map_contigs``; ``run_row`` / ``run_contig``: the runs of equal contig
-    names (a modkit file has one per contig).  Raises NmScanError for compressed input (use ``NativePileup``)."""
+    """A bedMethyl file — plain text or bgzip — parsed ON THE GPU (nm_bed_parse_device): the six columns live in device
+    memory in the types ``nm_ingest_pileup`` takes, no row ever becomes a host array.  ``contig_names``: first-appearance
+    order of the file = index space of the ``lut`` given to ``map_contigs``; ``run_row`` / ``run_contig``: the runs of equal
+    contig names (a modkit file has one per contig).  ``contigs`` + ``index_path``: only these contigs, through the tabix
+    index (nm_bed_parse_device_indexed — the reference's bgzip path, dataload.py:102-152); ``self.indexed`` tells whether
+    that happened: an index that is none, or does not fit the file, falls back to the whole file.  Raises NmScanError for a
+    gzip stream that is not bgzip (use ``NativePileup``)."""
 
     COLUMNS = (("contig", np.uint32), ("file_contig", np.uint32), ("position", np.uint32), ("mod_type", np.int8), ("strand", np.uint8),
                ("fraction_mod", np.float64), ("nvalid_cov", np.int32))
 
-    def __init__(self, engine, path: str, threads: int = 0):
+    def __init__(self, engine, path: str, threads: int = 0, contigs=None, index_path=None):
         import ctypes as C
         from . import _lib
         self.engine, self._lib, self._check = engine, _lib.load(), _lib.check
         self._h = C.c_void_p()
-        self._check(self._lib.nm_bed_parse_device(engine.ctx, os.fsencode(path), int(threads), C.byref(self._h)))
+        self.indexed, self.bytes_inflated, self.bytes_file = False, None, None
+        self.index_problem, self.contigs_not_indexed = None, 0
+        if contigs is not None and index_path is not None:
+            names = [c.encode() for c in contigs]
+            off = np.zeros(len(names) + 1, dtype=np.uint32)
+            np.cumsum([len(x) for x in names], out=off[1:])
+            stats = (C.c_uint64 * 4)()
+            rc = self._lib.nm_bed_parse_device_indexed(engine.ctx, os.fsencode(path), os.fsencode(index_path), len(names), b"".join(names),
+                                                       off.ctypes.data_as(C.POINTER(C.c_uint32)), int(threads), C.byref(self._h), stats)
+            if rc == 0:
+                self.indexed, self.bytes_inflated, self.bytes_file = True, int(stats[0]), int(stats[1])
+                self.contigs_not_indexed = int(stats[2])
+                if self.contigs_not_indexed:
+                    import logging
+                    logging.warning(f"{self.contigs_not_indexed} of {len(names)} wanted contigs have no entry in {index_path} (no rows read for them)")
+            else:
+                # not a tabix index, or one that does not fit this file: the whole file instead — slower, never a wrong subset
+                import logging
+                self.index_problem = self._lib.nm_last_error().decode()
+                self._h = C.c_void_p()
+                logging.warning(f"tabix index not used ({self.index_problem}): reading the whole pileup")
+        if not self.indexed:
+            self._check(self._lib.nm_bed_parse_device(engine.ctx, os.fsencode(path), int(threads), C.byref(self._h)))
         n, nc, nr = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
         times = (C.c_double * 2)()
         self._check(self._lib.nm_bedcols_shape(self._h, C.byref(n), C.byref(nc), C.byref(nr), times))

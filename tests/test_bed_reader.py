@@ -196,3 +196,51 @@ def test_tabix_indexed_read_equals_filtered_full_read(tmp_path):
     assert not p3.indexed and p3.index_problem and len(p3) == len(cols_full["position"])
     assert sorted(p3.contig_names) == sorted(names_full)
     p3.close()
+
+
+def test_native_bgzip_tabix_writer_of_the_bench(tmp_path):
+    """libnmsynth's bgzip + tabix writer (what bench.py uses to make the 7.5 GB .gz input of its CLI leg) against the
+    Python writer of tests/helpers.py: the same compressed bytes (both are zlib level 6), and the same rows through the index."""
+    from helpers import write_bgzf_tabix
+    from nanomotif_amd import e2e_synth
+    spec = synth.SynthSpec(n_contigs=5, total_bp=400_000, n_bins=2, mod_types=("a", "m"), seed=62, min_contig_bp=30_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    raw = open(path, "rb").read()
+    for bs in (0xFF00, 5_000):
+        a, b = str(tmp_path / f"py{bs}.bed.gz"), str(tmp_path / f"native{bs}.bed.gz")
+        write_bgzf_tabix(raw, a, block_size=bs)
+        e2e_synth.bgzip_tabix(path, b, threads=3, block_size=bs)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        whole = pp.NativePileup(b)
+        assert len(whole) == 400_000
+        whole.close()
+        wanted = [mg.names[3], mg.names[0]]
+        rows = []
+        for gz in (a, b):
+            t = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
+            assert t.indexed and set(t.contig_names) == set(wanted)
+            c = t.ingest_columns(np.arange(len(t.contig_names), dtype=np.uint32))
+            rows.append((list(t.contig_names), {k: v.copy() for k, v in c.items()}, t.bytes_inflated))
+            t.close()
+        assert rows[0][0] == rows[1][0] and rows[0][2] == rows[1][2]
+        for k in rows[0][1]:
+            assert np.array_equal(rows[0][1][k], rows[1][1][k]), k
+
+
+def test_ingest_columns_may_be_asked_for_twice(tmp_path):
+    """nm_bed_ingest_columns gives up the reader's 64-bit originals on the first call; a second call (another contig map) used
+    to walk the freed vectors."""
+    spec = synth.SynthSpec(n_contigs=3, total_bp=100_000, n_bins=1, mod_types=("a",), seed=63, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    t = pp.NativePileup(path)
+    a = {k: v.copy() for k, v in t.ingest_columns(np.arange(3, dtype=np.uint32)).items()}
+    b = {k: v.copy() for k, v in t.ingest_columns(np.array([2, 0, 1], dtype=np.uint32)).items()}
+    t.close()
+    for k in a:
+        if k != "contig":
+            assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(np.array([2, 0, 1], dtype=np.uint32)[a["contig"]], b["contig"])

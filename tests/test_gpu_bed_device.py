@@ -80,8 +80,78 @@ def test_device_parser_equals_host_parser(tmp_path):
     import gzip
     with gzip.open(path + ".gz", "wb") as g:
         g.write(b"c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")
-    with pytest.raises(NmScanError, match="compressed input"):
+    with pytest.raises(NmScanError, match="compressed input that is not bgzip"):
         pp.DevicePileup(eng, path + ".gz")
+    eng.close()
+
+
+def _columns(t, lut=None):
+    if isinstance(t, pp.NativePileup):
+        return {k: v.copy() for k, v in t.ingest_columns(np.arange(len(t.contig_names), dtype=np.uint32)).items()}
+    t.map_contigs(np.arange(len(t.contig_names), dtype=np.uint32))
+    return t.to_host()
+
+
+def _assert_same_rows(dev, host):
+    assert dev.contig_names == host.contig_names and len(dev) == len(host)
+    cd, ch = _columns(dev), _columns(host)
+    for k in ("contig", "position", "mod_type", "strand", "nvalid_cov"):
+        assert np.array_equal(cd[k], ch[k]), k
+    assert np.array_equal(cd["fraction_mod"].view(np.uint64), ch["fraction_mod"].view(np.uint64))
+
+
+def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
+    """bgzip input (what the reference recommends, docs/source/required_files.md:21): the BGZF blocks are inflated into the
+    pinned slabs of the device parser — whole file and the tabix-selected contigs (dataload.py:102-152) — and every row
+    equals nm_bed_open / nm_bed_open_indexed on the same files; block sizes that cut lines anywhere, several slabs' worth
+    of pieces per copy thread, a stale index falling back to the whole file."""
+    from helpers import write_bgzf_tabix
+    from nanomotif_amd._lib import NmScanError
+    from nanomotif_amd.engine import ScanEngine
+    eng = ScanEngine(0)
+    spec = synth.SynthSpec(n_contigs=9, total_bp=700_000, n_bins=3, mod_types=("a", "m"), seed=93, min_contig_bp=20_000)
+    mg = synth.make_metagenome(spec)
+    bed = str(tmp_path / "p.bed")
+    mg.write_bed(bed)
+    text = open(bed, "rb").read()
+    plain = pp.NativePileup(bed)
+    for block_size in (0xFF00, 4_000, 777):
+        gz = str(tmp_path / f"p{block_size}.bed.gz")
+        write_bgzf_tabix(text, gz, block_size=block_size)
+        for threads in (0, 2, 5):
+            dev = pp.DevicePileup(eng, gz, threads=threads)
+            _assert_same_rows(dev, plain)
+            dev.close()
+        # the tabix subset: every other contig, in a shuffled order (the index is walked in file order whatever is asked)
+        wanted = mg.names[1::2][::-1]
+        host = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
+        dev = pp.DevicePileup(eng, gz, contigs=wanted, index_path=gz + ".tbi")
+        assert host.indexed and dev.indexed and dev.bytes_inflated == host.bytes_inflated and dev.bytes_file == host.bytes_file
+        assert set(dev.contig_names) == set(wanted) and 0 < len(dev) < len(plain)
+        _assert_same_rows(dev, host)
+        dev.close()
+        host.close()
+        # one contig only, and a contig the index does not know
+        dev = pp.DevicePileup(eng, gz, contigs=[mg.names[4], "not_in_the_file"], index_path=gz + ".tbi")
+        assert dev.indexed and dev.contig_names == [mg.names[4]] and dev.contigs_not_indexed == 1
+        dev.close()
+    plain.close()
+    # a stale index (written for another file): the regions land off the blocks or on other contigs' rows -> whole file
+    other = synth.make_metagenome(synth.SynthSpec(n_contigs=9, total_bp=500_000, n_bins=3, mod_types=("a", "m"), seed=94, min_contig_bp=20_000))
+    obed = str(tmp_path / "o.bed")
+    other.write_bed(obed)
+    write_bgzf_tabix(open(obed, "rb").read(), str(tmp_path / "o.bed.gz"), block_size=4_000)
+    gz = str(tmp_path / "p4000.bed.gz")
+    os.replace(str(tmp_path / "o.bed.gz.tbi"), gz + ".tbi")
+    dev = pp.DevicePileup(eng, gz, contigs=mg.names[:3], index_path=gz + ".tbi")
+    assert not dev.indexed and dev.index_problem and len(dev) == 700_000
+    dev.close()
+    # a truncated file: the last block is cut in the middle
+    bad = str(tmp_path / "cut.bed.gz")
+    raw = open(gz, "rb").read()
+    open(bad, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(NmScanError, match="not bgzip|corrupt BGZF"):
+        pp.DevicePileup(eng, bad)
     eng.close()
 
 

@@ -22,8 +22,8 @@ def _free_port():
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_cli(tmp, args, nproc=1, check=True):
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+def _run_cli(tmp, args, nproc=1, check=True, env_extra=None):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **(env_extra or {}))
     cmd = [sys.executable, "-m", "nanomotif_amd", "motif_discovery"] + args
     if nproc > 1:      # several ranks on the one GPU of the test box: gloo carries the all-reduces
         env["NANOMOTIF_DIST_BACKEND"] = "gloo"
@@ -209,10 +209,14 @@ def test_bgzip_pileup_is_read_through_its_tabix_index(tmp_path):
             if b in bins:
                 f.write(f"{n}\t{b}\n")
     r = _run_cli(tmp, ["assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv", "--out", "out"])
-    assert "tabix-indexed" in r.stdout + r.stderr
+    assert "tabix-indexed" in r.stdout + r.stderr and "parsed on the device" in r.stdout + r.stderr      # round 4: bgzip on the device parser
     got = open(tmp + "/out/bin-motifs.tsv").read()
     assert got == oracle_pipeline(mg, bgzip_order=True, bins=set(bins))
     assert {l.split("\t")[0] for l in got.strip().split("\n")[1:]} == set(bins)
+    # the host reader on the same files gives the same table
+    r = _run_cli(tmp, ["assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv", "--out", "out_host"], env_extra={"NANOMOTIF_HOST_PARSER": "1"})
+    assert "parsed on the device" not in r.stdout + r.stderr
+    assert open(tmp + "/out_host/bin-motifs.tsv").read() == got
 
 
 def test_more_ranks_than_contigs(tmp_path):
