@@ -51,3 +51,20 @@ def test_product_never_imports_the_oracle():
             assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path} imports the oracle"
     src = open(os.path.join(root, "nanomotif_amd", "_lib.py")).read()
     assert "no CPU fallback" in src and "raise NmScanError" in src
+
+
+def test_console_entry_point_is_the_references():
+    """setup.py:48-52 of the reference installs `nanomotif = nanomotif.main:main`; pyproject.toml installs the same command
+    on this package, and the target parses the reference's motif_discovery flags (argparser.py:101-136)."""
+    import importlib
+    import tomli
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as f:
+        scripts = tomli.load(f)["project"]["scripts"]
+    assert list(scripts) == ["nanomotif"]
+    mod, fn = scripts["nanomotif"].split(":")
+    main = getattr(importlib.import_module(mod), fn)
+    assert callable(main)
+    from nanomotif_amd.argparser import create_parser
+    a = create_parser().parse_args(["motif_discovery", "a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "-t", "3", "--seed", "7",
+                                    "--search_frame_size", "40", "--min_motif_score", "0.2", "--minimum_kl_divergence", "0.05"])
+    assert (a.command, a.assembly, a.pileup, a.contig_bin, a.out, a.threads, a.seed) == ("motif_discovery", "a.fasta", "p.bed", "cb.tsv", "o", 3, 7)
