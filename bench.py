@@ -313,6 +313,11 @@ def run_cli_extra(device, log_fn, total_bp=100_000_000):
     import tempfile
     from nanomotif_amd import e2e_synth, synth
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    need = int(96 * total_bp)                    # ~75 B of text + ~16 B of bgzip per raw row, one row per bp
+    free = shutil.disk_usage(base).free
+    if free < 1.15 * need:
+        raise RuntimeError(f"cli extra: {base} has {free / 1e9:.1f} GB free, the files of a {total_bp:,} bp run need ~{need / 1e9:.1f} GB "
+                           "(set TMPDIR, or a smaller --cli-bp)")
     tmp = tempfile.mkdtemp(prefix="nm_bench_cli_", dir=base)
     try:
         spec = synth.config("cfg3") if total_bp == 100_000_000 else synth.SynthSpec(
@@ -334,30 +339,47 @@ def run_cli_extra(device, log_fn, total_bp=100_000_000):
                        f"({sizes['rows']:,} rows) on a tmpfs (page cache, read through once after writing) -> bin-motifs.tsv; wall clock of "
                        "the whole process, cold interpreter and HIP runtime each time",
                "bed_bytes": sizes["bed_bytes"], "rows": sizes["rows"], "total_bp": total_bp, "warm_read_s": warm_s}
+        # the same pileup as bgzip + tabix (what the reference recommends, docs/source/required_files.md:21): written natively
+        # (libnmsynth: zlib level 6 on all threads), read through its index
+        t0 = time.perf_counter()
+        e2e_synth.bgzip_tabix(os.path.join(tmp, "pileup.bed"), os.path.join(tmp, "pileup.bed.gz"))
+        out["gz_bytes"] = os.path.getsize(os.path.join(tmp, "pileup.bed.gz"))
+        log_fn(f"cli extra: bgzip + tabix of the pileup: {out['gz_bytes'] / 1e9:.2f} GB in {time.perf_counter() - t0:.1f}s")
+        with open(os.path.join(tmp, "pileup.bed.gz"), "rb", buffering=0) as f:
+            buf = bytearray(64 << 20)
+            while f.readinto(buf):
+                pass
         texts = {}
-        for parser in ("device", "host"):
+        for leg, pileup, parser in (("device", "pileup.bed", "device"), ("host", "pileup.bed", "host"), ("gz_device", "pileup.bed.gz", "device"),
+                                    ("gz_host", "pileup.bed.gz", "host")):
             env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
             if parser == "host":
                 env["NANOMOTIF_HOST_PARSER"] = "1"
             t0 = time.perf_counter()
-            r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv",
-                                "--out", "out_" + parser], cwd=tmp, env=env, capture_output=True, text=True)
+            r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", pileup, "-c", "contig_bin.tsv",
+                                "--out", "out_" + leg], cwd=tmp, env=env, capture_output=True, text=True)
             wall = time.perf_counter() - t0
             if r.returncode:
-                out[parser] = {"error": (r.stdout + r.stderr)[-500:]}
+                out[leg] = {"error": (r.stdout + r.stderr)[-500:]}
                 continue
-            tj = os.path.join(tmp, "out_" + parser, "logs", "timings.motif_discovery.json")
+            tj = os.path.join(tmp, "out_" + leg, "logs", "timings.motif_discovery.json")
             t = json.load(open(tj)) if os.path.exists(tj) else {}
-            texts[parser] = open(os.path.join(tmp, "out_" + parser, "bin-motifs.tsv")).read()
-            out[parser] = {"wall_s": wall, "pileup_parse_s": t.get("pileup_parse_s"), "upload_filter_s": t.get("upload_filter_s"),
-                           "search_s": t.get("search_s"), "assembly_s": t.get("assembly_s"), "engine_start_s": t.get("engine_start_s"),
-                           "write_s": t.get("write_s"), "in_find_motifs_bin_s": t.get("find_motifs_bin_s"),
-                           "text_GB_per_s_of_parse": sizes["bed_bytes"] / 1e9 / t["pileup_parse_s"] if t.get("pileup_parse_s") else None,
-                           "motif_rows": max(len(texts[parser].splitlines()) - 1, 0)}
-        if len(texts) == 2:
+            texts[leg] = open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read()
+            out[leg] = {"wall_s": wall, "pileup_parse_s": t.get("pileup_parse_s"), "upload_filter_s": t.get("upload_filter_s"),
+                        "search_s": t.get("search_s"), "assembly_s": t.get("assembly_s"), "engine_start_s": t.get("engine_start_s"),
+                        "write_s": t.get("write_s"), "in_find_motifs_bin_s": t.get("find_motifs_bin_s"), "pileup_parser": t.get("pileup_parser"),
+                        "text_GB_per_s_of_parse": sizes["bed_bytes"] / 1e9 / t["pileup_parse_s"] if t.get("pileup_parse_s") else None,
+                        "motif_rows": max(len(texts[leg].splitlines()) - 1, 0)}
+        if "device" in texts and "host" in texts:
             out["outputs_byte_equal"] = texts["device"] == texts["host"]
+        if "gz_device" in texts and "gz_host" in texts:
+            # (a .gz run seeds once per bin, a plain run once per (bin, mod type) — find_motifs_bin.py:152-171 / :219-248 — so
+            # the two formats are compared within themselves)
+            out["gz_outputs_byte_equal"] = texts["gz_device"] == texts["gz_host"]
+        if "gz_device" in out and "device" in out and "wall_s" in out["gz_device"] and "wall_s" in out["device"]:
+            out["gz_over_plain_wall"] = out["gz_device"]["wall_s"] / out["device"]["wall_s"]
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -384,7 +406,7 @@ def main():
     ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes,cli (auto: all that apply; none)")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: those that apply; none), and the opt-in cli (cfg 3 as FILES, plain and bgzip: writes ~9 GB to a tmpfs, four CLI processes)")
     ap.add_argument("--cli-bp", type=int, default=100_000_000, help="size of the file-to-bin-motifs.tsv extra (cfg 3: 100 Mbp = 7.8 GB of bedMethyl text)")
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
                     help="debug, one GPU: hold the shard rank 0 of an N-rank run would hold (contigs as shard.assign_contigs deals "
@@ -469,7 +491,7 @@ def main():
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
-    extras = {"e2e", "cfg5_all", "weak", "two_lanes", "cli"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
+    extras = {"e2e", "cfg5_all", "weak", "two_lanes"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
     if args.workload != "cfg5" or weak:
         extras = set()
     if world == 1:

@@ -586,18 +586,29 @@ class ScanEngine:
             slot_of[int(code)] = self.slot_of_mod[label]
             canon[int(code)] = ord(base)
         run_eng = lut[table.run_contig]                                   # engine contig of every run
-        real = run_eng[run_eng != 0xFFFFFFFF]
-        one_run_each = len(np.unique(real)) == len(real)
         n = len(table)
         bounds = [0]
-        if one_run_each and max_part_rows and n > max_part_rows:
-            at = 0
-            for e in table.run_row[1:].tolist():
-                if e - at >= max_part_rows:
+        if max_part_rows and n > max_part_rows:
+            # a part must hold whole contigs: a run boundary is a cut when every contig seen so far has had its LAST run
+            # (a modkit file has one run per contig: every boundary is one; a file that comes back to a contig later is cut
+            # behind that contig's last run, so its parts can be larger than asked for — said below, never silently whole)
+            last_run = {}
+            for r, c in enumerate(run_eng.tolist()):
+                if c != 0xFFFFFFFF:
+                    last_run[c] = r
+            at, open_until = 0, -1
+            for r, (c, e) in enumerate(zip(run_eng.tolist(), table.run_row[1:].tolist())):
+                if c != 0xFFFFFFFF:
+                    open_until = max(open_until, last_run[c])
+                if open_until <= r and e - at >= max_part_rows:
                     bounds.append(int(e))
                     at = e
         if bounds[-1] != n:
             bounds.append(n)
+        if max_part_rows and max(b - a for a, b in zip(bounds, bounds[1:])) > 2 * max_part_rows:
+            import logging
+            logging.warning(f"pileup rows are not grouped by contig: ingestion parts of up to {max(b - a for a, b in zip(bounds, bounds[1:])):,} rows "
+                            f"instead of {max_part_rows:,} (device memory for the raw rows and the adjacency scratch grows with them)")
         n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
         for k in range(len(bounds) - 1):
             a, b = bounds[k], bounds[k + 1]

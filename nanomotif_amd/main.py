@@ -188,10 +188,30 @@ def find_motifs_bin(args):
         gather_world = 1
     if world > 1 and dist.get_backend() == "nccl" and os.environ.get("NANOMOTIF_ALLREDUCE", "native") == "native":
         # the per-round count tables travel through the C ABI's own RCCL communicator (nm_allreduce_counts_host);
-        # torch.distributed only carried the 128-byte id to the ranks.  Every rank must end up on the SAME path: a rank
-        # whose bring-up fails (librccl not loadable, ncclCommInitRank error) reports it, all ranks agree with a MIN
-        # all-reduce, and the run falls back to torch.distributed as a whole instead of leaving the others blocked
+        # torch.distributed only carried the 128-byte id to the ranks.  Every rank must end up on the SAME path.  What is
+        # guaranteed: a rank on which librccl does not load says so BEFORE anybody enters ncclCommInitRank (every rank makes
+        # a unique id as a probe; MIN all-reduce), and a rank whose ncclCommInitRank RETURNS an error says so after it (second
+        # MIN all-reduce) — the run then falls back to torch.distributed as a whole.  What no agreement can cover is a rank
+        # that never arrives inside the collective init (it died, or hangs): the others would wait there for ever, so the
+        # init runs under a watchdog that ends this process with a message (NANOMOTIF_COMM_TIMEOUT seconds, default 300)
+        import threading
         import torch
+
+        def comm_init_watched():
+            limit = float(os.environ.get("NANOMOTIF_COMM_TIMEOUT", "300"))
+            done = threading.Event()
+
+            def watchdog():
+                if not done.wait(limit):
+                    sys.stderr.write(f"rank {rank}: nm_comm_init did not return within {limit:.0f} s (a rank missing from ncclCommInitRank?): "
+                                     "giving up; NANOMOTIF_ALLREDUCE=torch takes torch.distributed instead\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+            threading.Thread(target=watchdog, name="nm-comm-watchdog", daemon=True).start()
+            try:
+                eng.comm_init(rank, world, uid[0])
+            finally:
+                done.set()
 
         def agreed(ok_here: int) -> bool:
             flag = torch.tensor([ok_here], dtype=torch.int32, device=torch.device("cuda", device))
@@ -209,7 +229,7 @@ def find_motifs_bin(args):
         if agreed(ok):
             dist.broadcast_object_list(uid, src=0)
             try:
-                eng.comm_init(rank, world, uid[0])
+                comm_init_watched()
             except NmScanError as e:
                 ok = 0
                 log.warning(f"rank {rank}: nm_comm_init failed ({e})")

@@ -203,3 +203,35 @@ def test_cli_on_the_device_parser_equals_the_host_parser_run(tmp_path):
         assert ("parsed on the device" in r.stdout + r.stderr) == (not env_extra)
         outs.append(open(f"{tmp}/{out}/bin-motifs.tsv").read())
     assert outs[0] == outs[1] and "GATC" in outs[0]
+
+
+def test_parts_of_a_pileup_that_comes_back_to_a_contig(tmp_path):
+    """Rows not grouped by contig (the second half of one contig's rows moved to the end of the file) and a small part size:
+    parts are cut only where every contig seen so far is complete, and the result equals the one-piece ingest."""
+    from nanomotif_amd.engine import ScanEngine
+    from nanomotif_amd.motif import Motif
+    spec = synth.SynthSpec(n_contigs=6, total_bp=600_000, n_bins=2, mod_types=("a",), seed=95, min_contig_bp=30_000, fixed_motifs=(("GATC", 1, "a"),))
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    lines = open(path).read().splitlines(keepends=True)
+    first = [l.split("\t")[0] for l in lines]
+    name = mg.names[1]
+    idx = [i for i, n in enumerate(first) if n == name]
+    tail = idx[len(idx) // 2:]
+    moved = [l for i, l in enumerate(lines) if i not in set(tail)] + [lines[i] for i in tail]
+    open(path, "w").write("".join(moved))
+    labels = {1: ("a", "A")}
+    cands = [(Motif("GATC", 1), "a", b) for b in sorted(set(mg.bin_names))]
+    out = []
+    for part_rows in (None, 50_000):
+        eng = ScanEngine(0)
+        eng.upload_assembly(mg.names, [mg.contig_ascii(i) for i in range(len(mg.names))], mg.bin_names)
+        t = pp.DevicePileup(eng, path)
+        assert len(t.run_contig) == 7
+        lut = np.array([mg.names.index(n) for n in t.contig_names], dtype=np.uint32)
+        res = eng.ingest_device_pileup(t, lut, labels, max_part_rows=part_rows)
+        out.append((res["n_kept"], res["kept"].tolist(), eng.score(cands).tolist()))
+        t.close()
+        eng.close()
+    assert out[0] == out[1] and out[0][0] > 0
