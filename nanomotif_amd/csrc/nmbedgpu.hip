@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -106,6 +107,222 @@ __global__ __launch_bounds__(256) void bed_starts_kernel(const uint8_t *__restri
         line_start[at++] = (uint32_t)(base + k);
     }
 }
+
+// ---- DEFLATE on the device (round 4): the BGZF blocks of a bgzip pileup (<= 64 KiB of text each, independent streams) are
+// inflated by the GPU — one LANE per block, canonical Huffman decoding from per-length code counts (held in registers) and a
+// symbol table per lane in LDS, output straight into the text buffer the parse kernels read.  A lane takes ~40 ms for a
+// block (every back-reference is a round trip through memory), but a 3 GiB slab is 48 000 blocks in flight together:
+// tools/inflate_proto.hip measures 27 GB/s of text on one wave per CU against 0.9 GB/s for zlib on a host thread, and only
+// the compressed bytes (a fifth of the text) cross PCIe.
+struct InfPiece {
+    unsigned long long in_off;          // raw deflate stream inside the packed compressed buffer
+    unsigned int in_len, out_len;       // compressed bytes, text bytes of the whole block
+    unsigned long long dst_off;         // where the WANTED text goes in the slab
+    unsigned int skip, take;            // the wanted part of the block's text
+    unsigned long long full_off;        // partial blocks (skip / take cut them): the whole text goes to scratch + full_off first
+};
+
+constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
+struct InfTables {                      // entry-major: lane l of the wave touches [entry][l]
+    unsigned short lcount[16][INF_LANES], lsym[INF_MAXL][INF_LANES], dcount[16][INF_LANES], dsym[INF_MAXD][INF_LANES];
+};
+
+struct InfBits {
+    const unsigned char *p;
+    unsigned long long buf;
+    int cnt;
+    __device__ __forceinline__ void refill() {              // (the compressed buffer has 8 readable bytes after its end)
+        unsigned long long w;
+        memcpy(&w, p, 8);
+        buf |= w << cnt;
+        const int take = (63 - cnt) >> 3;
+        p += take;
+        cnt += take * 8;
+    }
+    __device__ __forceinline__ unsigned int get(int n) {       // n <= 16
+        if (cnt < 32) refill();
+        const unsigned int v = (unsigned int)(buf & ((1ull << n) - 1));
+        buf >>= n;
+        cnt -= n;
+        return v;
+    }
+};
+
+// canonical code from code lengths; > 0: incomplete, < 0: over-subscribed (zlib contrib/puff: construct)
+__device__ int inf_construct(unsigned short (*count)[INF_LANES], unsigned short (*symbol)[INF_LANES], const unsigned char *length, int n, int lane) {
+    for (int len = 0; len <= 15; ++len) count[len][lane] = 0;
+    for (int s = 0; s < n; ++s) count[length[s]][lane] += 1;
+    if (count[0][lane] == n) return 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= count[len][lane];
+        if (left < 0) return left;
+    }
+    unsigned short offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + count[len][lane];
+    for (int s = 0; s < n; ++s)
+        if (length[s] != 0) symbol[offs[length[s]]++][lane] = (unsigned short)s;
+    return left;
+}
+
+struct InfCounts { unsigned int c[16]; };
+__device__ __forceinline__ InfCounts inf_counts(unsigned short (*count)[INF_LANES], int lane) {
+    InfCounts k;
+#pragma unroll
+    for (int len = 0; len < 16; ++len) k.c[len] = count[len][lane];
+    return k;
+}
+
+__device__ __forceinline__ int inf_decode(InfBits &b, const InfCounts &k, unsigned short (*symbol)[INF_LANES], int lane) {
+    if (b.cnt < 32) b.refill();
+    int code = 0, first = 0, index = 0;
+    unsigned int bits = (unsigned int)b.buf;
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(bits & 1);
+        bits >>= 1;
+        const int c = (int)k.c[len];
+        if (code - c < first) {
+            b.buf >>= len;
+            b.cnt -= len;
+            return symbol[index + (code - first)][lane];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__constant__ unsigned short INF_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ unsigned char INF_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ unsigned short INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ unsigned char INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ unsigned char INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// status: 0, or (piece index << 8 | what went wrong) of the first bad block
+__global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned char *__restrict__ in, const InfPiece *__restrict__ pieces, unsigned int n_pieces,
+                                                                unsigned char *__restrict__ text, unsigned char *__restrict__ scratch,
+                                                                unsigned int *__restrict__ status) {
+    __shared__ InfTables T;
+    const int lane = threadIdx.x;
+    const unsigned int i = blockIdx.x * INF_LANES + lane;
+    if (i >= n_pieces) return;
+    const InfPiece pc = pieces[i];
+    const bool partial = pc.skip != 0 || pc.take != pc.out_len;
+    InfBits b{in + pc.in_off, 0ull, 0};
+    unsigned char *dst = partial ? scratch + pc.full_off : text + pc.dst_off;
+    unsigned int o = 0;
+    int err = 0, last = 0;
+    unsigned char lengths[INF_MAXL + INF_MAXD];
+    while (!last && !err) {
+        last = (int)b.get(1);
+        const int type = (int)b.get(2);
+        if (type == 0) {                                         // stored
+            b.buf >>= (b.cnt & 7);
+            b.cnt -= (b.cnt & 7);
+            const unsigned int len = b.get(16), nlen = b.get(16);
+            if ((len ^ 0xFFFFu) != nlen || o + len > pc.out_len) { err = 2; break; }
+            for (unsigned int k = 0; k < len; ++k) dst[o++] = (unsigned char)b.get(8);
+            continue;
+        }
+        if (type == 3) { err = 3; break; }
+        if (type == 1) {                                         // fixed code
+            int s = 0;
+            for (; s < 144; ++s) lengths[s] = 8;
+            for (; s < 256; ++s) lengths[s] = 9;
+            for (; s < 280; ++s) lengths[s] = 7;
+            for (; s < 288; ++s) lengths[s] = 8;
+            inf_construct(T.lcount, T.lsym, lengths, 288, lane);
+            for (s = 0; s < 30; ++s) lengths[s] = 5;
+            inf_construct(T.dcount, T.dsym, lengths, 30, lane);
+        } else {                                                 // dynamic code
+            const int nlen = (int)b.get(5) + 257, ndist = (int)b.get(5) + 1, ncode = (int)b.get(4) + 4;
+            if (nlen > 286 || ndist > 30) { err = 4; break; }
+            int idx = 0;
+            for (; idx < ncode; ++idx) lengths[INF_CLORDER[idx]] = (unsigned char)b.get(3);
+            for (; idx < 19; ++idx) lengths[INF_CLORDER[idx]] = 0;
+            if (inf_construct(T.lcount, T.lsym, lengths, 19, lane) != 0) { err = 5; break; }
+            const InfCounts kc = inf_counts(T.lcount, lane);
+            idx = 0;
+            while (idx < nlen + ndist) {
+                const int sym = inf_decode(b, kc, T.lsym, lane);
+                if (sym < 0) { err = 6; break; }
+                if (sym < 16) lengths[idx++] = (unsigned char)sym;
+                else {
+                    int len = 0, rep;
+                    if (sym == 16) {
+                        if (idx == 0) { err = 7; break; }
+                        len = lengths[idx - 1];
+                        rep = 3 + (int)b.get(2);
+                    } else if (sym == 17) rep = 3 + (int)b.get(3);
+                    else rep = 11 + (int)b.get(7);
+                    if (idx + rep > nlen + ndist) { err = 8; break; }
+                    while (rep--) lengths[idx++] = (unsigned char)len;
+                }
+            }
+            if (err) break;
+            if (lengths[256] == 0) { err = 9; break; }
+            int r = inf_construct(T.lcount, T.lsym, lengths, nlen, lane);
+            if (r < 0 || (r > 0 && nlen - T.lcount[0][lane] != 1)) { err = 10; break; }
+            r = inf_construct(T.dcount, T.dsym, lengths + nlen, ndist, lane);
+            if (r < 0 || (r > 0 && ndist - T.dcount[0][lane] != 1)) { err = 11; break; }
+        }
+        const InfCounts kl = inf_counts(T.lcount, lane), kd = inf_counts(T.dcount, lane);
+        for (;;) {                                               // the block's symbols
+            int sym = inf_decode(b, kl, T.lsym, lane);
+            if (sym < 0) { err = 12; break; }
+            if (sym < 256) {
+                if (o >= pc.out_len) { err = 13; break; }
+                dst[o++] = (unsigned char)sym;
+            } else if (sym == 256) break;
+            else {
+                sym -= 257;
+                if (sym >= 29) { err = 14; break; }
+                const unsigned int len = INF_LBASE[sym] + b.get(INF_LEXT[sym]);
+                const int ds = inf_decode(b, kd, T.dsym, lane);
+                if (ds < 0 || ds >= 30) { err = 15; break; }
+                const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
+                if (dist > o || o + len > pc.out_len) { err = 16; break; }
+                unsigned int k = 0;
+                if (dist >= 8)
+                    for (; k + 8 <= len; k += 8) {                // eight bytes at a time (unaligned global accesses are fine)
+                        unsigned long long v;
+                        memcpy(&v, dst + o + k - dist, 8);
+                        memcpy(dst + o + k, &v, 8);
+                    }
+                for (; k < len; ++k) dst[o + k] = dst[o + k - dist];
+                o += len;
+            }
+        }
+    }
+    if (!err && o != pc.out_len) err = 17;
+    if (!err && (size_t)(b.p - (in + pc.in_off)) > (size_t)pc.in_len + 8) err = 18;      // ran past the block's stream
+    if (err) { atomicCAS(status, 0u, (unsigned int)err | (i << 8)); return; }
+    if (partial) {
+        unsigned char *out = text + pc.dst_off;
+        for (unsigned int k = 0; k < pc.take; ++k) out[k] = dst[pc.skip + k];
+    }
+}
+
+// the byte after the last '\n' of text[0, n) (0 when there is none in the last `window` bytes): what lies behind it is the
+// beginning of a line that continues in the next slab.  One workgroup.
+__global__ __launch_bounds__(256) void bed_tail_kernel(const uint8_t *__restrict__ text, uint64_t n, uint64_t window, unsigned long long *out) {
+    __shared__ unsigned long long best;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    const uint64_t lo = n > window ? n - window : 0;
+    unsigned long long mine = 0;
+    for (uint64_t i = lo + threadIdx.x; i < n; i += 256)
+        if (text[i] == '\n') mine = i + 1;
+    atomicMax(&best, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = best;
+}
+
 
 struct BedOut {
     uint64_t *hash;             // [line of the slab] name hash (scratch of one slab)
@@ -549,9 +766,32 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     if (!b) return fail(NM_ENOMEM, "out of host memory");
     b->ctx = c;
     struct Fail { nm_bedcols *b; bool keep = false; ~Fail() { if (!keep) (void)nm_bedcols_close(b); } } guard{b};
-    // slabs of whole lines
+    // bgzip: the blocks are inflated ON THE DEVICE (bed_inflate_kernel) unless NM_BED_HOST_INFLATE=1 asks for the copy threads
+    const bool dev_inflate = src.bgzf && getenv("NM_BED_HOST_INFLATE") == nullptr;
+    // device inflate: slabs of whole BLOCKS (up to 3 GiB of text: line offsets are 32-bit), a line that straddles two slabs is
+    // carried over on the device
+    constexpr uint64_t INF_SLAB_TEXT = 3ull << 30, CARRY_CAP = 1ull << 20;
+    struct InfSlab { size_t first, last; uint64_t text, comp; };
+    std::vector<InfSlab> inf_slabs;
+    uint64_t inf_text_cap = 0, inf_comp_cap = 0;
+    if (dev_inflate) {
+        const uint64_t cap = getenv("NM_BED_INFLATE_SLAB") ? std::max<uint64_t>(1u << 16, strtoull(getenv("NM_BED_INFLATE_SLAB"), nullptr, 10)) : INF_SLAB_TEXT;
+        for (size_t i = 0; i < src.pieces.size();) {
+            InfSlab sl{i, i, 0, 0};
+            while (sl.last < src.pieces.size() && (sl.last == sl.first || sl.text + src.pieces[sl.last].take <= cap)) {
+                sl.text += src.pieces[sl.last].take;
+                sl.comp += src.pieces[sl.last].in_len;
+                sl.last += 1;
+            }
+            inf_text_cap = std::max(inf_text_cap, sl.text);
+            inf_comp_cap = std::max(inf_comp_cap, sl.comp);
+            inf_slabs.push_back(sl);
+            i = sl.last;
+        }
+    }
+    // slabs of whole lines (text read or inflated by the host)
     std::vector<uint64_t> cut(1, 0);
-    while (cut.back() < n) {
+    while (!dev_inflate && cut.back() < n) {
         uint64_t e = std::min<uint64_t>(n, cut.back() + SLAB_BYTES);
         if (e < n) {                                       // back to the end of the last whole line (the tail of the slab is read in pieces)
             const uint64_t lo = cut.back();
@@ -596,7 +836,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             if (cs) (void)hipStreamDestroy(cs);
         }
     } cleanup{h_ring, d_slab, dev_tmp, copy_stream, h2d_done, parsed, c};
-    const uint64_t slab_cap = std::min<uint64_t>(SLAB_BYTES, std::max<uint64_t>(n, 1));
+    const uint64_t slab_cap = dev_inflate ? inf_text_cap + CARRY_CAP + 64 : std::min<uint64_t>(SLAB_BYTES, std::max<uint64_t>(n, 1));
     const uint32_t max_blocks = (uint32_t)((slab_cap + BLOCK_BYTES - 1) / BLOCK_BYTES);
     const uint64_t max_lines = slab_cap / 2 + 1;                          // a non-empty line and its '\n'
     if (n_slabs) {
@@ -672,6 +912,153 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
 
     bool first_rows = true;                 // the next slab with rows holds row 0
     size_t n_parsed = 0;                    // slabs with rows so far (ping-pong of the "hash of the row before")
+    // the whole lines of text[0, len) (16-byte aligned, device memory) -> rows; text_base: the text offset of its first byte;
+    // grow_hint: file size / slab size when this is the first of several slabs (sizes the columns once); counted(): called
+    // as soon as the line count is back on the host
+    auto parse_text = [&](const uint8_t *d_text, uint64_t len, uint64_t text_base, double grow_hint, const std::function<void()> &counted) -> int {
+        const uint32_t nblk = (uint32_t)((len + BLOCK_BYTES - 1) / BLOCK_BYTES);
+        hipLaunchKernelGGL(bed_count_kernel, dim3(nblk), dim3(256), 0, c->stream, d_text, len, d_block_cnt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(d_block_cnt + nblk, 0, 4, c->stream));
+        HIP_TRY(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)nblk + 1, rocprim::plus<unsigned int>(), c->stream));
+        uint32_t n_lines = 0;
+        HIP_TRY(hipMemcpyAsync(&n_lines, d_block_off + nblk, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        counted();
+        if (n_lines > line_cap) return fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path);
+        if (b->n_rows + n_lines >= 0xFFFFFFFFull) return fail(NM_ERANGE, "%s: more than 4G rows in one pileup", path);
+        // the columns are sized ONCE, from the line density of the first slab (+ 3 % and one slab's worth of slack): every
+        // regrow is a fresh allocation (scrubbed by the driver when the memory was used before) plus a copy
+        uint64_t want = b->n_rows + n_lines;
+        if (grow_hint > 0) want = std::max<uint64_t>(want, (uint64_t)((double)n_lines * grow_hint * 1.03) + n_lines);
+        int rc = grow(b, want, c->stream);
+        if (rc) return rc;
+        if (n_lines) {
+            hipLaunchKernelGGL(bed_starts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_text, len, d_block_off, d_line_start);
+            BedOut o{d_hash, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
+            hipLaunchKernelGGL(bed_parse_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_text, len, d_line_start, n_lines, b->n_rows,
+                               text_base, o);
+            hipLaunchKernelGGL(bed_runs_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_hash, d_line_start, n_lines, b->n_rows, text_base,
+                               first_rows ? 1 : 0, d_prev + (n_parsed & 1), d_prev + ((n_parsed + 1) & 1), d_counters + 1, d_runs, RUN_CAP);
+            HIP_TRY(hipGetLastError());
+            first_rows = false;
+            n_parsed += 1;
+        }
+        b->n_rows += n_lines;
+        return NM_OK;
+    };
+    // ---- bgzip, inflated on the device: per slab the compressed bytes of its blocks (packed, through the pinned ring) ->
+    // bed_inflate_kernel -> the same line / field kernels
+    if (dev_inflate && !inf_slabs.empty()) {
+        constexpr uint64_t CHUNK = SLAB_BYTES;                        // compressed bytes per pinned buffer
+        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp = nullptr, *d_scratch = nullptr;
+        InfPiece *d_pieces = nullptr;
+        unsigned int *d_status = nullptr;
+        unsigned long long *d_tail = nullptr;
+        size_t max_pieces = 0, max_partial = 0;
+        for (const InfSlab &sl : inf_slabs) {
+            max_pieces = std::max(max_pieces, sl.last - sl.first);
+            size_t np = 0;
+            for (size_t i = sl.first; i < sl.last; ++i) np += src.pieces[i].skip != 0 || src.pieces[i].take != src.pieces[i].out_len;
+            max_partial = std::max(max_partial, np);
+        }
+        for (int i = 0; i < 2 && (size_t)i < inf_slabs.size(); ++i) HIP_TRY(tmp_alloc((void **)&d_text[i], slab_cap + 128));
+        HIP_TRY(tmp_alloc((void **)&d_comp, inf_comp_cap + 64));
+        HIP_TRY(tmp_alloc((void **)&d_scratch, std::max<size_t>(max_partial, 1) << 16));
+        HIP_TRY(tmp_alloc((void **)&d_pieces, max_pieces * sizeof(InfPiece)));
+        HIP_TRY(tmp_alloc((void **)&d_status, 4));
+        HIP_TRY(tmp_alloc((void **)&d_tail, 8));
+        HIP_TRY(hipMemsetAsync(d_status, 0, 4, c->stream));
+        uint8_t *h_chunk[2] = {nullptr, nullptr};
+        hipEvent_t chunk_done[2] = {nullptr, nullptr};
+        struct Pinned { uint8_t **h; hipEvent_t *e; hipStream_t &cs; ~Pinned() {
+            if (cs) (void)hipStreamSynchronize(cs);
+            for (int i = 0; i < 2; ++i) { if (h[i]) (void)hipHostFree(h[i]); if (e[i]) (void)hipEventDestroy(e[i]); }
+        } } pinned{h_chunk, chunk_done, copy_stream};
+        if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));
+        }
+        const bool timing = getenv("NM_BED_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
+        std::vector<InfPiece> hp;
+        uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
+        size_t n_chunk = 0;
+        const unsigned nt = std::max(1u, threads - 1);
+        for (size_t si = 0; si < inf_slabs.size(); ++si) {
+            const InfSlab &sl = inf_slabs[si];
+            uint8_t *text = d_text[si % 2];
+            // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
+            hp.clear();
+            uint64_t coff = 0, toff = CARRY_CAP, poff = 0;
+            for (size_t i = sl.first; i < sl.last; ++i) {
+                const nmbgzf::Piece &pp = src.pieces[i];
+                const bool partial = pp.skip != 0 || pp.take != pp.out_len;
+                hp.push_back({coff, (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff});
+                coff += pp.in_len;
+                toff += pp.take;
+                if (partial) poff += 1u << 16;
+            }
+            HIP_TRY(hipMemcpyAsync(d_pieces, hp.data(), hp.size() * sizeof(InfPiece), hipMemcpyHostToDevice, c->stream));
+            // compressed bytes: chunks of whole pieces through two pinned buffers, memcpy on several threads
+            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            for (size_t a = 0; a < hp.size();) {
+                size_t e = a;
+                while (e < hp.size() && (e == a || hp[e].in_off + hp[e].in_len - hp[a].in_off <= CHUNK)) ++e;
+                const uint64_t lo = hp[a].in_off, bytes = hp[e - 1].in_off + hp[e - 1].in_len - lo;
+                uint8_t *dst = h_chunk[n_chunk % 2];
+                if (n_chunk >= 2) HIP_TRY(hipEventSynchronize(chunk_done[n_chunk % 2]));
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nt; ++t)
+                    pool.emplace_back([&, t] {
+                        for (size_t i = a + t; i < e; i += nt) memcpy(dst + (hp[i].in_off - lo), src.z + src.pieces[sl.first + i].in_off, hp[i].in_len);
+                    });
+                for (auto &th : pool) th.join();
+                HIP_TRY(hipMemcpyAsync(d_comp + lo, dst, bytes, hipMemcpyHostToDevice, copy_stream));
+                HIP_TRY(hipEventRecord(chunk_done[n_chunk % 2], copy_stream));
+                n_chunk += 1;
+                a = e;
+            }
+            const double t_copied = now();
+            t_read += t_copied - t0;
+            HIP_TRY(hipStreamWaitEvent(c->stream, chunk_done[(n_chunk - 1) % 2], 0));
+            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((hp.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, c->stream, d_comp, d_pieces,
+                               (unsigned int)hp.size(), text, d_scratch, d_status);
+            HIP_TRY(hipGetLastError());
+            // where the last whole line ends; what follows it is carried into the next slab
+            const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
+            const bool last_slab = si + 1 == inf_slabs.size();
+            unsigned long long end_of_lines = total;
+            unsigned int status = 0;
+            if (!last_slab) {
+                hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, c->stream, text, total, CARRY_CAP, d_tail);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&end_of_lines, d_tail, 8, hipMemcpyDeviceToHost, c->stream));
+            }
+            HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const double t_inflated = now();
+            if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, inflate error %u)", path, status >> 8, status & 255u);
+            if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
+                return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16));
+            // the parse kernels want a 16-byte aligned start: the few bytes in front of the carried line become empty lines
+            const uint64_t aligned = begin & ~15ull;
+            if (aligned < begin) HIP_TRY(hipMemsetAsync(text + aligned, '\n', begin - aligned, c->stream));
+            const uint64_t text_base = src.pieces[sl.first].text_off - carry - (begin - aligned);
+            int rc = parse_text(text + aligned, end_of_lines - aligned, text_base, si == 0 && inf_slabs.size() > 1 ? (double)n / (double)sl.text : 0.0, [] {});
+            if (rc) return rc;
+            if (timing) {
+                (void)hipStreamSynchronize(c->stream);
+                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: copies %.3f s, + inflate %.3f s, + parse %.3f s\n", si, hp.size(), sl.text / 1e9,
+                        t_copied - t0, t_inflated - t_copied, now() - t_inflated);
+            }
+            carry = total - end_of_lines;
+            if (!last_slab && carry) HIP_TRY(hipMemcpyAsync(d_text[(si + 1) % 2] + CARRY_CAP - carry, text + end_of_lines, carry, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     for (size_t k = 0; k < n_slabs; ++k) {
         const uint64_t len = cut[k + 1] - cut[k];
         {
@@ -683,40 +1070,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipMemcpyAsync(d_slab[k % 2], h_ring[k % RING], len, hipMemcpyHostToDevice, copy_stream));
         HIP_TRY(hipEventRecord(h2d_done[k % RING], copy_stream));
         HIP_TRY(hipStreamWaitEvent(c->stream, h2d_done[k % RING], 0));
-        const uint32_t nblk = (uint32_t)((len + BLOCK_BYTES - 1) / BLOCK_BYTES);
-        hipLaunchKernelGGL(bed_count_kernel, dim3(nblk), dim3(256), 0, c->stream, d_slab[k % 2], len, d_block_cnt);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemsetAsync(d_block_cnt + nblk, 0, 4, c->stream));
-        HIP_TRY(rocprim::exclusive_scan(d_scan_tmp, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)nblk + 1, rocprim::plus<unsigned int>(), c->stream));
-        uint32_t n_lines = 0;
-        HIP_TRY(hipMemcpyAsync(&n_lines, d_block_off + nblk, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        {   // the pinned buffer of this slab may be refilled once its H2D is done (it is: the count kernel ran after it)
-            std::lock_guard<std::mutex> lk(mu);
-            consumed = k + 1;
-        }
-        cv.notify_all();
-        if (n_lines > line_cap) return fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path);
-        if (b->n_rows + n_lines >= 0xFFFFFFFFull) return fail(NM_ERANGE, "%s: more than 4G rows in one pileup", path);
-        // the columns are sized ONCE, from the line density of the first slab (+ 3 % and one slab's worth of slack): every
-        // regrow is a fresh allocation (scrubbed by the driver when the memory was used before) plus a copy
-        uint64_t want = b->n_rows + n_lines;
-        if (k == 0 && n_slabs > 1) want = std::max<uint64_t>(want, (uint64_t)((double)n_lines * ((double)n / (double)len) * 1.03) + n_lines);
-        int rc = grow(b, want, c->stream);
+        int rc = parse_text(d_slab[k % 2], len, cut[k], k == 0 && n_slabs > 1 ? (double)n / (double)len : 0.0, [&] {
+            // the pinned buffer of this slab may be refilled once its H2D is done (it is: the count kernel ran after it)
+            { std::lock_guard<std::mutex> lk(mu); consumed = k + 1; }
+            cv.notify_all();
+        });
         if (rc) return rc;
-        if (n_lines) {
-            hipLaunchKernelGGL(bed_starts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_slab[k % 2], len, d_block_off, d_line_start);
-            BedOut o{d_hash, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
-            hipLaunchKernelGGL(bed_parse_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_slab[k % 2], len, d_line_start, n_lines, b->n_rows,
-                               cut[k], o);
-            hipLaunchKernelGGL(bed_runs_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_hash, d_line_start, n_lines, b->n_rows, cut[k],
-                               first_rows ? 1 : 0, d_prev + (n_parsed & 1), d_prev + ((n_parsed + 1) & 1), d_counters + 1, d_runs, RUN_CAP);
-            HIP_TRY(hipGetLastError());
-            first_rows = false;
-            n_parsed += 1;
-        }
         HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
-        b->n_rows += n_lines;
     }
     if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block" : "cannot read pileup '%s'", path);
     unsigned long long first_error = ~0ull;
@@ -724,10 +1084,17 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first_error != ~0ull) return fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF)));
     std::vector<char> line_buf(1u << 16);
-    auto field = [&](uint64_t line, int k, const char **fb, const char **fe) {     // k-th tab-separated field of the line at `line`
-        const uint64_t got = std::min<uint64_t>(line_buf.size(), n - line);
-        if (!read_at(line, line_buf.data(), got)) { *fb = *fe = line_buf.data(); return; }
-        const char *p = line_buf.data(), *end = line_buf.data() + got;
+    // k-th tab-separated field of the line at text offset `line` (buf: scratch of the calling thread).  A short window first:
+    // in a bgzip file every window costs the inflation of the block(s) under it
+    auto field_in = [&](std::vector<char> &buf, uint64_t line, int k, const char **fb, const char **fe) {
+        if (buf.size() < (1u << 16)) buf.resize(1u << 16);
+        uint64_t got = std::min<uint64_t>(1024, n - line);
+        if (!read_at(line, buf.data(), got)) { *fb = *fe = buf.data(); return; }
+        if (!memchr(buf.data(), '\n', (size_t)got) && got < n - line) {
+            got = std::min<uint64_t>(buf.size(), n - line);
+            if (!read_at(line, buf.data(), got)) { *fb = *fe = buf.data(); return; }
+        }
+        const char *p = buf.data(), *end = buf.data() + got;
         const char *le = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
         if (!le) le = end;
         if (le > p && le[-1] == '\r') --le;
@@ -739,6 +1106,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         *fb = p;
         *fe = t ? t : le;
     };
+    auto field = [&](uint64_t line, int k, const char **fb, const char **fe) { field_in(line_buf, line, k, fb, fe); };
     // ---- runs of equal contig names -> names, ids, the contig column
     if (b->n_rows) {
         unsigned int n_runs = 0;
@@ -754,10 +1122,24 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         std::unordered_map<std::string, uint32_t> ids;
         b->run_row.assign(rows.begin(), rows.end());
         b->run_contig.resize(n_runs);
+        // the name of every run, read (and for bgzip: inflated) on several threads
+        std::vector<std::string> run_names(n_runs);
+        {
+            const unsigned nt = n_runs >= 64 ? std::max(1u, threads) : 1u;
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nt; ++t)
+                pool.emplace_back([&, t] {
+                    std::vector<char> buf;
+                    for (unsigned int r = t; r < n_runs; r += nt) {
+                        const char *fb, *fe;
+                        field_in(buf, offs[r], 0, &fb, &fe);
+                        run_names[r].assign(fb, fe);
+                    }
+                });
+            for (auto &th : pool) th.join();
+        }
         for (unsigned int r = 0; r < n_runs; ++r) {
-            const char *fb, *fe;
-            field(offs[r], 0, &fb, &fe);
-            std::string name(fb, fe);
+            const std::string &name = run_names[r];
             auto it = ids.find(name);
             if (it == ids.end()) {
                 it = ids.emplace(name, (uint32_t)b->names.size()).first;

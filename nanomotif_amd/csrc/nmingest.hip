@@ -28,41 +28,49 @@ struct RawRows {
 // three keys for thousands of iterations: the sums stay in a four-entry cache of wave-uniform registers and go to memory
 // when a key is evicted or the wave is done — with one atomic per wave iteration every wave of the device was still
 // hammering the same few addresses (3e7 serialised atomics = most of the 24 ms the classification pass took).
-struct KeyCache {
-    uint32_t key[4] = {~0u, ~0u, ~0u, ~0u}, n0[4] = {0, 0, 0, 0}, n1[4] = {0, 0, 0, 0};
-    uint32_t next = 0;
+struct KeyCache {                       // four entries, most recently used first; every member is wave-uniform
+    uint32_t k0 = ~0u, k1 = ~0u, k2 = ~0u, k3 = ~0u;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;      // counter [key * stride]
+    uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0;      // counter [key * stride + 1]
 };
 
-__device__ __forceinline__ void cache_flush_entry(const KeyCache &kc, int j, unsigned int *counters, uint32_t stride, uint32_t lane) {
-    if (lane == 0 && kc.key[j] != ~0u) {
-        if (kc.n0[j]) atomicAdd(counters + (size_t)kc.key[j] * stride, kc.n0[j]);
-        if (stride > 1 && kc.n1[j]) atomicAdd(counters + (size_t)kc.key[j] * stride + 1, kc.n1[j]);
+__device__ __forceinline__ void cache_flush_one(uint32_t key, uint32_t a, uint32_t b, unsigned int *counters, uint32_t stride, uint32_t lane) {
+    if (lane == 0 && key != ~0u) {
+        if (a) atomicAdd(counters + (size_t)key * stride, a);
+        if (stride > 1 && b) atomicAdd(counters + (size_t)key * stride + 1, b);
     }
 }
 
-// all arguments but `lane` are wave-uniform
+// all arguments but `lane` are wave-uniform.  The entries are plain scalars moved to the front on use (no indexed array: a
+// `next` index made the compiler keep the round-3 cache in private memory — 56 bytes of scratch per lane and a dependent
+// scratch round trip in every call, in the two classification kernels).
 __device__ __forceinline__ void cache_add(KeyCache &kc, unsigned int *counters, uint32_t stride, uint32_t key, uint32_t a, uint32_t b, uint32_t lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (kc.key[j] == key) {
-            kc.n0[j] += a;
-            kc.n1[j] += b;
-            return;
-        }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (kc.next == (uint32_t)j) {
-            cache_flush_entry(kc, j, counters, stride, lane);
-            kc.key[j] = key;
-            kc.n0[j] = a;
-            kc.n1[j] = b;
-        }
-    kc.next = (kc.next + 1) & 3u;
+    if (kc.k0 == key) {
+        kc.a0 += a;
+        kc.b0 += b;
+        return;
+    }
+    uint32_t k = key, x = a, y = b;               // what goes to the front
+    if (kc.k1 == key) {
+        x += kc.a1; y += kc.b1;
+    } else if (kc.k2 == key) {
+        x += kc.a2; y += kc.b2;
+        kc.k2 = kc.k1; kc.a2 = kc.a1; kc.b2 = kc.b1;
+    } else {
+        if (kc.k3 == key) { x += kc.a3; y += kc.b3; }
+        else cache_flush_one(kc.k3, kc.a3, kc.b3, counters, stride, lane);      // the least recently used leaves
+        kc.k3 = kc.k2; kc.a3 = kc.a2; kc.b3 = kc.b2;
+        kc.k2 = kc.k1; kc.a2 = kc.a1; kc.b2 = kc.b1;
+    }
+    kc.k1 = kc.k0; kc.a1 = kc.a0; kc.b1 = kc.b0;
+    kc.k0 = k; kc.a0 = x; kc.b0 = y;
 }
 
 __device__ __forceinline__ void cache_flush(const KeyCache &kc, unsigned int *counters, uint32_t stride, uint32_t lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cache_flush_entry(kc, j, counters, stride, lane);
+    cache_flush_one(kc.k0, kc.a0, kc.b0, counters, stride, lane);
+    cache_flush_one(kc.k1, kc.a1, kc.b1, counters, stride, lane);
+    cache_flush_one(kc.k2, kc.a2, kc.b2, counters, stride, lane);
+    cache_flush_one(kc.k3, kc.a3, kc.b3, counters, stride, lane);
 }
 
 // counters[key * stride] += lanes with pred0, counters[key * stride + 1] += lanes with pred0 && pred1, through the cache.

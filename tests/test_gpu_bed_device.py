@@ -118,18 +118,31 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
     for block_size in (0xFF00, 4_000, 777):
         gz = str(tmp_path / f"p{block_size}.bed.gz")
         write_bgzf_tabix(text, gz, block_size=block_size)
-        for threads in (0, 2, 5):
-            dev = pp.DevicePileup(eng, gz, threads=threads)
+        # the blocks inflated ON THE DEVICE (the default), in slabs small enough that lines straddle them, and by the copy threads
+        for threads, env in ((0, {}), (2, {}), (3, {"NM_BED_INFLATE_SLAB": "150000"}), (5, {"NM_BED_INFLATE_SLAB": "70000"}), (0, {"NM_BED_HOST_INFLATE": "1"}),
+                             (5, {"NM_BED_HOST_INFLATE": "1"})):
+            os.environ.update(env)
+            try:
+                dev = pp.DevicePileup(eng, gz, threads=threads)
+            finally:
+                for k in env:
+                    del os.environ[k]
             _assert_same_rows(dev, plain)
             dev.close()
         # the tabix subset: every other contig, in a shuffled order (the index is walked in file order whatever is asked)
         wanted = mg.names[1::2][::-1]
         host = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
-        dev = pp.DevicePileup(eng, gz, contigs=wanted, index_path=gz + ".tbi")
-        assert host.indexed and dev.indexed and dev.bytes_inflated == host.bytes_inflated and dev.bytes_file == host.bytes_file
-        assert set(dev.contig_names) == set(wanted) and 0 < len(dev) < len(plain)
-        _assert_same_rows(dev, host)
-        dev.close()
+        for env in ({}, {"NM_BED_INFLATE_SLAB": "100000"}, {"NM_BED_HOST_INFLATE": "1"}):
+            os.environ.update(env)
+            try:
+                dev = pp.DevicePileup(eng, gz, contigs=wanted, index_path=gz + ".tbi")
+            finally:
+                for k in env:
+                    del os.environ[k]
+            assert host.indexed and dev.indexed and dev.bytes_inflated == host.bytes_inflated and dev.bytes_file == host.bytes_file
+            assert set(dev.contig_names) == set(wanted) and 0 < len(dev) < len(plain)
+            _assert_same_rows(dev, host)
+            dev.close()
         host.close()
         # one contig only, and a contig the index does not know
         dev = pp.DevicePileup(eng, gz, contigs=[mg.names[4], "not_in_the_file"], index_path=gz + ".tbi")

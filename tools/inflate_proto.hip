@@ -34,11 +34,16 @@ struct Bits {
     const unsigned char *p, *end;
     unsigned long long buf;
     int cnt;
-    __device__ __forceinline__ void refill() {
-        while (cnt <= 56 && p < end) { buf |= (unsigned long long)(*p++) << cnt; cnt += 8; }
+    __device__ __forceinline__ void refill() {              // (the input buffer has 8 readable bytes after its end)
+        unsigned long long w;
+        memcpy(&w, p, 8);                                      // one unaligned 8-byte load
+        buf |= w << cnt;
+        const int take = (63 - cnt) >> 3;                      // whole bytes that fit
+        p += take;
+        cnt += take * 8;
     }
     __device__ __forceinline__ unsigned int get(int n) {       // n <= 16
-        if (cnt < n) refill();
+        if (cnt < 32) refill();
         const unsigned int v = (unsigned int)(buf & ((1ull << n) - 1));
         buf >>= n;
         cnt -= n;
@@ -66,14 +71,23 @@ __device__ int construct(unsigned short (*count)[LANES], unsigned short (*symbol
     return left;
 }
 
-__device__ __forceinline__ int decode(Bits &b, unsigned short (*count)[LANES], unsigned short (*symbol)[LANES], int lane) {
-    if (b.cnt < 15) b.refill();
+struct Counts { unsigned int c[16]; };      // per-length code counts in registers (static indices in the unrolled walk)
+__device__ __forceinline__ Counts load_counts(unsigned short (*count)[LANES], int lane) {
+    Counts k;
+#pragma unroll
+    for (int len = 0; len < 16; ++len) k.c[len] = count[len][lane];
+    return k;
+}
+
+__device__ __forceinline__ int decode(Bits &b, const Counts &k, unsigned short (*symbol)[LANES], int lane) {
+    if (b.cnt < 32) b.refill();
     int code = 0, first = 0, index = 0;
-    unsigned long long bits = b.buf;
+    unsigned int bits = (unsigned int)b.buf;
+#pragma unroll
     for (int len = 1; len <= 15; ++len) {
         code |= (int)(bits & 1);
         bits >>= 1;
-        const int c = count[len][lane];
+        const int c = (int)k.c[len];
         if (code - c < first) {
             b.buf >>= len;
             b.cnt -= len;
@@ -134,9 +148,10 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
             for (; idx < ncode; ++idx) lengths[CLORDER[idx]] = (unsigned char)b.get(3);
             for (; idx < 19; ++idx) lengths[CLORDER[idx]] = 0;
             if (construct<MAXL>(T.lcount, T.lsym, lengths, 19, lane) != 0) { err = 5; break; }
+            const Counts kc = load_counts(T.lcount, lane);
             idx = 0;
             while (idx < nlen + ndist) {
-                int sym = decode(b, T.lcount, T.lsym, lane);
+                int sym = decode(b, kc, T.lsym, lane);
                 if (sym < 0) { err = 6; break; }
                 if (sym < 16) lengths[idx++] = (unsigned char)sym;
                 else {
@@ -158,8 +173,9 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
             r = construct<MAXD>(T.dcount, T.dsym, lengths + nlen, ndist, lane);
             if (r < 0 || (r > 0 && ndist - T.dcount[0][lane] != 1)) { err = 11; break; }
         }
+        const Counts kl = load_counts(T.lcount, lane), kd = load_counts(T.dcount, lane);
         for (;;) {                                               // the block's symbols
-            int sym = decode(b, T.lcount, T.lsym, lane);
+            int sym = decode(b, kl, T.lsym, lane);
             if (sym < 0) { err = 12; break; }
             if (sym < 256) {
                 if (o >= pc.out_len) { err = 13; break; }
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
                 sym -= 257;
                 if (sym >= 29) { err = 14; break; }
                 const unsigned int len = LBASE[sym] + b.get(LEXT[sym]);
-                const int ds = decode(b, T.dcount, T.dsym, lane);
+                const int ds = decode(b, kd, T.dsym, lane);
                 if (ds < 0 || ds >= 30) { err = 15; break; }
                 const unsigned int dist = DBASE[ds] + b.get(DEXT[ds]);
                 if (dist > o || o + len > pc.out_len) { err = 16; break; }
