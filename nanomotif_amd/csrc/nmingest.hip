@@ -28,6 +28,9 @@ struct RawRows {
 // three keys for thousands of iterations: the sums stay in a four-entry cache of wave-uniform registers and go to memory
 // when a key is evicted or the wave is done — with one atomic per wave iteration every wave of the device was still
 // hammering the same few addresses (3e7 serialised atomics = most of the 24 ms the classification pass took).
+#ifndef NM_DECIDE_U
+#define NM_DECIDE_U 2      /* same-device A/B at 1e9 rows (tools/gpu_r4e.sh): 4 pieces 8.46 ms (101 VGPRs, 4 waves), 2 pieces 7.52 (78, 6 waves), 1 piece 8.22 */
+#endif
 struct KeyCache {                       // four entries, most recently used first; every member is wave-uniform
     uint32_t k0 = ~0u, k1 = ~0u, k2 = ~0u, k3 = ~0u;
     uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;      // counter [key * stride]
@@ -316,7 +319,7 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
 //    counting pass) a word is COMPLETE once the wave has moved past it, and leaves as a plain store, whole runs of
 //    consecutive words per plane at a time; only the first word a wave touches and what it holds at its end can be shared
 //    with a neighbouring wave and go out as atomicOr.  Unordered input: the window is flushed with atomicOr every iteration.
-template <bool LIST>      // LIST: the candidate rows are ingest_judge_kernel's — skipped here, no queue
+template <bool LIST, int U>      // LIST: the candidate rows are ingest_judge_kernel's — skipped here, no queue; U: 64-row pieces requested together
 __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_cov, const uint8_t *__restrict__ ok,
                                      const uint32_t *__restrict__ contig_chunk, const uint64_t *__restrict__ dense_off,
                                      const unsigned long long *__restrict__ dense_plus,
@@ -407,16 +410,14 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
     // 256 rows per turn: the columns of four consecutive 64-row pieces are requested together (1 KB of consecutive addresses
     // per column and wave — the counting pass reaches the streaming rate of the device this way), then the pieces are
     // worked on one after the other
-    constexpr int U = 4;
     for (uint64_t i00 = row_begin; i00 < row_end; i00 += 64 * U) {
       RowCols cols[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) cols[u] = load_row(r, min(i00 + (uint64_t)u * 64 + lane, row_end - 1));
       // what hangs on the contig / mod code of a row (frequency-filter verdict, dense offset, first chunk) is fetched for
       // all four pieces together: one dependent round trip per 256 rows, not one per 64
-      bool pre[U];
+      bool pre[U], in_part[U];
       uint8_t okv[U];
-      uint64_t doffv[U];
       uint32_t chunkv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         pre[u] = i00 + (uint64_t)u * 64 + lane < row_end && x.c != 0xFFFFFFFFu && x.m >= 0 && x.nv > min_cov && (x.st == '+' || x.st == '-') && !(x.f < 0);
         const uint32_t c = pre[u] ? x.c : 0u;
         okv[u] = ok[(size_t)c * NM_CODE_STRIDE + (pre[u] ? x.m : 0)];
-        doffv[u] = dense_off[c];
+        in_part[u] = dense_off[c] != ~0ull;                         // (~0: the contig is not listed for this part; flagged by the scatter pass)
         chunkv[u] = contig_chunk[c];
       }
 #pragma unroll
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         if (i0 >= row_end) break;                                // wave-uniform
         const uint64_t i = i0 + lane;
         const RowCols x = cols[u];
-        const bool alive = pre[u] && okv[u] && doffv[u] != ~0ull;      // (doff == ~0: flagged by the scatter pass)
+        const bool alive = pre[u] && okv[u] && in_part[u];
         const uint32_t c = alive ? x.c : 0u;
         const bool plus = x.st == '+';
         // candidates for the adjacency test are queued; everybody else survives the filter
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
             qn += (uint32_t)__popcll(cmask);
         }
         if (LIST) {
-            if (pre[u] && okv[u] && doffv[u] == ~0ull && x.f >= meth_thr) atomicOr(err, 8u);     // contig not listed for this part
+            if (pre[u] && okv[u] && !in_part[u] && x.f >= meth_thr) atomicOr(err, 8u);     // contig not listed for this part
             const bool take = cand && x.f >= meth_thr;           // (a NaN fraction is a candidate without an entry: it fails like against the table)
             const unsigned long long tmask = __ballot(take);
             if (take) {
@@ -781,7 +782,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             }
             // one pass over the rows classifies everything below the adjacency threshold and compacts the rest; the list is
             // then packed, indexed per contig and judged
-            hipLaunchKernelGGL(ingest_decide_kernel<true>, walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
+            hipLaunchKernelGGL((ingest_decide_kernel<true, NM_DECIDE_U>), walk, blk, 0, c->stream, r, 5, d_ok, c->d_contig_chunk, d_dense_off, nullptr, nullptr, 8, 0.7, low,
                                high, sl, d_order, d_kept, d_scalars, d_scalars + 1, d_wave_first, lists[0], d_wave_n, c->d_err);
             hipLaunchKernelGGL(ingest_scan_kernel, dim3(1), dim3(1024), 0, c->stream, d_wave_n, n_waves, d_packed_first);
             hipLaunchKernelGGL(ingest_pack_kernel, dim3((n_waves + 3) / 4), blk, 0, c->stream, n_waves, d_wave_first, d_wave_n, d_packed_first, lists[0], lists[1]);
@@ -798,7 +799,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "memset failed: %s", hipGetErrorString(e)); }
             hipLaunchKernelGGL(ingest_scatter_kernel, walk, blk, 0, c->stream, r, 5, d_ok, d_dense_off, d_dense, d_dense + npos, 0.7, c->d_err);
             if (getenv("NM_INGEST_ATOMIC")) (void)hipMemsetAsync(d_order, 0xFF, 4, c->stream);       // A/B switch: never take the store path
-            hipLaunchKernelGGL(ingest_decide_kernel<false>, walk, blk, 0, c->stream, r, 5, d_ok,
+            hipLaunchKernelGGL((ingest_decide_kernel<false, 4>), walk, blk, 0, c->stream, r, 5, d_ok,
                                c->d_contig_chunk, d_dense_off, d_dense, d_dense + npos, 8, 0.7, low, high, sl, d_order, d_kept, d_scalars, d_scalars + 1,
                                nullptr, CandList{}, nullptr, c->d_err);
         }
