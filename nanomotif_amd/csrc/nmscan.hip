@@ -549,7 +549,11 @@ __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, u
     for (int t = 0; t < T_WORDS; ++t) acc[t] = 0xFFFFFFFFu;
     eval_strand<K>((cu32p)(prog + (which >= 2 ? K::PDW : 0)), tile, acc);
 #pragma unroll
-    for (int t = 0; t < T_WORDS; ++t) out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & raw.s[0][which][t];
+    for (int t = 0; t < T_WORDS; ++t) {
+        // (a select chain, not raw.s[0][which][t]: a register array indexed at run time lives in private memory)
+        const uint32_t state = which == 0 ? raw.s[0][0][t] : which == 1 ? raw.s[0][1][t] : which == 2 ? raw.s[0][2][t] : raw.s[0][3][t];
+        out[(size_t)ck * CHUNK_WORDS + lane * T_WORDS + t] = acc[t] & state;
+    }
 }
 
 // nm_hit_positions, device-side compaction of the site masks hits_kernel wrote: only the hit INDICES cross PCIe.

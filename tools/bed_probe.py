@@ -23,5 +23,16 @@ for rep in range(3):
     print("device parse: %d rows, %d contigs in %.3f s (%.1f GB/s); library: total %.3f, copying the file %.3f" %
           (len(d), len(d.contig_names), dt, os.path.getsize(tmp + "/pileup.bed") / 1e9 / dt, d.seconds, d.seconds_reading), flush=True)
     d.close()
+# the same rows as bgzip + tabix (blocks inflated on the device)
+from nanomotif_amd import e2e_synth
+e2e_synth.bgzip_tabix(tmp + "/pileup.bed", tmp + "/pileup.bed.gz")
+print("bgzip %.2f GB" % (os.path.getsize(tmp + "/pileup.bed.gz") / 1e9), flush=True)
+for rep in range(3):
+    t0 = time.perf_counter()
+    d = pp.DevicePileup(eng, tmp + "/pileup.bed.gz")
+    dt = time.perf_counter() - t0
+    print("device parse of the bgzip file: %d rows in %.3f s (%.1f GB/s of text); library: total %.3f, copying the compressed bytes %.3f" %
+          (len(d), dt, os.path.getsize(tmp + "/pileup.bed") / 1e9 / dt, d.seconds, d.seconds_reading), flush=True)
+    d.close()
 eng.close()
 shutil.rmtree(tmp)
