@@ -125,12 +125,12 @@ def motif_zoo():
 # bgzip + tabix of a bedMethyl text (what `bgzip p.bed; tabix -p bed p.bed.gz` produce), written from the format
 # specifications (SAM spec §4.1 BGZF; tabix.pdf) — htslib / pysam are not in the image
 # ---------------------------------------------------------------------------------------------
-def write_bgzf_tabix(bed_text: bytes, gz_path: str, block_size: int = 0xFF00):
+def write_bgzf_tabix(bed_text: bytes, gz_path: str, block_size: int = 0xFF00, level: int = 6, strategy: int = 0):
     import struct
     import zlib
 
     def block(data: bytes) -> bytes:
-        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
         comp = c.compress(data) + c.flush()
         return (struct.pack("<BBBBIBBHBBHH", 31, 139, 8, 4, 0, 0, 255, 6, 66, 67, 2, len(comp) + 25) + comp
                 + struct.pack("<II", zlib.crc32(data), len(data)))

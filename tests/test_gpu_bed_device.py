@@ -148,6 +148,25 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
         dev = pp.DevicePileup(eng, gz, contigs=[mg.names[4], "not_in_the_file"], index_path=gz + ".tbi")
         assert dev.indexed and dev.contig_names == [mg.names[4]] and dev.contigs_not_indexed == 1
         dev.close()
+    # every kind of DEFLATE block through the device decoder: stored (level 0), fixed Huffman codes (Z_FIXED, and what zlib
+    # picks for tiny blocks), dynamic codes at the extremes of the compressor's effort, run-length matches (Z_RLE: distance 1,
+    # overlapping copies), literals only (Z_HUFFMAN_ONLY)
+    import zlib
+    for tag, kw in (("stored", dict(level=0)), ("fixed", dict(level=6, strategy=zlib.Z_FIXED)), ("tiny", dict(level=6, block_size=96)),
+                    ("fast", dict(level=1)), ("best", dict(level=9, block_size=0xFF00)), ("rle", dict(level=6, strategy=zlib.Z_RLE)),
+                    ("huffman", dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY))):
+        gz = str(tmp_path / f"k_{tag}.bed.gz")
+        part, ref = text, plain
+        if tag == "tiny":                                  # 96-byte blocks: a few thousand of them are enough
+            part = text[:text.rfind(b"\n", 0, 400_000) + 1]
+            open(str(tmp_path / "part.bed"), "wb").write(part)
+            ref = pp.NativePileup(str(tmp_path / "part.bed"))
+        write_bgzf_tabix(part, gz, **{"block_size": 20_000, **kw})
+        dev = pp.DevicePileup(eng, gz)
+        _assert_same_rows(dev, ref)
+        dev.close()
+        if ref is not plain:
+            ref.close()
     plain.close()
     # a stale index (written for another file): the regions land off the blocks or on other contigs' rows -> whole file
     other = synth.make_metagenome(synth.SynthSpec(n_contigs=9, total_bp=500_000, n_bins=3, mod_types=("a", "m"), seed=94, min_contig_bp=20_000))
