@@ -109,7 +109,7 @@ __constant__ unsigned char CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 
 
 // status: 0 ok, else the first thing that went wrong
 __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__restrict__ in, const Piece *__restrict__ pieces, unsigned int n_pieces,
-                                                        unsigned char *__restrict__ out, unsigned int *__restrict__ status) {
+                                                        unsigned char *__restrict__ out, unsigned int *__restrict__ status, int mode) {
     __shared__ Tables T;
     const int lane = threadIdx.x;
     const unsigned int i = blockIdx.x * LANES + lane;
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
             if (sym < 0) { err = 12; break; }
             if (sym < 256) {
                 if (o >= pc.out_len) { err = 13; break; }
-                dst[o++] = (unsigned char)sym;
+                if (mode < 2) dst[o] = (unsigned char)sym;
+                o++;
             } else if (sym == 256) break;
             else {
                 sym -= 257;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
                 const unsigned int dist = DBASE[ds] + b.get(DEXT[ds]);
                 if (dist > o || o + len > pc.out_len) { err = 16; break; }
                 unsigned int k = 0;
+                if (mode >= 1) k = len;                           // probe: the match is not copied
                 if (dist >= 8)
                     for (; k + 8 <= len; k += 8) {                // eight bytes at a time (unaligned global accesses are fine)
                         unsigned long long v;
@@ -275,7 +277,8 @@ int main(int argc, char **argv) {
     CHK(hipMemset(d_status, 0, 4));
     CHK(hipMemset(d_out, 0, n));
     const unsigned int np = (unsigned int)pieces.size();
-    auto launch = [&]() { hipLaunchKernelGGL(inflate_kernel, dim3((np + LANES - 1) / LANES), dim3(LANES), 0, 0, d_in, d_pieces, np, d_out, d_status); };
+    int mode = 0;
+    auto launch = [&]() { hipLaunchKernelGGL(inflate_kernel, dim3((np + LANES - 1) / LANES), dim3(LANES), 0, 0, d_in, d_pieces, np, d_out, d_status, mode); };
     launch();
     CHK(hipDeviceSynchronize());
     unsigned int status = 0;
@@ -295,5 +298,15 @@ int main(int argc, char **argv) {
     CHK(hipEventElapsedTime(&ms, e0, e1));
     ms /= 3;
     printf("device inflate: %.2f ms for %.1f MB of text = %.1f GB/s (%zu blocks, one lane each)\n", ms, n / 1e6, n / 1e9 / (ms * 1e-3), pieces.size());
+    for (mode = 1; mode <= 2; ++mode) {                           // probes: where a lane's time goes
+        launch();
+        CHK(hipDeviceSynchronize());
+        CHK(hipEventRecord(e0));
+        for (int it = 0; it < 3; ++it) launch();
+        CHK(hipEventRecord(e1));
+        CHK(hipEventSynchronize(e1));
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  probe %s: %.2f ms\n", mode == 1 ? "matches decoded but not copied" : "nothing written at all", ms / 3);
+    }
     return same && status == 0 ? 0 : 1;
 }
