@@ -287,14 +287,35 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
                 if (ds < 0 || ds >= 30) { err = 15; break; }
                 const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
                 if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                unsigned int k = 0;
-                if (dist >= 8)
-                    for (; k + 8 <= len; k += 8) {                // eight bytes at a time (unaligned global accesses are fine)
-                        unsigned long long v;
-                        memcpy(&v, dst + o + k - dist, 8);
-                        memcpy(dst + o + k, &v, 8);
+                const unsigned char *src = dst + o - dist;
+                unsigned char *d = dst + o;
+                // A match is copied in 8-byte words (unaligned global accesses are fine).  Words may write up to 7 bytes past
+                // the match: those bytes are rewritten by what follows before anything can refer to them (a back-reference
+                // only reaches positions below the current end of the output) — hence the room test.  With a distance of 32
+                // or more, up to four words are LOADED before the first is stored: one round trip through memory instead of
+                // one per word (and one per BYTE in the tail: the byte loop was 56 % of a lane's time, tools/inflate_proto.hip).
+                if (dist >= 32 && o + len + 8 <= pc.out_len) {
+                    for (unsigned int k = 0; k < len; k += 32) {
+                        const unsigned int rem = len - k;
+                        unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
+                        memcpy(&v0, src + k, 8);
+                        if (rem > 8) memcpy(&v1, src + k + 8, 8);
+                        if (rem > 16) memcpy(&v2, src + k + 16, 8);
+                        if (rem > 24) memcpy(&v3, src + k + 24, 8);
+                        memcpy(d + k, &v0, 8);
+                        if (rem > 8) memcpy(d + k + 8, &v1, 8);
+                        if (rem > 16) memcpy(d + k + 16, &v2, 8);
+                        if (rem > 24) memcpy(d + k + 24, &v3, 8);
                     }
-                for (; k < len; ++k) dst[o + k] = dst[o + k - dist];
+                } else if (dist >= 8 && o + len + 8 <= pc.out_len) {
+                    for (unsigned int k = 0; k < len; k += 8) {
+                        unsigned long long v;
+                        memcpy(&v, src + k, 8);
+                        memcpy(d + k, &v, 8);
+                    }
+                } else {
+                    for (unsigned int k = 0; k < len; ++k) d[k] = src[k];
+                }
                 o += len;
             }
         }
@@ -853,13 +874,16 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     };
     // (line starts of a slab: worst case one per two bytes is absurd for a pileup; sized for lines of >= 16 bytes, checked)
     const uint64_t line_cap = std::min<uint64_t>(max_lines, slab_cap / 16 + 1024);
-    HIP_TRY(tmp_alloc((void **)&d_line_start, line_cap * 4));
+    // the two per-line arrays: sized for lines of >= 16 bytes when a slab is 32 MB; a multi-GiB slab of the device-inflate path
+    // gets them once its line count is known (12 bytes per line: a 3 GiB slab of 75-byte lines needs 0.5 GB, not 2.4)
+    uint64_t line_have = dev_inflate ? 0 : line_cap;
+    if (line_have) HIP_TRY(tmp_alloc((void **)&d_line_start, line_have * 4));
     HIP_TRY(tmp_alloc((void **)&d_block_cnt, ((size_t)max_blocks + 1) * 4));
     HIP_TRY(tmp_alloc((void **)&d_block_off, ((size_t)max_blocks + 1) * 4));
     HIP_TRY(tmp_alloc((void **)&d_first_error, 8));
     HIP_TRY(tmp_alloc((void **)&d_counters, 8));
     HIP_TRY(tmp_alloc((void **)&d_patch, (size_t)PATCH_CAP * sizeof(uint4)));
-    HIP_TRY(tmp_alloc((void **)&d_hash, line_cap * 8));
+    if (line_have) HIP_TRY(tmp_alloc((void **)&d_hash, line_have * 8));
     HIP_TRY(tmp_alloc((void **)&d_runs, (size_t)RUN_CAP * sizeof(BedRun)));
     HIP_TRY(tmp_alloc((void **)&d_prev, 16));
     size_t scan_bytes = 0;
@@ -926,6 +950,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipStreamSynchronize(c->stream));
         counted();
         if (n_lines > line_cap) return fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path);
+        if (n_lines > line_have) {                                    // (device-inflate slabs: the arrays follow the line count)
+            line_have = std::min<uint64_t>(line_cap, (uint64_t)((double)n_lines * 1.1) + 1024);
+            HIP_TRY(tmp_alloc((void **)&d_line_start, line_have * 4));            // (the smaller ones stay in dev_tmp until the call ends)
+            HIP_TRY(tmp_alloc((void **)&d_hash, line_have * 8));
+        }
         if (b->n_rows + n_lines >= 0xFFFFFFFFull) return fail(NM_ERANGE, "%s: more than 4G rows in one pileup", path);
         // the columns are sized ONCE, from the line density of the first slab (+ 3 % and one slab's worth of slack): every
         // regrow is a fresh allocation (scrubbed by the driver when the memory was used before) plus a copy
@@ -962,7 +991,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             for (size_t i = sl.first; i < sl.last; ++i) np += src.pieces[i].skip != 0 || src.pieces[i].take != src.pieces[i].out_len;
             max_partial = std::max(max_partial, np);
         }
-        for (int i = 0; i < 2 && (size_t)i < inf_slabs.size(); ++i) HIP_TRY(tmp_alloc((void **)&d_text[i], slab_cap + 128));
+        // ONE text buffer: everything of a slab — inflate, line / field kernels, the copy of its unfinished last line to the front —
+        // is ordered on the ctx stream before the next slab's inflate writes (device memory that other processes used before is
+        // scrubbed by the driver when it is allocated: what this path asks for is what it pays for)
+        HIP_TRY(tmp_alloc((void **)&d_text[0], slab_cap + 128));
+        d_text[1] = d_text[0];
         HIP_TRY(tmp_alloc((void **)&d_comp, inf_comp_cap + 64));
         HIP_TRY(tmp_alloc((void **)&d_scratch, std::max<size_t>(max_partial, 1) << 16));
         HIP_TRY(tmp_alloc((void **)&d_pieces, max_pieces * sizeof(InfPiece)));

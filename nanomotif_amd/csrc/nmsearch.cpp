@@ -726,9 +726,11 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // NM_SEARCH_THREADS: host threads that advance the searches between two batches (default: half the hardware threads, at
-    // most 8; a phase with fewer than NM_SEARCH_MIN_PARALLEL = 8 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
+    // most 12; a phase with fewer than NM_SEARCH_MIN_PARALLEL = 8 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
     // of children_of (164 logarithms per expansion, bit-exact with scipy): 24 ms on one thread, 16-17 on four, 14-15 on eight
-    unsigned n_threads = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    // (round 4, same box: 4 threads 51 ms of native search, 8: 46.5, 12: 42.6, 16: 42.1 — the box shows 256 hardware threads and
+    // grants 16 CPUs; the default went from 8 to 12)
+    unsigned n_threads = std::max(1u, std::min(12u, std::thread::hardware_concurrency() / 2));
     if (const char *e = getenv("NM_SEARCH_THREADS")) n_threads = (unsigned)std::max(1, std::min(64, atoi(e)));
     if (tasks.size() < 8) n_threads = 1;
     Workers workers(n_threads);

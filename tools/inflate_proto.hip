@@ -190,15 +190,36 @@ __global__ __launch_bounds__(LANES) void inflate_kernel(const unsigned char *__r
                 if (ds < 0 || ds >= 30) { err = 15; break; }
                 const unsigned int dist = DBASE[ds] + b.get(DEXT[ds]);
                 if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                unsigned int k = 0;
-                if (mode >= 1) k = len;                           // probe: the match is not copied
-                if (dist >= 8)
-                    for (; k + 8 <= len; k += 8) {                // eight bytes at a time (unaligned global accesses are fine)
-                        unsigned long long v;
-                        memcpy(&v, dst + o + k - dist, 8);
-                        memcpy(dst + o + k, &v, 8);
+                if (mode >= 1) { o += len; continue; }                 // probe: the match is not copied
+                const unsigned char *src = dst + o - dist;
+                unsigned char *d = dst + o;
+                // A match is copied in 8-byte words (unaligned global accesses are fine).  Words may write up to 7 bytes past
+                // the match: those bytes are rewritten by what follows before anything can refer to them (a back-reference
+                // only reaches positions below the current end of the output) — hence the room test.  With a distance of 32
+                // or more, up to four words are LOADED before the first is stored: one round trip through memory instead of
+                // one per word (and one per BYTE in the tail: the byte loop was 56 % of a lane's time, tools/inflate_proto.hip).
+                if (dist >= 32 && o + len + 8 <= pc.out_len) {
+                    for (unsigned int k = 0; k < len; k += 32) {
+                        const unsigned int rem = len - k;
+                        unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
+                        memcpy(&v0, src + k, 8);
+                        if (rem > 8) memcpy(&v1, src + k + 8, 8);
+                        if (rem > 16) memcpy(&v2, src + k + 16, 8);
+                        if (rem > 24) memcpy(&v3, src + k + 24, 8);
+                        memcpy(d + k, &v0, 8);
+                        if (rem > 8) memcpy(d + k + 8, &v1, 8);
+                        if (rem > 16) memcpy(d + k + 16, &v2, 8);
+                        if (rem > 24) memcpy(d + k + 24, &v3, 8);
                     }
-                for (; k < len; ++k) dst[o + k] = dst[o + k - dist];
+                } else if (dist >= 8 && o + len + 8 <= pc.out_len) {
+                    for (unsigned int k = 0; k < len; k += 8) {
+                        unsigned long long v;
+                        memcpy(&v, src + k, 8);
+                        memcpy(d + k, &v, 8);
+                    }
+                } else {
+                    for (unsigned int k = 0; k < len; ++k) d[k] = src[k];
+                }
                 o += len;
             }
         }
