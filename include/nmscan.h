@@ -39,7 +39,7 @@ typedef enum nm_status {
     NM_ERANGE = -5       /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
 } nm_status;
 
-#define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base (nm_hit_positions, nm_contig_methylation: 63) */
+#define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base */
 #define NM_MAX_MOD_SLOTS 8    /* pileup classifications resident at once: the reference's 3 mod types (m, a, 21839 — constants.py:29-33), each possibly under two threshold pairs */
 
 /* motif position sets are 4-bit masks: bit0 = A, bit1 = C, bit2 = G, bit3 = T; 15 = '.'/N (any character,

@@ -391,28 +391,26 @@ int nm_contig_methylation(nm_ctx *c, uint32_t n_motifs, const uint8_t *motif_slo
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t nc = c->n_contigs;
     if (nc == 0) return NM_OK;
-    // programs: every motif on the general path (the modified position's own constraint included); narrow unless one is wide
-    std::vector<uint32_t> full((size_t)n_motifs * PROG_DW);
-    std::vector<uint8_t> is_wide(n_motifs, 0);
+    // programs: every motif on the general path (the modified position's own constraint included); grouped by how far they reach
+    std::vector<uint32_t> full((size_t)n_motifs * PROG6_DW);
+    std::vector<uint8_t> reach(n_motifs, 0);
     for (uint32_t m = 0; m < n_motifs; ++m) {
         if (motif_slot[m] >= NM_MAX_MOD_SLOTS || !c->readstats[motif_slot[m]].present)
             return fail(NM_ESTATE, "motif %u: read-statistics slot %u holds no pileup (nm_readstats_upload)", m, motif_slot[m]);
-        bool wide = false;
-        uint32_t mpm = 0;
-        const int rc = compile_program(motif_masks + motif_mask_offset[m], motif_len[m], motif_modpos[m], full.data() + (size_t)m * PROG_DW, &wide, &mpm);
+        int cls = 0;
+        const int rc = compile_program(motif_masks + motif_mask_offset[m], motif_len[m], motif_modpos[m], full.data() + (size_t)m * PROG6_DW, &cls);
         if (rc) return rc;
-        add_modpos_constraint(full.data() + (size_t)m * PROG_DW, mpm);
-        is_wide[m] = wide;
+        reach[m] = (uint8_t)cls;
     }
-    // batches: motifs of one mod code, at most MB of them, all narrow or (when one is wide) all on the wide kernel
+    // batches: motifs of one mod code, at most MB of them, all of one reach class (32 / 64 / 96 positions either side)
     constexpr uint32_t MB = 32;
     constexpr uint64_t MAX_KEYS = 1ull << 30;                          // 8 GB of keys (+ as much for the sorted copy) per batch
     std::vector<std::vector<uint32_t>> batches;
     for (uint32_t slot = 0; slot < NM_MAX_MOD_SLOTS; ++slot)
-        for (int wide = 0; wide < 2; ++wide) {
+        for (int wide = 0; wide < 3; ++wide) {
             std::vector<uint32_t> cur;
             for (uint32_t m = 0; m < n_motifs; ++m)
-                if (motif_slot[m] == slot && is_wide[m] == wide) {
+                if (motif_slot[m] == slot && reach[m] == wide) {
                     cur.push_back(m);
                     if (cur.size() == MB) { batches.push_back(cur); cur.clear(); }
                 }
@@ -443,7 +441,7 @@ int nm_contig_methylation(nm_ctx *c, uint32_t n_motifs, const uint8_t *motif_slo
     HIP_TRY(alloc((void **)&d_valid, seg_cap * 8));
     HIP_TRY(alloc((void **)&d_mod, seg_cap * 8));
     HIP_TRY(alloc((void **)&d_total, 8));
-    HIP_TRY(alloc((void **)&d_prog, (size_t)MB * PROG_DW * 4));
+    HIP_TRY(alloc((void **)&d_prog, (size_t)MB * PROG6_DW * 4));
     HIP_TRY(alloc((void **)&d_on, seg_cap * 4));
     HIP_TRY(alloc((void **)&d_ocov, seg_cap * 8));
     HIP_TRY(alloc((void **)&d_omed, seg_cap * 8));
@@ -459,16 +457,11 @@ int nm_contig_methylation(nm_ctx *c, uint32_t n_motifs, const uint8_t *motif_slo
     for (size_t bi = 0; bi < batches.size(); ++bi) {
         std::vector<uint32_t> batch = batches[bi];
         const uint32_t nb = (uint32_t)batch.size();
-        const bool wide = is_wide[batch[0]] != 0;
-        const uint32_t pdw = wide ? 32u : 16u;                        // dwords per strand on the 8-plane tile
+        const int G = reach[batch[0]] + 1;                            // word-groups either side of the modified base
+        const uint32_t pdw = 16u * G;                                 // dwords per strand on the 8-plane tile
         const size_t n_seg = (size_t)nb * nc;
         std::vector<uint32_t> prog((size_t)nb * 2 * pdw);
-        for (uint32_t k = 0; k < nb; ++k) {
-            const uint32_t *f = full.data() + (size_t)batch[k] * PROG_DW;
-            uint32_t *p = prog.data() + (size_t)k * 2 * pdw;
-            if (wide) memcpy(p, f, PROG_DW * 4);
-            else { memcpy(p, f + 8, 16 * 4); memcpy(p + 16, f + 32 + 8, 16 * 4); }
-        }
+        for (uint32_t k = 0; k < nb; ++k) slice_program(full.data() + (size_t)batch[k] * PROG6_DW, G, prog.data() + (size_t)k * 2 * pdw);
         const ReadStats &rs = c->readstats[motif_slot[batch[0]]];
         const size_t words = plane_words(c);
         CmArgs a{};
@@ -490,7 +483,8 @@ int nm_contig_methylation(nm_ctx *c, uint32_t n_motifs, const uint8_t *motif_slo
         HIP_TRY(hipMemsetAsync(d_valid, 0, n_seg * 8, c->stream));
         HIP_TRY(hipMemsetAsync(d_mod, 0, n_seg * 8, c->stream));
         // pass 1: sites and coverage sums per (motif, contig)
-        if (wide) launch_scan<Variant<2, 2, false, 1, false, false>>(a, false, c->stream);
+        if (G == 3) launch_scan<Variant<3, 3, false, 1, false, false>>(a, false, c->stream);
+        else if (G == 2) launch_scan<Variant<2, 2, false, 1, false, false>>(a, false, c->stream);
         else launch_scan<Variant<1, 1, false, 1, false, false>>(a, false, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(d_total, 0, 8, c->stream));
@@ -517,7 +511,8 @@ int nm_contig_methylation(nm_ctx *c, uint32_t n_motifs, const uint8_t *motif_slo
             }
             a.keys = d_keys;
             // pass 2: the fractions into their segments
-            if (wide) launch_scan<Variant<2, 2, false, 1, false, false>>(a, true, c->stream);
+            if (G == 3) launch_scan<Variant<3, 3, false, 1, false, false>>(a, true, c->stream);
+            else if (G == 2) launch_scan<Variant<2, 2, false, 1, false, false>>(a, true, c->stream);
             else launch_scan<Variant<1, 1, false, 1, false, false>>(a, true, c->stream);
             HIP_TRY(hipGetLastError());
             size_t need = 0;

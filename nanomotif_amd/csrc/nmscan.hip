@@ -1538,37 +1538,30 @@ int nm_hit_positions(nm_ctx *c, uint32_t contig_id, uint32_t mod_slot, uint8_t l
     if (mod_slot >= NM_MAX_MOD_SLOTS || !c->slots[mod_slot].present) return fail(NM_ESTATE, "mod slot %u has no pileup", mod_slot);
     if (which < 0 || which > 3) return fail(NM_EINVAL, "which must be 0..3");
     HIP_TRY(hipSetDevice(c->device));
-    uint32_t full[PROG_DW], prog[PROG_DW];
-    bool wide = false;
-    uint32_t mpm = 0;
-    int rc = compile_program(masks, len, modpos, full, &wide, &mpm);
+    uint32_t full[PROG6_DW], prog[PROG6_DW];
+    int reach = 0;
+    int rc = compile_program(masks, len, modpos, full, &reach);
     if (rc) return rc;
-    add_modpos_constraint(full, mpm);
-    if (wide) {
-        memcpy(prog, full, sizeof full);
-    } else {
-        memset(prog, 0, sizeof prog);
-        memcpy(prog, full + 8, 16 * 4);
-        memcpy(prog + 16, full + 32 + 8, 16 * 4);
-    }
+    slice_program(full, reach + 1, prog);
     const uint32_t nch = c->contig_nchunks[contig_id];
     const size_t out_words = (size_t)nch * CHUNK_WORDS;
     // scratch: site masks of the contig | set bits per chunk | their exclusive prefix (+ total)
-    const size_t o_cnt = PROG_DW * 4 + out_words * 4, o_off = (o_cnt + (size_t)nch * 4 + 7) & ~(size_t)7;
+    const size_t o_cnt = PROG6_DW * 4 + out_words * 4, o_off = (o_cnt + (size_t)nch * 4 + 7) & ~(size_t)7;
     rc = ensure_stage(c, o_off + ((size_t)nch + 1) * 8);
     if (rc) return rc;
     memcpy(c->h_stage, prog, sizeof prog);
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, sizeof prog, hipMemcpyHostToDevice, c->stream));
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
     uint32_t *d_prog = reinterpret_cast<uint32_t *>(ds);
-    uint32_t *d_masks = d_prog + PROG_DW;
+    uint32_t *d_masks = d_prog + PROG6_DW;
     uint32_t *d_cnt = reinterpret_cast<uint32_t *>(ds + o_cnt);
     unsigned long long *d_off = reinterpret_cast<unsigned long long *>(ds + o_off);
     const ModSlot &ms = c->slots[mod_slot];
     Planes seq{c->dH, c->dL, c->dV, c->d_needs_v};
     StatePlanes st{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
     dim3 grid((nch + 3) / 4);
-    if (wide) hipLaunchKernelGGL((hits_kernel<2, 2>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
+    if (reach == 2) hipLaunchKernelGGL((hits_kernel<3, 3>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
+    else if (reach == 1) hipLaunchKernelGGL((hits_kernel<2, 2>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
     else hipLaunchKernelGGL((hits_kernel<1, 1>), grid, dim3(256), 0, c->stream, seq, st, c->contig_chunk[contig_id], nch, d_prog, which, d_masks);
     HIP_TRY(hipGetLastError());
     // compaction on the device (popcount prefix + scatter): only the hit indices cross PCIe, not the contig's masks

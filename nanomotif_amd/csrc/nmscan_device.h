@@ -141,31 +141,31 @@ __device__ __forceinline__ void eval_strand(cu32p prog, const Tile<K> &tile, uin
 // ---- host: one stripped motif -> per-strand constraint masks ---------------------------------------------------------
 inline uint32_t comp_mask(uint32_t m) { return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3); }
 
-// Compile one stripped motif into the per-strand constraint masks.  Layout: prog[strand*32 + gi*8 + plane],
-// gi = floor(d/32) + 2, bit r = d mod 32.
-inline int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_t *prog, bool *wide,
-                    uint32_t *modpos_mask) {
+// Compile one stripped motif into the per-strand constraint masks of the general path (accumulator starting from all
+// ones: the modified position's own constraint is part of the program).  Layout: prog[strand * 48 + gi * 8 + plane],
+// gi = floor(d / 32) + 3 (six word-groups: offsets in [-96, 95]), bit r = d mod 32.  *reach_class: 0 when every offset lies
+// in [-32, 31], 1 in [-64, 63], 2 beyond (the Variant<G, G, ...> with G = class + 1 reads exactly those groups).
+constexpr int PROG6_DW = 96;
+inline int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, uint32_t *prog, int *reach_class) {
     if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "motif length %u outside 1..%d", len, NM_MAX_MOTIF_LEN);
     if (modpos >= len) return fail(NM_EINVAL, "mod_position %u outside motif of length %u", modpos, len);
-    memset(prog, 0, PROG_DW * sizeof(uint32_t));
+    memset(prog, 0, PROG6_DW * sizeof(uint32_t));
     bool any = false;
-    *wide = false;
+    *reach_class = 0;
     for (uint32_t j = 0; j < len; ++j) {
         const uint32_t m = masks[j] & 15u;
         if (m == 0) return fail(NM_EINVAL, "empty base set at motif position %u", j);
         if (m == 15u) continue;
         any = true;
-        if (j == modpos) continue;      // offset 0: folded into the accumulator init, or added by add_modpos_constraint
         for (int strand = 0; strand < 2; ++strand) {
             const int d = strand == 0 ? (int)j - (int)modpos : (int)modpos - (int)j;
             const uint32_t set = strand == 0 ? m : comp_mask(m);
-            const int gi = (d >> 5) + 2;                            // arithmetic shift = floor
+            const int gi = (d >> 5) + 3;                            // arithmetic shift = floor
             const uint32_t r = (uint32_t)d & 31u;
-            if (gi < 0 || gi > 3) return fail(NM_ERANGE, "offset %d from the modified base is outside [-64, 63]", d);
-            if (gi == 0 || gi == 3) *wide = true;
-            uint32_t *row = prog + strand * 32 + gi * 8;
-            const int nbits = __builtin_popcount(set);
-            if (nbits == 1) {
+            if (gi < 0 || gi > 5) return fail(NM_ERANGE, "offset %d from the modified base is outside [-96, 95]", d);
+            *reach_class = std::max(*reach_class, gi == 0 || gi == 5 ? 2 : gi == 1 || gi == 4 ? 1 : 0);
+            uint32_t *row = prog + strand * 48 + gi * 8;
+            if (__builtin_popcount(set) == 1) {
                 row[__builtin_ctz(set)] |= 1u << r;                 // literal: plane of that base
             } else {
                 uint32_t missing = (~set) & 15u;                    // 3-set: one "valid and not x"; 2-set: two of them
@@ -177,27 +177,13 @@ inline int compile_program(const uint8_t *masks, uint32_t len, uint32_t modpos, 
         }
     }
     if (!any) return fail(NM_EINVAL, "motif has no specified position");
-    *modpos_mask = masks[modpos] & 15u;
     return NM_OK;
 }
 
-// The constraint of the modified position itself (offset 0 -> word-group 2, shift 0), for programs that run on the
-// general path where the accumulator starts from all ones.
-inline void add_modpos_constraint(uint32_t *prog, uint32_t modpos_mask) {
-    if (modpos_mask == 15u) return;
-    for (int strand = 0; strand < 2; ++strand) {
-        const uint32_t set = strand == 0 ? modpos_mask : comp_mask(modpos_mask);
-        uint32_t *row = prog + strand * 32 + 2 * 8;
-        if (__builtin_popcount(set) == 1) {
-            row[__builtin_ctz(set)] |= 1u;
-        } else {
-            uint32_t missing = (~set) & 15u;
-            while (missing) {
-                row[4 + __builtin_ctz(missing)] |= 1u;
-                missing &= missing - 1;
-            }
-        }
-    }
+// The word-groups Variant<G, G, ...> reads (3 - G .. 2 + G) of a six-group program, as [strand][2 G][8 planes].
+inline void slice_program(const uint32_t *full, int G, uint32_t *out) {
+    for (int strand = 0; strand < 2; ++strand)
+        memcpy(out + strand * 2 * G * 8, full + strand * 48 + (3 - G) * 8, (size_t)2 * G * 8 * sizeof(uint32_t));
 }
 
 }  // namespace nmdetail

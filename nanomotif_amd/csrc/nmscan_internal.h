@@ -41,7 +41,6 @@ constexpr int CHUNK_BP = CHUNK_WORDS * 32;              // 8192 positions per wa
 constexpr int GAP_BP = 96;                              // invalid positions guaranteed after every contig (>= the widest offset a motif reaches: no match straddles contigs)
 constexpr int SEG_CHUNKS = 16;                          // chunks per workgroup segment (128 Kbp)
 constexpr int BMAX = 32;                                // candidates per LDS accumulation pass
-constexpr int PROG_DW = 64;                             // host-side program: [strand 2][word-group 4][plane 8]
 // device-side programs are packed to the word-groups the launched kernel variant reads:
 // narrow (offsets in [-32, 31]) = groups 1..2 -> 32 dwords (128 B), wide = all four -> 64 dwords
 constexpr int NM_MAX_MOD_CODES = 8;                     // mod codes that can be given a slot / reported (ABI: slot_of_mod[8])

@@ -335,6 +335,20 @@ def test_extra_wide_motifs_reach_95_positions_from_the_modified_base(engine_cls)
             per = eng.score_per_contig([(Motif(s, p), mt, b) for s, p in motifs])
             assert np.array_equal(np.array([t.sum(axis=0) for _, t in per]), want)
     assert eng.score([(Motif("T" + "." * 70 + "A", 71), "a", "bin_000")]).sum() > 0
+    # nm_hit_positions over the same reach (save_motif_positions=True, find_motifs_bin.py:1322-1329): all three kernel widths
+    from oracle.scan import motif_model_contig
+    from oracle.model import BetaBernoulliModel
+    from oracle.motif import Motif as OracleMotif
+    keys = ("index_meth_fwd", "index_nonmeth_fwd", "index_meth_rev", "index_nonmeth_rev")
+    for mt, motifs in zoo.items():
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        for s, p in motifs[:4] + [("G" + "." * 40 + "A", 41) if mt == "a" else ("C" + "." * 40 + "T", 0)]:
+            for ci in (0, 3):
+                _, want = motif_model_contig(pile[mg.names[ci]], seqs[mg.names[ci]], BetaBernoulliModel(), OracleMotif(s, p), save_motif_positions=True)
+                for which, k in enumerate(keys):
+                    assert eng.hit_positions(mg.names[ci], mt, Motif(s, p), which).tolist() == want[k].tolist(), (s, p, ci, k)
+    with pytest.raises(NmScanError, match="outside \\[-96, 95\\]"):
+        eng.hit_positions(mg.names[0], "a", Motif("A" + "." * 95 + "G", 0), 0)
     with pytest.raises(NmScanError, match="the engine reaches 95"):
         eng.score([(Motif("A" + "." * 95 + "G", 0), "a", "bin_000")])
     eng.close()

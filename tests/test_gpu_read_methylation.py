@@ -10,7 +10,8 @@ from nanomotif_amd.motif import iupac_to_regex
 pytestmark = pytest.mark.gpu
 
 ZOO = ["GATC_a_1", "CCWGG_m_1", "A_a_0", "C_m_0", "GAAGNNNNNTAC_a_2", "GATC_m_3", "AA_a_0", "AA_a_1", "GCGC_m_1", "TTAA_a_2", "RGATCY_a_2",
-       "G" + "N" * 35 + "AT_a_36", "CNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNG_m_0", "ACCCA_a_4", "GGCC_m_3", "VCB_m_1"]
+       "G" + "N" * 35 + "AT_a_36", "CNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNG_m_0", "ACCCA_a_4", "GGCC_m_3", "VCB_m_1",
+       "T" + "N" * 70 + "A_a_71", "C" + "N" * 90 + "G_m_0"]       # more than 63 positions from the modified base: the three-halo-word kernels
 
 
 def _records(mg, rng):
