@@ -79,6 +79,77 @@ def test_two_rank_sharded_search_equals_single_rank():
         assert {r for _, _, r in out[world]} == {out[1][0][2]}     # same number of lock-step rounds
 
 
+def _native_worker(rank, world, port, q):
+    """The NATIVE lock-step machine (nm_search_run_custom + nm_post_run_custom, csrc/nmsearch.cpp / nmpost.cpp) on every rank:
+    the scoring callback counts on the rank's contigs and sums the table over the ranks (what nm_search_run's reduce callback /
+    nm_allreduce_counts does on the GPUs), so every rank's machine takes the same decisions."""
+    import torch
+    import torch.distributed as dist
+    from nanomotif_amd import native_search as ns
+    from nanomotif_amd import postprocess as ppp
+    from nanomotif_amd import search as ps
+    from oracle.scan import score_candidates
+    from test_host_search import windows_for
+    from test_native_search import _backends
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden("g4_search.json")["ecoli_like_a"]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    shard = set(assign_contigs(mg.lengths, world)[rank].tolist())
+    mine = [mg.names[i] for i in sorted(shard)]
+    keys, piles, seqs_by_bin, wins = [], {}, {}, {}
+    store = ps.HostWindowStore()
+    for mt in ("a", "m"):
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        random.seed(1)
+        key = ("bin0", mt)
+        keys.append(key)
+        wins[key] = windows_for(mg, mt, pile)
+        piles[key] = {n: pile[n] for n in mine}
+        seqs_by_bin["bin0"] = {n: seqs[n] for n in mine}
+        store.add_task(key, wins[key][0])
+    local_score, window_fn = _backends(keys, piles, seqs_by_bin, store)
+    calls = [0]
+
+    def score_fn(reqs):
+        calls[0] += 1
+        t = torch.from_numpy(np.ascontiguousarray(local_score(reqs)) if mine else np.zeros((len(reqs), 2), np.int64))
+        if world > 1:
+            dist.all_reduce(t)
+        return t.numpy()
+    res = ns.find_best_candidates_custom([(k, store.totals[k], wins[k][1]) for k in keys], 20, 0.05, 1.5, score_fn, window_fn)
+    post = res.postprocess_custom(score_fn)
+    rows = [r for t in range(len(keys)) for r in (post.final(t) or [])]
+    q.put((rank, ppp.format_bin_motifs(rows), res.rounds, calls[0]))
+    res.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_native_search_and_postprocessing_sharded_over_ranks_equal_single_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2, 4):                  # 3 contigs: with 4 ranks one rank scores nothing and still takes part in every sum
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_native_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=800) for _ in range(world)]
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        out[world] = sorted(got)
+    single = out[1][0][1]
+    assert "GATC" in single and "CCWGG" in single
+    for world in (2, 4):
+        assert all(text == single for _, text, _, _ in out[world])
+        assert {(r, c) for _, _, r, c in out[world]} == {out[1][0][2:]}      # same rounds, same number of collective calls on every rank
+
+
 def test_contig_assignment_is_balanced_and_complete():
     lengths = synth.make_metagenome(synth.SynthSpec(n_contigs=1000, total_bp=100_000_000, n_bins=50, seed=1)).lengths
     for world in (1, 2, 4, 8):
