@@ -28,6 +28,11 @@ struct RawRows {
 // three keys for thousands of iterations: the sums stay in a four-entry cache of wave-uniform registers and go to memory
 // when a key is evicted or the wave is done — with one atomic per wave iteration every wave of the device was still
 // hammering the same few addresses (3e7 serialised atomics = most of the 24 ms the classification pass took).
+#ifndef NM_DECIDE_MEMO
+#define NM_DECIDE_MEMO 1   /* the contig a wave walks through: verdicts / chunk / part membership in wave-uniform registers: 7.45 -> 6.7 ms at 1e9 rows
+                              (tools/gpu_r4m.sh; requesting the next turn's columns ahead as well changed nothing at 1, 2 or 3 pieces: 6.7 / 6.7 / 7.4 ms —
+                              the pass is bound by the instructions it issues per row, not by the loads in flight) */
+#endif
 #ifndef NM_DECIDE_U
 #define NM_DECIDE_U 2      /* same-device A/B at 1e9 rows (tools/gpu_r4e.sh): 4 pieces 8.46 ms (101 VGPRs, 4 waves), 2 pieces 7.52 (78, 6 waves), 1 piece 8.22 */
 #endif
@@ -353,6 +358,9 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
     uint64_t w_base = 0, first_word = ~0ull;              // wave-uniform
     uint32_t cur_contig = 0xFFFFFFFFu;
     bool have = false;
+    uint32_t memo_c = 0xFFFFFFFFu, memo_chunk = 0;        // wave-uniform: what hangs on the contig the wave is walking through
+    unsigned long long memo_ok = 0;
+    bool memo_part = false;
 
     // words [lo, hi) of the window -> memory.  Lanes run along the words of one plane: consecutive stores.
     auto flush_range = [&](uint64_t lo, uint64_t hi, bool all_atomic) {
@@ -423,10 +431,25 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
       for (int u = 0; u < U; ++u) {
         const RowCols &x = cols[u];
         pre[u] = i00 + (uint64_t)u * 64 + lane < row_end && x.c != 0xFFFFFFFFu && x.m >= 0 && x.nv > min_cov && (x.st == '+' || x.st == '-') && !(x.f < 0);
-        const uint32_t c = pre[u] ? x.c : 0u;
-        okv[u] = ok[(size_t)c * NM_CODE_STRIDE + (pre[u] ? x.m : 0)];
-        in_part[u] = dense_off[c] != ~0ull;                         // (~0: the contig is not listed for this part; flagged by the scatter pass)
-        chunkv[u] = contig_chunk[c];
+        // a piece's rows nearly always share ONE contig (a pileup is grouped by contig): its verdicts, chunk and part
+        // membership stay in wave-uniform registers from piece to piece — no second, dependent round trip for the piece
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.c);
+        if (NM_DECIDE_MEMO && c0 != 0xFFFFFFFFu && __ballot(pre[u] && (x.c != c0 || x.m >= 8)) == 0) {
+            if (c0 != memo_c) {
+                memo_c = c0;
+                memo_ok = *reinterpret_cast<const unsigned long long *>(ok + (size_t)c0 * NM_CODE_STRIDE);      // codes 0..7
+                memo_chunk = contig_chunk[c0];
+                memo_part = dense_off[c0] != ~0ull;
+            }
+            okv[u] = (uint8_t)(memo_ok >> (8 * (x.m & 7)));
+            in_part[u] = memo_part;
+            chunkv[u] = memo_chunk;
+        } else {
+            const uint32_t c = pre[u] ? x.c : 0u;
+            okv[u] = ok[(size_t)c * NM_CODE_STRIDE + (pre[u] ? x.m : 0)];
+            in_part[u] = dense_off[c] != ~0ull;                     // (~0: the contig is not listed for this part; flagged by the scatter pass)
+            chunkv[u] = contig_chunk[c];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {

@@ -10,7 +10,7 @@ i=0
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
   rm -rf /tmp/pmc_$f_$i
-  rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc_${f}_$i -- /tmp/lds_proto 122072 10 0 $f 3 > $out/pmc_run_${f}_$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $pass --output-format csv -d /tmp/pmc_${f}_$i -- /tmp/lds_proto 122072 10 0 $f 3 > $out/pmc_run_${f}_$i.log 2>&1
   find /tmp/pmc_${f}_$i -name "*counter_collection.csv" -exec cp {} $out/pmc_${f}_$i.csv \;
 done
 done

@@ -10,9 +10,9 @@ bash profiles/run_profile_e2e.sh r4_e2e > /dev/null 2>&1
 bash tools/gpu_ingest_prof.sh prof_r4_ingest > /dev/null 2>&1
 bash tools/gpu_ingest_pmc.sh prof_r4_ingest_pmc > gpurun_out/prof_r4_ingest_pmc_summary.txt 2>&1
 mkdir -p gpurun_out/prof_r4_meth gpurun_out/prof_r4_bed
-rm -rf /tmp/pm; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -- python3 tools/meth_probe.py > gpurun_out/prof_r4_meth/probe.log 2>&1
+rm -rf /tmp/pm; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pm -- python3 tools/meth_probe.py > gpurun_out/prof_r4_meth/probe.log 2>&1
 find /tmp/pm -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_r4_meth/kernel_stats.csv \;
-rm -rf /tmp/pb; rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/pb -- python3 tools/bed_probe.py 20000000 5 > gpurun_out/prof_r4_bed/probe.log 2>&1
+rm -rf /tmp/pb; timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d /tmp/pb -- python3 tools/bed_probe.py 20000000 5 > gpurun_out/prof_r4_bed/probe.log 2>&1
 find /tmp/pb -name "*kernel_stats.csv" -exec cp {} gpurun_out/prof_r4_bed/kernel_stats.csv \;
 find /tmp/pb -name "*memory_copy_stats.csv" -exec cp {} gpurun_out/prof_r4_bed/memory_copy_stats.csv \;
 grep -h "readstats\|contig methylation" gpurun_out/prof_r4_meth/probe.log

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/trace
 LANES=${LANES:-1}
 SHAPE=${SHAPE:-125000000 1250 63 1260}
 rm -rf /tmp/tr
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 tools/gap_probe.py $SHAPE $LANES > gpurun_out/trace/run_$LANES.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python3 tools/gap_probe.py $SHAPE $LANES > gpurun_out/trace/run_$LANES.log 2>&1
 tail -2 gpurun_out/trace/run_$LANES.log
 f=$(find /tmp/tr -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
