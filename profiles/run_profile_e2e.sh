@@ -6,7 +6,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/trace -- python3 bench.py --workload e2e > $out/bench_under_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/trace -- python3 bench.py --workload e2e > $out/bench_under_trace.log 2>&1
 find /tmp/prof_$tag/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_all.csv \;
 grep -h '"metric"' $out/bench_under_trace.log | tail -1 > $out/bench_under_trace.json
 ls -la $out
