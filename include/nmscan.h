@@ -454,7 +454,7 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
 /*
  * Native modkit bedMethyl reader — replaces polars' scan_csv of the 18-column pileup (dataload.py:15-34, 72-100)
  * and the tabix reader of the bgzip path (dataload.py:102-152).  Accepts plain text, gzip and bgzip (BGZF blocks are
- * inflated in parallel; nm_bed_open reads everything, nm_bed_open_indexed only the contigs asked for).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
+ * inflated in parallel, size and CRC-32 of every member checked; nm_bed_open reads everything, nm_bed_open_indexed only the contigs asked for).  Columns kept, struct-of-arrays, in file order: contig id (first-appearance
  * order, names via nm_bed_contig_name), start (col 2), mod code id (col 4: 0 = m, 1 = a, 2 = 21839, other codes
  * numbered 3, 4, ... in first-appearance order, names via nm_bed_mod_code),
  * strand (col 6), fraction_mod = col 11 / 100 (-1 for the null markers "NA" / "null"), Nvalid_cov (col 10, -1 for
@@ -497,7 +497,10 @@ int nm_bed_close(nm_bed *bed);
  * become ids through a per-row hash and the runs of equal names (first-appearance order, like nm_bed_contig_name).
  * Every row equals nm_bed_open's bit for bit.  The columns stay in device memory in the types nm_ingest_pileup takes with
  * rows_on_device = 1.  A bgzip file (what the reference recommends, docs/source/required_files.md:21) takes the same path:
- * the copy threads inflate its BGZF blocks straight into the pinned slabs.  nm_bed_parse_device_indexed reads only the
+ * only the compressed bytes cross PCIe, its BGZF blocks are inflated ON THE DEVICE (one lane per block; NM_BED_HOST_INFLATE=1:
+ * by the copy threads, into the pinned slabs) and every block's text is checked against the size and the CRC-32 of its gzip
+ * member (NM_EINVAL "corrupt BGZF block ..." — the reference's readers, Python's gzip and htslib, refuse such a file too; so
+ * does nm_bed_open).  nm_bed_parse_device_indexed reads only the
  * blocks a tabix index names for the wanted contigs (dataload.py:102-152, find_motifs_bin.py:192-312: the reference fetches a
  * bin's contigs through the .tbi) — arguments, stats and errors as nm_bed_open_indexed; rows equal to it bit for bit.
  * Any other gzip stream is refused (NM_EINVAL "compressed input ...": use nm_bed_open).

@@ -167,11 +167,11 @@ bool load_gzip(const uint8_t *z, size_t zn, Buffer *b, unsigned threads, std::st
         for (unsigned t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
                 for (size_t i = t; i < blocks.size(); i += threads)
-                    if (!inflate_raw(z + blocks[i].in_off, blocks[i].in_len, b->owned.data() + blocks[i].text_off, blocks[i].out_len)) okv[t] = 0;
+                    if (!inflate_raw(z + blocks[i].in_off, blocks[i].in_len, b->owned.data() + blocks[i].text_off, blocks[i].out_len, blocks[i].crc)) okv[t] = 0;
             });
         for (auto &th : pool) th.join();
         for (int v : okv)
-            if (!v) { *err = "corrupt BGZF block"; return false; }
+            if (!v) { *err = "corrupt BGZF block (deflate stream, size or CRC-32)"; return false; }
         b->data = b->owned.data();
         b->size = b->owned.size();
         return true;
@@ -423,7 +423,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
             });
         for (auto &th : pool) th.join();
         for (int v : okv)
-            if (!v) return nm_set_error(NM_EINVAL, "%s: corrupt BGZF block", path);
+            if (!v) return nm_set_error(NM_EINVAL, "%s: corrupt BGZF block (deflate stream, size or CRC-32)", path);
     }
     text.data = text.owned.data();
     text.size = text.owned.size();

@@ -120,6 +120,7 @@ struct InfPiece {
     unsigned long long dst_off;         // where the WANTED text goes in the slab
     unsigned int skip, take;            // the wanted part of the block's text
     unsigned long long full_off;        // partial blocks (skip / take cut them): the whole text goes to scratch + full_off first
+    unsigned int crc, pad;              // CRC-32 the member's trailer states for the block's whole text
 };
 
 constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
@@ -327,6 +328,101 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
         unsigned char *out = text + pc.dst_off;
         for (unsigned int k = 0; k < pc.take; ++k) out[k] = dst[pc.skip + k];
     }
+}
+
+// CRC-32 of every inflated block against its member's trailer (what Python's gzip and htslib check for the reference): one
+// WAVE per block, the text streamed through in passes of 4 KiB — lane l takes 64 consecutive bytes of a pass, so a wave's loads
+// cover whole cache lines once.  A CRC is linear over GF(2): lane l computes the register of the message with everything but
+// ITS bytes zeroed (between two of its chunks lie 4032 zero bytes: one multiplication by the constant x^(8 * 4032) mod P, eight
+// nibble look-ups), the lanes' registers are carried to the end of the message (x^(8 * 64 * (63 - l)), once per block) and
+// XORed together.  Chunks are aligned to the END of the block, so only the first one can be short; the initial value
+// 0xFFFFFFFF is the same as complementing the first four bytes of the message.
+struct CrcConsts {
+    unsigned int gap;                   // x^(8 * 4032) mod P
+    unsigned int to_end[64];            // x^(8 * 64 * (63 - lane)) mod P
+};
+
+// product of two polynomials modulo the CRC-32 polynomial, bit-reflected (bit 31 = x^0) like the CRC register itself
+__host__ __device__ inline unsigned int crc_mulmod(unsigned int a, unsigned int b) {
+    unsigned int p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;        // b * x
+    }
+    return p;
+}
+
+inline unsigned int crc_xpow8(unsigned int n_bytes) {            // x^(8 n) mod P
+    unsigned int r = 0x80000000u, q = 0x00800000u;              // 1, x^8
+    for (; n_bytes; n_bytes >>= 1) {
+        if (n_bytes & 1u) r = crc_mulmod(r, q);
+        q = crc_mulmod(q, q);
+    }
+    return r;
+}
+
+inline CrcConsts crc_consts() {
+    CrcConsts k;
+    k.gap = crc_xpow8(4032);
+    for (int l = 0; l < 64; ++l) k.to_end[l] = crc_xpow8(64u * (unsigned int)(63 - l));
+    return k;
+}
+
+__global__ __launch_bounds__(256) void bed_crc_kernel(const InfPiece *__restrict__ pieces, unsigned int n_pieces, const unsigned char *__restrict__ text,
+                                                      const unsigned char *__restrict__ scratch, CrcConsts k, unsigned int *__restrict__ status) {
+    __shared__ unsigned int table[256], gap[8][16];
+    {
+        unsigned int c = threadIdx.x;
+        for (int j = 0; j < 8; ++j) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        table[threadIdx.x] = c;
+        if (threadIdx.x < 128) gap[threadIdx.x >> 4][threadIdx.x & 15] = crc_mulmod((threadIdx.x & 15u) << (4 * (threadIdx.x >> 4)), k.gap);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const unsigned int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_pieces) return;                                  // (wave-uniform)
+    const InfPiece pc = pieces[i];
+    const bool partial = pc.skip != 0 || pc.take != pc.out_len;
+    const unsigned char *src = partial ? scratch + pc.full_off : text + pc.dst_off;
+    const long long n = pc.out_len;
+    unsigned int c;
+    if (n <= 64) {                                              // the whole message is lane 63's only chunk: the plain definition
+        c = 0;
+        if (lane == 63) {
+            c = 0xFFFFFFFFu;
+            for (long long at = 0; at < n; ++at) c = table[(c ^ src[at]) & 255u] ^ (c >> 8);
+            c ^= 0xFFFFFFFFu;
+        }
+    } else {
+        c = 0;
+        const int first_pass = 15 - (int)((n - 1) >> 12);
+        for (int pass = first_pass; pass < 16; ++pass) {        // (wave-uniform bounds)
+            // the register moves over the 4032 bytes of the other lanes (zeros to this lane)
+            c = gap[0][c & 15u] ^ gap[1][(c >> 4) & 15u] ^ gap[2][(c >> 8) & 15u] ^ gap[3][(c >> 12) & 15u] ^ gap[4][(c >> 16) & 15u] ^
+                gap[5][(c >> 20) & 15u] ^ gap[6][(c >> 24) & 15u] ^ gap[7][c >> 28];
+            const long long e = n - (long long)(15 - pass) * 4096 - (long long)(63 - lane) * 64, b = e - 64;
+            if (e <= 0) continue;
+            if (b < 4) {                                        // the chunk that holds the beginning of the message: byte by byte
+                for (long long at = b > 0 ? b : 0; at < e; ++at) c = table[(c ^ src[at] ^ (at < 4 ? 255u : 0u)) & 255u] ^ (c >> 8);
+            } else {
+                unsigned long long w[8];
+                memcpy(w, src + b, 64);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        c = table[(c ^ (unsigned int)w[q]) & 255u] ^ (c >> 8);
+                        w[q] >>= 8;
+                    }
+                }
+            }
+        }
+        c = crc_mulmod(c, k.to_end[lane]);
+        for (int d = 32; d; d >>= 1) c ^= (unsigned int)__shfl_xor((int)c, d);
+        c ^= 0xFFFFFFFFu;
+    }
+    if (lane == 63 && c != pc.crc) atomicCAS(status, 0u, 19u | (i << 8));
 }
 
 // the byte after the last '\n' of text[0, n) (0 when there is none in the last `window` bytes): what lies behind it is the
@@ -642,7 +738,7 @@ struct TextSource {
                 if (!nmbgzf::inflate_piece(z, p, reinterpret_cast<char *>(dst + (a - off)), tmp)) return false;
             } else {                              // a piece cut by the range's end: its text through tmp
                 tmp.resize(p.out_len);
-                if (!nmbgzf::inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len)) return false;
+                if (!nmbgzf::inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len, p.crc)) return false;
                 memcpy(dst + (a - off), tmp.data() + p.skip + (a - p.text_off), (size_t)(e - a));
             }
         }
@@ -736,7 +832,7 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
             if (!nmbgzf::whole_file(idx.z, idx.zn, &idx.pieces, &idx.n)) return fail(NM_EINVAL, "%s: not a tabix index", tbi_path);
             idx.bgzf = true;
             index.resize(idx.n);
-            if (idx.n && !idx.read_at(0, index.data(), idx.n)) return fail(NM_EINVAL, "%s: corrupt BGZF block", tbi_path);
+            if (idx.n && !idx.read_at(0, index.data(), idx.n)) return fail(NM_EINVAL, "%s: corrupt BGZF block (deflate stream, size or CRC-32)", tbi_path);
         } else {
             index.assign(reinterpret_cast<const char *>(idx.z), reinterpret_cast<const char *>(idx.z) + idx.zn);
         }
@@ -1017,6 +1113,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
         std::vector<InfPiece> hp;
+        const CrcConsts crc_k = crc_consts();
+        const bool check_crc = getenv("NM_BED_NO_CRC") == nullptr;     // (timing probe only: what the check costs)
         uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
         size_t n_chunk = 0;
         const unsigned nt = std::max(1u, threads - 1);
@@ -1029,7 +1127,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             for (size_t i = sl.first; i < sl.last; ++i) {
                 const nmbgzf::Piece &pp = src.pieces[i];
                 const bool partial = pp.skip != 0 || pp.take != pp.out_len;
-                hp.push_back({coff, (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff});
+                hp.push_back({coff, (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff, pp.crc, 0u});
                 coff += pp.in_len;
                 toff += pp.take;
                 if (partial) poff += 1u << 16;
@@ -1060,6 +1158,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((hp.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, c->stream, d_comp, d_pieces,
                                (unsigned int)hp.size(), text, d_scratch, d_status);
             HIP_TRY(hipGetLastError());
+            if (check_crc) {
+                hipLaunchKernelGGL(bed_crc_kernel, dim3((unsigned)((hp.size() + 3) / 4)), dim3(256), 0, c->stream, d_pieces, (unsigned int)hp.size(), text, d_scratch,
+                                   crc_k, d_status);
+                HIP_TRY(hipGetLastError());
+            }
             // where the last whole line ends; what follows it is carried into the next slab
             const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
             const bool last_slab = si + 1 == inf_slabs.size();
@@ -1073,7 +1176,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const double t_inflated = now();
-            if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, inflate error %u)", path, status >> 8, status & 255u);
+            if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
             if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
                 return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16));
             // the parse kernels want a 16-byte aligned start: the few bytes in front of the carried line become empty lines
@@ -1098,7 +1201,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return filled > k; });
         }
-        if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block" : "cannot read pileup '%s'", path);
+        if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block (deflate stream, size or CRC-32)" : "cannot read pileup '%s'", path);
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(copy_stream, parsed[k % 2], 0));       // the device slab is free again
         HIP_TRY(hipMemcpyAsync(d_slab[k % 2], h_ring[k % RING], len, hipMemcpyHostToDevice, copy_stream));
         HIP_TRY(hipEventRecord(h2d_done[k % RING], copy_stream));
@@ -1111,7 +1214,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         if (rc) return rc;
         HIP_TRY(hipEventRecord(parsed[k % 2], c->stream));
     }
-    if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block" : "cannot read pileup '%s'", path);
+    if (read_failed) return fail(NM_EINVAL, src.bgzf ? "%s: corrupt BGZF block (deflate stream, size or CRC-32)" : "cannot read pileup '%s'", path);
     unsigned long long first_error = ~0ull;
     HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

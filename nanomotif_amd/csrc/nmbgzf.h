@@ -22,9 +22,12 @@ struct Piece {
     size_t out_len;             // text bytes of the whole block
     uint32_t skip, take;        // the wanted part of that text
     uint64_t text_off;          // where the wanted part starts in the concatenated text
+    uint32_t crc;               // CRC-32 of the block's whole text (the member's trailer)
 };
 
-inline bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n) {
+// one block's deflate stream -> dst; the text must have the size AND the CRC-32 the member's trailer states (gzip readers —
+// Python's gzip, htslib — refuse a block whose checksum is off; so does this one)
+inline bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n, uint32_t crc) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -34,11 +37,11 @@ inline bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n) {
     zs.avail_out = (uInt)dst_n;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
-    return rc == Z_STREAM_END && zs.avail_out == 0;
+    return rc == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(dst), (uInt)dst_n) == crc;
 }
 
 // header of the block at `off`: its size in the file, where its deflate stream sits, its text size.  false: not a BGZF block
-inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, size_t *in_off, size_t *in_len, size_t *isize) {
+inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, size_t *in_off, size_t *in_len, size_t *isize, uint32_t *crc) {
     if (off + 18 > zn) return false;
     if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return false;
     const size_t xlen = z[off + 10] | (z[off + 11] << 8);
@@ -54,6 +57,7 @@ inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, siz
     *in_off = off + 12 + xlen;
     *in_len = bs - 12 - xlen - 8;
     *isize = z[off + bs - 4] | (z[off + bs - 3] << 8) | (z[off + bs - 2] << 16) | ((size_t)z[off + bs - 1] << 24);
+    *crc = (uint32_t)z[off + bs - 8] | ((uint32_t)z[off + bs - 7] << 8) | ((uint32_t)z[off + bs - 6] << 16) | ((uint32_t)z[off + bs - 5] << 24);
     return true;
 }
 
@@ -64,8 +68,9 @@ inline bool whole_file(const uint8_t *z, size_t zn, std::vector<Piece> *pieces, 
     uint64_t out = 0;
     while (off < zn) {
         size_t bsize, in_off, in_len, isize;
-        if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize)) return false;
-        if (isize) pieces->push_back({in_off, in_len, isize, 0u, (uint32_t)isize, out});
+        uint32_t crc;
+        if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize, &crc)) return false;
+        if (isize) pieces->push_back({in_off, in_len, isize, 0u, (uint32_t)isize, out, crc});
         out += isize;
         off += bsize;
     }
@@ -152,13 +157,14 @@ inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<
         const uint32_t u_beg = (uint32_t)(g.beg & 0xFFFF), u_end = (uint32_t)(g.end & 0xFFFF);
         while (off <= last && off + 18 <= zn) {
             size_t bsize, in_off, in_len, isize;
+            uint32_t crc;
             if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return "the index points outside a BGZF block";
-            if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize)) return "corrupt BGZF block";
+            if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize, &crc)) return "corrupt BGZF block";
             const uint32_t skip = off == (size_t)(g.beg >> 16) ? u_beg : 0u;
             const uint32_t stop = off == last ? u_end : (uint32_t)isize;
             if (skip > isize || stop > isize) return "the index points beyond a BGZF block";
             if (stop > skip) {
-                pieces->push_back({in_off, in_len, isize, skip, stop - skip, text});
+                pieces->push_back({in_off, in_len, isize, skip, stop - skip, text, crc});
                 text += stop - skip;
                 infl += isize;
             }
@@ -172,9 +178,9 @@ inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<
 
 // the wanted text of one piece -> dst (take bytes); tmp is scratch for pieces that are not taken whole
 inline bool inflate_piece(const uint8_t *z, const Piece &p, char *dst, std::vector<char> &tmp) {
-    if (p.skip == 0 && p.take == p.out_len) return inflate_raw(z + p.in_off, p.in_len, dst, p.out_len);
+    if (p.skip == 0 && p.take == p.out_len) return inflate_raw(z + p.in_off, p.in_len, dst, p.out_len, p.crc);
     tmp.resize(p.out_len);
-    if (!inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len)) return false;
+    if (!inflate_raw(z + p.in_off, p.in_len, tmp.data(), p.out_len, p.crc)) return false;
     memcpy(dst, tmp.data() + p.skip, p.take);
     return true;
 }

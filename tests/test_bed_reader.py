@@ -244,3 +244,34 @@ def test_ingest_columns_may_be_asked_for_twice(tmp_path):
         if k != "contig":
             assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(np.array([2, 0, 1], dtype=np.uint32)[a["contig"]], b["contig"])
+
+
+def test_a_block_whose_text_does_not_match_its_checksum_is_refused(tmp_path):
+    """A flipped byte inside a STORED deflate block leaves a valid stream of the right size: only the member's CRC-32 tells
+    (Python's gzip and htslib, the reference's readers, raise on it) — whole file and tabix subset."""
+    from helpers import write_bgzf_tabix
+    from nanomotif_amd._lib import NmScanError
+    spec = synth.SynthSpec(n_contigs=3, total_bp=60_000, n_bins=1, mod_types=("a",), seed=5, min_contig_bp=10_000)
+    mg = synth.make_metagenome(spec)
+    bed = str(tmp_path / "p.bed")
+    mg.write_bed(bed)
+    text = open(bed, "rb").read()
+    gz = str(tmp_path / "p.bed.gz")
+    write_bgzf_tabix(text, gz, block_size=20_000, level=0)
+    raw = bytearray(open(gz, "rb").read())
+    good = pp.NativePileup(gz)
+    n = len(good)
+    good.close()
+    at = raw.find(b"\t255,0,0\t", len(raw) // 2)              # a digit of the colour column in some block of the second half
+    assert at > 0 and raw[at + 1:at + 2] == b"2"
+    raw[at + 1] = ord("1")
+    bad = str(tmp_path / "bad.bed.gz")
+    open(bad, "wb").write(bytes(raw))
+    import os
+    os.replace(gz + ".tbi", bad + ".tbi")
+    with pytest.raises(NmScanError, match="CRC-32"):
+        pp.NativePileup(bad)
+    with pytest.raises(NmScanError, match="CRC-32"):
+        pp.NativePileup(bad, contigs=list(mg.names), index_path=bad + ".tbi")
+    assert n > 0
+

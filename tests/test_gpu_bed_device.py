@@ -178,6 +178,25 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
     dev = pp.DevicePileup(eng, gz, contigs=mg.names[:3], index_path=gz + ".tbi")
     assert not dev.indexed and dev.index_problem and len(dev) == 700_000
     dev.close()
+    # a flipped byte inside a STORED block: a valid stream of the right size, only the member's CRC-32 tells (bed_crc_kernel;
+    # nmbgzf.h on the copy threads) — Python's gzip and htslib refuse such a file too
+    sgz = str(tmp_path / "k_stored.bed.gz")
+    raw = bytearray(open(sgz, "rb").read())
+    for frac in (0.02, 0.5, 0.97):
+        at = raw.find(b"\t255,0,0\t", int(len(raw) * frac))
+        assert at > 0
+        flipped = bytearray(raw)
+        flipped[at + 1] = ord("1")
+        bad = str(tmp_path / "flip.bed.gz")
+        open(bad, "wb").write(bytes(flipped))
+        for env in ({}, {"NM_BED_INFLATE_SLAB": "100000"}, {"NM_BED_HOST_INFLATE": "1"}):
+            os.environ.update(env)
+            try:
+                with pytest.raises(NmScanError, match="CRC-32"):
+                    pp.DevicePileup(eng, bad)
+            finally:
+                for k in env:
+                    del os.environ[k]
     # a truncated file: the last block is cut in the middle
     bad = str(tmp_path / "cut.bed.gz")
     raw = open(gz, "rb").read()
