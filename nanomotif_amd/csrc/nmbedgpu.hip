@@ -124,6 +124,9 @@ struct InfPiece {
 };
 
 constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
+// A damaged deflate block is noticed at its end at the latest (the text cannot grow beyond the member's size: at most 65 536
+// symbols of at most 48 bits) and at the head of the next one: the bit reader never gets further than this past the stream.
+constexpr size_t INF_OVERRUN = 512u << 10;
 struct InfTables {                      // entry-major: lane l of the wave touches [entry][l]
     unsigned short lcount[16][INF_LANES], lsym[INF_MAXL][INF_LANES], dcount[16][INF_LANES], dsym[INF_MAXD][INF_LANES];
 };
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
     int err = 0, last = 0;
     unsigned char lengths[INF_MAXL + INF_MAXD];
     while (!last && !err) {
+        if ((size_t)(b.p - (in + pc.in_off)) > (size_t)pc.in_len + 8) { err = 18; break; }      // ran past the block's stream
         last = (int)b.get(1);
         const int type = (int)b.get(2);
         if (type == 0) {                                         // stored
@@ -1092,7 +1096,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         // scrubbed by the driver when it is allocated: what this path asks for is what it pays for)
         HIP_TRY(tmp_alloc((void **)&d_text[0], slab_cap + 128));
         d_text[1] = d_text[0];
-        HIP_TRY(tmp_alloc((void **)&d_comp, inf_comp_cap + 64));
+        HIP_TRY(tmp_alloc((void **)&d_comp, inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
         HIP_TRY(tmp_alloc((void **)&d_scratch, std::max<size_t>(max_partial, 1) << 16));
         HIP_TRY(tmp_alloc((void **)&d_pieces, max_pieces * sizeof(InfPiece)));
         HIP_TRY(tmp_alloc((void **)&d_status, 4));

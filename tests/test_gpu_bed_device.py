@@ -197,6 +197,26 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
             finally:
                 for k in env:
                     del os.environ[k]
+    # damaged deflate streams (dynamic codes): a flipped byte anywhere in a block's payload is an inflate error or a CRC-32
+    # mismatch, never a crash, a hang or silently different rows
+    fgz = str(tmp_path / "p65280.bed.gz")
+    raw = bytearray(open(fgz, "rb").read())
+    rng = np.random.default_rng(11)
+    for trial in range(12):
+        flipped = bytearray(raw)
+        at = int(rng.integers(18, len(raw) - 28 - 8))
+        blk = 0
+        while True:                                                     # the block that holds `at`
+            size = int.from_bytes(raw[blk + 16:blk + 18], "little") + 1
+            if at < blk + size:
+                break
+            blk += size
+        at = min(max(at, blk + 18), blk + size - 9)                     # inside the payload (not the header, not the trailer)
+        flipped[at] ^= 1 << int(rng.integers(0, 8))
+        bad = str(tmp_path / "fuzz.bed.gz")
+        open(bad, "wb").write(bytes(flipped))
+        with pytest.raises(NmScanError, match="corrupt BGZF block"):
+            pp.DevicePileup(eng, bad)
     # a truncated file: the last block is cut in the middle
     bad = str(tmp_path / "cut.bed.gz")
     raw = open(gz, "rb").read()
