@@ -9,16 +9,4 @@ for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_
   timeout 600 rocprofv3 --pmc $pass --output-format csv -d /tmp/pp -- python3 tools/ingest_probe.py > gpurun_out/$tag/log_$name.txt 2>&1
   find /tmp/pp -name "*counter_collection.csv" -exec sh -c 'head -1 "$1" > '$out'/dev/null; grep "ingest_" "$1"' _ {} \; > gpurun_out/$tag/pmc_$name.csv
 done
-python3 - <<PY
-import csv, collections, glob
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/$tag/pmc_*.csv"):
-    for row in csv.reader(open(f)):
-        # columns: ...,Kernel_Name,...,Counter_Name,Counter_Value — find by content
-        name = next((x for x in row if "ingest_" in x), None)
-        if not name: continue
-        k = name.split("ingest_")[1].split("(")[0]
-        agg[k][row[-2]].append(float(row[-1]))
-for k, d in agg.items():
-    print(k, {c: round(sum(v)/len(v)/1e6, 2) for c, v in sorted(d.items())})
-PY
+python3 tools/ingest_pmc_summary.py gpurun_out/$tag
