@@ -482,6 +482,7 @@ static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uin
     uint32_t *nb = nullptr;
     HIP_TRY(nmdetail::dev_malloc(&nb, ncap * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));       // window batches in flight (batch_stream)
     if (*buf && used) HIP_TRY(hipMemcpy(nb, *buf, used * 4, hipMemcpyDeviceToDevice));
     if (*buf) (void)nmdetail::dev_free(*buf);
     *buf = nb;
@@ -492,6 +493,7 @@ static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uin
 int nm_win_clear(nm_ctx *c) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
     c->win_tasks.clear();
     c->win_planes_used = c->win_alive_used = 0;
     c->win_tasks_dirty = true;
@@ -530,6 +532,41 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
     return NM_OK;
 }
 
+// The stream window batches run on.  A round of the search enqueues its window batch and its scoring batch back to back and
+// collects the windows first: on ONE stream the scoring chain (copy, compile, clear, kernel, copy back) queued behind the
+// window chain (copy, clear, kernel, copy back) — some ten dependent commands of 5-8 us each per round; the two batches ask
+// about different tasks and touch different memory (the staging pairs are separate, the window planes belong to the window
+// engine), so the window chain goes to the context's second stream and the two overlap.  Window state is only ever changed
+// by these batches (in order, on that stream) and by the set-up calls, which finish on the ctx stream before a batch can
+// start (win_tasks_dirty / nm_plan_windows synchronise) and wait for this stream before they touch the planes.
+// NM_WIN_STREAM=0: everything on the ctx stream (A/B, tools/gpu_r4p.sh).
+static hipStream_t batch_stream(nm_ctx *c) {
+    static const bool second = getenv("NM_WIN_STREAM") == nullptr || atoi(getenv("NM_WIN_STREAM")) != 0;
+    return second && c->copy_stream ? c->copy_stream : c->stream;
+}
+
+// (nmdetail::busy_begin / busy_end bracket work on the ctx stream; the same bookkeeping for a batch on another stream)
+static void busy_begin_on(nm_ctx *c, hipStream_t st) {
+    if (st == c->stream) { nmdetail::busy_begin(c); return; }
+    if (!c->ev_collect_all) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 65536) return;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        c->ev_pool.emplace_back(a, b);
+    }
+    (void)hipEventRecord(c->ev_pool[c->ev_used].first, st);
+    c->busy_open = true;
+}
+
+static void busy_end_on(nm_ctx *c, hipStream_t st) {
+    if (st == c->stream) { nmdetail::busy_end(c); return; }
+    if (!c->ev_collect_all || !c->busy_open) return;
+    (void)hipEventRecord(c->ev_pool[c->ev_used].second, st);
+    c->ev_used += 1;
+    c->busy_open = false;
+}
+
 int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
                          uint32_t ws) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
@@ -550,6 +587,9 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
         if (c->win_tasks[req_task[r]].width > ws) return fail(NM_EINVAL, "request %u: window task of width %u, width stride %u", r, c->win_tasks[req_task[r]].width, ws);
     }
     if (c->win_tasks_dirty) {
+        // the set-up work on the ctx stream is complete, no earlier batch is in flight: then the task table is replaced
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
         if (c->d_win_tasks_cap < c->win_tasks.size()) {
             if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
             c->d_win_tasks = nullptr;
@@ -557,7 +597,6 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
             HIP_TRY(nmdetail::dev_malloc(&c->d_win_tasks, c->win_tasks.size() * 2 * sizeof(WinTask)));
             c->d_win_tasks_cap = c->win_tasks.size() * 2;
         }
-        HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(c->d_win_tasks, c->win_tasks.data(), c->win_tasks.size() * sizeof(WinTask), hipMemcpyHostToDevice));
         c->win_tasks_dirty = false;
     }
@@ -568,11 +607,12 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
     int rc = ensure_stage(c, total, 2);          // its own pair: a scoring batch enqueued behind this one never waits for it on the host
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    const hipStream_t st = batch_stream(c);
     memcpy(hs, req_task, (size_t)n_req * 4);
     memcpy(hs + o_kind, req_kind, n_req);
     memcpy(hs + o_sets, req_sets, (size_t)n_req * ws);
-    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, st));
     // slices of a task's words per request (blockIdx.z): one workgroup per 256 words when the batch is small, fewer and
     // fatter ones when a thousand requests already fill the device several times over (a workgroup's fixed cost — the match
     // mask set-up, the reduction of its 34 counters, its atomics — is most of what it does)
@@ -582,14 +622,14 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
         const uint64_t want = std::max<uint64_t>(1, (uint64_t)c->n_cus * 8 / std::max<uint64_t>(1, (uint64_t)n_req * n_col_groups));
         gz = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gz, want));
     }
-    nmdetail::busy_begin(c);
-    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, n_col_groups, gz), dim3(256), 0, c->stream, c->d_win_tasks, n_req,
+    busy_begin_on(c, st);
+    hipLaunchKernelGGL(win_request_kernel, dim3(n_req, n_col_groups, gz), dim3(256), 0, st, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), ws);
-    nmdetail::busy_end(c);
+    busy_end_on(c, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, c->stream));
-    rc = release_stage(c);
+    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, st));
+    rc = release_stage(c, st);
     if (rc) return rc;
     c->win_wait = nm_ctx::Waiting{hs + o_out, (size_t)n_req * stride * 4, c->cur_stage, true};
     return NM_OK;
@@ -1204,6 +1244,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     c->win_tasks.insert(c->win_tasks.end(), new_tasks.begin(), new_tasks.end());
     c->win_planes_used = planes_used;
     c->win_alive_used = alive_used;
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));           // window batches of an earlier search (batch_stream)
     if (c->d_win_tasks_cap < c->win_tasks.size()) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
