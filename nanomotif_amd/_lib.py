@@ -45,6 +45,15 @@ class NmScanError(RuntimeError):
     pass
 
 
+def text_of(raw: bytes, what: str) -> str:
+    """A name the library read from a file, as text.  polars (the reference's reader, dataload.py:72-100) refuses a file that
+    is not UTF-8; so does this, with the place named."""
+    try:
+        return raw.decode()
+    except UnicodeDecodeError:
+        raise NmScanError(f"{what} is not valid UTF-8: {raw[:60]!r}") from None
+
+
 def _cli_process() -> bool:
     """True when this interpreter was started as ``python -m nanomotif_amd`` (the only torch-free entry point)."""
     import sys

@@ -15,6 +15,11 @@ for _c in "ATGCRYSWKMBDHVN":
     IUPAC[ord(_c)] = True
 
 
+def _lib_text(raw: bytes) -> str:
+    from . import _lib
+    return _lib.text_of(raw, "a record name of the assembly")
+
+
 def _open(path):
     return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path, "r")
 
@@ -53,7 +58,7 @@ def read_fasta_names(path):
     names = []
     for m in re.finditer(rb"^>([^\r\n]*)", data, re.M):
         tok = m.group(1).split()
-        names.append(tok[0].decode() if tok else "")
+        names.append(_lib_text(tok[0]) if tok else "")
     return names
 
 
@@ -80,7 +85,7 @@ def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
         for i in range(n.value):
             name, off, ln = C.c_char_p(), C.c_uint64(0), C.c_uint64(0)
             _lib.check(lib.nm_fasta_record(h, i, C.byref(name), C.byref(off), C.byref(ln)))
-            key = name.value.decode()
+            key = _lib.text_of(name.value, "a record name of the assembly")
             if trim_names:
                 key = key.split(trim_character)[0]
             out[key] = whole[off.value:off.value + ln.value]

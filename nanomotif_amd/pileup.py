@@ -51,7 +51,7 @@ def load_pileup(path: str, threads: int = 0) -> PileupTable:
         for i in range(nc.value):
             s = C.c_char_p()
             _lib.check(lib.nm_bed_contig_name(h, i, C.byref(s)))
-            names.append(s.value.decode())
+            names.append(_lib.text_of(s.value, "a contig name of the pileup"))
         ptr = [C.c_void_p() for _ in range(6)]
         _lib.check(lib.nm_bed_columns(h, *[C.byref(x) for x in ptr]))
         def col(i, ctype, dtype):
@@ -112,7 +112,7 @@ class NativePileup:
         for i in range(nc.value):
             s = C.c_char_p()
             self._check(self._lib.nm_bed_contig_name(self._h, i, C.byref(s)))
-            self.contig_names.append(s.value.decode())
+            self.contig_names.append(_lib.text_of(s.value, "a contig name of the pileup"))
 
     def __len__(self):
         return self.n
@@ -197,7 +197,7 @@ class DevicePileup:
         for i in range(nc.value):
             s = C.c_char_p()
             self._check(self._lib.nm_bedcols_contig_name(self._h, i, C.byref(s)))
-            self.contig_names.append(s.value.decode())
+            self.contig_names.append(_lib.text_of(s.value, "a contig name of the pileup"))
         self.run_row = np.zeros(nr.value + 1, dtype=np.uint64)
         self.run_contig = np.zeros(max(nr.value, 1), dtype=np.uint32)
         self._check(self._lib.nm_bedcols_runs(self._h, self.run_row.ctypes.data_as(C.POINTER(C.c_uint64)),
@@ -211,7 +211,8 @@ class DevicePileup:
         import ctypes as C
         s = C.c_char_p()
         self._check(self._lib.nm_bedcols_mod_code(self._h, int(i), C.byref(s)))
-        return s.value.decode()
+        from . import _lib
+        return _lib.text_of(s.value, "a mod code of the pileup")
 
     def map_contigs(self, lut: np.ndarray):
         import ctypes as C

@@ -275,3 +275,21 @@ def test_a_block_whose_text_does_not_match_its_checksum_is_refused(tmp_path):
         pp.NativePileup(bad, contigs=list(mg.names), index_path=bad + ".tbi")
     assert n > 0
 
+
+def test_names_that_are_not_utf8_are_refused_with_a_message(tmp_path):
+    """polars (dataload.py:72-100) refuses a pileup that is not UTF-8; the native readers hand the bytes through and the
+    Python side names the place instead of dying in a UnicodeDecodeError."""
+    from nanomotif_amd import fasta
+    from nanomotif_amd._lib import NmScanError
+    bed = str(tmp_path / "p.bed")
+    open(bed, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")
+    with pytest.raises(NmScanError, match="contig name of the pileup is not valid UTF-8"):
+        pp.NativePileup(bed)
+    with pytest.raises(NmScanError, match="not valid UTF-8"):
+        pp.load_pileup(bed)
+    fa = str(tmp_path / "a.fasta")
+    open(fa, "wb").write(b">ok\nACGT\n>b\xfe\xff\nACGT\n")
+    for reader in (fasta.load_fasta, fasta.read_fasta_names):
+        with pytest.raises(NmScanError, match="record name of the assembly is not valid UTF-8"):
+            reader(fa)
+

@@ -74,6 +74,38 @@ def test_device_parser_equals_host_parser(tmp_path):
         open(path, "w").write("c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n" * 3 + bad)
         with pytest.raises(NmScanError, match=what):
             pp.DevicePileup(eng, path)
+    # random damage in the text (bytes overwritten, tabs / newlines / NULs / digits dropped in): the device parser and the host
+    # parser either both refuse the file or give the same rows
+    mg.write_bed(path)
+    good = open(path, "rb").read()[:120_000]
+    good = good[:good.rfind(b"\n") + 1]
+    rng = np.random.default_rng(23)
+    outcomes = {"same rows": 0, "both refused": 0}
+    for trial in range(24):
+        d = bytearray(good)
+        for at in rng.integers(0, len(d), int(rng.integers(1, 6))):
+            d[at] = int(rng.choice(np.frombuffer(b"\t\n\r\0 +-.e019NAnul", dtype=np.uint8))) if trial % 2 else int(rng.integers(0, 256))
+        open(path, "wb").write(bytes(d))
+        try:
+            host = pp.NativePileup(path)
+        except (NmScanError, SystemExit):
+            host = None
+        try:
+            dev = pp.DevicePileup(eng, path)
+        except (NmScanError, SystemExit):
+            dev = None
+        assert (host is None) == (dev is None), (trial, host, dev)
+        if host is not None:
+            _assert_same_rows(dev, host)
+            dev.close(); host.close()
+            outcomes["same rows"] += 1
+        else:
+            outcomes["both refused"] += 1
+    assert outcomes["same rows"] >= 3 and outcomes["both refused"] >= 3, outcomes
+    open(path, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")          # polars refuses text that is not UTF-8; so do both readers
+    for reader in (pp.NativePileup, lambda p: pp.DevicePileup(eng, p)):
+        with pytest.raises(NmScanError, match="not valid UTF-8"):
+            reader(path)
     open(path, "w").write("")
     with pytest.raises(SystemExit):
         pp.DevicePileup(eng, path)
