@@ -78,6 +78,26 @@ def test_fuzz_counts_match_oracle(seed):
             contigs = {names[i]: seqs[i].upper() for i in range(len(lens)) if bins[i] == b}
             exp = score_candidates({n: piles[mt][n] for n in contigs}, contigs, [(spec[k][0], spec[k][1]) for k in idx])
             assert np.array_equal(got[idx], exp), (seed, mt, b, [spec[k] for k in idx if got[k].tolist() != exp[idx.index(k)].tolist()][:3])
+    # the hit POSITIONS of some of them on one contig of their bin (nm_hit_positions against motif_model_contig(save_motif_positions=True),
+    # find_motifs_bin.py:1322-1329) and the per-contig counters (one row per contig of the bin) — the same numbers, three ways
+    from oracle.model import BetaBernoulliModel
+    from oracle.motif import Motif as OracleMotif
+    from oracle.scan import motif_model_contig
+    keys = ("index_meth_fwd", "index_nonmeth_fwd", "index_meth_rev", "index_nonmeth_rev")
+    for k in rng.choice(len(spec), size=min(24, len(spec)), replace=False):
+        s, p, mt, b = spec[int(k)]
+        members = [i for i in range(len(lens)) if bins[i] == b]
+        (ids, table), = eng.score_per_contig([cands[int(k)]])
+        assert np.array_equal(table.sum(axis=0), got[int(k)])
+        i = members[int(rng.integers(len(members)))]
+        _, want = motif_model_contig(piles[mt][names[i]], seqs[i].upper(), BetaBernoulliModel(), OracleMotif(s, p), save_motif_positions=True)
+        n_mod = n_non = 0
+        for which, key in enumerate(keys):
+            hits = eng.hit_positions(names[i], mt, Motif(s, p), which)
+            assert hits.tolist() == sorted(want[key].tolist()), (seed, s, p, mt, names[i], key)      # (the oracle keeps the pileup's row order: random here)
+            n_mod, n_non = n_mod + (len(hits) if which % 2 == 0 else 0), n_non + (len(hits) if which % 2 else 0)
+        row = [r for r, c in enumerate(ids) if c == names[i]]
+        assert len(row) == 1 and table[row[0]].tolist() == [n_mod, n_non], (seed, s, p, mt, names[i])
     eng.close()
 
 
