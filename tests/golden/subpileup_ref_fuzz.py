@@ -1,0 +1,100 @@
+"""The whole per-(bin, mod type) chain against the REFERENCE'S OWN process_subpileup (build container only, like gen_golden.py's
+g9): random small bins -> reference: find_best_candidates -> nxgraph_to_dataframe -> remove_noisy_motifs -> merge_motifs_in_df ->
+remove_sub_motifs -> join_motif_complements (its five stage tables recorded, its return value); product: native lock-step
+search + native post-processing (nm_search_run_custom + nm_post_run_custom on the CPU oracle's scan).  All five stage tables
+and the final rows must be equal.   usage: python3 tests/golden/subpileup_ref_fuzz.py [first_seed [n_seeds]]"""
+import os
+import random
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+if os.environ.get("PYTHONHASHSEED") != "0":
+    os.environ["PYTHONHASHSEED"] = "0"
+    os.execv(sys.executable, [sys.executable] + sys.argv)
+import numpy as np
+
+import gen_golden as G
+import refstub
+from helpers import oracle_bin_inputs
+from nanomotif_amd import native_search as ns
+from nanomotif_amd import search as ps
+from nanomotif_amd import synth
+from search_ref_fuzz import POOL
+from test_host_search import windows_for
+from test_native_search import _backends
+from test_oracle_golden import assert_tables_equal
+from test_postprocess_reference_vectors import STAGES, table
+
+
+def one(nm, seed):
+    from nanomotif.seq import DNAsequence
+    fmb = nm.find_motifs_bin
+    rng = np.random.default_rng(50_000 + seed)
+    mt = "a" if rng.random() < 0.55 else "m"
+    fixed = tuple((POOL[mt][k][0], POOL[mt][k][1], mt) for k in rng.choice(len(POOL[mt]), size=int(rng.integers(1, 4)), replace=False))
+    n_contigs, total_bp = int(rng.integers(1, 4)), int(rng.integers(60_000, 300_000))
+    spec = synth.SynthSpec(n_contigs=n_contigs, total_bp=total_bp, n_bins=1, mod_types=(mt,), seed=int(rng.integers(0, 1 << 30)),
+                           min_contig_bp=min(12_000, total_bp // (2 * n_contigs)), fixed_motifs=fixed, methylated_fraction=float(rng.choice([0.97, 0.9])))
+    mg = synth.make_metagenome(spec)
+    cols = G.filtered_bin_pileup(mg, mt)
+    names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+    pile = refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()], cols["fraction_mod"], mod_type=[mt] * len(names))
+    seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+    tmp = tempfile.mkdtemp()
+    rec = []
+    refstub.refframe.DataFrame.recorder = rec
+    random.seed(1)
+    try:
+        res = fmb.process_subpileup({"bin0": list(seqs)}, mt, pile, seqs, 0.05, 20, 0.3, 0.7, 1.5, output_dir=tmp)
+    finally:
+        refstub.refframe.DataFrame.recorder = None
+    ref_stages = {os.path.basename(path)[:-4]: G._table(refstub.refframe.DataFrame({k: [r[k] for r in rows] for k in rows[0]}) if rows else refstub.refframe.DataFrame())
+                  for path, rows in rec}
+    ref_final = [] if res is None else G._table(res)
+    # (a stage that holds one motif twice — two clusters merging into the same motif — keeps both rows in the stand-in because its
+    # unique() compares the Object cells by identity; what real polars does there is not known here: such seeds are not compared,
+    # like the fixtures, which record that no stage did)
+    for stage, rows in ref_stages.items():
+        keys_ = [(r[0], r[2], r[1], r[3]) for r in rows]
+        if len(set(keys_)) != len(keys_):
+            return f"{total_bp} bp {mt} {[f[0] for f in fixed]}: stage {stage} of the reference held one motif twice: skipped"
+    # ---- the product
+    opile, oseqs = oracle_bin_inputs(mg, mt)
+    random.seed(1)
+    windows = windows_for(mg, mt, opile, 0.7, 20)
+    if windows is None or windows[0] is None or len(windows[0]) == 0:
+        assert not ref_final, (seed, "no windows for the product, rows from the reference")
+        return f"{total_bp} bp {mt} {fixed}: no methylated windows"
+    key = ("bin0", mt)
+    store = ps.HostWindowStore()
+    store.add_task(key, windows[0])
+    score_fn, window_fn = _backends([key], {key: opile}, {"bin0": oseqs}, store)
+    found = ns.find_best_candidates_custom([(key, store.totals[key], windows[1])], 20, 0.05, 1.5, score_fn, window_fn)
+    post = found.postprocess_custom(score_fn)
+    for s, stage in enumerate(STAGES):
+        if stage in ref_stages:
+            assert_tables_equal(table(post.rows(0, s)), ref_stages[stage], (seed, fixed, stage))
+        else:
+            assert not post.rows(0, s) or s == 0 or not ref_stages, (seed, stage, "the reference wrote no such table")
+    assert_tables_equal(table(post.final(0) or []), ref_final, (seed, fixed, "final"))
+    found.close()
+    return f"{total_bp} bp {mt} {[f[0] for f in fixed]}: stages " + ", ".join(f"{k} {len(v)}" for k, v in ref_stages.items()) + f"; final {len(ref_final)}"
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    nm = refstub.load_reference()
+    bad = 0
+    for seed in range(first, first + n):
+        t0 = time.time()
+        try:
+            print(f"seed {seed}: {one(nm, seed)} ({time.time() - t0:.1f} s)", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(f"seed {seed}: MISMATCH {str(e)[:2500]}", flush=True)
+    print("process_subpileup fuzz against the reference done, mismatches:", bad)
+    sys.exit(1 if bad else 0)
