@@ -549,6 +549,8 @@ __global__ __launch_bounds__(256) void ingest_decide_kernel(RawRows r, int min_c
         my_kept += __shfl_xor(my_kept, d);
         my_cls += __shfl_xor(my_cls, d);
     }
+    // (per wave, not per workgroup: a barrier here keeps the finished waves of a workgroup resident until its slowest one is
+    // done — measured 6.7 -> 7.45 ms)
     if ((threadIdx.x & 63) == 0) {
         if (my_kept) atomicAdd(n_kept, my_kept);
         if (my_cls) atomicAdd(n_classified, my_cls);
@@ -617,28 +619,57 @@ __global__ __launch_bounds__(256) void ingest_judge_kernel(CandList list, const 
 }
 
 // compact planes of a slot from its general planes: a row counts on the compact path only when the base under it is the
-// one its strand implies ('+' rows on the canonical base, '-' rows on its complement) — word-parallel, no atomics
+// one its strand implies ('+' rows on the canonical base, '-' rows on its complement) — word-parallel, no atomics.  The same pass
+// counts the bits of the four general planes (the confident rows; the duplicate-row check of nm_ingest_pileup: every classified row
+// must have set its own bit) — four separate count launches per slot read the planes once more at 1 TB/s each (1.0 of the 13.7 ms
+// of a 1e9-row ingest).
 __global__ __launch_bounds__(256) void compact_planes_kernel(const uint32_t *__restrict__ H, const uint32_t *__restrict__ L,
                                                              const uint32_t *__restrict__ V, const uint32_t *__restrict__ MP,
                                                              const uint32_t *__restrict__ UP, const uint32_t *__restrict__ MM,
                                                              const uint32_t *__restrict__ UM, uint32_t can_l,
-                                                             uint32_t *__restrict__ M, uint32_t *__restrict__ U, size_t n_words) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t h = H[i], l = L[i], v = V[i];
-        const uint32_t lsel = can_l ? l : ~l;                 // A = 00 / C = 01 on '+', T = 10 / G = 11 on '-'
-        const uint32_t fwd = v & ~h & lsel, rev = v & h & lsel;
-        M[i] = (MP[i] & fwd) | (MM[i] & rev);
-        U[i] = (UP[i] & fwd) | (UM[i] & rev);
+                                                             uint32_t *__restrict__ M, uint32_t *__restrict__ U, size_t n_words,
+                                                             unsigned long long *n_meth_bits, unsigned long long *n_unmeth_bits) {
+    unsigned long long meth = 0, unmeth = 0;
+    // four words per lane and turn (a plane is a whole number of 256-word chunks): 16-byte requests, 32-bit partial counts
+    const size_t n4 = n_words / 4;
+    const uint4 *H4 = reinterpret_cast<const uint4 *>(H), *L4 = reinterpret_cast<const uint4 *>(L), *V4 = reinterpret_cast<const uint4 *>(V);
+    const uint4 *MP4 = reinterpret_cast<const uint4 *>(MP), *UP4 = reinterpret_cast<const uint4 *>(UP), *MM4 = reinterpret_cast<const uint4 *>(MM),
+                *UM4 = reinterpret_cast<const uint4 *>(UM);
+    uint4 *M4 = reinterpret_cast<uint4 *>(M), *U4 = reinterpret_cast<uint4 *>(U);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 h = H4[i], l = L4[i], v = V4[i], mp = MP4[i], up = UP4[i], mm = MM4[i], um = UM4[i];
+        uint4 m, u;
+        uint32_t cm = 0, cu = 0;
+#define NM_COMPACT_WORD(f)                                                                                              \
+        {                                                                                                               \
+            const uint32_t lsel = can_l ? l.f : ~l.f;         /* A = 00 / C = 01 on '+', T = 10 / G = 11 on '-' */       \
+            const uint32_t fwd = v.f & ~h.f & lsel, rev = v.f & h.f & lsel;                                              \
+            m.f = (mp.f & fwd) | (mm.f & rev);                                                                           \
+            u.f = (up.f & fwd) | (um.f & rev);                                                                           \
+            cm += __popc(mp.f) + __popc(mm.f);                                                                           \
+            cu += __popc(up.f) + __popc(um.f);                                                                           \
+        }
+        NM_COMPACT_WORD(x) NM_COMPACT_WORD(y) NM_COMPACT_WORD(z) NM_COMPACT_WORD(w)
+#undef NM_COMPACT_WORD
+        M4[i] = m;
+        U4[i] = u;
+        meth += cm;
+        unmeth += cu;
     }
-}
-
-// population count of a plane (duplicate-row check of nm_ingest_pileup)
-__global__ __launch_bounds__(256) void plane_popcount_kernel(const uint32_t *__restrict__ plane, size_t n_words,
-                                                             unsigned long long *out) {
-    unsigned long long acc = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) acc += __popc(plane[i]);
-    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+    for (int d = 32; d; d >>= 1) {
+        meth += __shfl_xor(meth, d);
+        unmeth += __shfl_xor(unmeth, d);
+    }
+    // one pair of atomics per WORKGROUP: the waves of the whole grid adding to the same two addresses one after the other
+    // was most of this kernel's time (32 768 same-address atomics ~ 0.25 ms)
+    __shared__ unsigned long long part[2][4];
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = meth; part[1][threadIdx.x >> 6] = unmeth; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = part[0][0] + part[0][1] + part[0][2] + part[0][3], b = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (a) atomicAdd(n_meth_bits, a);
+        if (b) atomicAdd(n_unmeth_bits, b);
+    }
 }
 
 }  // namespace
@@ -836,10 +867,9 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
         if (slot < 0 || seen[slot]) continue;
         seen[slot] = true;
         uint32_t *const *pl = c->slots[slot].planes;
-        for (int k = 2; k < 6; ++k)          // MP, MM -> scalar 2 (the confident rows), UP, UM -> scalar 3
-            hipLaunchKernelGGL(plane_popcount_kernel, dim3(2048), blk, 0, c->stream, pl[k], words, d_scalars + (k == 2 || k == 4 ? 2 : 3));
-        hipLaunchKernelGGL(compact_planes_kernel, dim3(4096), blk, 0, c->stream, c->dH, c->dL, c->dV, pl[2], pl[3], pl[4], pl[5],
-                           sl.can_l[slot], pl[0], pl[1], words);
+        // bits of MP, MM -> scalar 2 (the confident rows), of UP, UM -> scalar 3
+        hipLaunchKernelGGL(compact_planes_kernel, dim3(2048), blk, 0, c->stream, c->dH, c->dL, c->dV, pl[2], pl[3], pl[4], pl[5],
+                           sl.can_l[slot], pl[0], pl[1], words, d_scalars + 2, d_scalars + 3);
     }
     e = hipGetLastError();
     nmdetail::busy_end(c);
