@@ -60,6 +60,20 @@ def one(seed):
         env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         if bgzip and rng.random() < 0.3:
             env["NM_BED_INFLATE_SLAB"] = str(int(rng.choice([60_000, 300_000])))
+        # other routes through the same pipeline: the pileup ingested in several parts, the host parser, the Python twins of
+        # the native search / post-processing, windows planned per task
+        extra = []
+        if rng.random() < 0.35:
+            env["NANOMOTIF_INGEST_PART_ROWS"] = str(int(rng.choice([20_000, 100_000, 400_000]))); extra.append("parts " + env["NANOMOTIF_INGEST_PART_ROWS"])
+        if rng.random() < 0.2:
+            env["NANOMOTIF_HOST_PARSER"] = "1"; extra.append("host parser")
+        if rng.random() < 0.15:
+            env["NANOMOTIF_PY_POST"] = "1"; extra.append("python post")
+        if rng.random() < 0.1:
+            env["NANOMOTIF_PY_SEARCH"] = "1"; extra.append("python search")
+        if rng.random() < 0.1:
+            env["NANOMOTIF_PLAN_PER_TASK"] = "1"; extra.append("plan per task")
+        how += "".join(", " + e for e in extra)
         r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", bed, "-c", "contig_bin.tsv", "--out", "out", "-t", str(threads)],
                            cwd=tmp, env=env, capture_output=True, text=True)
         assert r.returncode == 0, (seed, how, r.stdout[-1500:], r.stderr[-1500:])
