@@ -45,6 +45,9 @@ def one(nm, seed):
     n_checked = 0
     for k in range(40):
         s, p = _motif(rng, wide=(k % 5 == 0))
+        if k % 10 == 7:                                              # reaches of 64..95 positions (the engine's widest kernels)
+            gap = int(rng.integers(60, 93))
+            s, p = ("ACGT"[int(rng.integers(4))] + "." * gap + s, p + gap + 1) if rng.random() < 0.5 else (s + "." * gap + "ACGT"[int(rng.integers(4))], p)
         # per contig, with positions
         for i, name in enumerate(names):
             sub = pile.filter(pl.col("contig") == name)
