@@ -538,6 +538,75 @@ def g10(nm):
     dump("g10_frequency_filter.json", out)
 
 
+def g11(nm):
+    """Search traces of RANDOM bins (cases of tests/golden/search_ref_fuzz.py with at most 160 nodes): find_best_candidates of the
+    reference with the case's min_kl / score threshold / random seed — nodes in order, edges, best candidates."""
+    from nanomotif.seq import DNAsequence
+    import search_ref_fuzz as F
+    fmb = nm.find_motifs_bin
+    out = {}
+    seed = 0
+    while len(out) < 24 and seed < 400:
+        kw, mt, min_kl, thr, rseed = F.make_case(seed)
+        seed += 1
+        mg = synth.make_metagenome(synth.SynthSpec(**kw))
+        cols = filtered_bin_pileup(mg, mt)
+        names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+        pile = refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()], cols["fraction_mod"], mod_type=[mt] * len(names))
+        seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+        tmp = tempfile.mkdtemp()
+        random.seed(rseed)
+        res = fmb.find_best_candidates(pile, seqs, mt, "bin0", tmp, low_meth_threshold=0.3, high_meth_threshold=0.7, padding=20, min_kl=min_kl,
+                                       max_dead_ends=25, max_rounds_since_new_best=30, score_threshold=thr)
+        if res is None or not 2 <= res[0].number_of_nodes() <= 160:
+            continue
+        graph, best = res
+        out[f"case_{seed - 1}"] = {
+            "spec": {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v)) for k, v in kw.items()},
+            "mod_type": mt, "params": dict(low=0.3, high=0.7, padding=20, min_kl=min_kl, score_threshold=thr, seed=rseed),
+            "best": [[m.string, int(m.mod_position)] for m in best],
+            "nodes": [{"motif": n.string, "pos": int(n.mod_position), "counts": model_counts(d["model"]), "score": float(d["score"]),
+                       "priority": float(d["priority"]), "depth": int(d["depth"]), "visited": bool(d["visited"])} for n, d in graph.nodes(data=True)],
+            "edges": [[u.string, v.string] for u, v in graph.edges()]}
+        print(f"case_{seed - 1}", mt, "nodes:", graph.number_of_nodes(), "best:", len(best))
+    dump("g11_random_search.json", out)
+
+
+def g12(nm):
+    """process_subpileup on RANDOM bins (cases of tests/golden/subpileup_ref_fuzz.py): the five stage tables and the return value."""
+    from nanomotif.seq import DNAsequence
+    import subpileup_ref_fuzz as F
+    fmb = nm.find_motifs_bin
+    out = {}
+    seed = 0
+    while len(out) < 20 and seed < 400:
+        kw, mt = F.make_case(seed)
+        seed += 1
+        mg = synth.make_metagenome(synth.SynthSpec(**kw))
+        cols = filtered_bin_pileup(mg, mt)
+        names = np.array(mg.names, dtype=object)[cols["contig_id"]]
+        pile = refstub.make_pileup(names, cols["position"], [chr(c) for c in cols["strand"].tolist()], cols["fraction_mod"], mod_type=[mt] * len(names))
+        seqs = {n: DNAsequence(mg.contig_str(i)) for i, n in enumerate(mg.names)}
+        tmp = tempfile.mkdtemp()
+        rec = []
+        refstub.refframe.DataFrame.recorder = rec
+        random.seed(1)
+        try:
+            res = fmb.process_subpileup({"bin0": list(seqs)}, mt, pile, seqs, 0.05, 20, 0.3, 0.7, 1.5, output_dir=tmp)
+        finally:
+            refstub.refframe.DataFrame.recorder = None
+        stages = {os.path.basename(path)[:-4]: _table(refstub.refframe.DataFrame({k: [r[k] for r in rows] for k in rows[0]}) if rows else refstub.refframe.DataFrame())
+                  for path, rows in rec}
+        dup = any(len({(r[0], r[2], r[1], r[3]) for r in rows}) != len(rows) for rows in stages.values())
+        if res is None or dup or len(stages.get("motifs", [])) < 2 or len(stages.get("motifs", [])) > 12:
+            continue
+        out[f"case_{seed - 1}"] = {"spec": {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v)) for k, v in kw.items()},
+                                   "mod_type": mt, "params": dict(low=0.3, high=0.7, padding=20, min_kl=0.05, score_threshold=1.5, seed=1),
+                                   "stages": stages, "final": _table(res), "a_stage_held_one_motif_twice": False}
+        print(f"case_{seed - 1}", mt, {k: len(v) for k, v in stages.items()})
+    dump("g12_random_process_subpileup.json", out)
+
+
 if __name__ == "__main__":
     if os.environ.get("PYTHONHASHSEED") != "0":
         # the reference appends missed candidates in SET order (find_motifs_bin.py:826-833): pin the hash seed so that
@@ -545,6 +614,6 @@ if __name__ == "__main__":
         os.environ["PYTHONHASHSEED"] = "0"
         os.execv(sys.executable, [sys.executable] + sys.argv)
     nm = refstub.load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w](nm)

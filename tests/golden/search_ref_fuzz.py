@@ -31,17 +31,25 @@ POOL = {"a": [("GATC", 1), ("CCAAAT", 4), ("ACCCA", 4), ("GAAGNNNNNNTAC", 2), ("
         "m": [("CCWGG", 1), ("GGCC", 2), ("GCGC", 1), ("CCGG", 0), ("ACGT", 1), ("CCSGG", 1), ("GCNGC", 1), ("TCGA", 1), ("RCCGGY", 2), ("CTAG", 0)]}
 
 
-def one(nm, seed):
-    from nanomotif.seq import DNAsequence
-    fmb = nm.find_motifs_bin
+def make_case(seed):
+    """(SynthSpec kwargs, mod type, min_kl, score threshold, random seed) of fuzz case ``seed`` — also what gen_golden.py's g11 records."""
     rng = np.random.default_rng(seed)
     mt = "a" if rng.random() < 0.55 else "m"
     fixed = tuple((POOL[mt][k][0], POOL[mt][k][1], mt) for k in rng.choice(len(POOL[mt]), size=int(rng.integers(0, 4)), replace=False))
     n_contigs, total_bp = int(rng.integers(1, 4)), int(rng.integers(50_000, 260_000))
-    spec = synth.SynthSpec(n_contigs=n_contigs, total_bp=total_bp, n_bins=1, mod_types=(mt,), seed=int(rng.integers(0, 1 << 30)),
-                           min_contig_bp=min(12_000, total_bp // (2 * n_contigs)), fixed_motifs=fixed, methylated_fraction=float(rng.choice([0.97, 0.9, 0.8])))
-    mg = synth.make_metagenome(spec)
+    kw = dict(n_contigs=n_contigs, total_bp=total_bp, n_bins=1, mod_types=(mt,), seed=int(rng.integers(0, 1 << 30)),
+              min_contig_bp=min(12_000, total_bp // (2 * n_contigs)), fixed_motifs=fixed, methylated_fraction=float(rng.choice([0.97, 0.9, 0.8])))
     min_kl, thr, rseed = float(rng.choice([0.05, 0.05, 0.02, 0.1])), float(rng.choice([1.5, 1.5, 1.0, 2.0])), int(rng.choice([1, 1, 7, 123]))
+    return kw, mt, min_kl, thr, rseed
+
+
+def one(nm, seed):
+    from nanomotif.seq import DNAsequence
+    fmb = nm.find_motifs_bin
+    kw, mt, min_kl, thr, rseed = make_case(seed)
+    fixed = kw["fixed_motifs"]
+    spec = synth.SynthSpec(**kw)
+    mg = synth.make_metagenome(spec)
     # ---- the reference
     cols = G.filtered_bin_pileup(mg, mt)
     names = np.array(mg.names, dtype=object)[cols["contig_id"]]

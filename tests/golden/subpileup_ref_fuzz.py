@@ -29,15 +29,22 @@ from test_oracle_golden import assert_tables_equal
 from test_postprocess_reference_vectors import STAGES, table
 
 
-def one(nm, seed):
-    from nanomotif.seq import DNAsequence
-    fmb = nm.find_motifs_bin
+def make_case(seed):
+    """(SynthSpec kwargs, mod type) of fuzz case ``seed`` — also what gen_golden.py's g12 records."""
     rng = np.random.default_rng(50_000 + seed)
     mt = "a" if rng.random() < 0.55 else "m"
     fixed = tuple((POOL[mt][k][0], POOL[mt][k][1], mt) for k in rng.choice(len(POOL[mt]), size=int(rng.integers(1, 4)), replace=False))
     n_contigs, total_bp = int(rng.integers(1, 4)), int(rng.integers(60_000, 300_000))
-    spec = synth.SynthSpec(n_contigs=n_contigs, total_bp=total_bp, n_bins=1, mod_types=(mt,), seed=int(rng.integers(0, 1 << 30)),
-                           min_contig_bp=min(12_000, total_bp // (2 * n_contigs)), fixed_motifs=fixed, methylated_fraction=float(rng.choice([0.97, 0.9])))
+    return dict(n_contigs=n_contigs, total_bp=total_bp, n_bins=1, mod_types=(mt,), seed=int(rng.integers(0, 1 << 30)),
+                min_contig_bp=min(12_000, total_bp // (2 * n_contigs)), fixed_motifs=fixed, methylated_fraction=float(rng.choice([0.97, 0.9]))), mt
+
+
+def one(nm, seed):
+    from nanomotif.seq import DNAsequence
+    fmb = nm.find_motifs_bin
+    kw, mt = make_case(seed)
+    fixed, total_bp = kw["fixed_motifs"], kw["total_bp"]
+    spec = synth.SynthSpec(**kw)
     mg = synth.make_metagenome(spec)
     cols = G.filtered_bin_pileup(mg, mt)
     names = np.array(mg.names, dtype=object)[cols["contig_id"]]

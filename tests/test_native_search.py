@@ -303,3 +303,34 @@ def test_random_bins_native_search_and_postprocessing_equal_the_coroutines(seed)
     import search_fuzz
     assert "tasks" in search_fuzz.one(seed)
 
+
+def _g11_cases():
+    return sorted(load_golden("g11_random_search.json"), key=lambda k: int(k.split("_")[1]))
+
+
+@pytest.mark.parametrize("name", _g11_cases())
+def test_native_search_reproduces_random_reference_traces(name):
+    """g11: find_best_candidates of the reference on random bins (random planted motifs, rates, min_kl, score threshold, seed);
+    the native lock-step machine must produce every node in order, the edges and the best candidates."""
+    g = load_golden("g11_random_search.json")[name]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    mt = g["mod_type"]
+    pile, seqs = oracle_bin_inputs(mg, mt)
+    P = g["params"]
+    random.seed(P["seed"])
+    windows = windows_for(mg, mt, pile, P["high"], P["padding"])
+    key = ("bin0", mt)
+    store = ps.HostWindowStore()
+    store.add_task(key, windows[0])
+    score_fn, window_fn = _backends([key], {key: pile}, {"bin0": seqs}, store)
+    res = ns.find_best_candidates_custom([(key, store.totals[key], windows[1])], P["padding"], P["min_kl"], P["score_threshold"], score_fn, window_fn)
+    graph, best, _ = res.result(0, full_graph=True)
+    assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
+    for (n, d), r in zip(graph.nodes.items(), g["nodes"]):
+        assert list(d["model"].get_raw_counts()) == r["counts"]
+        assert d["score"] == pytest.approx(r["score"], abs=1e-9, rel=1e-9)
+        assert d["priority"] == pytest.approx(r["priority"], abs=1e-12, rel=1e-12)
+        assert d["depth"] == r["depth"] and d["visited"] == r["visited"]
+    assert sorted((u.string, v.string) for u, v in graph.edges()) == sorted(map(tuple, g["edges"]))
+    assert sorted((m.string, m.mod_position) for m in best) == sorted(map(tuple, g["best"]))
+

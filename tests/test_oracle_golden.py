@@ -445,6 +445,55 @@ def test_g8_postprocess_glue_equals_the_reference_functions():
     assert fired == {"noise", "degenerate merge", "rejected merge", "sub-motif", "complement join changes the row count"}
 
 
+def _g11_cases():
+    return sorted(load_golden("g11_random_search.json"), key=lambda k: int(k.split("_")[1]))
+
+
+@pytest.mark.parametrize("name", _g11_cases())
+def test_g11_random_search_traces(name):
+    """find_best_candidates of the reference on RANDOM bins (tests/golden/search_ref_fuzz.py cases: random planted motifs,
+    methylation rates, min_kl, score threshold, random seed) against the oracle's search: nodes in order, edges, best."""
+    g = load_golden("g11_random_search.json")[name]
+    mg = synth.make_metagenome(spec_from_json(g["spec"]))
+    pile, seqs = oracle_bin_inputs(mg, g["mod_type"])
+    P = g["params"]
+    random.seed(P["seed"])
+    res = ose.find_best_candidates(pile, seqs, g["mod_type"], P["low"], P["high"], P["padding"], min_kl=P["min_kl"],
+                                   max_dead_ends=25, max_rounds_since_new_best=30, score_threshold=P["score_threshold"])
+    assert res is not None
+    graph, best, _ = res
+    assert [(n.string, n.mod_position) for n in graph.nodes] == [(r["motif"], r["pos"]) for r in g["nodes"]]
+    for (n, d), r in zip(graph.nodes.items(), g["nodes"]):
+        assert list(d["model"].get_raw_counts()) == r["counts"], r["motif"]
+        assert d["score"] == pytest.approx(r["score"], abs=1e-9, rel=1e-9), r["motif"]
+        assert d["priority"] == pytest.approx(r["priority"], abs=1e-12, rel=1e-12)
+        assert d["depth"] == r["depth"] and d["visited"] == r["visited"]
+    assert sorted((u.string, v.string) for u, v in graph.edges()) == sorted(map(tuple, g["edges"]))
+    assert sorted((m.string, m.mod_position) for m in best) == sorted(map(tuple, g["best"]))
+
+
+def test_g12_random_process_subpileup_stage_tables():
+    """process_subpileup of the reference on 20 RANDOM bins (tests/golden/subpileup_ref_fuzz.py cases) against the oracle's
+    search + post-processing chain: all five stage tables and the return value."""
+    g = load_golden("g12_random_process_subpileup.json")
+    assert len(g) >= 20
+    for name, rec in g.items():
+        mg = synth.make_metagenome(spec_from_json(rec["spec"]))
+        pile, seqs = oracle_bin_inputs(mg, rec["mod_type"])
+        p = rec["params"]
+        random.seed(p["seed"])
+        res = ose.find_best_candidates(pile, seqs, rec["mod_type"], p["low"], p["high"], p["padding"], min_kl=p["min_kl"],
+                                       score_threshold=p["score_threshold"])
+        rows = opp.graph_to_rows(res[0], res[1], "bin0", rec["mod_type"], p["padding"])
+        assert_tables_equal(post_table(rows), rec["stages"]["motifs"], (name, "motifs"))
+        stages = oracle_post_stages(rows, {rec["mod_type"]: pile}, seqs)
+        for ours, theirs in (("noise", "motifs-noise"), ("merge", "motifs-noise-merge"), ("sub", "motifs-noise-merge-sub"),
+                             ("complement", "motifs-noise-merge-sub-complement")):
+            assert_tables_equal(post_table(stages[ours]), rec["stages"][theirs], (name, theirs))
+        final = opp.process_bin(pile, seqs, "bin0", rec["mod_type"], res[0], res[1], p["padding"])
+        assert_tables_equal(post_table(final or []), rec["final"] or [], (name, "final"))
+
+
 def test_g9_process_subpileup_stage_tables():
     """process_subpileup itself (find_motifs_bin.py:468-596) run from the reference on six bins: every stage table it writes
     and its return value against the oracle's search + post-processing chain."""

@@ -106,3 +106,23 @@ def test_g9_both_implementations_equal_process_subpileup():
         assert_tables_equal(table(native_final), rec["final"] or [], (name, "final", "nm_post_run"))
         seen += 1
     assert seen >= 5
+
+
+def test_g12_both_implementations_equal_process_subpileup_on_random_bins():
+    """g12: process_subpileup of the reference on 20 random bins; from its first stage table (the graph rows, score-descending)
+    every later table and the return value must come out of the Python twin and of nm_post_run."""
+    g = load_golden("g12_random_process_subpileup.json")
+    for name, rec in g.items():
+        mg = synth.make_metagenome(spec_from_json(rec["spec"]))
+        mt = rec["mod_type"]
+        pile, seqs = oracle_bin_inputs(mg, mt)
+        keys = [("bin0", mt)]
+        first = sorted(rec["stages"]["motifs"], key=lambda r: -r[6])
+        rows = [[(r[1], r[4], r[5], r[6]) for r in first]]
+        py, native, py_final, native_final = both_implementations(keys, rows, oracle_scorer(keys, {mt: pile}, seqs))
+        for stage in STAGES:
+            assert_tables_equal(table(py[stage]), rec["stages"][stage], (name, stage, "python twin"))
+            assert_tables_equal(table(native[stage]), rec["stages"][stage], (name, stage, "nm_post_run"))
+        assert_tables_equal(table(py_final), rec["final"] or [], (name, "final", "python twin"))
+        assert_tables_equal(table(native_final), rec["final"] or [], (name, "final", "nm_post_run"))
+
