@@ -36,7 +36,9 @@ typedef enum nm_status {
     NM_EHIP = -2,        /* HIP runtime error */
     NM_ESTATE = -3,      /* call order (e.g. scoring before contigs / pileup were uploaded) */
     NM_ENOMEM = -4,
-    NM_ERANGE = -5       /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
+    NM_ERANGE = -5,      /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
+    NM_EINDEX = -6       /* nm_bed_*_indexed: the tabix index cannot be used with this pileup (not an index, stale):
+                            the caller reads the whole file instead; every other failure is final */
 } nm_status;
 
 #define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base */
@@ -469,10 +471,11 @@ int nm_bed_count_columns(nm_bed *bed, const int32_t **n_modified, const int32_t 
 /* The tabix path of the reference (dataload.py:102-152, find_motifs_bin.py:233-246: the records of a bin's contigs are
  * fetched through the .tbi index): only the BGZF blocks holding the n_contigs wanted contigs (names back to back,
  * name_offset[n_contigs + 1]) are inflated and parsed; contigs absent from the index are skipped and counted.  stats
- * (may be NULL): {bytes inflated, bytes of the compressed file, wanted contigs without an index entry, 0}.  NM_EINVAL
- * "not a tabix index" when tbi_path is not one; NM_EINVAL "does not match the pileup" / "index points ..." when the
- * regions the index names hold rows of other contigs or do not start at BGZF blocks (a stale index): the caller should
- * then read the whole file (nm_bed_open). */
+ * (may be NULL): {bytes inflated, bytes of the compressed file, wanted contigs without an index entry, 0}.  NM_EINDEX
+ * "not a tabix index" when tbi_path is not one; NM_EINDEX "does not match the pileup" / "index points ..." / "does not
+ * parse" when the regions the index names hold rows of other contigs, do not start at BGZF blocks or start inside a
+ * line (a stale index): the caller should then read the whole file (nm_bed_open).  A damaged pileup (NM_EINVAL "corrupt
+ * BGZF block", a CRC-32 that is off), NM_EHIP and NM_ENOMEM are NOT index problems and come back as themselves. */
 int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
                         uint32_t threads, nm_bed **out, uint64_t stats[4]);
 int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);

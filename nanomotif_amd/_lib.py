@@ -237,6 +237,9 @@ def use_torch_allocator(enable: bool = True):
     check(lib.nm_set_device_allocator(_torch_pool[0], _torch_pool[1], None))
 
 
+NM_EINDEX = -6          # include/nmscan.h: the tabix index cannot be used with this pileup (read the whole file)
+
+
 def check(rc: int):
     if rc != 0:
         raise NmScanError(f"libnmscan error {rc}: {load().nm_last_error().decode()}")

@@ -376,7 +376,7 @@ int nm_bed_count_columns(nm_bed *b, const int32_t **n_modified, const int32_t **
 // contigs through the .tbi index instead of reading the file): only the BGZF blocks that hold the wanted contigs are
 // inflated and parsed.  The index (tabix format: magic TBI\1, per reference the bins with their chunks of virtual
 // offsets) gives every contig its [begin, end) virtual offsets — from the pseudo-bin 37450 when present, else the
-// hull of its chunks.  NM_EINVAL with "not a tabix index" when the .tbi is not one (the caller may read the whole file).
+// hull of its chunks.  NM_EINDEX when the .tbi is not one or does not fit the file (the caller may read the whole file).
 int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
                         uint32_t threads, nm_bed **out, uint64_t stats[4]) {
     if (!path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return nm_set_error(NM_EINVAL, "NULL argument");
@@ -384,7 +384,10 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     if (threads == 0) threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     Buffer idx;
     int rc = load_file(tbi_path, threads, &idx, "tabix index");
-    if (rc) return rc;
+    if (rc) {                       // an index that cannot be read or inflated is an index problem, not a pileup problem
+        const std::string why = nm_last_error();
+        return nm_set_error(NM_EINDEX, "%s", why.c_str());
+    }
     struct Unmap {
         Buffer &b;
         ~Unmap() { if (b.map) munmap(b.map, b.map_size); b.map = nullptr; }
@@ -395,7 +398,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     uint64_t found_in_index = 0;
     {
         const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(idx.data), idx.size, want, &merged, &found_in_index);
-        if (!what.empty()) return nm_set_error(NM_EINVAL, "%s: %s", tbi_path, what.c_str());
+        if (!what.empty()) return nm_set_error(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
     }
     Buffer file;
     rc = load_file_raw(path, &file);
@@ -408,7 +411,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     uint64_t text_size = 0, inflated = 0;
     {
         const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated);
-        if (!what.empty()) return nm_set_error(NM_EINVAL, "%s: %s", path, what.c_str());
+        if (!what.empty()) return nm_set_error(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     Buffer text;
     text.owned.resize(text_size);
@@ -429,6 +432,10 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     text.size = text.owned.size();
     if (stats) { stats[0] = inflated; stats[1] = zn; stats[2] = n_contigs - std::min<uint64_t>(found_in_index, n_contigs); stats[3] = 0; }
     rc = parse_text(path, text, threads, out);
+    if (rc == NM_EINVAL) {          // blocks intact, lines that do not parse: a region that starts inside a line — the index is stale
+        const std::string why = nm_last_error();
+        return nm_set_error(NM_EINDEX, "%s: the text the tabix index names does not parse (%s): stale .tbi?", path, why.c_str());
+    }
     if (rc) return rc;
     // the text the index pointed at must belong to the contigs that were asked for: a stale or foreign .tbi otherwise
     // yields a silently wrong subset of rows
@@ -437,7 +444,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
             const std::string culprit = nm;
             delete *out;
             *out = nullptr;
-            return nm_set_error(NM_EINVAL, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
+            return nm_set_error(NM_EINDEX, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
                                 path, culprit.c_str());
         }
     return NM_OK;

@@ -831,12 +831,12 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
     {
         TextSource idx;
         int rc = map_file(tbi_path, &idx);
-        if (rc) return fail(NM_EINVAL, "cannot open tabix index '%s'", tbi_path);
+        if (rc) return fail(NM_EINDEX, "cannot open tabix index '%s'", tbi_path);
         if (idx.zn >= 2 && idx.z[0] == 31 && idx.z[1] == 139) {
-            if (!nmbgzf::whole_file(idx.z, idx.zn, &idx.pieces, &idx.n)) return fail(NM_EINVAL, "%s: not a tabix index", tbi_path);
+            if (!nmbgzf::whole_file(idx.z, idx.zn, &idx.pieces, &idx.n)) return fail(NM_EINDEX, "%s: not a tabix index", tbi_path);
             idx.bgzf = true;
             index.resize(idx.n);
-            if (idx.n && !idx.read_at(0, index.data(), idx.n)) return fail(NM_EINVAL, "%s: corrupt BGZF block (deflate stream, size or CRC-32)", tbi_path);
+            if (idx.n && !idx.read_at(0, index.data(), idx.n)) return fail(NM_EINDEX, "%s: not a tabix index (corrupt BGZF block: deflate stream, size or CRC-32)", tbi_path);
         } else {
             index.assign(reinterpret_cast<const char *>(idx.z), reinterpret_cast<const char *>(idx.z) + idx.zn);
         }
@@ -847,18 +847,23 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
     uint64_t found = 0, inflated = 0;
     {
         const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), want, &merged, &found);
-        if (!what.empty()) return fail(NM_EINVAL, "%s: %s", tbi_path, what.c_str());
+        if (!what.empty()) return fail(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
     }
     TextSource src;
     int rc = map_file(path, &src);
     if (rc) return rc;
     {
         const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated);
-        if (!what.empty()) return fail(NM_EINVAL, "%s: %s", path, what.c_str());
+        if (!what.empty()) return fail(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     src.bgzf = true;
     if (stats) { stats[0] = inflated; stats[1] = src.zn; stats[2] = n_contigs - std::min<uint64_t>(found, n_contigs); stats[3] = 0; }
     rc = parse_device_impl(c, path, src, threads, out);
+    if (rc == NM_EINVAL && strstr(nm_last_error(), "corrupt BGZF block") == nullptr) {
+        // blocks intact, lines that do not parse: a region that starts inside a line — the index is stale
+        const std::string why = nm_last_error();
+        return fail(NM_EINDEX, "%s: the text the tabix index names does not parse (%s): stale .tbi?", path, why.c_str());
+    }
     if (rc) return rc;
     // the text the index pointed at must belong to the contigs that were asked for: a stale or foreign .tbi otherwise
     // yields a silently wrong subset of rows
@@ -867,7 +872,7 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
             const std::string culprit = nm;
             (void)nm_bedcols_close(*out);
             *out = nullptr;
-            return fail(NM_EINVAL, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
+            return fail(NM_EINDEX, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
                         path, culprit.c_str());
         }
     return NM_OK;
@@ -1118,7 +1123,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
         std::vector<InfPiece> hp;
         const CrcConsts crc_k = crc_consts();
-        const bool check_crc = getenv("NM_BED_NO_CRC") == nullptr;     // (timing probe only: what the check costs)
+#ifdef NM_BED_PROBES                                                    // (timing probe builds only: what the check costs)
+        const bool check_crc = getenv("NM_BED_NO_CRC") == nullptr;
+#else
+        constexpr bool check_crc = true;                                // the shipped library always checks every member's CRC-32
+#endif
         uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
         size_t n_chunk = 0;
         const unsigned nt = std::max(1u, threads - 1);

@@ -41,6 +41,7 @@ inline bool inflate_raw(const uint8_t *src, size_t n, char *dst, size_t dst_n, u
 }
 
 // header of the block at `off`: its size in the file, where its deflate stream sits, its text size.  false: not a BGZF block
+// (or one whose trailer states more than the format's 64 KiB of text)
 inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, size_t *in_off, size_t *in_len, size_t *isize, uint32_t *crc) {
     if (off + 18 > zn) return false;
     if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) return false;
@@ -58,6 +59,9 @@ inline bool block_at(const uint8_t *z, size_t zn, size_t off, size_t *bsize, siz
     *in_len = bs - 12 - xlen - 8;
     *isize = z[off + bs - 4] | (z[off + bs - 3] << 8) | (z[off + bs - 2] << 16) | ((size_t)z[off + bs - 1] << 24);
     *crc = (uint32_t)z[off + bs - 8] | ((uint32_t)z[off + bs - 7] << 8) | ((uint32_t)z[off + bs - 6] << 16) | ((uint32_t)z[off + bs - 5] << 24);
+    // a BGZF block holds at most 64 KiB of text (SAM spec 4.1): the device inflate sizes its per-block scratch and the
+    // padding behind the compressed bytes for exactly that, so a trailer that claims more is a damaged file, not a big block
+    if (*isize > 65536) return false;
     return true;
 }
 

@@ -605,9 +605,10 @@ class ScanEngine:
                     at = e
         if bounds[-1] != n:
             bounds.append(n)
-        if max_part_rows and max(b - a for a, b in zip(bounds, bounds[1:])) > 2 * max_part_rows:
+        part_rows = [b - a for a, b in zip(bounds, bounds[1:])]          # empty for a table without rows
+        if max_part_rows and part_rows and max(part_rows) > 2 * max_part_rows:
             import logging
-            logging.warning(f"pileup rows are not grouped by contig: ingestion parts of up to {max(b - a for a, b in zip(bounds, bounds[1:])):,} rows "
+            logging.warning(f"pileup rows are not grouped by contig: ingestion parts of up to {max(part_rows):,} rows "
                             f"instead of {max_part_rows:,} (device memory for the raw rows and the adjacency scratch grows with them)")
         n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
         for k in range(len(bounds) - 1):

@@ -93,6 +93,8 @@ class NativePileup:
                 if self.contigs_not_indexed:
                     import logging
                     logging.warning(f"{self.contigs_not_indexed} of {len(names)} wanted contigs have no entry in {index_path} (no rows read for them)")
+            elif rc != _lib.NM_EINDEX:
+                self._check(rc)          # a damaged pileup, a device error, no memory: final, reading the file again would not help
             else:
                 # not a tabix index, or one that does not fit this file (stale: regions off the BGZF blocks, rows of other
                 # contigs): the whole file is read instead — slower, never a wrong subset of rows
@@ -178,6 +180,8 @@ class DevicePileup:
                 if self.contigs_not_indexed:
                     import logging
                     logging.warning(f"{self.contigs_not_indexed} of {len(names)} wanted contigs have no entry in {index_path} (no rows read for them)")
+            elif rc != _lib.NM_EINDEX:
+                self._check(rc)          # corrupt BGZF block / CRC-32, HIP error, no memory: final (not logged as an index problem)
             else:
                 # not a tabix index, or one that does not fit this file: the whole file instead — slower, never a wrong subset
                 import logging

@@ -276,6 +276,41 @@ def test_a_block_whose_text_does_not_match_its_checksum_is_refused(tmp_path):
     assert n > 0
 
 
+def _claim_oversized_block(gz_path, out_path):
+    """Rewrite the ISIZE field of a block in the second half of a BGZF file to 70 000 bytes (more than the format's 64 KiB)."""
+    raw = bytearray(open(gz_path, "rb").read())
+    off, blocks = 0, []
+    while off < len(raw):
+        bsize = struct.unpack_from("<H", raw, off + 16)[0] + 1
+        blocks.append((off, bsize))
+        off += bsize
+    o, b = blocks[len(blocks) // 2]
+    struct.pack_into("<I", raw, o + b - 4, 70_000)
+    open(out_path, "wb").write(bytes(raw))
+
+
+def test_a_block_that_claims_more_than_64k_of_text_is_refused(tmp_path):
+    """BGZF blocks hold at most 64 KiB of text; the device inflate sizes its scratch for that (round-4 advisor finding), so a
+    trailer that claims more makes the file "not BGZF": the host reader's gzip path then trips over the wrong length, the
+    tabix path says corrupt block — neither reads past a buffer."""
+    from helpers import write_bgzf_tabix
+    from nanomotif_amd._lib import NmScanError
+    spec = synth.SynthSpec(n_contigs=3, total_bp=60_000, n_bins=1, mod_types=("a",), seed=6, min_contig_bp=10_000)
+    mg = synth.make_metagenome(spec)
+    bed = str(tmp_path / "p.bed")
+    mg.write_bed(bed)
+    gz = str(tmp_path / "p.bed.gz")
+    write_bgzf_tabix(open(bed, "rb").read(), gz, block_size=20_000)
+    bad = str(tmp_path / "bad.bed.gz")
+    _claim_oversized_block(gz, bad)
+    import os
+    os.replace(gz + ".tbi", bad + ".tbi")
+    with pytest.raises(NmScanError):
+        pp.NativePileup(bad)
+    with pytest.raises(NmScanError, match="corrupt BGZF block"):
+        pp.NativePileup(bad, contigs=list(mg.names), index_path=bad + ".tbi")
+
+
 def test_names_that_are_not_utf8_are_refused_with_a_message(tmp_path):
     """polars (dataload.py:72-100) refuses a pileup that is not UTF-8; the native readers hand the bytes through and the
     Python side names the place instead of dying in a UnicodeDecodeError."""

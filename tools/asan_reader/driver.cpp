@@ -22,6 +22,7 @@ int nm_set_error(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+extern "C" const char *nm_last_error(void) { return g_err.c_str(); }
 
 static uint64_t checksum(nm_bed *b) {
     uint64_t n = 0, h = 1469598103934665603ULL;

@@ -64,6 +64,17 @@ for bs, lvl in ((0xFF00, 6), (3000, 6), (20000, 0)):
         cases.append(("bed", q))
         cases.append(("bed", q, q + ".tbi", ",".join(mg.names[:3])))
     cases.append(("bed", put(f"b{bs}_{lvl}_cut.bed.gz", bytes(raw[:len(raw) * 2 // 3]))))
+    # a trailer that claims more text than a BGZF block may hold (64 KiB): refused, whole file and tabix subset
+    import struct
+    d, off, heads = bytearray(raw), 0, []
+    while off < len(d):
+        heads.append(off)
+        off += struct.unpack_from("<H", d, off + 16)[0] + 1
+    struct.pack_into("<I", d, (heads[len(heads) // 2 + 1] if len(heads) > 2 else len(d)) - 4, 70_000)
+    q = put(f"b{bs}_{lvl}_isize.bed.gz", bytes(d))
+    open(q + ".tbi", "wb").write(tbi)
+    cases.append(("bed", q))
+    cases.append(("bed", q, q + ".tbi", ",".join(mg.names)))
     # damaged indexes: truncated, random bytes (re-compressed so that they inflate), not an index
     import zlib
     idx_raw = gzip.decompress(tbi)
