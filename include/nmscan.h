@@ -542,6 +542,29 @@ int nm_fasta_sequence(nm_fasta *fa, const uint8_t **seq_upper);
 int nm_fasta_close(nm_fasta *fa);
 
 /*
+ * Device-side FASTA parser (round 5) — the same records as nm_fasta_open, found ON THE GPU for plain-text assemblies
+ * (fasta.py:35-49: every record of the file; seq.py:53-71: upper-cased, non-empty, letters of ATGCRYSWKMBDHVN only): the host
+ * moves the file through pinned slabs into HBM, kernels find the header lines ('>' at the start of a line), measure every
+ * record (bytes that are neither '\n' nor '\r' up to the next header: CRLF files, a last line without newline and lines of
+ * any width are the same thing) and write the bases back to back in device memory — byte for byte the array nm_fasta_sequence
+ * returns.  Only the header lines come back to the host (record name = first whitespace-delimited token).  Errors as
+ * nm_fasta_open: the first record in file order that is empty or holds another letter (NM_EINVAL "DNA sequence must ...").
+ * A gzip file is refused (NM_EINVAL "compressed input ...": use nm_fasta_open).
+ *   nm_fastadev_shape            records, bases; times = {seconds in total, seconds a reader thread spent in pread}
+ *   nm_fastadev_record           name, offset into the packed sequence, length
+ *   nm_fastadev_sequence_device  DEVICE pointer to the packed upper-case sequence (nm_device_read copies from it)
+ *   nm_upload_contigs_fasta      nm_upload_contigs_device for contig i = record[i] of the parsed file: any subset, any order,
+ *                                a record more than once (a contig listed under several bins); no host copy of the sequence
+ */
+typedef struct nm_fastadev nm_fastadev;
+int nm_fasta_parse_device(nm_ctx *ctx, const char *path, uint32_t threads, nm_fastadev **out);
+int nm_fastadev_shape(nm_fastadev *fa, uint32_t *n_records, uint64_t *total_bp, double times[2]);
+int nm_fastadev_record(nm_fastadev *fa, uint32_t i, const char **name, uint64_t *offset, uint64_t *length);
+int nm_fastadev_sequence_device(nm_fastadev *fa, const uint8_t **d_seq_upper);
+int nm_upload_contigs_fasta(nm_ctx *ctx, nm_fastadev *fa, uint32_t n_contigs, const uint32_t *record, const uint32_t *bin_id, uint32_t n_bins);
+int nm_fastadev_close(nm_fastadev *fa);
+
+/*
  * Host helpers of the window-extraction step (no GPU involved).
  * nm_py_random_sample: the indices CPython's random.sample(range(n), k) would return from the MT19937 state
  *   mt_state[0..623] + position mt_state[624] (random.getstate()[1]); the state is advanced in place, so that

@@ -160,13 +160,18 @@ struct PRow {
     Model model;
     double score = 0;
     int complement = -1;             // index into the task's rows of the stage before (complement stage only)
+    int model_id = -1;               // which model OBJECT the row holds: its index among the models the task created
 };
 
+// motifs.unique() (find_motifs_bin.py:570, 579, 588) compares every cell; the `model` cells sit in an Object column and py-polars
+// compares those through Python's __hash__ / __eq__ — identity for BetaBernoulliModel (model.py defines neither).  Two rows are
+// one only when they hold the SAME model objects: two merge clusters that produce the same motif get a model each
+// (:1497-1504) and both rows stay (fixture g13).
 bool same_row(const PRow &a, const PRow &b, const std::vector<PRow> *prev) {     // MotifRow.key()
-    if (!a.m.same(b.m) || a.model.a != b.model.a || a.model.b != b.model.b || !(a.score == b.score)) return false;
+    if (!a.m.same(b.m) || a.model_id != b.model_id || !(a.score == b.score)) return false;
     if ((a.complement < 0) != (b.complement < 0)) return false;
     if (a.complement < 0) return true;
-    return (*prev)[a.complement].m.same((*prev)[b.complement].m);
+    return (*prev)[a.complement].m.same((*prev)[b.complement].m) && (*prev)[a.complement].model_id == (*prev)[b.complement].model_id;
 }
 
 std::vector<PRow> unique_rows(const std::vector<PRow> &rows, const std::vector<PRow> *prev = nullptr) {
@@ -336,7 +341,7 @@ struct PostTask {
 void prepare(PostTask &t, const std::vector<nmsearch::BestRow> &best, int padding, uint32_t task, std::vector<Request> &req) {
     // graph_to_rows: score-descending, ties in node order
     std::vector<PRow> rows;
-    for (const auto &b : best) rows.push_back(PRow{parse_plain(b.motif, padding), b.model, b.score, -1});
+    for (const auto &b : best) rows.push_back(PRow{parse_plain(b.motif, padding), b.model, b.score, -1, (int)rows.size()});
     std::stable_sort(rows.begin(), rows.end(), [](const PRow &a, const PRow &b) { return -a.score < -b.score; });
     if (rows.empty()) return;
     t.stage[0] = rows;
@@ -423,7 +428,7 @@ void finish(PostTask &t, const int64_t *counts) {
                     scores.push_back(evaluation_score(child, Model::from_counts(counts[2 * (at + 1 + j)], counts[2 * (at + 1 + j) + 1])));
                 score = nmsearch::np_mean(scores);
             }
-            rows.push_back(PRow{t.accepted[k], child, score, -1});
+            rows.push_back(PRow{t.accepted[k], child, score, -1, (int)(t.stage[0].size() + k)});
         }
     }
     rows = unique_rows(rows);

@@ -48,7 +48,8 @@ struct ScoreArgs {
 
 // Pack: one workgroup per chunk, 64 positions per wave per step, wave ballot builds the plane words.
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii,
-                                                   const uint64_t *__restrict__ contig_off,
+                                                   const uint64_t *__restrict__ contig_src,
+                                                   const uint64_t *__restrict__ contig_len,
                                                    const uint32_t *__restrict__ chunk_contig,
                                                    const uint32_t *__restrict__ chunk_first,
                                                    uint32_t *__restrict__ H, uint32_t *__restrict__ L,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     const uint32_t chunk = blockIdx.x;
     const uint32_t contig = chunk_contig[chunk];
     if (contig == 0xFFFFFFFFu) return;                               // pad chunk, planes already zero
-    const uint64_t beg = contig_off[contig], len = contig_off[contig + 1] - beg;
+    const uint64_t beg = contig_src[contig], len = contig_len[contig];     // (src: where the contig's bytes start in `ascii`)
     const uint64_t local0 = (uint64_t)(chunk - chunk_first[contig]) * CHUNK_BP;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int it = wave; it < CHUNK_BP / 64; it += 4) {
@@ -1244,7 +1245,8 @@ int nm_sync(nm_ctx *c) {
 }
 
 static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint32_t *bin_id,
-                               uint32_t n_bins, const uint8_t *seq_ascii, bool on_device) {
+                               uint32_t n_bins, const uint8_t *seq_ascii, bool on_device, const uint64_t *src_off = nullptr) {
+    // src_off (device sources only): where each contig's bytes start in seq_ascii; NULL = back to back, at offsets[i]
     // n_contigs == 0 is a valid shard: a rank of a multi-GPU run that received no contig (more GPUs than pieces) holds
     // the bins' numbering and two pad chunks, scores every candidate to zero and still joins every collective
     if (!c || !offsets || (n_contigs && (!bin_id || !seq_ascii))) return fail(NM_EINVAL, "NULL argument");
@@ -1333,7 +1335,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
     HIP_TRY(nmdetail::dev_malloc(&d_chunk_contig, (size_t)c->n_chunks * 4));
     guard.tmp[2] = d_chunk_contig;
     if (!on_device && c->total_bp) HIP_TRY(hipMemcpyAsync(d_ascii, seq_ascii, c->total_bp, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(n_contigs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, src_off ? src_off : offsets, (size_t)(n_contigs + (src_off ? 0 : 1)) * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_chunk_contig, chunk_contig.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice, c->stream));
     {   // per chunk: rank of its contig within its bin (the row of the per-contig counters)
         std::vector<uint32_t> chunk_rank(c->n_chunks, 0);
@@ -1343,7 +1345,7 @@ static int upload_contigs_impl(nm_ctx *c, uint32_t n_contigs, const uint64_t *of
         HIP_TRY(hipMemcpy(c->d_chunk_rank, chunk_rank.data(), (size_t)c->n_chunks * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemsetAsync(c->d_other, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, d_chunk_contig,
+    hipLaunchKernelGGL(pack_kernel, dim3(c->n_chunks), dim3(256), 0, c->stream, d_ascii, d_off, c->d_contig_len, d_chunk_contig,
                        c->d_contig_chunk, c->dH, c->dL, c->dV, c->d_other);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(needs_v_kernel, dim3(c->n_chunks), dim3(CHUNK_WORDS), 0, c->stream, c->dV, c->d_needs_v, c->n_chunks);
@@ -1455,6 +1457,16 @@ int nm_upload_contigs_device(nm_ctx *c, uint32_t n_contigs, const uint64_t *offs
                              uint32_t n_bins, const uint8_t *d_seq_ascii) {
     return upload_contigs_impl(c, n_contigs, offsets, bin_id, n_bins, d_seq_ascii, true);
 }
+
+}  // extern "C"
+
+// nmfasta.hip: the contigs picked out of a device-resident packed sequence (any subset, any order, a record more than once)
+int nmdetail::upload_contigs_gather(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint64_t *src_off, const uint32_t *bin_id,
+                                    uint32_t n_bins, const uint8_t *d_seq_ascii) {
+    return upload_contigs_impl(c, n_contigs, offsets, bin_id, n_bins, d_seq_ascii, true, src_off);
+}
+
+extern "C" {
 
 int nm_upload_pileup(nm_ctx *c, uint32_t mod_slot, uint8_t canonical_base, double low, double high, uint64_t n_rows,
                      const uint32_t *contig_id, const uint32_t *position, const uint8_t *strand,

@@ -244,6 +244,9 @@ inline void drop_ingest_rows(nm_ctx *c) {
 int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2: the asynchronous window batch's own pair
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
+// nm_upload_contigs_device with one source offset per contig (nmfasta.hip: records of a device-parsed FASTA)
+int upload_contigs_gather(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint64_t *src_off, const uint32_t *bin_id,
+                          uint32_t n_bins, const uint8_t *d_seq_ascii);
 void free_readstats(nm_ctx *c);
 // nm_timing_reset(ctx, 2): one event pair around a device phase of the library on the ctx stream (no-ops otherwise); the
 // pairs are summed by nm_timing_total_ms together with the scoring launches

@@ -72,6 +72,10 @@ def synth_lib():
         lib.nm_synth_write_bed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_char_p, u32p, u32p, u32p, C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_uint32]
         lib.nm_synth_bgzip.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32]
+        lib.nm_synth_bgz_open.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.nm_synth_bgz_append_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_char_p, u32p, u32p, u32p, C.POINTER(C.c_int8), C.POINTER(C.c_uint8),
+                                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.nm_synth_bgz_close.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _synth = lib
     return _synth
 
@@ -114,6 +118,63 @@ def write_text_inputs(mg: synth.SynthMetagenome, out_dir: str, device, threads: 
             f.write(b"\n")
     mg.write_contig_bin(os.path.join(out_dir, "contig_bin.tsv"))
     return {"rows": int(len(cid)), "bed_bytes": os.path.getsize(bed), "assembly_bp": int(lengths.sum())}
+
+
+def write_gz_inputs_streaming(mg: synth.SynthMetagenome, out_dir: str, device, bins_per_part: int = 25, threads: int = 0, level: int = 6,
+                              block_size: int = 0xFF00, text_twin: bool = False, log=None) -> dict:
+    """The metagenome as assembly.fasta + pileup.bed.gz + pileup.bed.gz.tbi + contig_bin.tsv, written PART BY PART: the rows of
+    ``bins_per_part`` bins at a time are generated on ``device``, formatted, cut into BGZF blocks that continue one text stream
+    and appended (nm_synth_bgz_* of libnmsynth.so) — the 75 GB of bedMethyl text of a 1 Gbp metagenome never exist as a file.
+    Byte for byte what ``write_text_inputs`` + ``bgzip_tabix`` write for the same metagenome (tests/test_gpu_synth.py); the
+    FASTA holds every contig on one line, contigs and rows in bin order.  ``text_twin``: also write pileup.bed."""
+    import os
+    lib = synth_lib()
+    h = C.c_void_p()
+    gz = os.path.join(out_dir, "pileup.bed.gz")
+    if lib.nm_synth_bgz_open(gz.encode(), os.path.join(out_dir, "pileup.bed").encode() if text_twin else None, int(threads), int(level), int(block_size),
+                             C.byref(h)):
+        raise RuntimeError(lib.nm_synth_last_error().decode())
+    bins = sorted(set(mg.bin_names))
+    by_bin = {b: [] for b in bins}
+    for i, b in enumerate(mg.bin_names):
+        by_bin[b].append(i)
+    p = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(t))
+    rows = 0
+    try:
+        with open(os.path.join(out_dir, "assembly.fasta"), "wb") as fa:
+            for k in range(0, len(bins), bins_per_part):
+                part = [i for b in bins[k:k + bins_per_part] for i in by_bin[b]]
+                mine, lengths, offsets, _, ascii_all, cat = generate_raw(mg, device, part)
+                torch.cuda.synchronize(device)
+                host = {key: v.cpu().numpy() for key, v in cat.items()}
+                pct = np.rint(host["frac"] * 10000.0).astype(np.int32)
+                names = "".join(mg.names[i] for i in mine).encode()
+                off = np.zeros(len(mine) + 1, dtype=np.uint32)
+                np.cumsum([len(mg.names[i]) for i in mine], out=off[1:])
+                cid = np.ascontiguousarray(host["contig"], dtype=np.uint32)
+                if lib.nm_synth_bgz_append_rows(h, len(cid), len(mine), names, p(off, C.c_uint32), p(cid, C.c_uint32),
+                                                p(np.ascontiguousarray(host["position"], dtype=np.uint32), C.c_uint32),
+                                                p(np.ascontiguousarray(host["mod"], dtype=np.int8), C.c_int8),
+                                                p(np.ascontiguousarray(host["strand"], dtype=np.uint8), C.c_uint8),
+                                                p(np.ascontiguousarray(host["nvalid"], dtype=np.int32), C.c_int32), p(pct, C.c_int32)):
+                    raise RuntimeError(lib.nm_synth_last_error().decode())
+                rows += len(cid)
+                seq = ascii_all.cpu().numpy()
+                for j, i in enumerate(mine):
+                    fa.write(b">" + mg.names[i].encode() + b"\n")
+                    fa.write(seq[int(offsets[j]):int(offsets[j + 1])].tobytes())
+                    fa.write(b"\n")
+                del cat, ascii_all, host, seq
+                if log:
+                    log(f"  part {k // bins_per_part + 1} of {(len(bins) + bins_per_part - 1) // bins_per_part}: {rows:,} rows so far")
+    finally:
+        text_bytes, gz_bytes = C.c_uint64(0), C.c_uint64(0)
+        rc = lib.nm_synth_bgz_close(h, C.byref(text_bytes), C.byref(gz_bytes))
+    if rc:
+        raise RuntimeError(lib.nm_synth_last_error().decode())
+    mg.write_contig_bin(os.path.join(out_dir, "contig_bin.tsv"))
+    return {"rows": rows, "bed_bytes": int(text_bytes.value), "gz_bytes": int(gz_bytes.value), "assembly_bp": int(sum(int(x) for x in mg.lengths)),
+            "fasta_bytes": os.path.getsize(os.path.join(out_dir, "assembly.fasta"))}
 
 
 def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, host_assembly=True):

@@ -460,6 +460,22 @@ class ScanEngine:
         self.contig_bin = bin_ids
         self.slot_of_mod = {}
 
+    def upload_assembly_fasta(self, assembly, names, bin_of_contig, bin_names=None):
+        """``upload_assembly`` for a ``fasta.DeviceAssembly`` (the FASTA was parsed on this device): contig ``names[i]`` is the
+        record of that name; the planes are packed straight from the parser's device buffer (nm_upload_contigs_fasta)."""
+        names = list(names)
+        records = np.array([assembly.record[n] for n in names], dtype=np.uint32)
+        self.bin_names = sorted(set(bin_of_contig)) if bin_names is None else list(bin_names)
+        self.bin_index = {b: i for i, b in enumerate(self.bin_names)}
+        bin_ids = np.array([self.bin_index[b] for b in bin_of_contig], dtype=np.uint32)
+        _lib.check(self.lib.nm_upload_contigs_fasta(self.ctx, assembly._h, len(names), _ptr(records, C.c_uint32), _ptr(bin_ids, C.c_uint32),
+                                                    len(self.bin_names)))
+        self.contig_names = names
+        self.contig_index = {n: i for i, n in enumerate(names)}
+        self.contig_lengths = np.array([assembly.length(n) for n in names], dtype=np.int64)
+        self.contig_bin = bin_ids
+        self.slot_of_mod = {}
+
     def contig_base_counts(self, base: str, padding: int) -> np.ndarray:
         """Per resident contig: positions p in [padding, len - padding) whose base is ``base`` — the number of valid
         starts ``sample_n_subsequences`` draws from (seq.py:202-225)."""

@@ -94,6 +94,83 @@ def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
     return out
 
 
+class DeviceAssembly:
+    """The assembly FASTA parsed ON THE GPU (nm_fasta_parse_device): the record table (names, lengths) lives here, the bases stay
+    in device memory, upper-cased and checked like ``load_fasta`` does (seq.py:53-71) — ``ScanEngine.upload_assembly_fasta`` packs
+    the wanted records into the planes from there.  Behaves like the dict ``load_fasta`` returns where the pipeline needs it:
+    ``in``, iteration over names, ``length(name)``; ``assembly[name]`` copies that record's bases to the host (only the host
+    window path of an assembly with IUPAC ambiguity letters ever asks).  Plain text only: a ``.gz`` assembly keeps ``load_fasta``."""
+
+    def __init__(self, engine, path, threads: int = 0):
+        import ctypes as C
+        from . import _lib
+        self.engine, self._lib, self._check = engine, _lib.load(), _lib.check
+        self._h = C.c_void_p()
+        rc = self._lib.nm_fasta_parse_device(engine.ctx, os.fsencode(str(path)), int(threads), C.byref(self._h))
+        if rc:
+            msg = self._lib.nm_last_error().decode()
+            if "DNA sequence must" in msg:
+                raise AssertionError(msg)                      # DNAsequence._check_sequence asserts (seq.py:68-71)
+            self._check(rc)
+        n, total = C.c_uint32(0), C.c_uint64(0)
+        times = (C.c_double * 2)()
+        self._check(self._lib.nm_fastadev_shape(self._h, C.byref(n), C.byref(total), times))
+        self.total_bp, self.seconds, self.seconds_reading = int(total.value), float(times[0]), float(times[1])
+        self.record, self._length, self._offset, self._host = {}, [], [], {}
+        for i in range(n.value):
+            name, off, ln = C.c_char_p(), C.c_uint64(0), C.c_uint64(0)
+            self._check(self._lib.nm_fastadev_record(self._h, i, C.byref(name), C.byref(off), C.byref(ln)))
+            self.record[_lib.text_of(name.value, "a record name of the assembly")] = i      # a repeated name: the last record wins, like a dict
+            self._length.append(int(ln.value))
+            self._offset.append(int(off.value))
+
+    def __contains__(self, name):
+        return name in self.record
+
+    def __iter__(self):
+        return iter(self.record)
+
+    def __len__(self):
+        return len(self.record)
+
+    def keys(self):
+        return self.record.keys()
+
+    def length(self, name) -> int:
+        return self._length[self.record[name]]
+
+    def alias(self, name, original):
+        """``name`` stands for the record of ``original`` as well (a contig listed under several bins)."""
+        self.record[name] = self.record[original]
+
+    def __getitem__(self, name):
+        import ctypes as C
+        i = self.record[name]
+        if i not in self._host:
+            ptr = C.c_void_p()
+            self._check(self._lib.nm_fastadev_sequence_device(self._h, C.byref(ptr)))
+            a = np.empty(self._length[i], dtype=np.uint8)
+            self._check(self._lib.nm_device_read(self.engine.ctx, a.ctypes.data_as(C.c_void_p), C.c_void_p((ptr.value or 0) + self._offset[i]), a.nbytes))
+            self._host[i] = a
+        return self._host[i]
+
+    def close(self):
+        if self._h:
+            self._lib.nm_fastadev_close(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assembly_length(assembly, name) -> int:
+    """Bases of a contig, whichever form the assembly has (dict of arrays, or a DeviceAssembly)."""
+    return assembly.length(name) if isinstance(assembly, DeviceAssembly) else len(assembly[name])
+
+
 ALIAS_SEP = "\x00"       # a contig listed under several bins: its further placements are named  contig + ALIAS_SEP + bin
 
 
@@ -122,7 +199,10 @@ def add_alias_sequences(assembly: dict, bin_contig: dict):
     """Every aliased placement gets its contig's sequence (the same array, no copy)."""
     for name in bin_contig:
         if ALIAS_SEP in name and original_name(name) in assembly:
-            assembly[name] = assembly[original_name(name)]
+            if isinstance(assembly, DeviceAssembly):
+                assembly.alias(name, original_name(name))
+            else:
+                assembly[name] = assembly[original_name(name)]
 
 
 def generate_contig_bin(args) -> dict:

@@ -116,8 +116,18 @@ def find_motifs_bin(args):
         eng.close()
         return None
     log.info("Loading assembly")
+    # A plain-text assembly is parsed ON THE GPU (nm_fasta_parse_device: the host only moves the file through pinned slabs; the
+    # bases never become a host array, the planes are packed from the parser's device buffer); a .gz assembly and
+    # NANOMOTIF_HOST_FASTA=1 take the native host reader, which runs while the HIP runtime comes up.
+    device_fasta = not str(args.assembly).endswith(".gz") and os.environ.get("NANOMOTIF_HOST_FASTA") != "1"
     try:
-        assembly = fasta.load_fasta(args.assembly)
+        if device_fasta:
+            eng = engine()
+            lap("engine_start_s")
+            assembly = fasta.DeviceAssembly(eng, args.assembly, threads=max(args.threads, 0) if args.threads > 1 else 0)
+            TIMINGS["assembly_reading_s"] = assembly.seconds_reading
+        else:
+            assembly = fasta.load_fasta(args.assembly)
         fasta.add_alias_sequences(assembly, bin_contig)      # a contig listed under several bins is a member of each
     except BaseException:
         starter.join()
@@ -125,8 +135,10 @@ def find_motifs_bin(args):
             started["eng"].close()
         raise
     lap("assembly_s")
-    eng = engine()
-    lap("engine_start_s")                        # what the assembly did not hide
+    TIMINGS["assembly_parser"] = "device" if device_fasta else "host"
+    if not device_fasta:
+        eng = engine()
+        lap("engine_start_s")                    # what the assembly did not hide
     log.info("Identifying motifs")
     cfg = ProcessorConfig(assembly=assembly, pileup_path=args.pileup, bin_contig=bin_contig, threads=args.threads,
                           search_frame_size=args.search_frame_size, methylation_threshold_low=args.methylation_threshold_low,
@@ -174,7 +186,7 @@ def find_motifs_bin(args):
     if world > 1 and args.shard != "contigs":
         sizes = {}
         for c in names:
-            sizes[cfg.bin_contig[c]] = sizes.get(cfg.bin_contig[c], 0) + len(assembly[c])
+            sizes[cfg.bin_contig[c]] = sizes.get(cfg.bin_contig[c], 0) + fasta.assembly_length(assembly, c)
         by_bins = assign_bins(sizes, world, tolerance=0.15 if args.shard == "auto" else float("inf"))
     if by_bins is not None:
         my_bins = set(by_bins[rank])
@@ -241,10 +253,13 @@ def find_motifs_bin(args):
         else:
             log.warning(f"rank {rank}: the C ABI's communicator is not up on every rank: count tables go through torch.distributed")
     try:
-        parts = assign_contigs([len(assembly[c]) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
+        parts = assign_contigs([fasta.assembly_length(assembly, c) for c in names], world, bins=[cfg.bin_contig[c] for c in names])
         mine = [names[i] for i in parts[rank if gather_world == 1 else 0]]
         all_bins = sorted(set(cfg.bin_contig[c] for c in names))       # bin ids must be identical on every rank
-        eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+        if device_fasta:
+            eng.upload_assembly_fasta(assembly, mine, [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+        else:
+            eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
         # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
         # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
         local_id = {c: i for i, c in enumerate(mine)}
@@ -269,7 +284,9 @@ def find_motifs_bin(args):
         else:
             res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
                                     cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
-        store, extractor = device_window_pipeline(eng, {c: len(assembly[c]) for c in names}, mine, cfg.padding, world)
+        store, extractor = device_window_pipeline(eng, {c: fasta.assembly_length(assembly, c) for c in names}, mine, cfg.padding, world)
+        if device_fasta and extractor is not None:
+            assembly.close()                     # the packed bases have served; (host windows would read contigs back from them)
         rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
         if (low, high) == (0.3, 0.7):
             for mt in pileup_mod.MOD_TYPES:
@@ -306,6 +323,8 @@ def find_motifs_bin(args):
     finally:
         # also on the early returns and on exceptions: the module-global reducer must not outlive its engine
         use_native_allreduce(None)
+        if device_fasta:
+            assembly.close()
         eng.close()
 
 

@@ -64,8 +64,13 @@ class MotifRow:
         return d[1] if d is not None else self._derived()[1]
 
     def key(self):
-        return (self.reference, self.motif, self.mod_type, self.mod_position, self.n_mod, self.n_nomod, self.score,
-                None if self.complement is None else (self.complement.motif, self.complement.mod_position))
+        """What ``DataFrame.unique()`` compares (find_motifs_bin.py:570, 579, 588): every cell of the row.  The ``model`` cells
+        are Python objects in an Object column and py-polars hashes / compares those through ``__hash__`` / ``__eq__`` — identity
+        for ``BetaBernoulliModel`` (model.py defines neither) — so two rows are one only when they hold the SAME model objects.
+        Two merge clusters that produce the same merged motif each get a model of their own (find_motifs_bin.py:1497-1504): the
+        reference keeps both rows and so does this (fixture g13; the stand-in frame of the fixtures compares the same way)."""
+        return (self.reference, self.motif, self.mod_type, self.mod_position, id(self.model), self.score,
+                None if self.complement is None else (self.complement.motif, self.complement.mod_position, id(self.complement.model)))
 
 
 def unique(rows):

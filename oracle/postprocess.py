@@ -86,9 +86,12 @@ def merge_motifs_in_rows(rows, pileup, contigs, low=0.3, high=0.7, merge_thresho
 
 
 def unique_rows(rows):
+    """``motifs.unique()`` (find_motifs_bin.py:570, 579): all cells of a row, the ``model`` cell (an Object column) compared
+    the way py-polars compares Python objects — ``__hash__`` / ``__eq__``, i.e. identity for BetaBernoulliModel.  Two clusters
+    merging into the same motif carry a model each (:1497-1504): both rows stay (fixture g13)."""
     seen, out = set(), []
     for r in rows:
-        k = (r["reference"], r["motif"], r["mod_type"], r["mod_position"], r["n_mod"], r["n_nomod"], r["score"])
+        k = (r["reference"], r["motif"], r["mod_type"], r["mod_position"], id(r["model"]), r["score"])
         if k not in seen:
             seen.add(k)
             out.append(r)

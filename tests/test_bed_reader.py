@@ -1,5 +1,6 @@
 """Native bedMethyl reader (nm_bed_*, libnmscan) — host-only, runs without a GPU."""
 import gzip
+import os
 import struct
 import time
 import zlib
@@ -227,6 +228,52 @@ def test_native_bgzip_tabix_writer_of_the_bench(tmp_path):
         assert rows[0][0] == rows[1][0] and rows[0][2] == rows[1][2]
         for k in rows[0][1]:
             assert np.array_equal(rows[0][1][k], rows[1][1][k]), k
+
+
+def test_streaming_bgzip_writer_of_the_bench_equals_the_file_writer(tmp_path):
+    """libnmsynth's part-by-part writer (nm_synth_bgz_*: rows -> one BGZF text stream + tabix index, what bench.py --extras cli1g
+    uses for the 1 Gbp pileup, whose 75 GB of text never exist as a file) against text file -> nm_synth_bgzip: identical .gz,
+    identical .tbi, identical text twin — also when a part ends in the middle of a contig and of a 16 kb index window."""
+    import ctypes as C
+    from nanomotif_amd import e2e_synth
+    spec = synth.SynthSpec(n_contigs=6, total_bp=500_000, n_bins=2, mod_types=("a", "m"), seed=64, min_contig_bp=30_000)
+    mg = synth.make_metagenome(spec)
+    path = str(tmp_path / "p.bed")
+    mg.write_bed(path)
+    cols = {k: [] for k in ("contig", "position", "mod", "strand", "cov", "pct")}
+    for i in range(len(mg.names)):                                     # the rows in write_bed's order
+        rows = []
+        for mt in mg.spec.mod_types:
+            pl = mg.contig_pileup(i, mt)
+            rows += [(int(a), mt, int(b), int(c), int(d)) for a, b, c, d in zip(pl["position"], pl["strand"], pl["nvalid"], pl["pct_hundredths"])]
+        rows.sort(key=lambda r: (r[0], r[1]))
+        for pos, mt, st, cov, pct in rows:
+            for k, v in zip(cols, (i, pos, pp.MOD_TYPES.index(mt), st, cov, pct)):
+                cols[k].append(v)
+    arr = {"contig": np.array(cols["contig"], np.uint32), "position": np.array(cols["position"], np.uint32), "mod": np.array(cols["mod"], np.int8),
+           "strand": np.array(cols["strand"], np.uint8), "cov": np.array(cols["cov"], np.int32), "pct": np.array(cols["pct"], np.int32)}
+    n = len(arr["contig"])
+    names = "".join(mg.names).encode()
+    off = np.zeros(len(mg.names) + 1, dtype=np.uint32)
+    np.cumsum([len(x) for x in mg.names], out=off[1:])
+    lib = e2e_synth.synth_lib()
+    ptr = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for bs, cuts in ((0xFF00, [0, n]), (0xFF00, [0, n // 3 + 7, n // 3 + 8, 2 * n // 3, n]), (3_000, [0, 1, n // 2, n])):
+        ref = str(tmp_path / f"ref{bs}.bed.gz")
+        e2e_synth.bgzip_tabix(path, ref, threads=3, block_size=bs)
+        out = str(tmp_path / f"stream{bs}_{len(cuts)}.bed.gz")
+        h = C.c_void_p()
+        assert lib.nm_synth_bgz_open(out.encode(), (out + ".txt").encode(), 3, 6, bs, C.byref(h)) == 0
+        for a, b in zip(cuts, cuts[1:]):
+            part = {k: np.ascontiguousarray(v[a:b]) for k, v in arr.items()}
+            assert lib.nm_synth_bgz_append_rows(h, b - a, len(mg.names), names, ptr(off, C.c_uint32), ptr(part["contig"], C.c_uint32),
+                                                ptr(part["position"], C.c_uint32), ptr(part["mod"], C.c_int8), ptr(part["strand"], C.c_uint8),
+                                                ptr(part["cov"], C.c_int32), ptr(part["pct"], C.c_int32)) == 0, lib.nm_synth_last_error()
+        tb, gb = C.c_uint64(0), C.c_uint64(0)
+        assert lib.nm_synth_bgz_close(h, C.byref(tb), C.byref(gb)) == 0
+        assert open(out + ".txt", "rb").read() == open(path, "rb").read() and tb.value == os.path.getsize(path)
+        assert open(out, "rb").read() == open(ref, "rb").read() and gb.value == os.path.getsize(ref)
+        assert open(out + ".tbi", "rb").read() == open(ref + ".tbi", "rb").read()
 
 
 def test_ingest_columns_may_be_asked_for_twice(tmp_path):
