@@ -385,6 +385,122 @@ def run_cli_extra(device, log_fn, total_bp=100_000_000):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def _memory_budget_bytes(base):
+    """What the files of an extra may take under ``base``: its free space, and — a tmpfs lives in this cgroup's memory — the
+    cgroup's limit minus what is in use."""
+    import shutil
+    free = shutil.disk_usage(base).free
+    try:
+        limit = open("/sys/fs/cgroup/memory.max").read().strip()
+        used = int(open("/sys/fs/cgroup/memory.current").read())
+        if limit != "max":
+            free = min(free, int(limit) - used)
+    except (OSError, ValueError):
+        pass
+    return free
+
+
+def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_level=6, keep_dir=None):
+    """The drop-in command at the size the metric is quoted on, from FILES: BASELINE cfg 4 / cfg 5's metagenome (1 Gbp, 10 000
+    contigs, 500 bins, 6mA + 5mC: 1e9 pileup rows) as assembly.fasta + pileup.bed.gz + .tbi + contig_bin.tsv on a tmpfs, written
+    part by part by libnmsynth.so (the 75 GB of bedMethyl text never exist), then ONE cold `python -m nanomotif_amd
+    motif_discovery` process: wall clock and the phase split the CLI records (engine start, FASTA, pileup read / inflate / parse,
+    device filters, search, write), each phase's GB/s, and the bin-motifs.tsv rows of ``parity_bins`` seeded bins against the
+    oracle pipeline (bgzip seeding: once per bin, find_motifs_bin.py:219-248).  Falls back to the largest size that fits and
+    says which."""
+    import shutil
+    import tempfile
+    from nanomotif_amd import e2e_synth, synth
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    asked = total_bp
+    budget = _memory_budget_bytes(base)
+    # per bp: ~15 B of .gz + 1 B of FASTA on the tmpfs; working set of the writer (one part of 25 bins: rows + text twice) and of
+    # the CLI process (pinned slabs, the mapped .gz is already counted) ~ 12 GB
+    while total_bp > 50_000_000 and 17.0 * total_bp + 14e9 > 0.8 * budget:
+        total_bp //= 2
+    out = {"asked_total_bp": asked, "total_bp": total_bp, "tmpfs": base, "budget_GB": budget / 1e9,
+           "size_note": ("the size BASELINE's metric is quoted on" if total_bp == asked else
+                         f"FELL BACK from {asked:,} bp: {base} / the cgroup leave {budget / 1e9:.0f} GB, the files + working set of {asked:,} bp need ~{(17.0 * asked + 14e9) / 0.8 / 1e9:.0f} GB")}
+    tmp = keep_dir or tempfile.mkdtemp(prefix="nm_bench_cli1g_", dir=base)
+    os.makedirs(tmp, exist_ok=True)
+    try:
+        spec = synth.config("cfg5") if total_bp == 1_000_000_000 else synth.SynthSpec(
+            n_contigs=max(8, total_bp // 100_000), total_bp=total_bp, n_bins=max(2, total_bp // 2_000_000), mod_types=("a", "m"), seed=1)
+        mg = synth.make_metagenome(spec)
+        t0 = time.perf_counter()
+        sizes = e2e_synth.write_gz_inputs_streaming(mg, tmp, device, bins_per_part=25, level=gz_level, log=log_fn)
+        out["write_s"] = time.perf_counter() - t0
+        out.update(rows=sizes["rows"], bed_text_bytes=sizes["bed_bytes"], gz_bytes=sizes["gz_bytes"], fasta_bytes=sizes["fasta_bytes"], gz_level=gz_level)
+        log_fn(f"cli1g: {sizes['rows']:,} rows = {sizes['bed_bytes'] / 1e9:.1f} GB of bedMethyl text as {sizes['gz_bytes'] / 1e9:.2f} GB of bgzip + tabix, "
+               f"{sizes['fasta_bytes'] / 1e9:.2f} GB of FASTA, written in {out['write_s']:.0f}s to {tmp}")
+        for name in ("pileup.bed.gz", "assembly.fasta"):               # page cache, read through once (see run_cli_extra)
+            with open(os.path.join(tmp, name), "rb", buffering=0) as f:
+                buf = bytearray(64 << 20)
+                while f.readinto(buf):
+                    pass
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        legs = {}
+        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1"})):      # (the second run also prints the parser's per-slab split)
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv",
+                                "--out", "out_" + leg], cwd=tmp, env=dict(env, **extra_env), capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode:
+                legs[leg] = {"error": (r.stdout + r.stderr)[-1500:]}
+                continue
+            t = json.load(open(os.path.join(tmp, "out_" + leg, "logs", "timings.motif_discovery.json")))
+            gb = lambda nbytes, s: (nbytes / 1e9 / s) if s else None
+            phases = {
+                "interpreter_and_imports_s": wall - t.get("find_motifs_bin_s", 0.0),
+                "engine_start_s": t.get("engine_start_s"),
+                "fasta_s": t.get("assembly_s"), "fasta_reading_s": t.get("assembly_reading_s"), "fasta_parser": t.get("assembly_parser"),
+                "pileup_s": t.get("pileup_parse_s"), "pileup_read_s": t.get("pileup_reading_s"), "pileup_inflate_s": t.get("pileup_inflating_s"),
+                "pileup_parse_s": t.get("pileup_parsing_s"), "pileup_parser": t.get("pileup_parser"),
+                "filters_s": t.get("upload_filter_s"), "search_s": t.get("search_s"), "write_s": t.get("write_s"),
+            }
+            rates = {
+                "fasta_file_GB_per_s": gb(sizes["fasta_bytes"], t.get("assembly_s")),
+                "pileup_gz_GB_per_s_read": gb(sizes["gz_bytes"], t.get("pileup_reading_s")),
+                "pileup_text_GB_per_s_inflate": gb(sizes["bed_bytes"], t.get("pileup_inflating_s")),
+                "pileup_text_GB_per_s_whole_parse": gb(sizes["bed_bytes"], t.get("pileup_parse_s")),
+                "pileup_gz_GB_per_s_whole_parse": gb(sizes["gz_bytes"], t.get("pileup_parse_s")),
+                "raw_rows_GB_per_s_filters": gb(22 * sizes["rows"], t.get("upload_filter_s")),
+                "pcie_h2d_measured_GB_per_s": 57.0,
+            }
+            timed = {k: v for k, v in phases.items() if k.endswith("_s") and isinstance(v, float) and k not in ("fasta_reading_s", "pileup_read_s", "pileup_inflate_s", "pileup_parse_s")}
+            legs[leg] = {"wall_s": wall, "in_find_motifs_bin_s": t.get("find_motifs_bin_s"), "phases": phases, "rates": rates,
+                         "the_wall_is": max(timed, key=timed.get), "assembly_s_per_Gbp": (t.get("assembly_s") or 0.0) / (total_bp / 1e9),
+                         "motif_rows": max(len(open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read().splitlines()) - 1, 0)}
+            if extra_env:
+                legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith("[bed]")][:64]
+        out["legs"] = legs
+        texts = {leg: open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read() for leg in legs if "error" not in legs[leg]}
+        if len(texts) == 2:
+            out["both_runs_byte_equal"] = texts["cold"] == texts["again"]
+        # parity: the rows of `parity_bins` seeded bins against the oracle pipeline (CPU; bgzip task order and seeding)
+        if texts and parity_bins:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from helpers import oracle_pipeline_parallel
+            bins = sorted(set(mg.bin_names))
+            rng = np.random.Generator(np.random.PCG64(2025))
+            sample = [bins[i] for i in sorted(rng.choice(len(bins), size=min(parity_bins, len(bins)), replace=False).tolist())]
+            t0 = time.perf_counter()
+            exp = oracle_pipeline_parallel(mg, sample, max(1, min(parity_bins, (os.cpu_count() or 2) - 1)), bgzip_order=True)
+            text = next(iter(texts.values()))
+            lines = text.splitlines()
+            col = lines[0].split("\t").index("reference")
+            got = "\n".join([lines[0]] + [ln for ln in lines[1:] if ln.split("\t")[col] in set(sample)]) + "\n"
+            out["parity"] = {"bins": sample, "byte_equal_to_the_oracle_pipeline": got == exp, "oracle_rows": exp.count("\n") - 1, "oracle_s": time.perf_counter() - t0}
+            if got != exp:
+                out["parity"]["product"], out["parity"]["oracle"] = got[:4000], exp[:4000]
+        return out
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,8 +522,11 @@ def main():
     ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: those that apply; none), and the opt-in cli (cfg 3 as FILES, plain and bgzip: writes ~9 GB to a tmpfs, four CLI processes)")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: those that apply; none), the opt-in cli (cfg 3 as FILES, plain and bgzip: writes ~9 GB to a tmpfs, four CLI processes) and the opt-in cli1g (the CLI at 1 Gbp from FASTA + .bed.gz + .tbi: ~16 GB on a tmpfs, minutes of writing)")
     ap.add_argument("--cli-bp", type=int, default=100_000_000, help="size of the file-to-bin-motifs.tsv extra (cfg 3: 100 Mbp = 7.8 GB of bedMethyl text)")
+    ap.add_argument("--cli1g-bp", type=int, default=1_000_000_000, help="size of the opt-in cli1g extra (the CLI on FASTA + .bed.gz + .tbi at the headline size; "
+                    "falls back to the largest size the tmpfs / cgroup holds and says which)")
+    ap.add_argument("--cli1g-gz-level", type=int, default=6, help="zlib level of the synthetic bgzip pileup of the cli1g extra (bgzip's default is 6)")
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
                     help="debug, one GPU: hold the shard rank 0 of an N-rank run would hold (contigs as shard.assign_contigs deals "
                          "them, the whole candidate table in every call); counts are this shard's only")
@@ -499,6 +618,7 @@ def main():
     else:
         extras.discard("cfg5_all")
         extras.discard("cli")
+        extras.discard("cli1g")
 
     if args.workload == "e2e":
         sizes = {}
@@ -955,6 +1075,12 @@ def main():
     except Exception as exc:
         log(f"extra 'cli' failed: {exc!r}")
         extra_errors["cli"] = repr(exc)
+    try:
+        if "cli1g" in extras and rank == 0:
+            result["cli1g"] = run_cli1g_extra(device, log, args.cli1g_bp, gz_level=args.cli1g_gz_level)
+    except Exception as exc:
+        log(f"extra 'cli1g' failed: {exc!r}")
+        extra_errors["cli1g"] = repr(exc)
 
     failed = 0
     if rank == 0:

@@ -508,6 +508,8 @@ int nm_bed_close(nm_bed *bed);
  * bin's contigs through the .tbi) — arguments, stats and errors as nm_bed_open_indexed; rows equal to it bit for bit.
  * Any other gzip stream is refused (NM_EINVAL "compressed input ...": use nm_bed_open).
  *   nm_bedcols_shape           rows, contigs, runs of equal contig names; times = {seconds in total, seconds copying the file}
+ *   nm_bedcols_phase_seconds   {total, moving the file (pread / memcpy into pinned slabs, H2D issue), waiting for the device inflate of
+ *                              a bgzip file's slabs (0 for plain text), the rest: line / field kernels, contig tables}
  *   nm_bedcols_runs            run_row[n_runs + 1] (first row of each run, then n_rows), run_contig[n_runs] (file contig id)
  *   nm_bedcols_map_contigs     contig column = contig_lut[file contig id] (engine contig id or 0xFFFFFFFF)
  *   nm_bedcols_device_columns  DEVICE pointers; contig_id is valid after nm_bedcols_map_contigs
@@ -523,6 +525,7 @@ int nm_bedcols_runs(nm_bedcols *cols, uint64_t *run_row, uint32_t *run_contig);
 int nm_bedcols_map_contigs(nm_bedcols *cols, const uint32_t *contig_lut, uint32_t n_lut);
 int nm_bedcols_device_columns(nm_bedcols *cols, const uint32_t **contig_id, const uint32_t **file_contig_id, const uint32_t **position,
                               const int8_t **mod_type, const uint8_t **strand, const double **fraction_mod, const int32_t **nvalid_cov);
+int nm_bedcols_phase_seconds(nm_bedcols *cols, double out[4]);
 int nm_bedcols_close(nm_bedcols *cols);
 /* Copy `bytes` from device memory the library handed out (e.g. the columns above) to host memory, after the work queued on
  * the ctx stream. */

@@ -643,7 +643,7 @@ struct nm_bedcols {
     std::vector<const char *> name_ptrs;
     std::vector<uint64_t> run_row;          // ascending, + n_rows at the end
     std::vector<uint32_t> run_contig;
-    double t_read = 0, t_total = 0;
+    double t_read = 0, t_total = 0, t_inflate = 0;
 };
 
 namespace {
@@ -1189,6 +1189,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
             const double t_inflated = now();
+            b->t_inflate += t_inflated - t_copied;
             if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
             if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
                 return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16));
@@ -1377,6 +1378,15 @@ int nm_bedcols_shape(nm_bedcols *b, uint64_t *n_rows, uint32_t *n_contigs, uint3
     *n_contigs = (uint32_t)b->names.size();
     if (n_runs) *n_runs = (uint32_t)b->run_contig.size();
     if (times) { times[0] = b->t_total; times[1] = b->t_read; }
+    return NM_OK;
+}
+
+int nm_bedcols_phase_seconds(nm_bedcols *b, double out[4]) {
+    if (!b || !out) return fail(NM_EINVAL, "NULL argument");
+    out[0] = b->t_total;
+    out[1] = b->t_read;
+    out[2] = b->t_inflate;
+    out[3] = b->t_total - b->t_read - b->t_inflate;
     return NM_OK;
 }
 

@@ -175,6 +175,8 @@ def find_motifs_bin(args):
     on_device = isinstance(table, pileup_mod.DevicePileup)
     lap("pileup_parse_s")
     TIMINGS["pileup_parser"] = "device" if on_device else "host"
+    if on_device:
+        TIMINGS.update(pileup_reading_s=table.seconds_reading, pileup_inflating_s=table.seconds_inflating, pileup_parsing_s=table.seconds_parsing)
     TIMINGS["pileup_rows"] = len(table)
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they

@@ -194,6 +194,9 @@ class DevicePileup:
         times = (C.c_double * 2)()
         self._check(self._lib.nm_bedcols_shape(self._h, C.byref(n), C.byref(nc), C.byref(nr), times))
         self.n, self.seconds, self.seconds_reading = int(n.value), float(times[0]), float(times[1])
+        phase = (C.c_double * 4)()
+        self._check(self._lib.nm_bedcols_phase_seconds(self._h, phase))
+        self.seconds_inflating, self.seconds_parsing = float(phase[2]), float(phase[3])
         if self.n == 0:
             self.close()
             raise SystemExit("Pileup is empty after initial load")      # dataload.py:89-91 exits with status 1

@@ -406,46 +406,68 @@ G8_CASES = [
 ]
 
 
-def g8(nm):
+def _post_case(nm, cache, out, name, bin_name, mts, members, scores):
+    """One motif family through the reference's four post-processing functions: the case record of g8 / g13."""
     from nanomotif.model import BetaBernoulliModel
     fmb = nm.find_motifs_bin
     pl = sys.modules["polars"]
+    if (bin_name, mts) not in cache:
+        cache[(bin_name, mts)] = _post_bin(nm, bin_name, mts)
+    kw, mg, pile, seqs = cache[(bin_name, mts)]
+    out["bins"][bin_name] = {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v))
+                             for k, v in kw.items()}
+    data = {"reference": [], "motif": [], "mod_type": [], "mod_position": [], "model": [], "score": []}
+    rec_in = []
+    for k, (core, pos, mt) in enumerate(members):
+        m = _wide(nm, core, pos)
+        sub = pile.filter(pl.col("mod_type") == mt)
+        model = fmb.motif_model_bin(sub, seqs, m, BetaBernoulliModel(), 0.3, 0.7)
+        for key, v in zip(data, ("bin0", m.string, mt, int(m.mod_position), model, scores[k])):
+            data[key].append(v)
+        rec_in.append([m.string, int(m.mod_position), mt, model_counts(model), scores[k]])
+    df = nm.motif.MotifSearchResult(pl.DataFrame(data))
+    stages = {}
+    dup = False
+    a = nm.postprocess.remove_noisy_motifs(df)
+    stages["noise"] = _table(a)
+    b = fmb.merge_motifs_in_df(a, pile, seqs, {"bin0": list(seqs)}).unique()
+    stages["merge"] = _table(b)
+    dup |= _has_duplicate_motifs(b)
+    c = nm.postprocess.remove_sub_motifs(b).unique()
+    stages["sub"] = _table(c)
+    dup |= _has_duplicate_motifs(c)
+    d = nm.postprocess.join_motif_complements(c).unique()
+    stages["complement"] = _table(d)
+    print(name, {k: len(v) for k, v in stages.items()}, "one motif twice" if dup else "")
+    return {"name": name, "bin": bin_name, "mod_types": list(mts), "input": rec_in, "stages": stages, "a_stage_held_one_motif_twice": bool(dup)}
+
+
+def g8(nm):
     out = {"bins": {}, "cases": [], "stand_in": "tests/golden/refframe.py"}
     cache = {}
     for name, bin_name, members in G8_CASES:
         mts = tuple(sorted({m[2] for m in members}))
-        if (bin_name, mts) not in cache:
-            cache[(bin_name, mts)] = _post_bin(nm, bin_name, mts)
-        kw, mg, pile, seqs = cache[(bin_name, mts)]
-        out["bins"][bin_name] = {k: (list(map(list, v)) if k == "fixed_motifs" else (list(v) if isinstance(v, tuple) else v))
-                                 for k, v in kw.items()}
-        data = {"reference": [], "motif": [], "mod_type": [], "mod_position": [], "model": [], "score": []}
-        rec_in = []
-        for k, (core, pos, mt) in enumerate(members):
-            m = _wide(nm, core, pos)
-            sub = pile.filter(pl.col("mod_type") == mt)
-            model = fmb.motif_model_bin(sub, seqs, m, BetaBernoulliModel(), 0.3, 0.7)
-            score = 2.0 + 0.25 * k                   # the stages carry the search's score along; any value does
-            for key, v in zip(data, ("bin0", m.string, mt, int(m.mod_position), model, score)):
-                data[key].append(v)
-            rec_in.append([m.string, int(m.mod_position), mt, model_counts(model), score])
-        df = nm.motif.MotifSearchResult(pl.DataFrame(data))
-        stages = {}
-        dup = False
-        a = nm.postprocess.remove_noisy_motifs(df)
-        stages["noise"] = _table(a)
-        b = fmb.merge_motifs_in_df(a, pile, seqs, {"bin0": list(seqs)}).unique()
-        stages["merge"] = _table(b)
-        dup |= _has_duplicate_motifs(b)
-        c = nm.postprocess.remove_sub_motifs(b).unique()
-        stages["sub"] = _table(c)
-        dup |= _has_duplicate_motifs(c)
-        d = nm.postprocess.join_motif_complements(c).unique()
-        stages["complement"] = _table(d)
-        out["cases"].append({"name": name, "bin": bin_name, "mod_types": list(mts), "input": rec_in, "stages": stages,
-                             "a_stage_held_one_motif_twice": bool(dup)})
-        print(name, {k: len(v) for k, v in stages.items()})
+        # the stages carry the search's score along; any value does
+        out["cases"].append(_post_case(nm, cache, out, name, bin_name, mts, members, [2.0 + 0.25 * k for k in range(len(members))]))
     dump("g8_postprocess_glue.json", out)
+
+
+G13_SEEDS = (19, 38, 64, 625)    # post_ref_fuzz.py cases in which two merge clusters produce the SAME merged motif
+
+
+def g13(nm):
+    """Families in which a stage holds ONE MOTIF TWICE: merge_motifs_in_df gives every accepted cluster a row and a model of its own
+    (find_motifs_bin.py:1497-1504), `motifs.unique()` compares the Object `model` cells by identity and keeps both, remove_sub_motifs
+    removes all rows of a discarded motif, join_motif_complements pairs every row with every partner row (seed 38: 7 -> 9 rows)."""
+    import post_ref_fuzz as F
+    out = {"bins": {}, "cases": [], "stand_in": "tests/golden/refframe.py"}
+    cache = {}
+    for seed in G13_SEEDS:
+        bin_name, mts, members, scores = F.case_of(nm, seed, cache)
+        case = _post_case(nm, cache, out, f"post_ref_fuzz_seed_{seed}", bin_name, mts, members, scores)
+        assert case["a_stage_held_one_motif_twice"], seed
+        out["cases"].append(case)
+    dump("g13_duplicate_merged_motifs.json", out)
 
 
 def g9(nm):
@@ -614,6 +636,6 @@ if __name__ == "__main__":
         os.environ["PYTHONHASHSEED"] = "0"
         os.execv(sys.executable, [sys.executable] + sys.argv)
     nm = refstub.load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w](nm)

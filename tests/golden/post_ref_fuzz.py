@@ -89,9 +89,8 @@ def family(rng, planted, mts):
     return uniq
 
 
-def one(nm, seed, cache):
-    from nanomotif.model import BetaBernoulliModel
-    fmb, pl = nm.find_motifs_bin, sys.modules["polars"]
+def case_of(nm, seed, cache):
+    """(bin, mod types of the frame, [(core, pos, mod type)], [score]) of fuzz case ``seed`` — gen_golden.py's g13 records two of them."""
     rng = np.random.default_rng(seed)
     bin_name = list(G.POST_BINS)[int(rng.integers(len(G.POST_BINS)))]
     kw0, _ = G.POST_BINS[bin_name]
@@ -101,6 +100,14 @@ def one(nm, seed, cache):
     kw, mg, pile, seqs = cache[(bin_name, mts)]
     planted = [tuple(x) for b in mg.bin_motifs.values() for x in b]
     members = family(rng, planted, mts)
+    return bin_name, mts, members, [float(np.round(1.0 + 3.0 * rng.random(), 3)) for _ in members]
+
+
+def one(nm, seed, cache):
+    from nanomotif.model import BetaBernoulliModel
+    fmb, pl = nm.find_motifs_bin, sys.modules["polars"]
+    bin_name, mts, members, scores = case_of(nm, seed, cache)
+    kw, mg, pile, seqs = cache[(bin_name, mts)]
     if not members:
         return "no members"
     data = {"reference": [], "motif": [], "mod_type": [], "mod_position": [], "model": [], "score": []}
@@ -108,7 +115,7 @@ def one(nm, seed, cache):
     for k, (core, pos, mt) in enumerate(members):
         m = G._wide(nm, core, pos)
         model = fmb.motif_model_bin(pile.filter(pl.col("mod_type") == mt), seqs, m, BetaBernoulliModel(), 0.3, 0.7)
-        score = float(np.round(1.0 + 3.0 * rng.random(), 3))
+        score = scores[k]
         for key, v in zip(data, ("bin0", m.string, mt, int(m.mod_position), model, score)):
             data[key].append(v)
         rec_in.append([m.string, int(m.mod_position), mt, G.model_counts(model), score])

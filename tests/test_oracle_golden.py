@@ -445,6 +445,26 @@ def test_g8_postprocess_glue_equals_the_reference_functions():
     assert fired == {"noise", "degenerate merge", "rejected merge", "sub-motif", "complement join changes the row count"}
 
 
+def test_g13_duplicate_merged_motifs_follow_the_reference():
+    """g13 (round 5): families in which two merge clusters produce the SAME merged motif.  merge_motifs_in_df gives each accepted
+    cluster its own row and model (find_motifs_bin.py:1497-1504); `motifs.unique()` (:570, 579, 588) compares the Object `model`
+    cells by identity and keeps both; remove_sub_motifs drops every row of a discarded motif; join_motif_complements pairs every
+    row with every partner row, so a duplicated palindrome comes out four times (seed 625: 3 rows -> 5)."""
+    g = load_golden("g13_duplicate_merged_motifs.json")
+    assert len(g["cases"]) >= 4
+    grew = 0
+    for case in g["cases"]:
+        assert case["a_stage_held_one_motif_twice"]
+        keys = [(r[0], r[2], r[1], r[3]) for r in case["stages"]["merge"]]
+        assert len(set(keys)) < len(keys)
+        piles, seqs, rows = g8_case_inputs(g, case)
+        stages = oracle_post_stages(rows, piles, seqs)
+        for name in ("noise", "merge", "sub", "complement"):
+            assert_tables_equal(post_table(stages[name]), case["stages"][name], (case["name"], name))
+        grew += len(case["stages"]["complement"]) > len(case["stages"]["sub"])
+    assert grew >= 2
+
+
 def _g11_cases():
     return sorted(load_golden("g11_random_search.json"), key=lambda k: int(k.split("_")[1]))
 

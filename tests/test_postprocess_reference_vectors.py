@@ -65,8 +65,11 @@ def both_implementations(keys, rows_per_task, score_fn):
     return py, native, py_final, native_final
 
 
-def test_g8_both_implementations_equal_the_reference_stage_tables():
-    g = load_golden("g8_postprocess_glue.json")
+@pytest.mark.parametrize("fixture", ["g8_postprocess_glue.json", "g13_duplicate_merged_motifs.json"])
+def test_g8_g13_both_implementations_equal_the_reference_stage_tables(fixture):
+    """g8: twelve families firing every branch; g13 (round 5): families in which two merge clusters produce the SAME merged motif —
+    the reference keeps one row per cluster (unique() compares the Object `model` cells by identity) and so do both implementations."""
+    g = load_golden(fixture)
     for case in g["cases"]:
         mg = synth.make_metagenome(spec_from_json(g["bins"][case["bin"]]))
         piles, seqs = {}, None
