@@ -674,6 +674,10 @@ def main():
                                  "motif_rows": int(sum(p[6] for p in per)), "planted": int(sum(p[7] for p in per)),
                                  "planted_recovered": int(sum(p[8] for p in per)),
                                  "gpu_busy_over_wall": max(p[3] for p in per) / max(p[0] for p in per),
+                                 # rounds = scoring batches (search + post-processing); the search's lock-step loop ran search_iterations times;
+                                 # children whose counts came with their parent's window reply (speculation on the device) / asked for after all
+                                 "search_iterations": t.get("search_iterations"), "speculation_hits": t.get("speculation_hits"),
+                                 "speculation_misses": t.get("speculation_misses"),
                                  "gpu_busy_covers": "every device phase of the run (pre-filter kernels, window gathers and batches, background counts, scoring launches), HIP events on the ctx stream",
                                  "not_in_wall_s": {"generate_s": t.get("generate_s"), "allocator_prewarm_s": t.get("allocator_prewarm_s")},
                                  "timings_rank0": t}

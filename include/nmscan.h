@@ -374,6 +374,14 @@ int nm_search_run_custom(uint32_t n_tasks, const nm_search_params *params, const
                          nm_search_result **out);
 /* stats[3] = scoring batches (lock-step rounds), candidates scored, window requests */
 int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_best, uint64_t stats[3]);
+/* Speculative children (round 5, nm_search_run on one GPU with windows of at most 63 columns; NM_SEARCH_NO_SPEC=1 turns it off): the
+ * window batch of a round also picks, ON THE DEVICE, the column of the largest KL divergence of every PSSM request and scores the
+ * children there in the same chain of launches (find_motifs_bin.py:957-1023, :1116-1135: what the host would ask for in its next
+ * round).  The host still makes the reference's pick itself, in float64 the way scipy does, and takes a speculative count only
+ * for the very motif it was computed for — results are identical with and without, a differing pick costs the round it would
+ * have cost anyway.  stats[3] = lock-step iterations of the run, children answered by the speculation, children asked for after
+ * all. */
+int nm_search_result_speculation(const nm_search_result *res, uint64_t stats[3]);
 /* offsets are [n_tasks + 1]; any of the column pointers may be NULL */
 int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uint64_t *edge_off, uint64_t *best_off, uint8_t *task_none,
                             char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,
@@ -555,6 +563,7 @@ int nm_fasta_close(nm_fasta *fa);
  * A gzip file is refused (NM_EINVAL "compressed input ...": use nm_fasta_open).
  *   nm_fastadev_shape            records, bases; times = {seconds in total, seconds a reader thread spent in pread}
  *   nm_fastadev_record           name, offset into the packed sequence, length
+ *   nm_fastadev_table            all records at once: the names back to back, each followed by a NUL, and offsets[n_records + 1]
  *   nm_fastadev_sequence_device  DEVICE pointer to the packed upper-case sequence (nm_device_read copies from it)
  *   nm_upload_contigs_fasta      nm_upload_contigs_device for contig i = record[i] of the parsed file: any subset, any order,
  *                                a record more than once (a contig listed under several bins); no host copy of the sequence
@@ -563,6 +572,7 @@ typedef struct nm_fastadev nm_fastadev;
 int nm_fasta_parse_device(nm_ctx *ctx, const char *path, uint32_t threads, nm_fastadev **out);
 int nm_fastadev_shape(nm_fastadev *fa, uint32_t *n_records, uint64_t *total_bp, double times[2]);
 int nm_fastadev_record(nm_fastadev *fa, uint32_t i, const char **name, uint64_t *offset, uint64_t *length);
+int nm_fastadev_table(nm_fastadev *fa, const char **names, uint64_t *names_bytes, const uint64_t **offsets);
 int nm_fastadev_sequence_device(nm_fastadev *fa, const uint8_t **d_seq_upper);
 int nm_upload_contigs_fasta(nm_ctx *ctx, nm_fastadev *fa, uint32_t n_contigs, const uint32_t *record, const uint32_t *bin_id, uint32_t n_bins);
 int nm_fastadev_close(nm_fastadev *fa);

@@ -395,9 +395,10 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     std::unordered_map<std::string, uint32_t> want;
     for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
     std::vector<nmbgzf::Region> merged;
+    std::vector<uint64_t> block_starts;
     uint64_t found_in_index = 0;
     {
-        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(idx.data), idx.size, want, &merged, &found_in_index);
+        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(idx.data), idx.size, want, &merged, &found_in_index, &block_starts);
         if (!what.empty()) return nm_set_error(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
     }
     Buffer file;
@@ -410,7 +411,7 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     std::vector<nmbgzf::Piece> blocks;
     uint64_t text_size = 0, inflated = 0;
     {
-        const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated);
+        const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated, &block_starts, threads);
         if (!what.empty()) return nm_set_error(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     Buffer text;

@@ -844,16 +844,18 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
     std::unordered_map<std::string, uint32_t> want;
     for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
     std::vector<nmbgzf::Region> merged;
+    std::vector<uint64_t> block_starts;
     uint64_t found = 0, inflated = 0;
     {
-        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), want, &merged, &found);
+        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), want, &merged, &found, &block_starts);
         if (!what.empty()) return fail(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
     }
     TextSource src;
     int rc = map_file(path, &src);
     if (rc) return rc;
     {
-        const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated);
+        const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated, &block_starts,
+                                                       threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
         if (!what.empty()) return fail(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     src.bgzf = true;
@@ -896,7 +898,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     const bool dev_inflate = src.bgzf && getenv("NM_BED_HOST_INFLATE") == nullptr;
     // device inflate: slabs of whole BLOCKS (up to 3 GiB of text: line offsets are 32-bit), a line that straddles two slabs is
     // carried over on the device
-    constexpr uint64_t INF_SLAB_TEXT = 3ull << 30, CARRY_CAP = 1ull << 20;
+    constexpr uint64_t INF_SLAB_TEXT = 3ull << 29, CARRY_CAP = 1ull << 20;      // 1.5 GiB of text per slab, two slabs in flight
     struct InfSlab { size_t first, last; uint64_t text, comp; };
     std::vector<InfSlab> inf_slabs;
     uint64_t inf_text_cap = 0, inf_comp_cap = 0;
@@ -1084,11 +1086,17 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     // ---- bgzip, inflated on the device: per slab the compressed bytes of its blocks (packed, through the pinned ring) ->
     // bed_inflate_kernel -> the same line / field kernels
     if (dev_inflate && !inf_slabs.empty()) {
+        // A PIPELINE of three stages over the slabs (round 5; the stages ran one after the other before: 0.098 s per 3 GiB slab, of
+        // which the inflate kernel is 0.065): (1) host: a slab's compressed bytes -> pinned chunks -> device (copy stream);
+        // (2) inflate stream: bed_inflate_kernel + CRC-32 + end of the last whole line, into one of TWO text buffers; (3) ctx stream:
+        // the line / field kernels.  Slab k+1 is copied and its inflate queued while slab k inflates; slab k is parsed while
+        // slab k+1 inflates (the inflate lanes wait on memory most of the time: the parse kernels run beside them).  Everything a
+        // slab owns on the device exists twice; a slab is half as large as before, so the memory is what it was.
         constexpr uint64_t CHUNK = SLAB_BYTES;                        // compressed bytes per pinned buffer
-        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp = nullptr, *d_scratch = nullptr;
-        InfPiece *d_pieces = nullptr;
+        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp[2] = {nullptr, nullptr}, *d_scratch[2] = {nullptr, nullptr};
+        InfPiece *d_pieces[2] = {nullptr, nullptr};
         unsigned int *d_status = nullptr;
-        unsigned long long *d_tail = nullptr;
+        unsigned long long *d_tail = nullptr;                         // [2]
         size_t max_pieces = 0, max_partial = 0;
         for (const InfSlab &sl : inf_slabs) {
             max_pieces = std::max(max_pieces, sl.last - sl.first);
@@ -1096,100 +1104,138 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             for (size_t i = sl.first; i < sl.last; ++i) np += src.pieces[i].skip != 0 || src.pieces[i].take != src.pieces[i].out_len;
             max_partial = std::max(max_partial, np);
         }
-        // ONE text buffer: everything of a slab — inflate, line / field kernels, the copy of its unfinished last line to the front —
-        // is ordered on the ctx stream before the next slab's inflate writes (device memory that other processes used before is
-        // scrubbed by the driver when it is allocated: what this path asks for is what it pays for)
-        HIP_TRY(tmp_alloc((void **)&d_text[0], slab_cap + 128));
-        d_text[1] = d_text[0];
-        HIP_TRY(tmp_alloc((void **)&d_comp, inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
-        HIP_TRY(tmp_alloc((void **)&d_scratch, std::max<size_t>(max_partial, 1) << 16));
-        HIP_TRY(tmp_alloc((void **)&d_pieces, max_pieces * sizeof(InfPiece)));
+        const int n_buf = inf_slabs.size() > 1 ? 2 : 1;
+        for (int b = 0; b < 2; ++b) {
+            if (b >= n_buf) { d_text[b] = d_text[0]; d_comp[b] = d_comp[0]; d_scratch[b] = d_scratch[0]; d_pieces[b] = d_pieces[0]; continue; }
+            HIP_TRY(tmp_alloc((void **)&d_text[b], slab_cap + 128));
+            HIP_TRY(tmp_alloc((void **)&d_comp[b], inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
+            HIP_TRY(tmp_alloc((void **)&d_scratch[b], std::max<size_t>(max_partial, 1) << 16));
+            HIP_TRY(tmp_alloc((void **)&d_pieces[b], max_pieces * sizeof(InfPiece)));
+        }
         HIP_TRY(tmp_alloc((void **)&d_status, 4));
-        HIP_TRY(tmp_alloc((void **)&d_tail, 8));
+        HIP_TRY(tmp_alloc((void **)&d_tail, 16));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         uint8_t *h_chunk[2] = {nullptr, nullptr};
-        hipEvent_t chunk_done[2] = {nullptr, nullptr};
-        struct Pinned { uint8_t **h; hipEvent_t *e; hipStream_t &cs; ~Pinned() {
+        hipEvent_t chunk_done[2] = {nullptr, nullptr}, inflated[2] = {nullptr, nullptr}, parsed_ev[2] = {nullptr, nullptr};
+        hipStream_t inf_stream = nullptr;
+        struct Pinned { uint8_t **h; hipEvent_t *e, *e2, *e3; hipStream_t &cs, &is; ~Pinned() {
             if (cs) (void)hipStreamSynchronize(cs);
-            for (int i = 0; i < 2; ++i) { if (h[i]) (void)hipHostFree(h[i]); if (e[i]) (void)hipEventDestroy(e[i]); }
-        } } pinned{h_chunk, chunk_done, copy_stream};
+            if (is) (void)hipStreamSynchronize(is);
+            for (int i = 0; i < 2; ++i) {
+                if (h[i]) (void)hipHostFree(h[i]);
+                if (e[i]) (void)hipEventDestroy(e[i]);
+                if (e2[i]) (void)hipEventDestroy(e2[i]);
+                if (e3[i]) (void)hipEventDestroy(e3[i]);
+            }
+            if (is) (void)hipStreamDestroy(is);
+        } } pinned{h_chunk, chunk_done, inflated, parsed_ev, copy_stream, inf_stream};
         if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&inf_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&inflated[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&parsed_ev[i], hipEventDisableTiming));
         }
         const bool timing = getenv("NM_BED_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
-        std::vector<InfPiece> hp;
+        std::vector<InfPiece> hp[2];
         const CrcConsts crc_k = crc_consts();
 #ifdef NM_BED_PROBES                                                    // (timing probe builds only: what the check costs)
         const bool check_crc = getenv("NM_BED_NO_CRC") == nullptr;
 #else
         constexpr bool check_crc = true;                                // the shipped library always checks every member's CRC-32
 #endif
-        uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
         size_t n_chunk = 0;
         const unsigned nt = std::max(1u, threads - 1);
-        for (size_t si = 0; si < inf_slabs.size(); ++si) {
+        unsigned long long end_of_lines_h[2] = {0, 0};
+        unsigned int status_h[2] = {0, 0};
+        double t_copy_slab[2] = {0, 0};
+        // stages (1) and (2) of slab si: everything it needs goes to the device, its inflate is queued
+        auto stage_slab = [&](size_t si) -> int {
             const InfSlab &sl = inf_slabs[si];
-            uint8_t *text = d_text[si % 2];
+            const int b = (int)(si % n_buf);
+            uint8_t *text = d_text[b];
             // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
-            hp.clear();
+            std::vector<InfPiece> &pieces = hp[b];
+            pieces.clear();
             uint64_t coff = 0, toff = CARRY_CAP, poff = 0;
             for (size_t i = sl.first; i < sl.last; ++i) {
                 const nmbgzf::Piece &pp = src.pieces[i];
                 const bool partial = pp.skip != 0 || pp.take != pp.out_len;
-                hp.push_back({coff, (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff, pp.crc, 0u});
+                pieces.push_back({coff, (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff, pp.crc, 0u});
                 coff += pp.in_len;
                 toff += pp.take;
                 if (partial) poff += 1u << 16;
             }
-            HIP_TRY(hipMemcpyAsync(d_pieces, hp.data(), hp.size() * sizeof(InfPiece), hipMemcpyHostToDevice, c->stream));
+            // (d_pieces[b], d_comp[b], d_scratch[b] were last read by the inflate of slab si - 2: the host has waited for it)
+            HIP_TRY(hipMemcpyAsync(d_pieces[b], pieces.data(), pieces.size() * sizeof(InfPiece), hipMemcpyHostToDevice, copy_stream));
             // compressed bytes: chunks of whole pieces through two pinned buffers, memcpy on several threads
-            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            for (size_t a = 0; a < hp.size();) {
+            const double t0 = now();
+            for (size_t a = 0; a < pieces.size();) {
                 size_t e = a;
-                while (e < hp.size() && (e == a || hp[e].in_off + hp[e].in_len - hp[a].in_off <= CHUNK)) ++e;
-                const uint64_t lo = hp[a].in_off, bytes = hp[e - 1].in_off + hp[e - 1].in_len - lo;
+                while (e < pieces.size() && (e == a || pieces[e].in_off + pieces[e].in_len - pieces[a].in_off <= CHUNK)) ++e;
+                const uint64_t lo = pieces[a].in_off, bytes = pieces[e - 1].in_off + pieces[e - 1].in_len - lo;
                 uint8_t *dst = h_chunk[n_chunk % 2];
                 if (n_chunk >= 2) HIP_TRY(hipEventSynchronize(chunk_done[n_chunk % 2]));
                 std::vector<std::thread> pool;
                 for (unsigned t = 0; t < nt; ++t)
                     pool.emplace_back([&, t] {
-                        for (size_t i = a + t; i < e; i += nt) memcpy(dst + (hp[i].in_off - lo), src.z + src.pieces[sl.first + i].in_off, hp[i].in_len);
+                        for (size_t i = a + t; i < e; i += nt) memcpy(dst + (pieces[i].in_off - lo), src.z + src.pieces[sl.first + i].in_off, pieces[i].in_len);
                     });
                 for (auto &th : pool) th.join();
-                HIP_TRY(hipMemcpyAsync(d_comp + lo, dst, bytes, hipMemcpyHostToDevice, copy_stream));
+                HIP_TRY(hipMemcpyAsync(d_comp[b] + lo, dst, bytes, hipMemcpyHostToDevice, copy_stream));
                 HIP_TRY(hipEventRecord(chunk_done[n_chunk % 2], copy_stream));
                 n_chunk += 1;
                 a = e;
             }
-            const double t_copied = now();
-            t_read += t_copied - t0;
-            HIP_TRY(hipStreamWaitEvent(c->stream, chunk_done[(n_chunk - 1) % 2], 0));
-            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((hp.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, c->stream, d_comp, d_pieces,
-                               (unsigned int)hp.size(), text, d_scratch, d_status);
+            t_copy_slab[b] = now() - t0;
+            t_read += t_copy_slab[b];
+            HIP_TRY(hipStreamWaitEvent(inf_stream, chunk_done[(n_chunk - 1) % 2], 0));
+            if (si >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(inf_stream, parsed_ev[b], 0));      // the text buffer has been parsed
+            else if (si == 0) HIP_TRY(hipStreamSynchronize(c->stream));                             // (allocations, clears above)
+            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, inf_stream, d_comp[b],
+                               d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status);
             HIP_TRY(hipGetLastError());
             if (check_crc) {
-                hipLaunchKernelGGL(bed_crc_kernel, dim3((unsigned)((hp.size() + 3) / 4)), dim3(256), 0, c->stream, d_pieces, (unsigned int)hp.size(), text, d_scratch,
-                                   crc_k, d_status);
+                hipLaunchKernelGGL(bed_crc_kernel, dim3((unsigned)((pieces.size() + 3) / 4)), dim3(256), 0, inf_stream, d_pieces[b], (unsigned int)pieces.size(), text,
+                                   d_scratch[b], crc_k, d_status);
                 HIP_TRY(hipGetLastError());
             }
             // where the last whole line ends; what follows it is carried into the next slab
-            const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
-            const bool last_slab = si + 1 == inf_slabs.size();
-            unsigned long long end_of_lines = total;
-            unsigned int status = 0;
-            if (!last_slab) {
-                hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, c->stream, text, total, CARRY_CAP, d_tail);
+            const uint64_t total = CARRY_CAP + sl.text;
+            end_of_lines_h[b] = total;
+            if (si + 1 != inf_slabs.size()) {
+                hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, inf_stream, text, total, CARRY_CAP, d_tail + b);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(&end_of_lines, d_tail, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(&end_of_lines_h[b], d_tail + b, 8, hipMemcpyDeviceToHost, inf_stream));
             }
-            HIP_TRY(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpyAsync(&status_h[b], d_status, 4, hipMemcpyDeviceToHost, inf_stream));
+            HIP_TRY(hipEventRecord(inflated[b], inf_stream));
+            return NM_OK;
+        };
+        uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
+        int rc0 = stage_slab(0);
+        if (rc0) return rc0;
+        for (size_t si = 0; si < inf_slabs.size(); ++si) {
+            const InfSlab &sl = inf_slabs[si];
+            const int bi = (int)(si % n_buf);
+            uint8_t *text = d_text[bi];
+            const bool last_slab = si + 1 == inf_slabs.size();
+            const double t_staged = now();
+            if (!last_slab && n_buf == 2) {                             // the next slab travels and queues while this one inflates
+                rc0 = stage_slab(si + 1);
+                if (rc0) return rc0;
+            }
+            const double t_wait = now();
+            HIP_TRY(hipEventSynchronize(inflated[bi]));
             const double t_inflated = now();
-            b->t_inflate += t_inflated - t_copied;
+            b->t_inflate += t_inflated - t_wait;
+            const unsigned int status = status_h[bi];
+            const unsigned long long end_of_lines = end_of_lines_h[bi];
+            const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
             if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
             if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
                 return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16));
@@ -1199,13 +1245,16 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             const uint64_t text_base = src.pieces[sl.first].text_off - carry - (begin - aligned);
             int rc = parse_text(text + aligned, end_of_lines - aligned, text_base, si == 0 && inf_slabs.size() > 1 ? (double)n / (double)sl.text : 0.0, [] {});
             if (rc) return rc;
-            if (timing) {
-                (void)hipStreamSynchronize(c->stream);
-                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: copies %.3f s, + inflate %.3f s, + parse %.3f s\n", si, hp.size(), sl.text / 1e9,
-                        t_copied - t0, t_inflated - t_copied, now() - t_inflated);
-            }
             carry = total - end_of_lines;
-            if (!last_slab && carry) HIP_TRY(hipMemcpyAsync(d_text[(si + 1) % 2] + CARRY_CAP - carry, text + end_of_lines, carry, hipMemcpyDeviceToDevice, c->stream));
+            if (!last_slab && carry) HIP_TRY(hipMemcpyAsync(d_text[(si + 1) % n_buf] + CARRY_CAP - carry, text + end_of_lines, carry, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipEventRecord(parsed_ev[bi], c->stream));
+            if (!last_slab && n_buf == 1) {                             // (one buffer: nothing overlaps)
+                rc0 = stage_slab(si + 1);
+                if (rc0) return rc0;
+            }
+            if (timing)
+                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: next slab staged in %.3f s (copies %.3f), waited %.3f s for the inflate, parse queued in %.3f s\n",
+                        si, hp[bi].size(), sl.text / 1e9, t_wait - t_staged, t_copy_slab[(si + 1) % n_buf], t_inflated - t_wait, now() - t_inflated);
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }

@@ -35,6 +35,7 @@ using namespace nmdetail;
 struct nm_fastadev {
     nm_ctx *ctx = nullptr;
     std::vector<std::string> names;
+    std::string names_blob;                   // the names, each followed by a NUL (nm_fastadev_table)
     std::vector<uint64_t> offset;             // n + 1: where each record's bases start in d_seq
     uint8_t *d_seq = nullptr;                 // every record's bases, upper-cased, back to back (file order)
     double seconds = 0, seconds_reading = 0;
@@ -272,6 +273,7 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     if (!c || !path || !out) return fail(NM_EINVAL, "NULL argument");
     *out = nullptr;
     const double t_begin = now_s();
+    const bool timing = getenv("NM_FASTA_TIMING") != nullptr;     // where the wall time of the call goes (stderr)
     if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(NM_EINVAL, "cannot open assembly '%s'", path);
@@ -325,6 +327,7 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(hipHostMalloc((void **)&h_ring[i], slab_cap, hipHostMallocDefault));
     for (int i = 0; i < RING; ++i) HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    const double t_alloc = now_s();
     std::atomic<bool> read_failed{false};
     std::mutex mu;
     std::condition_variable cv;
@@ -380,6 +383,7 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     }
     HIP_TRY(hipStreamWaitEvent(c->stream, h2d_done[(n_slabs - 1) % RING], 0));
     f->seconds_reading = t_read;
+    const double t_copied = now_s();
     // ---- records
     busy_begin(c);
     unsigned long long *d_tile_seq = nullptr, *d_tile_cum = nullptr;
@@ -467,6 +471,9 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
                          : fail(NM_EINVAL, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", f->names.back().c_str());
     }
     f->seconds = now_s() - t_begin;
+    if (timing)
+        fprintf(stderr, "[fasta] %.2f GB, %u records: buffers %.3f s, file -> device %.3f s (a reader spent %.3f s in pread), kernels + tables %.3f s\n", n / 1e9, n_rec,
+                t_alloc - t_begin, t_copied - t_alloc, t_read, now_s() - t_copied);
     guard.keep = true;
     *out = f;
     return NM_OK;
@@ -485,6 +492,16 @@ int nm_fastadev_record(nm_fastadev *f, uint32_t i, const char **name, uint64_t *
     *name = f->names[i].c_str();
     *offset = f->offset[i];
     *length = f->offset[i + 1] - f->offset[i];
+    return NM_OK;
+}
+
+int nm_fastadev_table(nm_fastadev *f, const char **names, uint64_t *names_bytes, const uint64_t **offsets) {
+    if (!f || !names || !names_bytes || !offsets) return fail(NM_EINVAL, "NULL argument");
+    if (f->names_blob.empty())
+        for (const std::string &nm : f->names) { f->names_blob.append(nm); f->names_blob.push_back('\0'); }
+    *names = f->names_blob.data();
+    *names_bytes = f->names_blob.size();
+    *offsets = f->offset.data();
     return NM_OK;
 }
 

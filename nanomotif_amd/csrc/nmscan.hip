@@ -399,13 +399,6 @@ __global__ NM_SCORE_BOUNDS void score_kernel(ScoreArgs a) {
     score_piece<K>(a, sg, stp, is_c, lds_acc, lane, wave);
 }
 
-// One candidate record as the host stages it (sorted by mod-type slot, then bin).
-struct CandRec {
-    uint32_t mask_off;   // into the staged mask bytes
-    uint32_t orig;       // caller's index of this candidate
-    uint8_t len, modpos, slot, pad;
-};
-
 // Compile the staged candidates into constraint programs ON THE DEVICE: one thread per candidate.  A literal is one
 // constraint on an is-X plane, a 3-set one on a valid-not-X plane, a 2-set two of those; the reverse strand takes
 // the complemented set at the negated offset (motif.py:260-266).  Program layout: [strand][word-group][plane] with
@@ -646,10 +639,14 @@ int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
     // nm_win_batch_w_begin) is never handed out: the next user would copy over — or, growing the pair, free — what
     // nm_*_end has yet to read.  At most two pairs are held at a time, so the walk always finds a free one.
     auto held = [&](int i) {
-        return (c->score_wait.open && c->score_wait.stage == &c->stage[i]) || (c->win_wait.open && c->win_wait.stage == &c->stage[i]);
+        for (int f = 0; f < NM_FLIGHTS; ++f)
+            if ((c->score_wait[f].open && c->score_wait[f].stage == &c->stage[i]) || (c->win_wait[f].open && c->win_wait[f].stage == &c->stage[i]) ||
+                (c->spec_wait[f].open && c->spec_wait[f].stage == &c->stage[i]))
+                return true;
+        return false;
     };
     int idx;
-    if (mode == 2) idx = NM_STAGE_RING;
+    if (mode >= 2) idx = NM_STAGE_RING + (mode - 2);
     else if (mode == 1) {
         idx = c->stage_next_deep;
         for (int tries = 0; tries < NM_STAGE_RING && held(idx); ++tries) idx = (idx + 1) % NM_STAGE_RING;
@@ -767,13 +764,15 @@ void launch_score(const ScoreArgs &a, uint32_t gx, const LaunchShape &sh, hipStr
 int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
                const uint8_t *cand_masks, unsigned long long *d_out, int64_t *h_out, const uint64_t *row_offset = nullptr,
-               bool defer = false) {
+               bool defer = false, const SpecSource *spec = nullptr, hipStream_t spec_stream = nullptr, int flight = 0) {
     // defer: host counts, collected later by nm_score_batch_end (the call returns with everything enqueued)
+    // spec: the motifs are written on the device (SpecSource, nmscan_internal.h); always deferred, noted in c->spec_wait, on spec_stream
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    nm_ctx::Waiting &wait_slot = spec ? c->spec_wait[flight] : c->score_wait[flight];
     if (defer) {
-        if (c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
-        c->score_wait = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+        if (wait_slot.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
+        wait_slot = nm_ctx::Waiting{nullptr, 0, nullptr, true};
     }
     if (n_cand == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -793,6 +792,14 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
             return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, slot);
         if (bin >= n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, bin, n_bins);
         if (c->bin_nchunks[bin] == 0) continue;         // not resident here: the rank that holds the bin validates it
+        if (spec) {                                      // motif unknown here: literal, compact, narrow by contract; mask_stride bytes each
+            mask_lo = 0;
+            mask_bytes = std::max<uint64_t>(mask_bytes, (uint64_t)(k + 1) * spec->mask_stride);
+            bucket[(size_t)slot * n_bins + bin + 1] += 1;
+            slot_used[slot] = true;
+            n_prog += 1;
+            continue;
+        }
         const uint32_t len = cand_len[k], mp = cand_modpos[k];
         if (len == 0 || len > NM_MAX_MOTIF_LEN) return fail(NM_ERANGE, "candidate %u: motif length %u outside 1..%d", k, len, NM_MAX_MOTIF_LEN);
         if (mp >= len) return fail(NM_EINVAL, "candidate %u: mod_position %u outside motif of length %u", k, mp, len);
@@ -862,7 +869,9 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     }
     const bool own_segments = n_prog && n_active_segs * 4 <= (size_t)c->n_segments * 3 && getenv("NM_ALL_SEGMENTS") == nullptr;
     const size_t off_segs = (off_rows + (per_contig ? (size_t)n_prog * 8 : 0) + 15) & ~(size_t)15;
-    const size_t total = own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
+    const size_t off_posof = ((own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_segs) + 15) & ~(size_t)15;     // spec: sorted position of candidate k
+    const size_t total = spec ? off_posof + (size_t)n_cand * 4
+                              : own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
     // host counts come back through the pinned half of the staging pair (a copy into pageable memory is staged by the
     // runtime and costs tens of microseconds more per round of the search); tables too large for that go directly
     const size_t out_bytes = (size_t)out_rows * 2 * sizeof(int64_t);
@@ -873,12 +882,12 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // scoring lane of this call (nm_set_score_lanes): asynchronous device-output batches take the lane of their staging
     // pair — a pair, its half of the program table and its stream are reused together; every other call runs on the
     // ctx stream after the second lane has drained
-    hipStream_t sst = c->stream;
-    const bool laned = c->score_lanes == 2 && d_out && !h_out;
-    if (!laned) {
+    hipStream_t sst = spec ? spec_stream : c->stream;
+    const bool laned = c->score_lanes == 2 && d_out && !h_out && !spec && !defer;
+    if (!laned && !spec) {
         rc = join_lanes(c);
         if (rc) return rc;
-    } else if ((c->cur_stage - c->stage) & 1) {
+    } else if (laned && ((c->cur_stage - c->stage) & 1)) {
         sst = c->lane_stream;
         c->lane_pending = true;
     }
@@ -893,7 +902,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     CandRec *h_rec = reinterpret_cast<CandRec *>(hs);
     uint32_t *h_orig = reinterpret_cast<uint32_t *>(hs + off_orig);
     uint4 *h_range = reinterpret_cast<uint4 *>(hs + off_range);
-    memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
+    if (!spec) memcpy(hs + off_masks, cand_masks + mask_lo, mask_bytes - mask_lo);
     memset(h_range, 0, range_bytes);
     if (own_segments) {
         uint4 *h_segs = reinterpret_cast<uint4 *>(hs + off_segs);
@@ -920,6 +929,12 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k];
         if (c->bin_nchunks[bin] == 0) continue;
         const uint32_t at = bucket[(size_t)slot * n_bins + bin]++;
+        if (spec) {
+            h_rec[at] = CandRec{k * spec->mask_stride, k, 0, 0, (uint8_t)slot, 0};
+            h_orig[at] = k;
+            reinterpret_cast<uint32_t *>(hs + off_posof)[k] = at;
+            continue;
+        }
         h_rec[at] = CandRec{(uint32_t)(cand_mask_offset[k] - mask_lo), k, cand_len[k], cand_modpos[k], (uint8_t)slot, 0};
         h_orig[at] = k;
         if (per_contig) reinterpret_cast<uint64_t *>(hs + off_rows)[at] = row_offset[k];
@@ -934,6 +949,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
         rc = join_lanes(c);
         if (rc) return rc;
         if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
@@ -950,6 +966,11 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     hipStream_t pst = inline_prep ? sst : c->copy_stream;
     HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, pst));
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
+    if (spec && n_prog) {
+        rc = spec->fill(pst, reinterpret_cast<CandRec *>(ds), reinterpret_cast<const uint32_t *>(ds + off_posof), ds + off_masks,
+                        reinterpret_cast<uint4 *>(ds + off_range), slot_to_active);
+        if (rc) return rc;
+    }
     if (n_prog) {
         if (cf && n_prog <= 2048 && n_entries <= 8192 && !c->opt_no_inline) {
             const size_t lds_bytes = (size_t)n_prog * pdw * 4 <= 48 * 1024 ? (size_t)n_prog * pdw * 4 : 0;
@@ -1061,7 +1082,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     c->last_compact = all_compact ? n_prog : 0;
     c->last_general = all_compact ? 0 : n_prog;
     if (defer) {
-        c->score_wait = nm_ctx::Waiting{hs + off_counts, out_bytes, c->cur_stage, true};
+        wait_slot = nm_ctx::Waiting{hs + off_counts, out_bytes, c->cur_stage, true};
     } else if (via_stage) {
         HIP_TRY(hipEventSynchronize(c->cur_stage->busy));
         memcpy(h_out, hs + off_counts, out_bytes);
@@ -1195,6 +1216,12 @@ int nm_ctx_destroy(nm_ctx *c) {
     }
     if (c->d_counts) (void)nmdetail::dev_free(c->d_counts);
     if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
+    if (c->d_spec_bg) (void)nmdetail::dev_free(c->d_spec_bg);
+    for (int f = 0; f < NM_FLIGHTS; ++f) {
+        if (c->d_spec_counts[f]) (void)nmdetail::dev_free(c->d_spec_counts[f]);
+        if (c->d_flight_counts[f]) (void)nmdetail::dev_free(c->d_flight_counts[f]);
+    }
+    if (c->flight_stream) (void)hipStreamDestroy(c->flight_stream);
     if (c->d_win_planes) (void)nmdetail::dev_free(c->d_win_planes);
     if (c->d_win_alive) (void)nmdetail::dev_free(c->d_win_alive);
     if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
@@ -1460,6 +1487,53 @@ int nm_upload_contigs_device(nm_ctx *c, uint32_t n_contigs, const uint64_t *offs
 
 }  // extern "C"
 
+// the count table of a deferred batch of a flight: grown on demand behind the stream that may still write the old one
+static int flight_table(nm_ctx *c, unsigned long long **table, size_t *cap, size_t rows, hipStream_t st) {
+    if (*cap >= rows) return NM_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*table) (void)nmdetail::dev_free(*table);
+    *table = nullptr;
+    *cap = 0;
+    HIP_TRY(nmdetail::dev_malloc(table, rows * 2 * sizeof(unsigned long long) * 2));
+    *cap = rows * 2;
+    return NM_OK;
+}
+
+int nmdetail::score_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const SpecSource &spec,
+                                     hipStream_t st) {
+    if (n_cand && (!cand_bin || !cand_mod_slot)) return fail(NM_EINVAL, "NULL argument");
+    int rc = flight_table(c, &c->d_spec_counts[flight], &c->spec_counts_cap[flight], n_cand, st);
+    if (rc) return rc;
+    rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, nullptr, nullptr, nullptr, nullptr, c->d_spec_counts[flight], nullptr, nullptr, true, &spec, st, flight);
+    if (rc) c->spec_wait[flight].open = false;
+    return rc;
+}
+
+int nmdetail::score_batch_flight_begin(nm_ctx *c, int flight, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const uint8_t *cand_len,
+                                       const uint8_t *cand_modpos, const uint32_t *cand_mask_offset, const uint8_t *cand_masks) {
+    if (!c || flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
+    if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks)) return fail(NM_EINVAL, "NULL argument");
+    if (c->score_wait[flight].open) return fail(NM_ESTATE, "score batch: the previous batch of the flight has not been collected");
+    int rc = flight_table(c, &c->d_flight_counts[flight], &c->flight_counts_cap[flight], n_cand, c->stream);
+    if (rc) return rc;
+    rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, c->d_flight_counts[flight], nullptr, nullptr, true,
+                    nullptr, nullptr, flight);
+    if (rc) c->score_wait[flight].open = false;
+    return rc;
+}
+
+int nmdetail::score_batch_flight_end(nm_ctx *c, int flight, int64_t *out_counts) {
+    if (!c || flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
+    if (!c->score_wait[flight].open) return fail(NM_ESTATE, "score batch end without begin");
+    const nm_ctx::Waiting w = c->score_wait[flight];
+    c->score_wait[flight].open = false;
+    if (w.bytes == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(w.stage->busy));
+    if (out_counts) memcpy(out_counts, w.h, w.bytes);           // NULL: the batch is dropped
+    return NM_OK;
+}
+
 // nmfasta.hip: the contigs picked out of a device-resident packed sequence (any subset, any order, a record more than once)
 int nmdetail::upload_contigs_gather(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint64_t *src_off, const uint32_t *bin_id,
                                     uint32_t n_bins, const uint8_t *d_seq_ascii) {
@@ -1495,17 +1569,17 @@ int nm_score_batch_begin(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, c
                          const uint8_t *cand_masks) {
     if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks))
         return fail(NM_EINVAL, "NULL argument");
-    if (c && c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
+    if (c && c->score_wait[0].open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
     const int rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, nullptr, nullptr, true);
-    if (rc && c) c->score_wait.open = false;         // (a batch that failed half way is not open)
+    if (rc && c) c->score_wait[0].open = false;      // (a batch that failed half way is not open)
     return rc;
 }
 
 int nm_score_batch_end(nm_ctx *c, int64_t *out_counts) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
-    if (!c->score_wait.open) return fail(NM_ESTATE, "nm_score_batch_end without nm_score_batch_begin");
-    const nm_ctx::Waiting w = c->score_wait;
-    c->score_wait.open = false;
+    if (!c->score_wait[0].open) return fail(NM_ESTATE, "nm_score_batch_end without nm_score_batch_begin");
+    const nm_ctx::Waiting w = c->score_wait[0];
+    c->score_wait[0].open = false;
     if (w.bytes == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(w.stage->busy));

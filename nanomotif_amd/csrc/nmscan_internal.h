@@ -8,11 +8,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <vector>
 
 #include "../../include/nmscan.h"
+#include "nmspec.h"
 
 // error sink shared by all translation units (defined in nmscan.hip; the text is what nm_last_error() returns)
 int nm_set_error(int code, const char *fmt, ...);
@@ -59,6 +61,13 @@ struct StatePlanes {
     const uint32_t *MP, *UP, *MM, *UM;   // general
 };
 
+// One candidate record as the host stages it (sorted by mod-type slot, then bin).
+struct CandRec {
+    uint32_t mask_off;   // into the staged mask bytes
+    uint32_t orig;       // caller's index of this candidate
+    uint8_t len, modpos, slot, pad;
+};
+
 struct WinTask {
     uint64_t plane_off;     // into the plane pool (words): [col][5][nw]
     uint64_t alive_off;     // into the alive pool (words): [nw]
@@ -96,7 +105,9 @@ struct ReadStats {
 // the upload and the compile of batch k+1 ... k+3 run while batch k is scored — on a small shard of a multi-GPU run that
 // chain (~85 us) is as long as the scoring kernel itself, two pairs would hide only one kernel's worth of it.
 #define NM_STAGE_RING 4
-#define NM_STAGE_SLOTS (NM_STAGE_RING + 1)     /* + the pair of the asynchronous window batch (nm_win_batch_w_begin) */
+#define NM_FLIGHTS 2                           /* batches of one kind that may be begun and not yet collected: the native search keeps two
+                                                  groups of tasks in flight, one travelling while the other is on the host (nmsearch.cpp) */
+#define NM_STAGE_SLOTS (NM_STAGE_RING + NM_FLIGHTS)   /* + the pairs of the asynchronous window batches (nm_win_batch_w_begin) */
 
 struct nm_ctx {
     int device = 0;
@@ -168,7 +179,13 @@ struct nm_ctx {
         size_t bytes = 0;
         Stage *stage = nullptr;
         bool open = false;
-    } score_wait, win_wait;
+    } score_wait[NM_FLIGHTS], win_wait[NM_FLIGHTS], spec_wait[NM_FLIGHTS];   // spec_wait: the speculative child scores riding on a window batch
+    hipStream_t flight_stream = nullptr;           // window batches of flight 1 (flight 0: copy_stream)
+    // speculative child scoring of the search: the tasks' background PSSMs [task][4][W] (doubles, rows A T G C) and the count table
+    double *d_spec_bg = nullptr;
+    uint32_t spec_tasks = 0, spec_width = 0;
+    unsigned long long *d_spec_counts[NM_FLIGHTS] = {}, *d_flight_counts[NM_FLIGHTS] = {};   // count tables of the deferred batches of a flight
+    size_t spec_counts_cap[NM_FLIGHTS] = {}, flight_counts_cap[NM_FLIGHTS] = {};
     unsigned long long *d_counts = nullptr;
     size_t counts_cap = 0;
     unsigned int *d_err = nullptr;
@@ -241,9 +258,22 @@ inline void drop_ingest_rows(nm_ctx *c) {
 
 // pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it
 // busy until the work enqueued so far on the ctx stream has run
-int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2: the asynchronous window batch's own pair
+int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2 + f: the asynchronous window batch's own pair
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
+// A scoring batch whose candidates are WRITTEN ON THE DEVICE (speculative children of the search, nmwindows.hip): the host knows
+// every candidate's (bin, slot) — grouping, ranges, segment table are built as for any batch — but not its motif.  `fill` is
+// called with the tables staged and copied to the device, on the batch's stream, before the programs are compiled: it must set
+// len / modpos of every record (d_rec[pos_of[k]] is caller's candidate k), write its mask bytes (mask_stride reserved each, at
+// d_masks + rec.mask_off) and may lower the candidate count range[entry].y of a group (entry = active index of the slot * n_bins +
+// bin).  The candidates must be literal, compact (the canonical base at the modified position) and reach at most 31 positions.
+struct SpecSource {
+    uint32_t mask_stride;
+    std::function<int(hipStream_t st, CandRec *d_rec, const uint32_t *d_pos_of, uint8_t *d_masks, uint4 *d_range, const int *slot_to_active)> fill;
+};
+// begin: everything enqueued on `st`, counts land in the pinned half of a staging pair noted in c->spec_wait[flight] (and stay in c->d_spec_counts[flight])
+int score_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const SpecSource &spec,
+                           hipStream_t st);
 // nm_upload_contigs_device with one source offset per contig (nmfasta.hip: records of a device-parsed FASTA)
 int upload_contigs_gather(nm_ctx *c, uint32_t n_contigs, const uint64_t *offsets, const uint64_t *src_off, const uint32_t *bin_id,
                           uint32_t n_bins, const uint8_t *d_seq_ascii);

@@ -34,6 +34,7 @@
 
 #include "../../include/nmscan.h"
 #include "nmsearch_internal.h"
+#include "nmspec.h"
 
 namespace {
 
@@ -237,6 +238,14 @@ struct Task {
     std::vector<Model> rep_models;
     int64_t rep_a = 0, rep_b = 0;                   // pssm: n_active ; remove: before, left
     int64_t rep_counts[4][MAXW];
+    // speculative children that came with a PSSM reply (engine back end, nmspec.h): the column the device picked (-1: none), the
+    // base rows A T G C it scored there, their counts in the order of the set bits
+    int spec_col = -1;
+    uint32_t spec_bases = 0;
+    int64_t spec_counts[4][2];
+    int nb_col = -1;                                // children_of: the column and the rows of `neighbors`
+    int nb_row[4];
+    uint32_t spec_hits = 0, spec_misses = 0;        // children answered by the speculation / asked for after all
     // --- state
     int state = 0;
     uint32_t dead_ends = 0;
@@ -340,13 +349,31 @@ struct Task {
         }
         if (!nan && kl[pos] < P->min_kl) return;
         static const char BASES[4] = {'A', 'T', 'G', 'C'};
+        nb_col = pos;
         for (int r = 0; r < 4; ++r) {
             if (meth[r][pos] > bg[r * W + pos] * 0.5 && meth[r][pos] > P->freq_threshold) {
                 std::string c = motif;
                 c[pos] = BASES[r];
+                nb_row[neighbors.size()] = r;
                 neighbors.push_back(std::move(c));
             }
         }
+    }
+
+    // A new child whose counts came with the PSSM reply goes into the memo: request_score then finds it there, and a request that
+    // is answered completely costs no round.  The host's own pick above stays authoritative: a speculative count is used only for
+    // the very motif it was computed for (same column, same base) — it is the same kernel's count of the same candidate.
+    void take_speculation() {
+        if (spec_col < 0 || !use_memo) return;
+        for (size_t ni = 0; ni < neighbors.size(); ++ni) {
+            if (neighbor_ids[ni] >= 0 || memo.find(neighbors[ni]) >= 0) continue;
+            if (spec_col != nb_col || !((spec_bases >> nb_row[ni]) & 1u)) { spec_misses += 1; continue; }
+            const int k = __builtin_popcount(spec_bases & ((1u << nb_row[ni]) - 1u));
+            memo.insert(neighbors[ni], (int)memo_models.size());
+            memo_models.push_back(Model::from_counts(spec_counts[k][0], spec_counts[k][1]));
+            spec_hits += 1;
+        }
+        spec_col = -1;
     }
 
     // Counts are a pure function of (task, motif): what this task has had scanned before — the root at the start of
@@ -493,6 +520,7 @@ struct Task {
                 neighbor_ids.push_back(g.find(m));
                 if (neighbor_ids.back() < 0) fresh.push_back(m);
             }
+            take_speculation();
             if (fresh.empty()) rep_models.clear();
             else if (request_score(fresh)) {
                 state = 3;
@@ -612,6 +640,7 @@ struct nm_search_result {
     uint32_t width = 0;
     std::vector<Task> tasks;
     uint64_t rounds = 0, candidates = 0, window_requests = 0;
+    uint64_t iterations = 0, spec_hits = 0, spec_misses = 0;     // lock-step iterations; children answered by / asked for despite the speculation
 };
 
 namespace {
@@ -711,10 +740,13 @@ private:
 struct Backend {
     nm_search_score_fn score = nullptr;
     nm_search_window_fn window = nullptr;
-    int (*score_begin)(void *user, uint32_t n, const uint32_t *task, const char *motifs) = nullptr;
-    int (*score_end)(void *user, uint32_t n, int64_t *out) = nullptr;
-    int (*window_begin)(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) = nullptr;
-    int (*window_end)(void *user, uint32_t n, int32_t *out) = nullptr;
+    // the engine's halves; flight = which of the two groups of tasks the batch belongs to (each has its own batches in flight)
+    int (*score_begin)(void *user, int flight, uint32_t n, const uint32_t *task, const char *motifs) = nullptr;
+    int (*score_end)(void *user, int flight, uint32_t n, int64_t *out) = nullptr;
+    int (*window_begin)(void *user, int flight, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) = nullptr;
+    // also fills spec_info[n][2] and spec_counts[n][4][2] (speculative children, nmspec.h; column -1 where there are none)
+    int (*window_end)(void *user, int flight, uint32_t n, int32_t *out, int32_t *spec_info, int64_t *spec_counts) = nullptr;
+    uint32_t (*group_of)(void *user, uint32_t task) = nullptr;      // which flight a task travels with (both mod types of a bin together)
     void *user = nullptr;
 };
 
@@ -737,11 +769,6 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     double t0 = now();
     workers.run(tasks.size(), [&](size_t i) { tasks[i].resume(); });
     t_resume += now() - t0;
-    std::vector<uint32_t> s_task, w_task, s_owner;
-    std::vector<char> s_motifs, w_motifs;
-    std::vector<uint8_t> w_kind;
-    std::vector<int64_t> counts;
-    std::vector<int32_t> wout;
     auto resume_these = [&](const std::vector<uint32_t> &which) {
         const double t1 = now();
         workers.run(which.size(), [&](size_t k) {
@@ -751,84 +778,130 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
         });
         t_resume += now() - t1;
     };
-    for (;;) {
-        s_task.clear(); w_task.clear(); s_motifs.clear(); w_motifs.clear(); w_kind.clear(); s_owner.clear();
-        t0 = now();
-        for (uint32_t i = 0; i < tasks.size(); ++i) {
+    // Two FLIGHTS (engine back end): the tasks are split into two groups, each with its own window batch and scoring batch; while
+    // one group's batches are on the device the other group's replies are taken in, its state machines advanced and its next
+    // batches sent.  A task's requests depend only on its own replies, so the grouping changes no result.  Callbacks answer at
+    // once: one group.
+    const int n_flights = (B.window_begin && B.score_begin && tasks.size() >= 16 && getenv("NM_SEARCH_ONE_FLIGHT") == nullptr) ? 2 : 1;
+    struct Flight {
+        std::vector<uint32_t> members, s_task, w_task, s_owner;
+        std::vector<char> s_motifs, w_motifs;
+        std::vector<uint8_t> w_kind;
+        std::vector<int64_t> counts, spec_counts;
+        std::vector<int32_t> wout, spec_info;
+        bool flying = false;
+    } fl[2];
+    for (uint32_t i = 0; i < tasks.size(); ++i) fl[n_flights == 2 ? ((B.group_of ? B.group_of(B.user, i) : i) & 1u) : 0].members.push_back(i);
+    // the requests of a group go out: its window batch first, its scoring batch behind it
+    auto issue = [&](int f) -> int {
+        Flight &F = fl[f];
+        F.s_task.clear(); F.w_task.clear(); F.s_motifs.clear(); F.w_motifs.clear(); F.w_kind.clear(); F.s_owner.clear();
+        double t1 = now();
+        for (uint32_t i : F.members) {
             Task &t = tasks[i];
             if (t.req == REQ_SCORE) {
-                s_owner.push_back(i);
+                F.s_owner.push_back(i);
                 for (const auto &m : t.req_motifs) {
-                    s_task.push_back(i);
-                    s_motifs.insert(s_motifs.end(), m.begin(), m.end());
+                    F.s_task.push_back(i);
+                    F.s_motifs.insert(F.s_motifs.end(), m.begin(), m.end());
                 }
             } else if (t.req == REQ_PSSM || t.req == REQ_REMOVE) {
-                w_task.push_back(i);
-                w_kind.push_back(t.req == REQ_REMOVE ? 1 : 0);
-                w_motifs.insert(w_motifs.end(), t.req_motifs[0].begin(), t.req_motifs[0].end());
+                F.w_task.push_back(i);
+                F.w_kind.push_back(t.req == REQ_REMOVE ? 1 : 0);
+                F.w_motifs.insert(F.w_motifs.end(), t.req_motifs[0].begin(), t.req_motifs[0].end());
             }
         }
-        t_gather += now() - t0;
-        if (s_task.empty() && w_task.empty()) break;
-        // ---- both batches go out
-        if (!w_task.empty()) {
-            t0 = now();
-            wout.assign(w_task.size() * (size_t)(2 + 4 * WS), 0);
-            const int rc = B.window_begin ? B.window_begin(B.user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data())
-                                          : B.window(B.user, (uint32_t)w_task.size(), w_task.data(), w_kind.data(), w_motifs.data(), wout.data());
+        t_gather += now() - t1;
+        F.flying = !(F.s_task.empty() && F.w_task.empty());
+        if (!F.flying) return NM_OK;
+        res->iterations += 1;
+        if (!F.w_task.empty()) {
+            t1 = now();
+            F.wout.assign(F.w_task.size() * (size_t)(2 + 4 * WS), 0);
+            const int rc = B.window_begin ? B.window_begin(B.user, f, (uint32_t)F.w_task.size(), F.w_task.data(), F.w_kind.data(), F.w_motifs.data())
+                                          : B.window(B.user, (uint32_t)F.w_task.size(), F.w_task.data(), F.w_kind.data(), F.w_motifs.data(), F.wout.data());
             if (rc) return rc;
-            res->window_requests += w_task.size();
-            t_window += now() - t0;
+            res->window_requests += F.w_task.size();
+            t_window += now() - t1;
         }
-        if (!s_task.empty()) {
-            t0 = now();
-            counts.assign(s_task.size() * 2, 0);
-            const int rc = B.score_begin ? B.score_begin(B.user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data())
-                                         : B.score(B.user, (uint32_t)s_task.size(), s_task.data(), s_motifs.data(), counts.data());
+        if (!F.s_task.empty()) {
+            t1 = now();
+            F.counts.assign(F.s_task.size() * 2, 0);
+            const int rc = B.score_begin ? B.score_begin(B.user, f, (uint32_t)F.s_task.size(), F.s_task.data(), F.s_motifs.data())
+                                         : B.score(B.user, (uint32_t)F.s_task.size(), F.s_task.data(), F.s_motifs.data(), F.counts.data());
             if (rc) return rc;
             res->rounds += 1;
-            res->candidates += s_task.size();
-            t_score += now() - t0;
+            res->candidates += F.s_task.size();
+            t_score += now() - t1;
         }
-        // ---- the windows come back first; their tasks advance while the scoring kernel is still running
-        if (!w_task.empty()) {
-            t0 = now();
+        return NM_OK;
+    };
+    // the replies of a group: the windows come back first, their tasks advance while the scoring kernel may still be running
+    auto collect = [&](int f) -> int {
+        Flight &F = fl[f];
+        if (!F.flying) return NM_OK;
+        F.flying = false;
+        if (!F.w_task.empty()) {
+            double t1 = now();
+            F.spec_info.assign(F.w_task.size() * 2, -1);
+            F.spec_counts.assign(F.w_task.size() * 8, 0);
             if (B.window_end) {
-                const int rc = B.window_end(B.user, (uint32_t)w_task.size(), wout.data());
+                const int rc = B.window_end(B.user, f, (uint32_t)F.w_task.size(), F.wout.data(), F.spec_info.data(), F.spec_counts.data());
                 if (rc) return rc;
             }
-            t_window += now() - t0;
-            t0 = now();
-            for (size_t k = 0; k < w_task.size(); ++k) {
-                Task &t = tasks[w_task[k]];
-                const int32_t *o = wout.data() + k * (size_t)(2 + 4 * WS);
+            t_window += now() - t1;
+            t1 = now();
+            for (size_t k = 0; k < F.w_task.size(); ++k) {
+                Task &t = tasks[F.w_task[k]];
+                const int32_t *o = F.wout.data() + k * (size_t)(2 + 4 * WS);
                 t.rep_a = o[0];
                 t.rep_b = o[1];
-                if (w_kind[k] == 0)
+                t.spec_col = -1;
+                if (F.w_kind[k] == 0) {
+                    t.spec_col = F.spec_info[2 * k];
+                    t.spec_bases = (uint32_t)F.spec_info[2 * k + 1];
+                    for (int q = 0; q < 4; ++q) { t.spec_counts[q][0] = F.spec_counts[8 * k + 2 * q]; t.spec_counts[q][1] = F.spec_counts[8 * k + 2 * q + 1]; }
                     for (int r = 0; r < 4; ++r)
                         for (uint32_t j = 0; j < W; ++j) t.rep_counts[r][j] = o[2 + r * WS + j];
+                }
             }
-            t_reply += now() - t0;
-            resume_these(w_task);
+            t_reply += now() - t1;
+            resume_these(F.w_task);
         }
-        if (!s_task.empty()) {
-            t0 = now();
+        if (!F.s_task.empty()) {
+            double t1 = now();
             if (B.score_end) {
-                const int rc = B.score_end(B.user, (uint32_t)s_task.size(), counts.data());
+                const int rc = B.score_end(B.user, f, (uint32_t)F.s_task.size(), F.counts.data());
                 if (rc) return rc;
             }
-            t_score += now() - t0;
-            t0 = now();
+            t_score += now() - t1;
+            t1 = now();
             size_t si = 0;
-            while (si < s_task.size()) {
-                Task &t = tasks[s_task[si]];
+            while (si < F.s_task.size()) {
+                Task &t = tasks[F.s_task[si]];
                 t.rep_models.clear();
-                for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(counts[2 * si], counts[2 * si + 1]));
+                for (size_t k = 0; k < t.req_motifs.size(); ++k, ++si) t.rep_models.push_back(Model::from_counts(F.counts[2 * si], F.counts[2 * si + 1]));
             }
-            t_reply += now() - t0;
-            resume_these(s_owner);
+            t_reply += now() - t1;
+            resume_these(F.s_owner);
         }
+        return NM_OK;
+    };
+    for (int f = 0; f < n_flights; ++f) {
+        const int rc = issue(f);
+        if (rc) return rc;
     }
+    while (fl[0].flying || fl[1].flying)
+        for (int f = 0; f < n_flights; ++f) {
+            int rc = collect(f);
+            if (rc) return rc;
+            rc = issue(f);
+            if (rc) return rc;
+        }
+    for (const auto &t : tasks) { res->spec_hits += t.spec_hits; res->spec_misses += t.spec_misses; }
+    if (timing)
+        fprintf(stderr, "[nm_search] %llu lock-step iterations, speculative children: %llu answered, %llu asked for after all\n",
+                (unsigned long long)res->iterations, (unsigned long long)res->spec_hits, (unsigned long long)res->spec_misses);
     if (timing)
         fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds: resume %.1f ms, request gathering %.1f ms, window batches %.1f ms, "
                         "scoring batches %.1f ms, replies %.1f ms\n", tasks.size(), (unsigned long long)res->rounds, t_resume * 1e3,
@@ -857,11 +930,16 @@ struct EngineUser {
     std::vector<uint32_t> bins, offs, wtask;
     std::vector<uint8_t> slots, lens, modpos, masks, sets;
     std::vector<int64_t> tmp64;
+    // speculative children (nmspec.h): single-GPU searches whose windows reach at most 31 positions; NM_SEARCH_NO_SPEC=1 turns it off
+    bool spec = false;
+    double min_kl = 0, freq_threshold = 0;
+    std::vector<uint32_t> sbin, stask;
+    std::vector<uint8_t> sslot;
 };
 
 inline uint8_t set_of(char ch) { return ch == 'A' ? NM_BASE_A : ch == 'C' ? NM_BASE_C : ch == 'G' ? NM_BASE_G : ch == 'T' ? NM_BASE_T : 15; }
 
-int engine_score_begin(void *user, uint32_t n, const uint32_t *task, const char *motifs) {
+int engine_score_begin(void *user, int flight, uint32_t n, const uint32_t *task, const char *motifs) {
     EngineUser &u = *static_cast<EngineUser *>(user);
     const uint32_t W = u.width;
     u.bins.resize(n); u.offs.resize(n); u.slots.resize(n); u.lens.resize(n); u.modpos.resize(n);
@@ -878,18 +956,18 @@ int engine_score_begin(void *user, uint32_t n, const uint32_t *task, const char 
         u.offs[i] = (uint32_t)u.masks.size();
         for (uint32_t j = lo; j < hi; ++j) u.masks.push_back(set_of(m[j]));
     }
-    return nm_score_batch_begin(u.ctx, n, u.bins.data(), u.slots.data(), u.lens.data(), u.modpos.data(), u.offs.data(), u.masks.data());
+    return nmdetail::score_batch_flight_begin(u.ctx, flight, n, u.bins.data(), u.slots.data(), u.lens.data(), u.modpos.data(), u.offs.data(), u.masks.data());
 }
 
-int engine_score_end(void *user, uint32_t n, int64_t *out) {
+int engine_score_end(void *user, int flight, uint32_t n, int64_t *out) {
     EngineUser &u = *static_cast<EngineUser *>(user);
-    int rc = nm_score_batch_end(u.ctx, out);
+    int rc = nmdetail::score_batch_flight_end(u.ctx, flight, out);
     if (rc) return rc;
     if (u.reduce) rc = u.reduce(u.reduce_user, out, (uint64_t)n * 2);
     return rc;
 }
 
-int engine_window_begin(void *user, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) {
+int engine_window_begin(void *user, int flight, uint32_t n, const uint32_t *task, const uint8_t *kind, const char *motifs) {
     EngineUser &u = *static_cast<EngineUser *>(user);
     const uint32_t W = u.width;
     u.wtask.resize(n);
@@ -899,14 +977,18 @@ int engine_window_begin(void *user, uint32_t n, const uint32_t *task, const uint
         u.wtask[i] = u.task_win[task[i]];
         for (uint32_t j = 0; j < W; ++j) u.sets[(size_t)i * WS + j] = set_of(motifs[(size_t)i * W + j]);
     }
-    return nm_win_batch_w_begin(u.ctx, n, u.wtask.data(), kind, u.sets.data(), WS);
+    if (!u.spec) return nmdetail::win_batch_spec_begin(u.ctx, flight, n, u.wtask.data(), kind, u.sets.data(), WS, nullptr);
+    u.sbin.resize(n); u.sslot.resize(n); u.stask.assign(task, task + n);
+    for (uint32_t i = 0; i < n; ++i) { u.sbin[i] = u.task_bin[task[i]]; u.sslot[i] = (uint8_t)u.task_slot[task[i]]; }
+    const nmdetail::WinSpec ws{u.sbin.data(), u.sslot.data(), u.stask.data(), W, u.padding, u.min_kl, u.freq_threshold};
+    return nmdetail::win_batch_spec_begin(u.ctx, flight, n, u.wtask.data(), kind, u.sets.data(), WS, &ws);
 }
 
-int engine_window_end(void *user, uint32_t n, int32_t *out) {
+int engine_window_end(void *user, int flight, uint32_t n, int32_t *out, int32_t *spec_info, int64_t *spec_counts) {
     EngineUser &u = *static_cast<EngineUser *>(user);
-    int rc = nm_win_batch_w_end(u.ctx, out);
+    int rc = nmdetail::win_batch_spec_end(u.ctx, flight, n, out, spec_info, spec_counts);
     if (rc) return rc;
-    if (u.reduce) {                                  // contig-sharded run: every rank holds the windows of its contigs
+    if (u.reduce) {                                  // contig-sharded run: every rank holds the windows of its contigs (no speculation there)
         const size_t m = (size_t)n * (2 + 4 * width_stride(u.width));
         u.tmp64.resize(m);
         for (size_t i = 0; i < m; ++i) u.tmp64[i] = out[i];
@@ -915,6 +997,8 @@ int engine_window_end(void *user, uint32_t n, int32_t *out) {
     }
     return rc;
 }
+
+uint32_t engine_group_of(void *user, uint32_t task) { return static_cast<EngineUser *>(user)->task_bin[task]; }
 
 int start(uint32_t n_tasks, const nm_search_params *p, const double *bg_pssm, const uint64_t *total_windows, const uint8_t *canonical,
           nm_search_result **out, Params &P) {
@@ -996,17 +1080,30 @@ int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const
     int rc = check_params(params);
     if (rc) return rc;
     EngineUser u{ctx, task_bin, task_slot, task_window, 2 * params->padding + 1, params->padding, reduce, reduce_user, {}, {}, {}, {}, {}, {}, {}, {}, {}};
+    // speculative children: every rank of a contig-sharded run sees only its own windows (the counts are summed by `reduce` on the
+    // host), so the device cannot pick the column there; windows wider than 63 columns reach beyond the narrow scoring kernels
+    u.spec = reduce == nullptr && params->padding <= 31 && n_tasks > 0 && getenv("NM_SEARCH_NO_SPEC") == nullptr;
+    u.min_kl = params->min_kl;
+    u.freq_threshold = params->freq_threshold;
+    if (u.spec) {
+        rc = nmdetail::spec_setup(ctx, n_tasks, 2 * params->padding + 1, bg_pssm);
+        if (rc) return rc;
+    }
     Backend B;
     B.score_begin = engine_score_begin;
     B.score_end = engine_score_end;
     B.window_begin = engine_window_begin;
     B.window_end = engine_window_end;
+    B.group_of = engine_group_of;
     B.user = &u;
     rc = run_search(n_tasks, params, bg_pssm, total_windows, canonical, B, out);
     if (rc) {                                        // a round that failed half way: nothing stays open on the ctx
-        (void)nm_win_batch_w_end(ctx, nullptr);
-        (void)nm_score_batch_end(ctx, nullptr);
+        for (int f = 0; f < 2; ++f) {
+            (void)nmdetail::win_batch_spec_end(ctx, f, 0, nullptr, nullptr, nullptr);
+            (void)nmdetail::score_batch_flight_end(ctx, f, nullptr);
+        }
     }
+    if (u.spec) (void)nmdetail::spec_setup(ctx, 0, 0, nullptr);
     return rc;
 }
 
@@ -1021,6 +1118,14 @@ int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint6
     }
     *n_nodes = nn; *n_edges = ne; *n_best = nb;
     if (stats) { stats[0] = res->rounds; stats[1] = res->candidates; stats[2] = res->window_requests; }
+    return NM_OK;
+}
+
+int nm_search_result_speculation(const nm_search_result *res, uint64_t stats[3]) {
+    if (!res || !stats) return nm_set_error(NM_EINVAL, "NULL argument");
+    stats[0] = res->iterations;
+    stats[1] = res->spec_hits;
+    stats[2] = res->spec_misses;
     return NM_OK;
 }
 

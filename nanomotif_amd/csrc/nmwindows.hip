@@ -483,6 +483,7 @@ static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uin
     HIP_TRY(nmdetail::dev_malloc(&nb, ncap * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));       // window batches in flight (batch_stream)
+    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
     if (*buf && used) HIP_TRY(hipMemcpy(nb, *buf, used * 4, hipMemcpyDeviceToDevice));
     if (*buf) (void)nmdetail::dev_free(*buf);
     *buf = nb;
@@ -494,6 +495,7 @@ int nm_win_clear(nm_ctx *c) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
     c->win_tasks.clear();
     c->win_planes_used = c->win_alive_used = 0;
     c->win_tasks_dirty = true;
@@ -540,8 +542,12 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
 // by these batches (in order, on that stream) and by the set-up calls, which finish on the ctx stream before a batch can
 // start (win_tasks_dirty / nm_plan_windows synchronise) and wait for this stream before they touch the planes.
 // NM_WIN_STREAM=0: everything on the ctx stream (A/B, tools/gpu_r4p.sh).
-static hipStream_t batch_stream(nm_ctx *c) {
+static hipStream_t batch_stream(nm_ctx *c, int flight = 0) {
     static const bool second = getenv("NM_WIN_STREAM") == nullptr || atoi(getenv("NM_WIN_STREAM")) != 0;
+    if (flight == 1 && second) {                     // the second flight of the search: a stream of its own, made on first use
+        if (!c->flight_stream && hipStreamCreateWithFlags(&c->flight_stream, hipStreamNonBlocking) != hipSuccess) c->flight_stream = nullptr;
+        if (c->flight_stream) return c->flight_stream;
+    }
     return second && c->copy_stream ? c->copy_stream : c->stream;
 }
 
@@ -567,12 +573,114 @@ static void busy_end_on(nm_ctx *c, hipStream_t st) {
     c->busy_open = false;
 }
 
-int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
-                         uint32_t ws) {
+
+// ------------------------------------------------------------------------------------------------------
+// Speculative children of the search (round 5).  A task of the lock-step search alternates two dependent round trips: the
+// window counts of its current motif, then — once the host has picked the column of the largest KL divergence against the
+// bin's background and the bases that pass the two frequency filters (find_motifs_bin.py:957-1023) — the counts of the
+// up-to-four children there.  This kernel makes the same pick ON THE DEVICE right behind win_request_kernel and writes the
+// children as candidate records of a scoring batch that runs in the same chain of launches (nmdetail::score_batch_spec_begin):
+// when the host's own, exact pick agrees (it recomputes it the way scipy does and stays authoritative), the children's counts
+// are already there and the second round trip is not made.  A pick that differs — double-precision log of the device against
+// the host's on a near-tie — only costs the round trip it would have cost anyway.
+// One wave per request; lane j holds column j.
+// ------------------------------------------------------------------------------------------------------
+struct SpecParams {
+    uint32_t n_req, ws, width, pad;
+    double min_kl, freq_threshold;
+};
+
+__global__ __launch_bounds__(256) void spec_children_kernel(SpecParams P, const uint8_t *__restrict__ req_kind, const uint8_t *__restrict__ req_sets,
+                                                            const uint32_t *__restrict__ req_search_task, const uint32_t *__restrict__ req_entry,
+                                                            const int *__restrict__ win_out, const double *__restrict__ bg /*[task][4][width]*/,
+                                                            int *__restrict__ spec_info /*[n_req][2]: column (-1: none), base rows as bits*/,
+                                                            CandRec *__restrict__ rec, const uint32_t *__restrict__ pos_of, uint8_t *__restrict__ masks,
+                                                            uint4 *__restrict__ range, uint32_t mask_stride) {
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= P.n_req) return;
+    const uint32_t W = P.width;
+    const int *o = win_out + (size_t)r * (2 + 4 * P.ws);
+    const uint8_t *sets = req_sets + (size_t)r * P.ws;
+    const int n_active = o[0];
+    const double *q = bg + (size_t)req_search_task[r] * 4 * W;
+    // KL(column j) = sum_r rel_entr(p_r / sum p, q_r / sum q)  (scipy.stats.entropy), specified columns count as 0
+    double kl = 0.0;
+    bool is_nan = false;
+    const uint32_t my_set = lane < W ? sets[lane] : 0u;
+    if (lane < W && my_set == 15u && req_kind[r] == 0 && n_active > 0) {
+        double p[4], qq[4];
+        for (int k = 0; k < 4; ++k) { p[k] = (double)o[2 + k * P.ws + lane] / (double)n_active; qq[k] = q[k * W + lane]; }
+        const double sp = ((p[0] + p[1]) + p[2]) + p[3], sq = ((qq[0] + qq[1]) + qq[2]) + qq[3];
+        double e[4];
+        for (int k = 0; k < 4; ++k) {
+            const double x = p[k] / sp, y = qq[k] / sq;
+            e[k] = (x > 0 && y > 0) ? x * log(x / y) : (x == 0 && y >= 0) ? 0.0 : INFINITY;
+            if (x != x || y != y) e[k] = x + y;                       // NaN in, NaN out
+        }
+        kl = ((e[0] + e[1]) + e[2]) + e[3];
+        is_nan = kl != kl;
+    }
+    // np.argmax: a NaN wins, otherwise the first maximum
+    const unsigned long long nan_lanes = __ballot(is_nan);
+    int col;
+    double best;
+    if (nan_lanes) {
+        col = __ffsll((long long)nan_lanes) - 1;
+        best = 0.0;
+    } else {
+        best = kl;
+        col = (int)lane;
+        for (int s = 32; s; s >>= 1) {
+            const double ob = __shfl_xor(best, s);
+            const int oc = __shfl_xor(col, s);
+            if (ob > best || (ob == best && oc < col)) { best = ob; col = oc; }
+        }
+    }
+    // the bases at that column: frequency above half the background's and above the threshold (rows A, T, G, C)
+    uint32_t bases = 0;
+    const bool any_dot = __ballot(lane < W && my_set == 15u) != 0;
+    if (req_kind[r] == 0 && n_active > 0 && any_dot && (nan_lanes || !(best < P.min_kl))) {
+        for (int k = 0; k < 4; ++k) {
+            const double m = (double)o[2 + k * P.ws + col] / (double)n_active;
+            if (m > q[k * W + col] * 0.5 && m > P.freq_threshold) bases |= 1u << k;
+        }
+    }
+    const uint32_t nv = __popc(bases);
+    if (lane == 0) {
+        spec_info[2 * r] = nv ? col : -1;
+        spec_info[2 * r + 1] = (int)bases;
+        range[req_entry[r]].y = nv;                                   // the group's candidates: its valid children, packed first
+    }
+    // the four records of the request: child c = the c-th passing base (rows in order), the others a harmless one-letter motif
+    const uint32_t row_bit[4] = {NM_BASE_A, NM_BASE_T, NM_BASE_G, NM_BASE_C};
+    uint32_t left = bases;
+    for (uint32_t c = 0; c < 4; ++c) {
+        const uint32_t at = pos_of[4 * r + c];
+        uint8_t *m = masks + rec[at].mask_off;
+        if (c < nv) {
+            const int k = __ffs(left) - 1;
+            left &= left - 1;
+            const uint32_t set = lane < W ? ((int)lane == col ? row_bit[k] : my_set) : 15u;
+            const unsigned long long spec_cols = __ballot(lane < W && set != 15u);     // never empty: the modified position is specified
+            const int lo = __ffsll((long long)spec_cols) - 1, hi = 63 - __clzll((long long)spec_cols);
+            if ((int)lane >= lo && (int)lane <= hi) m[lane - lo] = (uint8_t)set;
+            if (lane == 0) { rec[at].len = (uint8_t)(hi - lo + 1); rec[at].modpos = (uint8_t)(P.pad - lo); }
+        } else if (lane == 0) {
+            m[0] = (uint8_t)sets[P.pad];
+            rec[at].len = 1;
+            rec[at].modpos = 0;
+        }
+    }
+}
+
+// The window batch; spec != NULL: with the speculative children of its PSSM requests scored behind it (see above)
+static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                                uint32_t ws, const nmdetail::WinSpec *spec, int flight = 0) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
-    if (c->win_wait.open) return fail(NM_ESTATE, "nm_win_batch_w_begin: the previous batch has not been collected (nm_win_batch_w_end)");
+    if (flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
+    if (c->win_wait[flight].open) return fail(NM_ESTATE, "nm_win_batch_w_begin: the previous batch has not been collected (nm_win_batch_w_end)");
     if (n_req == 0) {
-        c->win_wait = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+        c->win_wait[flight] = nm_ctx::Waiting{nullptr, 0, nullptr, true};
         return NM_OK;
     }
     if (!req_task || !req_kind || !req_sets) return fail(NM_EINVAL, "NULL argument");
@@ -590,6 +698,7 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
         // the set-up work on the ctx stream is complete, no earlier batch is in flight: then the task table is replaced
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
         if (c->d_win_tasks_cap < c->win_tasks.size()) {
             if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
             c->d_win_tasks = nullptr;
@@ -602,15 +711,31 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
     }
     const uint32_t stride = 2 + 4 * ws;
     const size_t o_kind = (size_t)n_req * 4, o_sets = (o_kind + n_req + 15) & ~(size_t)15;
-    const size_t o_out = (o_sets + (size_t)n_req * ws + 15) & ~(size_t)15;
-    const size_t total = o_out + (size_t)n_req * stride * 4;
-    int rc = ensure_stage(c, total, 2);          // its own pair: a scoring batch enqueued behind this one never waits for it on the host
+    // spec: + the search task and the (slot, bin) range entry of every request in front of the outputs, + {column, bases} behind them
+    const size_t o_stask = (o_sets + (size_t)n_req * ws + 15) & ~(size_t)15;
+    const size_t o_entry = o_stask + (spec ? (size_t)n_req * 4 : 0);
+    const size_t o_out = (o_entry + (spec ? (size_t)n_req * 4 : 0) + 15) & ~(size_t)15;
+    const size_t o_info = o_out + (size_t)n_req * stride * 4;
+    const size_t total = o_info + (spec ? (size_t)n_req * 8 : 0);
+    int rc = ensure_stage(c, total, 2 + flight);  // its own pair: a scoring batch enqueued behind this one never waits for it on the host
     if (rc) return rc;
     uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
-    const hipStream_t st = batch_stream(c);
+    const hipStream_t st = batch_stream(c, flight);
     memcpy(hs, req_task, (size_t)n_req * 4);
     memcpy(hs + o_kind, req_kind, n_req);
     memcpy(hs + o_sets, req_sets, (size_t)n_req * ws);
+    nm_ctx::Stage *const win_stage = c->cur_stage;
+    if (spec) {
+        // range entry of a request's (slot, bin) group in the scoring batch: active index of the slot * n_bins + bin, the active
+        // slots numbered in ascending order (score_impl does the same)
+        bool used[NM_MAX_MOD_SLOTS] = {};
+        for (uint32_t r = 0; r < n_req; ++r) used[spec->req_slot[r]] = true;
+        int act[NM_MAX_MOD_SLOTS], na = 0;
+        for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) act[s] = used[s] ? na++ : -1;
+        uint32_t *h_entry = reinterpret_cast<uint32_t *>(hs + o_entry);
+        for (uint32_t r = 0; r < n_req; ++r) h_entry[r] = (uint32_t)act[spec->req_slot[r]] * c->n_bins + spec->req_bin[r];
+        memcpy(hs + o_stask, spec->req_search_task, (size_t)n_req * 4);
+    }
     HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, st));
     // slices of a task's words per request (blockIdx.z): one workgroup per 256 words when the batch is small, fewer and
@@ -628,18 +753,97 @@ int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, co
                        reinterpret_cast<int *>(ds + o_out), ws);
     busy_end_on(c, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, (size_t)n_req * stride * 4, hipMemcpyDeviceToHost, st));
+    if (spec) {
+        // four candidate slots per request, (bin, slot) known here, motifs written by spec_children_kernel from the counts above
+        std::vector<uint32_t> cbin((size_t)n_req * 4);
+        std::vector<uint8_t> cslot((size_t)n_req * 4);
+        for (uint32_t r = 0; r < n_req; ++r)
+            for (int k = 0; k < 4; ++k) { cbin[4 * r + k] = spec->req_bin[r]; cslot[4 * r + k] = spec->req_slot[r]; }
+        nmdetail::SpecSource src;
+        src.mask_stride = ws;
+        const SpecParams P{n_req, ws, spec->width, spec->pad, spec->min_kl, spec->freq_threshold};
+        src.fill = [&](hipStream_t s, nmdetail::CandRec *d_rec, const uint32_t *d_pos_of, uint8_t *d_masks, uint4 *d_range, const int *) -> int {
+            hipLaunchKernelGGL(spec_children_kernel, dim3((n_req + 3) / 4), dim3(256), 0, s, P, ds + o_kind, ds + o_sets,
+                               reinterpret_cast<const uint32_t *>(ds + o_stask), reinterpret_cast<const uint32_t *>(ds + o_entry),
+                               reinterpret_cast<const int *>(ds + o_out), c->d_spec_bg, reinterpret_cast<int *>(ds + o_info), d_rec, d_pos_of, d_masks,
+                               d_range, ws);
+            HIP_TRY(hipGetLastError());
+            return NM_OK;
+        };
+        // (no busy_begin / busy_end bracket: the scoring launch inside takes its own event pair from the same pool)
+        rc = nmdetail::score_batch_spec_begin(c, flight, n_req * 4, cbin.data(), cslot.data(), src, st);
+        c->cur_stage = win_stage;                                     // (the scoring batch took a pair of its own)
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, st));
     rc = release_stage(c, st);
     if (rc) return rc;
-    c->win_wait = nm_ctx::Waiting{hs + o_out, (size_t)n_req * stride * 4, c->cur_stage, true};
+    c->win_wait[flight] = nm_ctx::Waiting{hs + o_out, (size_t)n_req * stride * 4, c->cur_stage, true};
     return NM_OK;
 }
 
+int nm_win_batch_w_begin(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                         uint32_t ws) {
+    return win_batch_begin_impl(c, n_req, req_task, req_kind, req_sets, ws, nullptr);
+}
+
+}  // extern "C"
+
+int nmdetail::win_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
+                                   uint32_t ws, const WinSpec *spec) {
+    if (!spec) return win_batch_begin_impl(c, n_req, req_task, req_kind, req_sets, ws, nullptr, flight);
+    if (n_req && (!spec->req_bin || !spec->req_slot || !spec->req_search_task)) return fail(NM_EINVAL, "NULL argument");
+    if (!c || !c->d_spec_bg || spec->width != c->spec_width) return fail(NM_ESTATE, "speculative window batch without nmdetail::spec_setup");
+    for (uint32_t r = 0; r < n_req; ++r)
+        if (spec->req_search_task[r] >= c->spec_tasks || spec->req_slot[r] >= NM_MAX_MOD_SLOTS || spec->req_bin[r] >= c->n_bins)
+            return fail(NM_EINVAL, "request %u: search task / slot / bin out of range", r);
+    return win_batch_begin_impl(c, n_req, req_task, req_kind, req_sets, ws, spec, flight);
+}
+
+// the window replies (like nm_win_batch_w_end) + per request {column or -1, base rows A T G C as bits} and the counts of its children
+// in the order of the set bits (n_mod, n_nomod; four slots per request)
+int nmdetail::win_batch_spec_end(nm_ctx *c, int flight, uint32_t n_req, int32_t *out, int32_t *spec_info, int64_t *spec_counts) {
+    if (!c || flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
+    if (!c->win_wait[flight].open) return fail(NM_ESTATE, "win_batch_spec_end without win_batch_spec_begin");
+    const nm_ctx::Waiting w = c->win_wait[flight], s = c->spec_wait[flight];
+    const bool had_spec = s.open;
+    c->win_wait[flight].open = false;
+    c->spec_wait[flight].open = false;
+    if (w.bytes == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(w.stage->busy));                    // recorded behind the whole chain
+    if (out) memcpy(out, w.h, w.bytes);
+    if (spec_info && had_spec) memcpy(spec_info, static_cast<const uint8_t *>(w.h) + w.bytes, (size_t)n_req * 8);
+    else if (spec_info) for (uint32_t r = 0; r < n_req; ++r) { spec_info[2 * r] = -1; spec_info[2 * r + 1] = 0; }
+    if (spec_counts && had_spec && s.h && s.bytes == (size_t)n_req * 4 * 2 * sizeof(int64_t)) memcpy(spec_counts, s.h, s.bytes);
+    else if (spec_counts) memset(spec_counts, 0, (size_t)n_req * 4 * 2 * sizeof(int64_t));
+    return NM_OK;
+}
+
+int nmdetail::spec_setup(nm_ctx *c, uint32_t n_tasks, uint32_t width, const double *bg_pssm) {
+    if (!c || (n_tasks && !bg_pssm)) return fail(NM_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
+    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+    if (c->d_spec_bg) (void)nmdetail::dev_free(c->d_spec_bg);
+    c->d_spec_bg = nullptr;
+    c->spec_tasks = c->spec_width = 0;
+    if (n_tasks == 0) return NM_OK;
+    HIP_TRY(nmdetail::dev_malloc(&c->d_spec_bg, (size_t)n_tasks * 4 * width * sizeof(double)));
+    HIP_TRY(hipMemcpy(c->d_spec_bg, bg_pssm, (size_t)n_tasks * 4 * width * sizeof(double), hipMemcpyHostToDevice));
+    c->spec_tasks = n_tasks;
+    c->spec_width = width;
+    return NM_OK;
+}
+
+extern "C" {
+
 int nm_win_batch_w_end(nm_ctx *c, int32_t *out) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
-    if (!c->win_wait.open) return fail(NM_ESTATE, "nm_win_batch_w_end without nm_win_batch_w_begin");
-    const nm_ctx::Waiting w = c->win_wait;
-    c->win_wait.open = false;
+    if (!c->win_wait[0].open) return fail(NM_ESTATE, "nm_win_batch_w_end without nm_win_batch_w_begin");
+    const nm_ctx::Waiting w = c->win_wait[0];
+    c->win_wait[0].open = false;
     if (w.bytes == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(w.stage->busy));
@@ -1245,6 +1449,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     c->win_planes_used = planes_used;
     c->win_alive_used = alive_used;
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));           // window batches of an earlier search (batch_stream)
+    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
     if (c->d_win_tasks_cap < c->win_tasks.size()) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);

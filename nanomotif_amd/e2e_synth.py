@@ -262,4 +262,5 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None, use_dist
     t["gpu_busy_s"] = ms * 1e-3              # every device phase: pre-filters, window gathers and batches, background counts, scoring launches (HIP events on the ctx stream)
     t["device_phases"] = n
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
+    t["search_iterations"], t["speculation_hits"], t["speculation_misses"] = scorer.search_iterations, scorer.speculation_hits, scorer.speculation_misses
     return rows, t

@@ -116,13 +116,19 @@ class DeviceAssembly:
         times = (C.c_double * 2)()
         self._check(self._lib.nm_fastadev_shape(self._h, C.byref(n), C.byref(total), times))
         self.total_bp, self.seconds, self.seconds_reading = int(total.value), float(times[0]), float(times[1])
-        self.record, self._length, self._offset, self._host = {}, [], [], {}
-        for i in range(n.value):
-            name, off, ln = C.c_char_p(), C.c_uint64(0), C.c_uint64(0)
-            self._check(self._lib.nm_fastadev_record(self._h, i, C.byref(name), C.byref(off), C.byref(ln)))
-            self.record[_lib.text_of(name.value, "a record name of the assembly")] = i      # a repeated name: the last record wins, like a dict
-            self._length.append(int(ln.value))
-            self._offset.append(int(off.value))
+        self.record, self._host = {}, {}
+        blob, nbytes, offs = C.c_void_p(), C.c_uint64(0), C.c_void_p()
+        self._check(self._lib.nm_fastadev_table(self._h, C.byref(blob), C.byref(nbytes), C.byref(offs)))      # one call for the whole table
+        names = C.string_at(blob.value, nbytes.value).split(b"\0")[:n.value] if n.value else []
+        off = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).astype(np.int64)
+        self._offset = off[:-1].tolist()
+        self._length = np.diff(off).tolist()
+        try:
+            for i, raw in enumerate(names):
+                self.record[raw.decode()] = i                         # a repeated name: the last record wins, like a dict
+        except UnicodeDecodeError:
+            self.close()
+            _lib.text_of(raw, "a record name of the assembly")        # raises with the place named
 
     def __contains__(self, name):
         return name in self.record

@@ -124,6 +124,8 @@ class LockstepScorer:
         self.use_dist, self.group = use_dist, group
         self.rounds = 0
         self.candidates = 0
+        # native search only: lock-step iterations, children answered by the device's speculation / asked for after all
+        self.search_iterations = self.speculation_hits = self.speculation_misses = 0
 
     def __call__(self, flat):
         self.rounds += 1
@@ -409,6 +411,9 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                 cfg.minimum_kl_divergence, cfg.score_threshold, reduce=reduce)
             scorer.rounds += found.rounds
             scorer.candidates += found.candidates
+            scorer.search_iterations += found.iterations
+            scorer.speculation_hits += found.spec_hits
+            scorer.speculation_misses += found.spec_misses
             lap("native_search_s")
             if os.environ.get("NANOMOTIF_PY_POST") == "1":
                 for t, (key, stage_writer, temp_dir) in enumerate(planned):
@@ -443,6 +448,9 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
         if r:
             rows += r
     log.info(f"scoring rounds: {scorer.rounds}, candidates scored: {scorer.candidates}")
+    if scorer.search_iterations:
+        log.info(f"search: {scorer.search_iterations} lock-step iterations; speculative children: {scorer.speculation_hits} answered, "
+                 f"{scorer.speculation_misses} asked for after all")
     return rows, scorer
 
 

@@ -35,6 +35,8 @@ class SearchResults:
         stats = (C.c_uint64 * 3)()
         _lib.check(lib.nm_search_result_sizes(handle, C.byref(nn), C.byref(ne), C.byref(nb), stats))
         self.rounds, self.candidates, self.window_requests = (int(x) for x in stats)
+        _lib.check(lib.nm_search_result_speculation(handle, stats))
+        self.iterations, self.spec_hits, self.spec_misses = (int(x) for x in stats)
         self.node_off, self.edge_off, self.best_off = (np.zeros(n + 1, dtype=np.uint64) for _ in range(3))
         self.none = np.zeros(max(n, 1), dtype=np.uint8)
         self.motif = np.zeros(max(int(nn.value) * W, 1), dtype=np.uint8)

@@ -25,6 +25,14 @@ int nm_score_batch_begin(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, 
 int nm_score_batch_end(nm_ctx *, int64_t *) { return NM_ESTATE; }
 int nm_win_batch_w_begin(nm_ctx *, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, uint32_t) { return NM_ESTATE; }
 int nm_win_batch_w_end(nm_ctx *, int32_t *) { return NM_ESTATE; }
+}  // extern "C" — the engine's speculative window batch (nmspec.h) is C++
+#include "../../nanomotif_amd/csrc/nmspec.h"
+int nmdetail::spec_setup(nm_ctx *, uint32_t, uint32_t, const double *) { return NM_ESTATE; }
+int nmdetail::win_batch_spec_begin(nm_ctx *, int, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, uint32_t, const WinSpec *) { return NM_ESTATE; }
+int nmdetail::win_batch_spec_end(nm_ctx *, int, uint32_t, int32_t *, int32_t *, int64_t *) { return NM_ESTATE; }
+int nmdetail::score_batch_flight_begin(nm_ctx *, int, uint32_t, const uint32_t *, const uint8_t *, const uint8_t *, const uint8_t *, const uint32_t *, const uint8_t *) { return NM_ESTATE; }
+int nmdetail::score_batch_flight_end(nm_ctx *, int, int64_t *) { return NM_ESTATE; }
+extern "C" {
 }
 
 static uint64_t mix(uint64_t x) {
