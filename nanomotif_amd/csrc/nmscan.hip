@@ -399,102 +399,10 @@ __global__ NM_SCORE_BOUNDS void score_kernel(ScoreArgs a) {
     score_piece<K>(a, sg, stp, is_c, lds_acc, lane, wave);
 }
 
-// Compile the staged candidates into constraint programs ON THE DEVICE: one thread per candidate.  A literal is one
-// constraint on an is-X plane, a 3-set one on a valid-not-X plane, a 2-set two of those; the reverse strand takes
-// the complemented set at the negated offset (motif.py:260-266).  Program layout: [strand][word-group][plane] with
-// the word-groups the launched variant reads (narrow: groups 1..2, wide: 0..3) and its planes (np = 4: literal-only
-// batch, is-X planes; np = 8); bit r of a word = offset 32 g + r.
-// fold_modpos: the modified position's own constraint is left out (compact batches start the accumulator from the
-// canonical plane instead).
-__device__ __forceinline__ void compile_one(uint32_t k, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
-                                            uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
-    const int groups = 2 + 2 * wide, g0 = 1 - wide;        // wide: 0 narrow (word-groups 1..2), 1 wide (0..3), 2 extra wide (-1..4)
-    const int pdw = 2 * groups * np;
-    uint32_t *prog = programs + (size_t)k * pdw;
-    for (int i = 0; i < pdw; ++i) prog[i] = 0;
-    const CandRec c = rec[k];
-    const uint8_t *m = masks + c.mask_off;
-    for (int j = 0; j < c.len; ++j) {
-        const uint32_t set_f = m[j] & 15u;
-        if (set_f == 15u || (fold_modpos && j == c.modpos)) continue;
-        for (int strand = 0; strand < 2; ++strand) {
-            const int d = strand == 0 ? j - (int)c.modpos : (int)c.modpos - j;
-            const uint32_t set = strand == 0 ? set_f
-                                             : (((set_f & 1) << 3) | ((set_f & 2) << 1) | ((set_f & 4) >> 1) | ((set_f & 8) >> 3));
-            const int g = (d >> 5) + 2 - g0;
-            const uint32_t bit = 1u << ((uint32_t)d & 31u);
-            uint32_t *row = prog + (strand * groups + g) * np;
-            if (__popc(set) == 1) {
-                row[__ffs(set) - 1] |= bit;
-            } else {                                    // never reached with np = 4: the host checked the batch
-                uint32_t missing = (~set) & 15u;
-                while (missing) {
-                    row[4 + __ffs(missing) - 1] |= bit;
-                    missing &= missing - 1;
-                }
-            }
-        }
-    }
-}
-
 __global__ void compile_kernel(uint32_t n_prog, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
                                uint32_t *__restrict__ programs, int wide, int np, int fold_modpos) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n_prog) compile_one(k, rec, masks, programs, wide, np, fold_modpos);
-}
-
-// Light batches (a round of the greedy search): the constraints shared by ALL candidates of a (slot, bin) group — the
-// parent of sibling children (find_motifs_bin.py:1116-1135), the motif under its parents in a pruning round
-// (:1408-1432) — become the group's COMMON program (index n_prog + group), evaluated once per tile; the candidates keep
-// the rest.  One thread per group; groups of 1 or of more than max_group candidates are left alone (range.z = ~0).
-// programs: the candidates' programs (global memory, or the LDS copy compile_common_kernel works on); commons: where the
-// common program of entry g goes (global memory, program index n_prog + g)
-__device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range, uint32_t *programs, uint32_t *commons, uint32_t pdw,
-                                           uint32_t n_prog, uint32_t max_group) {
-    uint4 r = range[g];
-    r.z = 0xFFFFFFFFu;
-    r.w = 0;
-    if (r.y >= 2 && r.y <= max_group) {
-        uint32_t *common = commons + (size_t)g * pdw;
-        uint32_t any = 0;
-        for (uint32_t i = 0; i < pdw; ++i) {
-            uint32_t c = programs[(size_t)r.x * pdw + i];
-            for (uint32_t k = 1; k < r.y; ++k) c &= programs[(size_t)(r.x + k) * pdw + i];
-            common[i] = c;
-            any |= c;
-        }
-        if (any) {
-            // siblings: every candidate keeps at most ONE constraint per strand -> its program shrinks to two
-            // descriptors (mask index << 5 | r; index = dwords per strand when nothing is left) and range.w = 1
-            bool single = true;
-            const uint32_t sdw = pdw / 2;
-            for (uint32_t k = 0; k < r.y; ++k) {
-                uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
-                for (uint32_t i = 0; i < pdw; ++i) prog[i] &= ~common[i];
-                for (uint32_t st = 0; st < 2; ++st) {
-                    uint32_t bits = 0;
-                    for (uint32_t i = 0; i < sdw; ++i) bits += __popc(prog[st * sdw + i]);
-                    if (bits > 1) single = false;
-                }
-            }
-            if (single) {
-                for (uint32_t k = 0; k < r.y; ++k) {
-                    uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
-                    uint32_t desc[2];
-                    for (uint32_t st = 0; st < 2; ++st) {
-                        desc[st] = sdw << 5;
-                        for (uint32_t i = 0; i < sdw; ++i)
-                            if (prog[st * sdw + i]) desc[st] = (i << 5) | (uint32_t)(__ffs(prog[st * sdw + i]) - 1);
-                    }
-                    prog[0] = desc[0];
-                    prog[1] = desc[1];
-                }
-                r.w = 1;
-            }
-            r.z = n_prog + g;
-        }
-    }
-    range[g] = r;
 }
 
 __global__ void common_kernel(uint32_t n_entries, uint4 *__restrict__ range, uint32_t *__restrict__ programs, uint32_t pdw,
@@ -634,6 +542,35 @@ hipError_t device_free(void *p) {
     return hipFree(p);
 }
 
+__global__ __launch_bounds__(256) void stage_in_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n_copy, uint4 *__restrict__ zero,
+                                                       uint32_t n_zero) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t k = i; k < n_copy; k += stride) dst[k] = src[k];
+    for (uint32_t k = i; k < n_zero; k += stride) zero[k] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void stage_out_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint32_t k = i; k < n; k += stride) dst[k] = src[k];
+}
+
+int stage_in(hipStream_t st, const void *h_src, void *d_dst, size_t bytes, void *d_zero, size_t zero_bytes) {
+    const uint32_t n_copy = (uint32_t)((bytes + 15) / 16), n_zero = (uint32_t)((zero_bytes + 15) / 16);
+    const uint32_t blocks = std::max(1u, std::min(256u, (std::max(n_copy, n_zero) + 255) / 256));
+    hipLaunchKernelGGL(stage_in_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4 *>(h_src), static_cast<uint4 *>(d_dst), n_copy,
+                       static_cast<uint4 *>(d_zero), n_zero);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
+int stage_out(hipStream_t st, const void *d_src, void *h_dst, size_t bytes) {
+    const uint32_t n = (uint32_t)((bytes + 15) / 16);
+    hipLaunchKernelGGL(stage_out_kernel, dim3(std::max(1u, std::min(256u, (n + 255) / 256))), dim3(256), 0, st, static_cast<const uint4 *>(d_src),
+                       static_cast<uint4 *>(h_dst), n);
+    HIP_TRY(hipGetLastError());
+    return NM_OK;
+}
+
 int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
     // A pair whose pinned half still holds the results of an open begin / end batch (nm_score_batch_begin,
     // nm_win_batch_w_begin) is never handed out: the next user would copy over — or, growing the pair, free — what
@@ -655,6 +592,7 @@ int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
         idx = c->stage_next;
         if (held(idx)) idx ^= 1;
         c->stage_next = idx ^ 1;
+        for (int tries = 0; tries < NM_STAGE_RING && held(idx); ++tries) idx = (idx + 1) % NM_STAGE_RING;     // (two flights may hold both)
     }
     if (held(idx)) return fail(NM_ESTATE, "staging ring: every pair is held by an uncollected batch");
     nm_ctx::Stage &st = c->stage[idx];
@@ -663,6 +601,7 @@ int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
         HIP_TRY(hipEventSynchronize(st.busy));
         st.pending = false;
     }
+    bytes += 32;                                           // stage_in / stage_out move whole 16-byte words
     if (bytes > st.bytes) {
         const size_t nb = std::max(bytes, st.bytes * 2);
         if (st.d) (void)nmdetail::dev_free(st.d);
@@ -870,14 +809,17 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const bool own_segments = n_prog && n_active_segs * 4 <= (size_t)c->n_segments * 3 && getenv("NM_ALL_SEGMENTS") == nullptr;
     const size_t off_segs = (off_rows + (per_contig ? (size_t)n_prog * 8 : 0) + 15) & ~(size_t)15;
     const size_t off_posof = ((own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_segs) + 15) & ~(size_t)15;     // spec: sorted position of candidate k
-    const size_t total = spec ? off_posof + (size_t)n_cand * 4
+    const size_t off_xin = (off_posof + (size_t)n_cand * 4 + 15) & ~(size_t)15;                                            // spec: the writer's extra input
+    const size_t total = spec ? off_xin + spec->extra_in
                               : own_segments ? off_segs + n_active_segs * sizeof(uint4) : off_rows + (per_contig ? (size_t)n_prog * 8 : 0);
     // host counts come back through the pinned half of the staging pair (a copy into pageable memory is staged by the
     // runtime and costs tens of microseconds more per round of the search); tables too large for that go directly
     const size_t out_bytes = (size_t)out_rows * 2 * sizeof(int64_t);
     const bool via_stage = defer || (h_out && out_bytes <= ((size_t)4 << 20));
     const size_t off_counts = (total + 15) & ~(size_t)15;
-    int rc = ensure_stage(c, via_stage ? off_counts + out_bytes : total, 1);
+    const size_t off_xout = (off_counts + out_bytes + 15) & ~(size_t)15;                // spec: the writer's extra output, behind the counts
+    const size_t stage_end = spec ? off_xout + spec->extra_out : off_counts + out_bytes;
+    int rc = ensure_stage(c, via_stage ? stage_end : total, 1);
     if (rc) return rc;
     // scoring lane of this call (nm_set_score_lanes): asynchronous device-output batches take the lane of their staging
     // pair — a pair, its half of the program table and its stream are reused together; every other call runs on the
@@ -964,14 +906,55 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     // it prepares on the scoring stream itself — no event, no cross-stream wait in its chain of launch latencies
     const bool inline_prep = (h_out || defer) && !c->opt_no_inline;
     hipStream_t pst = inline_prep ? sst : c->copy_stream;
-    HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, pst));
+    if (spec && spec->extra_in) spec->fill_host(hs + off_xin);
     uint8_t *ds = static_cast<uint8_t *>(c->d_stage);
-    if (spec && n_prog) {
-        rc = spec->fill(pst, reinterpret_cast<CandRec *>(ds), reinterpret_cast<const uint32_t *>(ds + off_posof), ds + off_masks,
-                        reinterpret_cast<uint4 *>(ds + off_range), slot_to_active);
-        if (rc) return rc;
+    // ---- output counters
+    unsigned long long *out = spec ? reinterpret_cast<unsigned long long *>(ds + off_counts) : d_out;
+    if (!out) {
+        if (c->counts_cap < out_rows) {
+            if (c->d_counts) (void)nmdetail::dev_free(c->d_counts);
+            c->d_counts = nullptr;
+            c->counts_cap = 0;
+            HIP_TRY(nmdetail::dev_malloc(&c->d_counts, (size_t)out_rows * 2 * sizeof(unsigned long long) * 2));
+            c->counts_cap = (size_t)out_rows * 2;
+        }
+        out = c->d_counts;
     }
-    if (n_prog) {
+    // a batch somebody waits for (a round of the search): tables in, outputs cleared, results out by KERNELS on its own stream — no
+    // copy engine in the chain (nmscan_internal.h: stage_in); everything else keeps the copy engines
+    const bool by_kernels = inline_prep && pst == sst && total <= STAGE_KERNEL_MAX && (via_stage || !h_out) && getenv("NM_STAGE_COPIES") == nullptr;
+    const size_t clear_bytes = spec ? stage_end - off_counts : (size_t)out_rows * 2 * sizeof(unsigned long long);
+    if (by_kernels) {
+        rc = stage_in(pst, c->h_stage, c->d_stage, total, out, clear_bytes);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_stage, c->h_stage, total, hipMemcpyHostToDevice, pst));
+    }
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    const bool timed_launch = c->ev_collect || !defer;          // (a deferred batch of the search is not asked for its kernel time)
+    if (c->ev_collect) {
+        if (c->ev_used == c->ev_pool.size()) {
+            if (c->ev_pool.size() >= 65536) return fail(NM_ESTATE, "timing pool exhausted: call nm_timing_reset");
+            hipEvent_t a_ = nullptr, b_ = nullptr;
+            HIP_TRY(hipEventCreate(&a_));
+            HIP_TRY(hipEventCreate(&b_));
+            c->ev_pool.emplace_back(a_, b_);
+        }
+        e0 = c->ev_pool[c->ev_used].first;
+        e1 = c->ev_pool[c->ev_used].second;
+        c->ev_used += 1;
+    }
+    if (spec) {
+        // counts and the writer's extra output: one clear; the writer (window kernel + children + their programs); timed with the scoring
+        if (!by_kernels) HIP_TRY(hipMemsetAsync(ds + off_counts, 0, clear_bytes, pst));
+        if (timed_launch) HIP_TRY(hipEventRecord(e0, pst));
+        const SpecCompile cc{reinterpret_cast<CandRec *>(ds), reinterpret_cast<const uint32_t *>(ds + off_posof), ds + off_masks,
+                             reinterpret_cast<uint4 *>(ds + off_range), d_prog, pdw, n_prog, (int)np, any_wide, all_compact ? 1 : 0, cf ? 1 : 0};
+        rc = spec->launch(pst, ds + off_xin, ds + off_xout, cc);
+        if (rc) return rc;
+        *spec->h_extra_out = hs + off_xout;
+    }
+    if (n_prog && !spec) {
         if (cf && n_prog <= 2048 && n_entries <= 8192 && !c->opt_no_inline) {
             const size_t lds_bytes = (size_t)n_prog * pdw * 4 <= 48 * 1024 ? (size_t)n_prog * pdw * 4 : 0;
             hipLaunchKernelGGL(compile_common_kernel, dim3(1), dim3(1024), lds_bytes, pst, n_prog, reinterpret_cast<const CandRec *>(ds),
@@ -998,19 +981,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (laned || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
         else HIP_TRY(hipEventSynchronize(c->copy_done));
     }
-    // ---- output counters
-    unsigned long long *out = d_out;
-    if (!out) {
-        if (c->counts_cap < out_rows) {
-            if (c->d_counts) (void)nmdetail::dev_free(c->d_counts);
-            c->d_counts = nullptr;
-            c->counts_cap = 0;
-            HIP_TRY(nmdetail::dev_malloc(&c->d_counts, (size_t)out_rows * 2 * sizeof(unsigned long long) * 2));
-            c->counts_cap = (size_t)out_rows * 2;
-        }
-        out = c->d_counts;
-    }
-    HIP_TRY(hipMemsetAsync(out, 0, (size_t)out_rows * 2 * sizeof(unsigned long long), sst));
+    if (!spec && !by_kernels) HIP_TRY(hipMemsetAsync(out, 0, clear_bytes, sst));
     // ---- launch
     ScoreArgs a{};
     a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
@@ -1053,30 +1024,21 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
     const bool fuse = n_active == 2 && shape.light && lit;
 
-    hipEvent_t e0 = c->ev0, e1 = c->ev1;
-    if (c->ev_collect) {
-        if (c->ev_used == c->ev_pool.size()) {
-            if (c->ev_pool.size() >= 65536) return fail(NM_ESTATE, "timing pool exhausted: call nm_timing_reset");
-            hipEvent_t a_ = nullptr, b_ = nullptr;
-            HIP_TRY(hipEventCreate(&a_));
-            HIP_TRY(hipEventCreate(&b_));
-            c->ev_pool.emplace_back(a_, b_);
-        }
-        e0 = c->ev_pool[c->ev_used].first;
-        e1 = c->ev_pool[c->ev_used].second;
-        c->ev_used += 1;
-    }
-    HIP_TRY(hipEventRecord(e0, sst));
+    if (timed_launch && !spec) HIP_TRY(hipEventRecord(e0, sst));
     if (n_prog) launch_score(a, gx, shape, sst);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(e1, sst));
-    if (via_stage) HIP_TRY(hipMemcpyAsync(hs + off_counts, out, out_bytes, hipMemcpyDeviceToHost, sst));
+    if (timed_launch) HIP_TRY(hipEventRecord(e1, sst));
+    if (by_kernels && (spec || via_stage)) {
+        rc = stage_out(sst, out, hs + off_counts, spec ? stage_end - off_counts : out_bytes);
+        if (rc) return rc;
+    } else if (spec) HIP_TRY(hipMemcpyAsync(hs + off_counts, ds + off_counts, stage_end - off_counts, hipMemcpyDeviceToHost, sst));
+    else if (via_stage) HIP_TRY(hipMemcpyAsync(hs + off_counts, out, out_bytes, hipMemcpyDeviceToHost, sst));
     rc = release_stage(c, sst);
     if (rc) return rc;
     c->cur_stage->last_out = d_out;
     c->cur_stage->last_stream = sst;
     c->last_score_stream = sst;
-    c->timed = !c->ev_collect;
+    c->timed = !c->ev_collect && timed_launch;
     c->launches += 1;
     c->last_wgs = (uint64_t)gx * (fuse ? 1 : std::max(n_active, 1u));
     c->last_compact = all_compact ? n_prog : 0;
@@ -1502,9 +1464,7 @@ static int flight_table(nm_ctx *c, unsigned long long **table, size_t *cap, size
 int nmdetail::score_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const SpecSource &spec,
                                      hipStream_t st) {
     if (n_cand && (!cand_bin || !cand_mod_slot)) return fail(NM_EINVAL, "NULL argument");
-    int rc = flight_table(c, &c->d_spec_counts[flight], &c->spec_counts_cap[flight], n_cand, st);
-    if (rc) return rc;
-    rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, nullptr, nullptr, nullptr, nullptr, c->d_spec_counts[flight], nullptr, nullptr, true, &spec, st, flight);
+    const int rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, &spec, st, flight);
     if (rc) c->spec_wait[flight].open = false;
     return rc;
 }

@@ -186,4 +186,100 @@ inline void slice_program(const uint32_t *full, int G, uint32_t *out) {
         memcpy(out + strand * 2 * G * 8, full + strand * 48 + (3 - G) * 8, (size_t)2 * G * 8 * sizeof(uint32_t));
 }
 
+// ---- candidate records -> constraint programs (nmscan.hip: compile_kernel / common_kernel / compile_common_kernel; nmwindows.hip: the
+// speculative children of the search compile their own)
+// Compile the staged candidates into constraint programs ON THE DEVICE: one thread per candidate.  A literal is one
+// constraint on an is-X plane, a 3-set one on a valid-not-X plane, a 2-set two of those; the reverse strand takes
+// the complemented set at the negated offset (motif.py:260-266).  Program layout: [strand][word-group][plane] with
+// the word-groups the launched variant reads (narrow: groups 1..2, wide: 0..3) and its planes (np = 4: literal-only
+// batch, is-X planes; np = 8); bit r of a word = offset 32 g + r.
+// fold_modpos: the modified position's own constraint is left out (compact batches start the accumulator from the
+// canonical plane instead).
+// prog_slot: where in `programs` the program goes (default: slot k)
+__device__ __forceinline__ void compile_one(uint32_t k, const CandRec *__restrict__ rec, const uint8_t *__restrict__ masks,
+                                            uint32_t *__restrict__ programs, int wide, int np, int fold_modpos, uint32_t prog_slot = 0xFFFFFFFFu) {
+    const int groups = 2 + 2 * wide, g0 = 1 - wide;        // wide: 0 narrow (word-groups 1..2), 1 wide (0..3), 2 extra wide (-1..4)
+    const int pdw = 2 * groups * np;
+    uint32_t *prog = programs + (size_t)(prog_slot == 0xFFFFFFFFu ? k : prog_slot) * pdw;
+    for (int i = 0; i < pdw; ++i) prog[i] = 0;
+    const CandRec c = rec[k];
+    const uint8_t *m = masks + c.mask_off;
+    for (int j = 0; j < c.len; ++j) {
+        const uint32_t set_f = m[j] & 15u;
+        if (set_f == 15u || (fold_modpos && j == c.modpos)) continue;
+        for (int strand = 0; strand < 2; ++strand) {
+            const int d = strand == 0 ? j - (int)c.modpos : (int)c.modpos - j;
+            const uint32_t set = strand == 0 ? set_f
+                                             : (((set_f & 1) << 3) | ((set_f & 2) << 1) | ((set_f & 4) >> 1) | ((set_f & 8) >> 3));
+            const int g = (d >> 5) + 2 - g0;
+            const uint32_t bit = 1u << ((uint32_t)d & 31u);
+            uint32_t *row = prog + (strand * groups + g) * np;
+            if (__popc(set) == 1) {
+                row[__ffs(set) - 1] |= bit;
+            } else {                                    // never reached with np = 4: the host checked the batch
+                uint32_t missing = (~set) & 15u;
+                while (missing) {
+                    row[4 + __ffs(missing) - 1] |= bit;
+                    missing &= missing - 1;
+                }
+            }
+        }
+    }
+}
+
+// Light batches (a round of the greedy search): the constraints shared by ALL candidates of a (slot, bin) group — the
+// parent of sibling children (find_motifs_bin.py:1116-1135), the motif under its parents in a pruning round
+// (:1408-1432) — become the group's COMMON program (index n_prog + group), evaluated once per tile; the candidates keep
+// the rest.  One thread per group; groups of 1 or of more than max_group candidates are left alone (range.z = ~0).
+// programs: the candidates' programs (global memory, or the LDS copy compile_common_kernel works on); commons: where the
+// common program of entry g goes (global memory, program index n_prog + g)
+__device__ __forceinline__ void common_one(uint32_t g, uint4 *__restrict__ range, uint32_t *programs, uint32_t *commons, uint32_t pdw,
+                                           uint32_t n_prog, uint32_t max_group) {
+    uint4 r = range[g];
+    r.z = 0xFFFFFFFFu;
+    r.w = 0;
+    if (r.y >= 2 && r.y <= max_group) {
+        uint32_t *common = commons + (size_t)g * pdw;
+        uint32_t any = 0;
+        for (uint32_t i = 0; i < pdw; ++i) {
+            uint32_t c = programs[(size_t)r.x * pdw + i];
+            for (uint32_t k = 1; k < r.y; ++k) c &= programs[(size_t)(r.x + k) * pdw + i];
+            common[i] = c;
+            any |= c;
+        }
+        if (any) {
+            // siblings: every candidate keeps at most ONE constraint per strand -> its program shrinks to two
+            // descriptors (mask index << 5 | r; index = dwords per strand when nothing is left) and range.w = 1
+            bool single = true;
+            const uint32_t sdw = pdw / 2;
+            for (uint32_t k = 0; k < r.y; ++k) {
+                uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
+                for (uint32_t i = 0; i < pdw; ++i) prog[i] &= ~common[i];
+                for (uint32_t st = 0; st < 2; ++st) {
+                    uint32_t bits = 0;
+                    for (uint32_t i = 0; i < sdw; ++i) bits += __popc(prog[st * sdw + i]);
+                    if (bits > 1) single = false;
+                }
+            }
+            if (single) {
+                for (uint32_t k = 0; k < r.y; ++k) {
+                    uint32_t *prog = programs + (size_t)(r.x + k) * pdw;
+                    uint32_t desc[2];
+                    for (uint32_t st = 0; st < 2; ++st) {
+                        desc[st] = sdw << 5;
+                        for (uint32_t i = 0; i < sdw; ++i)
+                            if (prog[st * sdw + i]) desc[st] = (i << 5) | (uint32_t)(__ffs(prog[st * sdw + i]) - 1);
+                    }
+                    prog[0] = desc[0];
+                    prog[1] = desc[1];
+                }
+                r.w = 1;
+            }
+            r.z = n_prog + g;
+        }
+    }
+    range[g] = r;
+}
+
+
 }  // namespace nmdetail

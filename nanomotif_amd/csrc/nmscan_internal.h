@@ -261,15 +261,41 @@ inline void drop_ingest_rows(nm_ctx *c) {
 int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2 + f: the asynchronous window batch's own pair
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained
+// The tables of a lock-step round are a few KB to a few hundred KB.  As hipMemcpyAsync they go through the SDMA engines: every
+// hand-over between a compute queue and an SDMA queue costs ~10 us, and two chains on two streams block each other at the head of
+// a shared SDMA queue (round 5: the search's scoring batches waited 100 us for the other chain's copy-back).  These two are plain
+// KERNELS on the batch's own stream instead: stage_in copies pinned host memory to the device and clears the outputs in the same
+// launch, stage_out writes results to pinned host memory.  bytes are rounded up to 16 (the staging pairs have the slack).
+constexpr size_t STAGE_KERNEL_MAX = (size_t)4 << 20;     // larger transfers keep the copy engines
+int stage_in(hipStream_t st, const void *h_src, void *d_dst, size_t bytes, void *d_zero, size_t zero_bytes);
+int stage_out(hipStream_t st, const void *d_src, void *h_dst, size_t bytes);
 // A scoring batch whose candidates are WRITTEN ON THE DEVICE (speculative children of the search, nmwindows.hip): the host knows
 // every candidate's (bin, slot) — grouping, ranges, segment table are built as for any batch — but not its motif.  `fill` is
 // called with the tables staged and copied to the device, on the batch's stream, before the programs are compiled: it must set
 // len / modpos of every record (d_rec[pos_of[k]] is caller's candidate k), write its mask bytes (mask_stride reserved each, at
 // d_masks + rec.mask_off) and may lower the candidate count range[entry].y of a group (entry = active index of the slot * n_bins +
 // bin).  The candidates must be literal, compact (the canonical base at the modified position) and reach at most 31 positions.
+// The writer ALSO compiles the programs (what compile_common_kernel does for a host-written batch; compile_one / common_one of
+// nmscan_device.h) and rides in the batch's own staging pair: `extra_in` bytes behind the staged tables (fill_host writes them,
+// they travel in the batch's one host-to-device copy), `extra_out` bytes behind the count table (cleared with it by one memset,
+// copied back with it by one copy; *h_extra_out says where they land in pinned memory).  `launch` is called on the batch's stream
+// with the tables on the device and the outputs cleared, before the scoring kernel.  (The window batch of the search travels
+// this way: six commands for window counts + children's counts.)
+struct SpecCompile {
+    CandRec *rec;
+    const uint32_t *pos_of;
+    uint8_t *masks;
+    uint4 *range;
+    uint32_t *programs;
+    uint32_t pdw, n_prog;
+    int np, wide, fold_modpos, common;        // common: factor the siblings' shared constraints out (common_one), like the batch's kernel expects
+};
 struct SpecSource {
     uint32_t mask_stride;
-    std::function<int(hipStream_t st, CandRec *d_rec, const uint32_t *d_pos_of, uint8_t *d_masks, uint4 *d_range, const int *slot_to_active)> fill;
+    size_t extra_in, extra_out;
+    std::function<void(uint8_t *h_in)> fill_host;
+    std::function<int(hipStream_t st, const uint8_t *d_in, uint8_t *d_extra_out, const SpecCompile &cc)> launch;
+    const void **h_extra_out;
 };
 // begin: everything enqueued on `st`, counts land in the pinned half of a staging pair noted in c->spec_wait[flight] (and stay in c->d_spec_counts[flight])
 int score_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const SpecSource &spec,

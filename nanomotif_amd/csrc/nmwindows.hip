@@ -5,7 +5,7 @@
 #include <cmath>
 #include <thread>
 
-#include "nmscan_internal.h"
+#include "nmscan_device.h"
 
 using namespace nmdetail;
 
@@ -594,9 +594,9 @@ __global__ __launch_bounds__(256) void spec_children_kernel(SpecParams P, const 
                                                             const uint32_t *__restrict__ req_search_task, const uint32_t *__restrict__ req_entry,
                                                             const int *__restrict__ win_out, const double *__restrict__ bg /*[task][4][width]*/,
                                                             int *__restrict__ spec_info /*[n_req][2]: column (-1: none), base rows as bits*/,
-                                                            CandRec *__restrict__ rec, const uint32_t *__restrict__ pos_of, uint8_t *__restrict__ masks,
-                                                            uint4 *__restrict__ range, uint32_t mask_stride) {
-    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                            nmdetail::SpecCompile cc, uint32_t mask_stride) {
+    __shared__ uint32_t lds_prog[4][4 * 64];                         // per wave: its four children's programs while they are built
+    const uint32_t wave = threadIdx.x >> 6, r = blockIdx.x * 4 + wave, lane = threadIdx.x & 63;
     if (r >= P.n_req) return;
     const uint32_t W = P.width;
     const int *o = win_out + (size_t)r * (2 + 4 * P.ws);
@@ -646,17 +646,18 @@ __global__ __launch_bounds__(256) void spec_children_kernel(SpecParams P, const 
         }
     }
     const uint32_t nv = __popc(bases);
+    const uint32_t entry = req_entry[r];
     if (lane == 0) {
         spec_info[2 * r] = nv ? col : -1;
         spec_info[2 * r + 1] = (int)bases;
-        range[req_entry[r]].y = nv;                                   // the group's candidates: its valid children, packed first
+        cc.range[entry].y = nv;                                       // the group's candidates: its valid children, packed first
     }
     // the four records of the request: child c = the c-th passing base (rows in order), the others a harmless one-letter motif
     const uint32_t row_bit[4] = {NM_BASE_A, NM_BASE_T, NM_BASE_G, NM_BASE_C};
     uint32_t left = bases;
     for (uint32_t c = 0; c < 4; ++c) {
-        const uint32_t at = pos_of[4 * r + c];
-        uint8_t *m = masks + rec[at].mask_off;
+        const uint32_t at = cc.pos_of[4 * r + c];
+        uint8_t *m = cc.masks + cc.rec[at].mask_off;
         if (c < nv) {
             const int k = __ffs(left) - 1;
             left &= left - 1;
@@ -664,16 +665,45 @@ __global__ __launch_bounds__(256) void spec_children_kernel(SpecParams P, const 
             const unsigned long long spec_cols = __ballot(lane < W && set != 15u);     // never empty: the modified position is specified
             const int lo = __ffsll((long long)spec_cols) - 1, hi = 63 - __clzll((long long)spec_cols);
             if ((int)lane >= lo && (int)lane <= hi) m[lane - lo] = (uint8_t)set;
-            if (lane == 0) { rec[at].len = (uint8_t)(hi - lo + 1); rec[at].modpos = (uint8_t)(P.pad - lo); }
+            if (lane == 0) { cc.rec[at].len = (uint8_t)(hi - lo + 1); cc.rec[at].modpos = (uint8_t)(P.pad - lo); }
         } else if (lane == 0) {
             m[0] = (uint8_t)sets[P.pad];
-            rec[at].len = 1;
-            rec[at].modpos = 0;
+            cc.rec[at].len = 1;
+            cc.rec[at].modpos = 0;
         }
+    }
+    // ---- the children's programs (what compile_common_kernel does for a host-written batch): built in LDS, one lane per child, the
+    // group's common constraints factored out by lane 0, then copied to the program table.  The four records sit next to each other
+    // (the batch is sorted by (slot, bin) and a group holds exactly this request's children).
+    __threadfence();                                                  // the records and masks written above are read back below
+    const uint32_t first = cc.pos_of[4 * r];
+    uint32_t *wp = lds_prog[wave];
+    if (cc.pdw <= 64) {
+        if (lane < 4) nmdetail::compile_one(first + lane, cc.rec, cc.masks, wp, cc.wide, cc.np, cc.fold_modpos, lane);
+        __threadfence_block();
+        if (lane == 0 && cc.common) {
+            uint4 *rg = cc.range + entry;
+            const uint4 saved = *rg;
+            uint4 local = saved;
+            local.x = 0;                                              // the group's programs start at wp
+            *rg = local;
+            nmdetail::common_one(entry, cc.range, wp, cc.programs + (size_t)cc.n_prog * cc.pdw, cc.pdw, cc.n_prog, 8u);
+            uint4 done = *rg;
+            done.x = saved.x;
+            *rg = done;
+        }
+        __threadfence_block();
+        for (uint32_t i = lane; i < 4 * cc.pdw; i += 64) cc.programs[(size_t)first * cc.pdw + i] = wp[i];
+    } else {
+        if (lane < 4) nmdetail::compile_one(first + lane, cc.rec, cc.masks, cc.programs, cc.wide, cc.np, cc.fold_modpos);
+        __threadfence();
+        if (lane == 0 && cc.common) nmdetail::common_one(entry, cc.range, cc.programs, cc.programs + (size_t)cc.n_prog * cc.pdw, cc.pdw, cc.n_prog, 8u);
     }
 }
 
-// The window batch; spec != NULL: with the speculative children of its PSSM requests scored behind it (see above)
+// The window batch; spec != NULL: with the speculative children of its PSSM requests scored behind it (see above) — then the whole
+// batch rides in the staging pair of that scoring batch: ONE copy in, one clear, window kernel, children kernel, scoring kernel, ONE
+// copy out (a lock-step round of the search is a chain of commands, ~10 us each all told: their number is its cost)
 static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_task, const uint8_t *req_kind, const uint8_t *req_sets,
                                 uint32_t ws, const nmdetail::WinSpec *spec, int flight = 0) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
@@ -710,34 +740,13 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
         c->win_tasks_dirty = false;
     }
     const uint32_t stride = 2 + 4 * ws;
+    // input tables: task, kind, sets (+ spec: the search task and the (slot, bin) range entry of every request); outputs: the counts
+    // (+ spec: {column, bases} per request)
     const size_t o_kind = (size_t)n_req * 4, o_sets = (o_kind + n_req + 15) & ~(size_t)15;
-    // spec: + the search task and the (slot, bin) range entry of every request in front of the outputs, + {column, bases} behind them
     const size_t o_stask = (o_sets + (size_t)n_req * ws + 15) & ~(size_t)15;
     const size_t o_entry = o_stask + (spec ? (size_t)n_req * 4 : 0);
-    const size_t o_out = (o_entry + (spec ? (size_t)n_req * 4 : 0) + 15) & ~(size_t)15;
-    const size_t o_info = o_out + (size_t)n_req * stride * 4;
-    const size_t total = o_info + (spec ? (size_t)n_req * 8 : 0);
-    int rc = ensure_stage(c, total, 2 + flight);  // its own pair: a scoring batch enqueued behind this one never waits for it on the host
-    if (rc) return rc;
-    uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
-    const hipStream_t st = batch_stream(c, flight);
-    memcpy(hs, req_task, (size_t)n_req * 4);
-    memcpy(hs + o_kind, req_kind, n_req);
-    memcpy(hs + o_sets, req_sets, (size_t)n_req * ws);
-    nm_ctx::Stage *const win_stage = c->cur_stage;
-    if (spec) {
-        // range entry of a request's (slot, bin) group in the scoring batch: active index of the slot * n_bins + bin, the active
-        // slots numbered in ascending order (score_impl does the same)
-        bool used[NM_MAX_MOD_SLOTS] = {};
-        for (uint32_t r = 0; r < n_req; ++r) used[spec->req_slot[r]] = true;
-        int act[NM_MAX_MOD_SLOTS], na = 0;
-        for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) act[s] = used[s] ? na++ : -1;
-        uint32_t *h_entry = reinterpret_cast<uint32_t *>(hs + o_entry);
-        for (uint32_t r = 0; r < n_req; ++r) h_entry[r] = (uint32_t)act[spec->req_slot[r]] * c->n_bins + spec->req_bin[r];
-        memcpy(hs + o_stask, spec->req_search_task, (size_t)n_req * 4);
-    }
-    HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ds + o_out, 0, (size_t)n_req * stride * 4, st));
+    const size_t in_bytes = (o_entry + (spec ? (size_t)n_req * 4 : 0) + 15) & ~(size_t)15;
+    const size_t out_bytes = (size_t)n_req * stride * 4, info_bytes = spec ? (size_t)n_req * 8 : 0;
     // slices of a task's words per request (blockIdx.z): one workgroup per 256 words when the batch is small, fewer and
     // fatter ones when a thousand requests already fill the device several times over (a workgroup's fixed cost — the match
     // mask set-up, the reduction of its 34 counters, its atomics — is most of what it does)
@@ -747,38 +756,79 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
         const uint64_t want = std::max<uint64_t>(1, (uint64_t)c->n_cus * 8 / std::max<uint64_t>(1, (uint64_t)n_req * n_col_groups));
         gz = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gz, want));
     }
+    const hipStream_t st = batch_stream(c, flight);
+    auto fill_tables = [&](uint8_t *h) {
+        memcpy(h, req_task, (size_t)n_req * 4);
+        memcpy(h + o_kind, req_kind, n_req);
+        memcpy(h + o_sets, req_sets, (size_t)n_req * ws);
+        if (!spec) return;
+        // range entry of a request's (slot, bin) group in the scoring batch: active index of the slot * n_bins + bin, the active
+        // slots numbered in ascending order (score_impl does the same)
+        bool used[NM_MAX_MOD_SLOTS] = {};
+        for (uint32_t r = 0; r < n_req; ++r) used[spec->req_slot[r]] = true;
+        int act[NM_MAX_MOD_SLOTS], na = 0;
+        for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) act[s] = used[s] ? na++ : -1;
+        uint32_t *h_entry = reinterpret_cast<uint32_t *>(h + o_entry);
+        for (uint32_t r = 0; r < n_req; ++r) h_entry[r] = (uint32_t)act[spec->req_slot[r]] * c->n_bins + spec->req_bin[r];
+        memcpy(h + o_stask, spec->req_search_task, (size_t)n_req * 4);
+    };
+    if (spec) {
+        // four candidate slots per request, (bin, slot) known here, motifs written by spec_children_kernel from the window counts
+        std::vector<uint32_t> cbin((size_t)n_req * 4);
+        std::vector<uint8_t> cslot((size_t)n_req * 4);
+        for (uint32_t r = 0; r < n_req; ++r)
+            for (int k = 0; k < 4; ++k) { cbin[4 * r + k] = spec->req_bin[r]; cslot[4 * r + k] = spec->req_slot[r]; }
+        const void *h_out = nullptr;
+        nmdetail::SpecSource src;
+        src.mask_stride = ws;
+        src.extra_in = in_bytes;
+        src.extra_out = out_bytes + info_bytes;
+        src.h_extra_out = &h_out;
+        src.fill_host = fill_tables;
+        const SpecParams P{n_req, ws, spec->width, spec->pad, spec->min_kl, spec->freq_threshold};
+        src.launch = [&](hipStream_t s, const uint8_t *d_in, uint8_t *d_out, const nmdetail::SpecCompile &cc) -> int {
+            hipLaunchKernelGGL(win_request_kernel, dim3(n_req, n_col_groups, gz), dim3(256), 0, s, c->d_win_tasks, n_req, reinterpret_cast<const uint32_t *>(d_in),
+                               d_in + o_kind, d_in + o_sets, c->d_win_planes, c->d_win_alive, reinterpret_cast<int *>(d_out), ws);
+            hipLaunchKernelGGL(spec_children_kernel, dim3((n_req + 3) / 4), dim3(256), 0, s, P, d_in + o_kind, d_in + o_sets,
+                               reinterpret_cast<const uint32_t *>(d_in + o_stask), reinterpret_cast<const uint32_t *>(d_in + o_entry),
+                               reinterpret_cast<const int *>(d_out), c->d_spec_bg, reinterpret_cast<int *>(d_out + out_bytes), cc, ws);
+            HIP_TRY(hipGetLastError());
+            return NM_OK;
+        };
+        const int rc = nmdetail::score_batch_spec_begin(c, flight, n_req * 4, cbin.data(), cslot.data(), src, st);
+        if (rc) return rc;
+        c->win_wait[flight] = nm_ctx::Waiting{h_out, out_bytes, c->spec_wait[flight].stage, true};
+        return NM_OK;
+    }
+    const size_t o_out = in_bytes;
+    int rc = ensure_stage(c, o_out + out_bytes, 2 + flight);   // its own pair: a scoring batch enqueued behind this one never waits for it on the host
+    if (rc) return rc;
+    uint8_t *hs = static_cast<uint8_t *>(c->h_stage), *ds = static_cast<uint8_t *>(c->d_stage);
+    fill_tables(hs);
+    // tables in, counts cleared, counts out: kernels on the batch's stream, no copy engine in the chain (nmscan_internal.h: stage_in)
+    const bool by_kernels = o_out + out_bytes <= nmdetail::STAGE_KERNEL_MAX && getenv("NM_STAGE_COPIES") == nullptr;
+    if (by_kernels) {
+        rc = nmdetail::stage_in(st, hs, ds, o_out, ds + o_out, out_bytes);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(ds, hs, o_out, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(ds + o_out, 0, out_bytes, st));
+    }
     busy_begin_on(c, st);
     hipLaunchKernelGGL(win_request_kernel, dim3(n_req, n_col_groups, gz), dim3(256), 0, st, c->d_win_tasks, n_req,
                        reinterpret_cast<const uint32_t *>(ds), ds + o_kind, ds + o_sets, c->d_win_planes, c->d_win_alive,
                        reinterpret_cast<int *>(ds + o_out), ws);
     busy_end_on(c, st);
     HIP_TRY(hipGetLastError());
-    if (spec) {
-        // four candidate slots per request, (bin, slot) known here, motifs written by spec_children_kernel from the counts above
-        std::vector<uint32_t> cbin((size_t)n_req * 4);
-        std::vector<uint8_t> cslot((size_t)n_req * 4);
-        for (uint32_t r = 0; r < n_req; ++r)
-            for (int k = 0; k < 4; ++k) { cbin[4 * r + k] = spec->req_bin[r]; cslot[4 * r + k] = spec->req_slot[r]; }
-        nmdetail::SpecSource src;
-        src.mask_stride = ws;
-        const SpecParams P{n_req, ws, spec->width, spec->pad, spec->min_kl, spec->freq_threshold};
-        src.fill = [&](hipStream_t s, nmdetail::CandRec *d_rec, const uint32_t *d_pos_of, uint8_t *d_masks, uint4 *d_range, const int *) -> int {
-            hipLaunchKernelGGL(spec_children_kernel, dim3((n_req + 3) / 4), dim3(256), 0, s, P, ds + o_kind, ds + o_sets,
-                               reinterpret_cast<const uint32_t *>(ds + o_stask), reinterpret_cast<const uint32_t *>(ds + o_entry),
-                               reinterpret_cast<const int *>(ds + o_out), c->d_spec_bg, reinterpret_cast<int *>(ds + o_info), d_rec, d_pos_of, d_masks,
-                               d_range, ws);
-            HIP_TRY(hipGetLastError());
-            return NM_OK;
-        };
-        // (no busy_begin / busy_end bracket: the scoring launch inside takes its own event pair from the same pool)
-        rc = nmdetail::score_batch_spec_begin(c, flight, n_req * 4, cbin.data(), cslot.data(), src, st);
-        c->cur_stage = win_stage;                                     // (the scoring batch took a pair of its own)
+    if (by_kernels) {
+        rc = nmdetail::stage_out(st, ds + o_out, hs + o_out, out_bytes);
         if (rc) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, out_bytes, hipMemcpyDeviceToHost, st));
     }
-    HIP_TRY(hipMemcpyAsync(hs + o_out, ds + o_out, total - o_out, hipMemcpyDeviceToHost, st));
     rc = release_stage(c, st);
     if (rc) return rc;
-    c->win_wait[flight] = nm_ctx::Waiting{hs + o_out, (size_t)n_req * stride * 4, c->cur_stage, true};
+    c->win_wait[flight] = nm_ctx::Waiting{hs + o_out, out_bytes, c->cur_stage, true};
     return NM_OK;
 }
 
