@@ -442,7 +442,7 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         legs = {}
-        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1"})):      # (the second run also prints the parser's per-slab split)
+        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})):      # (the second run also prints the parser's per-slab split)
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv",
                                 "--out", "out_" + leg], cwd=tmp, env=dict(env, **extra_env), capture_output=True, text=True)
@@ -458,6 +458,7 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                 "fasta_s": t.get("assembly_s"), "fasta_reading_s": t.get("assembly_reading_s"), "fasta_parser": t.get("assembly_parser"),
                 "pileup_s": t.get("pileup_parse_s"), "pileup_read_s": t.get("pileup_reading_s"), "pileup_inflate_s": t.get("pileup_inflating_s"),
                 "pileup_parse_s": t.get("pileup_parsing_s"), "pileup_parser": t.get("pileup_parser"),
+                "pileup_index_and_block_walk_s": (t.get("pileup_parse_s") - t.get("pileup_in_parser_s")) if t.get("pileup_in_parser_s") else None,
                 "filters_s": t.get("upload_filter_s"), "search_s": t.get("search_s"), "write_s": t.get("write_s"),
             }
             rates = {
@@ -469,12 +470,12 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                 "raw_rows_GB_per_s_filters": gb(22 * sizes["rows"], t.get("upload_filter_s")),
                 "pcie_h2d_measured_GB_per_s": 57.0,
             }
-            timed = {k: v for k, v in phases.items() if k.endswith("_s") and isinstance(v, float) and k not in ("fasta_reading_s", "pileup_read_s", "pileup_inflate_s", "pileup_parse_s")}
+            timed = {k: v for k, v in phases.items() if k.endswith("_s") and isinstance(v, float) and k not in ("fasta_reading_s", "pileup_read_s", "pileup_inflate_s", "pileup_parse_s", "pileup_index_and_block_walk_s")}
             legs[leg] = {"wall_s": wall, "in_find_motifs_bin_s": t.get("find_motifs_bin_s"), "phases": phases, "rates": rates,
                          "the_wall_is": max(timed, key=timed.get), "assembly_s_per_Gbp": (t.get("assembly_s") or 0.0) / (total_bp / 1e9),
                          "motif_rows": max(len(open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read().splitlines()) - 1, 0)}
             if extra_env:
-                legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith("[bed]")][:64]
+                legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith(("[bed]", "[fasta]", "[nm_search]"))][:80]
         out["legs"] = legs
         texts = {leg: open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read() for leg in legs if "error" not in legs[leg]}
         if len(texts) == 2:

@@ -176,7 +176,8 @@ def find_motifs_bin(args):
     lap("pileup_parse_s")
     TIMINGS["pileup_parser"] = "device" if on_device else "host"
     if on_device:
-        TIMINGS.update(pileup_reading_s=table.seconds_reading, pileup_inflating_s=table.seconds_inflating, pileup_parsing_s=table.seconds_parsing)
+        TIMINGS.update(pileup_reading_s=table.seconds_reading, pileup_inflating_s=table.seconds_inflating, pileup_parsing_s=table.seconds_parsing,
+                       pileup_in_parser_s=table.seconds)       # (the rest of pileup_parse_s: the tabix index, the walk over the BGZF blocks, the tables)
     TIMINGS["pileup_rows"] = len(table)
 
     # engine: this rank's contigs (all contigs that belong to a bin).  Several GPUs: whole bins per GPU when they

@@ -12,9 +12,11 @@ Polars semantics this stand-in ASSUMES (stated in DESIGN.md §2 as well):
     ``pl.count()`` counts rows whatever they hold, ``(expr).sum()`` skips nulls;
   * ``group_by`` yields its groups in first-appearance order (polars: unspecified; nothing recorded depends on it — every
     recorded table is sorted);
-  * ``unique()`` compares Object cells the way py-polars does, through Python ``__hash__`` / ``__eq__`` — identity for
-    ``BetaBernoulliModel``; every fixture records whether a stage ever held two rows with the same motif (none does), so
-    no recorded value rests on this;
+  * ``unique()`` compares Object cells the way py-polars does (its ObjectValue hashes and compares through the Python
+    object's ``__hash__`` / ``__eq__``) — identity for ``BetaBernoulliModel``, which defines neither: two rows that hold
+    different model OBJECTS are two rows, whatever the counts.  g8-g12 record that no stage of theirs held one motif twice;
+    g13 (round 5) records families in which two merge clusters produce the same motif and both rows stay — the product
+    follows this since round 5;
   * ``sort`` is stable; a left ``join`` drops the right frame's key columns and suffixes the right frame's other columns
     that clash; ``concat`` is vertical and needs equal column sets.
 ``nm.motif.MotifSearchResult`` (a subclass of the REAL ``pl.DataFrame`` that reaches into polars internals) is replaced by
