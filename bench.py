@@ -893,23 +893,27 @@ def main():
             g_bytes = ALGO_BYTES_PER_BP_STEP * sum(my_bin_bp.get(b, 0) for b, _ in g_groups) + 16 * len(g_cands)
             g_ms = allmax([g_ms])[0]
             tr = load_traffic("greedy", args.total_bp, len(g_cands)) if world == 1 else None
-            # frac = what the DRAM counters saw / time / 8 TB/s (the fused two-slot launch reads the sequence planes once for
-            # both mod types: 0.83 GB, not the 1.0 GB the algorithmic 0.5 B/bp/slot charges); the algorithmic figure is kept
-            # beside it.  Without a counter entry for this configuration frac falls back to the algorithmic bytes and says so.
-            traffic_bytes = tr["hbm_bytes_per_launch"] if tr else None
+            # frac = ALGORITHMIC bytes / live kernel time / 8 TB/s, like the main roofline (round-4 advisor: a fraction must not mix a
+            # recorded counter value of another build with a live time).  What the DRAM counters saw (the fused two-slot launch reads
+            # the sequence planes once for both mod types: 0.83 GB, not the 1.0 GB that 0.5 B/bp/slot charges) stands beside it under
+            # its own keys, with the sha of the kernel sources it was measured on, and only while that sha is the current one.
+            traffic_bytes = tr["hbm_bytes_per_launch"] if tr and not tr.get("stale") else None
             hbm_round = {"workload": f"greedy round: {len(g_cands)} candidates = 2 sibling children per (bin, mod type)",
                          "bound": "hbm", "kernel_ms": g_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "achieved": (traffic_bytes if traffic_bytes else g_bytes) / (g_ms * 1e-3) / 1e9,
-                         "frac": (traffic_bytes if traffic_bytes else g_bytes) / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "frac_is": "counter traffic / time / peak" if traffic_bytes else "algorithmic bytes / time / peak (no counter entry for this configuration)",
+                         "achieved": g_bytes / (g_ms * 1e-3) / 1e9,
+                         "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_is": "algorithmic bytes / live kernel time / peak",
+                         "counter_achieved": traffic_bytes / (g_ms * 1e-3) / 1e9 if traffic_bytes else None,
+                         "counter_frac": traffic_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic_bytes else None,
+                         "counter_entry_sha16": tr.get("kernel_source_sha16") if tr else None, "counter_entry_stale": bool(tr.get("stale")) if tr else None,
                          "algorithmic_achieved": g_bytes / (g_ms * 1e-3) / 1e9, "algorithmic_frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": g_bytes, "launches": args.hbm_round_steps,
                          "traffic": traffic_bytes,
                          # the fused two-slot launch reads the sequence planes once for both mod types: real DRAM bytes are
                          # below the algorithmic 0.5 B/bp/slot; this is the fraction of the device's streaming rate they reach
-                         "traffic_rate_GBs": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 if tr else None,
-                         "traffic_frac_of_spec": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
-                         "traffic_frac_of_streaming": tr["hbm_bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / HBM_STREAM_GBS if tr else None,
+                         "traffic_rate_GBs": traffic_bytes / (g_ms * 1e-3) / 1e9 if traffic_bytes else None,
+                         "traffic_frac_of_spec": traffic_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic_bytes else None,
+                         "traffic_frac_of_streaming": traffic_bytes / (g_ms * 1e-3) / 1e9 / HBM_STREAM_GBS if traffic_bytes else None,
                          "streaming_peak_GBs": HBM_STREAM_GBS,
                          "motif_sites_per_s": sum(2 * bin_bp[b] for _, _, b in g_cands) / (g_ms * 1e-3)}
     except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:

@@ -429,6 +429,14 @@ __global__ __launch_bounds__(256) void bed_crc_kernel(const InfPiece *__restrict
     if (lane == 63 && c != pc.crc) atomicCAS(status, 0u, 19u | (i << 8));
 }
 
+// a slab's results for the host, written straight into pinned memory (no copy engine on the inflate stream: see parse_device_impl)
+__global__ void bed_report_kernel(const unsigned long long *__restrict__ tail, unsigned long long total, const unsigned int *__restrict__ status,
+                                  unsigned long long *h_end_of_lines, unsigned long long *h_status) {
+    *h_end_of_lines = tail ? *tail : total;
+    *h_status = *status;
+    __threadfence_system();
+}
+
 // the byte after the last '\n' of text[0, n) (0 when there is none in the last `window` bytes): what lies behind it is the
 // beginning of a line that continues in the next slab.  One workgroup.
 __global__ __launch_bounds__(256) void bed_tail_kernel(const uint8_t *__restrict__ text, uint64_t n, uint64_t window, unsigned long long *out) {
@@ -785,7 +793,8 @@ int map_file(const char *path, TextSource *src) {
         if (m == MAP_FAILED) { close(fd); src->zn = 0; return fail(NM_EINVAL, "cannot map pileup '%s'", path); }
         src->z = static_cast<const uint8_t *>(m);
     }
-    close(fd);
+    if (src->fd >= 0) close(src->fd);
+    src->fd = fd;                                      // kept: the walk over the BGZF blocks reads their headers through it (nmbgzf.h)
     return NM_OK;
 }
 
@@ -855,7 +864,7 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
     if (rc) return rc;
     {
         const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated, &block_starts,
-                                                       threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+                                                       threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())), src.fd);
         if (!what.empty()) return fail(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     src.bgzf = true;
@@ -1150,8 +1159,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
 #endif
         size_t n_chunk = 0;
         const unsigned nt = std::max(1u, threads - 1);
-        unsigned long long end_of_lines_h[2] = {0, 0};
-        unsigned int status_h[2] = {0, 0};
+        // where a slab's last whole line ends and the inflate status come back through PINNED words written by a kernel on the inflate
+        // stream: a hipMemcpyAsync there would sit in a copy-engine queue behind the inflate kernel it waits for — and in front of the
+        // next slab's compressed bytes on the copy stream, which then travel only after the inflate (measured: 0.036 s of 0.042 per slab)
+        unsigned long long *h_words = nullptr;                         // [2] end of lines, [2] status
+        HIP_TRY(hipHostMalloc((void **)&h_words, 64, hipHostMallocDefault));
+        struct FreeWords { unsigned long long *p; hipStream_t &is; ~FreeWords() { if (is) (void)hipStreamSynchronize(is); (void)hipHostFree(p); } } free_words{h_words, inf_stream};
+        volatile unsigned long long *end_of_lines_h = h_words, *status_h = h_words + 2;
         double t_copy_slab[2] = {0, 0};
         // stages (1) and (2) of slab si: everything it needs goes to the device, its inflate is queued
         auto stage_slab = [&](size_t si) -> int {
@@ -1206,13 +1220,14 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             }
             // where the last whole line ends; what follows it is carried into the next slab
             const uint64_t total = CARRY_CAP + sl.text;
-            end_of_lines_h[b] = total;
-            if (si + 1 != inf_slabs.size()) {
+            const bool want_tail = si + 1 != inf_slabs.size();
+            if (want_tail) {
                 hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, inf_stream, text, total, CARRY_CAP, d_tail + b);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(&end_of_lines_h[b], d_tail + b, 8, hipMemcpyDeviceToHost, inf_stream));
             }
-            HIP_TRY(hipMemcpyAsync(&status_h[b], d_status, 4, hipMemcpyDeviceToHost, inf_stream));
+            hipLaunchKernelGGL(bed_report_kernel, dim3(1), dim3(1), 0, inf_stream, want_tail ? d_tail + b : nullptr, (unsigned long long)total, d_status,
+                               h_words + b, h_words + 2 + b);
+            HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(inflated[b], inf_stream));
             return NM_OK;
         };
@@ -1233,7 +1248,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             HIP_TRY(hipEventSynchronize(inflated[bi]));
             const double t_inflated = now();
             b->t_inflate += t_inflated - t_wait;
-            const unsigned int status = status_h[bi];
+            const unsigned int status = (unsigned int)status_h[bi];
             const unsigned long long end_of_lines = end_of_lines_h[bi];
             const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
             if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
