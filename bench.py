@@ -442,7 +442,8 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         legs = {}
-        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})):      # (the second run also prints the parser's per-slab split)
+        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})) + tuple(
+                (f"slab_{int(x) >> 20}M", {"NM_BED_INFLATE_SLAB": x, "NM_BED_TIMING": "1"}) for x in os.environ.get("NM_BENCH_CLI1G_SLABS", "").split(",") if x):      # (the second run also prints the parser's per-slab split)
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv",
                                 "--out", "out_" + leg], cwd=tmp, env=dict(env, **extra_env), capture_output=True, text=True)
@@ -478,8 +479,8 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                 legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith(("[bed]", "[fasta]", "[nm_search]"))][:80]
         out["legs"] = legs
         texts = {leg: open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read() for leg in legs if "error" not in legs[leg]}
-        if len(texts) == 2:
-            out["both_runs_byte_equal"] = texts["cold"] == texts["again"]
+        if len(texts) >= 2:
+            out["both_runs_byte_equal"] = all(t == texts["cold"] for t in texts.values())
         # parity: the rows of `parity_bins` seeded bins against the oracle pipeline (CPU; bgzip task order and seeding)
         if texts and parity_bins:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
