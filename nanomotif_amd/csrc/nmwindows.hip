@@ -672,28 +672,67 @@ __global__ __launch_bounds__(256) void spec_children_kernel(SpecParams P, const 
             cc.rec[at].modpos = 0;
         }
     }
-    // ---- the children's programs (what compile_common_kernel does for a host-written batch): built in LDS, one lane per child, the
-    // group's common constraints factored out by lane 0, then copied to the program table.  The four records sit next to each other
-    // (the batch is sorted by (slot, bin) and a group holds exactly this request's children).
+    // ---- the children's programs (what compile_common_kernel does for a host-written batch): built in LDS, one lane per child; the
+    // group's common constraints are factored out by the WAVE — lane i owns dword i of the programs (common_one of nmscan_device.h
+    // walks them on one thread: 12 us of dependent LDS round trips per request) —, then the programs go to the table.  The four
+    // records sit next to each other (the batch is sorted by (slot, bin) and a group holds exactly this request's children).
     __threadfence();                                                  // the records and masks written above are read back below
     const uint32_t first = cc.pos_of[4 * r];
     uint32_t *wp = lds_prog[wave];
     if (cc.pdw <= 64) {
+        const uint32_t pdw = cc.pdw, sdw = pdw / 2;
         if (lane < 4) nmdetail::compile_one(first + lane, cc.rec, cc.masks, wp, cc.wide, cc.np, cc.fold_modpos, lane);
         __threadfence_block();
-        if (lane == 0 && cc.common) {
-            uint4 *rg = cc.range + entry;
-            const uint4 saved = *rg;
-            uint4 local = saved;
-            local.x = 0;                                              // the group's programs start at wp
-            *rg = local;
-            nmdetail::common_one(entry, cc.range, wp, cc.programs + (size_t)cc.n_prog * cc.pdw, cc.pdw, cc.n_prog, 8u);
-            uint4 done = *rg;
-            done.x = saved.x;
-            *rg = done;
+        uint4 rg = cc.range[entry];
+        rg.y = nv;
+        rg.z = 0xFFFFFFFFu;
+        rg.w = 0;
+        if (cc.common && nv >= 2) {
+            // common[i] = AND over the children of their dword i
+            uint32_t common = 0xFFFFFFFFu;
+            if (lane < pdw) for (uint32_t k = 0; k < nv; ++k) common &= wp[k * pdw + lane];
+            else common = 0;
+            if (__ballot(common != 0)) {
+                if (lane < pdw) cc.programs[((size_t)cc.n_prog + entry) * pdw + lane] = common;
+                // every child keeps what is not common; siblings keep at most ONE constraint per strand: then a child's program
+                // shrinks to two descriptors (dword index << 5 | bit; index = dwords per strand when nothing is left)
+                bool single = true;
+                uint32_t rest[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < nv; ++k) {
+                    rest[k] = lane < pdw ? wp[k * pdw + lane] & ~common : 0u;
+                    const unsigned long long nz = __ballot(rest[k] != 0);
+                    const unsigned long long lo_mask = sdw >= 64 ? ~0ull : ((1ull << sdw) - 1);
+                    const unsigned long long s0 = nz & lo_mask, s1 = (nz >> sdw) & lo_mask;
+                    // more than one dword of a strand left, or more than one bit in the one that is
+                    if (__popcll(s0) > 1 || __popcll(s1) > 1) single = false;
+                    if (__ballot(rest[k] != 0 && __popc(rest[k]) > 1)) single = false;
+                }
+                for (uint32_t k = 0; k < nv; ++k) {
+                    if (single) {
+                        const unsigned long long nz = __ballot(rest[k] != 0);
+                        const unsigned long long lo_mask = sdw >= 64 ? ~0ull : ((1ull << sdw) - 1);
+                        uint32_t desc[2];
+                        for (uint32_t st = 0; st < 2; ++st) {
+                            const unsigned long long sm = (nz >> (st * sdw)) & lo_mask;
+                            desc[st] = sdw << 5;
+                            if (sm) {
+                                const int i = __ffsll((long long)sm) - 1;                       // dword within the strand
+                                const uint32_t word = __shfl(rest[k], (int)(st * sdw) + i);
+                                desc[st] = ((uint32_t)i << 5) | (uint32_t)(__ffs(word) - 1);
+                            }
+                        }
+                        if (lane < pdw) wp[k * pdw + lane] = lane == 0 ? desc[0] : lane == 1 ? desc[1] : rest[k];
+                    } else if (lane < pdw) {
+                        wp[k * pdw + lane] = rest[k];
+                    }
+                }
+                rg.w = single ? 1u : 0u;
+                rg.z = cc.n_prog + entry;
+            }
         }
+        if (lane == 0) cc.range[entry] = rg;
         __threadfence_block();
-        for (uint32_t i = lane; i < 4 * cc.pdw; i += 64) cc.programs[(size_t)first * cc.pdw + i] = wp[i];
+        for (uint32_t i = lane; i < 4 * pdw; i += 64) cc.programs[(size_t)first * pdw + i] = wp[i];
     } else {
         if (lane < 4) nmdetail::compile_one(first + lane, cc.rec, cc.masks, cc.programs, cc.wide, cc.np, cc.fold_modpos);
         __threadfence();
