@@ -442,8 +442,10 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         legs = {}
-        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})) + tuple(
-                (f"slab_{int(x) >> 20}M", {"NM_BED_INFLATE_SLAB": x, "NM_BED_TIMING": "1"}) for x in os.environ.get("NM_BENCH_CLI1G_SLABS", "").split(",") if x):      # (the second run also prints the parser's per-slab split)
+        # NM_BENCH_CLI1G_LEGS = "name:KEY=VALUE;KEY=VALUE,name2:..." adds A/B legs with other environments (builder probes)
+        more = tuple((spec.split(":", 1)[0], dict(kv.split("=", 1) for kv in spec.split(":", 1)[1].split(";") if kv), )
+                     for spec in os.environ.get("NM_BENCH_CLI1G_LEGS", "").split(",") if ":" in spec)
+        for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})) + more:      # (the second run also prints the parser's per-slab split)
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv",
                                 "--out", "out_" + leg], cwd=tmp, env=dict(env, **extra_env), capture_output=True, text=True)

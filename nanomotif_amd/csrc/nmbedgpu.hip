@@ -908,7 +908,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     const bool dev_inflate = src.bgzf && getenv("NM_BED_HOST_INFLATE") == nullptr;
     // device inflate: slabs of whole BLOCKS (up to 3 GiB of text: line offsets are 32-bit), a line that straddles two slabs is
     // carried over on the device
-    constexpr uint64_t INF_SLAB_TEXT = 3ull << 29, CARRY_CAP = 1ull << 20;      // 1.5 GiB of text per slab, two slabs in flight
+    constexpr uint64_t INF_SLAB_TEXT = 3ull << 30, CARRY_CAP = 1ull << 20;      // 3 GiB of text per slab (49 000 blocks: every lane slot of the device), two slabs in flight
     // The compressed bytes of a slab travel as CHUNKS: byte ranges of the file (the few bytes of gzip header / trailer between two
     // blocks ride along), copied into the pinned buffers in a few large pieces — no per-block work on the host.
     struct InfChunk { size_t first, last; uint64_t file_lo, file_hi, dev_off; };
@@ -1116,7 +1116,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         // (2) inflate stream: bed_inflate_kernel + CRC-32 + end of the last whole line, into one of TWO text buffers; (3) ctx stream:
         // the line / field kernels.  Slab k+1 is copied and its inflate queued while slab k inflates; slab k is parsed while
         // slab k+1 inflates (the inflate lanes wait on memory most of the time: the parse kernels run beside them).  Everything a
-        // slab owns on the device exists twice; a slab is half as large as before, so the memory is what it was.
+        // slab owns on the device exists twice (2 x 3 GiB of text: slabs of 1.5 GiB were 6 % slower, 47 against 50 GB/s — a slab
+        // should fill every lane slot the kernel's LDS tables leave).
         constexpr uint64_t CHUNK = SLAB_BYTES;                        // compressed bytes per pinned buffer
         uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp[2] = {nullptr, nullptr}, *d_scratch[2] = {nullptr, nullptr};
         InfPiece *d_pieces[2] = {nullptr, nullptr};
@@ -1156,7 +1157,18 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             if (is) (void)hipStreamDestroy(is);
         } } pinned{h_chunk, chunk_done, inflated, parsed_ev, copy_stream, inf_stream};
         if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&inf_stream, hipStreamNonBlocking));
+        {
+            // The inflate stream gets the LOWEST priority, which also gives it a hardware queue of its own: the runtime deals streams of
+            // one priority round-robin onto 4 hardware queues, and when this stream landed on the copy stream's queue the next slab's
+            // host-to-device copies only ran between two inflate kernels (measured, tools/gpu_r5k.sh: 0.047 s per slab against 0.034 s
+            // with GPU_MAX_HW_QUEUES=8 — per slab inflate + copy instead of their maximum).  A long-running, latency-bound kernel is
+            // the right thing to give way to copies and parse kernels in any case.
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && getenv("NM_BED_FLAT_PRIORITY") == nullptr)
+                HIP_TRY(hipStreamCreateWithPriority(&inf_stream, hipStreamNonBlocking, least));
+            else
+                HIP_TRY(hipStreamCreateWithFlags(&inf_stream, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));       // (a chunk is at most SLAB_BYTES = CHUNK of file)
             HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));

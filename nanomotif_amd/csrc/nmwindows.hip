@@ -545,7 +545,16 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
 static hipStream_t batch_stream(nm_ctx *c, int flight = 0) {
     static const bool second = getenv("NM_WIN_STREAM") == nullptr || atoi(getenv("NM_WIN_STREAM")) != 0;
     if (flight == 1 && second) {                     // the second flight of the search: a stream of its own, made on first use
-        if (!c->flight_stream && hipStreamCreateWithFlags(&c->flight_stream, hipStreamNonBlocking) != hipSuccess) c->flight_stream = nullptr;
+        if (!c->flight_stream) {
+            // A plain stream.  NM_FLIGHT_PRIORITY=1 gives it a priority — and with it a hardware queue — of its own (A/B, tools/gpu_r5l.sh):
+            // the search gets SLOWER (window batches 12.8 -> 22 ms at 1 Gbp, as with GPU_MAX_HW_QUEUES=8): two chains of small kernels
+            // that run truly side by side lengthen each other more than taking turns on one queue costs
+            int least = 0, greatest = 0;
+            const bool prio = getenv("NM_FLIGHT_PRIORITY") != nullptr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+            const hipError_t e = prio ? hipStreamCreateWithPriority(&c->flight_stream, hipStreamNonBlocking, greatest)
+                                      : hipStreamCreateWithFlags(&c->flight_stream, hipStreamNonBlocking);
+            if (e != hipSuccess) c->flight_stream = nullptr;
+        }
         if (c->flight_stream) return c->flight_stream;
     }
     return second && c->copy_stream ? c->copy_stream : c->stream;
