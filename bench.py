@@ -462,6 +462,8 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                 "pileup_s": t.get("pileup_parse_s"), "pileup_read_s": t.get("pileup_reading_s"), "pileup_inflate_s": t.get("pileup_inflating_s"),
                 "pileup_parse_s": t.get("pileup_parsing_s"), "pileup_parser": t.get("pileup_parser"),
                 "pileup_index_and_block_walk_s": (t.get("pileup_parse_s") - t.get("pileup_in_parser_s")) if t.get("pileup_in_parser_s") else None,
+                # the tabix index + the walk over the BGZF blocks, done on a thread beside the engine start and the FASTA parse (not in pileup_s)
+                "pileup_plan_on_a_thread_s": t.get("pileup_plan_s_on_a_thread"),
                 "filters_s": t.get("upload_filter_s"), "search_s": t.get("search_s"), "write_s": t.get("write_s"),
             }
             rates = {
@@ -473,7 +475,7 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                 "raw_rows_GB_per_s_filters": gb(22 * sizes["rows"], t.get("upload_filter_s")),
                 "pcie_h2d_measured_GB_per_s": 57.0,
             }
-            timed = {k: v for k, v in phases.items() if k.endswith("_s") and isinstance(v, float) and k not in ("fasta_reading_s", "pileup_read_s", "pileup_inflate_s", "pileup_parse_s", "pileup_index_and_block_walk_s")}
+            timed = {k: v for k, v in phases.items() if k.endswith("_s") and isinstance(v, float) and k not in ("fasta_reading_s", "pileup_read_s", "pileup_inflate_s", "pileup_parse_s", "pileup_index_and_block_walk_s", "pileup_plan_on_a_thread_s")}
             legs[leg] = {"wall_s": wall, "in_find_motifs_bin_s": t.get("find_motifs_bin_s"), "phases": phases, "rates": rates,
                          "the_wall_is": max(timed, key=timed.get), "assembly_s_per_Gbp": (t.get("assembly_s") or 0.0) / (total_bp / 1e9),
                          "motif_rows": max(len(open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read().splitlines()) - 1, 0)}

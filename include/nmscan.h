@@ -534,6 +534,16 @@ int nm_bedcols_map_contigs(nm_bedcols *cols, const uint32_t *contig_lut, uint32_
 int nm_bedcols_device_columns(nm_bedcols *cols, const uint32_t **contig_id, const uint32_t **file_contig_id, const uint32_t **position,
                               const int8_t **mod_type, const uint8_t **strand, const double **fraction_mod, const int32_t **nvalid_cov);
 int nm_bedcols_phase_seconds(nm_bedcols *cols, double out[4]);
+/* nm_bed_parse_device_indexed in two halves (round 5).  nm_bed_plan_indexed is its HOST-ONLY half — the tabix index read, the wanted
+ * contigs' regions, the walk over their BGZF blocks (half a second at 1 Gbp) — with no GPU involved: a caller runs it on a thread
+ * while the HIP runtime comes up and the assembly is parsed (python -m nanomotif_amd does; find_motifs_bin.py:382-396 needs the .tbi
+ * before anything else too).  Arguments, stats and errors as nm_bed_open_indexed (stats[3] = microseconds spent).
+ * nm_bed_parse_device_planned does the rest on the device; the plan can be used once or several times and is closed by the caller. */
+typedef struct nm_bedplan nm_bedplan;
+int nm_bed_plan_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset, uint32_t threads,
+                        nm_bedplan **out, uint64_t stats[4]);
+int nm_bed_parse_device_planned(nm_ctx *ctx, nm_bedplan *plan, uint32_t threads, nm_bedcols **out);
+int nm_bedplan_close(nm_bedplan *plan);
 int nm_bedcols_close(nm_bedcols *cols);
 /* Copy `bytes` from device memory the library handed out (e.g. the columns above) to host memory, after the work queued on
  * the ctx stream. */

@@ -802,6 +802,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
 
 }  // namespace
 
+struct nm_bedplan {                          // nm_bed_plan_indexed: the pieces of the wanted text, the file they sit in
+    std::string path;
+    TextSource src;
+    std::unordered_map<std::string, uint32_t> want;
+    uint64_t stats[4] = {0, 0, 0, 0};
+};
+
 extern "C" {
 
 int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcols **out) {
@@ -831,10 +838,14 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
     return parse_device_impl(c, path, src, threads, out);
 }
 
-int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
-                                uint32_t threads, nm_bedcols **out, uint64_t stats[4]) {
-    if (!c || !path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return fail(NM_EINVAL, "NULL argument");
+// The HOST-ONLY half of the indexed parse — the tabix index read, the wanted contigs' regions, the walk over their BGZF blocks (half a
+// second of page faults for the pileup of a 1 Gbp metagenome) — as a call of its own: no GPU is involved, so a caller can run it on a
+// thread while the HIP runtime comes up and the assembly is parsed (python -m nanomotif_amd does).
+int nm_bed_plan_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset, uint32_t threads,
+                        nm_bedplan **out, uint64_t stats[4]) {
+    if (!path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return fail(NM_EINVAL, "NULL argument");
     *out = nullptr;
+    const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // the index: a small bgzip file itself
     std::vector<char> index;
     {
@@ -850,27 +861,45 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
             index.assign(reinterpret_cast<const char *>(idx.z), reinterpret_cast<const char *>(idx.z) + idx.zn);
         }
     }
-    std::unordered_map<std::string, uint32_t> want;
-    for (uint32_t i = 0; i < n_contigs; ++i) want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
+    nm_bedplan *p = new (std::nothrow) nm_bedplan();
+    if (!p) return fail(NM_ENOMEM, "out of host memory");
+    struct Guard { nm_bedplan *p; bool keep = false; ~Guard() { if (!keep) delete p; } } guard{p};
+    p->path = path;
+    for (uint32_t i = 0; i < n_contigs; ++i) p->want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
     std::vector<nmbgzf::Region> merged;
     std::vector<uint64_t> block_starts;
     uint64_t found = 0, inflated = 0;
     {
-        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), want, &merged, &found, &block_starts);
+        const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(index.data()), index.size(), p->want, &merged, &found, &block_starts);
         if (!what.empty()) return fail(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
     }
-    TextSource src;
-    int rc = map_file(path, &src);
+    int rc = map_file(path, &p->src);
     if (rc) return rc;
     {
-        const std::string what = nmbgzf::region_pieces(src.z, src.zn, merged, &src.pieces, &src.n, &inflated, &block_starts,
+        // (the walk reads the block headers through the MAPPING: two small preads per block were measured at twice the page faults' time)
+        const std::string what = nmbgzf::region_pieces(p->src.z, p->src.zn, merged, &p->src.pieces, &p->src.n, &inflated, &block_starts,
                                                        threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-    // (the walk reads the block headers through the MAPPING: two small preads per block were measured at twice the page faults' time)
         if (!what.empty()) return fail(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
-    src.bgzf = true;
-    if (stats) { stats[0] = inflated; stats[1] = src.zn; stats[2] = n_contigs - std::min<uint64_t>(found, n_contigs); stats[3] = 0; }
-    rc = parse_device_impl(c, path, src, threads, out);
+    p->src.bgzf = true;
+    p->stats[0] = inflated; p->stats[1] = p->src.zn; p->stats[2] = n_contigs - std::min<uint64_t>(found, n_contigs);
+    p->stats[3] = (uint64_t)((std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin) * 1e6);   // microseconds in this call
+    if (stats) for (int i = 0; i < 4; ++i) stats[i] = p->stats[i];
+    guard.keep = true;
+    *out = p;
+    return NM_OK;
+}
+
+int nm_bedplan_close(nm_bedplan *p) {
+    delete p;
+    return NM_OK;
+}
+
+int nm_bed_parse_device_planned(nm_ctx *c, nm_bedplan *p, uint32_t threads, nm_bedcols **out) {
+    if (!c || !p || !out) return fail(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    const char *path = p->path.c_str();
+    int rc = parse_device_impl(c, path, p->src, threads, out);
     if (rc == NM_EINVAL && strstr(nm_last_error(), "corrupt BGZF block") == nullptr) {
         // blocks intact, lines that do not parse: a region that starts inside a line — the index is stale
         const std::string why = nm_last_error();
@@ -880,7 +909,7 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
     // the text the index pointed at must belong to the contigs that were asked for: a stale or foreign .tbi otherwise
     // yields a silently wrong subset of rows
     for (const std::string &nm : (*out)->names)
-        if (!want.count(nm)) {
+        if (!p->want.count(nm)) {
             const std::string culprit = nm;
             (void)nm_bedcols_close(*out);
             *out = nullptr;
@@ -888,6 +917,19 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
                         path, culprit.c_str());
         }
     return NM_OK;
+}
+
+int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
+                                uint32_t threads, nm_bedcols **out, uint64_t stats[4]) {
+    if (!c || !path || !tbi_path || !out || (n_contigs && (!names || !name_offset))) return fail(NM_EINVAL, "NULL argument");
+    *out = nullptr;
+    nm_bedplan *plan = nullptr;
+    int rc = nm_bed_plan_indexed(path, tbi_path, n_contigs, names, name_offset, threads, &plan, stats);
+    if (rc) return rc;
+    if (stats) stats[3] = 0;
+    rc = nm_bed_parse_device_planned(c, plan, threads, out);
+    (void)nm_bedplan_close(plan);
+    return rc;
 }
 
 }  // extern "C"

@@ -115,6 +115,21 @@ def find_motifs_bin(args):
         eng = engine()
         eng.close()
         return None
+    # A bgzip pileup: the host-only half of its indexed parse (tabix index, the walk over the BGZF blocks: half a second at 1 Gbp)
+    # starts NOW on a thread, for the contigs the bin table names — beside the HIP runtime coming up and the assembly being parsed.
+    # It is used when the assembly turns out to hold them all (else the plan is dropped and made again for the ones it holds).
+    plan_box = {}
+    if str(args.pileup).endswith(".gz") and os.path.exists(str(args.pileup) + ".tbi") and os.environ.get("NANOMOTIF_HOST_PARSER") != "1" \
+            and not any(fasta.ALIAS_SEP in c for c in bin_contig) and os.environ.get("NANOMOTIF_NO_PREPLAN") != "1":
+        guess = list(dict.fromkeys(fasta.original_name(c) for c in bin_contig))
+
+        def make_plan():
+            try:
+                plan_box["plan"] = pileup_mod.BedPlan(str(args.pileup), str(args.pileup) + ".tbi", guess, threads=max(args.threads, 0) if args.threads > 1 else 0)
+            except BaseException as e:           # (the regular path will meet the same problem and report it)
+                plan_box["error"] = e
+        plan_box["thread"] = threading.Thread(target=make_plan, name="nm-bed-plan")
+        plan_box["thread"].start()
     log.info("Loading assembly")
     # A plain-text assembly is parsed ON THE GPU (nm_fasta_parse_device: the host only moves the file through pinned slabs; the
     # bases never become a host array, the planes are packed from the parser's device buffer); a .gz assembly and
@@ -157,10 +172,19 @@ def find_motifs_bin(args):
     # parser's bit for bit); a gzip stream that is not bgzip, a contig listed under several bins (its rows are needed twice)
     # and NANOMOTIF_HOST_PARSER=1 take the host parser
     table = None
+    plan = None
+    if "thread" in plan_box:
+        plan_box["thread"].join()
+        plan = plan_box.get("plan")
+        if plan is not None and (wanted is None or list(plan.contigs) != list(wanted)):
+            plan.close()                         # the assembly lacks some of the binned contigs: plan again for the ones it holds
+            plan = None
+        if plan is not None:
+            TIMINGS["pileup_plan_s_on_a_thread"] = plan.seconds
     if os.environ.get("NANOMOTIF_HOST_PARSER") != "1" and not any(fasta.ALIAS_SEP in c for c in cfg.bin_contig):
         try:
             table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0,
-                                            contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
+                                            contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None, plan=plan)
             how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
             log.info(f"pileup: {len(table):,} rows parsed on the device ({time.perf_counter() - t0:.1f}s, {table.seconds_reading:.1f}s of it "
                      f"moving the file{how})")
@@ -172,6 +196,8 @@ def find_motifs_bin(args):
         table = pileup_mod.NativePileup(cfg.pileup_path, contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None)
         how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
         log.info(f"pileup: {len(table):,} rows read ({time.perf_counter() - t0:.1f}s{how})")
+    if plan is not None:
+        plan.close()
     on_device = isinstance(table, pileup_mod.DevicePileup)
     lap("pileup_parse_s")
     TIMINGS["pileup_parser"] = "device" if on_device else "host"

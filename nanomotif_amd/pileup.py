@@ -148,6 +148,39 @@ class NativePileup:
             pass
 
 
+class BedPlan:
+    """The host-only half of the indexed device parse of a bgzip pileup (nm_bed_plan_indexed): the tabix index read, the regions of
+    ``contigs``, the walk over their BGZF blocks — no GPU involved, the library call releases the interpreter lock: the CLI runs it on
+    a thread while the HIP runtime comes up and the assembly is parsed.  ``rc`` / ``error``: how the call ended (``NM_EINDEX``: the
+    index cannot be used, read the whole file).  Hand it to ``DevicePileup(..., plan=...)`` when ``contigs`` are still the wanted ones."""
+
+    def __init__(self, path: str, index_path: str, contigs, threads: int = 0):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.contigs = list(contigs)
+        names = [c.encode() for c in self.contigs]
+        off = np.zeros(len(names) + 1, dtype=np.uint32)
+        np.cumsum([len(x) for x in names], out=off[1:])
+        self._h = C.c_void_p()
+        stats = (C.c_uint64 * 4)()
+        self.rc = self._lib.nm_bed_plan_indexed(os.fsencode(path), os.fsencode(index_path), len(names), b"".join(names),
+                                                off.ctypes.data_as(C.POINTER(C.c_uint32)), int(threads), C.byref(self._h), stats)
+        self.error = self._lib.nm_last_error().decode() if self.rc else None
+        self.bytes_inflated, self.bytes_file, self.contigs_not_indexed, self.seconds = int(stats[0]), int(stats[1]), int(stats[2]), int(stats[3]) * 1e-6
+
+    def close(self):
+        if self._h:
+            self._lib.nm_bedplan_close(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DevicePileup:
     """A bedMethyl file — plain text or bgzip — parsed ON THE GPU (nm_bed_parse_device): the six columns live in device
     memory in the types ``nm_ingest_pileup`` takes, no row ever becomes a host array.  ``contig_names``: first-appearance
@@ -160,14 +193,31 @@ class DevicePileup:
     COLUMNS = (("contig", np.uint32), ("file_contig", np.uint32), ("position", np.uint32), ("mod_type", np.int8), ("strand", np.uint8),
                ("fraction_mod", np.float64), ("nvalid_cov", np.int32))
 
-    def __init__(self, engine, path: str, threads: int = 0, contigs=None, index_path=None):
+    def __init__(self, engine, path: str, threads: int = 0, contigs=None, index_path=None, plan=None):
+        """``plan``: a ``BedPlan`` made for exactly ``contigs`` (the host half already done, possibly on another thread)."""
         import ctypes as C
         from . import _lib
         self.engine, self._lib, self._check = engine, _lib.load(), _lib.check
         self._h = C.c_void_p()
         self.indexed, self.bytes_inflated, self.bytes_file = False, None, None
         self.index_problem, self.contigs_not_indexed = None, 0
-        if contigs is not None and index_path is not None:
+        if plan is not None and contigs is not None and list(plan.contigs) == list(contigs):
+            rc = plan.rc or self._lib.nm_bed_parse_device_planned(engine.ctx, plan._h, int(threads), C.byref(self._h))
+            problem = plan.error if plan.rc else (self._lib.nm_last_error().decode() if rc else None)
+            if rc == 0:
+                self.indexed, self.bytes_inflated, self.bytes_file = True, plan.bytes_inflated, plan.bytes_file
+                self.contigs_not_indexed = plan.contigs_not_indexed
+                if self.contigs_not_indexed:
+                    import logging
+                    logging.warning(f"{self.contigs_not_indexed} of {len(plan.contigs)} wanted contigs have no entry in {index_path} (no rows read for them)")
+            elif rc != _lib.NM_EINDEX:
+                raise _lib.NmScanError(f"libnmscan error {rc}: {problem}")
+            else:
+                import logging
+                self.index_problem = problem
+                self._h = C.c_void_p()
+                logging.warning(f"tabix index not used ({self.index_problem}): reading the whole pileup")
+        elif contigs is not None and index_path is not None:
             names = [c.encode() for c in contigs]
             off = np.zeros(len(names) + 1, dtype=np.uint32)
             np.cumsum([len(x) for x in names], out=off[1:])
