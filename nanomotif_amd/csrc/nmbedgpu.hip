@@ -135,13 +135,17 @@ struct InfBits {
     const unsigned char *p;
     unsigned long long buf;
     int cnt;
-    __device__ __forceinline__ void refill() {              // (the compressed buffer has 8 readable bytes after its end)
-        unsigned long long w;
-        memcpy(&w, p, 8);
-        buf |= w << cnt;
+    // The 8 bytes at p, LOADED AHEAD: a refill takes them from this register and at once asks memory for the 8 bytes at the new p,
+    // which nobody looks at before the next refill, several symbols later.  (Round 5: the wave waited for a refill load of SOME lane
+    // in nearly every iteration — 64 lanes, a refill every two or three symbols each — one round trip through L2 per symbol.)
+    unsigned long long ahead;
+    __device__ __forceinline__ void start() { memcpy(&ahead, p, 8); }   // (the compressed buffer has 8 readable bytes after its end)
+    __device__ __forceinline__ void refill() {
+        buf |= ahead << cnt;
         const int take = (63 - cnt) >> 3;
         p += take;
         cnt += take * 8;
+        memcpy(&ahead, p, 8);
     }
     __device__ __forceinline__ unsigned int get(int n) {       // n <= 16
         if (cnt < 32) refill();
@@ -217,7 +221,8 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
     if (i >= n_pieces) return;
     const InfPiece pc = pieces[i];
     const bool partial = pc.skip != 0 || pc.take != pc.out_len;
-    InfBits b{in + pc.in_off, 0ull, 0};
+    InfBits b{in + pc.in_off, 0ull, 0, 0ull};
+    b.start();
     unsigned char *dst = partial ? scratch + pc.full_off : text + pc.dst_off;
     unsigned int o = 0;
     int err = 0, last = 0;
@@ -277,7 +282,62 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
             if (r < 0 || (r > 0 && ndist - T.dcount[0][lane] != 1)) { err = 11; break; }
         }
         const InfCounts kl = inf_counts(T.lcount, lane), kd = inf_counts(T.dcount, lane);
+        // The 64 lanes of a wave decode 64 blocks in lock-step: whatever ONE lane does in an iteration, the others wait for.  A match
+        // used to be copied whole inside the iteration that decoded it — every iteration then cost the LONGEST match among the lanes,
+        // one round trip through memory per 8 (or 32) bytes of it (round 5: that was most of a lane's 64 ms per block).  Now a match is
+        // a STATE of the lane: an iteration copies one bounded piece of it — at most 32 bytes, all loaded before any is stored: one
+        // round trip — and lanes without a match in progress decode their next symbol meanwhile.
+        unsigned int pend = 0, pdist = 0;                        // bytes of the match in progress still to copy, its distance
         for (;;) {                                               // the block's symbols
+            if (pend) {
+                unsigned char *d = dst + o;
+                const unsigned char *src = d - pdist;
+                unsigned int done;
+                if (o + 40 > pc.out_len) {                       // at the block's end: no room for whole words
+                    done = pend;
+                    for (unsigned int k = 0; k < done; ++k) d[k] = src[k];
+                } else if (pdist >= 8) {
+                    // up to four 8-byte words, as many as lie wholly in front of the piece's first store
+                    const unsigned int nw = pdist >= 32 ? 4u : pdist >> 3;
+                    done = pend < 8 * nw ? pend : 8 * nw;
+                    unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
+                    memcpy(&v0, src, 8);
+                    if (nw > 1 && done > 8) memcpy(&v1, src + 8, 8);
+                    if (nw > 2 && done > 16) memcpy(&v2, src + 16, 8);
+                    if (nw > 3 && done > 24) memcpy(&v3, src + 24, 8);
+                    memcpy(d, &v0, 8);
+                    if (nw > 1 && done > 8) memcpy(d + 8, &v1, 8);
+                    if (nw > 2 && done > 16) memcpy(d + 16, &v2, 8);
+                    if (nw > 3 && done > 24) memcpy(d + 24, &v3, 8);
+                } else {
+                    // a distance below 8 repeats its last `pdist` bytes: 16 bytes of the periodic sequence in two registers, the
+                    // words of the piece are cut out of them at the phase they start with
+                    unsigned long long s8;
+                    memcpy(&s8, src, 8);
+                    unsigned long long lo = 0, hi = 0;
+                    unsigned int ph = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const unsigned long long byte = (s8 >> (8 * ph)) & 0xFFull;
+                        if (j < 8) lo |= byte << (8 * j);
+                        else hi |= byte << (8 * (j - 8));
+                        ph = ph + 1 == pdist ? 0 : ph + 1;
+                    }
+                    done = pend < 32 ? pend : 32;
+                    unsigned int r = 0;                           // phase of the next word = (bytes written so far) mod pdist
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if ((unsigned int)(8 * k) < done) {
+                            const unsigned long long w = r ? (lo >> (8 * r)) | (hi << (64 - 8 * r)) : lo;
+                            memcpy(d + 8 * k, &w, 8);
+                        }
+                        r = (r + 8) % pdist;
+                    }
+                }
+                o += done;
+                pend -= done;
+                continue;
+            }
             int sym = inf_decode(b, kl, T.lsym, lane);
             if (sym < 0) { err = 12; break; }
             if (sym < 256) {
@@ -292,36 +352,8 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
                 if (ds < 0 || ds >= 30) { err = 15; break; }
                 const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
                 if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                const unsigned char *src = dst + o - dist;
-                unsigned char *d = dst + o;
-                // A match is copied in 8-byte words (unaligned global accesses are fine).  Words may write up to 7 bytes past
-                // the match: those bytes are rewritten by what follows before anything can refer to them (a back-reference
-                // only reaches positions below the current end of the output) — hence the room test.  With a distance of 32
-                // or more, up to four words are LOADED before the first is stored: one round trip through memory instead of
-                // one per word (and one per BYTE in the tail: the byte loop was 56 % of a lane's time, tools/inflate_proto.hip).
-                if (dist >= 32 && o + len + 8 <= pc.out_len) {
-                    for (unsigned int k = 0; k < len; k += 32) {
-                        const unsigned int rem = len - k;
-                        unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
-                        memcpy(&v0, src + k, 8);
-                        if (rem > 8) memcpy(&v1, src + k + 8, 8);
-                        if (rem > 16) memcpy(&v2, src + k + 16, 8);
-                        if (rem > 24) memcpy(&v3, src + k + 24, 8);
-                        memcpy(d + k, &v0, 8);
-                        if (rem > 8) memcpy(d + k + 8, &v1, 8);
-                        if (rem > 16) memcpy(d + k + 16, &v2, 8);
-                        if (rem > 24) memcpy(d + k + 24, &v3, 8);
-                    }
-                } else if (dist >= 8 && o + len + 8 <= pc.out_len) {
-                    for (unsigned int k = 0; k < len; k += 8) {
-                        unsigned long long v;
-                        memcpy(&v, src + k, 8);
-                        memcpy(d + k, &v, 8);
-                    }
-                } else {
-                    for (unsigned int k = 0; k < len; ++k) d[k] = src[k];
-                }
-                o += len;
+                pend = len;                                      // copied piece by piece by the iterations that follow
+                pdist = dist;
             }
         }
     }
