@@ -42,6 +42,7 @@ typedef enum nm_status {
 } nm_status;
 
 #define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base */
+#define NM_MAX_WIDE_MOTIF_LEN 4095   /* nm_score_batch_wide: candidates of search frames above 191 */
 #define NM_MAX_MOD_SLOTS 8    /* pileup classifications resident at once: the reference's 3 mod types (m, a, 21839 — constants.py:29-33), each possibly under two threshold pairs */
 
 /* motif position sets are 4-bit masks: bit0 = A, bit1 = C, bit2 = G, bit3 = T; 15 = '.'/N (any character,
@@ -170,6 +171,14 @@ int nm_score_batch(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const
 int nm_score_batch_device(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
                           const uint8_t *cand_len, const uint8_t *cand_modpos, const uint32_t *cand_mask_offset,
                           const uint8_t *cand_masks, int64_t *d_out_counts);
+/* Candidates of a search frame above 191 (find_motifs_bin.py:110-130 takes any --search_frame_size): the same counts as
+ * nm_score_batch for motifs up to NM_MAX_WIDE_MOTIF_LEN positions, any distance from the modified base, lengths and mod
+ * positions as uint16.  A site counts only while every specified position lies inside the site's own contig (a regex match
+ * never leaves the string, utils.py:44-67).  Plain kernel (plane words fetched per specified position), synchronous,
+ * host counts; whole bins on this device only (no per-contig rows).  Not a hot path: nobody runs such frames. */
+int nm_score_batch_wide(nm_ctx *ctx, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,
+                        const uint16_t *cand_len, const uint16_t *cand_modpos, const uint32_t *cand_mask_offset,
+                        const uint8_t *cand_masks, int64_t *out_counts);
 /* nm_score_batch in two halves, for a caller with host work to do while the batch runs (the native search resumes the
  * tasks of a round's window batch under the scoring kernel): _begin returns with the upload, the program compile and
  * the scoring launch enqueued; _end waits for the counts (pinned staging, then out_counts) and must be called before the

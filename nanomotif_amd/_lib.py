@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NM_LIB", os.path.join(_HERE, "libnmscan.so"))   # NM_
 
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_set_device_allocator", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_set_score_lanes", "nm_sync", "nm_upload_contigs",
-    "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_hit_positions", "nm_stats",
+    "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_score_batch_wide", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
@@ -114,6 +114,7 @@ def load():
                                             C.c_int]
     for name in ("nm_score_batch", "nm_score_batch_device"):
         getattr(lib, name).argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p, p]
+    lib.nm_score_batch_wide.argtypes = [p, C.c_uint32, u32p, u8p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), u32p, u8p, i64p]
     lib.nm_score_batch_begin.argtypes = [p, C.c_uint32, u32p, u8p, u8p, u8p, u32p, u8p]
     lib.nm_score_batch_end.argtypes = [p, i64p]
     lib.nm_win_batch_w_begin.argtypes = [p, C.c_uint32, u32p, u8p, u8p, C.c_uint32]

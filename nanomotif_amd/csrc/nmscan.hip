@@ -431,6 +431,83 @@ __global__ __launch_bounds__(1024) void compile_common_kernel(uint32_t n_prog, c
     }
 }
 
+// ---- candidates that reach further than 95 positions from the modified base (a search frame above 191: the reference takes any
+// --search_frame_size, find_motifs_bin.py:110-130): a plain, slow kernel — speed is irrelevant there.  One workgroup per (chunk of the
+// candidate's bin, candidate), one thread per 32-position word; per specified motif position the plane words are FETCHED at the
+// shifted address (no register tile), a site survives only while every constrained position lies inside its own contig
+// (utils.py:44-67: a regex match cannot leave the string; beyond 96 positions the padding between contigs no longer guarantees it).
+struct WideArgs {
+    Planes seq;
+    StatePlanes st[NM_MAX_MOD_SLOTS];
+    const uint32_t *cand_bin, *cand_mask_off;
+    const uint16_t *cand_len, *cand_modpos;
+    const uint8_t *cand_slot, *masks;
+    const uint32_t *bin_chunk0, *bin_nchunks, *chunk_contig, *contig_chunk;
+    const uint64_t *contig_len;
+    unsigned long long *out;
+    long long n_words;
+};
+
+__device__ __forceinline__ uint32_t plane_bits_at(const uint32_t *__restrict__ pl, long long n_words, long long g) {      // the 32 bits of a plane from position g on
+    const long long i = g >> 5;                                           // (arithmetic shift: floor)
+    const uint32_t sh = (uint32_t)(g & 31);
+    const uint32_t lo = i >= 0 && i < n_words ? pl[i] : 0u;
+    const uint32_t hi = sh && i + 1 >= 0 && i + 1 < n_words ? pl[i + 1] : 0u;
+    return sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+}
+
+__global__ __launch_bounds__(256) void score_wide_kernel(WideArgs a) {
+    __shared__ unsigned int part[2][4];
+    const uint32_t k = blockIdx.y, bin = a.cand_bin[k];
+    if (blockIdx.x >= a.bin_nchunks[bin]) return;
+    const uint32_t chunk = a.bin_chunk0[bin] + blockIdx.x, contig = a.chunk_contig[chunk];
+    if (contig == 0xFFFFFFFFu) return;
+    const uint32_t len = a.cand_len[k], mp = a.cand_modpos[k], slot = a.cand_slot[k];
+    const uint8_t *m = a.masks + a.cand_mask_off[k];
+    const size_t w = (size_t)chunk * CHUNK_WORDS + threadIdx.x;
+    const long long g0 = (long long)w * 32;                               // global position of the word's bit 0
+    const long long p0 = (long long)(chunk - a.contig_chunk[contig]) * CHUNK_BP + 32ll * threadIdx.x;      // ... inside its contig
+    const long long clen = (long long)a.contig_len[contig];
+    auto inside = [&](long long d) -> uint32_t {                          // bits b of the word with 0 <= p0 + b + d < clen
+        const long long lo = -(p0 + d), hi = clen - (p0 + d);
+        const long long l = lo < 0 ? 0 : lo, h = hi > 32 ? 32 : hi;
+        if (h <= l) return 0u;
+        const uint32_t upto_h = h >= 32 ? 0xFFFFFFFFu : ((1u << h) - 1u);
+        return upto_h & ~(l ? ((1u << l) - 1u) : 0u);
+    };
+    uint32_t acc[2];
+    for (int strand = 0; strand < 2; ++strand) {
+        uint32_t s = inside(0);
+        for (uint32_t j = 0; j < len && s; ++j) {
+            const uint32_t set_f = m[j] & 15u;
+            if (set_f == 15u) continue;
+            const long long d = strand == 0 ? (long long)j - mp : (long long)mp - j;
+            const uint32_t set = strand == 0 ? set_f : (((set_f & 1) << 3) | ((set_f & 2) << 1) | ((set_f & 4) >> 1) | ((set_f & 8) >> 3));
+            const uint32_t ok = inside(d);
+            if (!ok) { s = 0; break; }
+            const uint32_t h = plane_bits_at(a.seq.H, a.n_words, g0 + d), l = plane_bits_at(a.seq.L, a.n_words, g0 + d), v = plane_bits_at(a.seq.V, a.n_words, g0 + d);
+            uint32_t match = 0;                                           // A = 00, C = 01, G = 11, T = 10 as (H, L)
+            if (set & NM_BASE_A) match |= ~h & ~l;
+            if (set & NM_BASE_C) match |= ~h & l;
+            if (set & NM_BASE_G) match |= h & l;
+            if (set & NM_BASE_T) match |= h & ~l;
+            s &= match & v & ok;
+        }
+        acc[strand] = s;
+    }
+    const StatePlanes &st = a.st[slot];
+    unsigned int n_mod = __popc(acc[0] & st.MP[w]) + __popc(acc[1] & st.MM[w]);
+    unsigned int n_non = __popc(acc[0] & st.UP[w]) + __popc(acc[1] & st.UM[w]);
+    for (int o = 32; o; o >>= 1) { n_mod += __shfl_xor(n_mod, o); n_non += __shfl_xor(n_non, o); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = n_mod; part[1][threadIdx.x >> 6] = n_non; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int x = part[0][0] + part[0][1] + part[0][2] + part[0][3], y = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (x) atomicAdd(a.out + 2 * (size_t)k, (unsigned long long)x);
+        if (y) atomicAdd(a.out + 2 * (size_t)k + 1, (unsigned long long)y);
+    }
+}
+
 // Site masks of one candidate over the chunks of one contig (general planes) for nm_hit_positions.
 template <int GN, int GP>
 __global__ __launch_bounds__(256) void hits_kernel(Planes seq, StatePlanes st, uint32_t chunk0, uint32_t n_chunks,
@@ -1522,6 +1599,83 @@ int nm_score_batch(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const u
     if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !out_counts))
         return fail(NM_EINVAL, "NULL argument");
     return score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, nullptr, out_counts);
+}
+
+int nm_score_batch_wide(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot, const uint16_t *cand_len,
+                        const uint16_t *cand_modpos, const uint32_t *cand_mask_offset, const uint8_t *cand_masks, int64_t *out_counts) {
+    if (!c) return fail(NM_EINVAL, "ctx is NULL");
+    if (n_cand && (!cand_bin || !cand_mod_slot || !cand_len || !cand_modpos || !cand_mask_offset || !cand_masks || !out_counts)) return fail(NM_EINVAL, "NULL argument");
+    if (!c->dH) return fail(NM_ESTATE, "nm_upload_contigs has not been called");
+    if (n_cand == 0) return NM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = join_lanes(c);
+    if (rc) return rc;
+    uint64_t mask_bytes = 0;
+    uint32_t max_chunks = 0;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const uint32_t slot = cand_mod_slot[k], bin = cand_bin[k], len = cand_len[k], mp = cand_modpos[k];
+        if (slot >= NM_MAX_MOD_SLOTS || !c->slots[slot].present) return fail(NM_ESTATE, "candidate %u uses mod slot %u with no pileup uploaded", k, slot);
+        if (bin >= c->n_bins) return fail(NM_EINVAL, "candidate %u: bin %u >= n_bins %u", k, bin, c->n_bins);
+        if (len == 0 || len > NM_MAX_WIDE_MOTIF_LEN) return fail(NM_ERANGE, "candidate %u: motif length %u outside 1..%d", k, len, NM_MAX_WIDE_MOTIF_LEN);
+        if (mp >= len) return fail(NM_EINVAL, "candidate %u: mod_position %u outside motif of length %u", k, mp, len);
+        const uint8_t *m = cand_masks + cand_mask_offset[k];
+        uint32_t all_and = 15u;
+        for (uint32_t j = 0; j < len; ++j) {
+            if ((m[j] & 15u) == 0) return fail(NM_EINVAL, "candidate %u: empty base set in the motif", k);
+            all_and &= m[j] & 15u;
+        }
+        if (all_and == 15u) return fail(NM_EINVAL, "candidate %u: motif has no specified position", k);
+        mask_bytes = std::max<uint64_t>(mask_bytes, (uint64_t)cand_mask_offset[k] + len);
+        max_chunks = std::max(max_chunks, c->bin_nchunks[bin]);
+    }
+    memset(out_counts, 0, (size_t)n_cand * 2 * sizeof(int64_t));
+    if (max_chunks == 0) return NM_OK;                                    // none of the bins is resident on this rank
+    // (plain synchronous staging: tables in, counts out; this path is not timed by anything)
+    std::vector<uint32_t> chunk_contig(c->n_chunks, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < c->n_contigs; ++i)
+        for (uint32_t q = 0; q < c->contig_nchunks[i]; ++q) chunk_contig[c->contig_chunk[i] + q] = i;
+    const size_t o_bin = 0, o_off = o_bin + (size_t)n_cand * 4, o_len = o_off + (size_t)n_cand * 4, o_mp = o_len + (size_t)n_cand * 2,
+                 o_slot = o_mp + (size_t)n_cand * 2, o_masks = (o_slot + n_cand + 15) & ~(size_t)15, o_b0 = (o_masks + mask_bytes + 15) & ~(size_t)15,
+                 o_bn = o_b0 + (size_t)c->n_bins * 4, o_cc = o_bn + (size_t)c->n_bins * 4, o_out = (o_cc + (size_t)c->n_chunks * 4 + 15) & ~(size_t)15,
+                 total = o_out + (size_t)n_cand * 16;
+    std::vector<uint8_t> h(total, 0);
+    memcpy(h.data() + o_bin, cand_bin, (size_t)n_cand * 4);
+    memcpy(h.data() + o_off, cand_mask_offset, (size_t)n_cand * 4);
+    memcpy(h.data() + o_len, cand_len, (size_t)n_cand * 2);
+    memcpy(h.data() + o_mp, cand_modpos, (size_t)n_cand * 2);
+    memcpy(h.data() + o_slot, cand_mod_slot, n_cand);
+    memcpy(h.data() + o_masks, cand_masks, mask_bytes);
+    memcpy(h.data() + o_b0, c->bin_chunk0.data(), (size_t)c->n_bins * 4);
+    memcpy(h.data() + o_bn, c->bin_nchunks.data(), (size_t)c->n_bins * 4);
+    memcpy(h.data() + o_cc, chunk_contig.data(), (size_t)c->n_chunks * 4);
+    uint8_t *d = nullptr;
+    HIP_TRY(nmdetail::dev_malloc(&d, total));
+    struct Free { uint8_t *p; nm_ctx *c; ~Free() { (void)hipStreamSynchronize(c->stream); (void)nmdetail::dev_free(p); } } guard{d, c};
+    HIP_TRY(hipMemcpyAsync(d, h.data(), total, hipMemcpyHostToDevice, c->stream));
+    WideArgs a{};
+    a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
+    for (int s = 0; s < NM_MAX_MOD_SLOTS; ++s) {
+        const ModSlot &ms = c->slots[s];
+        a.st[s] = StatePlanes{ms.planes[0], ms.planes[1], ms.planes[2], ms.planes[3], ms.planes[4], ms.planes[5]};
+    }
+    a.cand_bin = reinterpret_cast<const uint32_t *>(d + o_bin);
+    a.cand_mask_off = reinterpret_cast<const uint32_t *>(d + o_off);
+    a.cand_len = reinterpret_cast<const uint16_t *>(d + o_len);
+    a.cand_modpos = reinterpret_cast<const uint16_t *>(d + o_mp);
+    a.cand_slot = d + o_slot;
+    a.masks = d + o_masks;
+    a.bin_chunk0 = reinterpret_cast<const uint32_t *>(d + o_b0);
+    a.bin_nchunks = reinterpret_cast<const uint32_t *>(d + o_bn);
+    a.chunk_contig = reinterpret_cast<const uint32_t *>(d + o_cc);
+    a.contig_chunk = c->d_contig_chunk;
+    a.contig_len = c->d_contig_len;
+    a.out = reinterpret_cast<unsigned long long *>(d + o_out);
+    a.n_words = (long long)plane_words(c);
+    hipLaunchKernelGGL(score_wide_kernel, dim3(max_chunks, n_cand), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_counts, d + o_out, (size_t)n_cand * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return NM_OK;
 }
 
 int nm_score_batch_begin(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8_t *cand_mod_slot,

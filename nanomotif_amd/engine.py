@@ -12,6 +12,11 @@ from . import _lib
 from .motif import MOD_TYPE_TO_CANONICAL, Motif
 
 
+MAX_MOTIF_LEN = 191        # include/nmscan.h NM_MAX_MOTIF_LEN: stripped length of a candidate on the fast scoring kernels ...
+MAX_REACH = 95             # ... and its furthest position from the modified base; beyond: nm_score_batch_wide
+MAX_DEVICE_WINDOW_WIDTH = 191      # NM_WIN_MAX_WIDTH 192 columns: wider search frames keep their windows on the host
+
+
 def _ptr(arr, ctype):
     return arr.ctypes.data_as(C.POINTER(ctype))
 
@@ -717,10 +722,39 @@ class ScanEngine:
 
     def score(self, candidates) -> np.ndarray:
         """int64[n, 2] = (n_mod, n_nomod) per candidate — what ``model.update`` receives (find_motifs_bin.py:1320)."""
+        if not isinstance(candidates, CandidateBatch) and any(len(c[0].tokens) > MAX_REACH + 1 for c in candidates):
+            return self._score_with_wide(candidates)
         b = candidates if isinstance(candidates, CandidateBatch) else self.make_batch(candidates)
         out = np.zeros((len(b), 2), dtype=np.int64)
         if len(b):
             _lib.check(self.lib.nm_score_batch(self.ctx, *self._batch_args(b), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def _score_with_wide(self, candidates) -> np.ndarray:
+        """A search frame above 191 (find_motifs_bin.py:110-130 takes any): candidates that stay within 95 positions of the
+        modified base once stripped go the usual way, the others through nm_score_batch_wide (plain kernel, any reach)."""
+        stripped = [c[0].stripped_sets() for c in candidates]
+        wide = [k for k, (sets, mp) in enumerate(stripped) if max(mp, len(sets) - 1 - mp) > MAX_REACH or len(sets) > MAX_MOTIF_LEN]
+        is_wide = set(wide)
+        narrow = [k for k in range(len(candidates)) if k not in is_wide]
+        out = np.zeros((len(candidates), 2), dtype=np.int64)
+        if narrow:
+            out[narrow] = self.score(self.make_batch([candidates[k] for k in narrow]))
+        if wide:
+            n = len(wide)
+            bi, so = self.bin_index, self.slot_of_mod
+            bins = np.fromiter((bi[candidates[k][2]] if isinstance(candidates[k][2], str) else candidates[k][2] for k in wide), dtype=np.uint32, count=n)
+            slots = np.fromiter((so[candidates[k][1]] for k in wide), dtype=np.uint8, count=n)
+            lens = np.fromiter((len(stripped[k][0]) for k in wide), dtype=np.uint16, count=n)
+            modpos = np.fromiter((stripped[k][1] for k in wide), dtype=np.uint16, count=n)
+            moff = np.zeros(n, dtype=np.uint32)
+            np.cumsum(lens[:-1], out=moff[1:])
+            masks = np.concatenate([stripped[k][0] for k in wide]).astype(np.uint8)
+            res = np.zeros((n, 2), dtype=np.int64)
+            _lib.check(self.lib.nm_score_batch_wide(self.ctx, n, _ptr(bins, C.c_uint32), _ptr(slots, C.c_uint8), _ptr(lens, C.c_uint16),
+                                                    _ptr(modpos, C.c_uint16), _ptr(moff, C.c_uint32), _ptr(masks, C.c_uint8), _ptr(res, C.c_int64)))
+            out[wide] = res
+            self.wide_scored = getattr(self, "wide_scored", 0) + n
         return out
 
     def bin_contigs(self, bin_name) -> list:

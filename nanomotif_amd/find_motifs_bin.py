@@ -25,7 +25,7 @@ from .pileup import MOD_TYPES, PileupTable
 from .search import HostWindowStore, extract_windows, find_best_candidates_co, get_parent_scores_co, run_lockstep
 
 IUPAC_LETTERS = set("ATGCRYSWKMBDHVN")
-MAX_WINDOW_WIDTH = 191         # include/nmscan.h: NM_WIN_MAX_WIDTH 192 columns, scoring offsets within 95 of the modified base
+MAX_WINDOW_WIDTH = 4095        # include/nmscan.h NM_MAX_WIDE_MOTIF_LEN: a candidate is at most one window long
 
 
 # ------------------------------------------------------------------------------------------------ config
@@ -65,9 +65,9 @@ class ProcessorConfig:
         if self.search_frame_size <= 1:
             raise ValueError("search_frame_size must be greater than 1")
         if 2 * (self.search_frame_size // 2) + 1 > MAX_WINDOW_WIDTH:
-            # the reference takes any frame (find_motifs_bin.py:128-130; default 40); the engine's window planes hold 192
-            # columns and its scoring kernels reach 95 positions either side of the modified base (include/nmscan.h)
-            raise ValueError(f"search_frame_size must be at most {MAX_WINDOW_WIDTH - 1} on the MI355X engine "
+            # the reference takes any frame (find_motifs_bin.py:128-130; default 40).  Up to 191 columns everything runs on the
+            # device; above, windows stay on the host and far-reaching candidates go through nm_score_batch_wide (main.py)
+            raise ValueError(f"search_frame_size must be at most {MAX_WINDOW_WIDTH} on the MI355X engine "
                              f"(windows of 2 * (search_frame_size // 2) + 1 <= {MAX_WINDOW_WIDTH} positions)")
         if not (0 <= self.methylation_threshold_high <= 1):
             raise ValueError("methylation_threshold_high must be in [0,1]")

@@ -20,6 +20,7 @@ import numpy as np
 from . import fasta, pileup as pileup_mod, postprocess
 from .argparser import __version__, create_parser
 from .find_motifs_bin import FilteredPileup, ProcessorConfig, allreduce_counts, discover, engine_scorer, use_native_allreduce
+from .engine import MAX_DEVICE_WINDOW_WIDTH
 from .motif import MOD_TYPE_TO_CANONICAL
 from .shard import assign_bins, assign_contigs
 
@@ -314,7 +315,13 @@ def find_motifs_bin(args):
         else:
             res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
                                     cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
-        store, extractor = device_window_pipeline(eng, {c: fasta.assembly_length(assembly, c) for c in names}, mine, cfg.padding, world)
+        if 2 * cfg.padding + 1 > MAX_DEVICE_WINDOW_WIDTH:
+            # a search frame beyond the device's window planes (default 40; nobody runs such frames): windows are extracted and
+            # filtered on the host (search.HostWindowStore), candidates scored on the device (far-reaching ones by the plain kernel)
+            log.info(f"search frame {cfg.search_frame_size}: windows of {2 * cfg.padding + 1} positions stay on the host")
+            store, extractor = None, None
+        else:
+            store, extractor = device_window_pipeline(eng, {c: fasta.assembly_length(assembly, c) for c in names}, mine, cfg.padding, world)
         if device_fasta and extractor is not None:
             assembly.close()                     # the packed bases have served; (host windows would read contigs back from them)
         rows_part = eng.confident_rows() if extractor is None else tuple(np.zeros(0, dt) for dt in (np.uint32, np.uint32, np.uint8, np.int8))
@@ -345,6 +352,8 @@ def find_motifs_bin(args):
         scorer = engine_scorer(eng, low, high, use_dist=world > 1)
         rows, scorer = discover(cfg, filtered, scorer, rank=0 if gather_world > 1 else rank, bgzip_order=bgzip,
                                 window_store=store, extractor=extractor)
+        if getattr(eng, "wide_scored", 0):
+            log.info(f"{eng.wide_scored} candidates reaching further than 95 positions from the modified base scored by nm_score_batch_wide")
         lap("search_s")
         TIMINGS.update({"search_" + k: v for k, v in getattr(scorer, "timings", {}).items()})
         out = _gather_rows(args, rows, rank, gather_world, bin_order)

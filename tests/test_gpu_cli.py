@@ -3,6 +3,7 @@ against the CPU oracle's full pipeline on the same data — cfg 1 of BASELINE.js
 geobacillus motifs planted in synthetic contigs (the reference's own pileup blob is not distributable)."""
 import gzip
 import os
+import re
 import subprocess
 import sys
 
@@ -235,10 +236,11 @@ def test_more_ranks_than_contigs(tmp_path):
     assert open(tmp + "/out2/bin-motifs.tsv").read() == one
 
 
-def test_wide_search_frames_equal_the_oracle_and_the_limit_is_refused(tmp_path):
+def test_wide_search_frames_equal_the_oracle(tmp_path):
     """The reference takes any --search_frame_size (find_motifs_bin.py:128-130).  Frames above 63 use the three-word window
     fields and, once a child reaches more than 63 positions from the modified base, the extra-wide scoring kernels
-    (offsets in [-96, 95]); the engine stops at 191 (windows of 191 columns)."""
+    (offsets in [-96, 95]); above 191 columns the windows stay on the host and children that reach further than 95 positions
+    are scored by nm_score_batch_wide."""
     spec = synth.SynthSpec(n_contigs=3, total_bp=300_000, n_bins=1, mod_types=("a", "m"), seed=64, min_contig_bp=60_000,
                            fixed_motifs=(("GATC", 1, "a"), ("GCACNNNNNNGTT", 2, "a"), ("CCWGG", 1, "m")))
     mg = synth.make_metagenome(spec)
@@ -251,8 +253,24 @@ def test_wide_search_frames_equal_the_oracle_and_the_limit_is_refused(tmp_path):
         got = open(f"{tmp}/o{frame}/bin-motifs.tsv").read()
         assert got == oracle_pipeline(mg, padding=frame // 2), frame
         assert "GATC" in got
-    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "192"], check=False)
-    assert r.returncode != 0 and "search_frame_size must be at most 190" in r.stdout + r.stderr
+    # a planted pair of half-sites 120 positions apart: its far columns stand out of the background, so the root's children there
+    # are scored (nodes longer than 25 are never expanded, find_motifs_bin.py:1010: such a motif is not REPORTED by either side)
+    spec = synth.SynthSpec(n_contigs=3, total_bp=300_000, n_bins=1, mod_types=("a", "m"), seed=64, min_contig_bp=60_000,
+                           fixed_motifs=(("GATC", 1, "a"), ("GA" + "N" * 120 + "TC", 1, "a"), ("CCWGG", 1, "m")))
+    mg = synth.make_metagenome(spec)
+    mg.write_fasta(tmp + "/a.fasta")
+    mg.write_bed(tmp + "/p.bed")
+    from helpers import write_bgzf_tabix
+    write_bgzf_tabix(open(tmp + "/p.bed", "rb").read(), tmp + "/p.bed.gz", block_size=50_000)
+    for frame, pileup, bgzip in ((192, "p.bed", False), (300, "p.bed", False), (400, "p.bed.gz", True)):
+        r = _run_cli(tmp, ["a.fasta", pileup, "-c", "cb.tsv", "--out", f"w{frame}", "--search_frame_size", str(frame)])
+        got = open(f"{tmp}/w{frame}/bin-motifs.tsv").read()
+        assert got == oracle_pipeline(mg, padding=frame // 2, bgzip_order=bgzip), frame
+        assert "CCWGG" in got and ("GATC" in got) == (frame != 400) and "stay on the host" in r.stdout + r.stderr     # (the oracle loses GATC at 400 too)
+        m = re.search(r"(\d+) candidates reaching further than 95 positions", r.stdout + r.stderr)
+        assert frame == 192 or (m and int(m.group(1)) > 0), frame          # (the planted far columns lie outside a frame of 192)
+    r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "4096"], check=False)
+    assert r.returncode != 0 and "search_frame_size must be at most 4095" in r.stdout + r.stderr
 
 
 def test_assembly_with_other_iupac_letters_takes_the_host_window_path(tmp_path):

@@ -349,6 +349,50 @@ def test_extra_wide_motifs_reach_95_positions_from_the_modified_base(engine_cls)
                     assert eng.hit_positions(mg.names[ci], mt, Motif(s, p), which).tolist() == want[k].tolist(), (s, p, ci, k)
     with pytest.raises(NmScanError, match="outside \\[-96, 95\\]"):
         eng.hit_positions(mg.names[0], "a", Motif("A" + "." * 95 + "G", 0), 0)
-    with pytest.raises(NmScanError, match="the engine reaches 95"):
-        eng.score([(Motif("A" + "." * 95 + "G", 0), "a", "bin_000")])
+    with pytest.raises(NmScanError, match="the engine reaches 95"):           # the fast kernels; ScanEngine.score routes such a list to nm_score_batch_wide
+        eng.score(eng.make_batch([(Motif("A" + "." * 95 + "G", 0), "a", "bin_000")]))
+    eng.close()
+
+
+def test_candidates_of_frames_above_191_are_scored_by_the_wide_entry(engine_cls):
+    """nm_score_batch_wide: any reach from the modified base (a --search_frame_size above 191 makes such children,
+    find_motifs_bin.py:110-130).  (1) on candidates the fast kernels take, the same counts as nm_score_batch; (2) far-reaching
+    ones against the oracle scan, including motifs longer than the shortest contig's margin (a site whose motif would leave
+    its contig is no site: a regex match never leaves the string) and contigs shorter than the motif."""
+    import ctypes as C
+    from nanomotif_amd import _lib
+    from nanomotif_amd._lib import NmScanError
+    from oracle.scan import score_candidates
+    spec = synth.SynthSpec(n_contigs=7, total_bp=300_000, n_bins=2, mod_types=("a", "m"), seed=78, min_contig_bp=300)
+    mg = synth.make_metagenome(spec)
+    eng = engine_cls()
+    _upload_metagenome(eng, mg, ("a", "m"))
+    ptr = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    # (1) the zoo of the fast kernels through the wide entry
+    rng = np.random.default_rng(5)
+    cands = [(Motif(s, p), mt, b) for s, p, mt in synth.random_candidates(300, seed=21, mod_types=("a", "m")) for b in ("bin_000", "bin_001")]
+    batch = eng.make_batch(cands)
+    want = eng.score(batch)
+    got = np.zeros_like(want)
+    _lib.check(eng.lib.nm_score_batch_wide(eng.ctx, len(batch), ptr(batch.bins, C.c_uint32), ptr(batch.slots, C.c_uint8),
+                                           ptr(batch.lens.astype(np.uint16), C.c_uint16), ptr(batch.modpos.astype(np.uint16), C.c_uint16),
+                                           ptr(batch.offsets, C.c_uint32), ptr(batch.masks, C.c_uint8), ptr(got, C.c_int64)))
+    assert want.sum() > 0 and np.array_equal(got, want)
+    # (2) far reaches against the oracle
+    zoo = {"a": [("A" + "." * 95 + "G", 0), ("T" + "." * 150 + "A", 151), ("G" + "." * 199 + "A" + "." * 199 + "[CT]", 200), ("GATC", 1),
+                 ("A" + "." * 400, 0), ("." * 200 + "A" + "." * 200, 200), ("[AG]" + "." * 250 + "A" + "." * 30 + "T", 251),
+                 ("A" + "." * 299 + "[ACG]", 0), ("C" + "." * 1000 + "A", 1001), ("T.A" + "." * 120 + "[GT]", 2)],
+           "m": [("C" + "." * 120 + "G", 0), ("A" + "." * 300 + "C", 301), ("G" + "." * 170 + "C" + "." * 170 + "[AT]", 171), ("CC[AT]GG", 1)]}
+    any_hits = 0
+    for mt, motifs in zoo.items():
+        for b in sorted(set(mg.bin_names)):
+            idx = [i for i, x in enumerate(mg.bin_names) if x == b]
+            pile, seqs = oracle_bin_inputs(mg, mt, contigs=idx)
+            want = score_candidates(pile, seqs, motifs)
+            got = eng.score([(Motif(s, p), mt, b) for s, p in motifs])
+            assert np.array_equal(got, want), (mt, b, got.tolist(), want.tolist())
+            any_hits += int(want[:3].sum())
+    assert any_hits > 0
+    with pytest.raises(NmScanError, match="outside 1..4095"):
+        eng.score([(Motif("A" + "." * 4095 + "G", 0), "a", "bin_000")])
     eng.close()
