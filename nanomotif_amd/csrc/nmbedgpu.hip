@@ -127,8 +127,33 @@ constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
 // A damaged deflate block is noticed at its end at the latest (the text cannot grow beyond the member's size: at most 65 536
 // symbols of at most 48 bits) and at the head of the next one: the bit reader never gets further than this past the stream.
 constexpr size_t INF_OVERRUN = 512u << 10;
-struct InfTables {                      // entry-major: lane l of the wave touches [entry][l]
-    unsigned short lcount[16][INF_LANES], lsym[INF_MAXL][INF_LANES], dcount[16][INF_LANES], dsym[INF_MAXD][INF_LANES];
+// Entry-major: lane l of the wave touches [entry][l].  A symbol of the literal / length code is 9 bits: its low byte in `lo`, bit 8
+// in a bit plane of 288 bits per lane — 25.1 KB per workgroup instead of the 44.8 KB of 16-bit entries, six workgroups on a
+// compute unit's 160 KB instead of three (round 5: the lanes wait on memory most of the time; a CU held three waves for four SIMDs).
+struct InfSymbols {
+    unsigned char lo[INF_MAXL][INF_LANES];
+    unsigned int hi[(INF_MAXL + 31) / 32][INF_LANES];
+    __device__ __forceinline__ void clear(int lane) {
+#pragma unroll
+        for (int w = 0; w < (INF_MAXL + 31) / 32; ++w) hi[w][lane] = 0;
+    }
+    __device__ __forceinline__ void put(int idx, int lane, int sym) {
+        lo[idx][lane] = (unsigned char)sym;
+        if (sym & 256) hi[idx >> 5][lane] |= 1u << (idx & 31);
+    }
+    __device__ __forceinline__ int get(int idx, int lane) const { return (int)lo[idx][lane] | (int)(((hi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8); }
+};
+struct InfDistSymbols {                 // distance symbols are below 30
+    unsigned char lo[INF_MAXD][INF_LANES];
+    __device__ __forceinline__ void clear(int) {}
+    __device__ __forceinline__ void put(int idx, int lane, int sym) { lo[idx][lane] = (unsigned char)sym; }
+    __device__ __forceinline__ int get(int idx, int lane) const { return (int)lo[idx][lane]; }
+};
+struct InfTables {
+    unsigned short lcount[16][INF_LANES];
+    unsigned char dcount[16][INF_LANES];
+    InfSymbols lsym;
+    InfDistSymbols dsym;
 };
 
 struct InfBits {
@@ -157,7 +182,9 @@ struct InfBits {
 };
 
 // canonical code from code lengths; > 0: incomplete, < 0: over-subscribed (zlib contrib/puff: construct)
-__device__ int inf_construct(unsigned short (*count)[INF_LANES], unsigned short (*symbol)[INF_LANES], const unsigned char *length, int n, int lane) {
+template <typename Count, typename Symbols>
+__device__ int inf_construct(Count (*count)[INF_LANES], Symbols &symbol, const unsigned char *length, int n, int lane) {
+    symbol.clear(lane);
     for (int len = 0; len <= 15; ++len) count[len][lane] = 0;
     for (int s = 0; s < n; ++s) count[length[s]][lane] += 1;
     if (count[0][lane] == n) return 0;
@@ -171,19 +198,21 @@ __device__ int inf_construct(unsigned short (*count)[INF_LANES], unsigned short 
     offs[1] = 0;
     for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + count[len][lane];
     for (int s = 0; s < n; ++s)
-        if (length[s] != 0) symbol[offs[length[s]]++][lane] = (unsigned short)s;
+        if (length[s] != 0) symbol.put(offs[length[s]]++, lane, s);
     return left;
 }
 
 struct InfCounts { unsigned int c[16]; };
-__device__ __forceinline__ InfCounts inf_counts(unsigned short (*count)[INF_LANES], int lane) {
+template <typename Count>
+__device__ __forceinline__ InfCounts inf_counts(Count (*count)[INF_LANES], int lane) {
     InfCounts k;
 #pragma unroll
     for (int len = 0; len < 16; ++len) k.c[len] = count[len][lane];
     return k;
 }
 
-__device__ __forceinline__ int inf_decode(InfBits &b, const InfCounts &k, unsigned short (*symbol)[INF_LANES], int lane) {
+template <typename Symbols>
+__device__ __forceinline__ int inf_decode(InfBits &b, const InfCounts &k, const Symbols &symbol, int lane) {
     if (b.cnt < 32) b.refill();
     int code = 0, first = 0, index = 0;
     unsigned int bits = (unsigned int)b.buf;
@@ -195,7 +224,7 @@ __device__ __forceinline__ int inf_decode(InfBits &b, const InfCounts &k, unsign
         if (code - c < first) {
             b.buf >>= len;
             b.cnt -= len;
-            return symbol[index + (code - first)][lane];
+            return symbol.get(index + (code - first), lane);
         }
         index += c;
         first += c;
@@ -982,7 +1011,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     const bool dev_inflate = src.bgzf && getenv("NM_BED_HOST_INFLATE") == nullptr;
     // device inflate: slabs of whole BLOCKS (up to 3 GiB of text: line offsets are 32-bit), a line that straddles two slabs is
     // carried over on the device
-    constexpr uint64_t INF_SLAB_TEXT = 3ull << 30, CARRY_CAP = 1ull << 20;      // 3 GiB of text per slab (49 000 blocks: every lane slot of the device), two slabs in flight
+    constexpr uint64_t INF_SLAB_TEXT = 3ull << 30, CARRY_CAP = 1ull << 20;      // 3 GiB of text per slab (49 000 blocks = 768 workgroups), two slabs in flight — and inflating side by side
     // The compressed bytes of a slab travel as CHUNKS: byte ranges of the file (the few bytes of gzip header / trailer between two
     // blocks ride along), copied into the pinned buffers in a few large pieces — no per-block work on the host.
     struct InfChunk { size_t first, last; uint64_t file_lo, file_hi, dev_off; };
@@ -990,7 +1019,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     std::vector<InfSlab> inf_slabs;
     uint64_t inf_text_cap = 0, inf_comp_cap = 0;
     if (dev_inflate) {
-        const uint64_t cap = getenv("NM_BED_INFLATE_SLAB") ? std::max<uint64_t>(1u << 16, strtoull(getenv("NM_BED_INFLATE_SLAB"), nullptr, 10)) : INF_SLAB_TEXT;
+        // (line starts are 32-bit offsets into a slab's text: a slab stays below 4 GiB whatever the environment asks for)
+        const uint64_t cap = std::min<uint64_t>(0xE0000000ull, getenv("NM_BED_INFLATE_SLAB") ? std::max<uint64_t>(1u << 16, strtoull(getenv("NM_BED_INFLATE_SLAB"), nullptr, 10)) : INF_SLAB_TEXT);
         for (size_t i = 0; i < src.pieces.size();) {
             InfSlab sl{i, i, 0, 0};
             while (sl.last < src.pieces.size() && (sl.last == sl.first || sl.text + src.pieces[sl.last].take <= cap)) {
@@ -1218,18 +1248,21 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipStreamSynchronize(c->stream));
         uint8_t *h_chunk[2] = {nullptr, nullptr};
         hipEvent_t chunk_done[2] = {nullptr, nullptr}, inflated[2] = {nullptr, nullptr}, parsed_ev[2] = {nullptr, nullptr};
-        hipStream_t inf_stream = nullptr;
-        struct Pinned { uint8_t **h; hipEvent_t *e, *e2, *e3; hipStream_t &cs, &is; ~Pinned() {
+        // TWO inflate streams, one per text buffer: a slab of 3 GiB is 49 000 blocks = 768 workgroups, half of the 1 536 the device holds at
+        // six per CU (the line-start offsets are 32 bits: a slab stays below 4 GiB), so the next slab's kernel starts beside the current
+        // one's as soon as its compressed bytes have arrived and its buffer has been parsed
+        hipStream_t inf_streams[2] = {nullptr, nullptr};
+        struct Pinned { uint8_t **h; hipEvent_t *e, *e2, *e3; hipStream_t &cs; hipStream_t *is; ~Pinned() {
             if (cs) (void)hipStreamSynchronize(cs);
-            if (is) (void)hipStreamSynchronize(is);
+            for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]);
             for (int i = 0; i < 2; ++i) {
                 if (h[i]) (void)hipHostFree(h[i]);
                 if (e[i]) (void)hipEventDestroy(e[i]);
                 if (e2[i]) (void)hipEventDestroy(e2[i]);
                 if (e3[i]) (void)hipEventDestroy(e3[i]);
             }
-            if (is) (void)hipStreamDestroy(is);
-        } } pinned{h_chunk, chunk_done, inflated, parsed_ev, copy_stream, inf_stream};
+            for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamDestroy(is[i]);
+        } } pinned{h_chunk, chunk_done, inflated, parsed_ev, copy_stream, inf_streams};
         if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         {
             // The inflate stream gets the LOWEST priority, which also gives it a hardware queue of its own: the runtime deals streams of
@@ -1238,11 +1271,14 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             // with GPU_MAX_HW_QUEUES=8 — per slab inflate + copy instead of their maximum).  A long-running, latency-bound kernel is
             // the right thing to give way to copies and parse kernels in any case.
             int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && getenv("NM_BED_FLAT_PRIORITY") == nullptr)
-                HIP_TRY(hipStreamCreateWithPriority(&inf_stream, hipStreamNonBlocking, least));
-            else
-                HIP_TRY(hipStreamCreateWithFlags(&inf_stream, hipStreamNonBlocking));
+            const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && getenv("NM_BED_FLAT_PRIORITY") == nullptr;
+            const int n_inf = getenv("NM_BED_ONE_INFLATE_STREAM") ? 1 : 2;          // (A/B: the slabs' kernels one after the other)
+            for (int i = 0; i < n_inf; ++i) {
+                if (prio) HIP_TRY(hipStreamCreateWithPriority(&inf_streams[i], hipStreamNonBlocking, least));
+                else HIP_TRY(hipStreamCreateWithFlags(&inf_streams[i], hipStreamNonBlocking));
+            }
         }
+        auto inf_stream_of = [&](int buf) { return inf_streams[buf] ? inf_streams[buf] : inf_streams[0]; };
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));       // (a chunk is at most SLAB_BYTES = CHUNK of file)
             HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));
@@ -1266,13 +1302,14 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         // next slab's compressed bytes on the copy stream, which then travel only after the inflate (measured: 0.036 s of 0.042 per slab)
         unsigned long long *h_words = nullptr;                         // [2] end of lines, [2] status
         HIP_TRY(hipHostMalloc((void **)&h_words, 64, hipHostMallocDefault));
-        struct FreeWords { unsigned long long *p; hipStream_t &is; ~FreeWords() { if (is) (void)hipStreamSynchronize(is); (void)hipHostFree(p); } } free_words{h_words, inf_stream};
+        struct FreeWords { unsigned long long *p; hipStream_t *is; ~FreeWords() { for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]); (void)hipHostFree(p); } } free_words{h_words, inf_streams};
         volatile unsigned long long *end_of_lines_h = h_words, *status_h = h_words + 2;
         double t_copy_slab[2] = {0, 0};
         // stages (1) and (2) of slab si: everything it needs goes to the device, its inflate is queued
         auto stage_slab = [&](size_t si) -> int {
             const InfSlab &sl = inf_slabs[si];
             const int b = (int)(si % n_buf);
+            const hipStream_t inf_stream = inf_stream_of(b);
             uint8_t *text = d_text[b];
             // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
             std::vector<InfPiece> &pieces = hp[b];

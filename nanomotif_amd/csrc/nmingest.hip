@@ -1,5 +1,6 @@
 // libnmscan — raw pileup ingestion: the reference's three pre-filters on the device, classification into the state
 // planes, kept-row counts (C ABI: nm_ingest_pileup / nm_ingest_results, include/nmscan.h).
+#include <chrono>
 #include "nmscan_internal.h"
 
 using namespace nmdetail;
@@ -689,12 +690,19 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (n_rows && (!contig_id || !position || !mod_code || !strand || !fraction_mod || !nvalid_cov)) return fail(NM_EINVAL, "NULL column");
     if (!(high > low)) return fail(NM_EINVAL, "high threshold must exceed low");
     HIP_TRY(hipSetDevice(c->device));
+    // NM_INGEST_TIMING=1: where the host's time in this call goes (stderr, one line)
+    const bool timing = getenv("NM_INGEST_TIMING") != nullptr;
+    double t_marks[8] = {};
+    int n_marks = 0;
+    auto mark = [&] { if (timing && n_marks < 8) t_marks[n_marks++] = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    mark();
     HIP_TRY(hipStreamSynchronize(c->stream));      // an asynchronous scoring launch may still read the planes replaced below
     {
         const int rcj = nmdetail::join_lanes(c);
         if (rcj) return rcj;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    mark();                                        // [1] what was queued before (the assembly's pack kernel) has finished
     const size_t words = plane_words(c);
     const size_t n_groups = (size_t)c->n_contigs * NM_MAX_MOD_CODES;        // reported: kept rows per (contig, code < 8)
     const size_t n_fgroups = (size_t)c->n_contigs * NM_CODE_STRIDE;         // frequency-filter groups: every code
@@ -800,6 +808,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     ING_ALLOC(d_wave_first, ((size_t)n_waves + 1) * 8);
     ING_ALLOC(d_packed_first, ((size_t)n_waves + 1) * 8);
     hipError_t e = hipSuccess;
+    mark();                                        // [2] slot planes, tables, scratch allocated
     nmdetail::busy_begin(c);
     e = hipMemsetAsync(d_cnt, 0, n_fgroups * 2 * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_kept, 0, n_groups * 4, c->stream);
@@ -825,6 +834,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { nmdetail::busy_end(c); cleanup(); invalidate(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
             use_list = order_flags == 0;
+            mark();                                // [3] counting pass done (the host waits for the row order and the candidate count)
         }
         CandList lists[2] = {};
         if (use_list) {
@@ -873,6 +883,7 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     }
     e = hipGetLastError();
     nmdetail::busy_end(c);
+    mark();                                        // [4] everything else queued
     if (e != hipSuccess) { cleanup(); invalidate(); return fail(NM_EHIP, "ingest launch failed: %s", hipGetErrorString(e)); }
     unsigned long long scal[4] = {0, 0, 0, 0};
     unsigned int err = 0;
@@ -881,7 +892,14 @@ static int ingest_impl(nm_ctx *c, uint64_t n_rows, const uint32_t *contig_id, co
     if (e == hipSuccess) e = hipMemcpyAsync(&err, c->d_err, 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(part_kept.data(), d_kept, n_groups * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    mark();                                        // [5] the device is done
     cleanup();
+    mark();                                        // [6] scratch given back
+    if (timing && n_marks == 7)
+        fprintf(stderr, "[nm_ingest] %llu rows: waiting for earlier work %.2f ms, allocations %.2f ms, clears + counting pass + wait %.2f ms, "
+                        "queueing the rest %.2f ms, waiting for it %.2f ms, freeing scratch %.2f ms\n", (unsigned long long)n_rows,
+                (t_marks[1] - t_marks[0]) * 1e3, (t_marks[2] - t_marks[1]) * 1e3, (t_marks[3] - t_marks[2]) * 1e3, (t_marks[4] - t_marks[3]) * 1e3,
+                (t_marks[5] - t_marks[4]) * 1e3, (t_marks[6] - t_marks[5]) * 1e3);
     if (e != hipSuccess) { invalidate(); return fail(NM_EHIP, "ingest failed: %s", hipGetErrorString(e)); }
     if (err & 1u) { invalidate(); return fail(NM_EINVAL, "pileup row with contig_id / position / mod code outside the uploaded assembly"); }
     if (err & 8u) { invalidate(); return fail(NM_EINVAL, "pileup row of a contig that is not listed in part_contigs"); }

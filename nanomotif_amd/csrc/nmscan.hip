@@ -660,6 +660,7 @@ int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
         return false;
     };
     int idx;
+    std::unique_lock<std::mutex> lk(c->wait_mu);
     if (mode >= 2) idx = NM_STAGE_RING + (mode - 2);
     else if (mode == 1) {
         idx = c->stage_next_deep;
@@ -672,6 +673,7 @@ int ensure_stage(nm_ctx *c, size_t bytes, int mode) {
         for (int tries = 0; tries < NM_STAGE_RING && held(idx); ++tries) idx = (idx + 1) % NM_STAGE_RING;     // (two flights may hold both)
     }
     if (held(idx)) return fail(NM_ESTATE, "staging ring: every pair is held by an uncollected batch");
+    lk.unlock();
     nm_ctx::Stage &st = c->stage[idx];
     if (!st.busy) HIP_TRY(hipEventCreateWithFlags(&st.busy, hipEventDisableTiming));
     if (st.pending) {
@@ -788,7 +790,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     nm_ctx::Waiting &wait_slot = spec ? c->spec_wait[flight] : c->score_wait[flight];
     if (defer) {
         if (wait_slot.open) return fail(NM_ESTATE, "nm_score_batch_begin: the previous batch has not been collected (nm_score_batch_end)");
-        wait_slot = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+        nmdetail::wait_set(c, wait_slot, nm_ctx::Waiting{nullptr, 0, nullptr, true});
     }
     if (n_cand == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -968,7 +970,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     if (c->prog_cap_dw < need_dw) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->copy_stream));
-        if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+        HIP_TRY(nmdetail::sync_flight_streams(c));
         rc = join_lanes(c);
         if (rc) return rc;
         if (c->d_programs) (void)nmdetail::dev_free(c->d_programs);
@@ -1121,7 +1123,7 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     c->last_compact = all_compact ? n_prog : 0;
     c->last_general = all_compact ? 0 : n_prog;
     if (defer) {
-        wait_slot = nm_ctx::Waiting{hs + off_counts, out_bytes, c->cur_stage, true};
+        nmdetail::wait_set(c, wait_slot, nm_ctx::Waiting{hs + off_counts, out_bytes, c->cur_stage, true});
     } else if (via_stage) {
         HIP_TRY(hipEventSynchronize(c->cur_stage->busy));
         memcpy(h_out, hs + off_counts, out_bytes);
@@ -1260,7 +1262,7 @@ int nm_ctx_destroy(nm_ctx *c) {
         if (c->d_spec_counts[f]) (void)nmdetail::dev_free(c->d_spec_counts[f]);
         if (c->d_flight_counts[f]) (void)nmdetail::dev_free(c->d_flight_counts[f]);
     }
-    if (c->flight_stream) (void)hipStreamDestroy(c->flight_stream);
+    for (hipStream_t s : c->flight_stream) if (s) (void)hipStreamDestroy(s);
     if (c->d_win_planes) (void)nmdetail::dev_free(c->d_win_planes);
     if (c->d_win_alive) (void)nmdetail::dev_free(c->d_win_alive);
     if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
@@ -1542,7 +1544,7 @@ int nmdetail::score_batch_spec_begin(nm_ctx *c, int flight, uint32_t n_cand, con
                                      hipStream_t st) {
     if (n_cand && (!cand_bin || !cand_mod_slot)) return fail(NM_EINVAL, "NULL argument");
     const int rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true, &spec, st, flight);
-    if (rc) c->spec_wait[flight].open = false;
+    if (rc) nmdetail::wait_close(c, c->spec_wait[flight]);
     return rc;
 }
 
@@ -1555,7 +1557,7 @@ int nmdetail::score_batch_flight_begin(nm_ctx *c, int flight, uint32_t n_cand, c
     if (rc) return rc;
     rc = score_impl(c, n_cand, cand_bin, cand_mod_slot, cand_len, cand_modpos, cand_mask_offset, cand_masks, c->d_flight_counts[flight], nullptr, nullptr, true,
                     nullptr, nullptr, flight);
-    if (rc) c->score_wait[flight].open = false;
+    if (rc) nmdetail::wait_close(c, c->score_wait[flight]);
     return rc;
 }
 
@@ -1563,7 +1565,7 @@ int nmdetail::score_batch_flight_end(nm_ctx *c, int flight, int64_t *out_counts)
     if (!c || flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
     if (!c->score_wait[flight].open) return fail(NM_ESTATE, "score batch end without begin");
     const nm_ctx::Waiting w = c->score_wait[flight];
-    c->score_wait[flight].open = false;
+    nmdetail::WaitCloser closer{c, &c->score_wait[flight], nullptr};          // (the pair stays held until the counts are copied out)
     if (w.bytes == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(w.stage->busy));

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -104,9 +105,10 @@ struct ReadStats {
 // Staging pairs (device + pinned host buffer) and parts of the program table.  Scoring walks all of them: the host side,
 // the upload and the compile of batch k+1 ... k+3 run while batch k is scored — on a small shard of a multi-GPU run that
 // chain (~85 us) is as long as the scoring kernel itself, two pairs would hide only one kernel's worth of it.
-#define NM_STAGE_RING 4
-#define NM_FLIGHTS 2                           /* batches of one kind that may be begun and not yet collected: the native search keeps two
-                                                  groups of tasks in flight, one travelling while the other is on the host (nmsearch.cpp) */
+#define NM_STAGE_RING 8
+#define NM_FLIGHTS NM_SEARCH_MAX_FLIGHTS        /* batches of one kind that may be begun and not yet collected: the native search keeps several
+                                                  groups of tasks in flight, some travelling while another is on the host (nmsearch.cpp);
+                                                  each holds up to two pairs of the ring (its children's batch, its regular scoring batch) */
 #define NM_STAGE_SLOTS (NM_STAGE_RING + NM_FLIGHTS)   /* + the pairs of the asynchronous window batches (nm_win_batch_w_begin) */
 
 struct nm_ctx {
@@ -180,7 +182,12 @@ struct nm_ctx {
         Stage *stage = nullptr;
         bool open = false;
     } score_wait[NM_FLIGHTS], win_wait[NM_FLIGHTS], spec_wait[NM_FLIGHTS];   // spec_wait: the speculative child scores riding on a window batch
-    hipStream_t flight_stream = nullptr;           // window batches of flight 1 (flight 0: copy_stream)
+    // The native search sends the batches of one flight from a thread of its own while the calling thread collects another flight's
+    // (nmsearch.cpp): the *_begin halves run on the sending thread, the *_end halves on the collecting one.  What the two share are
+    // these slots — ensure_stage looks at all of them to find a pair nobody holds — hence the mutex around every change of `open`;
+    // a pair stays held until its results have been copied out of the pinned half.
+    std::mutex wait_mu;
+    hipStream_t flight_stream[NM_FLIGHTS - 1] = {};   // window batches of flight f > 0 (flight 0: copy_stream), made on first use
     // speculative child scoring of the search: the tasks' background PSSMs [task][4][W] (doubles, rows A T G C) and the count table
     double *d_spec_bg = nullptr;
     uint32_t spec_tasks = 0, spec_width = 0;
@@ -258,6 +265,28 @@ inline void drop_ingest_rows(nm_ctx *c) {
 
 // pinned staging ring of the ctx (nmscan.hip): acquire a (device, host) buffer pair of at least `bytes`, and mark it
 // busy until the work enqueued so far on the ctx stream has run
+inline void wait_set(nm_ctx *c, nm_ctx::Waiting &slot, const nm_ctx::Waiting &v) {
+    std::lock_guard<std::mutex> lk(c->wait_mu);
+    slot = v;
+}
+inline void wait_close(nm_ctx *c, nm_ctx::Waiting &slot) {
+    std::lock_guard<std::mutex> lk(c->wait_mu);
+    slot.open = false;
+}
+struct WaitCloser {                                     // closes the slots of a collected batch when the *_end half returns, however it returns
+    nm_ctx *c;
+    nm_ctx::Waiting *a, *b;
+    ~WaitCloser() {
+        std::lock_guard<std::mutex> lk(c->wait_mu);
+        if (a) a->open = false;
+        if (b) b->open = false;
+    }
+};
+inline hipError_t sync_flight_streams(nm_ctx *c) {     // window batches of the search's further flights (nmwindows.hip: batch_stream)
+    for (hipStream_t s : c->flight_stream)
+        if (s) { const hipError_t e = hipStreamSynchronize(s); if (e != hipSuccess) return e; }
+    return hipSuccess;
+}
 int ensure_stage(nm_ctx *c, size_t bytes, int mode = 0);   // 0: pairs 0 / 1 in turn; 1: scoring, all NM_STAGE_RING pairs; 2 + f: the asynchronous window batch's own pair
 int release_stage(nm_ctx *c, hipStream_t s = nullptr);   // s: the stream that read the pair (default: c->stream)
 int join_lanes(nm_ctx *c);                               // host-side: the second scoring lane has drained

@@ -747,7 +747,88 @@ struct Backend {
     // also fills spec_info[n][2] and spec_counts[n][4][2] (speculative children, nmspec.h; column -1 where there are none)
     int (*window_end)(void *user, int flight, uint32_t n, int32_t *out, int32_t *spec_info, int64_t *spec_counts) = nullptr;
     uint32_t (*group_of)(void *user, uint32_t task) = nullptr;      // which flight a task travels with (both mod types of a bin together)
+    bool threaded_issue = false;                                    // the *_begin halves may run on another thread than the *_end halves
     void *user = nullptr;
+};
+
+// One thread that runs issue(f) for the flights handed to it, in the order they were handed over (or the caller itself: threaded = false).
+// The hand-over is two atomics per flight; both sides spin (the gaps are tens of microseconds), the thread sleeps after 400 us without work.
+class Sender {
+public:
+    Sender(bool threaded, std::function<int(int)> issue) : issue_(std::move(issue)) {
+        for (auto &s : state_) s.store(IDLE);
+        if (threaded) th_ = std::thread([this] { loop(); });
+    }
+    ~Sender() {
+        if (!th_.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_.store(true);
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void submit(int f) {
+        if (!th_.joinable()) { rc_[f] = issue_(f); state_[f].store(DONE); return; }
+        state_[f].store(QUEUED, std::memory_order_relaxed);
+        queue_[tail_ % QN] = f;
+        tail_.store(tail_ + 1, std::memory_order_release);
+        if (asleep_.load()) {
+            std::lock_guard<std::mutex> lk(m_);
+            cv_.notify_all();
+        }
+    }
+    // the flight's batches are out (or failed: the code, with the sending thread's message as this thread's nm_last_error)
+    int wait(int f) {
+        while (state_[f].load(std::memory_order_acquire) != DONE) relax();
+        state_[f].store(IDLE, std::memory_order_relaxed);
+        if (rc_[f] && th_.joinable()) return nm_set_error(rc_[f], "%s", err_[f].c_str());
+        return rc_[f];
+    }
+
+private:
+    enum { IDLE = 0, QUEUED = 1, DONE = 2 };
+    static constexpr unsigned QN = 2 * NM_SEARCH_MAX_FLIGHTS;
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
+    void loop() {
+        unsigned head = 0;
+        for (;;) {
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (tail_.load(std::memory_order_acquire) == head) {
+                if (stop_.load()) return;
+                relax();
+                if ((++spins & 255u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) {
+                    std::unique_lock<std::mutex> lk(m_);
+                    asleep_.store(1);
+                    cv_.wait(lk, [&] { return tail_.load() != head || stop_.load(); });
+                    asleep_.store(0);
+                }
+            }
+            const int f = queue_[head % QN];
+            head += 1;
+            rc_[f] = issue_(f);
+            if (rc_[f]) err_[f] = nm_last_error();
+            state_[f].store(DONE, std::memory_order_release);
+        }
+    }
+    std::function<int(int)> issue_;
+    std::thread th_;
+    std::atomic<int> state_[NM_SEARCH_MAX_FLIGHTS];
+    int rc_[NM_SEARCH_MAX_FLIGHTS] = {};
+    std::string err_[NM_SEARCH_MAX_FLIGHTS];
+    int queue_[QN] = {};
+    std::atomic<unsigned> tail_{0};
+    std::atomic<bool> stop_{false};
+    std::atomic<int> asleep_{0};
+    std::mutex m_;
+    std::condition_variable cv_;
 };
 
 int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
@@ -755,7 +836,7 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     const uint32_t W = P.width, WS = width_stride(W);
     // NM_SEARCH_TIMING: where the wall time of the lock-step loop goes (stderr, one line)
     const bool timing = getenv("NM_SEARCH_TIMING") != nullptr;
-    double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0;
+    double t_resume = 0, t_gather = 0, t_window = 0, t_score = 0, t_reply = 0, t_window_begin = 0, t_score_begin = 0, t_sender = 0;   // (t_gather and *_begin: the sending thread's)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     // NM_SEARCH_THREADS: host threads that advance the searches between two batches (default: half the hardware threads, at
     // most 12; a phase with fewer than NM_SEARCH_MIN_PARALLEL = 8 tasks runs on the calling thread).  1 Gbp run, 18 485 resumes, 10 ms of them the KL columns
@@ -782,7 +863,12 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
     // one group's batches are on the device the other group's replies are taken in, its state machines advanced and its next
     // batches sent.  A task's requests depend only on its own replies, so the grouping changes no result.  Callbacks answer at
     // once: one group.
-    const int n_flights = (B.window_begin && B.score_begin && tasks.size() >= 16 && getenv("NM_SEARCH_ONE_FLIGHT") == nullptr) ? 2 : 1;
+    int n_flights = 1;
+    if (B.window_begin && B.score_begin && tasks.size() >= 16 && getenv("NM_SEARCH_ONE_FLIGHT") == nullptr) {
+        n_flights = NM_SEARCH_DEFAULT_FLIGHTS;
+        if (const char *e = getenv("NM_SEARCH_FLIGHTS")) n_flights = std::max(1, std::min(NM_SEARCH_MAX_FLIGHTS, atoi(e)));
+        n_flights = (int)std::min<size_t>((size_t)n_flights, tasks.size() / 8);
+    }
     struct Flight {
         std::vector<uint32_t> members, s_task, w_task, s_owner;
         std::vector<char> s_motifs, w_motifs;
@@ -790,8 +876,8 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
         std::vector<int64_t> counts, spec_counts;
         std::vector<int32_t> wout, spec_info;
         bool flying = false;
-    } fl[2];
-    for (uint32_t i = 0; i < tasks.size(); ++i) fl[n_flights == 2 ? ((B.group_of ? B.group_of(B.user, i) : i) & 1u) : 0].members.push_back(i);
+    } fl[NM_SEARCH_MAX_FLIGHTS];
+    for (uint32_t i = 0; i < tasks.size(); ++i) fl[(B.group_of ? B.group_of(B.user, i) : i) % (uint32_t)n_flights].members.push_back(i);
     // the requests of a group go out: its window batch first, its scoring batch behind it
     auto issue = [&](int f) -> int {
         Flight &F = fl[f];
@@ -822,7 +908,7 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
                                           : B.window(B.user, (uint32_t)F.w_task.size(), F.w_task.data(), F.w_kind.data(), F.w_motifs.data(), F.wout.data());
             if (rc) return rc;
             res->window_requests += F.w_task.size();
-            t_window += now() - t1;
+            t_window_begin += now() - t1;
         }
         if (!F.s_task.empty()) {
             t1 = now();
@@ -832,7 +918,7 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
             if (rc) return rc;
             res->rounds += 1;
             res->candidates += F.s_task.size();
-            t_score += now() - t1;
+            t_score_begin += now() - t1;
         }
         return NM_OK;
     };
@@ -887,25 +973,40 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
         }
         return NM_OK;
     };
+    // The SENDING THREAD (engine back end with several flights, one GPU): gathering a flight's requests and sending its batches — a
+    // dozen HIP calls, 30 us of this thread's time per iteration at 1 Gbp, 8.5 ms of a 33 ms search — happens on a thread of its own
+    // while this one waits for, takes in and resumes the next flight.  NM_SEARCH_NO_SENDER=1: everything on this thread.
+    const bool threaded = n_flights >= 2 && B.threaded_issue && getenv("NM_SEARCH_NO_SENDER") == nullptr;
+    Sender sender(threaded, [&](int f) { return issue(f); });
+    bool active[NM_SEARCH_MAX_FLIGHTS] = {};
     for (int f = 0; f < n_flights; ++f) {
-        const int rc = issue(f);
-        if (rc) return rc;
+        active[f] = true;
+        sender.submit(f);
     }
-    while (fl[0].flying || fl[1].flying)
+    for (bool any = true; any;) {
+        any = false;
         for (int f = 0; f < n_flights; ++f) {
-            int rc = collect(f);
+            if (!active[f]) continue;
+            const double t1 = now();
+            int rc = sender.wait(f);
+            t_sender += now() - t1;
             if (rc) return rc;
-            rc = issue(f);
+            if (!fl[f].flying) { active[f] = false; continue; }        // nothing left to ask for: the flight's searches have ended
+            rc = collect(f);
             if (rc) return rc;
+            sender.submit(f);
+            any = true;
         }
+    }
     for (const auto &t : tasks) { res->spec_hits += t.spec_hits; res->spec_misses += t.spec_misses; }
     if (timing)
         fprintf(stderr, "[nm_search] %llu lock-step iterations, speculative children: %llu answered, %llu asked for after all\n",
                 (unsigned long long)res->iterations, (unsigned long long)res->spec_hits, (unsigned long long)res->spec_misses);
     if (timing)
-        fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds: resume %.1f ms, request gathering %.1f ms, window batches %.1f ms, "
-                        "scoring batches %.1f ms, replies %.1f ms\n", tasks.size(), (unsigned long long)res->rounds, t_resume * 1e3,
-                t_gather * 1e3, t_window * 1e3, t_score * 1e3, t_reply * 1e3);
+        fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds, %d flights%s: resume %.1f ms, waiting for window batches %.1f ms, for scoring batches %.1f ms, "
+                        "replies %.1f ms, waiting for the sender %.1f ms | sending: request gathering %.1f ms, window batches %.1f ms, scoring batches %.1f ms\n",
+                tasks.size(), (unsigned long long)res->rounds, n_flights, threaded ? ", batches sent from a thread of their own" : "", t_resume * 1e3,
+                t_window * 1e3, t_score * 1e3, t_reply * 1e3, t_sender * 1e3, t_gather * 1e3, t_window_begin * 1e3, t_score_begin * 1e3);
     return NM_OK;
 }
 
@@ -1095,10 +1196,11 @@ int nm_search_run(nm_ctx *ctx, uint32_t n_tasks, const uint32_t *task_bin, const
     B.window_begin = engine_window_begin;
     B.window_end = engine_window_end;
     B.group_of = engine_group_of;
+    B.threaded_issue = u.reduce == nullptr;          // (a contig-sharded run all-reduces inside the *_end halves on the ctx's communicator: one thread)
     B.user = &u;
     rc = run_search(n_tasks, params, bg_pssm, total_windows, canonical, B, out);
     if (rc) {                                        // a round that failed half way: nothing stays open on the ctx
-        for (int f = 0; f < 2; ++f) {
+        for (int f = 0; f < NM_SEARCH_MAX_FLIGHTS; ++f) {
             (void)nmdetail::win_batch_spec_end(ctx, f, 0, nullptr, nullptr, nullptr);
             (void)nmdetail::score_batch_flight_end(ctx, f, nullptr);
         }

@@ -5,6 +5,9 @@
 
 #include "../../include/nmscan.h"
 
+#define NM_SEARCH_MAX_FLIGHTS 4     /* groups of tasks the native search may keep in flight (NM_SEARCH_FLIGHTS picks how many) */
+#define NM_SEARCH_DEFAULT_FLIGHTS 2
+
 namespace nmdetail {
 
 // per request of the window batch: its (bin, mod slot) on the engine and its search task (row of the background table of spec_setup)

@@ -483,7 +483,7 @@ static int win_grow(nm_ctx *c, uint32_t **buf, uint64_t *cap, uint64_t used, uin
     HIP_TRY(nmdetail::dev_malloc(&nb, ncap * 4));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));       // window batches in flight (batch_stream)
-    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+    HIP_TRY(nmdetail::sync_flight_streams(c));
     if (*buf && used) HIP_TRY(hipMemcpy(nb, *buf, used * 4, hipMemcpyDeviceToDevice));
     if (*buf) (void)nmdetail::dev_free(*buf);
     *buf = nb;
@@ -495,7 +495,7 @@ int nm_win_clear(nm_ctx *c) {
     if (!c) return fail(NM_EINVAL, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
-    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+    HIP_TRY(nmdetail::sync_flight_streams(c));
     c->win_tasks.clear();
     c->win_planes_used = c->win_alive_used = 0;
     c->win_tasks_dirty = true;
@@ -544,18 +544,19 @@ int nm_win_add_task(nm_ctx *c, uint32_t n_windows, uint32_t width, const uint8_t
 // NM_WIN_STREAM=0: everything on the ctx stream (A/B, tools/gpu_r4p.sh).
 static hipStream_t batch_stream(nm_ctx *c, int flight = 0) {
     static const bool second = getenv("NM_WIN_STREAM") == nullptr || atoi(getenv("NM_WIN_STREAM")) != 0;
-    if (flight == 1 && second) {                     // the second flight of the search: a stream of its own, made on first use
-        if (!c->flight_stream) {
+    if (flight >= 1 && flight < NM_FLIGHTS && second) {       // the further flights of the search: a stream of their own each, made on first use
+        hipStream_t &fs = c->flight_stream[flight - 1];
+        if (!fs) {
             // A plain stream.  NM_FLIGHT_PRIORITY=1 gives it a priority — and with it a hardware queue — of its own (A/B, tools/gpu_r5l.sh):
             // the search gets SLOWER (window batches 12.8 -> 22 ms at 1 Gbp, as with GPU_MAX_HW_QUEUES=8): two chains of small kernels
             // that run truly side by side lengthen each other more than taking turns on one queue costs
             int least = 0, greatest = 0;
             const bool prio = getenv("NM_FLIGHT_PRIORITY") != nullptr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
-            const hipError_t e = prio ? hipStreamCreateWithPriority(&c->flight_stream, hipStreamNonBlocking, greatest)
-                                      : hipStreamCreateWithFlags(&c->flight_stream, hipStreamNonBlocking);
-            if (e != hipSuccess) c->flight_stream = nullptr;
+            const hipError_t e = prio ? hipStreamCreateWithPriority(&fs, hipStreamNonBlocking, greatest)
+                                      : hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+            if (e != hipSuccess) fs = nullptr;
         }
-        if (c->flight_stream) return c->flight_stream;
+        if (fs) return fs;
     }
     return second && c->copy_stream ? c->copy_stream : c->stream;
 }
@@ -758,7 +759,7 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
     if (flight < 0 || flight >= NM_FLIGHTS) return fail(NM_EINVAL, "bad flight");
     if (c->win_wait[flight].open) return fail(NM_ESTATE, "nm_win_batch_w_begin: the previous batch has not been collected (nm_win_batch_w_end)");
     if (n_req == 0) {
-        c->win_wait[flight] = nm_ctx::Waiting{nullptr, 0, nullptr, true};
+        nmdetail::wait_set(c, c->win_wait[flight], nm_ctx::Waiting{nullptr, 0, nullptr, true});
         return NM_OK;
     }
     if (!req_task || !req_kind || !req_sets) return fail(NM_EINVAL, "NULL argument");
@@ -776,7 +777,7 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
         // the set-up work on the ctx stream is complete, no earlier batch is in flight: then the task table is replaced
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
-        if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+        HIP_TRY(nmdetail::sync_flight_streams(c));
         if (c->d_win_tasks_cap < c->win_tasks.size()) {
             if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);
             c->d_win_tasks = nullptr;
@@ -845,7 +846,7 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
         };
         const int rc = nmdetail::score_batch_spec_begin(c, flight, n_req * 4, cbin.data(), cslot.data(), src, st);
         if (rc) return rc;
-        c->win_wait[flight] = nm_ctx::Waiting{h_out, out_bytes, c->spec_wait[flight].stage, true};
+        nmdetail::wait_set(c, c->win_wait[flight], nm_ctx::Waiting{h_out, out_bytes, c->spec_wait[flight].stage, true});
         return NM_OK;
     }
     const size_t o_out = in_bytes;
@@ -876,7 +877,7 @@ static int win_batch_begin_impl(nm_ctx *c, uint32_t n_req, const uint32_t *req_t
     }
     rc = release_stage(c, st);
     if (rc) return rc;
-    c->win_wait[flight] = nm_ctx::Waiting{hs + o_out, out_bytes, c->cur_stage, true};
+    nmdetail::wait_set(c, c->win_wait[flight], nm_ctx::Waiting{hs + o_out, out_bytes, c->cur_stage, true});
     return NM_OK;
 }
 
@@ -905,8 +906,7 @@ int nmdetail::win_batch_spec_end(nm_ctx *c, int flight, uint32_t n_req, int32_t 
     if (!c->win_wait[flight].open) return fail(NM_ESTATE, "win_batch_spec_end without win_batch_spec_begin");
     const nm_ctx::Waiting w = c->win_wait[flight], s = c->spec_wait[flight];
     const bool had_spec = s.open;
-    c->win_wait[flight].open = false;
-    c->spec_wait[flight].open = false;
+    nmdetail::WaitCloser closer{c, &c->win_wait[flight], &c->spec_wait[flight]};      // (the pair stays held until the replies are copied out)
     if (w.bytes == 0) return NM_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(w.stage->busy));                    // recorded behind the whole chain
@@ -923,7 +923,7 @@ int nmdetail::spec_setup(nm_ctx *c, uint32_t n_tasks, uint32_t width, const doub
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));
-    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+    HIP_TRY(nmdetail::sync_flight_streams(c));
     if (c->d_spec_bg) (void)nmdetail::dev_free(c->d_spec_bg);
     c->d_spec_bg = nullptr;
     c->spec_tasks = c->spec_width = 0;
@@ -1547,7 +1547,7 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     c->win_planes_used = planes_used;
     c->win_alive_used = alive_used;
     if (c->copy_stream) HIP_TRY(hipStreamSynchronize(c->copy_stream));           // window batches of an earlier search (batch_stream)
-    if (c->flight_stream) HIP_TRY(hipStreamSynchronize(c->flight_stream));
+    HIP_TRY(nmdetail::sync_flight_streams(c));
     if (c->d_win_tasks_cap < c->win_tasks.size()) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_win_tasks) (void)nmdetail::dev_free(c->d_win_tasks);

@@ -252,7 +252,8 @@ class DeviceWindowExtractor:
 
     def plan_all(self, tasks, seed, one_stream_per_bin=False) -> dict:
         """Every task of a single-GPU run in ONE native call (nm_plan_windows): ``tasks`` = [(key, contig names present in
-        the filtered pileup of the task's mod type, mod_type)] in task order; ``seed``: what the reference seeds ``random``
+        the filtered pileup of the task's mod type — or their engine indices, a uint32 array in the order of the sorted names —,
+        mod_type)] in task order; ``seed``: what the reference seeds ``random``
         with before a task (plain pileup, find_motifs_bin.py:152-171) or before a bin's tasks (``one_stream_per_bin``: the
         bgzip path, :219-248 — consecutive tasks of one bin share a stream).  Windows are gathered, backgrounds drawn and
         counted on the device / on native threads; the interpreter's generator ends where the sequential run would leave it.
@@ -265,12 +266,11 @@ class DeviceWindowExtractor:
         slot = np.fromiter((self.engine.slot_of_mod[t[2]] for t in tasks), dtype=np.uint32, count=n)
         base = np.fromiter((ord(MOD_TYPE_TO_CANONICAL[t[2]]) for t in tasks), dtype=np.uint8, count=n)
         begin = np.zeros(n + 1, dtype=np.uint32)
-        ids = []
         res = self.resident
-        for k, (_, names, _) in enumerate(tasks):
-            ids += [res[x] for x in sorted(names)]
-            begin[k + 1] = len(ids)
-        ids = np.asarray(ids, dtype=np.uint32)
+        parts = [t[1] if isinstance(t[1], np.ndarray) else np.fromiter((res[x] for x in sorted(t[1])), dtype=np.uint32, count=len(t[1]))
+                 for t in tasks]
+        np.cumsum(np.fromiter((len(x) for x in parts), dtype=np.uint32, count=n), out=begin[1:])
+        ids = np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
         if one_stream_per_bin:
             group = np.zeros(n, dtype=np.uint32)
             g, last_bin = -1, object()

@@ -272,6 +272,35 @@ class FilteredPileup:
                 out.append(name)
         return out
 
+    def present_sorted_ids(self, bins: dict, id_of: dict, n_mods: int):
+        """``present`` for every (bin, mod type) at once, for the native plan: ``bins``: bin -> contig names, ``id_of``: contig name ->
+        engine contig index.  Returns {(bin, mod id): uint32 array of the engine indices of the bin's contigs that have a surviving
+        row of that mod type, in the order of their sorted NAMES (what ``DeviceWindowExtractor.plan_all`` plans a task in)}; pairs
+        without such a contig are absent.  A handful of numpy passes over all contigs instead of a Python loop per contig and task."""
+        index = getattr(self, "_name_index", None) or {n: i for i, n in enumerate(self.contig_names)}
+        order, flat, begin = list(bins), [], [0]
+        for b in order:
+            flat += sorted(bins[b])
+            begin.append(len(flat))
+        n = len(flat)
+        fidx = np.fromiter((index.get(x, -1) for x in flat), dtype=np.int64, count=n)
+        eng = np.fromiter((id_of[x] for x in flat), dtype=np.uint32, count=n)
+        kept = np.asarray(self.kept) != 0
+        known = fidx >= 0
+        out = {}
+        starts = np.asarray(begin[:-1], dtype=np.int64)
+        nonempty = np.flatnonzero(np.diff(begin) > 0)
+        for m in range(n_mods):
+            mask = known & kept[np.where(known, fidx, 0), m] if n else np.zeros(0, bool)
+            if not mask.any():
+                continue
+            per_bin = np.zeros(len(order), dtype=np.int64)
+            per_bin[nonempty] = np.add.reduceat(mask.astype(np.int64), starts[nonempty])
+            for bi in np.flatnonzero(per_bin).tolist():
+                lo, hi = begin[bi], begin[bi + 1]
+                out[(order[bi], m)] = eng[lo:hi][mask[lo:hi]]
+        return out
+
     def positions(self, contig_names, mod_id):
         """(plus, minus): name -> ascending positions of confident rows, one entry for every listed contig that has
         at least one surviving row of this mod type (find_motifs_bin.py:629: contigs present in the bin pileup)."""
@@ -333,6 +362,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
     plan_natively = (extractor is not None and extractor.row_counts is not None and extractor.allreduce_i64 is None
                      and os.environ.get("NANOMOTIF_PLAN_PER_TASK") != "1")
     native_tasks = []
+    present_ids = filtered.present_sorted_ids(bins, extractor.resident, len(MOD_TYPES)) if plan_natively else None
     # task order and seeding follow the reference: plain pileup = one task per (bin, mod type), each seeded afresh
     # (find_motifs_bin.py:152-171); bgzip = one task per bin, seeded once, mod types in constants order (:219-222, 248)
     for bin_name in bins:
@@ -343,11 +373,13 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
         for mt_id, mod_type in enumerate(MOD_TYPES):
             if extractor is not None and extractor.row_counts is not None:
                 plus = minus = None
+                if plan_natively:
+                    ids = present_ids.get((bin_name, mt_id))
+                    if ids is not None:
+                        native_tasks.append(((bin_name, mod_type), ids, mod_type))
+                    continue
                 names = filtered.present(bins[bin_name], mt_id)
                 if not names:
-                    continue
-                if plan_natively:
-                    native_tasks.append(((bin_name, mod_type), names, mod_type))
                     continue
             else:
                 plus, minus = filtered.positions(bins[bin_name], mt_id)

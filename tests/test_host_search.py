@@ -149,3 +149,33 @@ def test_kl_columns_equals_scipy_entropy():
         q[rng.integers(4), rng.integers(41)] = 0.0          # inf where p > 0
         a, b = ps.kl_divergence_columns(p, q), entropy(p, q)
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_present_sorted_ids_equals_present_per_task():
+    """The native plan's vectorised presence table (FilteredPileup.present_sorted_ids) against ``present`` task by task: contigs
+    unknown to the pileup, empty bins, mod types nobody has."""
+    from nanomotif_amd.find_motifs_bin import FilteredPileup
+    rng = np.random.default_rng(3)
+    names = [f"contig_{i:03d}" for i in rng.permutation(60)]
+    kept = (rng.random((60, 8)) < 0.4).astype(np.uint32) * rng.integers(1, 9, (60, 8)).astype(np.uint32)
+    kept[:, 2] = 0                                            # a mod type without rows
+    z = np.zeros(0)
+    f = FilteredPileup(names, z, z, z, z, kept)
+    all_names = names + ["not_in_the_pileup_1", "not_in_the_pileup_2"]
+    order = rng.permutation(len(all_names))
+    bins = {}
+    for k, i in enumerate(order.tolist()):
+        bins.setdefault(f"bin_{k % 7}", []).append(all_names[i])
+    bins["bin_of_strangers"] = ["not_in_the_pileup_3"]
+    id_of = {n: 1000 + i for i, n in enumerate(sorted(set(all_names) | {"not_in_the_pileup_3"}))}
+    got = f.present_sorted_ids(bins, id_of, 3)
+    n_tasks = 0
+    for b, members in bins.items():
+        for m in range(3):
+            want = [id_of[x] for x in sorted(f.present(members, m))]
+            if want:
+                n_tasks += 1
+                assert got[(b, m)].tolist() == want and got[(b, m)].dtype == np.uint32
+            else:
+                assert (b, m) not in got
+    assert n_tasks == len(got) and n_tasks > 10 and ("bin_of_strangers", 0) not in got

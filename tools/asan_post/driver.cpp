@@ -15,6 +15,7 @@
 
 #include "../../include/nmscan.h"
 
+extern "C" const char *nm_last_error(void) { return ""; }
 int nm_set_error(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
