@@ -480,7 +480,7 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
                          "the_wall_is": max(timed, key=timed.get), "assembly_s_per_Gbp": (t.get("assembly_s") or 0.0) / (total_bp / 1e9),
                          "motif_rows": max(len(open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read().splitlines()) - 1, 0)}
             if extra_env:
-                legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith(("[bed]", "[fasta]", "[nm_search]"))][:80]
+                legs[leg]["parser_slab_log"] = [ln for ln in r.stderr.splitlines() if ln.startswith(("[bed]", "[fasta]", "[nm_search]", "[nm_ingest]", "[nm_plan_windows]", "[main]"))][:80]
         out["legs"] = legs
         texts = {leg: open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read() for leg in legs if "error" not in legs[leg]}
         if len(texts) >= 2:

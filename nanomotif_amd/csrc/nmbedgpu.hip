@@ -318,6 +318,27 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
         // round trip — and lanes without a match in progress decode their next symbol meanwhile.
         unsigned int pend = 0, pdist = 0;                        // bytes of the match in progress still to copy, its distance
         for (;;) {                                               // the block's symbols
+            // a lane without a match in progress decodes its next symbol; a lane that has one — from this very iteration or an earlier
+            // one — then copies a piece of it: a short match costs ONE turn of the wave, not two (a third of the turns at 1 Gbp)
+            if (!pend) {
+                int sym = inf_decode(b, kl, T.lsym, lane);
+                if (sym < 0) { err = 12; break; }
+                if (sym < 256) {
+                    if (o >= pc.out_len) { err = 13; break; }
+                    dst[o++] = (unsigned char)sym;
+                } else if (sym == 256) break;
+                else {
+                    sym -= 257;
+                    if (sym >= 29) { err = 14; break; }
+                    const unsigned int len = INF_LBASE[sym] + b.get(INF_LEXT[sym]);
+                    const int ds = inf_decode(b, kd, T.dsym, lane);
+                    if (ds < 0 || ds >= 30) { err = 15; break; }
+                    const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
+                    if (dist > o || o + len > pc.out_len) { err = 16; break; }
+                    pend = len;                                      // copied piece by piece by the iterations that follow
+                    pdist = dist;
+                }
+            }
             if (pend) {
                 unsigned char *d = dst + o;
                 const unsigned char *src = d - pdist;
@@ -365,24 +386,6 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
                 }
                 o += done;
                 pend -= done;
-                continue;
-            }
-            int sym = inf_decode(b, kl, T.lsym, lane);
-            if (sym < 0) { err = 12; break; }
-            if (sym < 256) {
-                if (o >= pc.out_len) { err = 13; break; }
-                dst[o++] = (unsigned char)sym;
-            } else if (sym == 256) break;
-            else {
-                sym -= 257;
-                if (sym >= 29) { err = 14; break; }
-                const unsigned int len = INF_LBASE[sym] + b.get(INF_LEXT[sym]);
-                const int ds = inf_decode(b, kd, T.dsym, lane);
-                if (ds < 0 || ds >= 30) { err = 15; break; }
-                const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
-                if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                pend = len;                                      // copied piece by piece by the iterations that follow
-                pdist = dist;
             }
         }
     }
@@ -1339,6 +1342,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                     pool.emplace_back([&, t] {
                         const uint64_t a = bytes * t / nt, e = bytes * (t + 1) / nt;
                         if (e > a) memcpy(dst + a, src.z + ch.file_lo + a, (size_t)(e - a));
+                        // the pages just copied leave the page tables HERE, a few thousand at a time on the copying threads (read lock
+                        // of the address space): unmapping the whole file at the end — 3.5 million entries at 1 Gbp — held the
+                        // address-space lock for 0.2 s, and whoever allocated or faulted meanwhile (the pre-filters' scratch) waited
+                        const uintptr_t lo = ((uintptr_t)(src.z + ch.file_lo + a) + 4095u) & ~(uintptr_t)4095u, hi = (uintptr_t)(src.z + ch.file_lo + e) & ~(uintptr_t)4095u;
+                        if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED);
                     });
                 for (auto &th : pool) th.join();
                 if (bad) return fail(NM_EINVAL, "cannot read pileup '%s'", path);

@@ -415,16 +415,45 @@ def device_window_pipeline(eng, lengths: dict, mine: list, padding: int, world: 
         dist.all_gather_object(gathered, local)
         return {k: v for g in gathered for k, v in g.items()}
 
-    # valid sample starts per contig (seq.py:202-225), counted on the device
-    n_valid = {base: everywhere(dict(zip(mine, eng.contig_base_counts(base, padding).tolist())))
-               for base in sorted({MOD_TYPE_TO_CANONICAL[mt] for mt in pileup_mod.MOD_TYPES})}
-    # confident rows per contig and strand: the windows themselves are read from the methylated-state planes
-    row_counts = {mt: everywhere(dict(zip(mine, eng.methylated_row_counts(mt, padding).tolist())))
-                  for mt in pileup_mod.MOD_TYPES if mt in eng.slot_of_mod}
+    # valid sample starts per contig (seq.py:202-225), counted on the device; confident rows per contig and strand (the windows
+    # themselves are read from the methylated-state planes).  One GPU: the native plan (nm_plan_windows) counts both itself, so the
+    # tables are made only when the task-by-task path asks for them (NANOMOTIF_PLAN_PER_TASK=1): four device round trips and four
+    # dictionaries over every contig otherwise — 4 ms of a 1 Gbp run.
+    bases = sorted({MOD_TYPE_TO_CANONICAL[mt] for mt in pileup_mod.MOD_TYPES})
+    mods = [mt for mt in pileup_mod.MOD_TYPES if mt in eng.slot_of_mod]
+    if world == 1:
+        n_valid = _LazyTables(bases, lambda base: dict(zip(mine, eng.contig_base_counts(base, padding).tolist())))
+        row_counts = _LazyTables(mods, lambda mt: dict(zip(mine, eng.methylated_row_counts(mt, padding).tolist())))
+    else:
+        n_valid = {base: everywhere(dict(zip(mine, eng.contig_base_counts(base, padding).tolist()))) for base in bases}
+        row_counts = {mt: everywhere(dict(zip(mine, eng.methylated_row_counts(mt, padding).tolist()))) for mt in mods}
     reduce = allreduce_counts if world > 1 else None
     store = DeviceWindowStore(eng, allreduce=reduce)
     return store, DeviceWindowExtractor(eng, store, lengths, n_valid, padding, resident=eng.contig_index, allreduce_i64=reduce,
                                         row_counts=row_counts)
+
+
+class _LazyTables:
+    """``tables[key]`` made by ``make(key)`` on first use (the keys are known up front: ``in`` and iteration work without making any)."""
+
+    def __init__(self, keys, make):
+        self._keys, self._make, self._made = list(keys), make, {}
+
+    def __getitem__(self, key):
+        if key not in self._made:
+            if key not in self._keys:
+                raise KeyError(key)
+            self._made[key] = self._make(key)
+        return self._made[key]
+
+    def __contains__(self, key):
+        return key in self._keys
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
 
 
 def check_installation():
