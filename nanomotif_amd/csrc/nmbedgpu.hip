@@ -124,6 +124,7 @@ struct InfPiece {
 };
 
 constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
+constexpr int INF_TURN_SYMBOLS = 1;       // symbols a lane may decode per turn of its wave (bed_inflate_kernel)
 // A damaged deflate block is noticed at its end at the latest (the text cannot grow beyond the member's size: at most 65 536
 // symbols of at most 48 bits) and at the head of the next one: the bit reader never gets further than this past the stream.
 constexpr size_t INF_OVERRUN = 512u << 10;
@@ -240,11 +241,23 @@ __constant__ unsigned short INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33
 __constant__ unsigned char INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+#ifdef NM_BED_PROBES
+// probe builds (NM_CXXFLAGS=-DNM_BED_PROBES, tools/gpu_r5ac.sh): NM_BED_INFLATE_PROBE = 1: matches are not copied, + 2: literals are not
+// stored, + 4: a block ends behind its first pair of Huffman tables — what each part of bed_inflate_kernel costs (the text is garbage: the
+// call fails on purpose after printing the slab's time)
+__device__ int g_inf_probe = 0;
+#endif
+
 // status: 0, or (piece index << 8 | what went wrong) of the first bad block
 __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned char *__restrict__ in, const InfPiece *__restrict__ pieces, unsigned int n_pieces,
                                                                 unsigned char *__restrict__ text, unsigned char *__restrict__ scratch,
                                                                 unsigned int *__restrict__ status) {
     __shared__ InfTables T;
+#ifdef NM_BED_PROBES
+    const int probe = g_inf_probe;
+#else
+    constexpr int probe = 0;
+#endif
     const int lane = threadIdx.x;
     const unsigned int i = blockIdx.x * INF_LANES + lane;
     if (i >= n_pieces) return;
@@ -311,59 +324,33 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
             if (r < 0 || (r > 0 && ndist - T.dcount[0][lane] != 1)) { err = 11; break; }
         }
         const InfCounts kl = inf_counts(T.lcount, lane), kd = inf_counts(T.dcount, lane);
+        if (probe & 4) break;
         // The 64 lanes of a wave decode 64 blocks in lock-step: whatever ONE lane does in an iteration, the others wait for.  A match
         // used to be copied whole inside the iteration that decoded it — every iteration then cost the LONGEST match among the lanes,
         // one round trip through memory per 8 (or 32) bytes of it (round 5: that was most of a lane's 64 ms per block).  Now a match is
         // a STATE of the lane: an iteration copies one bounded piece of it — at most 32 bytes, all loaded before any is stored: one
         // round trip — and lanes without a match in progress decode their next symbol meanwhile.
         unsigned int pend = 0, pdist = 0;                        // bytes of the match in progress still to copy, its distance
-        for (;;) {                                               // the block's symbols
-            // a lane without a match in progress decodes its next symbol; a lane that has one — from this very iteration or an earlier
-            // one — then copies a piece of it: a short match costs ONE turn of the wave, not two (a third of the turns at 1 Gbp)
-            if (!pend) {
-                int sym = inf_decode(b, kl, T.lsym, lane);
-                if (sym < 0) { err = 12; break; }
-                if (sym < 256) {
-                    if (o >= pc.out_len) { err = 13; break; }
-                    dst[o++] = (unsigned char)sym;
-                } else if (sym == 256) break;
-                else {
-                    sym -= 257;
-                    if (sym >= 29) { err = 14; break; }
-                    const unsigned int len = INF_LBASE[sym] + b.get(INF_LEXT[sym]);
-                    const int ds = inf_decode(b, kd, T.dsym, lane);
-                    if (ds < 0 || ds >= 30) { err = 15; break; }
-                    const unsigned int dist = INF_DBASE[ds] + b.get(INF_DEXT[ds]);
-                    if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                    pend = len;                                      // copied piece by piece by the iterations that follow
-                    pdist = dist;
-                }
-            }
-            if (pend) {
+        // A piece's source is LOADED at the end of one turn and STORED at the beginning of the next: the round trip to L2 / HBM that
+        // every turn used to wait out (some lane of the 64 always has a copy whose source missed L2; the counters of
+        // profiles/r5/bed_device/inflate_pmc.txt: 71 % of a wave's life waiting, one exposed round trip per turn) now runs under the
+        // other lanes' decoding.  Same-lane order keeps it exact: a piece is stored before the next piece's (or the next match's)
+        // source is asked for, and a lane decodes nothing while it has a match in progress.
+        struct Q { unsigned long long a, b; };
+        Q q0 = {0, 0}, q1 = {0, 0};
+        unsigned int fl = 0, fl_kind = 0;                        // bytes loaded and not yet stored (0: none); 1: 16-byte words, 2: one 8-byte word, 3: periodic
+        for (;;) {                                               // the block's symbols, one TURN of the wave per pass
+            if (fl) {                                            // (1) the piece loaded in the last turn goes out
                 unsigned char *d = dst + o;
-                const unsigned char *src = d - pdist;
-                unsigned int done;
-                if (o + 40 > pc.out_len) {                       // at the block's end: no room for whole words
-                    done = pend;
-                    for (unsigned int k = 0; k < done; ++k) d[k] = src[k];
-                } else if (pdist >= 8) {
-                    // up to four 8-byte words, as many as lie wholly in front of the piece's first store
-                    const unsigned int nw = pdist >= 32 ? 4u : pdist >> 3;
-                    done = pend < 8 * nw ? pend : 8 * nw;
-                    unsigned long long v0, v1 = 0, v2 = 0, v3 = 0;
-                    memcpy(&v0, src, 8);
-                    if (nw > 1 && done > 8) memcpy(&v1, src + 8, 8);
-                    if (nw > 2 && done > 16) memcpy(&v2, src + 16, 8);
-                    if (nw > 3 && done > 24) memcpy(&v3, src + 24, 8);
-                    memcpy(d, &v0, 8);
-                    if (nw > 1 && done > 8) memcpy(d + 8, &v1, 8);
-                    if (nw > 2 && done > 16) memcpy(d + 16, &v2, 8);
-                    if (nw > 3 && done > 24) memcpy(d + 24, &v3, 8);
+                if (fl_kind == 1) {
+                    memcpy(d, &q0, 16);
+                    if (fl > 16) memcpy(d + 16, &q1, 16);
+                } else if (fl_kind == 2) {
+                    memcpy(d, &q0.a, 8);
                 } else {
                     // a distance below 8 repeats its last `pdist` bytes: 16 bytes of the periodic sequence in two registers, the
                     // words of the piece are cut out of them at the phase they start with
-                    unsigned long long s8;
-                    memcpy(&s8, src, 8);
+                    const unsigned long long s8 = q0.a;
                     unsigned long long lo = 0, hi = 0;
                     unsigned int ph = 0;
 #pragma unroll
@@ -373,22 +360,81 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
                         else hi |= byte << (8 * (j - 8));
                         ph = ph + 1 == pdist ? 0 : ph + 1;
                     }
-                    done = pend < 32 ? pend : 32;
                     unsigned int r = 0;                           // phase of the next word = (bytes written so far) mod pdist
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if ((unsigned int)(8 * k) < done) {
+                        if ((unsigned int)(8 * k) < fl) {
                             const unsigned long long w = r ? (lo >> (8 * r)) | (hi << (64 - 8 * r)) : lo;
                             memcpy(d + 8 * k, &w, 8);
                         }
                         r = (r + 8) % pdist;
                     }
                 }
-                o += done;
-                pend -= done;
+                o += fl;
+                pend -= fl;
+                fl = 0;
+            }
+            // (2) a lane without a match in progress decodes its next symbol (INF_TURN_SYMBOLS > 1: several — measured slower, 0.66 ->
+            // 0.85 s at 1 Gbp: the wave then pays the longest run of literals among its lanes in every turn)
+            bool stop = false;                                   // end of block, or an error
+            for (int rep = 0; rep < INF_TURN_SYMBOLS && !pend && !stop; ++rep) {
+                int sym = inf_decode(b, kl, T.lsym, lane);
+                if (sym < 0) { err = 12; stop = true; }
+                else if (sym < 256) {
+                    if (o >= pc.out_len) { err = 13; stop = true; }
+                    else if (probe & 2) o += 1;
+                    else dst[o++] = (unsigned char)sym;
+                } else if (sym == 256) stop = true;
+                else {
+                    sym -= 257;
+                    if (sym >= 29) { err = 14; stop = true; }
+                    else {
+                        // base and extra bits of a length / distance code by ARITHMETIC (RFC 1951, 3.2.5: the codes come in groups of
+                        // four / two per extra bit): the __constant__ tables were four DEPENDENT per-lane loads per match — length
+                        // base, its extra bits, distance base, its extra bits, each a trip to L1 — in front of the copy's own
+                        const unsigned int lx = sym < 8 || sym == 28 ? 0u : ((unsigned int)sym >> 2) - 1u;
+                        const unsigned int lbase = sym < 8 ? 3u + (unsigned int)sym : sym == 28 ? 258u : 3u + ((4u + ((unsigned int)sym & 3u)) << lx);
+                        const unsigned int len = lbase + b.get((int)lx);
+                        const int ds = inf_decode(b, kd, T.dsym, lane);
+                        if (ds < 0 || ds >= 30) { err = 15; stop = true; }
+                        else {
+                            const unsigned int dx = ds < 4 ? 0u : ((unsigned int)ds >> 1) - 1u;
+                            const unsigned int dbase = ds < 4 ? 1u + (unsigned int)ds : 1u + ((2u + ((unsigned int)ds & 1u)) << dx);
+                            const unsigned int dist = dbase + b.get((int)dx);
+                            if (dist > o || o + len > pc.out_len) { err = 16; stop = true; }
+                            else {
+                                pend = len;                      // copied piece by piece, from this turn on
+                                pdist = dist;
+                            }
+                        }
+                    }
+                }
+            }
+            if (stop) break;                                     // (no match is in progress then: a lane decodes only without one)
+            if (probe & 1) { o += pend; pend = 0; }
+            if (pend) {                                          // (3) the next piece's source is asked for
+                unsigned char *d = dst + o;
+                const unsigned char *src = d - pdist;
+                if (o + 40 > pc.out_len) {                       // at the block's end there is no room for whole words: byte by byte, at once
+                    for (unsigned int k = 0; k < pend; ++k) d[k] = src[k];
+                    o += pend;
+                    pend = 0;
+                } else if (pdist >= 16) {
+                    // one or two 16-byte words, as many as lie wholly in front of the piece's first store
+                    const unsigned int nq = pdist >= 32 ? 2u : 1u;
+                    fl = pend < 16 * nq ? pend : 16 * nq;
+                    fl_kind = 1;
+                    memcpy(&q0, src, 16);
+                    if (fl > 16) memcpy(&q1, src + 16, 16);
+                } else {
+                    fl = pdist >= 8 ? (pend < 8 ? pend : 8) : (pend < 32 ? pend : 32);
+                    fl_kind = pdist >= 8 ? 2 : 3;
+                    memcpy(&q0.a, src, 8);
+                }
             }
         }
     }
+    if (probe) return;
     if (!err && o != pc.out_len) err = 17;
     if (!err && (size_t)(b.p - (in + pc.in_off)) > (size_t)pc.in_len + 8) err = 18;      // ran past the block's stream
     if (err) { atomicCAS(status, 0u, (unsigned int)err | (i << 8)); return; }
@@ -792,7 +838,14 @@ struct TextSource {
     size_t zn = 0;
     std::vector<nmbgzf::Piece> pieces;            // sorted by text_off, contiguous in the text
     ~TextSource() {
-        if (z) munmap(const_cast<uint8_t *>(z), zn);
+        // in pieces of 256 MiB: one munmap of a 14 GB pileup (3.5 million page-table entries where the copying threads' MADV_DONTNEED
+        // did not take) holds the address-space lock for 0.2 s, and every allocation of the other threads — the pre-filters' scratch —
+        // waits behind it; between two pieces they get their turn
+        if (z) {
+            constexpr size_t PIECE = 256u << 20;
+            uint8_t *base = const_cast<uint8_t *>(z);
+            for (size_t off = 0; off < zn; off += PIECE) munmap(base + off, std::min(PIECE, zn - off));
+        }
         if (fd >= 0) close(fd);
     }
     size_t piece_at(uint64_t off) const {          // the piece that holds text offset `off`
@@ -1359,7 +1412,17 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             HIP_TRY(hipStreamWaitEvent(inf_stream, chunk_done[(n_chunk - 1) % 2], 0));
             if (si >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(inf_stream, parsed_ev[b], 0));      // the text buffer has been parsed
             else if (si == 0) HIP_TRY(hipStreamSynchronize(c->stream));                             // (allocations, clears above)
-            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, inf_stream, d_comp[b],
+#ifdef NM_BED_PROBES
+            {
+                const int probe = getenv("NM_BED_INFLATE_PROBE") ? atoi(getenv("NM_BED_INFLATE_PROBE")) : 0;
+                HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_inf_probe), &probe, sizeof probe));
+            }
+#endif
+            // NM_BED_INFLATE_LDS_PAD (bytes of unused dynamic LDS per workgroup; A/B): fewer workgroups per CU.  The lanes' write fronts
+            // and match sources (~400 bytes per lane) of one XCD's 12 288 lanes overflow its 4 MB of L2 at six workgroups per CU (77 %
+            // hits, profiles/r5/bed_device/inflate_pmc.txt) — and matches are two thirds of the kernel's time (inflate_parts.txt)
+            static const unsigned lds_pad = getenv("NM_BED_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("NM_BED_INFLATE_LDS_PAD")) : 0u;
+            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), lds_pad, inf_stream, d_comp[b],
                                d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status);
             HIP_TRY(hipGetLastError());
             if (check_crc) {
@@ -1397,6 +1460,15 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             HIP_TRY(hipEventSynchronize(inflated[bi]));
             const double t_inflated = now();
             b->t_inflate += t_inflated - t_wait;
+#ifdef NM_BED_PROBES
+            if (getenv("NM_BED_INFLATE_PROBE") && atoi(getenv("NM_BED_INFLATE_PROBE"))) {
+                fprintf(stderr, "[bed] PROBE %s: slab %zu (%zu blocks, %.2f GB text): staged the next in %.3f s, waited %.3f s for the inflate\n", getenv("NM_BED_INFLATE_PROBE"), si,
+                        hp[bi].size(), sl.text / 1e9, t_wait - t_staged, t_inflated - t_wait);
+                if (last_slab || si == 3) return fail(NM_EINVAL, "inflate probe: the text is garbage on purpose");
+                HIP_TRY(hipEventRecord(parsed_ev[bi], c->stream));
+                continue;
+            }
+#endif
             const unsigned int status = (unsigned int)status_h[bi];
             const unsigned long long end_of_lines = end_of_lines_h[bi];
             const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
