@@ -13,7 +13,7 @@ def main():
     import torch
     from nanomotif_amd import e2e_synth, postprocess, synth
     from nanomotif_amd.engine import ScanEngine
-    out = os.path.join("gpurun_out", "cfg5_rows")
+    out = os.path.join("gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "cfg5_rows")       # (a second run into another directory: diff the texts)
     os.makedirs(out, exist_ok=True)
     mg = synth.make_metagenome(synth.config("cfg5"))
     eng = ScanEngine(0)
