@@ -1294,9 +1294,20 @@ __device__ __forceinline__ void wave_mem_sync() { __asm__ volatile("s_waitcnt vm
 
 __global__ __launch_bounds__(64) void bg_draw_kernel(const uint32_t *__restrict__ raw, uint32_t raw_len, const DrawCall *__restrict__ calls,
                                                      const uint32_t *__restrict__ group_call_off, const uint64_t *__restrict__ group_scratch_off,
-                                                     uint32_t *scratch, uint32_t *ranks, uint32_t *discard, uint32_t *consumed /*[n_groups]*/) {
+                                                     uint32_t *scratch, uint32_t *ranks, uint32_t *discard, uint32_t *consumed /*[n_groups]*/,
+                                                     uint32_t lds_words) {
+    // The membership bitmap (or the pool) of the group's calls lives in LDS when it fits the launch's dynamic allocation — the words of
+    // a 300 kbp contig's valid starts are 10 KB —: every tile of 64 draws is a dependent load, a round of atomics and a fence on it, and
+    // through a flat pointer to LDS that is a hundred clocks instead of a trip to L2.  A group that needs more keeps the global scratch.
+    extern __shared__ uint32_t lds_bm[];
     const uint32_t g = blockIdx.x, lane = threadIdx.x;
-    uint32_t *bm = scratch + group_scratch_off[g];
+    const uint64_t my_words = group_scratch_off[g + 1] - group_scratch_off[g];
+    const bool in_lds = my_words <= (uint64_t)lds_words;
+    uint32_t *bm = in_lds ? static_cast<uint32_t *>(lds_bm) : scratch + group_scratch_off[g];
+    if (in_lds) {
+        for (uint32_t i = lane; i < (uint32_t)my_words; i += 64) lds_bm[i] = 0;
+        wave_mem_sync();
+    }
     uint32_t p = 0;                                       // raw draws consumed so far (wave-uniform)
     bool overflow = false;
     for (uint32_t ci = group_call_off[g]; ci < group_call_off[g + 1] && !overflow; ++ci) {
@@ -1346,15 +1357,23 @@ __global__ __launch_bounds__(64) void bg_draw_kernel(const uint32_t *__restrict_
             const bool valid = in_range && r < n;
             const uint32_t word = valid ? r >> 5 : 0u, bit = 1u << (r & 31u);
             const bool cand = valid && !(load_coherent(bm + word) & bit);
+            // Every candidate sets its bit at once and looks at what was there: a candidate that finds the bit SET shares its value with
+            // another lane of this tile (nobody had it before the tile) — one tile in twenty.  Only then the lanes of that value are
+            // sorted out, the lowest keeps it (random.sample takes the first occurrence).  (The loop used to take one turn per DISTINCT
+            // value of every tile, ~50 turns: most of the kernel's 3 ms for the 2e7 draws of the 1 Gbp plan.)
             bool keep = cand;
-            unsigned long long todo = __ballot(cand);
-            while (todo) {                                   // wave-uniform: one turn per distinct value of the tile
-                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            uint32_t before = 0;
+            if (cand) before = atomicOr(bm + word, bit);
+            unsigned long long lost = __ballot(cand && (before & bit));
+            while (lost) {                                   // wave-uniform: one turn per value that occurs twice in the tile
+                const int leader = __builtin_amdgcn_readfirstlane(__ffsll((long long)lost) - 1);
                 const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
                 const unsigned long long same = __ballot(cand && r == v);
-                if (cand && r == v && (int)lane != leader) keep = false;
-                todo &= ~same;
+                const int first = __ffsll((long long)same) - 1;
+                if (cand && r == v && (int)lane != first) keep = false;
+                lost &= ~same;
             }
+            const bool first_of_value = keep;                // (its bit is set; a later lane of the same value set it too, at most)
             unsigned long long sel = __ballot(keep);
             uint32_t advance = 64;
             if (selected + (uint32_t)__popcll(sel) >= k) {   // the call ends inside this tile: at its (k - selected)-th selection
@@ -1365,10 +1384,8 @@ __global__ __launch_bounds__(64) void bg_draw_kernel(const uint32_t *__restrict_
                 keep = keep && (int)lane <= last;
                 advance = (uint32_t)last + 1u;
             }
-            if (keep) {
-                out[selected + (uint32_t)__popcll(sel & ((1ull << lane) - 1ull))] = r;
-                atomicOr(bm + word, bit);
-            }
+            if (keep) out[selected + (uint32_t)__popcll(sel & ((1ull << lane) - 1ull))] = r;
+            else if (first_of_value) atomicAnd(bm + word, ~bit);      // drawn after the call's last selection: not taken, the bit goes back
             selected += (uint32_t)__popcll(sel);
             p += advance;
             wave_mem_sync();                                 // this tile's bits before the next tile's membership loads
@@ -1660,11 +1677,15 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
         if (e == hipSuccess) e = hipMemsetAsync(d_draw + q_scr, 0, scratch_off[n_groups] * 4, c->stream);
         if (e == hipSuccess) {
             nmdetail::busy_begin(c);
-            hipLaunchKernelGGL(bg_draw_kernel, dim3(n_groups), dim3(64), 0, c->stream, reinterpret_cast<const uint32_t *>(d_draw + q_raw),
+            uint64_t max_words = 0;
+            for (uint32_t g = 0; g < n_groups; ++g) max_words = std::max<uint64_t>(max_words, scratch_off[g + 1] - scratch_off[g]);
+            static const bool no_lds = getenv("NM_DRAW_GLOBAL_BITMAP") != nullptr;       // (A/B: every bitmap in global memory)
+            const uint32_t lds_words = no_lds ? 0u : (uint32_t)std::min<uint64_t>(max_words, 8192);       // at most 32 KB per workgroup: five per CU
+            hipLaunchKernelGGL(bg_draw_kernel, dim3(n_groups), dim3(64), (size_t)lds_words * 4, c->stream, reinterpret_cast<const uint32_t *>(d_draw + q_raw),
                                (uint32_t)raw_len, reinterpret_cast<const DrawCall *>(d_draw + q_calls),
                                reinterpret_cast<const uint32_t *>(d_draw + q_coff), reinterpret_cast<const uint64_t *>(d_draw + q_soff),
                                reinterpret_cast<uint32_t *>(d_draw + q_scr), d_rank_col,
-                               reinterpret_cast<uint32_t *>(d_draw + q_disc), reinterpret_cast<uint32_t *>(d_draw + q_cons));
+                               reinterpret_cast<uint32_t *>(d_draw + q_disc), reinterpret_cast<uint32_t *>(d_draw + q_cons), lds_words);
             nmdetail::busy_end(c);
             e = hipGetLastError();
         }

@@ -210,11 +210,13 @@ class PostResults:
         self._cols = (self.task[:n].tolist(), self.stage[:n].tolist(), self.mod_position[:n].tolist(), self.mod_position_iupac[:n].tolist(),
                       self.counts[:n].tolist(), self.score[:n].tolist(), self.complement[:n].tolist())
         self._made = {}
+        from .postprocess import MotifRow
+        self._MotifRow = MotifRow
 
     def _row(self, i):
-        from .postprocess import MotifRow
         r = self._made.get(i)
         if r is None:
+            MotifRow = self._MotifRow                       # (bound once: an import statement per row costs a third of making the row)
             task, stage, modpos, modpos_iu, counts, score, complement = self._cols
             k = self.keys[task[i]]
             o, text = self._off, self._text

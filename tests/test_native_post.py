@@ -205,3 +205,23 @@ def test_native_post_on_the_best_candidates_of_real_searches():
         else:
             assert post.final(t) is None
     assert found >= 3
+
+
+def test_native_post_on_threads_equals_one_thread_and_the_python_twin(monkeypatch):
+    """run_post spreads the tasks' host work over threads from 64 tasks on (nmpost.cpp: contiguous ranges of tasks, request lists joined
+    in task order): 300 random tasks on 1 / 3 / 8 threads write the same stage tables, and they are the Python twin's."""
+    keys, rows = random_tasks(77, 300)
+
+    def dump(post):
+        return [[(r.motif, r.mod_position, r.n_mod, r.n_nomod, r.score, None if r.complement is None else r.complement.motif)
+                 for r in post.rows(t, s)] for t in range(len(keys)) for s in range(5)]
+    tables = {}
+    for n_thr in ("1", "3", "8"):
+        monkeypatch.setenv("NM_POST_THREADS", n_thr)
+        post = ns.postprocess_rows_custom(keys, rows, PAD, hash_scorer(77))
+        tables[n_thr] = (dump(post), post.batches, post.candidates)
+    assert tables["1"] == tables["3"] == tables["8"]
+    assert tables["1"][2] > 50                          # (merge candidates were scored: the joined request lists matter)
+    monkeypatch.delenv("NM_POST_THREADS")
+    total, post = compare(keys, rows, hash_scorer(77))  # default thread count against the Python twin, stage by stage
+    assert total > 500

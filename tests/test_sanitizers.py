@@ -41,3 +41,20 @@ def test_native_postprocessing_under_asan_and_ubsan(tmp_path):
     assert c.returncode == 0, c.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "identical exports" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.timeout(900)
+def test_native_postprocessing_on_threads_under_tsan(tmp_path):
+    """The same driver under ThreadSanitizer: run_post spreads its 400 tasks over threads (contiguous ranges, request lists joined in
+    task order) — no race report, exports identical between the two runs."""
+    src = tmp_path / "t.cpp"
+    src.write_text("int main() { return 0; }\n")
+    if not shutil.which("g++") or subprocess.run(["g++", "-fsanitize=thread", str(src), "-o", str(tmp_path / "t")], capture_output=True).returncode != 0:
+        pytest.skip("g++ -fsanitize=thread is not usable here")
+    exe = str(tmp_path / "tsan_post")
+    c = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread",
+                        os.path.join(ROOT, "tools", "asan_post", "driver.cpp"), os.path.join(ROOT, "nanomotif_amd", "csrc", "nmpost.cpp"),
+                        os.path.join(ROOT, "nanomotif_amd", "csrc", "nmsearch.cpp"), "-o", exe], capture_output=True, text=True)
+    assert c.returncode == 0, c.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, NM_POST_THREADS="6"))
+    assert r.returncode == 0 and "identical exports" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout[-2000:] + r.stderr[-3000:]
