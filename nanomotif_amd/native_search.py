@@ -221,9 +221,15 @@ class PostResults:
             k = self.keys[task[i]]
             o, text = self._off, self._text
             comp = complement[i]
-            r = MotifRow(k[0], text[o[2 * i]:o[2 * i + 1]], k[1], modpos[i], BetaBernoulliModel.from_counts(counts[i][0], counts[i][1]), score[i],
-                         None if comp < 0 else self._row(comp), stage[i] == 4)
-            r.__dict__["_cache"] = (text[o[2 * i + 1]:o[2 * i + 2]], modpos_iu[i], None)      # (the reverse complement on first use)
+            # (the fields set directly: a dataclass __init__ and a classmethod per row are half of what a row costs, and a 1 Gbp run
+            #  makes 2 600 of them; the counts are Python ints already — .tolist() —, like update() gets them)
+            model = BetaBernoulliModel.__new__(BetaBernoulliModel)
+            model._alpha_prior = model._beta_prior = 5
+            model._alpha, model._beta = 5 + counts[i][0], 5 + counts[i][1]
+            r = MotifRow.__new__(MotifRow)
+            r.__dict__ = {"reference": k[0], "motif": text[o[2 * i]:o[2 * i + 1]], "mod_type": k[1], "mod_position": modpos[i], "model": model,
+                          "score": score[i], "complement": None if comp < 0 else self._row(comp), "has_complement_columns": stage[i] == 4,
+                          "_cache": (text[o[2 * i + 1]:o[2 * i + 2]], modpos_iu[i], None)}       # (the reverse complement on first use)
             self._made[i] = r
         return r
 
