@@ -178,35 +178,71 @@ def allreduce_counts(counts: np.ndarray, group=None) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ per-task pipeline
-def task_coroutine(bin_name, mod_type, bin_pssm, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+def task_coroutine(bin_name, mod_type, bin_pssm, cfg: ProcessorConfig, stage_writer=None, temp_dir=None, files=None):
     """process_subpileup (find_motifs_bin.py:468-596) as one scoring coroutine: search, then post-processing."""
     res = yield from find_best_candidates_co(
         bin_pssm, mod_type, cfg.padding, min_kl=cfg.minimum_kl_divergence, max_dead_ends=25,
         max_rounds_since_new_best=30, score_threshold=cfg.score_threshold,
         log=lambda msg: log.info(f"[{bin_name} {mod_type}] {msg}"))
-    return (yield from post_coroutine(bin_name, mod_type, res, cfg, stage_writer, temp_dir))
+    return (yield from post_coroutine(bin_name, mod_type, res, cfg, stage_writer, temp_dir, files))
 
 
-def write_search_artifacts(bin_name, mod_type, res, temp_dir=None):
+def _write_text(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+
+
+class DeferredFiles:
+    """The small files a run with ``--out`` leaves per task (five precleanup tables, the background PSSM, the search graph: 7 000 files
+    for a thousand tasks): their text is made where the reference writes them, the files themselves are created at the end by a few
+    threads — creating a file is a handful of system calls that let the interpreter go, and was a tenth of a second of a 2 s run."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, path, text):
+        self.items.append((path, text))
+
+    def flush(self, threads=8):
+        if not self.items:
+            return
+        items, self.items = self.items, []
+
+        def write(item):
+            _write_text(*item)
+        if len(items) < 64:
+            for it in items:
+                write(it)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(write, items, chunksize=64))
+
+
+def write_search_artifacts(bin_name, mod_type, res, temp_dir=None, files=None):
     """What process_subpileup leaves next to the tables (find_motifs_bin.py:521-535): the "no motifs" log line, the
-    background PSSM and the search graph under ``temp_dir``.  Returns False when the search found nothing."""
+    background PSSM and the search graph under ``temp_dir`` (``files``: a DeferredFiles that writes them later).  Returns False when
+    the search found nothing."""
     if res is None:
         log.info(f"[{bin_name} {mod_type}] No motifs found")
         return False
     graph, best, bin_pssm = res
     if temp_dir:
         os.makedirs(temp_dir, exist_ok=True)
-        # (np.savetxt(path, bin_pssm, fmt="%.4f") byte for byte, a third of its cost: a thousand tasks write one each)
-        with open(os.path.join(temp_dir, "background_pssm.txt"), "w") as f:
-            f.write("".join(" ".join("%.4f" % x for x in row) + "\n" for row in np.asarray(bin_pssm, dtype=np.float64).tolist()))
-        graph.export_graph_gml(os.path.join(temp_dir, f"motif_graph_{mod_type}.gml"))
+        # (np.savetxt(path, bin_pssm, fmt="%.4f") byte for byte — one format call per row —, a fifth of its cost: a thousand tasks write one each)
+        rows = np.asarray(bin_pssm, dtype=np.float64).tolist()
+        row_fmt = " ".join(["%.4f"] * len(rows[0])) + "\n" if rows else ""
+        pssm_text = "".join(row_fmt % tuple(row) for row in rows)
+        sink = files.add if files is not None else _write_text
+        sink(os.path.join(temp_dir, "background_pssm.txt"), pssm_text)
+        sink(os.path.join(temp_dir, f"motif_graph_{mod_type}.gml"), graph.gml_text())
     return True
 
 
-def post_coroutine(bin_name, mod_type, res, cfg: ProcessorConfig, stage_writer=None, temp_dir=None):
+def post_coroutine(bin_name, mod_type, res, cfg: ProcessorConfig, stage_writer=None, temp_dir=None, files=None):
     """The part of process_subpileup after the search (find_motifs_bin.py:537-596): ``res`` = what
     find_best_candidates returned — (graph, best candidates, background PSSM) or None."""
-    if not write_search_artifacts(bin_name, mod_type, res, temp_dir):
+    if not write_search_artifacts(bin_name, mod_type, res, temp_dir, files):
         return None
     graph, best, bin_pssm = res
     rows = yield from postprocess.postprocess_co(graph, best, bin_name, mod_type, cfg.padding, on_stage=stage_writer)
@@ -352,6 +388,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
         timings[name] = timings.get(name, 0.0) + now - t_mark
         t_mark = now
     planned = []
+    files = DeferredFiles()                  # (the per-task files of a run with --out: written at the end, see the class)
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)
@@ -409,13 +446,13 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
             if out_dir and rank == 0:
                 pre = os.path.join(out_dir, "precleanup-motifs", f"{bin_name}-{mod_type}")
                 os.makedirs(pre, exist_ok=True)
-                stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
+                stage_writer = (lambda pre: lambda name, rows: files.add(os.path.join(pre, name + ".tsv"), postprocess.format_motifs(rows)))(pre)
                 temp_dir = os.path.join(out_dir, "temp", bin_name)
             if extractor is not None:
                 planned.append(((bin_name, mod_type), stage_writer, temp_dir))
                 continue
             store.add_task((bin_name, mod_type), windows[0])
-            tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir)
+            tasks[(bin_name, mod_type)] = task_coroutine(bin_name, mod_type, windows[1], cfg, stage_writer, temp_dir, files)
     lap("plan_s")
     if extractor is not None:
         if plan_natively:
@@ -428,7 +465,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                 if out_dir and rank == 0:
                     pre = os.path.join(out_dir, "precleanup-motifs", f"{key[0]}-{key[1]}")
                     os.makedirs(pre, exist_ok=True)
-                    stage_writer = (lambda pre: lambda name, rows: postprocess.write_motifs(rows, os.path.join(pre, name + ".tsv")))(pre)
+                    stage_writer = (lambda pre: lambda name, rows: files.add(os.path.join(pre, name + ".tsv"), postprocess.format_motifs(rows)))(pre)
                     temp_dir = os.path.join(out_dir, "temp", key[0])
                 planned.append((key, stage_writer, temp_dir))
         else:
@@ -451,7 +488,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
             lap("native_search_s")
             if os.environ.get("NANOMOTIF_PY_POST") == "1":
                 for t, (key, stage_writer, temp_dir) in enumerate(planned):
-                    tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir)
+                    tasks[key] = post_coroutine(key[0], key[1], found.result(t, full_graph=bool(temp_dir)), cfg, stage_writer, temp_dir, files)
             else:
                 # post-processing of all tasks inside libnmscan as well (nm_post_run: noise -> clique merge in two scoring
                 # batches on the merge stage's 0.3 / 0.7 classification -> sub-motifs -> complements); postprocess.py is its twin
@@ -461,7 +498,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                 scorer.candidates += post.candidates
                 for t, (key, stage_writer, temp_dir) in enumerate(planned):
                     if temp_dir or found.none[t]:
-                        write_search_artifacts(key[0], key[1], found.result(t, full_graph=True), temp_dir)
+                        write_search_artifacts(key[0], key[1], found.result(t, full_graph=True), temp_dir, files)
                     if stage_writer:
                         for s in range(post.n_stages(t)):
                             stage_writer(post.STAGES[s], post.rows(t, s))
@@ -472,9 +509,11 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
             threading.Thread(target=found.close, name="nm-search-free", daemon=False).start()
         else:
             for key, stage_writer, temp_dir in planned:
-                tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir)
+                tasks[key] = task_coroutine(key[0], key[1], pssms[key], cfg, stage_writer, temp_dir, files)
     results = run_lockstep(tasks, scorer, store.execute)
     lap("coroutines_s")
+    files.flush()
+    lap("files_s")
     scorer.timings = timings
     rows = []
     for key in list(tasks) + list(native_rows):

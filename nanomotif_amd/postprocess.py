@@ -255,20 +255,26 @@ def _fmt_float(x):
 
 def write_motifs(rows, path):
     """motif.py:891-897 — the per-stage precleanup TSVs (all non-object columns, sorted)."""
+    with open(path, "w") as f:
+        f.write(format_motifs(rows))
+
+
+def format_motifs(rows) -> str:
+    """The text ``write_motifs`` writes."""
     rows = sorted(rows, key=lambda r: (r.reference, r.mod_type, r.motif))
     cols = ["reference", "motif", "mod_type", "mod_position", "score", "n_mod", "n_nomod", "motif_iupac", "mod_position_iupac"]
     comp = any(r.has_complement_columns for r in rows)
     if comp:
         cols += ["motif_complement", "mod_position_complement", "score_complement", "n_mod_complement",
                  "n_nomod_complement", "motif_iupac_complement", "mod_position_iupac_complement"]
-    with open(path, "w") as f:
-        f.write("\t".join(cols) + "\n")
-        for r in rows:
-            vals = [r.reference, r.motif, r.mod_type, str(r.mod_position), _fmt_float(r.score), str(r.n_mod), str(r.n_nomod),
-                    r.motif_iupac, str(r.mod_position_iupac)]
-            if comp:
-                c = r.complement
-                vals += ["" if c is None else x for x in
-                         ([None] * 7 if c is None else [c.motif, str(c.mod_position), _fmt_float(c.score), str(c.n_mod),
-                                                        str(c.n_nomod), c.motif_iupac, str(c.mod_position_iupac)])]
-            f.write("\t".join(vals) + "\n")
+    out = ["\t".join(cols) + "\n"]
+    for r in rows:
+        vals = [r.reference, r.motif, r.mod_type, str(r.mod_position), _fmt_float(r.score), str(r.n_mod), str(r.n_nomod),
+                r.motif_iupac, str(r.mod_position_iupac)]
+        if comp:
+            c = r.complement
+            vals += ["" if c is None else x for x in
+                     ([None] * 7 if c is None else [c.motif, str(c.mod_position), _fmt_float(c.score), str(c.n_mod),
+                                                    str(c.n_nomod), c.motif_iupac, str(c.mod_position_iupac)])]
+        out.append("\t".join(vals) + "\n")
+    return "".join(out)

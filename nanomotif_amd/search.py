@@ -231,16 +231,20 @@ class MotifTree:
 
     def export_graph_gml(self, path):
         """Minimal GML writer (find_motifs_bin.py:836-837 / motif.py:630-652): counts, score, priority, depth."""
-        ids = {n: i for i, n in enumerate(self.nodes)}
         with open(path, "w") as f:
-            f.write("graph [\n  directed 1\n")
-            for n, d in self.nodes.items():
-                f.write(f'  node [\n    id {ids[n]}\n    label "{n.string.strip(".")}"\n    score {float(d.get("score", 0.0))}\n'
-                        f'    priority {float(d.get("priority", 0))}\n    depth {int(d.get("depth", 0))}\n'
-                        f'    visited {int(bool(d.get("visited", False)))}\n  ]\n')
-            for u, v in self.edges():
-                f.write(f"  edge [\n    source {ids[u]}\n    target {ids[v]}\n  ]\n")
-            f.write("]\n")
+            f.write(self.gml_text())
+
+    def gml_text(self) -> str:
+        ids = {n: i for i, n in enumerate(self.nodes)}
+        out = ["graph [\n  directed 1\n"]
+        for n, d in self.nodes.items():
+            out.append(f'  node [\n    id {ids[n]}\n    label "{n.string.strip(".")}"\n    score {float(d.get("score", 0.0))}\n'
+                       f'    priority {float(d.get("priority", 0))}\n    depth {int(d.get("depth", 0))}\n'
+                       f'    visited {int(bool(d.get("visited", False)))}\n  ]\n')
+        for u, v in self.edges():
+            out.append(f"  edge [\n    source {ids[u]}\n    target {ids[v]}\n  ]\n")
+        out.append("]\n")
+        return "".join(out)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -51,6 +51,16 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     assert {"GATC", "ACCCA", "CCWGG"} <= motifs
     assert os.path.exists(tmp + "/out/args.motif_discovery.json") and os.path.exists(tmp + "/out/logs/motif_discovery.main.log")
     assert os.path.isdir(tmp + "/out/precleanup-motifs")
+    # the per-task files (find_motifs_bin.py:521-596; written at the end of the run by a few threads): five precleanup tables, the
+    # background PSSM (np.savetxt's text: 4 rows of 41 "%.4f") and the search graph of every task that found something
+    b0 = sorted(set(mg.bin_names))[0]
+    stages = sorted(os.listdir(f"{tmp}/out/precleanup-motifs/{b0}-a"))
+    assert stages == sorted(n + ".tsv" for n in ("motifs", "motifs-noise", "motifs-noise-merge", "motifs-noise-merge-sub", "motifs-noise-merge-sub-complement"))
+    assert open(f"{tmp}/out/precleanup-motifs/{b0}-a/motifs.tsv").readline().startswith("reference\tmotif\tmod_type")
+    pssm = open(f"{tmp}/out/temp/{b0}/background_pssm.txt").read().splitlines()
+    assert len(pssm) == 4 and all(len(row.split(" ")) == 41 and all(len(x.split(".")[1]) == 4 for x in row.split(" ")) for row in pssm)
+    assert abs(sum(float(row.split(" ")[0]) for row in pssm) - 1.0) < 1e-3
+    assert open(f"{tmp}/out/temp/{b0}/motif_graph_a.gml").read().startswith("graph [\n  directed 1\n")
 
     # bgzip'd pileup (needs its .tbi to be present like the reference) and -f bin FASTA files
     with open(tmp + "/pileup.bed", "rb") as f, gzip.open(tmp + "/pileup.bed.gz", "wb") as g:
