@@ -498,7 +498,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
                 scorer.candidates += post.candidates
                 for t, (key, stage_writer, temp_dir) in enumerate(planned):
                     if temp_dir or found.none[t]:
-                        write_search_artifacts(key[0], key[1], found.result(t, full_graph=True), temp_dir, files)
+                        write_search_artifacts(key[0], key[1], found.artifacts(t), temp_dir, files)
                     if stage_writer:
                         for s in range(post.n_stages(t)):
                             stage_writer(post.STAGES[s], post.rows(t, s))

@@ -104,6 +104,31 @@ class SearchResults:
                      priority=(0 if self.priority[i] == 0 and self.depth[i] == 0 else float(self.priority[i])), depth=int(self.depth[i]))
         return m, attrs
 
+    def artifacts(self, t):
+        """What ``find_motifs_bin.write_search_artifacts`` needs of task ``t`` — (something with ``gml_text()``, None, background PSSM),
+        or None when the search found nothing — without building the graph's Python objects: the text is
+        ``result(t, full_graph=True)[0].gml_text()`` byte for byte (nodes in node order; a node's edges in the order they were made)."""
+        if self.none[t]:
+            return None
+        if getattr(self, "_gml_cols", None) is None:
+            self._gml_cols = (self.score.tolist(), self.priority.tolist(), self.depth.tolist(), self.visited.tolist())
+        score, priority, depth, visited = self._gml_cols
+        a, b = int(self.node_off[t]), int(self.node_off[t + 1])
+        W, text = self.W, self._text
+        out = ["graph [\n  directed 1\n"]
+        for k in range(b - a):
+            i = a + k
+            label = text[i * W:(i + 1) * W].strip(".")
+            out.append(f'  node [\n    id {k}\n    label "{label}"\n    score {score[i]}\n    priority {priority[i]}\n    depth {depth[i]}\n'
+                       f'    visited {1 if visited[i] else 0}\n  ]\n')
+        e = self.edges[int(self.edge_off[t]):int(self.edge_off[t + 1])]
+        if len(e):
+            e = e[np.argsort(e[:, 0], kind="stable")]
+            for u, v in e.tolist():
+                out.append(f"  edge [\n    source {u}\n    target {v}\n  ]\n")
+        out.append("]\n")
+        return _GmlText("".join(out)), None, self.pssms[t]
+
     def result(self, t, full_graph=False):
         """(graph, best, bin_pssm) of task ``t`` or None, as ``find_best_candidates_co`` returns it.  Without
         ``full_graph`` the graph holds the best candidates only (all that post-processing reads)."""
@@ -122,6 +147,14 @@ class SearchResults:
             for u, v in self.edges[int(self.edge_off[t]):int(self.edge_off[t + 1])].tolist():
                 g.add_edge(made[u], made[v])
         return g, [made[k] for k in best_idx], self.pssms[t]
+
+
+class _GmlText:
+    def __init__(self, text):
+        self._text = text
+
+    def gml_text(self):
+        return self._text
 
 
 def _reduce_callback(reduce, err):

@@ -125,6 +125,9 @@ def test_native_lockstep_equals_python_coroutines_bit_for_bit(memo, monkeypatch)
             assert a["score"] == b["score"] and a["priority"] == b["priority"], (n, a["score"], b["score"])
             assert a["depth"] == b["depth"] and a["visited"] == b["visited"]
         assert sorted(graph.edges()) == sorted(wg.edges())
+        # the search graph's GML text made straight from the result arrays (what a run with --out writes) = the graph object's
+        assert res.artifacts(t)[0].gml_text() == graph.gml_text() and graph.gml_text().count("node [") == len(graph.nodes)
+        assert res.artifacts(t)[2] is res.pssms[t]
 
 
 def test_native_scores_are_scipy_exact():
