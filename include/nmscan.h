@@ -63,6 +63,14 @@ typedef int (*nm_alloc_fn)(void *user, void **ptr, size_t bytes);
 typedef int (*nm_free_fn)(void *user, void *ptr);
 int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user);
 
+/* The library's own allocator for that slot, for a process that brings no pool (the command line): blocks of 32 MiB and more stay with
+ * the process when they are freed (at most max_idle_bytes of them) and serve the next request they fit — memory another process used
+ * before is scrubbed by the driver when it is handed out again, and hipFree synchronises the device.  enable 1: install (as
+ * nm_set_device_allocator: while no nm_ctx is alive) or change the limit; 0: uninstall and release the idle blocks (NM_ESTATE while
+ * blocks are in use); -1: statistics only.  stats (may be NULL): requests served from the cache, requests that went to hipMalloc,
+ * idle bytes, blocks in use. */
+int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]);
+
 /* Create / destroy an engine bound to HIP device `device`. */
 int nm_ctx_create(int device, nm_ctx **out);
 int nm_ctx_destroy(nm_ctx *ctx);

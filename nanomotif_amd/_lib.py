@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NM_LIB", os.path.join(_HERE, "libnmscan.so"))   # NM_
 
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_set_device_allocator", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_set_score_lanes", "nm_sync", "nm_upload_contigs",
-    "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_score_batch_wide", "nm_hit_positions", "nm_stats",
+    "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_score_batch_wide", "nm_block_cache", "nm_hit_positions", "nm_stats",
     "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
@@ -102,6 +102,7 @@ def load():
     lib.nm_last_error.restype = C.c_char_p
     lib.nm_ctx_create.argtypes = [C.c_int, C.POINTER(p)]
     lib.nm_set_device_allocator.argtypes = [ALLOC_FN, FREE_FN, p]
+    lib.nm_block_cache.argtypes = [C.c_int, C.c_uint64, u64p]
     lib.nm_ctx_destroy.argtypes = [p]
     lib.nm_set_stream.argtypes = [p, p]
     lib.nm_set_score_lanes.argtypes = [p, C.c_int]
@@ -220,6 +221,19 @@ def load():
 
 
 _torch_pool = None
+
+
+def use_block_cache(max_idle_bytes: int = 16 << 30):
+    """The library's own block cache behind its device allocations (nm_block_cache) — for a process without a pool of its own (the
+    command line).  Call before the first engine is created; ``max_idle_bytes`` 0 uninstalls it."""
+    lib = load()
+    check(lib.nm_block_cache(1 if max_idle_bytes > 0 else 0, int(max_idle_bytes), None))
+
+
+def block_cache_stats() -> dict:
+    stats = (C.c_uint64 * 4)()
+    check(load().nm_block_cache(-1, 0, stats))
+    return dict(served_from_cache=int(stats[0]), went_to_hipmalloc=int(stats[1]), idle_bytes=int(stats[2]), blocks_in_use=int(stats[3]))
 
 
 def use_torch_allocator(enable: bool = True):

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 SRC_HIP = [os.path.join(_CSRC, f) for f in ("nmscan.hip", "nmingest.hip", "nmwindows.hip", "nmmeth.hip", "nmbedgpu.hip", "nmfasta.hip")]
-SRC_HOST = [os.path.join(_CSRC, f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp", "nmsearch.cpp", "nmpost.cpp")]
+SRC_HOST = [os.path.join(_CSRC, f) for f in ("nmbed.cpp", "nmhost.cpp", "nmcomm.cpp", "nmsearch.cpp", "nmpost.cpp", "nmpool.cpp")]
 OUT = os.path.join(_HERE, "libnmscan.so")
 # synthetic-data tooling of bench.py and the tests (a bedMethyl text writer, a bgzip + tabix writer): its own small library,
 # not part of the product's C ABI

@@ -1,0 +1,147 @@
+// nmpool — a block cache behind nm_set_device_allocator for processes that bring no pool of their own (the command line).
+//
+// Why: memory another process used before is SCRUBBED by the driver when it is handed out again, at 7-30 GB/s — the first part of
+// the pre-filters waited 190 ms for its 1.5 GB of state planes (NM_INGEST_TIMING at 1 Gbp, profiles/r5/cli_1gbp.json) right after the
+// parser had given back 8 GB it had already paid that price for.  hipFree also synchronises the whole device.  With the cache a
+// large block that is freed stays with the process and serves the next request it fits; small blocks go to hipMalloc / hipFree as
+// before.  The library waits for its own streams before it frees, so a cached block has no work in flight.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/nmscan.h"
+
+int nm_set_error(int code, const char *fmt, ...);
+
+namespace {
+
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> live;             // blocks handed out by this cache (large ones only): their true size
+    std::vector<std::pair<size_t, void *>> idle;         // cached blocks, unordered (there are a handful)
+    size_t idle_bytes = 0, max_idle = 0;
+    uint64_t hits = 0, misses = 0, released = 0;
+    static constexpr size_t MIN_BLOCK = 32u << 20;       // smaller blocks are not worth keeping
+    static constexpr size_t ROUND = 2u << 20;
+
+    int alloc(void **out, size_t bytes) {
+        *out = nullptr;
+        if (bytes < MIN_BLOCK) return hipMalloc(out, bytes) == hipSuccess ? 0 : -4;
+        const size_t want = (bytes + ROUND - 1) / ROUND * ROUND;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            // best fit: the smallest idle block that holds the request and is not more than eight times its size
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); ++i)
+                if (idle[i].first >= want && idle[i].first <= 8 * want && (best < 0 || idle[i].first < idle[best].first)) best = i;
+            if (best >= 0) {
+                const auto blk = idle[best];
+                idle.erase(idle.begin() + best);
+                idle_bytes -= blk.first;
+                live[blk.second] = blk.first;
+                hits += 1;
+                *out = blk.second;
+                return 0;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {                            // out of memory with blocks lying idle: give them back and try once more
+            (void)hipGetLastError();
+            trim(0);
+            e = hipMalloc(&p, want);
+        }
+        if (e != hipSuccess) return -4;
+        std::lock_guard<std::mutex> lk(mu);
+        live[p] = want;
+        misses += 1;
+        *out = p;
+        return 0;
+    }
+
+    int release(void *p) {
+        if (!p) return 0;
+        size_t size = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = live.find(p);
+            if (it != live.end()) {
+                size = it->second;
+                live.erase(it);
+                if (idle_bytes + size <= max_idle) {
+                    idle.emplace_back(size, p);
+                    idle_bytes += size;
+                    return 0;
+                }
+            }
+        }
+        if (size) {
+            std::lock_guard<std::mutex> lk(mu);
+            released += 1;
+        }
+        return hipFree(p) == hipSuccess ? 0 : -1;        // a small block, or the cache is full
+    }
+
+    void trim(size_t keep_bytes) {                        // frees idle blocks, largest first, until at most keep_bytes stay
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            std::sort(idle.begin(), idle.end());
+            while (!idle.empty() && idle_bytes > keep_bytes) {
+                drop.push_back(idle.back().second);
+                idle_bytes -= idle.back().first;
+                idle.pop_back();
+            }
+        }
+        for (void *p : drop) (void)hipFree(p);
+    }
+};
+
+BlockCache g_cache;
+bool g_installed = false;
+
+int cache_alloc(void *, void **ptr, size_t bytes) { return g_cache.alloc(ptr, bytes); }
+int cache_free(void *, void *ptr) { return g_cache.release(ptr); }
+
+}  // namespace
+
+extern "C" {
+
+int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]) {
+    if (stats) {
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        stats[0] = g_cache.hits;
+        stats[1] = g_cache.misses;
+        stats[2] = g_cache.idle_bytes;
+        stats[3] = g_cache.live.size();
+    }
+    if (enable < 0) return NM_OK;                        // statistics only
+    if (enable) {
+        if (!g_installed) {
+            const int rc = nm_set_device_allocator(cache_alloc, cache_free, nullptr);
+            if (rc) return rc;
+            g_installed = true;
+        }
+        std::lock_guard<std::mutex> lk(g_cache.mu);
+        g_cache.max_idle = (size_t)max_idle_bytes;
+        return NM_OK;
+    }
+    if (g_installed) {
+        {
+            std::lock_guard<std::mutex> lk(g_cache.mu);
+            if (!g_cache.live.empty())
+                return nm_set_error(NM_ESTATE, "nm_block_cache(0): %zu blocks of the cache are still in use", g_cache.live.size());
+        }
+        const int rc = nm_set_device_allocator(nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        g_installed = false;
+    }
+    g_cache.trim(0);
+    return NM_OK;
+}
+
+}  // extern "C"

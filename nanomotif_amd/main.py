@@ -94,6 +94,13 @@ def find_motifs_bin(args):
 
     def start_engine():
         try:
+            # large device blocks stay with the process when the library frees them (nm_block_cache: memory another process used is
+            # scrubbed by the driver on its way back in — the pre-filters' state planes waited 0.19 s for that at 1 Gbp — and hipFree
+            # synchronises the device); NANOMOTIF_BLOCK_CACHE_GB=0 turns it off
+            cache_gb = float(os.environ.get("NANOMOTIF_BLOCK_CACHE_GB", "16"))
+            if cache_gb > 0:
+                from . import _lib as _l
+                _l.use_block_cache(int(cache_gb * (1 << 30)))
             started["eng"] = ScanEngine(device)
         except BaseException as e:               # re-raised on the main thread below
             started["error"] = e
