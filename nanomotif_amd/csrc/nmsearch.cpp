@@ -215,6 +215,20 @@ struct HeapCmp {                                    // min-heap on the Python tu
     }
 };
 
+// (the container of the heap, for Task::predict_next: which entry the loop would take next without taking it)
+struct Heap : std::priority_queue<HeapEntry, std::vector<HeapEntry>, HeapCmp> {
+    const std::vector<HeapEntry> &entries() const { return c; }
+};
+
+// The reply to a PSSM request as a task keeps it when it was asked for AHEAD of time (run_tasks: the tail of the search).
+struct WinReply {
+    int64_t n_active = 0;
+    std::vector<int64_t> counts;                    // [4][W]
+    int spec_col = -1;
+    uint32_t spec_bases = 0;
+    int64_t spec_counts[4][2] = {};
+};
+
 // One (bin, mod type) search as a resumable state machine.  `resume` consumes the reply to the pending request and
 // runs to the next one.
 struct Task {
@@ -246,11 +260,15 @@ struct Task {
     int nb_col = -1;                                // children_of: the column and the rows of `neighbors`
     int nb_row[4];
     uint32_t spec_hits = 0, spec_misses = 0;        // children answered by the speculation / asked for after all
+    // PSSM replies that arrived before they were asked for (run_tasks sends the request of the node this search would expand NEXT while
+    // the current one is on the device): valid while the task's windows are what they were — until its next REMOVE
+    std::unordered_map<std::string, WinReply> win_ahead;
+    uint32_t ahead_hits = 0, ahead_sent = 0;
     // --- state
     int state = 0;
     uint32_t dead_ends = 0;
     // MotifSearcher.run
-    std::priority_queue<HeapEntry, std::vector<HeapEntry>, HeapCmp> pq;
+    Heap pq;
     uint32_t epoch = 0;                             // `visited` of MotifSearcher.run = nodes whose seen_epoch is this
     Model root_model;
     double best_score = 0;
@@ -408,7 +426,46 @@ struct Task {
         rep_models.swap(full);
         ask_all.clear();
     }
-    void request_win(ReqKind k, const std::string &m) { req = k; req_motifs.assign(1, m); }
+    void request_win(ReqKind k, const std::string &m) {
+        req = k;
+        req_motifs.assign(1, m);
+        if (k == REQ_REMOVE) win_ahead.clear();        // the windows change: what was counted ahead is void
+    }
+    // the reply to ("pssm", m) if it is already here: becomes the current reply, exactly as if it had just arrived
+    bool take_ahead(const std::string &m) {
+        if (win_ahead.empty()) return false;
+        auto it = win_ahead.find(m);
+        if (it == win_ahead.end()) return false;
+        const WinReply &r = it->second;
+        const uint32_t W = P->width;
+        rep_a = r.n_active;
+        rep_b = 0;
+        for (int q = 0; q < 4; ++q)
+            for (uint32_t j = 0; j < W; ++j) rep_counts[q][j] = r.counts[(size_t)q * W + j];
+        spec_col = r.spec_col;
+        spec_bases = r.spec_bases;
+        memcpy(spec_counts, r.spec_counts, sizeof spec_counts);
+        win_ahead.erase(it);
+        ahead_hits += 1;
+        return true;
+    }
+    // The node MotifSearcher.run would expand after the one whose counts are on their way — if none of that one's children gets in
+    // front of it: the best entry of the heap that the loop would not skip (find_motifs_bin.py:1040-1052).  False: nothing to predict.
+    bool predict_next(std::string &out) const {
+        if (state != 2 || req != REQ_PSSM || rounds >= P->max_rounds) return false;
+        const HeapEntry *bestp = nullptr;
+        HeapCmp worse;
+        for (const HeapEntry &e : pq.entries()) {
+            const Node &n = g.nodes[e.id];
+            if (n.seen_epoch == epoch) continue;
+            if (n.model.n_mod() + n.model.n_nomod() < 10) continue;
+            if (stripped_length(e.motif) > P->max_motif_length) continue;
+            if (!bestp || worse(*bestp, e)) bestp = &e;
+        }
+        if (!bestp || win_ahead.count(bestp->motif)) return false;
+        out = bestp->motif;
+        return true;
+    }
 
     // get_parent_scores_co request for `temp` (find_motifs_bin.py:1382-1433)
     bool request_parents() {
@@ -490,7 +547,7 @@ struct Task {
             g.nodes[id].model = root_model;
             g.nodes[id].score = best_score;
         }
-        pq = decltype(pq)();
+        pq = Heap();
         pq.push(HeapEntry{0.0, 0, root, g.find(root)});
         while (!pq.empty()) {
             cur_id = pq.top().id;
@@ -508,9 +565,11 @@ struct Task {
             g.nodes[cur_id].seen_epoch = epoch;
             g.nodes[cur_id].visited = true;
             rounds += 1;
-            request_win(REQ_PSSM, cur);
-            state = 2;
-            return;
+            if (!take_ahead(cur)) {
+                request_win(REQ_PSSM, cur);
+                state = 2;
+                return;
+            }
         PSSM_DONE:
             if (rep_a == 0) continue;
             children_of(cur, rep_a);
@@ -876,7 +935,23 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
         std::vector<int64_t> counts, spec_counts;
         std::vector<int32_t> wout, spec_info;
         bool flying = false;
+        // requests sent AHEAD (below): the tasks, the motifs of the nodes they would expand next, the replies
+        std::vector<uint32_t> a_task;
+        std::vector<char> a_motifs;
+        std::vector<uint8_t> a_kind;
+        std::vector<int32_t> a_out, a_info;
+        std::vector<int64_t> a_counts;
+        int a_slot = -1;
     } fl[NM_SEARCH_MAX_FLIGHTS];
+    // THE TAIL: once every flight but one has ended, the last one runs alone — a hundred iterations of a handful of slow searches, one
+    // round trip each (a third of the search's time at 1 Gbp).  The ended flight's batch slot is free then: with every PSSM request the
+    // last flight also sends, through that slot, the request of the node each search would expand NEXT if none of the current node's
+    // children gets in front of it (Task::predict_next).  The reply waits in the task (win_ahead) until the search asks for exactly that
+    // motif — then it costs no round trip — or until the task's windows change.  Replies are pure functions of (windows, motif):
+    // asking early changes no result.  NM_SEARCH_NO_AHEAD=1: off.
+    std::atomic<int> ahead_slot{-1};
+    const bool ahead_on = n_flights >= 2 && B.window_begin && B.window_end && B.threaded_issue && getenv("NM_SEARCH_NO_AHEAD") == nullptr;
+    constexpr size_t AHEAD_MAX_REQUESTS = 256;
     for (uint32_t i = 0; i < tasks.size(); ++i) fl[(B.group_of ? B.group_of(B.user, i) : i) % (uint32_t)n_flights].members.push_back(i);
     // the requests of a group go out: its window batch first, its scoring batch behind it
     auto issue = [&](int f) -> int {
@@ -920,6 +995,29 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
             res->candidates += F.s_task.size();
             t_score_begin += now() - t1;
         }
+        F.a_slot = -1;
+        const int slot = ahead_slot.load(std::memory_order_acquire);
+        if (ahead_on && slot >= 0 && slot != f && !F.w_task.empty() && F.w_task.size() <= AHEAD_MAX_REQUESTS) {
+            t1 = now();
+            F.a_task.clear(); F.a_motifs.clear();
+            std::string next;
+            for (uint32_t i : F.w_task) {
+                Task &t = tasks[i];
+                if (!t.predict_next(next)) continue;
+                F.a_task.push_back(i);
+                F.a_motifs.insert(F.a_motifs.end(), next.begin(), next.end());
+                t.ahead_sent += 1;
+            }
+            if (!F.a_task.empty()) {
+                F.a_kind.assign(F.a_task.size(), 0);
+                F.a_out.assign(F.a_task.size() * (size_t)(2 + 4 * WS), 0);
+                const int rc = B.window_begin(B.user, slot, (uint32_t)F.a_task.size(), F.a_task.data(), F.a_kind.data(), F.a_motifs.data());
+                if (rc) return rc;
+                F.a_slot = slot;
+                res->window_requests += F.a_task.size();
+            }
+            t_window_begin += now() - t1;
+        }
         return NM_OK;
     };
     // the replies of a group: the windows come back first, their tasks advance while the scoring kernel may still be running
@@ -934,6 +1032,25 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
             if (B.window_end) {
                 const int rc = B.window_end(B.user, f, (uint32_t)F.w_task.size(), F.wout.data(), F.spec_info.data(), F.spec_counts.data());
                 if (rc) return rc;
+            }
+            if (F.a_slot >= 0) {                         // what was sent ahead has arrived too (its chain ran beside the regular one): into the tasks
+                F.a_info.assign(F.a_task.size() * 2, -1);
+                F.a_counts.assign(F.a_task.size() * 8, 0);
+                const int rc = B.window_end(B.user, F.a_slot, (uint32_t)F.a_task.size(), F.a_out.data(), F.a_info.data(), F.a_counts.data());
+                F.a_slot = -1;
+                if (rc) return rc;
+                for (size_t k = 0; k < F.a_task.size(); ++k) {
+                    Task &t = tasks[F.a_task[k]];
+                    const int32_t *o = F.a_out.data() + k * (size_t)(2 + 4 * WS);
+                    WinReply &r = t.win_ahead[std::string(F.a_motifs.data() + k * (size_t)W, W)];
+                    r.n_active = o[0];
+                    r.counts.resize(4 * (size_t)W);
+                    for (int q = 0; q < 4; ++q)
+                        for (uint32_t j = 0; j < W; ++j) r.counts[(size_t)q * W + j] = o[2 + q * WS + j];
+                    r.spec_col = F.a_info[2 * k];
+                    r.spec_bases = (uint32_t)F.a_info[2 * k + 1];
+                    for (int q = 0; q < 4; ++q) { r.spec_counts[q][0] = F.a_counts[8 * k + 2 * q]; r.spec_counts[q][1] = F.a_counts[8 * k + 2 * q + 1]; }
+                }
             }
             t_window += now() - t1;
             t1 = now();
@@ -991,17 +1108,25 @@ int run_tasks(nm_search_result *res, const Params &P, const Backend &B) {
             int rc = sender.wait(f);
             t_sender += now() - t1;
             if (rc) return rc;
-            if (!fl[f].flying) { active[f] = false; continue; }        // nothing left to ask for: the flight's searches have ended
+            if (!fl[f].flying) {                                       // nothing left to ask for: the flight's searches have ended
+                active[f] = false;
+                int n_active = 0;
+                for (int q = 0; q < n_flights; ++q) n_active += active[q];
+                if (n_active == 1) ahead_slot.store(f, std::memory_order_release);   // its batch slot serves the last flight's requests ahead
+                continue;
+            }
             rc = collect(f);
             if (rc) return rc;
             sender.submit(f);
             any = true;
         }
     }
-    for (const auto &t : tasks) { res->spec_hits += t.spec_hits; res->spec_misses += t.spec_misses; }
+    uint64_t ahead_hits = 0, ahead_sent = 0;
+    for (const auto &t : tasks) { res->spec_hits += t.spec_hits; res->spec_misses += t.spec_misses; ahead_hits += t.ahead_hits; ahead_sent += t.ahead_sent; }
     if (timing)
-        fprintf(stderr, "[nm_search] %llu lock-step iterations, speculative children: %llu answered, %llu asked for after all\n",
-                (unsigned long long)res->iterations, (unsigned long long)res->spec_hits, (unsigned long long)res->spec_misses);
+        fprintf(stderr, "[nm_search] %llu lock-step iterations, speculative children: %llu answered, %llu asked for after all; window counts asked for ahead: %llu, used %llu\n",
+                (unsigned long long)res->iterations, (unsigned long long)res->spec_hits, (unsigned long long)res->spec_misses,
+                (unsigned long long)ahead_sent, (unsigned long long)ahead_hits);
     if (timing)
         fprintf(stderr, "[nm_search] %zu tasks, %llu scoring rounds, %d flights%s: resume %.1f ms, waiting for window batches %.1f ms, for scoring batches %.1f ms, "
                         "replies %.1f ms, waiting for the sender %.1f ms | sending: request gathering %.1f ms, window batches %.1f ms, scoring batches %.1f ms\n",

@@ -187,7 +187,10 @@ static Export run(uint32_t n_tasks, const char *threads, int engine_flights = 0,
     std::vector<int64_t> left(n_tasks, 4000);
     if (engine_flights) {                // the engine back end of nm_search_run on the stand-in above (the ctx is never looked into)
         std::vector<uint32_t> tbin(n_tasks), tslot(n_tasks), twin(n_tasks);
-        for (uint32_t i = 0; i < n_tasks; ++i) { tbin[i] = i / 2; tslot[i] = i & 1; twin[i] = i; }
+        // (skew: all but a handful of tasks travel with flight 0 — bins even —, so flight 1 ends early and the last flight's requests
+        //  are sent AHEAD through its slot: the tail path of run_tasks)
+        const bool skew = getenv("NM_TSAN_SKEW") != nullptr;
+        for (uint32_t i = 0; i < n_tasks; ++i) { tbin[i] = skew ? (i + 8 < n_tasks ? 2 * i : 2 * i + 1) : i / 2; tslot[i] = i & 1; twin[i] = i; }
         g_left.assign(n_tasks, 4000);
         if (nm_search_run(reinterpret_cast<nm_ctx *>(&g_left), n_tasks, tbin.data(), tslot.data(), twin.data(), &p, bg.data(), total.data(), can.data(),
                           nullptr, nullptr, &res)) exit(2);
@@ -218,9 +221,18 @@ int main(int argc, char **argv) {
     printf("identical exports\n");
     // the flights of the engine back end and the thread that sends their batches: the same graphs however the tasks are grouped
     // (the batch counters differ: more flights, more and smaller batches)
-    const Export e1 = run(n, "8", 1), e2 = run(n, "3", 2, false), e3 = run(n, "8", 2, true), e4 = run(n, "3", 3, true), e5 = e4;
+    const Export e1 = run(n, "8", 1), e2 = run(n, "3", 2, false), e3 = run(n, "8", 2, true), e4 = run(n, "3", 3, true);
+    setenv("NM_TSAN_SKEW", "1", 1);
+    setenv("NM_SEARCH_TIMING", "1", 1);                 // (prints how many window counts were asked for ahead and used)
+    const Export e5 = run(n, "8", 2, true);
+    setenv("NM_SEARCH_NO_AHEAD", "1", 1);               // (the skew renames the bins, which the stand-in's counts hang on: its own pair of runs)
+    const Export e6 = run(n, "8", 2, true);
+    unsetenv("NM_SEARCH_NO_AHEAD");
+    unsetenv("NM_SEARCH_TIMING");
+    unsetenv("NM_TSAN_SKEW");
     auto same_graphs = [](const Export &x, const Export &y) { return x.off == y.off && x.motifs == y.motifs && x.counts == y.counts && x.score == y.score; };
-    if (!same_graphs(e1, e2) || !same_graphs(e1, e3) || !same_graphs(e1, e4) || !same_graphs(e1, e5)) { printf("MISMATCH between flight counts\n"); return 1; }
-    printf("identical graphs over 1 / 2 / 3 flights, with and without the sending thread\n");
+    if (!same_graphs(e1, e2) || !same_graphs(e1, e3) || !same_graphs(e1, e4)) { printf("MISMATCH between flight counts\n"); return 1; }
+    if (!same_graphs(e5, e6)) { printf("MISMATCH between requests sent ahead and not\n"); return 1; }
+    printf("identical graphs over 1 / 2 / 3 flights, with and without the sending thread, with requests sent ahead in the tail\n");
     return 0;
 }
