@@ -279,6 +279,11 @@ def test_wide_search_frames_equal_the_oracle(tmp_path):
         assert "CCWGG" in got and ("GATC" in got) == (frame != 400) and "stay on the host" in r.stdout + r.stderr     # (the oracle loses GATC at 400 too)
         m = re.search(r"(\d+) candidates reaching further than 95 positions", r.stdout + r.stderr)
         assert frame == 192 or (m and int(m.group(1)) > 0), frame          # (the planted far columns lie outside a frame of 192)
+    # the same frame on two ranks, contigs sharded (each rank scores its contigs — far-reaching candidates through the wide entry —, the
+    # count tables all-reduced; every rank holds all windows on the host): the text of one rank
+    for mode in ("contigs", "bins"):
+        _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", f"w300_{mode}", "--search_frame_size", "300", "--shard", mode], nproc=2)
+        assert open(f"{tmp}/w300_{mode}/bin-motifs.tsv").read() == open(f"{tmp}/w300/bin-motifs.tsv").read(), mode
     r = _run_cli(tmp, ["a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "--search_frame_size", "4096"], check=False)
     assert r.returncode != 0 and "search_frame_size must be at most 4095" in r.stdout + r.stderr
 
