@@ -4,7 +4,8 @@ sys.path.insert(0, ".")
 import torch
 from nanomotif_amd import synth, e2e_synth, find_motifs_bin as fmb, main as nm_main
 from nanomotif_amd.engine import ScanEngine
-mg = synth.make_metagenome(synth.SynthSpec(n_contigs=10_000, total_bp=1_000_000_000, n_bins=500, mod_types=("a", "m"), seed=1))
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # size in Gbp (10 000 contigs / 500 bins per Gbp)
+mg = synth.make_metagenome(synth.SynthSpec(n_contigs=10_000 * G, total_bp=1_000_000_000 * G, n_bins=500 * G, mod_types=("a", "m"), seed=1))
 prof = cProfile.Profile()
 def wrap(orig):
     def wrapped(*a, **k):
