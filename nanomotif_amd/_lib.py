@@ -39,6 +39,7 @@ POST_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint3
                             C.POINTER(C.c_int64))
 
 _lib = None
+warm_up_thread = None          # __main__.py: the thread that brings the HIP runtime up while the interpreter imports (joined by main.py)
 loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
 
 
@@ -62,8 +63,18 @@ def _cli_process() -> bool:
     return getattr(getattr(main, "__spec__", None), "name", "") in ("nanomotif_amd.__main__", "nanomotif_amd")
 
 
+_load_lock = __import__("threading").Lock()
+
+
 def load():
     """Load libnmscan.so (after torch, so both share one HIP runtime) and declare prototypes."""
+    if _lib is not None:
+        return _lib
+    with _load_lock:                        # (the command line's warm-up thread and the main thread may both come here first)
+        return _load_locked()
+
+
+def _load_locked():
     global _lib
     if _lib is not None:
         return _lib
