@@ -39,7 +39,6 @@ POST_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint3
                             C.POINTER(C.c_int64))
 
 _lib = None
-warm_up_thread = None          # __main__.py: the thread that brings the HIP runtime up while the interpreter imports (joined by main.py)
 loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
 
 

@@ -97,10 +97,6 @@ def find_motifs_bin(args):
             # large device blocks stay with the process when the library frees them (nm_block_cache: memory another process used is
             # scrubbed by the driver on its way back in — the pre-filters' state planes waited 0.19 s for that at 1 Gbp — and hipFree
             # synchronises the device); NANOMOTIF_BLOCK_CACHE_GB=0 turns it off
-            from . import _lib as _l0
-            if _l0.warm_up_thread is not None:           # (__main__.py: its throw-away context must be gone before the allocator goes in)
-                _l0.warm_up_thread.join()
-                _l0.warm_up_thread = None
             cache_gb = float(os.environ.get("NANOMOTIF_BLOCK_CACHE_GB", "16"))
             if cache_gb > 0:
                 from . import _lib as _l
