@@ -486,11 +486,16 @@ int nm_last_kernel_ms(nm_ctx *ctx, float *ms);
  * numbered 3, 4, ... in first-appearance order, names via nm_bed_mod_code),
  * strand (col 6), fraction_mod = col 11 / 100 (-1 for the null markers "NA" / "null"), Nvalid_cov (col 10, -1 for
  * null).  The column pointers stay valid until nm_bed_close.  threads = 0: one per core, at most 32.
+ * STRICT like the fixed 18-column schema the reference reads the file against (PILEUP_SCHEMA, dataload.py:15-34): a line that does
+ * not have exactly 18 tab-separated columns, a start that is not a non-negative integer, a strand other than "+" / "-" (the only
+ * values the scoring path compares with, find_motifs_bin.py:1308-1314), a coverage that is not an integer or a percentage that
+ * is not a number is NM_EINVAL naming the column — a damaged file is refused, never half-read.  The device parser below applies
+ * the same rules and the same messages.
  */
 typedef struct nm_bed nm_bed;
 int nm_bed_open(const char *path, uint32_t threads, nm_bed **out);
 /* The same, also keeping N_mod (col 12) and N_diff (col 17) as int32 columns (nm_bed_count_columns): the inputs of the
- * read-methylation table (nm_readstats_upload).  Lines with fewer than 17 columns are an error in this mode. */
+ * read-methylation table (nm_readstats_upload). */
 int nm_bed_open_counts(const char *path, uint32_t threads, nm_bed **out);
 int nm_bed_count_columns(nm_bed *bed, const int32_t **n_modified, const int32_t **n_diff);
 /* The tabix path of the reference (dataload.py:102-152, find_motifs_bin.py:233-246: the records of a bin's contigs are
@@ -503,6 +508,12 @@ int nm_bed_count_columns(nm_bed *bed, const int32_t **n_modified, const int32_t 
  * BGZF block", a CRC-32 that is off), NM_EHIP and NM_ENOMEM are NOT index problems and come back as themselves. */
 int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset,
                         uint32_t threads, nm_bed **out, uint64_t stats[4]);
+/* Host only, no pileup needed: the [begin, end) VIRTUAL offsets (file offset of a BGZF block << 16 | offset inside its text) a
+ * tabix index holds for each of the n_contigs names — the metadata pseudo-bin 37450 when the index carries it (htslib's do), else
+ * the hull of the sequence's chunks: what pysam's TabixFile.fetch(contig) starts from in the reference (dataload.py:102-152).
+ * present[i] = 0 for a name the index does not know (begin = end = 0).  NM_EINDEX when tbi_path is not a tabix index. */
+int nm_tabix_regions(const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset, uint64_t *begin,
+                     uint64_t *end, uint8_t *present);
 int nm_bed_shape(nm_bed *bed, uint64_t *n_rows, uint32_t *n_contigs);
 int nm_bed_contig_name(nm_bed *bed, uint32_t i, const char **name);
 int nm_bed_mod_code(nm_bed *bed, uint32_t id, const char **code);

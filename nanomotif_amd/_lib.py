@@ -20,6 +20,7 @@ SYMBOLS = [
     "nm_comm_sync", "nm_comm_info", "nm_comm_destroy",
     "nm_score_batch_per_contig", "nm_bin_contigs", "nm_readstats_upload", "nm_contig_methylation", "nm_bed_open_counts", "nm_bed_count_columns", "nm_bed_parse_device", "nm_bed_parse_device_indexed", "nm_bedcols_shape", "nm_bedcols_contig_name", "nm_bedcols_mod_code", "nm_bedcols_runs", "nm_bedcols_map_contigs", "nm_bedcols_device_columns", "nm_bedcols_close", "nm_device_read", "nm_score_batch_begin", "nm_score_batch_end", "nm_win_batch_w_begin", "nm_win_batch_w_end", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_speculation", "nm_search_result_export", "nm_search_result_free", "nm_post_run", "nm_post_run_custom", "nm_post_run_rows_custom", "nm_post_sizes", "nm_post_export", "nm_post_free", "nm_psi_posint",
     "nm_bedcols_phase_seconds", "nm_bed_plan_indexed", "nm_bed_parse_device_planned", "nm_bedplan_close", "nm_fasta_parse_device", "nm_fastadev_shape", "nm_fastadev_record", "nm_fastadev_table", "nm_fastadev_sequence_device", "nm_upload_contigs_fasta", "nm_fastadev_close",
+    "nm_tabix_regions",
 ]
 
 class SearchParams(C.Structure):
@@ -187,6 +188,7 @@ def _load_locked():
     lib.nm_window_letter_counts.argtypes = [u8p, C.c_uint64, i64p, C.c_uint64, C.c_uint32, i64p]
     lib.nm_bed_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(p)]
     lib.nm_bed_open_indexed.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, u32p, C.c_uint32, C.POINTER(p), u64p]
+    lib.nm_tabix_regions.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, u32p, u64p, u64p, u8p]
     lib.nm_bed_shape.argtypes = [p, u64p, u32p]
     lib.nm_bed_contig_name.argtypes = [p, C.c_uint32, C.POINTER(C.c_char_p)]
     lib.nm_bed_mod_code.argtypes = [p, C.c_uint32, C.POINTER(C.c_char_p)]

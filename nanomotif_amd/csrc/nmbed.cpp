@@ -79,21 +79,20 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
         if (le > p && le[-1] == '\r') --le;
         ++line_no;
         if (le > p) {
+            // exactly 18 tab-separated columns, like the fixed schema the reference reads the file against (dataload.py:15-34): a
+            // damaged file is refused, not half-read
             const char *f[18];
             const char *fe[18];
             int nf = 0;
             const char *q = p;
-            const int need = c->want_counts ? 17 : 11;
-            while (nf < need) {
+            for (;;) {
                 const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
-                f[nf] = q;
-                fe[nf] = t ? t : le;
+                if (nf < 18) { f[nf] = q; fe[nf] = t ? t : le; }
                 ++nf;
                 if (!t) break;
                 q = t + 1;
             }
-            if (nf < 11) { c->error = "pileup line with fewer than 11 tab-separated columns"; return; }
-            if (nf < need) { c->error = "pileup line with fewer than 17 tab-separated columns (N_mod / N_diff are columns 12 / 17)"; return; }
+            if (nf != 18) { c->error = "pileup line that does not have exactly 18 tab-separated columns (modkit bedMethyl)"; return; }
             // contig
             const size_t nl = (size_t)(fe[0] - f[0]);
             if (!have_last || nl != last_name.size() || memcmp(last_name.data(), f[0], nl) != 0) {
@@ -109,6 +108,9 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
             int64_t pos = 0, cov = -1;
             double pct = 0;
             if (!parse_int(f[1], fe[1], &pos)) { c->error = "pileup column 2 (start) is not an integer"; return; }
+            if (pos < 0) { c->error = "pileup column 2 (start) is negative"; return; }
+            // '+' or '-' and nothing else: the scoring path compares the column with exactly these (find_motifs_bin.py:1308-1314)
+            if (fe[5] - f[5] != 1 || (f[5][0] != '+' && f[5][0] != '-')) { c->error = "pileup column 6 (strand) is neither '+' nor '-'"; return; }
             if (!is_null(f[9], fe[9]) && !parse_int(f[9], fe[9], &cov)) { c->error = "pileup column 10 (Nvalid_cov) is not an integer"; return; }
             bool pct_null = is_null(f[10], fe[10]);
             if (!pct_null && !parse_double(f[10], fe[10], &pct)) { c->error = "pileup column 11 (percent modified) is not a number"; return; }
@@ -128,7 +130,7 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
             c->contig.push_back(last_id);
             c->position.push_back(pos);
             c->mod_type.push_back(mt);
-            c->strand.push_back(fe[5] > f[5] ? (uint8_t)f[5][0] : (uint8_t)'?');
+            c->strand.push_back((uint8_t)f[5][0]);
             c->nvalid.push_back(cov);
             c->fraction.push_back(pct_null ? -1.0 : pct / 100.0);     // dataload.py:85
             if (c->want_counts) {
@@ -411,8 +413,9 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     std::vector<nmbgzf::Piece> blocks;
     uint64_t text_size = 0, inflated = 0;
     {
-        const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated, &block_starts, threads);
-        if (!what.empty()) return nm_set_error(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
+        bool index_problem = false;
+        const std::string what = nmbgzf::region_pieces(z, zn, merged, &blocks, &text_size, &inflated, &block_starts, threads, -1, &index_problem);
+        if (!what.empty()) return nm_set_error(index_problem ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     Buffer text;
     text.owned.resize(text_size);
@@ -448,6 +451,47 @@ int nm_bed_open_indexed(const char *path, const char *tbi_path, uint32_t n_conti
             return nm_set_error(NM_EINDEX, "%s: the tabix index does not match the pileup (rows of contig '%s' where another contig was indexed): stale .tbi?",
                                 path, culprit.c_str());
         }
+    return NM_OK;
+}
+
+// The [begin, end) virtual offsets a tabix index holds for the named sequences (host only, no pileup needed): what the reference's
+// reader asks pysam for before it fetches a bin's contigs (dataload.py:102-152).  The one htslib-made index in the reference tree
+// (datasets/geobacillus-plasmids.pileup.bed.gz.tbi) is read through this call in tests/test_bed_reader.py.
+int nm_tabix_regions(const char *tbi_path, uint32_t n_contigs, const char *names, const uint32_t *name_offset, uint64_t *begin, uint64_t *end,
+                     uint8_t *present) {
+    if (!tbi_path || !begin || !end || !present || (n_contigs && (!names || !name_offset))) return nm_set_error(NM_EINVAL, "NULL argument");
+    Buffer idx;
+    int rc = load_file(tbi_path, 1, &idx, "tabix index");
+    if (rc) {
+        const std::string why = nm_last_error();
+        return nm_set_error(NM_EINDEX, "%s", why.c_str());
+    }
+    struct Unmap {
+        Buffer &b;
+        ~Unmap() { if (b.map) munmap(b.map, b.map_size); b.map = nullptr; }
+    } unmap_idx{idx};
+    std::unordered_map<std::string, uint32_t> want;
+    for (uint32_t i = 0; i < n_contigs; ++i) {
+        begin[i] = end[i] = 0;
+        present[i] = 0;
+        // a name given twice answers at its first position only
+        want.emplace(std::string(names + name_offset[i], name_offset[i + 1] - name_offset[i]), i);
+    }
+    std::vector<nmbgzf::Region> merged;
+    uint64_t found = 0;
+    // tabix_regions sizes its per-name tables by want.size(): number the distinct names densely and map back
+    std::vector<nmbgzf::Region> per_w;
+    std::vector<uint8_t> have_w;
+    std::unordered_map<std::string, uint32_t> dense;
+    std::vector<uint32_t> back;
+    for (const auto &kv : want) { dense.emplace(kv.first, (uint32_t)back.size()); back.push_back(kv.second); }
+    const std::string what = nmbgzf::tabix_regions(reinterpret_cast<const uint8_t *>(idx.data), idx.size, dense, &merged, &found, nullptr, &per_w, &have_w);
+    if (!what.empty()) return nm_set_error(NM_EINDEX, "%s: %s", tbi_path, what.c_str());
+    for (size_t k = 0; k < back.size(); ++k) {
+        begin[back[k]] = per_w[k].beg;
+        end[back[k]] = per_w[k].end;
+        present[back[k]] = have_w[k];
+    }
     return NM_OK;
 }
 

@@ -43,7 +43,7 @@ constexpr uint32_t BLOCK_BYTES = 16384;           // bytes per workgroup in the 
 constexpr uint64_t SLAB_BYTES = 32ull << 20;            // per slab: 3 pinned + 2 device buffers of this size (pinning memory costs ~0.2 ms per MB)
 constexpr uint32_t PATCH_CAP = 1u << 22;
 
-enum RowError : uint32_t { E_NONE = 0, E_COLUMNS = 1, E_START = 2, E_COV = 3, E_PCT = 4, E_POS_RANGE = 5 };
+enum RowError : uint32_t { E_NONE = 0, E_COLUMNS = 1, E_START = 2, E_COV = 3, E_PCT = 4, E_POS_RANGE = 5, E_STRAND = 6, E_START_NEG = 7 };
 
 // bit k of the result = byte k of the 64 bytes at `base` is the first byte of a non-empty line.  The 64 bytes come as four
 // 16-byte loads (the text buffers are 16-byte aligned and padded); the bytes before and after them decide the edges.
@@ -602,10 +602,11 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
     const uint64_t row = row0 + li;
     const uint8_t *p = b + line_start[li];
     const uint8_t *end = b + n;
-    // the line is walked once; the bounds of the six fields that matter are kept in registers (fields count from 0)
+    // the line is walked once, to its end: a bedMethyl row has exactly 18 tab-separated columns (dataload.py:15-34: the reference
+    // reads the file against a fixed 18-column schema), so every tab is counted; the bounds of the six fields that matter are kept
+    // in registers (fields count from 0)
     uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0, b3 = 0, e3 = 0, b5 = 0, e5 = 0, b9 = 0, e9 = 0, b10 = 0, e10 = 0;
     uint32_t nf = 0, at = 0, start = 0;
-    bool ended = false;                                                 // the line ended (newline / end of text) inside field nf - 1
     for (;;) {
         const bool stop = p + at >= end || p[at] == '\n';
         if (stop || p[at] == '\t') {
@@ -619,18 +620,14 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
                 default: break;
             }
             ++nf;
-            if (stop) { ended = true; break; }
-            if (nf >= 11) break;
+            if (stop) break;
             start = at + 1;
         }
         ++at;
     }
+    // ("\r\n" line ends: the '\r' can only sit in the eighteenth field, which is not read)
     uint32_t err = E_NONE;
-    if (nf < 11) err = E_COLUMNS;
-    // "\r\n" line ends: the host parser strips the '\r' before it splits the line; it can only sit in the last field
-    if (nf == 11 && ended && e10 > b10 && p[e10 - 1] == '\r') e10 -= 1;
-    if (nf < 11 && ended) {                                              // (a short line whose last field is "\r"-terminated is short either way)
-    }
+    if (nf != 18) err = E_COLUMNS;
     // contig name: FNV-1a over the bytes, the length folded in
     unsigned long long h = 1469598103934665603ull;
     if (!err) {
@@ -644,7 +641,8 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
     uint8_t st = '?';
     if (!err) {
         if (!dev_parse_int(p + b1, e1 - b1, &pos)) err = E_START;
-        else if (pos < 0 || pos > 0xFFFFFFFEll) err = E_POS_RANGE;
+        else if (pos < 0) err = E_START_NEG;
+        else if (pos > 0xFFFFFFFEll) err = E_POS_RANGE;
     }
     if (!err && !field_is_null(p + b9, e9 - b9) && !dev_parse_int(p + b9, e9 - b9, &cov)) err = E_COV;
     if (!err) {
@@ -684,7 +682,9 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
         else if (ml == 1 && m[0] == 'a') mt = 1;
         else if (ml == 5 && m[0] == '2' && m[1] == '1' && m[2] == '8' && m[3] == '3' && m[4] == '9') mt = 2;
         else flags |= 1u;
-        st = e5 > b5 ? p[b5] : (uint8_t)'?';
+        // '+' or '-' and nothing else: the scoring path compares the column with exactly these (find_motifs_bin.py:1308-1314)
+        if (e5 - b5 == 1 && (p[b5] == '+' || p[b5] == '-')) st = p[b5];
+        else err = E_STRAND;
     }
     if (err) {
         atomicMin(o.first_error, ((unsigned long long)row << 8) | err);
@@ -799,11 +799,13 @@ int grow(nm_bedcols *b, uint64_t rows, hipStream_t s) {
 
 const char *row_error_text(uint32_t code) {
     switch (code) {
-        case E_COLUMNS: return "pileup line with fewer than 11 tab-separated columns";
+        case E_COLUMNS: return "pileup line that does not have exactly 18 tab-separated columns (modkit bedMethyl)";
         case E_START: return "pileup column 2 (start) is not an integer";
         case E_COV: return "pileup column 10 (Nvalid_cov) is not an integer";
         case E_PCT: return "pileup column 11 (percent modified) is not a number";
         case E_POS_RANGE: return "pileup position beyond 4 Gbp";
+        case E_STRAND: return "pileup column 6 (strand) is neither '+' nor '-'";
+        case E_START_NEG: return "pileup column 2 (start) is negative";
         default: return "malformed pileup line";
     }
 }
@@ -915,7 +917,8 @@ int map_file(const char *path, TextSource *src) {
     return NM_OK;
 }
 
-int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out);
+// *row_error (may be NULL): NM_EINVAL came from the TEXT — a line that is no bedMethyl row — not from the file, its blocks or an argument
+int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out, bool *row_error = nullptr);
 
 }  // namespace
 
@@ -994,9 +997,10 @@ int nm_bed_plan_indexed(const char *path, const char *tbi_path, uint32_t n_conti
     if (rc) return rc;
     {
         // (the walk reads the block headers through the MAPPING: two small preads per block were measured at twice the page faults' time)
+        bool index_problem = false;
         const std::string what = nmbgzf::region_pieces(p->src.z, p->src.zn, merged, &p->src.pieces, &p->src.n, &inflated, &block_starts,
-                                                       threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
-        if (!what.empty()) return fail(what.compare(0, 9, "the index") == 0 ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
+                                                       threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency())), -1, &index_problem);
+        if (!what.empty()) return fail(index_problem ? NM_EINDEX : NM_EINVAL, "%s: %s", path, what.c_str());
     }
     p->src.bgzf = true;
     p->stats[0] = inflated; p->stats[1] = p->src.zn; p->stats[2] = n_contigs - std::min<uint64_t>(found, n_contigs);
@@ -1016,9 +1020,11 @@ int nm_bed_parse_device_planned(nm_ctx *c, nm_bedplan *p, uint32_t threads, nm_b
     if (!c || !p || !out) return fail(NM_EINVAL, "NULL argument");
     *out = nullptr;
     const char *path = p->path.c_str();
-    int rc = parse_device_impl(c, path, p->src, threads, out);
-    if (rc == NM_EINVAL && strstr(nm_last_error(), "corrupt BGZF block") == nullptr) {
-        // blocks intact, lines that do not parse: a region that starts inside a line — the index is stale
+    bool row_error = false;
+    int rc = parse_device_impl(c, path, p->src, threads, out, &row_error);
+    if (rc == NM_EINVAL && row_error) {
+        // blocks intact, LINES that do not parse (and only that: a damaged block, an unreadable file or a bad argument come back
+        // as themselves): a region that starts or ends inside a line — the index is stale
         const std::string why = nm_last_error();
         return fail(NM_EINDEX, "%s: the text the tabix index names does not parse (%s): stale .tbi?", path, why.c_str());
     }
@@ -1053,7 +1059,11 @@ int nm_bed_parse_device_indexed(nm_ctx *c, const char *path, const char *tbi_pat
 
 namespace {
 
-int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out) {
+int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t threads, nm_bedcols **out, bool *row_error) {
+    bool row_error_unused = false;
+    if (!row_error) row_error = &row_error_unused;
+    *row_error = false;
+    auto fail_row = [&](int code) { *row_error = true; return code; };
     if (threads == 0) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     HIP_TRY(hipSetDevice(c->device));
     const double t_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1118,7 +1128,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                 if (k > w0) { e = k; found = true; }
                 else e = w0;
             }
-            if (!found) return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)SLAB_BYTES);
+            if (!found) return fail_row(fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)SLAB_BYTES));
         }
         cut.push_back(e);
     }
@@ -1241,7 +1251,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipMemcpyAsync(&n_lines, d_block_off + nblk, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         counted();
-        if (n_lines > line_cap) return fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path);
+        if (n_lines > line_cap) return fail_row(fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path));
         if (n_lines > line_have) {                                    // (device-inflate slabs: the arrays follow the line count)
             line_have = std::min<uint64_t>(line_cap, (uint64_t)((double)n_lines * 1.1) + 1024);
             HIP_TRY(tmp_alloc((void **)&d_line_start, line_have * 4));            // (the smaller ones stay in dev_tmp until the call ends)
@@ -1474,7 +1484,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
             if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
             if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
-                return fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16));
+                return fail_row(fail(NM_EINVAL, "%s: a line longer than %llu bytes", path, (unsigned long long)(CARRY_CAP - 16)));
             // the parse kernels want a 16-byte aligned start: the few bytes in front of the carried line become empty lines
             const uint64_t aligned = begin & ~15ull;
             if (aligned < begin) HIP_TRY(hipMemsetAsync(text + aligned, '\n', begin - aligned, c->stream));
@@ -1517,7 +1527,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     unsigned long long first_error = ~0ull;
     HIP_TRY(hipMemcpyAsync(&first_error, d_first_error, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (first_error != ~0ull) return fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF)));
+    if (first_error != ~0ull) return fail_row(fail(NM_EINVAL, "%s: %s", path, row_error_text((uint32_t)(first_error & 0xFF))));
     std::vector<char> line_buf(1u << 16);
     // k-th tab-separated field of the line at text offset `line` (buf: scratch of the calling thread).  A short window first:
     // in a bgzip file every window costs the inflation of the block(s) under it
@@ -1618,13 +1628,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                     for (; k < b->other_mods.size(); ++k)
                         if (b->other_mods[k] == code) break;
                     if (k == b->other_mods.size()) b->other_mods.push_back(code);
-                    if (k > 100) return fail(NM_EINVAL, "%s: more than 100 distinct modification codes in column 4", path);
+                    if (k > 100) return fail_row(fail(NM_EINVAL, "%s: more than 100 distinct modification codes in column 4", path));
                     pmod[i] = (int8_t)(3 + k);
                 }
                 if (patch[i].y & 2u) {
                     field(poff[i], 10, &fb, &fe);
                     double pct = 0;
-                    if (!nmbedparse::parse_double(fb, fe, &pct)) return fail(NM_EINVAL, "%s: pileup column 11 (percent modified) is not a number", path);
+                    if (!nmbedparse::parse_double(fb, fe, &pct)) return fail_row(fail(NM_EINVAL, "%s: pileup column 11 (percent modified) is not a number", path));
                     pfrac[i] = pct / 100.0;
                 }
             }

@@ -120,8 +120,11 @@ struct Region { uint64_t beg, end; };    // virtual offsets
 // merged.  *found = wanted names the index knows.  Returns an empty string, or what is wrong with the index.
 // block_starts (may be NULL): the file offsets at which the wanted sequences' regions begin, ascending, unique — every one the first
 // byte of a BGZF block: where region_pieces may take up the walk on another thread.
+// per_want (may be NULL): the region of every wanted name by its number in `want` ({0, 0} and present = 0 for names the index lacks;
+// a sequence without records is present with beg == end).
 inline std::string tabix_regions(const uint8_t *t, size_t tn, const std::unordered_map<std::string, uint32_t> &want,
-                                 std::vector<Region> *merged, uint64_t *found, std::vector<uint64_t> *block_starts = nullptr) {
+                                 std::vector<Region> *merged, uint64_t *found, std::vector<uint64_t> *block_starts = nullptr,
+                                 std::vector<Region> *per_want = nullptr, std::vector<uint8_t> *present = nullptr) {
     const std::string bad = "not a tabix index";
     if (tn < 36 || memcmp(t, "TBI\1", 4) != 0) return bad;
     auto i32 = [&](size_t o) { int32_t v; memcpy(&v, t + o, 4); return v; };
@@ -138,6 +141,8 @@ inline std::string tabix_regions(const uint8_t *t, size_t tn, const std::unorder
     if ((int32_t)ref_names.size() != n_ref) return bad;
     std::vector<Region> regions;
     *found = 0;
+    if (per_want) per_want->assign(want.size(), Region{0, 0});
+    if (present) present->assign(want.size(), 0);
     size_t o = 36 + (size_t)l_nm;
     for (int32_t r = 0; r < n_ref; ++r) {
         if (o + 4 > tn) return bad;
@@ -169,9 +174,12 @@ inline std::string tabix_regions(const uint8_t *t, size_t tn, const std::unorder
         o += 4;
         if (n_intv < 0 || o + (size_t)n_intv * 8 > tn) return bad;
         o += (size_t)n_intv * 8;
-        if (want.count(ref_names[r])) {
+        const auto w = want.find(ref_names[r]);
+        if (w != want.end()) {
             *found += 1;
             if (hi > lo) regions.push_back({lo, hi});
+            if (per_want && w->second < per_want->size()) (*per_want)[w->second] = hi > lo ? Region{lo, hi} : Region{0, 0};
+            if (present && w->second < present->size()) (*present)[w->second] = 1;
         }
     }
     std::sort(regions.begin(), regions.end(), [](const Region &x, const Region &y) { return x.beg < y.beg; });
@@ -195,10 +203,13 @@ inline std::string tabix_regions(const uint8_t *t, size_t tn, const std::unorder
 // exactly where the next one begins (it does when the index belongs to the file).
 inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<Region> &merged, std::vector<Piece> *pieces,
                                  uint64_t *text_size, uint64_t *inflated, const std::vector<uint64_t> *block_starts = nullptr,
-                                 unsigned threads = 1, int fd = -1) {
+                                 unsigned threads = 1, int fd = -1, bool *index_problem = nullptr) {
+    // *index_problem: the error is the INDEX's (it points off the blocks of this file: a stale .tbi, the caller may read the whole
+    // file), not the file's (a damaged block) — callers branch on this flag, never on the message
+    if (index_problem) *index_problem = false;
     pieces->clear();
     // stretches: [first block, stop) of one region; stop = the next restart point, or beyond the region's last block
-    struct Stretch { size_t region; size_t off, stop; bool to_region_end; std::vector<Piece> pieces; std::string error; };
+    struct Stretch { size_t region; size_t off, stop; bool to_region_end; std::vector<Piece> pieces; std::string error; bool index_error = false; };
     std::vector<Stretch> work;
     for (size_t r = 0; r < merged.size(); ++r) {
         const Region &g = merged[r];
@@ -212,7 +223,7 @@ inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<
             for (size_t k = step; k < n_points; k += step) cuts.push_back((size_t)lo[k]);
         }
         for (size_t k = 0; k < cuts.size(); ++k)
-            work.push_back(Stretch{r, cuts[k], k + 1 < cuts.size() ? cuts[k + 1] : last + 1, k + 1 == cuts.size(), {}, {}});
+            work.push_back(Stretch{r, cuts[k], k + 1 < cuts.size() ? cuts[k + 1] : last + 1, k + 1 == cuts.size(), {}, {}, false});
     }
     auto walk = [&](Stretch &w) {
         const Region &g = merged[w.region];
@@ -226,20 +237,21 @@ inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<
                 bool is_bgzf = false;
                 if (!block_at_fd(fd, zn, off, &bsize, &in_off, &in_len, &isize, &crc, &is_bgzf)) {
                     w.error = is_bgzf ? "corrupt BGZF block" : "the index points outside a BGZF block";
+                    w.index_error = !is_bgzf;
                     return;
                 }
             } else {
-                if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) { w.error = "the index points outside a BGZF block"; return; }
+                if (!(z[off] == 31 && z[off + 1] == 139 && z[off + 2] == 8 && (z[off + 3] & 4))) { w.error = "the index points outside a BGZF block"; w.index_error = true; return; }
                 if (!block_at(z, zn, off, &bsize, &in_off, &in_len, &isize, &crc)) { w.error = "corrupt BGZF block"; return; }
             }
             const uint32_t skip = off == first ? u_beg : 0u;
             const uint32_t stop = off == last ? u_end : (uint32_t)isize;
-            if (skip > isize || stop > isize) { w.error = "the index points beyond a BGZF block"; return; }
+            if (skip > isize || stop > isize) { w.error = "the index points beyond a BGZF block"; w.index_error = true; return; }
             if (stop > skip) w.pieces.push_back({in_off, in_len, isize, skip, stop - skip, 0, crc});
             off += bsize;
         }
         // a stretch that is followed by another one of its region must end on that one's first block
-        if (!w.to_region_end && off != w.stop) w.error = "the index points outside a BGZF block";
+        if (!w.to_region_end && off != w.stop) { w.error = "the index points outside a BGZF block"; w.index_error = true; }
     };
     if (threads > 1 && work.size() > 1) {
         std::vector<std::thread> pool;
@@ -253,7 +265,10 @@ inline std::string region_pieces(const uint8_t *z, size_t zn, const std::vector<
     uint64_t text = 0, infl = 0;
     size_t total = 0;
     for (const auto &w : work) {
-        if (!w.error.empty()) return w.error;
+        if (!w.error.empty()) {
+            if (index_problem) *index_problem = w.index_error;
+            return w.error;
+        }
         total += w.pieces.size();
     }
     pieces->reserve(total);

@@ -148,6 +148,28 @@ class NativePileup:
             pass
 
 
+def tabix_regions(index_path: str, contigs) -> dict:
+    """``{contig: (begin, end)}`` — the virtual offsets (block file offset << 16 | offset in the block's text) a tabix index holds
+    for each of ``contigs`` (nm_tabix_regions; host only); a contig the index does not know is left out.  What pysam's
+    ``TabixFile.fetch(contig)`` starts from in the reference (dataload.py:102-152)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    contigs = list(contigs)
+    names = [c.encode() for c in contigs]
+    off = np.zeros(len(names) + 1, dtype=np.uint32)
+    np.cumsum([len(x) for x in names], out=off[1:])
+    beg = np.zeros(len(names), dtype=np.uint64)
+    end = np.zeros(len(names), dtype=np.uint64)
+    have = np.zeros(len(names), dtype=np.uint8)
+    rc = lib.nm_tabix_regions(os.fsencode(index_path), len(names), b"".join(names), off.ctypes.data_as(C.POINTER(C.c_uint32)),
+                              beg.ctypes.data_as(C.POINTER(C.c_uint64)), end.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              have.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc:
+        raise _lib.NmScanError(lib.nm_last_error().decode())
+    return {c: (int(b), int(e)) for c, b, e, h in zip(contigs, beg, end, have) if h}
+
+
 class BedPlan:
     """The host-only half of the indexed device parse of a bgzip pileup (nm_bed_plan_indexed): the tabix index read, the regions of
     ``contigs``, the walk over their BGZF blocks — no GPU involved, the library call releases the interpreter lock: the CLI runs it on

@@ -199,3 +199,69 @@ def write_bgzf_tabix(bed_text: bytes, gz_path: str, block_size: int = 0xFF00, le
     idx = b"".join(out)
     with open(gz_path + ".tbi", "wb") as f:                 # the index is itself BGZF
         f.write(b"".join(block(idx[i:i + block_size]) for i in range(0, len(idx), block_size)) + eof)
+
+
+REF_TBI = os.path.join(GOLDEN, "data_geobacillus-plasmids.pileup.bed.gz.tbi")
+# what the index holds (decoded by hand from the file: gzip -dc | od; tabix format, SAM/tabix spec): per sequence the pseudo-bin
+# 37450's first chunk = [begin, end) as virtual offsets (block file offset, offset inside the block's text)
+REF_TBI_REGIONS = {"contig_3": ((0, 0), (2938871, 11451)), "contig_2": ((2938871, 11451), (5249729, 59922))}
+
+
+def stored_bgzf_block(text: bytes) -> bytes:
+    """One BGZF member whose deflate stream is a single STORED block: its size in the file is exactly len(text) + 31, so a test
+    can put a block at any file offset it wants."""
+    import struct
+    import zlib
+    assert len(text) <= 65535
+    deflate = b"\x01" + struct.pack("<HH", len(text), len(text) ^ 0xFFFF) + text
+    bsize = 18 + len(deflate) + 8
+    head = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize - 1)
+    return head + deflate + struct.pack("<II", zlib.crc32(text) & 0xFFFFFFFF, len(text))
+
+
+def pileup_laid_out_like_the_reference_index(path: str):
+    """A bgzip pileup whose BLOCK LAYOUT is the one datasets/geobacillus-plasmids.pileup.bed.gz.tbi (made by htslib, the only real
+    third-party index in the reference tree) describes — the pileup itself is not in the tree: rows of contig_3 from virtual offset
+    0:0 to 2938871:11451, rows of contig_2 from there to 5249729:59922, then rows of a third contig the index does not know.
+    Stored deflate blocks put every block boundary exactly where the index says.  Returns the text of the three contigs."""
+    def rows(name, total, seed):
+        rng = np.random.default_rng(seed)
+        out, size, pos = [], 0, 0
+        while True:
+            pos += int(rng.integers(1, 9))
+            cov = int(rng.integers(1, 60))
+            nmod = int(rng.integers(0, cov + 1))
+            pct = nmod * 10000 // cov
+            st = "+-"[int(rng.integers(0, 2))]
+            mt = ("a", "m", "21839")[int(rng.integers(0, 3))]
+            ln = (f"{name}\t{pos}\t{pos + 1}\t{mt}\t{cov}\t{st}\t{pos}\t{pos + 1}\t255,0,0\t{cov}\t{pct // 100}.{pct % 100:02d}"
+                  f"\t{nmod}\t{cov - nmod}\t0\t0\t0\t0\t0\n").encode()
+            if size + len(ln) + 200 > total:
+                # the last row: the colour column (free text, never read) is stretched so that the contig's text ends on the byte
+                pad = total - size - len(ln)
+                assert pad >= 0
+                ln = ln.replace(b"255,0,0", b"255,0,0" + b"0" * pad)
+                out.append(ln)
+                return b"".join(out)
+            out.append(ln)
+            size += len(ln)
+    full = 0xFF00
+    # contig_3: blocks before file offset 2938871 = 44 full blocks + one of 65156 (44 * 65311 + 65187 = 2938871), + 11451 bytes of the next
+    sizes = [full] * 44 + [65156]
+    assert sum(x + 31 for x in sizes) == 2938871
+    t3 = rows("contig_3", sum(sizes) + 11451, 3)
+    # contig_2: the rest of the block at 2938871 (24942 bytes of text: 24973 in the file), 35 full blocks, 59922 bytes of the block at 5249729
+    sizes += [24942] + [full] * 35
+    assert sum(x + 31 for x in sizes) == 5249729
+    t2 = rows("contig_2", (24942 - 11451) + 35 * full + 59922, 2)
+    tx = rows("contig_x", 5000 + 30000, 1)
+    sizes += [59922 + 5000, 30000]
+    text = t3 + t2 + tx
+    assert len(text) == sum(sizes)
+    with open(path, "wb") as f:
+        at = 0
+        for n in sizes:
+            f.write(stored_bgzf_block(text[at:at + n]))
+            at += n
+        f.write(stored_bgzf_block(b""))                                  # the EOF marker block
+    return {"contig_3": t3, "contig_2": t2, "contig_x": tx}

@@ -71,9 +71,19 @@ def test_reader_edge_cases(tmp_path):
     assert t.fraction_mod[[0, 2, 3]].tolist() == [70.00 / 100, 33.333333333333336 / 100, 1.0]
     assert t.strand.tolist() == [ord("+"), ord("+"), ord("-"), ord("+")]
     from nanomotif_amd._lib import NmScanError
-    open(path, "w").write("c\t1\t2\ta\n")
-    with pytest.raises(NmScanError):
-        pp.load_pileup(path)
+    # strict like the fixed 18-column schema of the reference (PILEUP_SCHEMA, dataload.py:15-34): column count, start, strand
+    good = "c\t1\t2\ta\t9\t+\t1\t2\t0\t9\t1.0\t0\t9\t0\t0\t0\t0\t0"
+    open(path, "w").write(good + "\n")
+    assert len(pp.load_pileup(path)) == 1
+    cols = good.split("\t")
+    for bad, what in (("c\t1\t2\ta", "exactly 18"), ("\t".join(cols[:17]), "exactly 18"), (good + "\t0", "exactly 18"), (good + "\t", "exactly 18"),
+                      ("\t".join(cols[:5] + ["."] + cols[6:]), "column 6"), ("\t".join(cols[:5] + [""] + cols[6:]), "column 6"),
+                      ("\t".join(cols[:5] + ["++"] + cols[6:]), "column 6"), ("\t".join(cols[:1] + ["-1"] + cols[2:]), "negative"),
+                      ("\t".join(cols[:1] + ["1.5"] + cols[2:]), "column 2"), ("\t".join(cols[:9] + ["x"] + cols[10:]), "column 10"),
+                      ("\t".join(cols[:10] + ["1..0"] + cols[11:]), "column 11")):
+        open(path, "w").write(good + "\n" + bad + "\n" + good.replace("\t1\t2", "\t5\t6", 1) + "\n")
+        with pytest.raises(NmScanError, match=what):
+            pp.load_pileup(path)
     with pytest.raises(NmScanError):
         pp.load_pileup(str(tmp_path / "missing.bed"))
     open(path, "w").write("")
@@ -197,6 +207,41 @@ def test_tabix_indexed_read_equals_filtered_full_read(tmp_path):
     assert not p3.indexed and p3.index_problem and len(p3) == len(cols_full["position"])
     assert sorted(p3.contig_names) == sorted(names_full)
     p3.close()
+
+
+def test_the_tabix_index_the_reference_ships_is_read_right(tmp_path):
+    """datasets/geobacillus-plasmids.pileup.bed.gz.tbi is the one real htslib-made index in the reference tree (fixture: a copy of
+    that DATA file).  (1) nm_tabix_regions returns the regions it holds (decoded by hand in tests/helpers.py); (2) a bgzip pileup
+    whose blocks lie exactly where that index says is read through it: every wanted contig's rows and nothing else, equal to the
+    whole-file read restricted to the contig — the reference fetches a bin's contigs this way (dataload.py:102-152)."""
+    import shutil
+    from helpers import REF_TBI, REF_TBI_REGIONS, pileup_laid_out_like_the_reference_index
+    got = pp.tabix_regions(REF_TBI, ["contig_2", "nope", "contig_3"])
+    assert got == {k: ((b[0] << 16) | b[1], (e[0] << 16) | e[1]) for k, (b, e) in REF_TBI_REGIONS.items()}
+    from nanomotif_amd._lib import NmScanError
+    open(tmp_path / "x.tbi", "wb").write(b"not an index")
+    with pytest.raises(NmScanError, match="not a tabix index"):
+        pp.tabix_regions(str(tmp_path / "x.tbi"), ["contig_2"])
+    gz = str(tmp_path / "laid_out.bed.gz")
+    text = pileup_laid_out_like_the_reference_index(gz)
+    assert gzip.open(gz, "rb").read() == text["contig_3"] + text["contig_2"] + text["contig_x"]      # a valid gzip file
+    shutil.copy(REF_TBI, gz + ".tbi")
+    full = pp.NativePileup(gz)
+    assert full.contig_names == ["contig_3", "contig_2", "contig_x"]
+    cols_full = {k: v.copy() for k, v in full.ingest_columns(np.arange(3, dtype=np.uint32)).items()}
+    full.close()
+    for wanted in (["contig_3"], ["contig_2"], ["contig_2", "contig_3"], ["contig_x", "contig_2"]):
+        part = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
+        assert part.indexed, part.index_problem
+        present = [n for n in ("contig_3", "contig_2") if n in wanted]
+        assert part.contig_names == present
+        assert part.bytes_inflated < sum(len(text[n]) for n in present) + 2 * 65536         # only the blocks under the regions
+        assert len(part) == sum(text[n].count(b"\n") for n in present)
+        cols = part.ingest_columns(np.arange(len(present), dtype=np.uint32))
+        keep = np.isin(cols_full["contig"], [("contig_3", "contig_2").index(n) for n in present])
+        for k in ("position", "mod_type", "strand", "fraction_mod", "nvalid_cov"):
+            assert np.array_equal(cols[k], cols_full[k][keep]), (wanted, k)
+        part.close()
 
 
 def test_native_bgzip_tabix_writer_of_the_bench(tmp_path):
@@ -364,7 +409,7 @@ def test_names_that_are_not_utf8_are_refused_with_a_message(tmp_path):
     from nanomotif_amd import fasta
     from nanomotif_amd._lib import NmScanError
     bed = str(tmp_path / "p.bed")
-    open(bed, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")
+    open(bed, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\t0\t0\t0\t0\t0\t0\t0\n")
     with pytest.raises(NmScanError, match="contig name of the pileup is not valid UTF-8"):
         pp.NativePileup(bed)
     with pytest.raises(NmScanError, match="not valid UTF-8"):

@@ -46,7 +46,7 @@ def test_device_parser_equals_host_parser(tmp_path):
     assert len(dev) == 500_000 and len(dev.run_contig) == 6
     dev.close()
     # edge cases of the format: CRLF, empty lines, nulls, names with spaces, other mod codes, numbers outside the fast
-    # path (exponent, 20 digits), a contig that comes back later (two runs), no newline at the end, 11 columns only
+    # path (exponent, 20 digits), a contig that comes back later (two runs), no newline at the end
     lines = [
         "c 1\t10\t11\ta\t12\t+\t10\t11\t255,0,0\t12\t70.00\t8\t4\t0\t0\t0\t0\t0",
         "c 1\t11\t12\tm\t3\t-\t11\t12\t255,0,0\tNA\t50.5\t1\t2\t0\t0\t0\t0\t0",
@@ -54,10 +54,10 @@ def test_device_parser_equals_host_parser(tmp_path):
         "c2\t0\t1\t21839\t9\t+\t0\t1\t255,0,0\t9\tnull\t0\t9\t0\t0\t0\t0\t0",
         "c2\t5\t6\th\t9\t-\t5\t6\t255,0,0\t9\t33.333333333333336\t3\t6\t0\t0\t0\t0\t0",
         "c2\t7\t8\ta\t100\t+\t7\t8\t255,0,0\t100\t1e2\t100\t0\t0\t0\t0\t0\t0",
-        "c2\t8\t9\t17596\t100\t\t8\t9\t255,0,0\tnull\t\t100\t0\t0\t0\t0\t0\t0",
+        "c2\t8\t9\t17596\t100\t-\t8\t9\t255,0,0\tnull\t\t100\t0\t0\t0\t0\t0\t0",
         "c2\t9\t10\th\t7\t+\t9\t10\t255,0,0\t7\t12345678901234567890.5\t1\t1\t0\t0\t0\t0\t0",
         "c 1\t99\t100\ta\t12\t+\t99\t100\t255,0,0\t4000000000\t0.01\t8\t4\t0\t0\t0\t0\t0",
-        "c3\t4294967294\t4294967295\tm\t1\t-\t0\t0\t0\t6\t100.00",
+        "c3\t4294967294\t4294967295\tm\t1\t-\t0\t0\t0\t6\t100.00\t6\t0\t0\t0\t0\t0\t",
     ]
     for eol, tail in (("\n", "\n"), ("\r\n", "\r\n"), ("\n", "")):
         with open(path, "w", newline="") as f:
@@ -68,12 +68,23 @@ def test_device_parser_equals_host_parser(tmp_path):
         dev.close()
     # error texts of the host parser
     from nanomotif_amd._lib import NmScanError
-    for bad, what in (("c\t1\t2\ta\n", "fewer than 11"), ("c\tx\t2\ta\t1\t+\t1\t2\t0\t9\t1.0\n", "column 2"),
-                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9x\t1.0\n", "column 10"), ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0.0\n", "column 11"),
-                      ("c\t5000000000\t2\ta\t1\t+\t1\t2\t0\t9\t1.0\n", "beyond 4 Gbp")):
-        open(path, "w").write("c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n" * 3 + bad)
+    # (strict like the reference's fixed 18-column schema, dataload.py:15-34: column count, strand, start)
+    rest = "\t0\t0\t0\t0\t0\t0\t0"
+    for bad, what in (("c\t1\t2\ta\n", "exactly 18"), ("c\tx\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest + "\n", "column 2"),
+                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9x\t1.0" + rest + "\n", "column 10"), ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0.0" + rest + "\n", "column 11"),
+                      ("c\t5000000000\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest + "\n", "beyond 4 Gbp"),
+                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest[:-2] + "\n", "exactly 18"),             # 17 columns
+                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest + "\t0\n", "exactly 18"),               # 19 columns
+                      ("c\t1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest + "\t\n", "exactly 18"),                # a trailing tab is a nineteenth column
+                      ("c\t1\t2\ta\t1\t.\t1\t2\t0\t9\t1.0" + rest + "\n", "column 6"),
+                      ("c\t1\t2\ta\t1\t\t1\t2\t0\t9\t1.0" + rest + "\n", "column 6"),
+                      ("c\t1\t2\ta\t1\t+-\t1\t2\t0\t9\t1.0" + rest + "\n", "column 6"),
+                      ("c\t-1\t2\ta\t1\t+\t1\t2\t0\t9\t1.0" + rest + "\n", "negative")):
+        open(path, "w").write(("c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0" + rest + "\n") * 3 + bad)
         with pytest.raises(NmScanError, match=what):
             pp.DevicePileup(eng, path)
+        with pytest.raises(NmScanError, match=what):                   # the host reader: the same rule, the same words
+            pp.NativePileup(path)
     # random damage in the text (bytes overwritten, tabs / newlines / NULs / digits dropped in): the device parser and the host
     # parser either both refuse the file or give the same rows
     mg.write_bed(path)
@@ -102,7 +113,7 @@ def test_device_parser_equals_host_parser(tmp_path):
         else:
             outcomes["both refused"] += 1
     assert outcomes["same rows"] >= 3 and outcomes["both refused"] >= 3, outcomes
-    open(path, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")          # polars refuses text that is not UTF-8; so do both readers
+    open(path, "wb").write(b"c\xff\x9f\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\t0\t0\t0\t0\t0\t0\t0\n")          # polars refuses text that is not UTF-8; so do both readers
     for reader in (pp.NativePileup, lambda p: pp.DevicePileup(eng, p)):
         with pytest.raises(NmScanError, match="not valid UTF-8"):
             reader(path)
@@ -111,7 +122,7 @@ def test_device_parser_equals_host_parser(tmp_path):
         pp.DevicePileup(eng, path)
     import gzip
     with gzip.open(path + ".gz", "wb") as g:
-        g.write(b"c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\n")
+        g.write(b"c\t0\t1\ta\t1\t+\t0\t1\t0\t9\t1.0\t0\t0\t0\t0\t0\t0\t0\n")
     with pytest.raises(NmScanError, match="compressed input that is not bgzip"):
         pp.DevicePileup(eng, path + ".gz")
     eng.close()
@@ -271,6 +282,37 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
     shutil.copy(fgz + ".tbi", bad + ".tbi")
     with pytest.raises(NmScanError, match="corrupt BGZF block"):
         pp.DevicePileup(eng, bad, contigs=list(mg.names), index_path=bad + ".tbi")
+    eng.close()
+
+
+def test_the_reference_tree_tabix_index_on_the_device_parser(tmp_path):
+    """The one htslib-made index the reference ships (datasets/geobacillus-plasmids.pileup.bed.gz.tbi, a fixture) on a bgzip pileup
+    whose blocks lie exactly where it says (tests/helpers.py; STORED deflate blocks, which the device inflate therefore also
+    covers): the device parser reads the wanted contigs' rows through it, equal to the host reader's, plan and parse in two halves
+    and in one call (dataload.py:102-152)."""
+    import shutil
+    from helpers import REF_TBI, pileup_laid_out_like_the_reference_index
+    from nanomotif_amd.engine import ScanEngine
+    eng = ScanEngine(0)
+    gz = str(tmp_path / "laid_out.bed.gz")
+    text = pileup_laid_out_like_the_reference_index(gz)
+    shutil.copy(REF_TBI, gz + ".tbi")
+    whole_d, whole_h = pp.DevicePileup(eng, gz), pp.NativePileup(gz)
+    _assert_same_rows(whole_d, whole_h)
+    whole_d.close(); whole_h.close()
+    for wanted in (["contig_3"], ["contig_2"], ["contig_2", "contig_3"], ["contig_x", "contig_2"]):
+        host = pp.NativePileup(gz, contigs=wanted, index_path=gz + ".tbi")
+        assert host.indexed
+        plan = pp.BedPlan(gz, gz + ".tbi", wanted)
+        assert plan.rc == 0, plan.error
+        for kw in ({"plan": plan}, {}):
+            dev = pp.DevicePileup(eng, gz, contigs=wanted, index_path=gz + ".tbi", **kw)
+            assert dev.indexed, dev.index_problem
+            assert len(dev) == sum(text[n].count(b"\n") for n in wanted if n != "contig_x")
+            _assert_same_rows(dev, host)
+            dev.close()
+        plan.close()
+        host.close()
     eng.close()
 
 
