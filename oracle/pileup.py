@@ -1,6 +1,9 @@
 """Oracle restatement of the pileup pre-filters (reference: nanomotif/dataload.py:191-247).
-Test infrastructure only.  These need real polars to run in the reference, which is absent here:
-restated from source, pinned by the adjacency known-answer cases of tests/test_dataload.py:37-69.
+Test infrastructure only.  Pinned to OUTPUTS OF THE REFERENCE'S OWN FUNCTIONS run in the build container over the frame stand-in
+tests/golden/refframe.py (real polars is absent here): fixture g10 (coverage + frequency filters on every strict bound) and
+fixture g14 (the adjacency filter at the production distance 8 and at 1, 3 on gapped, tied, null-bearing, mixed-mod-type rows;
+refframe's Expr.rolling restates the polars definition and is itself checked against the two known answers of
+tests/test_dataload.py:37-69 before g14 is recorded), plus those two known answers literally (tests/test_oracle_golden.py).
 
 A pileup table is a dict of equal-length numpy columns:
 ``contig`` (any hashable dtype), ``position`` int64, ``strand`` (uint8 ASCII or str), ``mod_type``,

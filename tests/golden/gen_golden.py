@@ -20,6 +20,8 @@ Vectors:
       every branch (the REAL functions on the row-list frame of refframe.py)   -> g8_postprocess_glue.json
   G9  process_subpileup end to end: every stage table + the final rows          -> g9_process_subpileup.json
   G10 dataload.filter_pileup + filter_pileup_minimummod_frequency               -> g10_frequency_filter.json
+  G14 dataload.filter_pileup_adjacency_filter at the production distance 8 (and 1, 3) on gapped, tied, null-bearing rows of
+      mixed mod types (the REAL function over refframe's restatement of polars' Expr.rolling) -> g14_adjacency_filter.json
 """
 from __future__ import annotations
 
@@ -629,6 +631,72 @@ def g12(nm):
     dump("g12_random_process_subpileup.json", out)
 
 
+def g14(nm):
+    """dataload.filter_pileup_adjacency_filter (dataload.py:228-247) executed, not restated: rows on two contigs and both strands,
+    positions with gaps of 1 .. 40 (so a window of p - 8 .. p + 8 holds between one and seventeen rows), fractions from a small
+    pool (ties inside windows, values exactly at the threshold), nulls, 'm' and '21839' rows on the SAME positions (the filter
+    groups by contig and strand only: mod types compete), 'a' rows between them.  Every (contig, mod type) group passes the
+    coverage and the frequency filter (asserted with the reference's own functions), so the device pipeline — which always
+    runs all three — must end with exactly these rows."""
+    import importlib
+    dl = importlib.import_module("nanomotif.dataload")
+    # first: the stand-in's rolling window against the two known answers the reference's OWN tests hold for this function
+    # (tests/test_dataload.py:37-69, adjacency_distance = 1; the expected lists are theirs): it must be closed on the right and
+    # open on the left — position 9 of the first case survives only with the window (p - 2, p + 1]
+    DF = refstub.refframe.DataFrame
+    kat = DF({"contig": ["contig1"] * 10, "position": list(range(10)), "mod_type": ["m6A"] * 10, "strand": ["+"] * 10,
+              "fraction_mod": [0.8, 0.9, 0.1, 0.95, 0.85, 0.2, 0.75, 0.9, 0.05, 0.8], "Nvalid_cov": [10] * 10})
+    assert dl.filter_pileup_adjacency_filter(kat, methylation_threshold=0.7, adjacency_distance=1)["position"].to_list() == [1, 2, 3, 5, 7, 8, 9]
+    kat = DF({"contig": ["contig1"] * 5 + ["contig2"] * 5, "position": list(range(5)) + list(range(5)), "mod_type": ["m6A", "5mC"] * 5,
+              "strand": ["+"] * 5 + ["-"] * 5, "fraction_mod": [0.8, 0.9, 0.1, 0.95, 0.85, 0.2, 0.75, 0.9, 0.05, 0.8], "Nvalid_cov": [10] * 10})
+    f = dl.filter_pileup_adjacency_filter(kat, methylation_threshold=0.7, adjacency_distance=1)
+    assert f.filter(refstub.col("contig") == "contig1")["position"].to_list() == [1, 2, 3]
+    assert f.filter(refstub.col("contig") == "contig2")["position"].to_list() == [0, 2, 3, 4]
+    rng = np.random.default_rng(1414)
+    pool = np.array([0.0, 0.2, 0.69, 0.6999999999999999, 0.7, 0.7000000000000001, 0.75, 0.8, 0.8, 0.95, 0.95, 1.0])
+    contig, position, strand, mod, frac = [], [], [], [], []
+    for c in ("cA", "cB"):
+        for st in ("+", "-"):
+            n_sites = 900
+            gaps = rng.choice([1, 1, 1, 2, 2, 3, 4, 5, 7, 8, 9, 10, 16, 17, 18, 40], size=n_sites)
+            pos = np.cumsum(gaps) + (0 if st == "+" else 3)
+            for p in pos.tolist():
+                kind = rng.random()
+                codes = ["a"] if kind < 0.5 else (["m", "21839"] if kind < 0.75 else (["m"] if kind < 0.9 else ["21839"]))
+                for code in codes:
+                    contig.append(c); position.append(p); strand.append(st); mod.append(code)
+                    frac.append(float(rng.choice(pool)) if rng.random() > 0.04 else float("nan"))
+    n = len(position)
+    order = rng.permutation(n)                                            # file order is not position order: the function sorts
+    df = refstub.refframe.DataFrame()
+    df._cols = {"contig": np.array(contig, dtype=object)[order], "position": np.array(position, dtype=np.int64)[order],
+                "mod_type": np.array(mod, dtype=object)[order], "strand": np.array(strand, dtype=object)[order],
+                "fraction_mod": np.array(frac, dtype=np.float64)[order], "Nvalid_cov": np.full(n, 20, dtype=np.int64)}
+    df._cols["row"] = np.arange(n, dtype=np.int64)
+    before = dl.filter_pileup_minimummod_frequency(dl.filter_pileup(df))
+    assert len(before) == n, "every group must pass the first two filters"
+    out = {"seed": 1414, "n_rows": n, "methylation_threshold": 0.7,
+           "rows": {"contig": df._cols["contig"].tolist(), "position": df._cols["position"].tolist(), "mod_type": df._cols["mod_type"].tolist(),
+                    "strand": df._cols["strand"].tolist(), "fraction_mod": [None if np.isnan(x) else x for x in df._cols["fraction_mod"].tolist()],
+                    "Nvalid_cov": 20},
+           "kept_rows": {}}
+    for d in (8, 1, 3):
+        res = dl.filter_pileup_adjacency_filter(df, methylation_threshold=0.7, adjacency_distance=d)
+        assert res.columns == df.columns                                  # roll_max dropped again
+        kept = sorted(res._cols["row"].tolist())
+        assert len(set(kept)) == len(kept)
+        out["kept_rows"][str(d)] = kept
+        print(f"g14: d = {d}: {n} -> {len(kept)} rows")
+    # what the vector exercises, counted
+    fr = df._cols["fraction_mod"]
+    k8 = np.zeros(n, dtype=bool)
+    k8[out["kept_rows"]["8"]] = True
+    out["counts"] = {"nulls": int(np.isnan(fr).sum()), "nulls_kept": int((np.isnan(fr) & k8).sum()),
+                     "confident_dropped": int(((fr >= 0.7) & ~k8).sum()), "confident_kept": int(((fr >= 0.7) & k8).sum())}
+    print("g14:", out["counts"])
+    dump("g14_adjacency_filter.json", out)
+
+
 if __name__ == "__main__":
     if os.environ.get("PYTHONHASHSEED") != "0":
         # the reference appends missed candidates in SET order (find_motifs_bin.py:826-833): pin the hash seed so that
@@ -636,6 +704,6 @@ if __name__ == "__main__":
         os.environ["PYTHONHASHSEED"] = "0"
         os.execv(sys.executable, [sys.executable] + sys.argv)
     nm = refstub.load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w](nm)

@@ -210,6 +210,59 @@ class Expr:
     def cast(self, dtype):
         return self
 
+    def rolling(self, index_column, *, period, offset=None, closed="right"):
+        """``Expr.rolling(index_column=..., period="Ni", offset="-Mi")`` as the polars documentation defines it for an integer
+        index column: row i with index value t gets the window ``(t + offset, t + offset + period]`` BY VALUE (closed = "right",
+        the default; ``offset`` defaults to ``-period``); the index column must be sorted ascending (polars raises otherwise;
+        equal values are allowed and see each other); an expression that is not aggregated yields, per row, the LIST of its
+        values over the rows whose index lies in the window, in row order.  Used by the reference's adjacency filter
+        (dataload.py:228-247: period "17i", offset "-9i" for adjacency_distance 8 = positions p - 8 .. p + 8)."""
+        assert closed == "right", "only the polars default is restated here"
+
+        def span(text):
+            assert isinstance(text, str) and text.endswith("i"), f"integer index windows only: {text!r}"
+            return int(text[:-1])
+        per = span(period)
+        off = -per if offset is None else span(offset)
+        assert per > 0
+
+        def fn(df):
+            idx = np.asarray(df._cols[index_column])
+            assert idx.dtype.kind in "iu", "the index column must hold integers"
+            idx = idx.astype(np.int64)
+            if len(idx) > 1 and (np.diff(idx) < 0).any():
+                raise ValueError(f"argument in operation 'rolling' is not sorted: {index_column}")      # polars: InvalidOperationError
+            v = self(df)
+            lo = np.searchsorted(idx, idx + off, side="right")                # first row with index > t + offset
+            hi = np.searchsorted(idx, idx + off + per, side="right")          # one past the last row with index <= t + offset + period
+            out = np.empty(len(idx), dtype=object)
+            for i in range(len(idx)):
+                out[i] = v[lo[i]:hi[i]].tolist()
+            return out
+        return Expr(fn, self.name)
+
+    @property
+    def list(self):
+        return _ListNamespace(self)
+
+
+class _ListNamespace:
+    """``Expr.list``: only ``max`` (the largest non-null element of each row's list; null for a list with none)."""
+
+    def __init__(self, expr):
+        self.expr = expr
+
+    def max(self):
+        def fn(df):
+            lists = self.expr(df)
+            out = np.full(len(lists), np.nan, dtype=np.float64)
+            for i, items in enumerate(lists):
+                vals = [x for x in items if not _is_null(x)]
+                if vals:
+                    out[i] = max(vals)
+            return out
+        return Expr(fn, self.expr.name)
+
 
 class _When:
     def __init__(self, cond):
@@ -290,6 +343,14 @@ class GroupBy:
     def __iter__(self):
         for key, idx in self.groups:
             yield key, self.df._take(idx)
+
+    def map_groups(self, function):
+        """Every group's sub-frame (rows in frame order) through ``function``, the results stacked — in first-appearance order of
+        the groups here (polars: unspecified without maintain_order; what is recorded from it is sorted)."""
+        parts = [function(self.df._take(idx)) for _, idx in self.groups]
+        if not parts:
+            return self.df._take(np.zeros(0, dtype=np.int64))
+        return concat(parts)
 
     def agg(self, *exprs, **named):
         out = {k: [] for k in self.keys}

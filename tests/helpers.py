@@ -265,3 +265,13 @@ def pileup_laid_out_like_the_reference_index(path: str):
             at += n
         f.write(stored_bgzf_block(b""))                                  # the EOF marker block
     return {"contig_3": t3, "contig_2": t2, "contig_x": tx}
+
+
+def g14_table(g):
+    """The input rows of fixture g14 as an oracle.pileup table (+ a ``row`` column = the fixture's row numbers)."""
+    r = g["rows"]
+    n = g["n_rows"]
+    return dict(contig=np.array(r["contig"], dtype=object), position=np.array(r["position"], dtype=np.int64),
+                mod_type=np.array(r["mod_type"], dtype=object), strand=np.array(r["strand"], dtype=object),
+                fraction_mod=np.array([np.nan if x is None else x for x in r["fraction_mod"]], dtype=np.float64),
+                Nvalid_cov=np.full(n, r["Nvalid_cov"], dtype=np.int64), row=np.arange(n, dtype=np.int64))

@@ -1,5 +1,7 @@
 """Device-side pre-filters + classification (nm_ingest_pileup) against the CPU oracle's filters
 (oracle/pileup.py, pinned by the reference's adjacency known-answer cases)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -345,4 +347,55 @@ def test_g10_frequency_and_coverage_bounds_recorded_from_the_reference():
             want[c, m] = n
         assert np.array_equal(res["kept"].astype(np.int64), want), order
         assert {f"{names[c]}|{[k for k, v in codes.items() if v == m][0]}" for c, m in kept} == set(g["kept_groups"])
+    eng.close()
+
+
+def test_g14_adjacency_filter_recorded_from_the_reference_on_the_device():
+    """Fixture g14 — the reference's filter_pileup_adjacency_filter (dataload.py:228-247) EXECUTED at distance 8 on gapped, tied,
+    null-bearing rows of three mod codes, 'm' and '21839' on the same positions — through the device pre-filters
+    (ingest_judge_kernel and the dense-table path): the surviving rows per (contig, mod code) and the confident rows the
+    planes hold are the recorded ones, in modkit order and shuffled."""
+    from helpers import g14_table, load_golden
+    from nanomotif_amd.engine import ScanEngine
+    g = load_golden("g14_adjacency_filter.json")
+    t = g14_table(g)
+    names = sorted(set(t["contig"].tolist()))
+    codes = {"m": 0, "a": 1, "21839": 2}
+    cid = np.array([names.index(c) for c in t["contig"].tolist()], dtype=np.uint32)
+    mod = np.array([codes[m] for m in t["mod_type"].tolist()], dtype=np.int8)
+    st = np.array([ord(s) for s in t["strand"].tolist()], dtype=np.uint8)
+    frac = np.where(np.isnan(t["fraction_mod"]), -0.01, t["fraction_mod"])             # the readers' null
+    kept = np.array(g["kept_rows"]["8"], dtype=np.int64)
+    want_kept = np.zeros((len(names), 8), dtype=np.int64)
+    np.add.at(want_kept, (cid[kept], mod[kept]), 1)
+    conf = kept[t["fraction_mod"][kept] >= 0.7]
+    want_conf = sorted(zip(cid[conf].tolist(), t["position"][conf].tolist(), st[conf].tolist(), mod[conf].tolist()))
+    assert len(want_conf) == g["counts"]["confident_kept"]
+    rng = np.random.default_rng(2)
+    length = int(t["position"].max()) + 50
+    # 'm' and '21839' share one canonical base, so they get one sequence letter; the planes need the right base under a row
+    seqs = []
+    for c in range(len(names)):
+        s = rng.choice(list("ACGT"), size=length)
+        for code, base, comp in ((0, "C", "G"), (1, "A", "T"), (2, "C", "G")):
+            for strand, letter in ((ord("+"), base), (ord("-"), comp)):
+                sel = (cid == c) & (mod == code) & (st == strand)
+                s[t["position"][sel]] = letter
+        seqs.append("".join(s))
+    eng = ScanEngine(0)
+    eng.upload_assembly(names, seqs, ["b"] * len(names))
+    for order in ("modkit", "shuffled"):
+        idx = np.lexsort((mod, st, t["position"], cid)) if order == "modkit" else np.random.default_rng(7).permutation(len(cid))
+        for env in ({}, {"NM_INGEST_DENSE": "1"}):
+            os.environ.update(env)
+            try:
+                res = eng.ingest_pileup(cid[idx], t["position"][idx], mod[idx], st[idx], frac[idx], t["Nvalid_cov"][idx],
+                                        {0: ("m", "C"), 1: ("a", "A"), 2: ("21839", "C")})
+            finally:
+                for k in env:
+                    del os.environ[k]
+            assert res["n_kept"] == len(kept), (order, env)
+            assert np.array_equal(res["kept"].astype(np.int64), want_kept), (order, env)
+            cc, cp, cs, cm = res["confident"]
+            assert sorted(zip(cc.tolist(), cp.tolist(), cs.tolist(), cm.tolist())) == want_conf, (order, env)
     eng.close()

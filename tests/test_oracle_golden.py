@@ -591,3 +591,30 @@ def test_g10_coverage_and_frequency_filters():
         kept[f"{c}|{m}"] = kept.get(f"{c}|{m}", 0) + 1
     assert kept == g["kept_groups"]
     assert "c_null_tip|m" not in kept and "c_ratio_eq|a" not in kept and "c_ok|m" not in kept and "c_cov|a" not in kept
+
+
+def test_g14_adjacency_filter_run_from_the_reference():
+    """dataload.filter_pileup_adjacency_filter (dataload.py:228-247) EXECUTED by tests/golden/gen_golden.py at the production
+    distance 8 (and 1, 3) on gapped positions, tied fractions, nulls and 'm' / '21839' rows sharing positions: the oracle's
+    restatement and the product's host filter keep exactly the recorded rows."""
+    from helpers import g14_table
+    from nanomotif_amd import pileup as pp
+    g = load_golden("g14_adjacency_filter.json")
+    t = g14_table(g)
+    assert g["counts"]["nulls"] > 100 and g["counts"]["nulls_kept"] == 0 and g["counts"]["confident_dropped"] > 1000
+    names = sorted(set(t["contig"].tolist()))
+    codes = {"m": 0, "a": 1, "21839": 2}
+    table = pp.PileupTable(names, np.array([names.index(c) for c in t["contig"].tolist()], dtype=np.int32), t["position"],
+                           np.array([codes[m] for m in t["mod_type"].tolist()], dtype=np.int8),
+                           np.array([ord(s) for s in t["strand"].tolist()], dtype=np.uint8), t["fraction_mod"], t["Nvalid_cov"])
+    for d, kept in g["kept_rows"].items():
+        got = op.filter_pileup_adjacency_filter(t, methylation_threshold=g["methylation_threshold"], adjacency_distance=int(d))
+        assert sorted(got["row"].tolist()) == kept, d
+        # the product's host filter returns a table, not row numbers: compare the rows themselves
+        host = pp.filter_pileup_adjacency_filter(table, methylation_threshold=g["methylation_threshold"], adjacency_distance=int(d))
+        key = lambda c, p, s, m, f: sorted(zip(c, p, s, m, [None if np.isnan(x) else x for x in f]))
+        k = np.array(kept, dtype=np.int64)
+        assert key(host.contig.tolist(), host.position.tolist(), host.strand.tolist(), host.mod_type.tolist(), host.fraction_mod.tolist()) == \
+            key(table.contig[k].tolist(), table.position[k].tolist(), table.strand[k].tolist(), table.mod_type[k].tolist(), table.fraction_mod[k].tolist()), d
+    # all three filters in the pipeline's order leave the same rows (every group passes the first two: asserted at recording time)
+    assert sorted(op.prefilter(t)["row"].tolist()) == g["kept_rows"]["8"]
