@@ -109,6 +109,7 @@ void parse_slab(const char *beg, const char *end, Columns *c) {
             double pct = 0;
             if (!parse_int(f[1], fe[1], &pos)) { c->error = "pileup column 2 (start) is not an integer"; return; }
             if (pos < 0) { c->error = "pileup column 2 (start) is negative"; return; }
+            if (pos > 0xFFFFFFFEll) { c->error = "pileup position beyond 4 Gbp"; return; }      // (the engine's coordinates are 32-bit; the device parser says the same)
             // '+' or '-' and nothing else: the scoring path compares the column with exactly these (find_motifs_bin.py:1308-1314)
             if (fe[5] - f[5] != 1 || (f[5][0] != '+' && f[5][0] != '-')) { c->error = "pileup column 6 (strand) is neither '+' nor '-'"; return; }
             if (!is_null(f[9], fe[9]) && !parse_int(f[9], fe[9], &cov)) { c->error = "pileup column 10 (Nvalid_cov) is not an integer"; return; }
