@@ -1,0 +1,160 @@
+// Stand-alone harness (round 6) for the device inflate kernels of nanomotif_amd/csrc/nmbedinflate.h — the SHIPPED device code, included
+// as it is: bed_inflate_kernel (one lane per block, rounds 4 - 5) against the two-phase form bed_tokens_kernel + bed_resolve_kernel.
+// Host: makes modkit-like bedMethyl text, deflates DISTINCT blocks of it with zlib (level 6, raw streams, 65 280 bytes of text each: what
+// bgzip writes), lays copies of them out as one slab of the size the library uses (3 GiB of text by default), runs every kernel on the
+// slab, checks the text byte for byte and prints each kernel's time.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -o inflate2_proto tools/inflate2_proto.hip -lz -lpthread
+// Run:   ./inflate2_proto [blocks in the slab = 49152] [distinct blocks = 1024] [repetitions = 3]
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace {
+#include "../nanomotif_amd/csrc/nmbedinflate.h"
+}
+
+int main(int argc, char **argv) {
+    const size_t n_blocks = argc > 1 ? (size_t)atol(argv[1]) : 49152;
+    const size_t n_distinct = std::min(n_blocks, argc > 2 ? (size_t)atol(argv[2]) : 1024);
+    const int reps = argc > 3 ? atoi(argv[3]) : 3;
+    const size_t bs = 0xFF00;
+    // modkit-like rows (the columns and value ranges of nanomotif_amd/synth.py's writer)
+    std::string text;
+    {
+        std::mt19937_64 rng(7);
+        text.reserve(n_distinct * bs + 256);
+        unsigned long long pos = 0;
+        int contig = 0;
+        char line[256];
+        while (text.size() < n_distinct * bs) {
+            pos += 1 + rng() % 3;
+            if (pos > 2000000) { pos = rng() % 5; ++contig; }
+            const int cov = 10 + (int)(rng() % 40), pct = (int)(rng() % 10000), nmod = cov * pct / 10000;
+            const int k = snprintf(line, sizeof line, "contig_%04d\t%llu\t%llu\t%s\t%d\t%c\t%llu\t%llu\t255,0,0\t%d\t%d.%02d\t%d\t%d\t0\t0\t0\t0\t0\n", contig, pos, pos + 1,
+                                   (rng() & 1) ? "a" : "m", cov, (rng() & 1) ? '+' : '-', pos, pos + 1, cov, pct / 100, pct % 100, nmod, cov - nmod);
+            text.append(line, (size_t)k);
+        }
+        text.resize(n_distinct * bs);
+    }
+    struct Comp { std::string z; };
+    std::vector<Comp> comp(n_distinct);
+    {
+        const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&, t] {
+                std::vector<unsigned char> tmp(compressBound(bs) + 64);
+                for (size_t i = t; i < n_distinct; i += nt) {
+                    z_stream zs;
+                    memset(&zs, 0, sizeof zs);
+                    deflateInit2(&zs, i % 61 == 60 ? 1 : 6, Z_DEFLATED, -15, 8, i % 97 == 96 ? Z_FIXED : Z_DEFAULT_STRATEGY);      // a few fixed-code and level-1 blocks among them
+                    zs.next_in = (Bytef *)text.data() + i * bs;
+                    zs.avail_in = (uInt)bs;
+                    zs.next_out = tmp.data();
+                    zs.avail_out = (uInt)tmp.size();
+                    deflate(&zs, Z_FINISH);
+                    comp[i].z.assign((const char *)tmp.data(), tmp.size() - zs.avail_out);
+                    deflateEnd(&zs);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+    // the slab: block k is a copy of distinct block k % n_distinct; compressed streams packed back to back
+    std::vector<InfPiece> pieces(n_blocks);
+    std::string packed;
+    unsigned long long tok = 0;
+    for (size_t k = 0; k < n_blocks; ++k) {
+        const std::string &z = comp[k % n_distinct].z;
+        pieces[k] = InfPiece{(unsigned long long)packed.size(), (unsigned int)z.size(), (unsigned int)bs, (unsigned long long)k * bs, 0u, (unsigned int)bs, 0ull, 0u, 0u, tok};
+        tok += inf2_region_bytes((unsigned int)bs);
+        packed += z;
+    }
+    const size_t n = n_blocks * bs;
+    printf("slab: %zu blocks (%zu distinct), %.2f GB of text, %.2f GB deflated (ratio %.2f), token buffer %.2f GB\n", n_blocks, n_distinct, n / 1e9, packed.size() / 1e9,
+           (double)n / packed.size(), tok / 1e9);
+    unsigned char *d_in, *d_out, *d_tok, *d_scratch;
+    InfPiece *d_pieces;
+    InfTokMeta *d_meta;
+    unsigned int *d_status;
+    CHK(hipMalloc(&d_in, packed.size() + INF_OVERRUN));
+    CHK(hipMalloc(&d_out, n + 128));
+    CHK(hipMalloc(&d_tok, tok + 64));
+    CHK(hipMalloc(&d_scratch, 1 << 16));
+    CHK(hipMalloc(&d_pieces, n_blocks * sizeof(InfPiece)));
+    CHK(hipMalloc(&d_meta, n_blocks * sizeof(InfTokMeta)));
+    CHK(hipMalloc(&d_status, 4));
+    CHK(hipMemset(d_in, 0, packed.size() + INF_OVERRUN));
+    CHK(hipMemcpy(d_in, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(d_pieces, pieces.data(), n_blocks * sizeof(InfPiece), hipMemcpyHostToDevice));
+    const unsigned int np = (unsigned int)n_blocks;
+    std::vector<char> back(n);
+    auto check = [&](const char *what) {
+        unsigned int status = 0;
+        CHK(hipDeviceSynchronize());
+        CHK(hipMemcpy(&status, d_status, 4, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(back.data(), d_out, n, hipMemcpyDeviceToHost));
+        size_t bad = 0, first_bad = (size_t)-1;
+        for (size_t k = 0; k < n_blocks; ++k)
+            if (memcmp(back.data() + k * bs, text.data() + (k % n_distinct) * bs, bs) != 0) { if (!bad) first_bad = k; ++bad; }
+        printf("%s: status %u (code %u, block %u), %zu of %zu blocks differ%s\n", what, status, status & 255u, status >> 8, bad, n_blocks, bad ? "  <-- WRONG" : ": text IDENTICAL");
+        if (bad) {
+            const char *a = back.data() + first_bad * bs, *e = text.data() + (first_bad % n_distinct) * bs;
+            size_t at = 0;
+            while (at < bs && a[at] == e[at]) ++at;
+            printf("   first difference: block %zu, byte %zu\n", first_bad, at);
+        }
+        return bad == 0 && status == 0;
+    };
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    auto timed = [&](const char *what, auto &&launch) {
+        launch();
+        CHK(hipDeviceSynchronize());
+        float best = 1e30f, sum = 0;
+        for (int it = 0; it < reps; ++it) {
+            CHK(hipEventRecord(e0));
+            launch();
+            CHK(hipEventRecord(e1));
+            CHK(hipEventSynchronize(e1));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            best = std::min(best, ms);
+            sum += ms;
+        }
+        printf("%-44s %8.2f ms (best %8.2f) = %7.1f GB/s of text\n", what, sum / reps, best, n / 1e9 / (sum / reps * 1e-3));
+        return sum / reps;
+    };
+    bool ok = true;
+    // (1) the single-kernel form
+    CHK(hipMemset(d_status, 0, 4));
+    CHK(hipMemset(d_out, 0, n));
+    timed("bed_inflate_kernel (one lane per block)", [&] { hipLaunchKernelGGL(bed_inflate_kernel, dim3((np + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, 0, d_in, d_pieces, np, d_out, d_scratch, d_status); });
+    ok = check("bed_inflate_kernel") && ok;
+    // (2) two phases
+    CHK(hipMemset(d_status, 0, 4));
+    CHK(hipMemset(d_out, 0, n));
+    const float t1 = timed("bed_tokens_kernel (phase 1)", [&] { hipLaunchKernelGGL(bed_tokens_kernel, dim3((np + INF_LANES - 1) / INF_LANES), dim3(INF_LANES), 0, 0, d_in, d_pieces, np, d_tok, d_meta, d_status); });
+    const float t2 = timed("bed_resolve_kernel (phase 2)", [&] { hipLaunchKernelGGL(bed_resolve_kernel, dim3(np), dim3(64), 0, 0, d_pieces, np, d_tok, d_meta, d_out, d_scratch, d_status); });
+    printf("two phases together: %.2f ms = %.1f GB/s of text\n", t1 + t2, n / 1e9 / ((t1 + t2) * 1e-3));
+    ok = check("two-phase inflate") && ok;
+    {
+        std::vector<InfTokMeta> hm(n_blocks);
+        CHK(hipMemcpy(hm.data(), d_meta, n_blocks * sizeof(InfTokMeta), hipMemcpyDeviceToHost));
+        double s = 0, l = 0;
+        for (const auto &m : hm) { s += m.n_seq; l += m.n_lit; }
+        printf("tokens per block: %.0f sequence records, %.0f literals = %.1f KB of the %.1f KB region\n", s / n_blocks, l / n_blocks, (4 * s + l) / n_blocks / 1e3, inf2_region_bytes((unsigned int)bs) / 1e3);
+    }
+    return ok ? 0 : 1;
+}
