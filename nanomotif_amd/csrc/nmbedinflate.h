@@ -588,31 +588,74 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             r = inf2_construct(T.count, T.dtab, T.dsym, kd, lengths + nlen, ndist, lane);
             if (r < 0 || (r > 0 && ndist - T.count[0][lane] != 1)) { err = 11; break; }
         }
-        for (;;) {                                               // the block's symbols: one per turn of the wave, and every lane's turn costs the same
+        // The block's symbols, one per turn of the wave.  Straight-line code: a literal / length symbol, then — for every lane, whether its
+        // symbol was a length or not — the extra bits, the distance symbol and its extra bits, consuming no bits where there is no match;
+        // all that can go wrong is collected in `bad` and looked at once at the end of the turn.  (64 lanes in lock-step execute both
+        // sides of every branch anyway; without the branches the scalar unit has nothing to do and the turn is ~3 x shorter.)
+        for (;;) {
             if ((turn++ & 7u) == 0) b.service(ring, lane);
-            int sym = inf2_decode(b, ring, kl, T.ltab, T.lsym, lane);
-            if (sym < 0) { err = 12; break; }
-            if (sym < 256) {
-                if (o >= pc.out_len) { err = 13; break; }
-                literal((unsigned int)sym);
-            } else if (sym == 256) break;
-            else {
-                sym -= 257;
-                if (sym >= 29) { err = 14; break; }
-                // base and extra bits of a length / distance code by arithmetic (RFC 1951, 3.2.5), as in bed_inflate_kernel
-                const unsigned int lx = sym < 8 || sym == 28 ? 0u : ((unsigned int)sym >> 2) - 1u;
-                const unsigned int lbase = sym < 8 ? 3u + (unsigned int)sym : sym == 28 ? 258u : 3u + ((4u + ((unsigned int)sym & 3u)) << lx);
-                const unsigned int len = lbase + b.get((int)lx, ring, lane);
-                const int ds = inf2_decode(b, ring, kd, T.dtab, T.dsym, lane);
-                if (ds < 0 || ds >= 30) { err = 15; break; }
-                const unsigned int dx = ds < 4 ? 0u : ((unsigned int)ds >> 1) - 1u;
-                const unsigned int dbase = ds < 4 ? 1u + (unsigned int)ds : 1u + ((2u + ((unsigned int)ds & 1u)) << dx);
-                const unsigned int dist = dbase + b.get((int)dx, ring, lane);
-                if (dist > o || o + len > pc.out_len) { err = 16; break; }
-                seq[n_seq++] = inf2_record(run, false, len, dist);
-                run = 0;
-                o += len;
+            unsigned int bad = 0;
+            // literal / length symbol (the reader holds >= 32 bits after the check: 15 + 5 fit)
+            if (b.cnt < 32) b.refill(ring, lane);
+            unsigned int sym;
+            {
+                const unsigned int x = __builtin_bitreverse32((unsigned int)b.buf) >> 17;
+                unsigned int len = 1;
+#pragma unroll
+                for (int l = 0; l < 15; ++l) len += x >= kl.lim[l] ? 1u : 0u;
+                bad |= len > 15u ? 12u : 0u;
+                len = len > 15u ? 15u : len;
+                const unsigned int t = T.ltab[len - 1][lane];
+                unsigned int idx = (t >> 16) + ((x - (t & 0xFFFFu)) >> (15u - len));
+                idx = idx < (unsigned int)INF_MAXL ? idx : 0u;
+                sym = (unsigned int)T.lsym.get((int)idx, lane);
+                b.buf >>= len;
+                b.cnt -= (int)len;
             }
+            const bool is_lit = sym < 256u, is_end = sym == 256u, is_match = sym > 256u;
+            unsigned int ms = is_match ? sym - 257u : 0u;
+            bad |= ms >= 29u ? 14u : 0u;
+            ms = ms >= 29u ? 0u : ms;
+            const unsigned int lx = !is_match || ms < 8u || ms == 28u ? 0u : (ms >> 2) - 1u;
+            const unsigned int lbase = ms < 8u ? 3u + ms : ms == 28u ? 258u : 3u + ((4u + (ms & 3u)) << lx);
+            const unsigned int mlen = lbase + (unsigned int)(b.buf & ((1ull << lx) - 1));
+            b.buf >>= lx;
+            b.cnt -= (int)lx;
+            // distance symbol (15 + 13 bits)
+            if (b.cnt < 32) b.refill(ring, lane);
+            unsigned int ds;
+            {
+                const unsigned int x = __builtin_bitreverse32((unsigned int)b.buf) >> 17;
+                unsigned int len = 1;
+#pragma unroll
+                for (int l = 0; l < 15; ++l) len += x >= kd.lim[l] ? 1u : 0u;
+                bad |= is_match && len > 15u ? 15u : 0u;
+                len = len > 15u ? 15u : len;
+                const unsigned int t = T.dtab[len - 1][lane];
+                unsigned int idx = (t >> 16) + ((x - (t & 0xFFFFu)) >> (15u - len));
+                idx = idx < (unsigned int)INF_MAXD ? idx : 0u;
+                ds = (unsigned int)T.dsym.get((int)idx, lane);
+                len = is_match ? len : 0u;
+                b.buf >>= len;
+                b.cnt -= (int)len;
+            }
+            bad |= is_match && ds >= 30u ? 15u : 0u;
+            ds = ds >= 30u ? 0u : ds;
+            const unsigned int dx = !is_match || ds < 4u ? 0u : (ds >> 1) - 1u;
+            const unsigned int dbase = ds < 4u ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx);
+            const unsigned int dist = dbase + (unsigned int)(b.buf & ((1ull << dx) - 1));
+            b.buf >>= dx;
+            b.cnt -= (int)dx;
+            bad |= is_match && (dist > o || o + mlen > pc.out_len) ? 16u : 0u;
+            bad |= is_lit && o >= pc.out_len ? 13u : 0u;
+            if (is_lit && !bad) literal(sym);
+            if (is_match && !bad) {
+                seq[n_seq++] = inf2_record(run, false, mlen, dist);
+                run = 0;
+                o += mlen;
+            }
+            if (bad) err = (int)(bad & 31u);                           // (several checks may have failed at once: any of their codes)
+            if (bad || is_end) break;
         }
     }
     if (!err && o != pc.out_len) err = 17;
