@@ -860,8 +860,15 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         // slab owns on the device exists twice (2 x 3 GiB of text: slabs of 1.5 GiB were 6 % slower, 47 against 50 GB/s — a slab
         // should fill every lane slot the kernel's LDS tables leave).
         constexpr uint64_t CHUNK = SLAB_BYTES;                        // compressed bytes per pinned buffer
-        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp[2] = {nullptr, nullptr}, *d_scratch[2] = {nullptr, nullptr};
+        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp[2] = {nullptr, nullptr}, *d_scratch[2] = {nullptr, nullptr}, *d_tok[2] = {nullptr, nullptr};
         InfPiece *d_pieces[2] = {nullptr, nullptr};
+        InfTokMeta *d_meta[2] = {nullptr, nullptr};
+        // Round 6: the blocks are inflated in TWO PHASES (nmbedinflate.h: one lane per block decodes the Huffman stream into tokens, one
+        // wave per block turns the tokens into text) unless NM_BED_INFLATE_V1=1 asks for the single kernel of rounds 4 - 5 (A/B).  A
+        // block's token region is `token_fraction` of its text (NM_BED_TOKEN_FRACTION; tests shrink it to send blocks down the fallback)
+        const bool two_phase = getenv("NM_BED_INFLATE_V1") == nullptr;
+        const double token_fraction = getenv("NM_BED_TOKEN_FRACTION") ? atof(getenv("NM_BED_TOKEN_FRACTION")) : 0.625;
+        size_t max_tok = 0;
         unsigned int *d_status = nullptr;
         unsigned long long *d_tail = nullptr;                         // [2]
         size_t max_pieces = 0, max_partial = 0;
@@ -870,14 +877,21 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             size_t np = 0;
             for (size_t i = sl.first; i < sl.last; ++i) np += src.pieces[i].skip != 0 || src.pieces[i].take != src.pieces[i].out_len;
             max_partial = std::max(max_partial, np);
+            size_t tk = 0;
+            for (size_t i = sl.first; i < sl.last; ++i) tk += inf2_region_bytes((unsigned int)src.pieces[i].out_len, token_fraction);
+            max_tok = std::max(max_tok, tk);
         }
         const int n_buf = inf_slabs.size() > 1 ? 2 : 1;
         for (int b = 0; b < 2; ++b) {
-            if (b >= n_buf) { d_text[b] = d_text[0]; d_comp[b] = d_comp[0]; d_scratch[b] = d_scratch[0]; d_pieces[b] = d_pieces[0]; continue; }
+            if (b >= n_buf) { d_text[b] = d_text[0]; d_comp[b] = d_comp[0]; d_scratch[b] = d_scratch[0]; d_pieces[b] = d_pieces[0]; d_tok[b] = d_tok[0]; d_meta[b] = d_meta[0]; continue; }
             HIP_TRY(tmp_alloc((void **)&d_text[b], slab_cap + 128));
             HIP_TRY(tmp_alloc((void **)&d_comp[b], inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
             HIP_TRY(tmp_alloc((void **)&d_scratch[b], std::max<size_t>(max_partial, 1) << 16));
             HIP_TRY(tmp_alloc((void **)&d_pieces[b], max_pieces * sizeof(InfPiece)));
+            if (two_phase) {
+                HIP_TRY(tmp_alloc((void **)&d_tok[b], max_tok + 64));
+                HIP_TRY(tmp_alloc((void **)&d_meta[b], max_pieces * sizeof(InfTokMeta)));
+            }
         }
         HIP_TRY(tmp_alloc((void **)&d_status, 4));
         HIP_TRY(tmp_alloc((void **)&d_tail, 16));
@@ -951,13 +965,15 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
             std::vector<InfPiece> &pieces = hp[b];
             pieces.clear();
-            uint64_t toff = CARRY_CAP, poff = 0;
+            uint64_t toff = CARRY_CAP, poff = 0, tok_off = 0;
             for (const InfChunk &ch : sl.chunks)
                 for (size_t i = ch.first; i < ch.last; ++i) {
                     const nmbgzf::Piece &pp = src.pieces[i];
                     const bool partial = pp.skip != 0 || pp.take != pp.out_len;
-                    pieces.push_back({ch.dev_off + (pp.in_off - ch.file_lo), (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff, pp.crc, 0u});
+                    const unsigned int tok_len = inf2_region_bytes((unsigned int)pp.out_len, token_fraction);
+                    pieces.push_back({ch.dev_off + (pp.in_off - ch.file_lo), (unsigned int)pp.in_len, (unsigned int)pp.out_len, toff, pp.skip, pp.take, poff, pp.crc, tok_len, tok_off});
                     toff += pp.take;
+                    tok_off += tok_len;
                     if (partial) poff += 1u << 16;
                 }
             // (d_pieces[b], d_comp[b], d_scratch[b] were last read by the inflate of slab si - 2: the host has waited for it)
@@ -1003,8 +1019,20 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             // and match sources (~400 bytes per lane) of one XCD's 12 288 lanes overflow its 4 MB of L2 at six workgroups per CU (77 %
             // hits, profiles/r5/bed_device/inflate_pmc.txt) — and matches are two thirds of the kernel's time (inflate_parts.txt)
             static const unsigned lds_pad = getenv("NM_BED_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("NM_BED_INFLATE_LDS_PAD")) : 0u;
-            hipLaunchKernelGGL(bed_inflate_kernel, dim3((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), lds_pad, inf_stream, d_comp[b],
-                               d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status);
+            const dim3 lane_grid((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES));
+            if (two_phase) {
+                hipLaunchKernelGGL(bed_tokens_kernel, lane_grid, dim3(INF_LANES), 0, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), d_tok[b], d_meta[b], d_status);
+                HIP_TRY(hipGetLastError());
+                // (the blocks whose tokens did not fit their region, if any: the lanes of all others leave at once)
+                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), 0, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status,
+                                   (const InfTokMeta *)d_meta[b]);
+                HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(bed_resolve_kernel, dim3((unsigned)pieces.size()), dim3(64), 0, inf_stream, d_pieces[b], (unsigned int)pieces.size(), d_tok[b], d_meta[b], text,
+                                   d_scratch[b], d_status);
+            } else {
+                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), lds_pad, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status,
+                                   (const InfTokMeta *)nullptr);
+            }
             HIP_TRY(hipGetLastError());
             if (check_crc) {
                 hipLaunchKernelGGL(bed_crc_kernel, dim3((unsigned)((pieces.size() + 3) / 4)), dim3(256), 0, inf_stream, d_pieces[b], (unsigned int)pieces.size(), text,

@@ -16,8 +16,9 @@ struct InfPiece {
     unsigned long long dst_off;         // where the WANTED text goes in the slab
     unsigned int skip, take;            // the wanted part of the block's text
     unsigned long long full_off;        // partial blocks (skip / take cut them): the whole text goes to scratch + full_off first
-    unsigned int crc, pad;              // CRC-32 the member's trailer states for the block's whole text
-    unsigned long long tok_off;         // two-phase inflate (round 6): where the block's token region starts in the token buffer
+    unsigned int crc;                   // CRC-32 the member's trailer states for the block's whole text
+    unsigned int tok_len;               // two-phase inflate (round 6): bytes of the block's token region (a multiple of 16) ...
+    unsigned long long tok_off;         // ... and where it starts in the token buffer
 };
 
 constexpr int INF_LANES = 64, INF_MAXL = 288, INF_MAXD = 30;
@@ -138,6 +139,9 @@ __constant__ unsigned short INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33
 __constant__ unsigned char INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+struct InfTokMeta;                                          // (two-phase inflate, below)
+__device__ __forceinline__ unsigned int inf_meta_err(const InfTokMeta *meta, unsigned int i) { return reinterpret_cast<const unsigned int *>(meta)[4 * (size_t)i + 2]; }
+
 #ifdef NM_BED_PROBES
 // probe builds (NM_CXXFLAGS=-DNM_BED_PROBES, tools/gpu_r5ac.sh): NM_BED_INFLATE_PROBE = 1: matches are not copied, + 2: literals are not
 // stored, + 4: a block ends behind its first pair of Huffman tables — what each part of bed_inflate_kernel costs (the text is garbage: the
@@ -148,7 +152,7 @@ __device__ int g_inf_probe = 0;
 // status: 0, or (piece index << 8 | what went wrong) of the first bad block
 __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned char *__restrict__ in, const InfPiece *__restrict__ pieces, unsigned int n_pieces,
                                                                 unsigned char *__restrict__ text, unsigned char *__restrict__ scratch,
-                                                                unsigned int *__restrict__ status) {
+                                                                unsigned int *__restrict__ status, const struct InfTokMeta *__restrict__ only_full) {
     __shared__ InfTables T;
 #ifdef NM_BED_PROBES
     const int probe = g_inf_probe;
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
     const int lane = threadIdx.x;
     const unsigned int i = blockIdx.x * INF_LANES + lane;
     if (i >= n_pieces) return;
+    if (only_full && inf_meta_err(only_full, i) != 21u) return;         // (two-phase inflate: the blocks phase 1 gave up, nothing else)
     const InfPiece pc = pieces[i];
     const bool partial = pc.skip != 0 || pc.take != pc.out_len;
     InfBits b{in + pc.in_off, 0ull, 0, 0ull};
@@ -360,13 +365,21 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
 constexpr unsigned int INF2_CAP = 1536;            // text bytes of a chunk of phase 2 (a sequence is at most 254 + 258 bytes)
 constexpr int INF2_ROWS = (int)(INF2_CAP / 64);     // 64-byte rows of a chunk
 
-struct InfTokMeta {                                // per block, written by phase 1
+struct InfTokMeta {                                // per block, written by phase 1 (16 bytes: inf_meta_err reads word 2)
     unsigned int n_seq, n_lit, err, pad;
 };
 
-// bytes of a block's token region: 4 bytes per match (>= 3 bytes of text each), 4 per 255 literals that meet no match, 1 per literal,
-// the last literal word written whole — never more than 4/3 of the text + 32
-__host__ __device__ inline unsigned long long inf2_region_bytes(unsigned int out_len) { return ((unsigned long long)out_len * 4u / 3u + 32u + 15u) & ~15ull; }
+// Bytes of a block's token region.  4 bytes per match (>= 3 bytes of text each), 4 per 255 literals that meet no match, 1 per literal,
+// the last literal word written whole: never more than 4/3 of the text + 32.  bedMethyl text needs 0.4 of its size (5 700 records +
+// 3 000 literals per 65 280 bytes), and the buffers are fresh device memory on the critical path of a run: the host sizes a region at
+// `fraction` of the text (5/8 by default), phase 1 gives a block up when its tokens do not fit (INF2_FULL) and the one-lane-per-block
+// kernel above inflates exactly those blocks (only_full) — any deflate stream stays readable, the common one pays for what it needs.
+__host__ __device__ inline unsigned int inf2_region_bytes(unsigned int out_len, double fraction) {
+    const unsigned long long worst = ((unsigned long long)out_len * 4u / 3u + 32u + 15u) & ~15ull;
+    const unsigned long long want = ((unsigned long long)((double)out_len * fraction) + 64u + 15u) & ~15ull;
+    return (unsigned int)(want < worst ? want : worst);
+}
+constexpr unsigned int INF2_FULL = 21;             // InfTokMeta.err: the block's tokens did not fit its region (not an error of the stream)
 
 // sequence record: literals in front of the match (0..254; 255 = 255 literals and no match), bit 8 = no match (the tail of a block),
 // match length - 3, distance - 1
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
     b.start(ring, lane, skip);
     unsigned char *region = tokens + pc.tok_off;
     unsigned int *seq = reinterpret_cast<unsigned int *>(region);
-    unsigned char *lit_end = region + inf2_region_bytes(pc.out_len);
+    unsigned char *lit_end = region + pc.tok_len;
     unsigned int o = 0, n_seq = 0, n_lit = 0, run = 0;
     unsigned long long lw = 0;
     int err = 0, last = 0;
@@ -537,9 +550,10 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             b.cnt -= (b.cnt & 7);
             const unsigned int len = b.get(16, ring, lane), nlen = b.get(16, ring, lane);
             if ((len ^ 0xFFFFu) != nlen || o + len > pc.out_len) { err = 2; break; }
-            for (unsigned int k = 0; k < len; ++k) {
+            for (unsigned int k = 0; k < len && !err; ++k) {
                 if ((k & 7u) == 0) b.service(ring, lane);
-                literal(b.get(8, ring, lane));
+                if (4u * n_seq + (n_lit | 7u) + 24u > pc.tok_len) err = (int)INF2_FULL;
+                else literal(b.get(8, ring, lane));
             }
             continue;
         }
@@ -648,6 +662,8 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             b.cnt -= (int)dx;
             bad |= is_match && (dist > o || o + mlen > pc.out_len) ? 16u : 0u;
             bad |= is_lit && o >= pc.out_len ? 13u : 0u;
+            // room for this turn's record / literal (a literal may complete a word of 8 and a run of 255 at once)
+            if (!bad && 4u * n_seq + (n_lit | 7u) + 24u > pc.tok_len) bad = INF2_FULL;
             if (is_lit && !bad) literal(sym);
             if (is_match && !bad) {
                 seq[n_seq++] = inf2_record(run, false, mlen, dist);
@@ -665,7 +681,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
         if (n_lit & 7u) memcpy(lit_end - ((n_lit + 7u) & ~7u), &lw, 8);
     }
     meta[i] = InfTokMeta{n_seq, n_lit, (unsigned int)err, 0u};
-    if (err) atomicCAS(status, 0u, (unsigned int)err | (i << 8));
+    if (err && err != (int)INF2_FULL) atomicCAS(status, 0u, (unsigned int)err | (i << 8));
 }
 
 // inclusive prefix sum over the 64 lanes of a wave
@@ -698,7 +714,7 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
     unsigned char *dst = partial ? scratch + pc.full_off : text + pc.dst_off;
     const unsigned char *region = tokens + pc.tok_off;
     const unsigned int *seq = reinterpret_cast<const unsigned int *>(region);
-    const unsigned char *lit_end = region + inf2_region_bytes(pc.out_len);
+    const unsigned char *lit_end = region + pc.tok_len;
     unsigned int first = 0, out = 0, lit_pos = 0;
     bool bad = false;
     while (first < m.n_seq) {

@@ -162,8 +162,11 @@ def test_bgzip_and_tabix_subset_on_the_device_parser(tmp_path):
         gz = str(tmp_path / f"p{block_size}.bed.gz")
         write_bgzf_tabix(text, gz, block_size=block_size)
         # the blocks inflated ON THE DEVICE (the default), in slabs small enough that lines straddle them, and by the copy threads
+        # (round 6: two-phase inflate by default; the single kernel of rounds 4 - 5; token regions too small for some / for all blocks,
+        #  which then go through the single kernel while their neighbours take the two phases)
         for threads, env in ((0, {}), (2, {}), (3, {"NM_BED_INFLATE_SLAB": "150000"}), (5, {"NM_BED_INFLATE_SLAB": "70000"}), (0, {"NM_BED_HOST_INFLATE": "1"}),
-                             (5, {"NM_BED_HOST_INFLATE": "1"})):
+                             (5, {"NM_BED_HOST_INFLATE": "1"}), (0, {"NM_BED_INFLATE_V1": "1"}), (3, {"NM_BED_INFLATE_V1": "1", "NM_BED_INFLATE_SLAB": "150000"}),
+                             (0, {"NM_BED_TOKEN_FRACTION": "0.0"}), (2, {"NM_BED_TOKEN_FRACTION": "0.38", "NM_BED_INFLATE_SLAB": "150000"})):
             os.environ.update(env)
             try:
                 dev = pp.DevicePileup(eng, gz, threads=threads)
