@@ -68,7 +68,10 @@ int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user);
  * before is scrubbed by the driver when it is handed out again, and hipFree synchronises the device.  enable 1: install (as
  * nm_set_device_allocator: while no nm_ctx is alive) or change the limit; 0: uninstall and release the idle blocks (NM_ESTATE while
  * blocks are in use); -1: statistics only.  stats (may be NULL): requests served from the cache, requests that went to hipMalloc,
- * idle bytes, blocks in use. */
+ * idle bytes, blocks in use.  A block serves requests made with the same current HIP device only; max_idle_bytes is capped at a quarter
+ * of the device's memory (idle blocks are invisible to other users of hipMalloc in the process: torch, RCCL) and every idle block goes
+ * back to the driver when a request of the cache fails; a block that came back is reused only behind a hipDeviceSynchronize — the
+ * implicit synchronisation hipFree would have made — so the caller's contract is hipFree's: no work may still WRITE a block it frees. */
 int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]);
 
 /* Create / destroy an engine bound to HIP device `device`. */

@@ -20,44 +20,71 @@ int nm_set_error(int code, const char *fmt, ...);
 namespace {
 
 struct BlockCache {
+    struct Block { size_t size; void *ptr; int device; bool settled; };   // settled: the device has been synchronised since the block came back
     std::mutex mu;
-    std::unordered_map<void *, size_t> live;             // blocks handed out by this cache (large ones only): their true size
-    std::vector<std::pair<size_t, void *>> idle;         // cached blocks, unordered (there are a handful)
+    struct Live { size_t size; int device; };
+    std::unordered_map<void *, Live> live;               // blocks handed out by this cache (large ones only): their true size and device
+    std::vector<Block> idle;                             // cached blocks, unordered (there are a handful)
     size_t idle_bytes = 0, max_idle = 0;
     uint64_t hits = 0, misses = 0, released = 0;
     static constexpr size_t MIN_BLOCK = 32u << 20;       // smaller blocks are not worth keeping
     static constexpr size_t ROUND = 2u << 20;
 
+    // hipMalloc; when it fails while blocks lie idle, they go back to the driver first (small and large requests alike: the idle
+    // blocks are invisible to every other user of hipMalloc in the process)
+    hipError_t malloc_retry(void **p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            bool any;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                any = !idle.empty();
+            }
+            if (any) {
+                trim(0);
+                e = hipMalloc(p, bytes);
+                if (e != hipSuccess) (void)hipGetLastError();
+            }
+        }
+        return e;
+    }
+
     int alloc(void **out, size_t bytes) {
         *out = nullptr;
-        if (bytes < MIN_BLOCK) return hipMalloc(out, bytes) == hipSuccess ? 0 : -4;
+        if (bytes < MIN_BLOCK) return malloc_retry(out, bytes) == hipSuccess ? 0 : -4;
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return -4;
         const size_t want = (bytes + ROUND - 1) / ROUND * ROUND;
         {
-            std::lock_guard<std::mutex> lk(mu);
-            // best fit: the smallest idle block that holds the request and is not more than eight times its size
+            std::unique_lock<std::mutex> lk(mu);
+            // best fit ON THIS DEVICE: the smallest idle block that holds the request and is not more than eight times its size
             int best = -1;
             for (int i = 0; i < (int)idle.size(); ++i)
-                if (idle[i].first >= want && idle[i].first <= 8 * want && (best < 0 || idle[i].first < idle[best].first)) best = i;
+                if (idle[i].device == device && idle[i].size >= want && idle[i].size <= 8 * want && (best < 0 || idle[i].size < idle[best].size)) best = i;
             if (best >= 0) {
-                const auto blk = idle[best];
+                const Block blk = idle[best];
                 idle.erase(idle.begin() + best);
-                idle_bytes -= blk.first;
-                live[blk.second] = blk.first;
+                idle_bytes -= blk.size;
+                live[blk.ptr] = Live{blk.size, blk.device};
                 hits += 1;
-                *out = blk.second;
+                if (!blk.settled) {
+                    // hipFree would have synchronised the device before the memory could be handed out again; a cached block is reused at
+                    // once, so the cache does it here — once for everything that came back since the last time (the library waits for its
+                    // own streams before it frees: this costs a few microseconds and guards against a caller that does not)
+                    for (Block &o : idle)
+                        if (o.device == device) o.settled = true;
+                    lk.unlock();
+                    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+                }
+                *out = blk.ptr;
                 return 0;
             }
         }
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {                            // out of memory with blocks lying idle: give them back and try once more
-            (void)hipGetLastError();
-            trim(0);
-            e = hipMalloc(&p, want);
-        }
-        if (e != hipSuccess) return -4;
+        if (malloc_retry(&p, want) != hipSuccess) return -4;
         std::lock_guard<std::mutex> lk(mu);
-        live[p] = want;
+        live[p] = Live{want, device};
         misses += 1;
         *out = p;
         return 0;
@@ -70,10 +97,11 @@ struct BlockCache {
             std::lock_guard<std::mutex> lk(mu);
             auto it = live.find(p);
             if (it != live.end()) {
-                size = it->second;
+                size = it->second.size;
+                const int device = it->second.device;
                 live.erase(it);
                 if (idle_bytes + size <= max_idle) {
-                    idle.emplace_back(size, p);
+                    idle.push_back(Block{size, p, device, false});
                     idle_bytes += size;
                     return 0;
                 }
@@ -90,10 +118,10 @@ struct BlockCache {
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lk(mu);
-            std::sort(idle.begin(), idle.end());
+            std::sort(idle.begin(), idle.end(), [](const Block &x, const Block &y) { return x.size < y.size; });
             while (!idle.empty() && idle_bytes > keep_bytes) {
-                drop.push_back(idle.back().second);
-                idle_bytes -= idle.back().first;
+                drop.push_back(idle.back().ptr);
+                idle_bytes -= idle.back().size;
                 idle.pop_back();
             }
         }
@@ -126,6 +154,10 @@ int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]) {
             if (rc) return rc;
             g_installed = true;
         }
+        // never more than a quarter of the device: what lies idle here is invisible to the other users of hipMalloc in the process
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) max_idle_bytes = std::min<uint64_t>(max_idle_bytes, total_b / 4);
+        else (void)hipGetLastError();
         std::lock_guard<std::mutex> lk(g_cache.mu);
         g_cache.max_idle = (size_t)max_idle_bytes;
         return NM_OK;
