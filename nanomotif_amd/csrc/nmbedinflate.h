@@ -389,41 +389,42 @@ __device__ __forceinline__ unsigned int inf2_record(unsigned int lit, bool no_ma
 
 struct InfRing { unsigned int w[64][INF_LANES]; };                 // 64 dwords of compressed bytes per lane, [word][lane]
 
-// bit reader of phase 1: the stream arrives in pieces of 64 bytes (four 16-byte loads, issued at one service call, written into the ring
-// at the next one — eight turns of the wave later, when they have long arrived) and is consumed a dword at a time; the dword the next
-// refill will take is read from the ring one refill ahead, so that no turn waits for it
+// bit reader of phase 1: the stream arrives in pieces of 32 bytes — two 16-byte loads issued at EVERY service call (every eight turns of
+// the wave), written into the ring at the next one, when they have long arrived, provided the ring had room for them when they were asked
+// for (otherwise the same bytes are asked for again: no state hangs on a condition, so the loads stay in flight across the turns instead
+// of being waited for on the spot) — and is consumed a dword at a time; the dword the next refill will take is read from the ring one
+// refill ahead, so that no turn waits for it either
 struct InfBits2 {
     const uint4 *src;                   // the lane's stream from the 16-byte boundary in front of its first byte
     unsigned int fill, rd;              // dwords written into the ring / taken out of it so far (ring[rd] is in `ahead`)
     unsigned long long buf;
     int cnt;
     unsigned int ahead;
-    uint4 q0, q1, q2, q3;
-    bool inflight;
+    uint4 q0, q1;
+    bool room;                          // the ring had room for q0, q1 when they were asked for
     __device__ __forceinline__ void land(InfRing &r, int lane) {
-        const unsigned int f = fill;
-        r.w[(f + 0) & 63][lane] = q0.x; r.w[(f + 1) & 63][lane] = q0.y; r.w[(f + 2) & 63][lane] = q0.z; r.w[(f + 3) & 63][lane] = q0.w;
-        r.w[(f + 4) & 63][lane] = q1.x; r.w[(f + 5) & 63][lane] = q1.y; r.w[(f + 6) & 63][lane] = q1.z; r.w[(f + 7) & 63][lane] = q1.w;
-        r.w[(f + 8) & 63][lane] = q2.x; r.w[(f + 9) & 63][lane] = q2.y; r.w[(f + 10) & 63][lane] = q2.z; r.w[(f + 11) & 63][lane] = q2.w;
-        r.w[(f + 12) & 63][lane] = q3.x; r.w[(f + 13) & 63][lane] = q3.y; r.w[(f + 14) & 63][lane] = q3.z; r.w[(f + 15) & 63][lane] = q3.w;
-        fill = f + 16;
-        inflight = false;
+        if (room) {
+            const unsigned int f = fill;
+            r.w[(f + 0) & 63][lane] = q0.x; r.w[(f + 1) & 63][lane] = q0.y; r.w[(f + 2) & 63][lane] = q0.z; r.w[(f + 3) & 63][lane] = q0.w;
+            r.w[(f + 4) & 63][lane] = q1.x; r.w[(f + 5) & 63][lane] = q1.y; r.w[(f + 6) & 63][lane] = q1.z; r.w[(f + 7) & 63][lane] = q1.w;
+            fill = f + 8;
+        }
     }
     __device__ __forceinline__ void ask() {
+        room = fill - rd <= 56u;
         const uint4 *p = src + (fill >> 2);
-        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-        inflight = true;
+        q0 = p[0]; q1 = p[1];
     }
-    // every eight turns (at most 48 bits each: 12 dwords in all): the ring holds >= 36 dwords after every call, never more than 64
+    // every eight turns: on bedMethyl text a turn takes 13 bits, eight turns 3 - 4 dwords of the 8 that arrive; a stream that takes more
+    // than 32 bits per turn for long (long matches at far distances, one after the other) drains the ring and pays refill()'s slow path
     __device__ __forceinline__ void service(InfRing &r, int lane) {
-        if (inflight) land(r, lane);
-        if (fill - rd <= 48u) ask();
-    }
-    __device__ __forceinline__ void start(InfRing &r, int lane, unsigned int skip) {
-        fill = 0; rd = 0; buf = 0; cnt = 0; inflight = false;
-        ask();
         land(r, lane);
         ask();
+    }
+    __device__ __forceinline__ void start(InfRing &r, int lane, unsigned int skip) {
+        fill = 0; rd = 0; buf = 0; cnt = 0;
+        ask();
+        for (int k = 0; k < 4; ++k) service(r, lane);                // 32 dwords in the ring, 8 on their way
         rd = skip >> 2;
         ahead = r.w[rd & 63][lane];
         if (skip & 3u) { refill(r, lane); buf >>= 8 * (skip & 3u); cnt -= 8 * (int)(skip & 3u); }
@@ -432,7 +433,7 @@ struct InfBits2 {
         buf |= (unsigned long long)ahead << cnt;
         rd += 1;
         cnt += 32;
-        if (rd == fill) {                                              // (only where service() was not called in time: header loops)
+        if (rd == fill) {                                              // the ring is empty (header loops; streams of > 32 bits per turn)
             service(r, lane);
             if (rd == fill) service(r, lane);
         }
@@ -453,6 +454,16 @@ struct InfBits2 {
 // bits.  The length of the code in front of the reader is 1 + the number of limits the 15 bits reach — fifteen compares, no branch —
 // and tab[len - 1] = (lower limit of that length's codes | index of its first symbol << 16) gives the symbol's place.
 struct InfCanon { unsigned int lim[15]; };
+
+// 1 + the number of limits x reaches.  The limits grow with the length, so the signs of lim - 1 - x (x, lim < 2^16) are ones up to the
+// code's length and zeros from there on: they are shifted into one word (v_sub + v_alignbit per limit, no compare / select pairs with
+// their wait states) and counted
+__device__ __forceinline__ unsigned int inf2_code_length(unsigned int x, const InfCanon &k) {
+    unsigned int signs = 0;
+#pragma unroll
+    for (int l = 0; l < 15; ++l) signs = __builtin_amdgcn_alignbit(signs, k.lim[l] - 1u - x, 31);
+    return 1u + (unsigned int)__popc(signs & 0x7FFFu);
+}
 
 struct InfTables2 {
     unsigned short count[16][INF_LANES];         // codes per length while a table is built
@@ -494,9 +505,7 @@ template <typename Symbols>
 __device__ __forceinline__ int inf2_decode(InfBits2 &b, InfRing &ring, const InfCanon &k, const unsigned int (*tab)[INF_LANES], const Symbols &symbol, int lane) {
     if (b.cnt < 32) b.refill(ring, lane);
     const unsigned int x = __builtin_bitreverse32((unsigned int)b.buf) >> 17;
-    unsigned int len = 1;
-#pragma unroll
-    for (int l = 0; l < 15; ++l) len += x >= k.lim[l] ? 1u : 0u;
+    const unsigned int len = inf2_code_length(x, k);
     if (len > 15u) return -1;
     const unsigned int t = tab[len - 1][lane];
     const unsigned int idx = (t >> 16) + ((x - (t & 0xFFFFu)) >> (15u - len));
@@ -508,6 +517,7 @@ __device__ __forceinline__ int inf2_decode(InfBits2 &b, InfRing &ring, const Inf
 struct InfShared2 {
     InfTables2 T;
     InfRing ring;
+    unsigned int rec[8][INF_LANES];             // the sequence records of the last (at most eight) turns, stored together at the next service
 };
 
 // phase 1.  status: as bed_inflate_kernel (0, or piece index << 8 | code of the first bad block); meta[i].err repeats the code per block
@@ -528,18 +538,51 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
     unsigned char *region = tokens + pc.tok_off;
     unsigned int *seq = reinterpret_cast<unsigned int *>(region);
     unsigned char *lit_end = region + pc.tok_len;
-    unsigned int o = 0, n_seq = 0, n_lit = 0, run = 0;
-    unsigned long long lw = 0;
+    // Every global store of the lane happens at a service call, next to the ring's loads: the records of the turns since the last call
+    // wait in LDS (n_seq = stored + staged), a completed word of eight literals waits in a register (at most one completes in eight turns).
+    // The wait for the ring's loads at the next call — eight turns later — is then a wait for operations that have long finished, stores
+    // included (loads and stores share one counter: a store of the turn before would be waited for with them)
+    unsigned int o = 0, n_stored = 0, n_staged = 0, n_lit = 0, run = 0;
+    unsigned long long lw = 0, lw_done = 0;
+    unsigned int lw_at = 0;                                           // 0: no completed word; else the literal count it ends at
     int err = 0, last = 0;
     unsigned int turn = 0;
     unsigned char lengths[INF_MAXL + INF_MAXD];
+    auto record = [&](unsigned int rec) {
+        if (n_staged == 8u) {                                         // (never between two services of the symbol loop: stored-block and header paths)
+            uint4 a, c;
+            a.x = S.rec[0][lane]; a.y = S.rec[1][lane]; a.z = S.rec[2][lane]; a.w = S.rec[3][lane];
+            c.x = S.rec[4][lane]; c.y = S.rec[5][lane]; c.z = S.rec[6][lane]; c.w = S.rec[7][lane];
+            memcpy(seq + n_stored, &a, 16);
+            memcpy(seq + n_stored + 4, &c, 16);
+            n_stored += 8;
+            n_staged = 0;
+        }
+        S.rec[n_staged][lane] = rec;
+        n_staged += 1;
+    };
+    auto flush = [&]() {
+        if (n_staged) {                                               // eight dwords whatever is staged: what lies behind the staged ones is overwritten later
+            uint4 a, c;
+            a.x = S.rec[0][lane]; a.y = S.rec[1][lane]; a.z = S.rec[2][lane]; a.w = S.rec[3][lane];
+            c.x = S.rec[4][lane]; c.y = S.rec[5][lane]; c.z = S.rec[6][lane]; c.w = S.rec[7][lane];
+            memcpy(seq + n_stored, &a, 16);
+            memcpy(seq + n_stored + 4, &c, 16);
+            n_stored += n_staged;
+            n_staged = 0;
+        }
+        if (lw_at) { memcpy(lit_end - lw_at, &lw_done, 8); lw_at = 0; }
+    };
     auto literal = [&](unsigned int byte) {
         lw |= (unsigned long long)byte << (8u * (7u - (n_lit & 7u)));
         n_lit += 1;
-        if ((n_lit & 7u) == 0) { memcpy(lit_end - n_lit, &lw, 8); lw = 0; }
+        if ((n_lit & 7u) == 0) {
+            if (lw_at) memcpy(lit_end - lw_at, &lw_done, 8);            // (only where no service came in between: stored blocks)
+            lw_done = lw; lw_at = n_lit; lw = 0;
+        }
         o += 1;
         run += 1;
-        if (run == 255u) { seq[n_seq++] = inf2_record(255u, true, 3u, 1u); run = 0; }
+        if (run == 255u) { record(inf2_record(255u, true, 3u, 1u)); run = 0; }
     };
     while (!last && !err) {
         if (b.consumed_bytes(skip) > (long long)pc.in_len + 8) { err = 18; break; }      // ran past the block's stream
@@ -551,8 +594,8 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             const unsigned int len = b.get(16, ring, lane), nlen = b.get(16, ring, lane);
             if ((len ^ 0xFFFFu) != nlen || o + len > pc.out_len) { err = 2; break; }
             for (unsigned int k = 0; k < len && !err; ++k) {
-                if ((k & 7u) == 0) b.service(ring, lane);
-                if (4u * n_seq + (n_lit | 7u) + 24u > pc.tok_len) err = (int)INF2_FULL;
+                if ((k & 7u) == 0) { flush(); b.service(ring, lane); }
+                if (4u * (n_stored + n_staged) + (n_lit | 7u) + 56u > pc.tok_len) err = (int)INF2_FULL;
                 else literal(b.get(8, ring, lane));
             }
             continue;
@@ -607,16 +650,14 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
         // all that can go wrong is collected in `bad` and looked at once at the end of the turn.  (64 lanes in lock-step execute both
         // sides of every branch anyway; without the branches the scalar unit has nothing to do and the turn is ~3 x shorter.)
         for (;;) {
-            if ((turn++ & 7u) == 0) b.service(ring, lane);
+            if ((turn++ & 7u) == 0) { flush(); b.service(ring, lane); }
             unsigned int bad = 0;
             // literal / length symbol (the reader holds >= 32 bits after the check: 15 + 5 fit)
             if (b.cnt < 32) b.refill(ring, lane);
             unsigned int sym;
             {
                 const unsigned int x = __builtin_bitreverse32((unsigned int)b.buf) >> 17;
-                unsigned int len = 1;
-#pragma unroll
-                for (int l = 0; l < 15; ++l) len += x >= kl.lim[l] ? 1u : 0u;
+                unsigned int len = inf2_code_length(x, kl);
                 bad |= len > 15u ? 12u : 0u;
                 len = len > 15u ? 15u : len;
                 const unsigned int t = T.ltab[len - 1][lane];
@@ -640,9 +681,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             unsigned int ds;
             {
                 const unsigned int x = __builtin_bitreverse32((unsigned int)b.buf) >> 17;
-                unsigned int len = 1;
-#pragma unroll
-                for (int l = 0; l < 15; ++l) len += x >= kd.lim[l] ? 1u : 0u;
+                unsigned int len = inf2_code_length(x, kd);
                 bad |= is_match && len > 15u ? 15u : 0u;
                 len = len > 15u ? 15u : len;
                 const unsigned int t = T.dtab[len - 1][lane];
@@ -662,11 +701,12 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             b.cnt -= (int)dx;
             bad |= is_match && (dist > o || o + mlen > pc.out_len) ? 16u : 0u;
             bad |= is_lit && o >= pc.out_len ? 13u : 0u;
-            // room for this turn's record / literal (a literal may complete a word of 8 and a run of 255 at once)
-            if (!bad && 4u * n_seq + (n_lit | 7u) + 24u > pc.tok_len) bad = INF2_FULL;
+            // room for this turn's record / literal (a literal may complete a word of 8 and a run of 255 at once; a flush writes eight
+            // dwords from the first staged record on: 32 bytes that must stay below the literals)
+            if (!bad && 4u * (n_stored + n_staged) + (n_lit | 7u) + 56u > pc.tok_len) bad = INF2_FULL;
             if (is_lit && !bad) literal(sym);
             if (is_match && !bad) {
-                seq[n_seq++] = inf2_record(run, false, mlen, dist);
+                record(inf2_record(run, false, mlen, dist));
                 run = 0;
                 o += mlen;
             }
@@ -677,10 +717,11 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
     if (!err && o != pc.out_len) err = 17;
     if (!err && b.consumed_bytes(skip) > (long long)pc.in_len + 8) err = 18;
     if (!err) {
-        if (run) seq[n_seq++] = inf2_record(run, true, 3u, 1u);
+        if (run) record(inf2_record(run, true, 3u, 1u));
+        flush();
         if (n_lit & 7u) memcpy(lit_end - ((n_lit + 7u) & ~7u), &lw, 8);
     }
-    meta[i] = InfTokMeta{n_seq, n_lit, (unsigned int)err, 0u};
+    meta[i] = InfTokMeta{n_stored, n_lit, (unsigned int)err, 0u};
     if (err && err != (int)INF2_FULL) atomicCAS(status, 0u, (unsigned int)err | (i << 8));
 }
 
@@ -695,7 +736,10 @@ __device__ __forceinline__ unsigned int inf2_wave_scan(unsigned int v, int lane)
 }
 
 struct InfChunk2 {
-    unsigned short dist[INF2_CAP];                 // per byte of the chunk: 0 = literal, else the distance to a byte of equal value
+    union {
+        unsigned short dist[INF2_CAP];             // per byte of the chunk: 0 = literal, else the distance to a byte of equal value
+        unsigned int dist_pair[INF2_CAP / 2];      // (two entries at a time)
+    };
     unsigned char text[16 + INF2_CAP + 16];        // the chunk's bytes, shifted so that index = address mod 16 of where they go
 };
 
@@ -717,10 +761,15 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
     const unsigned char *lit_end = region + pc.tok_len;
     unsigned int first = 0, out = 0, lit_pos = 0;
     bool bad = false;
+    // A chunk is a chain of dependent steps, and what a wave waits for between them is memory: the records, the literals, the gathers,
+    // the stores before the next gathers.  The records of the NEXT chunk are asked for as soon as this chunk's size is known, the
+    // literals before the distances are written, and the wait for the chunk's stores stands in front of the next chunk's gathers, not
+    // behind the stores: one exposed round trip per chunk (the gathers) instead of four
+    unsigned int rec_ahead = (unsigned int)lane < m.n_seq ? seq[lane] : 0u;
     while (first < m.n_seq) {
         // (a) up to 64 sequences, as many of them as fit the chunk
         const unsigned int j = first + (unsigned int)lane;
-        const unsigned int rec = j < m.n_seq ? seq[j] : 0u;
+        const unsigned int rec = rec_ahead;
         unsigned int lit = rec & 255u;
         unsigned int mlen = (rec & 256u) ? 0u : ((rec >> 9) & 255u) + 3u;
         const unsigned int dist = (rec >> 17) + 1u;
@@ -729,13 +778,22 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
         const unsigned int end_rel = packed >> 16;
         const unsigned long long fits = __ballot(j < m.n_seq && end_rel <= INF2_CAP);
         const int n_take = __popcll(fits);                               // (a prefix: end_rel grows with the lane; at least one: a sequence is <= 512 bytes)
-        const unsigned int n_bytes = (unsigned int)__shfl((int)end_rel, n_take - 1), n_lits = (unsigned int)__shfl((int)(packed & 0xFFFFu), n_take - 1);
+        // (the same in every lane — said so, or the loops below are run with vector masks instead of scalar counters)
+        const unsigned int n_bytes = (unsigned int)__builtin_amdgcn_readfirstlane(__shfl((int)end_rel, n_take - 1));
+        const unsigned int n_lits = (unsigned int)__builtin_amdgcn_readfirstlane(__shfl((int)(packed & 0xFFFFu), n_take - 1));
         if (lane >= n_take) { lit = 0; mlen = 0; }
         if (out + n_bytes > pc.out_len || lit_pos + n_lits > m.n_lit) { bad = true; break; }      // (wave-uniform; cannot happen with phase 1's tokens)
         const unsigned int o_rel = end_rel - lit - mlen, lp = lit_pos + (packed & 0xFFFFu) - lit;
         const unsigned int a0 = (unsigned int)((size_t)(dst + out) & 15u);
-        // (b) literal runs: the literals of a run sit in descending addresses below lit_end, eight to an (unaligned) 8-byte load
-        for (unsigned int k8 = 0; __any(k8 < lit); k8 += 8) {
+        {
+            const unsigned int jn = first + (unsigned int)n_take + (unsigned int)lane;
+            rec_ahead = jn < m.n_seq ? seq[jn] : 0u;
+        }
+        // (b) literal runs: the literals of a run sit in descending addresses below lit_end, eight to an (unaligned) 8-byte load; the first
+        //     eight of every run are asked for here and written behind (c)
+        unsigned long long w0 = 0;
+        if (lit) memcpy(&w0, lit_end - lp - 8, 8);
+        for (unsigned int k8 = 8; __any(k8 < lit); k8 += 8) {
             if (k8 < lit) {
                 unsigned long long w;
                 memcpy(&w, lit_end - (lp + k8) - 8, 8);
@@ -749,28 +807,48 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
         }
         // (c) every match byte: the distance of its match; the unused bytes of the last 64-byte row: literals (the loops below run over
         //     whole rows and carry no bounds checks)
-        for (unsigned int k = 0; __any(k < mlen); ++k)
-            if (k < mlen) C.dist[o_rel + lit + k] = (unsigned short)dist;
+        {
+            // (two entries per store where the pair is aligned: half the turns of the loop, which the longest match of the chunk sets)
+            const unsigned int m0 = o_rel + lit, m1 = m0 + mlen;
+            unsigned int at = m0;
+            if ((at & 1u) && at < m1) { C.dist[at] = (unsigned short)dist; at += 1; }
+            const unsigned int pair = dist | (dist << 16);
+            while (__any(at + 2u <= m1))
+                if (at + 2u <= m1) { C.dist_pair[at >> 1] = pair; at += 2; }
+            if (at < m1) C.dist[at] = (unsigned short)dist;
+        }
         const unsigned int rows = (n_bytes + 63u) >> 6;
         if (n_bytes + (unsigned int)lane < rows * 64u) C.dist[n_bytes + (unsigned int)lane] = 0;
+#pragma unroll
+        for (unsigned int k = 0; k < 8; ++k)
+            if (k < lit) {
+                C.text[a0 + o_rel + k] = (unsigned char)(w0 >> (8u * (7u - k)));
+                C.dist[o_rel + k] = 0;
+            }
         // (d) distances that land on another match byte of this chunk are added up (pointer doubling); a byte is settled once its
         //     distance lands on a literal of the chunk or in front of the chunk.  Reading a neighbour's distance while its owner
         //     updates it is harmless: the old and the new value both lead to a byte of equal value.  No branch inside a round: a byte
         //     that has nothing to add reads itself and writes back what it held
-        for (;;) {
-            unsigned int changed = 0;
-            for (unsigned int r = 0; r < rows; ++r) {
+        //     A row (64 bytes) in which nothing was added in a round is settled for good — literals and bytes in front of the chunk never
+        //     change — and is left out of the later rounds
+        for (unsigned int live = rows >= 32u ? ~0u : (1u << rows) - 1u; live != 0;) {
+            unsigned int next = 0;
+            for (unsigned int todo = live; todo != 0; todo &= todo - 1u) {
+                const unsigned int r = (unsigned int)__builtin_ctz(todo);
                 const unsigned int bb = r * 64u + (unsigned int)lane;
                 const unsigned int d = C.dist[bb];
-                const bool inside = d != 0 && d <= bb;
-                const unsigned int d2 = C.dist[inside ? bb - d : bb];
-                const bool add = inside && d2 != 0;
-                C.dist[bb] = (unsigned short)(add ? d + d2 : d);
-                changed |= add ? 1u : 0u;
+                const bool inside = d - 1u < bb;                       // 1 <= d <= bb
+                const unsigned int d2 = C.dist[bb - (inside ? d : 0u)];
+                const unsigned int add = inside ? d2 : 0u;
+                C.dist[bb] = (unsigned short)(d + add);
+                next |= __ballot(add != 0) != 0ull ? 1u << r : 0u;
             }
-            if (!__any(changed != 0)) break;
+            live = next;
         }
-        // (e) the match bytes: from a literal of this chunk, or from text stored by an earlier chunk (eight rows' gathers asked for together)
+        // (e) the match bytes: from a literal of this chunk, or from text stored by an earlier chunk (eight rows' gathers asked for together).
+        //     The gathers read what the chunk before stored: same wave, same L1 — the stores must have left first
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         for (unsigned int r0 = 0; r0 < rows; r0 += 8) {
             unsigned int dd[8];
             unsigned char far[8];
@@ -790,7 +868,7 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
                 if (r0 + q < rows) {
                     const unsigned int bb = (r0 + q) * 64u + (unsigned int)lane;
                     const unsigned int d = dd[q];
-                    const unsigned char near = C.text[a0 + (d <= bb ? bb - d : bb)];      // (d = 0: the byte itself)
+                    const unsigned char near = C.text[a0 + bb - (d <= bb ? d : 0u)];      // (d = 0: the byte itself)
                     C.text[a0 + bb] = d > bb ? far[q] : near;
                 }
         }
@@ -807,9 +885,6 @@ __global__ __launch_bounds__(64) void bed_resolve_kernel(const InfPiece *__restr
                 }
             }
         }
-        // the next chunk gathers from what was just stored: same wave, same L1 — the stores must have left first
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         out += n_bytes;
         lit_pos += n_lits;
         first += (unsigned int)n_take;
