@@ -517,7 +517,7 @@ __device__ __forceinline__ int inf2_decode(InfBits2 &b, InfRing &ring, const Inf
 struct InfShared2 {
     InfTables2 T;
     InfRing ring;
-    unsigned int rec[8][INF_LANES];             // the sequence records of the last (at most eight) turns, stored together at the next service
+    unsigned int rec[16][INF_LANES];            // a ring of the lane's latest sequence records: they leave eight at a time, as one whole 32-byte sector
 };
 
 // phase 1.  status: as bed_inflate_kernel (0, or piece index << 8 | code of the first bad block); meta[i].err repeats the code per block
@@ -548,29 +548,26 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
     int err = 0, last = 0;
     unsigned int turn = 0;
     unsigned char lengths[INF_MAXL + INF_MAXD];
+    // (n_stored is a multiple of 8 while the block lasts: record k sits in slot k mod 16, a flush takes the eight oldest — an aligned
+    //  32-byte piece of the stream, written once; round 6 first stored whatever was staged every eight turns, eight dwords from the
+    //  first staged record on: 1.6 x the bytes, every sector written twice)
+    auto store8 = [&]() {
+        const unsigned int s0 = n_stored & 8u;
+        uint4 a, c;
+        a.x = S.rec[s0 + 0][lane]; a.y = S.rec[s0 + 1][lane]; a.z = S.rec[s0 + 2][lane]; a.w = S.rec[s0 + 3][lane];
+        c.x = S.rec[s0 + 4][lane]; c.y = S.rec[s0 + 5][lane]; c.z = S.rec[s0 + 6][lane]; c.w = S.rec[s0 + 7][lane];
+        *reinterpret_cast<uint4 *>(seq + n_stored) = a;
+        *reinterpret_cast<uint4 *>(seq + n_stored + 4) = c;
+        n_stored += 8;
+        n_staged -= 8;
+    };
     auto record = [&](unsigned int rec) {
-        if (n_staged == 8u) {                                         // (never between two services of the symbol loop: stored-block and header paths)
-            uint4 a, c;
-            a.x = S.rec[0][lane]; a.y = S.rec[1][lane]; a.z = S.rec[2][lane]; a.w = S.rec[3][lane];
-            c.x = S.rec[4][lane]; c.y = S.rec[5][lane]; c.z = S.rec[6][lane]; c.w = S.rec[7][lane];
-            memcpy(seq + n_stored, &a, 16);
-            memcpy(seq + n_stored + 4, &c, 16);
-            n_stored += 8;
-            n_staged = 0;
-        }
-        S.rec[n_staged][lane] = rec;
+        if (n_staged == 16u) store8();                                // (never between two services of the symbol loop: stored-block and header paths)
+        S.rec[(n_stored + n_staged) & 15u][lane] = rec;
         n_staged += 1;
     };
     auto flush = [&]() {
-        if (n_staged) {                                               // eight dwords whatever is staged: what lies behind the staged ones is overwritten later
-            uint4 a, c;
-            a.x = S.rec[0][lane]; a.y = S.rec[1][lane]; a.z = S.rec[2][lane]; a.w = S.rec[3][lane];
-            c.x = S.rec[4][lane]; c.y = S.rec[5][lane]; c.z = S.rec[6][lane]; c.w = S.rec[7][lane];
-            memcpy(seq + n_stored, &a, 16);
-            memcpy(seq + n_stored + 4, &c, 16);
-            n_stored += n_staged;
-            n_staged = 0;
-        }
+        if (n_staged >= 8u) store8();
         if (lw_at) { memcpy(lit_end - lw_at, &lw_done, 8); lw_at = 0; }
     };
     auto literal = [&](unsigned int byte) {
@@ -719,6 +716,10 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
     if (!err) {
         if (run) record(inf2_record(run, true, 3u, 1u));
         flush();
+        if (n_staged >= 8u) store8();
+        for (unsigned int k = 0; k < n_staged; ++k) seq[n_stored + k] = S.rec[(n_stored + k) & 15u][lane];      // the last, incomplete piece
+        n_stored += n_staged;
+        n_staged = 0;
         if (n_lit & 7u) memcpy(lit_end - ((n_lit + 7u) & ~7u), &lw, 8);
     }
     meta[i] = InfTokMeta{n_stored, n_lit, (unsigned int)err, 0u};
