@@ -165,17 +165,72 @@ __device__ __forceinline__ bool dev_parse_int(const uint8_t *p, uint32_t n, long
     return true;
 }
 
-// (3) one thread per line
-__global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restrict__ b, uint64_t n, const uint32_t *__restrict__ line_start,
-                                                        uint32_t n_lines, uint64_t row0, uint64_t slab_file_off, BedOut o) {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= n_lines) return;
-    const uint64_t row = row0 + li;
-    const uint8_t *p = b + line_start[li];
-    const uint8_t *end = b + n;
-    // the line is walked once, to its end: a bedMethyl row has exactly 18 tab-separated columns (dataload.py:15-34: the reference
-    // reads the file against a fixed 18-column schema), so every tab is counted; the bounds of the six fields that matter are kept
-    // in registers (fields count from 0)
+// bit k of the result: byte k of the eight bytes (lo, hi) equals the byte repeated in `cccc`.  Exact for every byte value: the byte-wise
+// difference is zero <=> its low seven bits are zero (0x80 - them keeps bit 7, no borrow between bytes) and its bit 7 is clear; the
+// eight marks (0x80 per byte) are weighted 1, 2, 4 ... 128 and summed by two v_dot4_u32_u8
+__device__ __forceinline__ uint32_t bytes_equal_mask8(uint32_t lo, uint32_t hi, uint32_t cccc) {
+    const uint32_t t0 = lo ^ cccc, t1 = hi ^ cccc;
+    const uint32_t z0 = (0x80808080u - (t0 & 0x7F7F7F7Fu)) & ~t0 & 0x80808080u;
+    const uint32_t z1 = (0x80808080u - (t1 & 0x7F7F7F7Fu)) & ~t1 & 0x80808080u;
+    return __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false) >> 7;
+}
+
+// The fields of one line, as byte offsets from its first byte: b/e of the six columns that are read (1 contig, 2 start, 4 mod code,
+// 6 strand, 10 N_valid_cov, 11 percent; numbered from 0 here) and the number of tab-separated fields up to the end of the line.
+struct BedFields { uint32_t b0, e0, b1, e1, b3, e3, b5, e5, b9, e9, b10, e10, nf; };
+
+// The line's tabs WITHOUT walking it byte by byte (round 6: the walk — ~80 dependent byte loads per line, a dozen instructions each —
+// was two thirds of this kernel, and with the inflate kernels no longer waiting on memory beside it, this kernel became the largest
+// consumer of the GPU in a from-files run): the line is loaded in pieces of 16 bytes (unaligned 16-byte loads), every piece gives 16
+// bits "is a tab" and 16 bits "is a newline", the first newline ends the line, and the tabs below it are taken out of a 128-bit mask one
+// by one.  false: no newline within 128 bytes (bed_split_walk does such lines).
+__device__ __forceinline__ bool bed_split_masks(const uint8_t *__restrict__ p, uint64_t avail, BedFields &f) {
+    const uint32_t want = avail < 128 ? (uint32_t)avail : 128u;
+    unsigned long long tab[2] = {0, 0}, nl[2] = {0, 0};
+    bool open = true;                                                   // no newline seen yet
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!__any(open && 16u * (unsigned)k < want)) break;            // (wave-uniform)
+        if (open && 16u * (unsigned)k < want) {
+            uint4 q;
+            memcpy(&q, p + 16 * k, 16);                                 // (the text buffers are padded: up to 15 bytes behind the text may be read)
+            const unsigned long long t = bytes_equal_mask8(q.x, q.y, 0x09090909u) | (bytes_equal_mask8(q.z, q.w, 0x09090909u) << 8);
+            const unsigned long long e = bytes_equal_mask8(q.x, q.y, 0x0A0A0A0Au) | (bytes_equal_mask8(q.z, q.w, 0x0A0A0A0Au) << 8);
+            tab[k >> 2] |= t << (16 * (k & 3));
+            nl[k >> 2] |= e << (16 * (k & 3));
+            open = e == 0;
+        }
+    }
+    // bytes behind the text are not the line's
+    if (want < 64) { const unsigned long long m = (1ull << want) - 1; nl[0] &= m; nl[1] = 0; }
+    else if (want < 128) nl[1] &= (1ull << (want - 64)) - 1;
+    uint32_t end;
+    if (nl[0]) end = (uint32_t)__builtin_ctzll(nl[0]);
+    else if (nl[1]) end = 64u + (uint32_t)__builtin_ctzll(nl[1]);
+    else if (avail <= 128) end = want;                                  // the last line of the text, without a newline
+    else return false;
+    if (end < 64) { tab[0] &= (1ull << end) - 1; tab[1] = 0; }
+    else if (end < 128) tab[1] &= (1ull << (end - 64)) - 1;
+    f.nf = (uint32_t)__popcll(tab[0]) + (uint32_t)__popcll(tab[1]) + 1u;
+    f.b0 = 0; f.e0 = f.b1 = f.e1 = f.b3 = f.e3 = f.b5 = f.e5 = f.b9 = f.e9 = f.b10 = f.e10 = 0;
+    if (f.nf < 12) return true;                                         // (fewer than eleven tabs: the caller refuses the line)
+    uint32_t t[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        if (tab[0]) { t[k] = (uint32_t)__builtin_ctzll(tab[0]); tab[0] &= tab[0] - 1; }
+        else { t[k] = 64u + (uint32_t)__builtin_ctzll(tab[1]); tab[1] &= tab[1] - 1; }
+    }
+    f.e0 = t[0];
+    f.b1 = t[0] + 1; f.e1 = t[1];
+    f.b3 = t[2] + 1; f.e3 = t[3];
+    f.b5 = t[4] + 1; f.e5 = t[5];
+    f.b9 = t[8] + 1; f.e9 = t[9];
+    f.b10 = t[9] + 1; f.e10 = t[10];
+    return true;
+}
+
+// the same by walking the line (lines of more than 128 bytes)
+__device__ __forceinline__ void bed_split_walk(const uint8_t *__restrict__ p, const uint8_t *__restrict__ end, BedFields &f) {
     uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0, b3 = 0, e3 = 0, b5 = 0, e5 = 0, b9 = 0, e9 = 0, b10 = 0, e10 = 0;
     uint32_t nf = 0, at = 0, start = 0;
     for (;;) {
@@ -196,6 +251,23 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
         }
         ++at;
     }
+    f = BedFields{b0, e0, b1, e1, b3, e3, b5, e5, b9, e9, b10, e10, nf};
+}
+
+// (3) one thread per line
+__global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restrict__ b, uint64_t n, const uint32_t *__restrict__ line_start,
+                                                        uint32_t n_lines, uint64_t row0, uint64_t slab_file_off, BedOut o) {
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_lines) return;
+    const uint64_t row = row0 + li;
+    const uint8_t *p = b + line_start[li];
+    const uint8_t *end = b + n;
+    // a bedMethyl row has exactly 18 tab-separated columns (dataload.py:15-34: the reference reads the file against a fixed 18-column
+    // schema), so every tab of the line is counted
+    BedFields f;
+    if (!bed_split_masks(p, n - line_start[li], f)) bed_split_walk(p, end, f);
+    const uint32_t b0 = f.b0, e0 = f.e0, b1 = f.b1, e1 = f.e1, b3 = f.b3, e3 = f.e3, b5 = f.b5, e5 = f.e5, b9 = f.b9, e9 = f.e9, b10 = f.b10, e10 = f.e10;
+    const uint32_t nf = f.nf;
     // ("\r\n" line ends: the '\r' can only sit in the eighteenth field, which is not read)
     uint32_t err = E_NONE;
     if (nf != 18) err = E_COLUMNS;
