@@ -424,7 +424,7 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
     tmp = keep_dir or tempfile.mkdtemp(prefix="nm_bench_cli1g_", dir=base)
     os.makedirs(tmp, exist_ok=True)
     try:
-        spec = synth.config("cfg5") if total_bp == 1_000_000_000 else synth.SynthSpec(
+        spec = synth.config("cfg5") if total_bp == 1_000_000_000 else synth.config("cfg3") if total_bp == 100_000_000 else synth.SynthSpec(
             n_contigs=max(8, total_bp // 100_000), total_bp=total_bp, n_bins=max(2, total_bp // 2_000_000), mod_types=("a", "m"), seed=1)
         mg = synth.make_metagenome(spec)
         t0 = time.perf_counter()
@@ -510,6 +510,30 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
             shutil.rmtree(tmp, ignore_errors=True)
 
 
+def run_files_extra(device, log_fn):
+    """The from-FILES leg of the DEFAULT line (round 6): BASELINE cfg 3 — 100 Mbp, 1000 contigs, 50 bins, 6mA + 5mC: 1e8 pileup rows — as
+    assembly.fasta + pileup.bed.gz + .tbi + contig_bin.tsv written once to a tmpfs (outside the timed process), then ONE cold
+    `python -m nanomotif_amd motif_discovery` process and a second one: wall clock, the phases the CLI records, and the
+    bin-motifs.tsv rows of eight seeded bins against the oracle pipeline.  (`--extras cli1g` is the same at 1 Gbp: 15 GB of files,
+    three minutes of writing — opt-in.)"""
+    full = run_cli1g_extra(device, log_fn, total_bp=100_000_000, parity_bins=8)
+    legs = full.get("legs", {})
+    cold, again = legs.get("cold", {}), legs.get("again", {})
+    out = {"workload": "BASELINE cfg 3 as FILES: 100 Mbp FASTA + pileup.bed.gz (bgzip, tabix index) + contig_bin.tsv on a tmpfs, page cache, one cold "
+                       "`python -m nanomotif_amd motif_discovery` process (interpreter, HIP runtime, parsers, pre-filters, search, writers)",
+           "total_bp": full.get("total_bp"), "rows": full.get("rows"), "bed_text_bytes": full.get("bed_text_bytes"), "gz_bytes": full.get("gz_bytes"),
+           "fasta_bytes": full.get("fasta_bytes"), "files_written_in_s": full.get("write_s"), "size_note": full.get("size_note"),
+           "wall_s": cold.get("wall_s"), "wall_s_second_process": again.get("wall_s"), "phases": cold.get("phases"), "rates": cold.get("rates"),
+           "the_wall_is": cold.get("the_wall_is"), "motif_rows": cold.get("motif_rows"), "both_runs_byte_equal": full.get("both_runs_byte_equal")}
+    for leg in (cold, again):
+        if "error" in leg:
+            out["error"] = leg["error"]
+    par = full.get("parity") or {}
+    out["parity"] = {"bins": len(par.get("bins", [])), "byte_equal_to_the_oracle_pipeline": par.get("byte_equal_to_the_oracle_pipeline"),
+                     "oracle_rows": par.get("oracle_rows"), "oracle_s": par.get("oracle_s")}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -531,7 +555,7 @@ def main():
     ap.add_argument("--cooldown", type=float, default=0.0, help="seconds of idle GPU before the warmup steps")
     ap.add_argument("--force-allreduce", action="store_true", help="debug: run the C-ABI all-reduce step even with one rank (RCCL world of 1)")
     ap.add_argument("--hbm-round-steps", type=int, default=20, help="extra launches of a greedy round for the HBM-bound roofline (0: skip)")
-    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes (auto: those that apply; none), the opt-in cli (cfg 3 as FILES, plain and bgzip: writes ~9 GB to a tmpfs, four CLI processes) and the opt-in cli1g (the CLI at 1 Gbp from FASTA + .bed.gz + .tbi: ~16 GB on a tmpfs, minutes of writing)")
+    ap.add_argument("--extras", default="auto", help="comma list of extra measurements of the cfg5 run: e2e,cfg5_all,weak,two_lanes,files (auto: those that apply; none; files = BASELINE cfg 3 from FASTA + .bed.gz + .tbi through one cold CLI process, N = 1 only), the opt-in cli (cfg 3 as FILES, plain and bgzip: writes ~9 GB to a tmpfs, four CLI processes) and the opt-in cli1g (the CLI at 1 Gbp from FASTA + .bed.gz + .tbi: ~16 GB on a tmpfs, minutes of writing)")
     ap.add_argument("--cli-bp", type=int, default=100_000_000, help="size of the file-to-bin-motifs.tsv extra (cfg 3: 100 Mbp = 7.8 GB of bedMethyl text)")
     ap.add_argument("--cli1g-bp", type=int, default=1_000_000_000, help="size of the opt-in cli1g extra (the CLI on FASTA + .bed.gz + .tbi at the headline size; "
                     "falls back to the largest size the tmpfs / cgroup holds and says which)")
@@ -619,7 +643,7 @@ def main():
         mine = np.arange(len(mg.names))
     else:
         mine = assign_contigs(mg.lengths, world, bins=mg.bin_names)[rank]
-    extras = {"e2e", "cfg5_all", "weak", "two_lanes"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
+    extras = {"e2e", "cfg5_all", "weak", "two_lanes", "files"} if args.extras == "auto" else set(x for x in args.extras.split(",") if x and x != "none")
     if args.workload != "cfg5" or weak:
         extras = set()
     if world == 1:
@@ -628,6 +652,7 @@ def main():
         extras.discard("cfg5_all")
         extras.discard("cli")
         extras.discard("cli1g")
+        extras.discard("files")
 
     if args.workload == "e2e":
         sizes = {}
@@ -1086,6 +1111,12 @@ def main():
                                       "value": sum(t[0] for t in tot) * args.steps / el, "unit": "motif-sites/s", "ms_per_step": el / args.steps * 1e3}
         eng_w.close()
 
+    try:
+        if "files" in extras and rank == 0:
+            result["e2e_files"] = run_files_extra(device, log)
+    except Exception as exc:
+        log(f"extra 'files' failed: {exc!r}")
+        extra_errors["files"] = repr(exc)
     try:
         if "cli" in extras and rank == 0:
             result["cli"] = run_cli_extra(device, log, args.cli_bp)
