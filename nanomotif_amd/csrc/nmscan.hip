@@ -1060,7 +1060,9 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (laned || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
         else HIP_TRY(hipEventSynchronize(c->copy_done));
     }
-    if (!spec && !by_kernels) HIP_TRY(hipMemsetAsync(out, 0, clear_bytes, sst));
+    // (NM_SCORE_PROBE, timing probes only — tools/gpu_step_gap.sh: 1 = the clear left out (counts are garbage), 2 = no event pair around the kernel)
+    static const int score_probe = getenv("NM_SCORE_PROBE") ? atoi(getenv("NM_SCORE_PROBE")) : 0;
+    if (!spec && !by_kernels && !(score_probe & 1)) HIP_TRY(hipMemsetAsync(out, 0, clear_bytes, sst));
     // ---- launch
     ScoreArgs a{};
     a.seq = Planes{c->dH, c->dL, c->dV, c->d_needs_v};
@@ -1103,10 +1105,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
     const bool fuse = n_active == 2 && shape.light && lit;
 
-    if (timed_launch && !spec) HIP_TRY(hipEventRecord(e0, sst));
+    if (timed_launch && !spec && !(score_probe & 2)) HIP_TRY(hipEventRecord(e0, sst));
     if (n_prog) launch_score(a, gx, shape, sst);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
-    if (timed_launch) HIP_TRY(hipEventRecord(e1, sst));
+    if (timed_launch && !(score_probe & 2)) HIP_TRY(hipEventRecord(e1, sst));
     if (by_kernels && (spec || via_stage)) {
         rc = stage_out(sst, out, hs + off_counts, spec ? stage_end - off_counts : out_bytes);
         if (rc) return rc;
