@@ -198,6 +198,7 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, hos
     t0 = time.perf_counter()
     engine.upload_assembly_device([mg.names[i] for i in mine], lengths, [mg.bin_names[i] for i in mine], ascii_all.data_ptr(),
                                   bin_names=bins)
+    t["upload_assembly_s"] = time.perf_counter() - t0
     slot_of = (C.c_int32 * 8)(*([-1] * 8))
     canon = (C.c_uint8 * 8)(*([0] * 8))
     for mt in mg.spec.mod_types:
@@ -208,9 +209,11 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, hos
     n = int(cat["position"].numel())
     n_kept, n_conf = C.c_uint64(0), C.c_uint64(0)
     vp = lambda x: C.c_void_p(x.data_ptr())
+    t1 = time.perf_counter()
     _lib.check(engine.lib.nm_ingest_pileup(engine.ctx, n, vp(cat["contig"]), vp(cat["position"]), vp(cat["mod"]), vp(cat["strand"]),
                                            vp(cat["frac"]), vp(cat["nvalid"]), slot_of, canon, 0.3, 0.7, 1,
                                            C.byref(n_kept), C.byref(n_conf)))
+    t["ingest_call_s"] = time.perf_counter() - t1
     k = n_conf.value
     engine._n_confident = int(k)
     kept = np.zeros((len(mine), 8), dtype=np.uint32)
