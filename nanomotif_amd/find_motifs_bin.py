@@ -360,14 +360,20 @@ def discover(cfg: ProcessorConfig, filtered: FilteredPileup, scorer: LockstepSco
     # post-processing walks every one of them (0.05 s of a 0.3 s search at 1 Gbp); reference counting still frees the rest
     gc_was_on = gc.isenabled()
     gc.disable()
+    files = DeferredFiles()                  # (the per-task files of a run with --out: written at the end, see the class)
     try:
-        return _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
+        return _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor, files)
     finally:
-        if gc_was_on:
-            gc.enable()
+        # also when a search or a post-processing step raised: what the tasks that had finished put aside — precleanup tables, PSSMs,
+        # graphs — is on disk for whoever looks into the failed run, as with the reference's per-task writes (round-5 advisor)
+        try:
+            files.flush()
+        finally:
+            if gc_was_on:
+                gc.enable()
 
 
-def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor):
+def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor, files):
     import time
     store = window_store if window_store is not None else HostWindowStore()
     t_mark = time.perf_counter()
@@ -379,7 +385,6 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor)
         timings[name] = timings.get(name, 0.0) + now - t_mark
         t_mark = now
     planned = []
-    files = DeferredFiles()                  # (the per-task files of a run with --out: written at the end, see the class)
     bins = {}
     for c, b in cfg.bin_contig.items():
         bins.setdefault(b, []).append(c)

@@ -138,6 +138,18 @@ def find_motifs_bin(args):
                 plan_box["error"] = e
         plan_box["thread"] = threading.Thread(target=make_plan, name="nm-bed-plan")
         plan_box["thread"].start()
+    def drop_plan():
+        """An error path between the plan thread's start and its use: the thread is waited for (it is not a daemon: the process would
+        wait for its half-second walk at exit anyway) and the plan's mapping of the pileup released now, not by a finaliser."""
+        th = plan_box.pop("thread", None)
+        if th is not None:
+            th.join()
+        made = plan_box.pop("plan", None)
+        if made is not None:
+            made.close()
+        if "error" in plan_box:
+            log.debug(f"the pre-planned indexed parse failed (the regular path reports the cause): {plan_box.pop('error')!r}")
+
     log.info("Loading assembly")
     # A plain-text assembly is parsed ON THE GPU (nm_fasta_parse_device: the host only moves the file through pinned slabs; the
     # bases never become a host array, the planes are packed from the parser's device buffer); a .gz assembly and
@@ -156,6 +168,7 @@ def find_motifs_bin(args):
         starter.join()
         if "eng" in started:
             started["eng"].close()
+        drop_plan()
         raise
     lap("assembly_s")
     TIMINGS["assembly_parser"] = "device" if device_fasta else "host"
@@ -170,6 +183,7 @@ def find_motifs_bin(args):
                           verbose=args.verbose, log_dir=args.out + "/logs", seed=args.seed, output_dir=args.out)
     bgzip = cfg.pileup_path.endswith(".gz")
     if bgzip and not os.path.exists(cfg.pileup_path + ".tbi"):
+        drop_plan()
         raise FileNotFoundError(f"Tabix index for {cfg.pileup_path} not found.")     # find_motifs_bin.py:383-384
     t0 = time.perf_counter()
     # native reader, raw rows kept in native memory; a bgzip pileup is read through its tabix index: only the blocks
@@ -182,8 +196,10 @@ def find_motifs_bin(args):
     table = None
     plan = None
     if "thread" in plan_box:
-        plan_box["thread"].join()
-        plan = plan_box.get("plan")
+        plan_box.pop("thread").join()
+        plan = plan_box.pop("plan", None)
+        if "error" in plan_box:
+            log.debug(f"the pre-planned indexed parse failed (the regular path reports the cause): {plan_box.pop('error')!r}")
         if plan is not None and (wanted is None or list(plan.contigs) != list(wanted)):
             plan.close()                         # the assembly lacks some of the binned contigs: plan again for the ones it holds
             plan = None
@@ -191,8 +207,14 @@ def find_motifs_bin(args):
             TIMINGS["pileup_plan_s_on_a_thread"] = plan.seconds
     if os.environ.get("NANOMOTIF_HOST_PARSER") != "1" and not any(fasta.ALIAS_SEP in c for c in cfg.bin_contig):
         try:
-            table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0,
-                                            contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None, plan=plan)
+            try:
+                table = pileup_mod.DevicePileup(eng, cfg.pileup_path, threads=max(args.threads, 0) if args.threads > 1 else 0,
+                                                contigs=wanted, index_path=cfg.pileup_path + ".tbi" if bgzip else None, plan=plan)
+            except BaseException:
+                if plan is not None:             # a final error of the parser: the plan's mapping goes back now
+                    plan.close()
+                    plan = None
+                raise
             how = (f", tabix-indexed: {table.bytes_inflated / 1e6:.1f} MB inflated for {len(wanted)} contigs" if table.indexed else "")
             log.info(f"pileup: {len(table):,} rows parsed on the device ({time.perf_counter() - t0:.1f}s, {table.seconds_reading:.1f}s of it "
                      f"moving the file{how})")
