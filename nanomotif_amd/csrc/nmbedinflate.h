@@ -162,7 +162,10 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
     const int lane = threadIdx.x;
     const unsigned int i = blockIdx.x * INF_LANES + lane;
     if (i >= n_pieces) return;
-    if (only_full && inf_meta_err(only_full, i) != 21u) return;         // (two-phase inflate: the blocks phase 1 gave up, nothing else)
+    if (only_full) {                                                    // (two-phase inflate: the blocks phase 1 gave up — INF2_FULL, INF2_WIDE —, nothing else)
+        const unsigned int gave_up = inf_meta_err(only_full, i);
+        if (gave_up != 21u && gave_up != 22u) return;
+    }
     const InfPiece pc = pieces[i];
     const bool partial = pc.skip != 0 || pc.take != pc.out_len;
     InfBits b{in + pc.in_off, 0ull, 0, 0ull};
@@ -387,10 +390,10 @@ __device__ __forceinline__ unsigned int inf2_record(unsigned int lit, bool no_ma
     return lit | (no_match ? 256u : 0u) | ((len - 3u) << 9) | ((dist - 1u) << 17);
 }
 
-struct InfRing { unsigned int w[64][INF_LANES]; };                 // 64 dwords of compressed bytes per lane, [word][lane]
+struct InfRing { unsigned int w[32][INF_LANES]; };                 // 32 dwords of compressed bytes per lane, [word][lane]
 
 // bit reader of phase 1: the stream arrives in pieces of 32 bytes — two 16-byte loads issued at EVERY service call (every eight turns of
-// the wave), written into the ring at the next one, when they have long arrived, provided the ring had room for them when they were asked
+// the wave), written into the ring (32 dwords per lane) at the next one, when they have long arrived, provided the ring had room for them when they were asked
 // for (otherwise the same bytes are asked for again: no state hangs on a condition, so the loads stay in flight across the turns instead
 // of being waited for on the spot) — and is consumed a dword at a time; the dword the next refill will take is read from the ring one
 // refill ahead, so that no turn waits for it either
@@ -405,13 +408,13 @@ struct InfBits2 {
     __device__ __forceinline__ void land(InfRing &r, int lane) {
         if (room) {
             const unsigned int f = fill;
-            r.w[(f + 0) & 63][lane] = q0.x; r.w[(f + 1) & 63][lane] = q0.y; r.w[(f + 2) & 63][lane] = q0.z; r.w[(f + 3) & 63][lane] = q0.w;
-            r.w[(f + 4) & 63][lane] = q1.x; r.w[(f + 5) & 63][lane] = q1.y; r.w[(f + 6) & 63][lane] = q1.z; r.w[(f + 7) & 63][lane] = q1.w;
+            r.w[(f + 0) & 31][lane] = q0.x; r.w[(f + 1) & 31][lane] = q0.y; r.w[(f + 2) & 31][lane] = q0.z; r.w[(f + 3) & 31][lane] = q0.w;
+            r.w[(f + 4) & 31][lane] = q1.x; r.w[(f + 5) & 31][lane] = q1.y; r.w[(f + 6) & 31][lane] = q1.z; r.w[(f + 7) & 31][lane] = q1.w;
             fill = f + 8;
         }
     }
     __device__ __forceinline__ void ask() {
-        room = fill - rd <= 56u;
+        room = fill - rd <= 24u;
         const uint4 *p = src + (fill >> 2);
         q0 = p[0]; q1 = p[1];
     }
@@ -424,9 +427,9 @@ struct InfBits2 {
     __device__ __forceinline__ void start(InfRing &r, int lane, unsigned int skip) {
         fill = 0; rd = 0; buf = 0; cnt = 0;
         ask();
-        for (int k = 0; k < 4; ++k) service(r, lane);                // 32 dwords in the ring, 8 on their way
+        for (int k = 0; k < 3; ++k) service(r, lane);                // 24 dwords in the ring, 8 on their way
         rd = skip >> 2;
-        ahead = r.w[rd & 63][lane];
+        ahead = r.w[rd & 31][lane];
         if (skip & 3u) { refill(r, lane); buf >>= 8 * (skip & 3u); cnt -= 8 * (int)(skip & 3u); }
     }
     __device__ __forceinline__ void refill(InfRing &r, int lane) {
@@ -437,7 +440,7 @@ struct InfBits2 {
             service(r, lane);
             if (rd == fill) service(r, lane);
         }
-        ahead = r.w[rd & 63][lane];
+        ahead = r.w[rd & 31][lane];
     }
     __device__ __forceinline__ unsigned int get(int n, InfRing &r, int lane) {       // n <= 16
         if (cnt < 32) refill(r, lane);
@@ -465,19 +468,43 @@ __device__ __forceinline__ unsigned int inf2_code_length(unsigned int x, const I
     return 1u + (unsigned int)__popc(signs & 0x7FFFu);
 }
 
+// Phase 1 keeps its LDS at 45 KB per workgroup (a ring of 32 dwords, not 64): three workgroups — a slab is 768 of them, three per CU —
+// leave 28 KB of a CU's LDS to six phase-2 waves of the slab before, so the two phases of neighbouring slabs run side by side.  The
+// literal / length table holds INF2_LSYM codes: all 288 (a table of 224 would make room for two more phase-2 waves, but every block
+// in the FIXED code — the short last block of most files — would then go through bed_inflate_kernel, ~40 ms for however few blocks;
+// the INF2_WIDE path below stays for whoever shrinks the table).
+constexpr int INF2_LSYM = 288;
+constexpr unsigned int INF2_WIDE = 22;            // InfTokMeta.err: more than INF2_LSYM literal / length codes in use (not an error of the stream)
+struct InfSymbols2 {
+    unsigned char lo[INF2_LSYM][INF_LANES];
+    unsigned int hi[INF2_LSYM / 32][INF_LANES];
+    __device__ __forceinline__ void clear(int lane) {
+#pragma unroll
+        for (int w = 0; w < INF2_LSYM / 32; ++w) hi[w][lane] = 0;
+    }
+    __device__ __forceinline__ void put(int idx, int lane, int sym) {
+        lo[idx][lane] = (unsigned char)sym;
+        if (sym & 256) hi[idx >> 5][lane] |= 1u << (idx & 31);
+    }
+    __device__ __forceinline__ int get(int idx, int lane) const { return (int)lo[idx][lane] | (int)(((hi[idx >> 5][lane] >> (idx & 31)) & 1u) << 8); }
+};
+
 struct InfTables2 {
     unsigned short count[16][INF_LANES];         // codes per length while a table is built
     unsigned int ltab[16][INF_LANES], dtab[16][INF_LANES];
-    InfSymbols lsym;
+    InfSymbols2 lsym;
     InfDistSymbols dsym;
 };
 
 // canonical code from code lengths; > 0: incomplete, < 0: over-subscribed (zlib contrib/puff: construct)
+// (*too_wide: more codes in use than the symbol table holds — nothing is written then)
 template <typename Symbols>
-__device__ int inf2_construct(unsigned short (*count)[INF_LANES], unsigned int (*tab)[INF_LANES], Symbols &symbol, InfCanon &canon, const unsigned char *length, int n, int lane) {
+__device__ int inf2_construct(unsigned short (*count)[INF_LANES], unsigned int (*tab)[INF_LANES], Symbols &symbol, InfCanon &canon, const unsigned char *length, int n, int lane,
+                              int capacity, bool *too_wide) {
     symbol.clear(lane);
     for (int len = 0; len <= 15; ++len) count[len][lane] = 0;
     for (int s = 0; s < n; ++s) count[length[s]][lane] += 1;
+    if (n - (int)count[0][lane] > capacity) { *too_wide = true; return 0; }
     int left = 1;
     if (count[0][lane] == n) left = 0;                                  // (no code at all: every decode fails, as in puff)
     else
@@ -599,15 +626,17 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
         }
         if (type == 3) { err = 3; break; }
         InfCanon kl, kd;
+        bool wide = false;
         if (type == 1) {                                         // fixed code
             int s = 0;
             for (; s < 144; ++s) lengths[s] = 8;
             for (; s < 256; ++s) lengths[s] = 9;
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < 288; ++s) lengths[s] = 8;
-            inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, 288, lane);
+            inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, 288, lane, INF2_LSYM, &wide);
+            if (wide) { err = (int)INF2_WIDE; break; }                  // (the fixed code uses all 288: such blocks are the single kernel's)
             for (s = 0; s < 30; ++s) lengths[s] = 5;
-            inf2_construct(T.count, T.dtab, T.dsym, kd, lengths, 30, lane);
+            inf2_construct(T.count, T.dtab, T.dsym, kd, lengths, 30, lane, INF_MAXD, &wide);
         } else {                                                 // dynamic code
             const int nlen = (int)b.get(5, ring, lane) + 257, ndist = (int)b.get(5, ring, lane) + 1, ncode = (int)b.get(4, ring, lane) + 4;
             if (nlen > 286 || ndist > 30) { err = 4; break; }
@@ -615,7 +644,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             for (; idx < ncode; ++idx) lengths[INF_CLORDER[idx]] = (unsigned char)b.get(3, ring, lane);
             for (; idx < 19; ++idx) lengths[INF_CLORDER[idx]] = 0;
             InfCanon kc;
-            if (inf2_construct(T.count, T.ltab, T.lsym, kc, lengths, 19, lane) != 0) { err = 5; break; }
+            if (inf2_construct(T.count, T.ltab, T.lsym, kc, lengths, 19, lane, INF2_LSYM, &wide) != 0) { err = 5; break; }
             idx = 0;
             unsigned int hs = 0;
             while (idx < nlen + ndist) {
@@ -637,9 +666,10 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             }
             if (err) break;
             if (lengths[256] == 0) { err = 9; break; }
-            int r = inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, nlen, lane);
+            int r = inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, nlen, lane, INF2_LSYM, &wide);
+            if (wide) { err = (int)INF2_WIDE; break; }
             if (r < 0 || (r > 0 && nlen - T.count[0][lane] != 1)) { err = 10; break; }
-            r = inf2_construct(T.count, T.dtab, T.dsym, kd, lengths + nlen, ndist, lane);
+            r = inf2_construct(T.count, T.dtab, T.dsym, kd, lengths + nlen, ndist, lane, INF_MAXD, &wide);
             if (r < 0 || (r > 0 && ndist - T.count[0][lane] != 1)) { err = 11; break; }
         }
         // The block's symbols, one per turn of the wave.  Straight-line code: a literal / length symbol, then — for every lane, whether its
@@ -659,7 +689,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
                 len = len > 15u ? 15u : len;
                 const unsigned int t = T.ltab[len - 1][lane];
                 unsigned int idx = (t >> 16) + ((x - (t & 0xFFFFu)) >> (15u - len));
-                idx = idx < (unsigned int)INF_MAXL ? idx : 0u;
+                idx = idx < (unsigned int)INF2_LSYM ? idx : 0u;
                 sym = (unsigned int)T.lsym.get((int)idx, lane);
                 b.buf >>= len;
                 b.cnt -= (int)len;
@@ -723,7 +753,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
         if (n_lit & 7u) memcpy(lit_end - ((n_lit + 7u) & ~7u), &lw, 8);
     }
     meta[i] = InfTokMeta{n_stored, n_lit, (unsigned int)err, 0u};
-    if (err && err != (int)INF2_FULL) atomicCAS(status, 0u, (unsigned int)err | (i << 8));
+    if (err && err != (int)INF2_FULL && err != (int)INF2_WIDE) atomicCAS(status, 0u, (unsigned int)err | (i << 8));
 }
 
 // inclusive prefix sum over the 64 lanes of a wave

@@ -158,7 +158,7 @@ int main(int argc, char **argv) {
         double s = 0, l = 0, mx = 0;
         size_t full = 0;
         for (const auto &m : hm) {
-            if (m.err == INF2_FULL) { ++full; continue; }
+            if (m.err == INF2_FULL || m.err == INF2_WIDE) { ++full; continue; }
             s += m.n_seq; l += m.n_lit; mx = std::max(mx, 4.0 * m.n_seq + m.n_lit);
         }
         printf("tokens per block: %.0f sequence records, %.0f literals = %.1f KB (largest %.1f KB) of the %.1f KB region; %zu blocks did not fit and went through bed_inflate_kernel\n",
