@@ -492,6 +492,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor,
                                          (engine.slot_of_mod[state_label(key[1], "merge")] for key, _, _ in planned), reduce=reduce)
                 scorer.rounds += post.batches
                 scorer.candidates += post.candidates
+                timings["post_native_call_s"] = time.perf_counter() - t_mark        # (part of postprocess_s: nm_post_run + the export of its rows)
                 for t, (key, stage_writer, temp_dir) in enumerate(planned):
                     if temp_dir or found.none[t]:
                         write_search_artifacts(key[0], key[1], found.artifacts(t), temp_dir, files)

@@ -29,6 +29,10 @@ int main(int argc, char **argv) {
     const size_t n_distinct = std::min(n_blocks, argc > 2 ? (size_t)atol(argv[2]) : 1024);
     const int reps = argc > 3 ? atoi(argv[3]) : 3;
     const double fraction = argc > 4 ? atof(argv[4]) : 0.625;         // token region per block as a fraction of its text (the library's default)
+    // what the text is: 0 = modkit-like rows; 1 = runs and periodic patterns (period 1 .. 300, run lengths up to 70 000: matches whose
+    // distance is below their length, matches of 258 bytes one after the other); 2 = random bytes (nothing to compress: literal runs far
+    // beyond 255, token regions overflow and the single kernel takes over); 3 = a mixture of all three, block by block
+    const int mode = argc > 5 ? atoi(argv[5]) : 0;
     const size_t bs = 0xFF00;
     // modkit-like rows (the columns and value ranges of nanomotif_amd/synth.py's writer)
     std::string text;
@@ -38,7 +42,19 @@ int main(int argc, char **argv) {
         unsigned long long pos = 0;
         int contig = 0;
         char line[256];
+        auto want_mode = [&]() { return mode == 3 ? (int)((text.size() / bs) % 3) : mode; };
         while (text.size() < n_distinct * bs) {
+            if (want_mode() == 1) {                                    // a run of one pattern
+                const size_t period = 1 + rng() % (rng() % 4 == 0 ? 300 : 12), len = 1 + rng() % (rng() % 8 == 0 ? 70000 : 600);
+                std::string pat(period, 'x');
+                for (auto &ch : pat) ch = (char)('A' + rng() % 20);
+                for (size_t k = 0; k < len; ++k) text.push_back(pat[k % period]);
+                continue;
+            }
+            if (want_mode() == 2) {                                    // noise
+                for (int k = 0; k < 4096; ++k) text.push_back((char)(rng() & 0xFF));
+                continue;
+            }
             pos += 1 + rng() % 3;
             if (pos > 2000000) { pos = rng() % 5; ++contig; }
             const int cov = 10 + (int)(rng() % 40), pct = (int)(rng() % 10000), nmod = cov * pct / 10000;
