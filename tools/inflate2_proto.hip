@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
         std::vector<std::thread> pool;
         for (unsigned t = 0; t < nt; ++t)
             pool.emplace_back([&, t] {
-                std::vector<unsigned char> tmp(compressBound(bs) + 64);
+                std::vector<unsigned char> tmp(2 * bs + 1024);             // (noise in the FIXED code is 9/8 of its size: compressBound() is not enough)
                 for (size_t i = t; i < n_distinct; i += nt) {
                     z_stream zs;
                     memset(&zs, 0, sizeof zs);
@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
                     zs.avail_in = (uInt)bs;
                     zs.next_out = tmp.data();
                     zs.avail_out = (uInt)tmp.size();
-                    deflate(&zs, Z_FINISH);
+                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { printf("deflate of block %zu did not finish\n", i); exit(2); }
                     comp[i].z.assign((const char *)tmp.data(), tmp.size() - zs.avail_out);
                     deflateEnd(&zs);
                 }
@@ -131,6 +131,11 @@ int main(int argc, char **argv) {
             size_t at = 0;
             while (at < bs && a[at] == e[at]) ++at;
             printf("   first difference: block %zu, byte %zu\n", first_bad, at);
+            // the block itself, for a look at it on a host: the deflate stream and the text it must give
+            const std::string &z = comp[first_bad % n_distinct].z;
+            if (FILE *f = fopen("gpurun_out/inflate2_bad_block.deflate", "wb")) { fwrite(z.data(), 1, z.size(), f); fclose(f); }
+            if (FILE *f = fopen("gpurun_out/inflate2_bad_block.text", "wb")) { fwrite(e, 1, bs, f); fclose(f); }
+            if (FILE *f = fopen("gpurun_out/inflate2_bad_block.got", "wb")) { fwrite(a, 1, bs, f); fclose(f); }
         }
         return bad == 0 && status == 0;
     };
