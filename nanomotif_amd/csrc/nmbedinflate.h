@@ -139,8 +139,12 @@ __constant__ unsigned short INF_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33
 __constant__ unsigned char INF_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ unsigned char INF_CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-struct InfTokMeta;                                          // (two-phase inflate, below)
-__device__ __forceinline__ unsigned int inf_meta_err(const InfTokMeta *meta, unsigned int i) { return reinterpret_cast<const unsigned int *>(meta)[4 * (size_t)i + 2]; }
+// what phase 1 of the two-phase inflate (below) leaves per block; INF2_FULL / INF2_WIDE in `err` are not errors of the stream: the block's
+// tokens did not fit its region / it uses more literal-length codes than phase 1's table holds — bed_inflate_kernel inflates such blocks
+struct InfTokMeta {
+    unsigned int n_seq, n_lit, err, pad;
+};
+constexpr unsigned int INF2_FULL = 21, INF2_WIDE = 22;
 
 #ifdef NM_BED_PROBES
 // probe builds (NM_CXXFLAGS=-DNM_BED_PROBES, tools/gpu_r5ac.sh): NM_BED_INFLATE_PROBE = 1: matches are not copied, + 2: literals are not
@@ -152,7 +156,7 @@ __device__ int g_inf_probe = 0;
 // status: 0, or (piece index << 8 | what went wrong) of the first bad block
 __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned char *__restrict__ in, const InfPiece *__restrict__ pieces, unsigned int n_pieces,
                                                                 unsigned char *__restrict__ text, unsigned char *__restrict__ scratch,
-                                                                unsigned int *__restrict__ status, const struct InfTokMeta *__restrict__ only_full) {
+                                                                unsigned int *__restrict__ status, const InfTokMeta *__restrict__ only_full) {
     __shared__ InfTables T;
 #ifdef NM_BED_PROBES
     const int probe = g_inf_probe;
@@ -162,9 +166,9 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
     const int lane = threadIdx.x;
     const unsigned int i = blockIdx.x * INF_LANES + lane;
     if (i >= n_pieces) return;
-    if (only_full) {                                                    // (two-phase inflate: the blocks phase 1 gave up — INF2_FULL, INF2_WIDE —, nothing else)
-        const unsigned int gave_up = inf_meta_err(only_full, i);
-        if (gave_up != 21u && gave_up != 22u) return;
+    if (only_full) {                                                    // (two-phase inflate: the blocks phase 1 gave up, nothing else)
+        const unsigned int gave_up = only_full[i].err;
+        if (gave_up != INF2_FULL && gave_up != INF2_WIDE) return;
     }
     const InfPiece pc = pieces[i];
     const bool partial = pc.skip != 0 || pc.take != pc.out_len;
@@ -368,9 +372,6 @@ __global__ __launch_bounds__(INF_LANES) void bed_inflate_kernel(const unsigned c
 constexpr unsigned int INF2_CAP = 1536;            // text bytes of a chunk of phase 2 (a sequence is at most 254 + 258 bytes)
 constexpr int INF2_ROWS = (int)(INF2_CAP / 64);     // 64-byte rows of a chunk
 
-struct InfTokMeta {                                // per block, written by phase 1 (16 bytes: inf_meta_err reads word 2)
-    unsigned int n_seq, n_lit, err, pad;
-};
 
 // Bytes of a block's token region.  4 bytes per match (>= 3 bytes of text each), 4 per 255 literals that meet no match, 1 per literal,
 // the last literal word written whole: never more than 4/3 of the text + 32.  bedMethyl text needs 0.4 of its size (5 700 records +
@@ -382,7 +383,7 @@ __host__ __device__ inline unsigned int inf2_region_bytes(unsigned int out_len, 
     const unsigned long long want = ((unsigned long long)((double)out_len * fraction) + 64u + 15u) & ~15ull;
     return (unsigned int)(want < worst ? want : worst);
 }
-constexpr unsigned int INF2_FULL = 21;             // InfTokMeta.err: the block's tokens did not fit its region (not an error of the stream)
+
 
 // sequence record: literals in front of the match (0..254; 255 = 255 literals and no match), bit 8 = no match (the tail of a block),
 // match length - 3, distance - 1
@@ -474,7 +475,6 @@ __device__ __forceinline__ unsigned int inf2_code_length(unsigned int x, const I
 // in the FIXED code — the short last block of most files — would then go through bed_inflate_kernel, ~40 ms for however few blocks;
 // the INF2_WIDE path below stays for whoever shrinks the table).
 constexpr int INF2_LSYM = 288;
-constexpr unsigned int INF2_WIDE = 22;            // InfTokMeta.err: more than INF2_LSYM literal / length codes in use (not an error of the stream)
 struct InfSymbols2 {
     unsigned char lo[INF2_LSYM][INF_LANES];
     unsigned int hi[INF2_LSYM / 32][INF_LANES];
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < 288; ++s) lengths[s] = 8;
             inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, 288, lane, INF2_LSYM, &wide);
-            if (wide) { err = (int)INF2_WIDE; break; }                  // (the fixed code uses all 288: such blocks are the single kernel's)
+            if (wide) { err = (int)INF2_WIDE; break; }                  // (never with a table of 288: the fixed code uses them all)
             for (s = 0; s < 30; ++s) lengths[s] = 5;
             inf2_construct(T.count, T.dtab, T.dsym, kd, lengths, 30, lane, INF_MAXD, &wide);
         } else {                                                 // dynamic code

@@ -3,7 +3,7 @@
 // Design (DESIGN.md has the long form):
 //   * Assembly resident in HBM as three bit planes over one padded coordinate space: H, L (the two bits of
 //     the base code, "bit-sliced 2-bit") and V (1 = A/C/G/T inside a contig).  Contigs are grouped by bin and
-//     start on 8192-bp chunk boundaries with >= 64 invalid positions after each one, so a match can never
+//     start on 8192-bp chunk boundaries with >= 96 invalid positions (GAP_BP) after each one, so a match can never
 //     straddle two contigs and a chunk never straddles two bins.
 //   * Per modification type two state planes M / U (methylated, unmethylated; the strand of a row is implied by
 //     the base under it: '+' rows sit on the canonical base, '-' rows on its complement) — 0.5 byte per bp per
@@ -1060,8 +1060,12 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
         if (laned || c->opt_stream_wait) HIP_TRY(hipStreamWaitEvent(sst, c->copy_done, 0));
         else HIP_TRY(hipEventSynchronize(c->copy_done));
     }
-    // (NM_SCORE_PROBE, timing probes only — tools/gpu_step_gap.sh: 1 = the clear left out (counts are garbage), 2 = no event pair around the kernel)
+#ifdef NM_SCORE_PROBES
+    // probe builds only (NM_CXXFLAGS=-DNM_SCORE_PROBES, tools/gpu_step_gap.sh): NM_SCORE_PROBE=1 leaves the clear out (the counts are garbage)
     static const int score_probe = getenv("NM_SCORE_PROBE") ? atoi(getenv("NM_SCORE_PROBE")) : 0;
+#else
+    constexpr int score_probe = 0;                       // (the shipped library has no switch that changes what a call computes)
+#endif
     if (!spec && !by_kernels && !(score_probe & 1)) HIP_TRY(hipMemsetAsync(out, 0, clear_bytes, sst));
     // ---- launch
     ScoreArgs a{};
@@ -1105,10 +1109,10 @@ int score_impl(nm_ctx *c, uint32_t n_cand, const uint32_t *cand_bin, const uint8
     const LaunchShape shape{any_wide, all_compact, lit, light && !c->opt_no_cf, n_active, per_contig};
     const bool fuse = n_active == 2 && shape.light && lit;
 
-    if (timed_launch && !spec && !(score_probe & 2)) HIP_TRY(hipEventRecord(e0, sst));
+    if (timed_launch && !spec) HIP_TRY(hipEventRecord(e0, sst));
     if (n_prog) launch_score(a, gx, shape, sst);   // else nothing resident for this batch: the zeroed table is the answer
     HIP_TRY(hipGetLastError());
-    if (timed_launch && !(score_probe & 2)) HIP_TRY(hipEventRecord(e1, sst));
+    if (timed_launch) HIP_TRY(hipEventRecord(e1, sst));
     if (by_kernels && (spec || via_stage)) {
         rc = stage_out(sst, out, hs + off_counts, spec ? stage_end - off_counts : out_bytes);
         if (rc) return rc;

@@ -1,10 +1,13 @@
 #!/bin/bash
 # what lies between two scoring kernels of the headline step: ms_per_step with the counter clear left out
-# (NM_SCORE_PROBE=1: counts are garbage, the line's own parity leg fails on purpose), without the event pair (2), without both (3)
+# (NM_SCORE_PROBE=1 on a PROBE BUILD of the library, made here with NM_CXXFLAGS=-DNM_SCORE_PROBES and unmade at the end: the
+# counts are garbage, the line's own parity leg fails on purpose)
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/step_gap
+NM_CXXFLAGS=-DNM_SCORE_PROBES python3 -c "from nanomotif_amd import build; build.build()" > gpurun_out/step_gap/build.log 2>&1
+trap 'python3 -c "from nanomotif_amd import build; build.build()" >> gpurun_out/step_gap/build.log 2>&1' EXIT
 for rep in 1 2; do
-  for probe in 0 1 2 3; do
+  for probe in 0 1; do
     NM_SCORE_PROBE=$probe timeout 600 python bench.py --extras none --cpu-bins 0 --steps 200 --warmup 20 > gpurun_out/step_gap/p${probe}_$rep.json 2> gpurun_out/step_gap/p${probe}_$rep.log
     python3 - gpurun_out/step_gap/p${probe}_$rep.json $probe <<'PY'
 import json, sys
