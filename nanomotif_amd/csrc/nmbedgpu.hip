@@ -934,17 +934,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     // ---- bgzip, inflated on the device: per slab the compressed bytes of its blocks (packed, through the pinned ring) ->
     // bed_inflate_kernel -> the same line / field kernels
     if (dev_inflate && !inf_slabs.empty()) {
-        // A PIPELINE of three stages over the slabs (round 5; the stages ran one after the other before: 0.098 s per 3 GiB slab, of
-        // which the inflate kernel is 0.065): (1) host: a slab's compressed bytes -> pinned chunks -> device (copy stream);
-        // (2) inflate stream: bed_inflate_kernel + CRC-32 + end of the last whole line, into one of TWO text buffers; (3) ctx stream:
-        // the line / field kernels.  Slab k+1 is copied and its inflate queued while slab k inflates; slab k is parsed while
-        // slab k+1 inflates (the inflate lanes wait on memory most of the time: the parse kernels run beside them).  Everything a
-        // slab owns on the device exists twice (2 x 3 GiB of text: slabs of 1.5 GiB were 6 % slower, 47 against 50 GB/s — a slab
-        // should fill every lane slot the kernel's LDS tables leave).
+        // A PIPELINE over the slabs (round 5; the stages ran one after the other before: 0.098 s per 3 GiB slab, of which the inflate
+        // kernel was 0.065): (1) a slab's compressed bytes -> pinned chunks -> device (copy stream); (2) its inflate streams: phase 1 into
+        // the slab's token buffer, then phase 2 + CRC-32 + end of the last whole line into one of TWO text buffers; (3) ctx stream: the
+        // line / field kernels.  A slab stays below 4 GiB of text (line starts are 32-bit offsets): 2 x 3 GiB of text buffers (slabs of
+        // 1.5 GiB were 6 % slower — a slab should fill every lane slot phase 1's LDS tables leave: 768 workgroups, three per CU).
         constexpr uint64_t CHUNK = SLAB_BYTES;                        // compressed bytes per pinned buffer
-        uint8_t *d_text[2] = {nullptr, nullptr}, *d_comp[2] = {nullptr, nullptr}, *d_scratch[2] = {nullptr, nullptr}, *d_tok[2] = {nullptr, nullptr};
-        InfPiece *d_pieces[2] = {nullptr, nullptr};
-        InfTokMeta *d_meta[2] = {nullptr, nullptr};
+        uint8_t *d_text[2] = {nullptr, nullptr};
         // Round 6: the blocks are inflated in TWO PHASES (nmbedinflate.h: one lane per block decodes the Huffman stream into tokens, one
         // wave per block turns the tokens into text) unless NM_BED_INFLATE_V1=1 asks for the single kernel of rounds 4 - 5 (A/B).  A
         // block's token region is `token_fraction` of its text (NM_BED_TOKEN_FRACTION; tests shrink it to send blocks down the fallback)
@@ -963,89 +959,99 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             for (size_t i = sl.first; i < sl.last; ++i) tk += inf2_region_bytes((unsigned int)src.pieces[i].out_len, token_fraction);
             max_tok = std::max(max_tok, tk);
         }
-        const int n_buf = inf_slabs.size() > 1 ? 2 : 1;
-        for (int b = 0; b < 2; ++b) {
-            if (b >= n_buf) { d_text[b] = d_text[0]; d_comp[b] = d_comp[0]; d_scratch[b] = d_scratch[0]; d_pieces[b] = d_pieces[0]; d_tok[b] = d_tok[0]; d_meta[b] = d_meta[0]; continue; }
-            HIP_TRY(tmp_alloc((void **)&d_text[b], slab_cap + 128));
-            HIP_TRY(tmp_alloc((void **)&d_comp[b], inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
-            HIP_TRY(tmp_alloc((void **)&d_scratch[b], std::max<size_t>(max_partial, 1) << 16));
-            HIP_TRY(tmp_alloc((void **)&d_pieces[b], max_pieces * sizeof(InfPiece)));
+        // Round 6: the pipeline is one stage deeper.  What a slab needs BEFORE its text can be written — its compressed bytes on the device,
+        // its piece table, its tokens (phase 1) — exists three times (n_cmp) and is produced by a STAGING THREAD that runs up to two slabs
+        // ahead of the slab being parsed; what needs the text buffer (phase 2 / the single kernel, CRC-32, the end of the last line) is
+        // queued by the calling thread once the parse of the slab that used the buffer before has been queued.  Before, the calling thread
+        // copied slab k+1 (12 ms of memcpy on 15 threads), THEN waited for slab k's inflate, THEN queued its parse: phase 1 of slab k+1
+        // could not start before phase 2 of slab k - 1 ... had been waited for, and the two phases of neighbouring slabs never overlapped.
+        constexpr int NC = 3;
+        const size_t n_inf_slabs = inf_slabs.size();
+        const int n_txt = n_inf_slabs > 1 ? 2 : 1, n_cmp = (int)std::min<size_t>(NC, n_inf_slabs);
+        uint8_t *d_cmp_comp[NC] = {nullptr, nullptr, nullptr}, *d_cmp_scratch[NC] = {nullptr, nullptr, nullptr}, *d_cmp_tok[NC] = {nullptr, nullptr, nullptr};
+        InfPiece *d_cmp_pieces[NC] = {nullptr, nullptr, nullptr};
+        InfTokMeta *d_cmp_meta[NC] = {nullptr, nullptr, nullptr};
+        for (int b = 0; b < n_txt; ++b) HIP_TRY(tmp_alloc((void **)&d_text[b], slab_cap + 128));
+        if (n_txt == 1) d_text[1] = d_text[0];
+        for (int b = 0; b < n_cmp; ++b) {
+            HIP_TRY(tmp_alloc((void **)&d_cmp_comp[b], inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
+            HIP_TRY(tmp_alloc((void **)&d_cmp_scratch[b], std::max<size_t>(max_partial, 1) << 16));
+            HIP_TRY(tmp_alloc((void **)&d_cmp_pieces[b], max_pieces * sizeof(InfPiece)));
             if (two_phase) {
-                HIP_TRY(tmp_alloc((void **)&d_tok[b], max_tok + 64));
-                HIP_TRY(tmp_alloc((void **)&d_meta[b], max_pieces * sizeof(InfTokMeta)));
+                HIP_TRY(tmp_alloc((void **)&d_cmp_tok[b], max_tok + 64));
+                HIP_TRY(tmp_alloc((void **)&d_cmp_meta[b], max_pieces * sizeof(InfTokMeta)));
             }
         }
         HIP_TRY(tmp_alloc((void **)&d_status, 4));
-        HIP_TRY(tmp_alloc((void **)&d_tail, 16));
+        HIP_TRY(tmp_alloc((void **)&d_tail, 8 * NC));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         uint8_t *h_chunk[2] = {nullptr, nullptr};
-        hipEvent_t chunk_done[2] = {nullptr, nullptr}, inflated[2] = {nullptr, nullptr}, parsed_ev[2] = {nullptr, nullptr};
-        // TWO inflate streams, one per text buffer: a slab of 3 GiB is 49 000 blocks = 768 workgroups, half of the 1 536 the device holds at
-        // six per CU (the line-start offsets are 32 bits: a slab stays below 4 GiB), so the next slab's kernel starts beside the current
-        // one's as soon as its compressed bytes have arrived and its buffer has been parsed
-        hipStream_t inf_streams[2] = {nullptr, nullptr};
+        hipEvent_t chunk_done[2] = {nullptr, nullptr}, parsed_ev[2] = {nullptr, nullptr}, inflated[NC] = {nullptr, nullptr, nullptr};
+        // One inflate stream per set: a slab's phase 1, phase 2, CRC-32 and tail kernels follow each other on its own stream; the kernels of
+        // neighbouring slabs run side by side as far as the device has room (three phase-1 workgroups per CU leave LDS for six phase-2 waves)
+        hipStream_t inf_streams[NC] = {nullptr, nullptr, nullptr};
         struct Pinned { uint8_t **h; hipEvent_t *e, *e2, *e3; hipStream_t &cs; hipStream_t *is; ~Pinned() {
             if (cs) (void)hipStreamSynchronize(cs);
-            for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]);
+            for (int i = 0; i < NC; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]);
             for (int i = 0; i < 2; ++i) {
                 if (h[i]) (void)hipHostFree(h[i]);
                 if (e[i]) (void)hipEventDestroy(e[i]);
-                if (e2[i]) (void)hipEventDestroy(e2[i]);
                 if (e3[i]) (void)hipEventDestroy(e3[i]);
             }
-            for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamDestroy(is[i]);
+            for (int i = 0; i < NC; ++i) if (e2[i]) (void)hipEventDestroy(e2[i]);
+            for (int i = 0; i < NC; ++i) if (is[i]) (void)hipStreamDestroy(is[i]);
         } } pinned{h_chunk, chunk_done, inflated, parsed_ev, copy_stream, inf_streams};
         if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         {
-            // The inflate stream gets the LOWEST priority, which also gives it a hardware queue of its own: the runtime deals streams of
-            // one priority round-robin onto 4 hardware queues, and when this stream landed on the copy stream's queue the next slab's
-            // host-to-device copies only ran between two inflate kernels (measured, tools/gpu_r5k.sh: 0.047 s per slab against 0.034 s
-            // with GPU_MAX_HW_QUEUES=8 — per slab inflate + copy instead of their maximum).  A long-running, latency-bound kernel is
-            // the right thing to give way to copies and parse kernels in any case.
+            // The inflate streams get the LOWEST priority, which also gives them hardware queues of their own: the runtime deals streams of
+            // one priority round-robin onto 4 hardware queues, and when an inflate stream landed on the copy stream's queue the next slab's
+            // host-to-device copies only ran between two inflate kernels (measured, tools/leases/r5/gpu_r5k.sh: 0.047 s per slab against
+            // 0.034 s with GPU_MAX_HW_QUEUES=8 — per slab inflate + copy instead of their maximum).  Long-running, latency-bound kernels
+            // are the right thing to give way to copies and parse kernels in any case.
             int least = 0, greatest = 0;
             const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && getenv("NM_BED_FLAT_PRIORITY") == nullptr;
-            const int n_inf = getenv("NM_BED_ONE_INFLATE_STREAM") ? 1 : 2;          // (A/B: the slabs' kernels one after the other)
+            const int n_inf = getenv("NM_BED_ONE_INFLATE_STREAM") ? 1 : n_cmp;        // (A/B: the slabs' kernels one after the other)
             for (int i = 0; i < n_inf; ++i) {
                 if (prio) HIP_TRY(hipStreamCreateWithPriority(&inf_streams[i], hipStreamNonBlocking, least));
                 else HIP_TRY(hipStreamCreateWithFlags(&inf_streams[i], hipStreamNonBlocking));
             }
         }
-        auto inf_stream_of = [&](int buf) { return inf_streams[buf] ? inf_streams[buf] : inf_streams[0]; };
+        auto inf_stream_of = [&](int set) { return inf_streams[set] ? inf_streams[set] : inf_streams[0]; };
         for (int i = 0; i < 2; ++i) {
             HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));       // (a chunk is at most SLAB_BYTES = CHUNK of file)
             HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&inflated[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&parsed_ev[i], hipEventDisableTiming));
         }
+        for (int i = 0; i < NC; ++i) HIP_TRY(hipEventCreateWithFlags(&inflated[i], hipEventDisableTiming));
         const bool timing = getenv("NM_BED_TIMING") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
-        std::vector<InfPiece> hp[2];
+        std::vector<InfPiece> hp[NC];
         const CrcConsts crc_k = crc_consts();
 #ifdef NM_BED_PROBES                                                    // (timing probe builds only: what the check costs)
         const bool check_crc = getenv("NM_BED_NO_CRC") == nullptr;
 #else
         constexpr bool check_crc = true;                                // the shipped library always checks every member's CRC-32
 #endif
-        size_t n_chunk = 0;
         const unsigned nt = std::max(1u, threads - 1);
         // where a slab's last whole line ends and the inflate status come back through PINNED words written by a kernel on the inflate
         // stream: a hipMemcpyAsync there would sit in a copy-engine queue behind the inflate kernel it waits for — and in front of the
         // next slab's compressed bytes on the copy stream, which then travel only after the inflate (measured: 0.036 s of 0.042 per slab)
-        unsigned long long *h_words = nullptr;                         // [2] end of lines, [2] status
+        unsigned long long *h_words = nullptr;                         // [NC] end of lines, [NC] status
         HIP_TRY(hipHostMalloc((void **)&h_words, 64, hipHostMallocDefault));
-        struct FreeWords { unsigned long long *p; hipStream_t *is; ~FreeWords() { for (int i = 0; i < 2; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]); (void)hipHostFree(p); } } free_words{h_words, inf_streams};
-        volatile unsigned long long *end_of_lines_h = h_words, *status_h = h_words + 2;
-        double t_copy_slab[2] = {0, 0};
-        // stages (1) and (2) of slab si: everything it needs goes to the device, its inflate is queued
-        auto stage_slab = [&](size_t si) -> int {
+        struct FreeWords { unsigned long long *p; hipStream_t *is; ~FreeWords() { for (int i = 0; i < NC; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]); (void)hipHostFree(p); } } free_words{h_words, inf_streams};
+        volatile unsigned long long *end_of_lines_h = h_words, *status_h = h_words + NC;
+        double t_copy_slab[NC] = {0, 0, 0};
+        // ---- the front half of slab si (STAGING THREAD): piece table and compressed bytes to the device, phase 1 queued on the slab's stream
+        size_t n_chunk = 0;
+        double t_read_staging = 0;
+        auto stage_front = [&](size_t si) -> int {
             const InfSlab &sl = inf_slabs[si];
-            const int b = (int)(si % n_buf);
-            const hipStream_t inf_stream = inf_stream_of(b);
-            uint8_t *text = d_text[b];
+            const int cs = (int)(si % (size_t)n_cmp);
+            const hipStream_t inf_stream = inf_stream_of(cs);
             // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
-            std::vector<InfPiece> &pieces = hp[b];
+            std::vector<InfPiece> &pieces = hp[cs];
             pieces.clear();
             uint64_t toff = CARRY_CAP, poff = 0, tok_off = 0;
             for (const InfChunk &ch : sl.chunks)
@@ -1058,8 +1064,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                     tok_off += tok_len;
                     if (partial) poff += 1u << 16;
                 }
-            // (d_pieces[b], d_comp[b], d_scratch[b] were last read by the inflate of slab si - 2: the host has waited for it)
-            HIP_TRY(hipMemcpyAsync(d_pieces[b], pieces.data(), pieces.size() * sizeof(InfPiece), hipMemcpyHostToDevice, copy_stream));
+            // (this set's buffers were last read by the kernels of slab si - n_cmp: the calling thread has waited for them)
+            HIP_TRY(hipMemcpyAsync(d_cmp_pieces[cs], pieces.data(), pieces.size() * sizeof(InfPiece), hipMemcpyHostToDevice, copy_stream));
             // compressed bytes: chunks of whole pieces through two pinned buffers, memcpy on several threads
             const double t0 = now();
             for (const InfChunk &ch : sl.chunks) {
@@ -1067,7 +1073,6 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                 uint8_t *dst = h_chunk[n_chunk % 2];
                 if (n_chunk >= 2) HIP_TRY(hipEventSynchronize(chunk_done[n_chunk % 2]));
                 std::vector<std::thread> pool;
-                std::atomic<bool> bad{false};
                 // (out of the MAPPING: its pages are in the page tables since the walk over the blocks — the kernel maps 64 KiB around
                 //  every fault — and 15 threads copy 50 GB/s; preads of the same ranges were measured at 6.5 GB/s)
                 for (unsigned t = 0; t < nt; ++t)
@@ -1081,87 +1086,135 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                         if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_DONTNEED);
                     });
                 for (auto &th : pool) th.join();
-                if (bad) return fail(NM_EINVAL, "cannot read pileup '%s'", path);
-                HIP_TRY(hipMemcpyAsync(d_comp[b] + ch.dev_off, dst, bytes, hipMemcpyHostToDevice, copy_stream));
+                HIP_TRY(hipMemcpyAsync(d_cmp_comp[cs] + ch.dev_off, dst, bytes, hipMemcpyHostToDevice, copy_stream));
                 HIP_TRY(hipEventRecord(chunk_done[n_chunk % 2], copy_stream));
                 n_chunk += 1;
             }
-            t_copy_slab[b] = now() - t0;
-            t_read += t_copy_slab[b];
+            t_copy_slab[cs] = now() - t0;
+            t_read_staging += t_copy_slab[cs];
             HIP_TRY(hipStreamWaitEvent(inf_stream, chunk_done[(n_chunk - 1) % 2], 0));
-            if (si >= (size_t)n_buf) HIP_TRY(hipStreamWaitEvent(inf_stream, parsed_ev[b], 0));      // the text buffer has been parsed
-            else if (si == 0) HIP_TRY(hipStreamSynchronize(c->stream));                             // (allocations, clears above)
+            if (two_phase) {
+                hipLaunchKernelGGL(bed_tokens_kernel, dim3((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES)), dim3(INF_LANES), 0, inf_stream, d_cmp_comp[cs], d_cmp_pieces[cs],
+                                   (unsigned int)pieces.size(), d_cmp_tok[cs], d_cmp_meta[cs], d_status);
+                HIP_TRY(hipGetLastError());
+            }
+            return NM_OK;
+        };
+        // ---- the back half of slab si (calling thread, after the parse of slab si - n_txt has been queued): everything that writes or
+        // reads the slab's text buffer
+        auto stage_back = [&](size_t si) -> int {
+            const InfSlab &sl = inf_slabs[si];
+            const int cs = (int)(si % (size_t)n_cmp), tb = (int)(si % (size_t)n_txt);
+            const hipStream_t inf_stream = inf_stream_of(cs);
+            uint8_t *text = d_text[tb];
+            const unsigned int n_pieces = (unsigned int)hp[cs].size();
+            if (si >= (size_t)n_txt) HIP_TRY(hipStreamWaitEvent(inf_stream, parsed_ev[tb], 0));      // the text buffer has been parsed
 #ifdef NM_BED_PROBES
             {
                 const int probe = getenv("NM_BED_INFLATE_PROBE") ? atoi(getenv("NM_BED_INFLATE_PROBE")) : 0;
                 HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_inf_probe), &probe, sizeof probe));
             }
 #endif
-            // NM_BED_INFLATE_LDS_PAD (bytes of unused dynamic LDS per workgroup; A/B): fewer workgroups per CU.  The lanes' write fronts
-            // and match sources (~400 bytes per lane) of one XCD's 12 288 lanes overflow its 4 MB of L2 at six workgroups per CU (77 %
-            // hits, profiles/r5/bed_device/inflate_pmc.txt) — and matches are two thirds of the kernel's time (inflate_parts.txt)
+            // NM_BED_INFLATE_LDS_PAD (bytes of unused dynamic LDS per workgroup; A/B of the single kernel): fewer workgroups per CU
             static const unsigned lds_pad = getenv("NM_BED_INFLATE_LDS_PAD") ? (unsigned)atoi(getenv("NM_BED_INFLATE_LDS_PAD")) : 0u;
-            const dim3 lane_grid((unsigned)((pieces.size() + INF_LANES - 1) / INF_LANES));
+            const dim3 lane_grid((n_pieces + INF_LANES - 1) / INF_LANES);
             if (two_phase) {
-                hipLaunchKernelGGL(bed_tokens_kernel, lane_grid, dim3(INF_LANES), 0, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), d_tok[b], d_meta[b], d_status);
-                HIP_TRY(hipGetLastError());
                 // (the blocks whose tokens did not fit their region, if any: the lanes of all others leave at once)
-                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), 0, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status,
-                                   (const InfTokMeta *)d_meta[b]);
+                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), 0, inf_stream, d_cmp_comp[cs], d_cmp_pieces[cs], n_pieces, text, d_cmp_scratch[cs], d_status,
+                                   (const InfTokMeta *)d_cmp_meta[cs]);
                 HIP_TRY(hipGetLastError());
-                hipLaunchKernelGGL(bed_resolve_kernel, dim3((unsigned)pieces.size()), dim3(64), 0, inf_stream, d_pieces[b], (unsigned int)pieces.size(), d_tok[b], d_meta[b], text,
-                                   d_scratch[b], d_status);
+                hipLaunchKernelGGL(bed_resolve_kernel, dim3(n_pieces), dim3(64), 0, inf_stream, d_cmp_pieces[cs], n_pieces, d_cmp_tok[cs], d_cmp_meta[cs], text,
+                                   d_cmp_scratch[cs], d_status);
             } else {
-                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), lds_pad, inf_stream, d_comp[b], d_pieces[b], (unsigned int)pieces.size(), text, d_scratch[b], d_status,
+                hipLaunchKernelGGL(bed_inflate_kernel, lane_grid, dim3(INF_LANES), lds_pad, inf_stream, d_cmp_comp[cs], d_cmp_pieces[cs], n_pieces, text, d_cmp_scratch[cs], d_status,
                                    (const InfTokMeta *)nullptr);
             }
             HIP_TRY(hipGetLastError());
             if (check_crc) {
-                hipLaunchKernelGGL(bed_crc_kernel, dim3((unsigned)((pieces.size() + 3) / 4)), dim3(256), 0, inf_stream, d_pieces[b], (unsigned int)pieces.size(), text,
-                                   d_scratch[b], crc_k, d_status);
+                hipLaunchKernelGGL(bed_crc_kernel, dim3((n_pieces + 3) / 4), dim3(256), 0, inf_stream, d_cmp_pieces[cs], n_pieces, text, d_cmp_scratch[cs], crc_k, d_status);
                 HIP_TRY(hipGetLastError());
             }
             // where the last whole line ends; what follows it is carried into the next slab
             const uint64_t total = CARRY_CAP + sl.text;
             const bool want_tail = si + 1 != inf_slabs.size();
             if (want_tail) {
-                hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, inf_stream, text, total, CARRY_CAP, d_tail + b);
+                hipLaunchKernelGGL(bed_tail_kernel, dim3(1), dim3(256), 0, inf_stream, text, total, CARRY_CAP, d_tail + cs);
                 HIP_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(bed_report_kernel, dim3(1), dim3(1), 0, inf_stream, want_tail ? d_tail + b : nullptr, (unsigned long long)total, d_status,
-                               h_words + b, h_words + 2 + b);
+            hipLaunchKernelGGL(bed_report_kernel, dim3(1), dim3(1), 0, inf_stream, want_tail ? d_tail + cs : nullptr, (unsigned long long)total, d_status,
+                               h_words + cs, h_words + NC + cs);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(inflated[b], inf_stream));
+            HIP_TRY(hipEventRecord(inflated[cs], inf_stream));
+            return NM_OK;
+        };
+        // ---- the staging thread: front halves in slab order, at most n_cmp slabs ahead of the last slab whose inflate has been waited for
+        std::mutex pmu;
+        std::condition_variable pcv;
+        size_t fronts_done = 0, retired = 0;
+        int front_rc = NM_OK;
+        std::string front_error;
+        bool stop_staging = false;
+        std::thread stager([&] {
+            (void)hipSetDevice(c->device);
+            for (size_t si = 0; si < n_inf_slabs; ++si) {
+                {
+                    std::unique_lock<std::mutex> lk(pmu);
+                    pcv.wait(lk, [&] { return stop_staging || si < retired + (size_t)n_cmp; });
+                    if (stop_staging) return;
+                }
+                const int rc = stage_front(si);
+                {
+                    std::lock_guard<std::mutex> lk(pmu);
+                    if (rc) { front_rc = rc; front_error = nm_last_error(); }
+                    fronts_done = si + 1;
+                }
+                pcv.notify_all();
+                if (rc) return;
+            }
+        });
+        struct JoinStager {                                             // (declared last: leaves first, before the buffers and streams above it go)
+            std::thread &t; std::mutex &m; std::condition_variable &cv; bool &stop;
+            ~JoinStager() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); if (t.joinable()) t.join(); }
+        } join_stager{stager, pmu, pcv, stop_staging};
+        auto wait_front = [&](size_t si) -> int {
+            std::unique_lock<std::mutex> lk(pmu);
+            pcv.wait(lk, [&] { return fronts_done > si || front_rc != NM_OK; });
+            if (front_rc != NM_OK) return fail(front_rc, "%s", front_error.c_str());       // (the message was made on the staging thread)
             return NM_OK;
         };
         uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
-        int rc0 = stage_slab(0);
-        if (rc0) return rc0;
+        for (size_t k = 0; k < std::min<size_t>(2, n_inf_slabs); ++k) {   // (both text buffers are free: the first two back halves at once)
+            int rc0 = wait_front(k);
+            if (rc0) return rc0;
+            rc0 = stage_back(k);
+            if (rc0) return rc0;
+        }
         for (size_t si = 0; si < inf_slabs.size(); ++si) {
             const InfSlab &sl = inf_slabs[si];
-            const int bi = (int)(si % n_buf);
-            uint8_t *text = d_text[bi];
+            const int cs = (int)(si % (size_t)n_cmp), tb = (int)(si % (size_t)n_txt);
+            uint8_t *text = d_text[tb];
             const bool last_slab = si + 1 == inf_slabs.size();
-            const double t_staged = now();
-            if (!last_slab && n_buf == 2) {                             // the next slab travels and queues while this one inflates
-                rc0 = stage_slab(si + 1);
-                if (rc0) return rc0;
-            }
             const double t_wait = now();
-            HIP_TRY(hipEventSynchronize(inflated[bi]));
+            HIP_TRY(hipEventSynchronize(inflated[cs]));
             const double t_inflated = now();
             b->t_inflate += t_inflated - t_wait;
+            {
+                std::lock_guard<std::mutex> lk(pmu);                    // the set of slab si is free for slab si + n_cmp
+                retired = si + 1;
+            }
+            pcv.notify_all();
 #ifdef NM_BED_PROBES
             if (getenv("NM_BED_INFLATE_PROBE") && atoi(getenv("NM_BED_INFLATE_PROBE"))) {
-                fprintf(stderr, "[bed] PROBE %s: slab %zu (%zu blocks, %.2f GB text): staged the next in %.3f s, waited %.3f s for the inflate\n", getenv("NM_BED_INFLATE_PROBE"), si,
-                        hp[bi].size(), sl.text / 1e9, t_wait - t_staged, t_inflated - t_wait);
+                fprintf(stderr, "[bed] PROBE %s: slab %zu (%zu blocks, %.2f GB text): waited %.3f s for the inflate\n", getenv("NM_BED_INFLATE_PROBE"), si,
+                        hp[cs].size(), sl.text / 1e9, t_inflated - t_wait);
                 if (last_slab || si == 3) return fail(NM_EINVAL, "inflate probe: the text is garbage on purpose");
-                HIP_TRY(hipEventRecord(parsed_ev[bi], c->stream));
+                HIP_TRY(hipEventRecord(parsed_ev[tb], c->stream));
+                if (si + 2 < inf_slabs.size()) { int r2 = wait_front(si + 2); if (r2) return r2; r2 = stage_back(si + 2); if (r2) return r2; }
                 continue;
             }
 #endif
-            const unsigned int status = (unsigned int)status_h[bi];
-            const unsigned long long end_of_lines = end_of_lines_h[bi];
+            const unsigned int status = (unsigned int)status_h[cs];
+            const unsigned long long end_of_lines = end_of_lines_h[cs];
             const uint64_t begin = CARRY_CAP - carry, total = CARRY_CAP + sl.text;
             if (status) return fail(NM_EINVAL, "%s: corrupt BGZF block (block %u of the slab, %s %u)", path, status >> 8, (status & 255u) == 19u ? "CRC-32 mismatch, code" : "inflate error", status & 255u);
             if (!last_slab && (end_of_lines <= begin || total - end_of_lines > CARRY_CAP - 16))
@@ -1173,16 +1226,26 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             int rc = parse_text(text + aligned, end_of_lines - aligned, text_base, si == 0 && inf_slabs.size() > 1 ? (double)n / (double)sl.text : 0.0, [] {});
             if (rc) return rc;
             carry = total - end_of_lines;
-            if (!last_slab && carry) HIP_TRY(hipMemcpyAsync(d_text[(si + 1) % n_buf] + CARRY_CAP - carry, text + end_of_lines, carry, hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipEventRecord(parsed_ev[bi], c->stream));
-            if (!last_slab && n_buf == 1) {                             // (one buffer: nothing overlaps)
-                rc0 = stage_slab(si + 1);
-                if (rc0) return rc0;
+            if (!last_slab && carry) HIP_TRY(hipMemcpyAsync(d_text[(si + 1) % (size_t)n_txt] + CARRY_CAP - carry, text + end_of_lines, carry, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipEventRecord(parsed_ev[tb], c->stream));
+            const double t_parsed = now();
+            if (si + 2 < inf_slabs.size()) {                            // this text buffer's next user: its back half behind the parse just queued
+                rc = wait_front(si + 2);
+                if (rc) return rc;
+                rc = stage_back(si + 2);
+                if (rc) return rc;
             }
             if (timing)
-                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: next slab staged in %.3f s (copies %.3f), waited %.3f s for the inflate, parse queued in %.3f s\n",
-                        si, hp[bi].size(), sl.text / 1e9, t_wait - t_staged, t_copy_slab[(si + 1) % n_buf], t_inflated - t_wait, now() - t_inflated);
+                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: waited %.3f s for the inflate, parse queued in %.3f s, back half of slab %zu in %.3f s (its copies took the staging thread %.3f s)\n",
+                        si, hp[cs].size(), sl.text / 1e9, t_inflated - t_wait, t_parsed - t_inflated, si + 2, now() - t_parsed, t_copy_slab[(si + 2) % (size_t)n_cmp]);
         }
+        {
+            std::lock_guard<std::mutex> lk(pmu);
+            stop_staging = true;
+        }
+        pcv.notify_all();
+        stager.join();
+        t_read += t_read_staging;
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (size_t k = 0; k < n_slabs; ++k) {
