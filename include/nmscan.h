@@ -548,7 +548,9 @@ int nm_bed_close(nm_bed *bed);
  * Any other gzip stream is refused (NM_EINVAL "compressed input ...": use nm_bed_open).
  *   nm_bedcols_shape           rows, contigs, runs of equal contig names; times = {seconds in total, seconds copying the file}
  *   nm_bedcols_phase_seconds   {total, moving the file (pread / memcpy into pinned slabs, H2D issue), waiting for the device inflate of
- *                              a bgzip file's slabs (0 for plain text), the rest: line / field kernels, contig tables}
+ *                              a bgzip file's slabs (0 for plain text), the rest: line / field kernels, contig tables}; for a bgzip file
+ *                              inflated on the device the file is moved by a staging thread BESIDE the rest (round 6): its seconds
+ *                              are reported but not part of the sum
  *   nm_bedcols_runs            run_row[n_runs + 1] (first row of each run, then n_rows), run_contig[n_runs] (file contig id)
  *   nm_bedcols_map_contigs     contig column = contig_lut[file contig id] (engine contig id or 0xFFFFFFFF)
  *   nm_bedcols_device_columns  DEVICE pointers; contig_id is valid after nm_bedcols_map_contigs
