@@ -1237,8 +1237,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                 if (rc) return rc;
             }
             if (timing)
-                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: waited %.3f s for the inflate, parse queued in %.3f s, back half of slab %zu in %.3f s (its copies took the staging thread %.3f s)\n",
-                        si, hp[cs].size(), sl.text / 1e9, t_inflated - t_wait, t_parsed - t_inflated, si + 2, now() - t_parsed, t_copy_slab[(si + 2) % (size_t)n_cmp]);
+                fprintf(stderr, "[bed] slab %zu: %zu blocks, %.2f GB text: waited %.3f s for the inflate, parse queued in %.3f s, back half of slab %zu in %.3f s\n",
+                        si, sl.last - sl.first, sl.text / 1e9, t_inflated - t_wait, t_parsed - t_inflated, si + 2, now() - t_parsed);
         }
         {
             std::lock_guard<std::mutex> lk(pmu);
