@@ -289,12 +289,22 @@ def checksum(table):
             int((table * np.arange(1, table.size + 1).reshape(table.shape) % 1000003).sum() % (2**61 - 1))]
 
 
-def run_e2e(mg, eng_device, device, my_bins=None):
+def run_e2e(mg, eng_device, device, my_bins=None, lanes=1):
     """The whole motif_discovery pipeline on (the bins ``my_bins`` of) the metagenome: raw pileup rows -> device-side
-    filters -> windows -> lock-step greedy search with pruning -> post-processing.  Returns (rows, timings)."""
+    filters -> windows -> lock-step greedy search with pruning -> post-processing.  ``lanes`` > 1: the bins dealt to that many
+    engines on this device that run side by side (e2e_synth.run_lanes).  Returns (rows, timings)."""
     import torch
     from nanomotif_amd import e2e_synth
     from nanomotif_amd.engine import ScanEngine
+    if lanes > 1:
+        assert my_bins is None
+        engines = [ScanEngine(eng_device) for _ in range(lanes)]
+        try:
+            rows, t = e2e_synth.run_lanes(mg, engines, device)
+        finally:
+            for e in engines:
+                e.close()
+        return [r for r in rows if r.n_mod + r.n_nomod >= 50], t
     eng = ScanEngine(eng_device)
     t0 = time.perf_counter()
     rows, t = e2e_synth.run(mg, eng, device, bins=my_bins)
@@ -544,6 +554,10 @@ def main():
     ap.add_argument("--bins", type=int, default=500)
     ap.add_argument("--candidates", type=int, default=10_000)
     ap.add_argument("--workload", choices=["cfg5", "greedy", "cfg5_all", "e2e"], default="cfg5")
+    ap.add_argument("--e2e-lanes", type=int, default=1,
+                    help="one GPU: the end-to-end run's bins go through the pipeline in this many lanes side by side — one engine and one host thread "
+                         "each (e2e_synth.run_lanes).  Measured in round 6 (profiles/r6/e2e/lanes.jsonl): two lanes 62-72 ms against 70-79 of one, "
+                         "three and more slower than one; same rows.  Not the default: the gain is within the box's noise")
     ap.add_argument("--per-group", type=int, default=2, help="greedy workload: children per (bin, mod type)")
     ap.add_argument("--cpu-bins", type=int, default=-1, help="bins in the CPU-baseline sample (-1: two per worker, at most all; 0: skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="CPU-baseline worker processes (0: os.cpu_count())")
@@ -661,11 +675,12 @@ def main():
         my_bins = None if world == 1 else assign_bins(sizes, world, tolerance=float("inf"))[rank]
         if world > 1:
             dist.barrier()
-        rows, t = run_e2e(mg, local_rank, device, my_bins)
-        pipeline = t["upload_filter_s"] + t["search_s"]
+        lanes = args.e2e_lanes if world == 1 else 1
+        rows, t = run_e2e(mg, local_rank, device, my_bins, lanes=lanes)
+        pipeline = t["wall_s"] if lanes > 1 else t["upload_filter_s"] + t["search_s"]
         planted = {(b, m[0]) for b, ms in mg.bin_motifs.items() if my_bins is None or b in set(my_bins) for m in ms}
         found = {(r.reference, r.motif_iupac) for r in rows}
-        per = gather([pipeline, t["search_s"], t["upload_filter_s"], len(rows), len(planted), len(planted & found), t["rounds"], t["candidates"]])
+        per = gather([pipeline, t.get("search_s", 0.0), t.get("upload_filter_s", 0.0), len(rows), len(planted), len(planted & found), t["rounds"], t["candidates"]])
         if rank == 0:
             wall = max(p[0] for p in per)
             emit(({
@@ -673,7 +688,9 @@ def main():
                 "value": wall, "unit": "s", "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": wall * 1e3, "higher_is_better": False,
                 "scaling": "strong", "vs_baseline": None, "dtype": "u32 bit-planes / int64 counts / f64 scores", "data": "synthetic",
                 "config": {"workload": f"e2e: motif_discovery on {args.total_bp:,} bp ({args.contigs} contigs, {args.bins} bins, 6mA+5mC), "
-                                       f"whole bins per GPU over {world} GPU(s), no collective until the rows are gathered"},
+                                       f"whole bins per GPU over {world} GPU(s), no collective until the rows are gathered"
+                                       + (f"; {lanes} lanes side by side on the GPU" if lanes > 1 else "")},
+                "gpu_busy_over_wall": (t.get("gpu_busy_union_s", 0.0) / pipeline) if world == 1 else None,
                 "per_rank": [dict(zip(["pipeline_s", "search_s", "upload_filter_s", "motif_rows", "planted", "planted_recovered", "rounds", "candidates"], p)) for p in per],
                 "timings_rank0": t}))
         if world > 1:
@@ -715,6 +732,25 @@ def main():
                                  "gpu_busy_covers": "every device phase of the run (pre-filter kernels, window gathers and batches, background counts, scoring launches), HIP events on the ctx stream",
                                  "not_in_wall_s": {"generate_s": t.get("generate_s"), "allocator_prewarm_s": t.get("allocator_prewarm_s")},
                                  "timings_rank0": t}
+                e2e_result["gpu_busy_union_s"] = t.get("gpu_busy_union_s")      # (gpu_busy_s sums the phases; the two flights of the search overlap a little)
+            if world == 1 and args.e2e_lanes > 1:
+                # the same run with the bins dealt to lanes that share the device (one engine + one host thread each): what a lane's
+                # search leaves idle between its small launches, another lane's pre-filters and gathers use
+                row_key = lambda r: (r.reference, r.motif, r.mod_type, r.mod_position, r.n_mod, r.n_nomod, r.score)
+                l_rows, lt = run_e2e(mg, local_rank, device, None, lanes=args.e2e_lanes)
+                single = {k: e2e_result[k] for k in ("wall_s", "search_s", "upload_filter_s", "gpu_busy_s", "gpu_busy_union_s", "gpu_busy_over_wall")}
+                single["wall_s_is"] = "upload_filter_s + search_s of the one lane (the figure of the earlier rounds); its whole call took run_call_s"
+                single["run_call_s"] = t.get("run_call_s")
+                e2e_result["single_lane"] = single
+                e2e_result.update({
+                    "lanes": args.e2e_lanes, "wall_s": lt["wall_s"], "gpu_busy_s": lt["gpu_busy_union_s"], "gpu_busy_over_wall": lt["gpu_busy_union_s"] / lt["wall_s"],
+                    "gpu_busy_sum_of_phases_s": lt["gpu_busy_s"], "lanes_rows_equal_single_lane": [row_key(r) for r in l_rows] == [row_key(r) for r in e_rows],
+                    "wall_s_is": f"first lane's start to the last lane's end, {args.e2e_lanes} lanes (threads) on one GPU, everything between included; "
+                                 "gpu_busy_s = union of all lanes' device phases on the device's clock (nm_timing_intervals)",
+                    "lane_pipeline_s": [x["upload_filter_s"] + x["search_s"] for x in lt["lanes"]],
+                    "not_in_wall_s": {"generate_s": lt.get("generate_s"), "allocator_prewarm_s": lt.get("allocator_prewarm_s")}})
+                del e2e_result["search_s"], e2e_result["upload_filter_s"], e2e_result["gpu_busy_union_s"]
+                e2e_result["timings_lanes"] = lt["lanes"]
     except Exception as exc:                    # an extra must not take the headline line down with it (one rank only:
         if world > 1:                           #  with several ranks a lone survivor would hang in the next collective)
             raise

@@ -647,6 +647,10 @@ int nm_window_letter_counts(const uint8_t *seq, uint64_t seq_len, const int64_t 
  * nm_plan_windows, every nm_win_batch): the sum is then the time the GPU was busy for this ctx. */
 int nm_timing_reset(nm_ctx *ctx, int enable);
 int nm_timing_total_ms(nm_ctx *ctx, double *total_ms, uint64_t *n_launches);
+/* The same phases on the device's clock: begin_ms[i] / end_ms[i] of phase i in ms after the FIRST phase `epoch` recorded (ctx itself,
+ * or another ctx on the same device: engines that work side by side share one time line that way).  Phases on different streams
+ * may overlap — the union of the intervals is the time the device was busy.  capacity 0: only *n (how many there are). */
+int nm_timing_intervals(nm_ctx *ctx, nm_ctx *epoch, uint64_t capacity, double *begin_ms, double *end_ms, uint64_t *n);
 
 #ifdef __cplusplus
 }

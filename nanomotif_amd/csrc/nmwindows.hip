@@ -1742,4 +1742,26 @@ int nm_plan_windows(nm_ctx *c, uint32_t n_tasks, const uint32_t *task_slot, cons
     return NM_OK;
 }
 
+// Where on the device's clock the phases of nm_timing_reset(ctx, 1 | 2) lie: begin / end of each in ms after the first phase that
+// `epoch` recorded (the ctx itself, or another ctx of the same device — several engines that work side by side are laid on one time
+// line that way; phases on different streams may overlap, their union is the time the device was busy).
+int nm_timing_intervals(nm_ctx *c, nm_ctx *epoch, uint64_t capacity, double *begin_ms, double *end_ms, uint64_t *n) {
+    if (!c || !epoch || !n || (capacity && (!begin_ms || !end_ms))) return fail(NM_EINVAL, "NULL argument");
+    *n = c->ev_used;
+    if (!capacity) return NM_OK;
+    if (capacity < c->ev_used) return fail(NM_EINVAL, "nm_timing_intervals: %zu phases recorded, room for %llu", c->ev_used, (unsigned long long)capacity);
+    if (!epoch->ev_used) return fail(NM_ESTATE, "nm_timing_intervals: the epoch ctx has recorded no phase");
+    hipEvent_t zero = epoch->ev_pool[0].first;
+    HIP_TRY(hipEventSynchronize(zero));
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(c->ev_pool[i].second));
+        HIP_TRY(hipEventElapsedTime(&a, zero, c->ev_pool[i].first));
+        HIP_TRY(hipEventElapsedTime(&b, zero, c->ev_pool[i].second));
+        begin_ms[i] = a;
+        end_ms[i] = b;
+    }
+    return NM_OK;
+}
+
 }  // extern "C"

@@ -177,21 +177,22 @@ def write_gz_inputs_streaming(mg: synth.SynthMetagenome, out_dir: str, device, b
             "fasta_bytes": os.path.getsize(os.path.join(out_dir, "assembly.fasta"))}
 
 
-def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, host_assembly=True):
-    """Generate (a shard of) ``mg`` on ``device`` and ingest it through the device-side filters.
-    Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
+def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, host_assembly=True, raw=None):
+    """Generate (a shard of) ``mg`` on ``device`` (or take ``raw`` = what ``generate_raw`` returned for it) and ingest it through the
+    device-side filters.  Returns (assembly dict name -> uint8 ASCII on the host, FilteredPileup of this shard, timings)."""
     t = {}
     t0 = time.perf_counter()
-    mine, lengths, offsets, bins, ascii_all, cat = generate_raw(mg, device, contigs)
+    mine, lengths, offsets, bins, ascii_all, cat = generate_raw(mg, device, contigs) if raw is None else raw
     # what the ingest will ask the allocator for (16 B per bp of dense maxima, the planes) is taken and given back to
     # torch's pool HERE, with the generation: a fresh hipMalloc of memory that another process used before is scrubbed
     # by the driver at 7-30 GB/s (DESIGN §7) — 0.4 s for this block right after the test suite, none on a fresh box —
     # and that is no more part of the pipeline than the generation of the synthetic rows is
     torch.cuda.synchronize(device)
     t_warm = time.perf_counter()
-    warm = torch.empty(int(lengths.sum()) * 20, dtype=torch.uint8, device=device)
-    del warm
-    torch.cuda.synchronize(device)
+    if raw is None:                                                # (a caller that brings the inputs has done this as well: run_lanes)
+        warm = torch.empty(int(lengths.sum()) * 20, dtype=torch.uint8, device=device)
+        del warm
+        torch.cuda.synchronize(device)
     t["allocator_prewarm_s"] = time.perf_counter() - t_warm        # reported, not part of wall_s (like the generation)
     t["generate_s"] = time.perf_counter() - t0
     engine.timing_reset(2)                                         # every device phase from here on counts as GPU-busy time
@@ -236,15 +237,28 @@ def load_and_filter(engine, mg: synth.SynthMetagenome, device, contigs=None, hos
     return assembly, FilteredPileup(engine.contig_names, cc, cp, cs, cm, kept), t
 
 
-def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None, use_dist=False):
+def union_ms(intervals) -> float:
+    """Length of the union of [begin, end] intervals (float64[n, 2], ms): the time the device was busy when phases overlap."""
+    iv = np.asarray(intervals, dtype=np.float64).reshape(-1, 2)
+    if not len(iv):
+        return 0.0
+    iv = iv[np.argsort(iv[:, 0], kind="stable")]
+    reach = np.maximum.accumulate(iv[:, 1])
+    # a phase adds what of it lies beyond everything that began before it
+    return float((reach - np.maximum(iv[:, 0], np.concatenate(([iv[0, 0]], reach[:-1])))).clip(min=0).sum())
+
+
+def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None, use_dist=False, raw=None, keep_timing=False):
     """End-to-end run on one GPU; ``bins``: only these bins (whole-bin sharding of a multi-GPU run: every rank runs the
     searches of its own bins alone, find_motifs_bin.py:152-171); ``use_dist``: every round's count and window tables go
-    through ``allreduce_counts`` like in a contig-sharded run (the caller has a communicator up).  Returns (rows, timings)."""
+    through ``allreduce_counts`` like in a contig-sharded run (the caller has a communicator up); ``raw``: the shard's
+    device-resident inputs when the caller generated them already (``generate_raw``).  Returns (rows, timings)."""
+    t_entry = time.perf_counter()
     contigs = None
     if bins is not None:
         keep = set(bins)
         contigs = [i for i, b in enumerate(mg.bin_names) if b in keep]
-    assembly, filtered, t = load_and_filter(engine, mg, device, contigs=contigs, host_assembly=False)
+    assembly, filtered, t = load_and_filter(engine, mg, device, contigs=contigs, host_assembly=False, raw=raw)
     names = mg.names if contigs is None else [mg.names[i] for i in contigs]
     bin_of = mg.bin_names if contigs is None else [mg.bin_names[i] for i in contigs]
     lengths = [int(mg.lengths[i]) for i in (range(len(mg.names)) if contigs is None else contigs)]
@@ -261,9 +275,93 @@ def run(mg: synth.SynthMetagenome, engine, device, log=None, bins=None, use_dist
     t["search_s"] = time.perf_counter() - t0
     t.update(getattr(scorer, "timings", {}))
     ms, n = engine.timing_total()
-    engine.timing_reset(False)
-    t["gpu_busy_s"] = ms * 1e-3              # every device phase: pre-filters, window gathers and batches, background counts, scoring launches (HIP events on the ctx stream)
+    t["gpu_busy_s"] = ms * 1e-3              # every device phase: pre-filters, window gathers and batches, background counts, scoring launches (HIP events, summed)
+    t["gpu_busy_union_s"] = union_ms(engine.timing_intervals()) * 1e-3       # the same as a union on the device's clock (phases of the two flights of the search overlap)
+    if not keep_timing:                      # (run_lanes lays the phases of all lanes on one time line first)
+        engine.timing_reset(False)
     t["device_phases"] = n
     t["rounds"], t["candidates"] = scorer.rounds, scorer.candidates
     t["search_iterations"], t["speculation_hits"], t["speculation_misses"] = scorer.search_iterations, scorer.speculation_hits, scorer.speculation_misses
+    t["run_call_s"] = time.perf_counter() - t_entry - t["generate_s"]       # everything of this call but the generation (+ pre-warm) of the inputs
+    return rows, t
+
+
+def lane_bins(mg: synth.SynthMetagenome, n_lanes: int):
+    """Whole bins dealt to ``n_lanes`` groups, longest first to the group with the fewest base pairs (the split of a multi-GPU run,
+    shard.assign_bins, on ONE device)."""
+    size = {}
+    for i, b in enumerate(mg.bin_names):
+        size[b] = size.get(b, 0) + int(mg.lengths[i])
+    groups, load = [[] for _ in range(n_lanes)], [0] * n_lanes
+    for b in sorted(size, key=lambda b: (-size[b], b)):
+        k = load.index(min(load))
+        groups[k].append(b)
+        load[k] += size[b]
+    return groups
+
+
+def run_lanes(mg: synth.SynthMetagenome, engines, device):
+    """``run`` with the bins dealt to ``len(engines)`` lanes that go through the pipeline SIDE BY SIDE — one engine (its own HIP
+    streams), one host thread each: bins are independent searches (find_motifs_bin.py:152-171 hands them to a process pool), so
+    while one lane's search waits for the host between two small launches, another lane's pre-filters or window gathers have the
+    device.  Returns (rows in the order of a single-lane run, timings: ``wall_s`` from the first lane's start to the last one's end,
+    ``lanes`` = every lane's own timings)."""
+    import gc
+    import threading
+    n = len(engines)
+    groups = lane_bins(mg, n)
+    t0 = time.perf_counter()
+    raws = []
+    for g in groups:
+        keep = set(g)
+        raws.append(generate_raw(mg, device, [i for i, b in enumerate(mg.bin_names) if b in keep]))
+    torch.cuda.synchronize(device)
+    generate_s = time.perf_counter() - t0
+    # (load_and_filter's allocator pre-warm, for all lanes at once: one block per lane, as the lanes will ask for them)
+    t0 = time.perf_counter()
+    warm = [torch.empty(int(r[1].sum()) * 20, dtype=torch.uint8, device=device) for r in raws]
+    del warm
+    torch.cuda.synchronize(device)
+    prewarm_s = time.perf_counter() - t0
+    out, err = [None] * n, [None] * n
+
+    def lane(k):
+        try:
+            out[k] = run(mg, engines[k], device, bins=groups[k], raw=raws[k], keep_timing=True)
+        except BaseException as e:           # re-raised on the caller's thread
+            err[k] = e
+    gc_was_on = gc.isenabled()
+    gc.disable()                             # (discover() pauses the collector per lane; a lane that ends early must not switch it back on for the others)
+    try:
+        threads = [threading.Thread(target=lane, args=(k,), name=f"nm-lane-{k}") for k in range(n)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+    finally:
+        if gc_was_on:
+            gc.enable()
+    for e in err:
+        if e is not None:
+            raise e
+    busy = union_ms(np.concatenate([e.timing_intervals(engines[0]) for e in engines])) * 1e-3
+    for e in engines:
+        e.timing_reset(False)
+    rank = {}
+    for b in mg.bin_names:
+        rank.setdefault(b, len(rank))
+    rows = sorted((r for rs, _ in out for r in rs), key=lambda r: rank[r.reference])       # stable: a bin's rows keep their order
+    lanes = [t for _, t in out]
+    t = {"wall_s": wall, "generate_s": generate_s, "lanes": lanes, "n_lanes": n, "gpu_busy_union_s": busy,
+         "gpu_busy_s": sum(x["gpu_busy_s"] for x in lanes),
+         "allocator_prewarm_s": prewarm_s}
+    for k in ("rounds", "candidates", "rows_raw", "rows_kept", "rows_confident", "device_phases"):
+        t[k] = sum(x.get(k, 0) for x in lanes)
+    for k in ("search_iterations",):
+        t[k] = max(x.get(k, 0) for x in lanes)
+    for k in ("speculation_hits", "speculation_misses"):
+        t[k] = sum(x.get(k, 0) for x in lanes)
     return rows, t

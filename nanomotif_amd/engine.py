@@ -871,6 +871,17 @@ class ScanEngine:
         _lib.check(self.lib.nm_timing_total_ms(self.ctx, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def timing_intervals(self, epoch=None) -> np.ndarray:
+        """float64[n, 2]: begin / end of every phase since ``timing_reset`` in ms after the first phase of ``epoch`` (another engine on
+        this device; default: this one) — nm_timing_intervals."""
+        ref = self if epoch is None else epoch
+        n = C.c_uint64(0)
+        _lib.check(self.lib.nm_timing_intervals(self.ctx, ref.ctx, 0, None, None, C.byref(n)))
+        out = np.zeros((2, max(int(n.value), 1)), dtype=np.float64)
+        if n.value:
+            _lib.check(self.lib.nm_timing_intervals(self.ctx, ref.ctx, int(n.value), _ptr(out[0], C.c_double), _ptr(out[1], C.c_double), C.byref(n)))
+        return np.ascontiguousarray(out[:, :int(n.value)].T)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)
         _lib.check(self.lib.nm_last_kernel_ms(self.ctx, C.byref(ms)))
