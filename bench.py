@@ -455,7 +455,16 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
         # NM_BENCH_CLI1G_LEGS = "name:KEY=VALUE;KEY=VALUE,name2:..." adds A/B legs with other environments (builder probes)
         more = tuple((spec.split(":", 1)[0], dict(kv.split("=", 1) for kv in spec.split(":", 1)[1].split(";") if kv), )
                      for spec in os.environ.get("NM_BENCH_CLI1G_LEGS", "").split(",") if ":" in spec)
+        # The device is left idle for two seconds before every process: the driver scrubs the memory the process before (or this one's
+        # generation) gave back, and a process that starts while that is going on waits for it in its first large allocation — 0.3 - 0.4 s
+        # on a run of 0.6 (measured, profiles/r6/cli_fixed_costs.md); a user's run does not start in the wake of another one
+        settle_s = float(os.environ.get("NM_BENCH_CLI_SETTLE_S", "2"))
+        out["device_left_idle_before_each_process_s"] = settle_s
         for leg, extra_env in (("cold", {}), ("again", {"NM_BED_TIMING": "1", "NM_FASTA_TIMING": "1", "NM_SEARCH_TIMING": "1"})) + more:      # (the second run also prints the parser's per-slab split)
+            if settle_s > 0:
+                import torch
+                torch.cuda.synchronize(device)
+                time.sleep(settle_s)
             t0 = time.perf_counter()
             r = subprocess.run([sys.executable, "-m", "nanomotif_amd", "motif_discovery", "assembly.fasta", "pileup.bed.gz", "-c", "contig_bin.tsv",
                                 "--out", "out_" + leg], cwd=tmp, env=dict(env, **extra_env), capture_output=True, text=True)
@@ -534,10 +543,15 @@ def run_files_extra(device, log_fn):
            "total_bp": full.get("total_bp"), "rows": full.get("rows"), "bed_text_bytes": full.get("bed_text_bytes"), "gz_bytes": full.get("gz_bytes"),
            "fasta_bytes": full.get("fasta_bytes"), "files_written_in_s": full.get("write_s"), "size_note": full.get("size_note"),
            "wall_s": cold.get("wall_s"), "wall_s_second_process": again.get("wall_s"), "phases": cold.get("phases"), "rates": cold.get("rates"),
-           "the_wall_is": cold.get("the_wall_is"), "motif_rows": cold.get("motif_rows"), "both_runs_byte_equal": full.get("both_runs_byte_equal")}
+           "the_wall_is": cold.get("the_wall_is"), "motif_rows": cold.get("motif_rows"), "both_runs_byte_equal": full.get("both_runs_byte_equal"),
+           "device_left_idle_before_each_process_s": full.get("device_left_idle_before_each_process_s")}
     for leg in (cold, again):
         if "error" in leg:
             out["error"] = leg["error"]
+    out["second_process_log"] = again.get("parser_slab_log")      # (its NM_*_TIMING lines: where the parsers' and the search's time went)
+    more = {k: {"wall_s": v.get("wall_s"), "phases": v.get("phases"), "log": v.get("parser_slab_log")} for k, v in legs.items() if k not in ("cold", "again")}
+    if more:
+        out["other_legs"] = more                                   # (NM_BENCH_CLI1G_LEGS: builder probes)
     par = full.get("parity") or {}
     out["parity"] = {"bins": len(par.get("bins", [])), "byte_equal_to_the_oracle_pipeline": par.get("byte_equal_to_the_oracle_pipeline"),
                      "oracle_rows": par.get("oracle_rows"), "oracle_s": par.get("oracle_s")}

@@ -34,6 +34,7 @@
 #include "nmbed_parse.h"
 #include "nmbgzf.h"
 #include "nmscan_internal.h"
+#include "nmres.h"
 
 using namespace nmdetail;
 
@@ -799,33 +800,41 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     unsigned int *d_counters = nullptr;           // [0] patches, [1] runs
     uint4 *d_patch = nullptr;
     void *d_scan_tmp = nullptr;
-    hipStream_t copy_stream = nullptr;
+    // the ctx's copy stream (idle during this call; a stream of its own only if the ctx has none: a new stream costs 10 - 15 ms, nmres.h)
+    hipStream_t copy_stream = getenv("NM_OWN_COPY_STREAM") ? nullptr : c->copy_stream;        // (A/B: a stream of its own, as before round 6)
+    const bool own_copy_stream = copy_stream == nullptr;
     hipEvent_t h2d_done[RING] = {nullptr, nullptr, nullptr}, parsed[2] = {nullptr, nullptr};
     std::vector<void *> dev_tmp;
     struct Cleanup {
-        uint8_t **h; uint8_t **d; std::vector<void *> &tmp; hipStream_t &cs; hipEvent_t *e1; hipEvent_t *e2; nm_ctx *c;
+        uint8_t **h; uint8_t **d; std::vector<void *> &tmp; hipStream_t &cs; bool own; hipEvent_t *e1; hipEvent_t *e2; nm_ctx *c;
         ~Cleanup() {
             (void)hipStreamSynchronize(c->stream);
             if (cs) (void)hipStreamSynchronize(cs);
-            for (int i = 0; i < RING; ++i) { if (h[i]) (void)hipHostFree(h[i]); if (e1[i]) (void)hipEventDestroy(e1[i]); }
+            for (int i = 0; i < RING; ++i) { nmres::pinned_give(h[i]); if (e1[i]) (void)hipEventDestroy(e1[i]); }      // (kept for the next parser: nmres.h)
             for (int i = 0; i < 2; ++i) { if (d[i]) (void)dev_free(d[i]); if (e2[i]) (void)hipEventDestroy(e2[i]); }
             for (void *p : tmp) (void)dev_free(p);
-            if (cs) (void)hipStreamDestroy(cs);
+            if (cs && own) (void)hipStreamDestroy(cs);
         }
-    } cleanup{h_ring, d_slab, dev_tmp, copy_stream, h2d_done, parsed, c};
+    } cleanup{h_ring, d_slab, dev_tmp, copy_stream, own_copy_stream, h2d_done, parsed, c};
     const uint64_t slab_cap = dev_inflate ? inf_text_cap + CARRY_CAP + 64 : std::min<uint64_t>(SLAB_BYTES, std::max<uint64_t>(n, 1));
     const uint32_t max_blocks = (uint32_t)((slab_cap + BLOCK_BYTES - 1) / BLOCK_BYTES);
     const uint64_t max_lines = slab_cap / 2 + 1;                          // a non-empty line and its '\n'
     if (n_slabs) {
-        for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(hipHostMalloc((void **)&h_ring[i], slab_cap, hipHostMallocDefault));
+        for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(nmres::pinned_take((void **)&h_ring[i], slab_cap));
         for (int i = 0; i < 2 && (size_t)i < n_slabs; ++i) HIP_TRY(dev_malloc(&d_slab[i], slab_cap + 128));
         for (int i = 0; i < RING; ++i) HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&parsed[i], hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        if (!copy_stream) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     }
+    const bool alloc_timing = getenv("NM_BED_TIMING") != nullptr;
     auto tmp_alloc = [&](void **p, size_t bytes) -> hipError_t {
+        const double t0 = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
         const hipError_t e = device_alloc(p, std::max<size_t>(bytes, 16));
         if (e == hipSuccess) dev_tmp.push_back(*p);
+        if (alloc_timing) {
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            if (dt > 0.003) fprintf(stderr, "[bed] an allocation of %.3f GB took %.3f s\n", (double)bytes / 1e9, dt);
+        }
         return e;
     };
     // (line starts of a slab: worst case one per two bytes is absurd for a pileup; sized for lines of >= 16 bytes, checked)
@@ -897,6 +906,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     // as soon as the line count is back on the host
     auto parse_text = [&](const uint8_t *d_text, uint64_t len, uint64_t text_base, double grow_hint, const std::function<void()> &counted) -> int {
         const uint32_t nblk = (uint32_t)((len + BLOCK_BYTES - 1) / BLOCK_BYTES);
+        auto clock_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tp0 = alloc_timing ? clock_s() : 0.0;
         hipLaunchKernelGGL(bed_count_kernel, dim3(nblk), dim3(256), 0, c->stream, d_text, len, d_block_cnt);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(d_block_cnt + nblk, 0, 4, c->stream));
@@ -904,6 +915,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         uint32_t n_lines = 0;
         HIP_TRY(hipMemcpyAsync(&n_lines, d_block_off + nblk, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        const double tp1 = alloc_timing ? clock_s() : 0.0;
         counted();
         if (n_lines > line_cap) return fail_row(fail(NM_EINVAL, "%s: lines shorter than 16 bytes are no bedMethyl rows", path));
         if (n_lines > line_have) {                                    // (device-inflate slabs: the arrays follow the line count)
@@ -916,8 +928,12 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         // regrow is a fresh allocation (scrubbed by the driver when the memory was used before) plus a copy
         uint64_t want = b->n_rows + n_lines;
         if (grow_hint > 0) want = std::max<uint64_t>(want, (uint64_t)((double)n_lines * grow_hint * 1.03) + n_lines);
+        const double tp2 = alloc_timing ? clock_s() : 0.0;
         int rc = grow(b, want, c->stream);
         if (rc) return rc;
+        if (alloc_timing && n_parsed == 0)
+            fprintf(stderr, "[bed] first slab's parse: line count known after %.3f s, line arrays %.3f s, columns for %llu rows %.3f s\n", tp1 - tp0, tp2 - tp1,
+                    (unsigned long long)want, clock_s() - tp2);
         if (n_lines) {
             hipLaunchKernelGGL(bed_starts_kernel, dim3(nblk), dim3(256), 0, c->stream, d_text, len, d_block_off, d_line_start);
             BedOut o{d_hash, b->d_position, b->d_mod, b->d_strand, b->d_frac, b->d_nvalid, d_first_error, d_counters, d_patch};
@@ -972,8 +988,12 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         uint8_t *d_cmp_comp[NC] = {nullptr, nullptr, nullptr}, *d_cmp_scratch[NC] = {nullptr, nullptr, nullptr}, *d_cmp_tok[NC] = {nullptr, nullptr, nullptr};
         InfPiece *d_cmp_pieces[NC] = {nullptr, nullptr, nullptr};
         InfTokMeta *d_cmp_meta[NC] = {nullptr, nullptr, nullptr};
+        const bool timing = getenv("NM_BED_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_alloc0 = now();
         for (int b = 0; b < n_txt; ++b) HIP_TRY(tmp_alloc((void **)&d_text[b], slab_cap + 128));
         if (n_txt == 1) d_text[1] = d_text[0];
+        const double t_alloc_text = now();
         for (int b = 0; b < n_cmp; ++b) {
             HIP_TRY(tmp_alloc((void **)&d_cmp_comp[b], inf_comp_cap + INF_OVERRUN));     // (what a lane can read past a damaged stream before it notices)
             HIP_TRY(tmp_alloc((void **)&d_cmp_scratch[b], std::max<size_t>(max_partial, 1) << 16));
@@ -987,16 +1007,19 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(tmp_alloc((void **)&d_tail, 8 * NC));
         HIP_TRY(hipMemsetAsync(d_status, 0, 4, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        const double t_alloc_sets = now();
         uint8_t *h_chunk[2] = {nullptr, nullptr};
         hipEvent_t chunk_done[2] = {nullptr, nullptr}, parsed_ev[2] = {nullptr, nullptr}, inflated[NC] = {nullptr, nullptr, nullptr};
         // One inflate stream per set: a slab's phase 1, phase 2, CRC-32 and tail kernels follow each other on its own stream; the kernels of
         // neighbouring slabs run side by side as far as the device has room (three phase-1 workgroups per CU leave LDS for six phase-2 waves)
         hipStream_t inf_streams[NC] = {nullptr, nullptr, nullptr};
+        int n_inf = 1, inf_priority = 0;
+        bool inf_with_priority = false;
         struct Pinned { uint8_t **h; hipEvent_t *e, *e2, *e3; hipStream_t &cs; hipStream_t *is; ~Pinned() {
             if (cs) (void)hipStreamSynchronize(cs);
             for (int i = 0; i < NC; ++i) if (is[i]) (void)hipStreamSynchronize(is[i]);
             for (int i = 0; i < 2; ++i) {
-                if (h[i]) (void)hipHostFree(h[i]);
+                nmres::pinned_give(h[i]);
                 if (e[i]) (void)hipEventDestroy(e[i]);
                 if (e3[i]) (void)hipEventDestroy(e3[i]);
             }
@@ -1012,22 +1035,35 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             // are the right thing to give way to copies and parse kernels in any case.
             int least = 0, greatest = 0;
             const bool prio = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest && getenv("NM_BED_FLAT_PRIORITY") == nullptr;
-            const int n_inf = getenv("NM_BED_ONE_INFLATE_STREAM") ? 1 : n_cmp;        // (A/B: the slabs' kernels one after the other)
-            for (int i = 0; i < n_inf; ++i) {
-                if (prio) HIP_TRY(hipStreamCreateWithPriority(&inf_streams[i], hipStreamNonBlocking, least));
-                else HIP_TRY(hipStreamCreateWithFlags(&inf_streams[i], hipStreamNonBlocking));
-            }
+            n_inf = getenv("NM_BED_ONE_INFLATE_STREAM") ? 1 : n_cmp;        // (A/B: the slabs' kernels one after the other)
+            inf_priority = prio ? least : 0;
+            inf_with_priority = prio;
+        }
+        // A new stream costs 9 - 15 ms (tools/alloc_costs_probe.hip): the first set's is made here, the others by the staging thread when it
+        // first gets to their set — while the first slab's phase 1 runs (NM_BED_EAGER_STREAMS=1: all of them here, as before)
+        auto make_inf_stream = [&](int i) -> int {
+            if (inf_streams[i] || i >= n_inf) return NM_OK;
+            if (inf_with_priority) HIP_TRY(hipStreamCreateWithPriority(&inf_streams[i], hipStreamNonBlocking, inf_priority));
+            else HIP_TRY(hipStreamCreateWithFlags(&inf_streams[i], hipStreamNonBlocking));
+            return NM_OK;
+        };
+        for (int i = 0; i < (getenv("NM_BED_EAGER_STREAMS") ? n_inf : 1); ++i) {
+            const int rcs = make_inf_stream(i);
+            if (rcs) return rcs;
         }
         auto inf_stream_of = [&](int set) { return inf_streams[set] ? inf_streams[set] : inf_streams[0]; };
         for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipHostMalloc((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16), hipHostMallocDefault));       // (a chunk is at most SLAB_BYTES = CHUNK of file)
+            HIP_TRY(nmres::pinned_take((void **)&h_chunk[i], std::min<uint64_t>(CHUNK, inf_comp_cap) + (1u << 16)));       // (a chunk is at most SLAB_BYTES = CHUNK of file)
             HIP_TRY(hipEventCreateWithFlags(&chunk_done[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&parsed_ev[i], hipEventDisableTiming));
         }
         for (int i = 0; i < NC; ++i) HIP_TRY(hipEventCreateWithFlags(&inflated[i], hipEventDisableTiming));
-        const bool timing = getenv("NM_BED_TIMING") != nullptr;
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        if (timing) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry\n", inf_slabs.size(), now() - t_begin); }
+        if (timing) {
+            (void)hipStreamSynchronize(c->stream);
+            fprintf(stderr, "[bed] device inflate: %zu slabs, buffers allocated %.3f s after entry (%.3f s before the first allocation; %d text buffers of %.2f GB %.3f s, "
+                            "%d sets of %.2f GB compressed + %.2f GB tokens %.3f s, streams + pinned chunks %.3f s)\n", inf_slabs.size(), now() - t_begin, t_alloc0 - t_begin,
+                    n_txt, (double)slab_cap / 1e9, t_alloc_text - t_alloc0, n_cmp, (double)inf_comp_cap / 1e9, (double)max_tok / 1e9, t_alloc_sets - t_alloc_text, now() - t_alloc_sets);
+        }
         std::vector<InfPiece> hp[NC];
         const CrcConsts crc_k = crc_consts();
 #ifdef NM_BED_PROBES                                                    // (timing probe builds only: what the check costs)
@@ -1050,6 +1086,10 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         auto stage_front = [&](size_t si) -> int {
             const InfSlab &sl = inf_slabs[si];
             const int cs = (int)(si % (size_t)n_cmp);
+            {
+                const int rcs = make_inf_stream(cs);                     // (the set's first slab: its stream is made now)
+                if (rcs) return rcs;
+            }
             const hipStream_t inf_stream = inf_stream_of(cs);
             // piece table of the slab: packed compressed offsets, where the text goes (behind the carry area)
             std::vector<InfPiece> &pieces = hp[cs];
@@ -1184,12 +1224,14 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             return NM_OK;
         };
         uint64_t carry = 0;                                             // bytes of an unfinished line in front of the slab
+        const double t_loop0 = now();
         for (size_t k = 0; k < std::min<size_t>(2, n_inf_slabs); ++k) {   // (both text buffers are free: the first two back halves at once)
             int rc0 = wait_front(k);
             if (rc0) return rc0;
             rc0 = stage_back(k);
             if (rc0) return rc0;
         }
+        const double t_slabs0 = now();
         for (size_t si = 0; si < inf_slabs.size(); ++si) {
             const InfSlab &sl = inf_slabs[si];
             const int cs = (int)(si % (size_t)n_cmp), tb = (int)(si % (size_t)n_txt);
@@ -1248,7 +1290,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         stager.join();
         t_read += t_read_staging;
         b->read_beside = true;
+        const double t_loop1 = now();
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (timing)
+            fprintf(stderr, "[bed] %.3f s after entry: first front half asked for; the first two back halves queued %.3f s later; all slabs queued %.3f s after that; "
+                            "the last parse kernels done %.3f s later\n", t_loop0 - t_begin, t_slabs0 - t_loop0, t_loop1 - t_slabs0, now() - t_loop1);
     }
     for (size_t k = 0; k < n_slabs; ++k) {
         const uint64_t len = cut[k + 1] - cut[k];
@@ -1299,6 +1345,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     };
     auto field = [&](uint64_t line, int k, const char **fb, const char **fe) { field_in(line_buf, line, k, fb, fe); };
     // ---- runs of equal contig names -> names, ids, the contig column
+    const double t_after_slabs = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (b->n_rows) {
         unsigned int n_runs = 0;
         HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1404,6 +1451,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     for (auto &s_ : b->names) b->name_ptrs.push_back(s_.c_str());
     b->t_read = t_read;
     b->t_total = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_begin;
+    if (alloc_timing) fprintf(stderr, "[bed] %.3f s in the parser; the runs, names and patched rows after the last slab took %.3f s\n", b->t_total, b->t_total - (t_after_slabs - t_begin));
     guard.keep = true;
     *out = b;
     return NM_OK;

@@ -29,6 +29,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "nmscan_internal.h"
+#include "nmres.h"
 
 using namespace nmdetail;
 
@@ -303,18 +304,19 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     constexpr int RING = 3;
     uint8_t *h_ring[RING] = {nullptr, nullptr, nullptr};
     hipEvent_t h2d_done[RING] = {nullptr, nullptr, nullptr};
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;                 // the ctx's copy stream (idle during this call); one of its own only if the ctx has none
+    bool own_copy_stream = false;
     std::vector<void *> dev_tmp;
     struct Cleanup {
-        uint8_t **h; hipEvent_t *e; hipStream_t &cs; std::vector<void *> &tmp; nm_ctx *c;
+        uint8_t **h; hipEvent_t *e; hipStream_t &cs; bool &own; std::vector<void *> &tmp; nm_ctx *c;
         ~Cleanup() {
             (void)hipStreamSynchronize(c->stream);
             if (cs) (void)hipStreamSynchronize(cs);
-            for (int i = 0; i < RING; ++i) { if (h[i]) (void)hipHostFree(h[i]); if (e[i]) (void)hipEventDestroy(e[i]); }
+            for (int i = 0; i < RING; ++i) { nmres::pinned_give(h[i]); if (e[i]) (void)hipEventDestroy(e[i]); }      // (kept for the next parser: nmres.h)
             for (void *p : tmp) (void)dev_free(p);
-            if (cs) (void)hipStreamDestroy(cs);
+            if (cs && own) (void)hipStreamDestroy(cs);
         }
-    } cleanup{h_ring, h2d_done, copy_stream, dev_tmp, c};
+    } cleanup{h_ring, h2d_done, copy_stream, own_copy_stream, dev_tmp, c};
     auto tmp_alloc = [&](void **p, size_t bytes) -> hipError_t {
         const hipError_t e = device_alloc(p, std::max<size_t>(bytes, 16));
         if (e == hipSuccess) dev_tmp.push_back(*p);
@@ -322,11 +324,17 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     };
     uint8_t *d_text = nullptr;
     HIP_TRY(tmp_alloc((void **)&d_text, (size_t)n_tiles * FA_TILE));
+    const double t_alloc_dev = now_s();
     const size_t n_slabs = (size_t)((n + FA_SLAB - 1) / FA_SLAB);
     const uint64_t slab_cap = std::min<uint64_t>(FA_SLAB, n);
-    for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(hipHostMalloc((void **)&h_ring[i], slab_cap, hipHostMallocDefault));
+    // (+ 64 KB: the size of the pileup parser's chunks, which take these buffers over from the cache)
+    for (int i = 0; i < RING && (size_t)i < n_slabs; ++i) HIP_TRY(nmres::pinned_take((void **)&h_ring[i], slab_cap + (1u << 16)));
     for (int i = 0; i < RING; ++i) HIP_TRY(hipEventCreateWithFlags(&h2d_done[i], hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    copy_stream = getenv("NM_OWN_COPY_STREAM") ? nullptr : c->copy_stream;        // (A/B: a stream of its own, as before round 6)
+    if (!copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        own_copy_stream = true;
+    }
     const double t_alloc = now_s();
     std::atomic<bool> read_failed{false};
     std::mutex mu;
@@ -472,8 +480,9 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     }
     f->seconds = now_s() - t_begin;
     if (timing)
-        fprintf(stderr, "[fasta] %.2f GB, %u records: buffers %.3f s, file -> device %.3f s (a reader spent %.3f s in pread), kernels + tables %.3f s\n", n / 1e9, n_rec,
-                t_alloc - t_begin, t_copied - t_alloc, t_read, now_s() - t_copied);
+        fprintf(stderr, "[fasta] %.2f GB, %u records: buffers %.3f s (the text's device buffer %.3f s, pinned ring + stream %.3f s), file -> device %.3f s "
+                        "(a reader spent %.3f s in pread), kernels + tables %.3f s\n", n / 1e9, n_rec,
+                t_alloc - t_begin, t_alloc_dev - t_begin, t_alloc - t_alloc_dev, t_copied - t_alloc, t_read, now_s() - t_copied);
     guard.keep = true;
     *out = f;
     return NM_OK;

@@ -1,4 +1,5 @@
-// nmpool — a block cache behind nm_set_device_allocator for processes that bring no pool of their own (the command line).
+// nmpool — a block cache behind nm_set_device_allocator for processes that bring no pool of their own (the command line), and the
+// file parsers' pinned host buffers (nmres.h, at the end).
 //
 // Why: memory another process used before is SCRUBBED by the driver when it is handed out again, at 7-30 GB/s — the first part of
 // the pre-filters waited 190 ms for its 1.5 GB of state planes (NM_INGEST_TIMING at 1 Gbp, profiles/r5/cli_1gbp.json) right after the
@@ -8,12 +9,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/nmscan.h"
+#include "nmres.h"
 
 int nm_set_error(int code, const char *fmt, ...);
 
@@ -135,7 +138,84 @@ bool g_installed = false;
 int cache_alloc(void *, void **ptr, size_t bytes) { return g_cache.alloc(ptr, bytes); }
 int cache_free(void *, void *ptr) { return g_cache.release(ptr); }
 
+// ---- pinned host buffers of the file parsers (nmres.h)
+struct PinnedCache {
+    struct Buf { void *p; size_t size; };
+    std::mutex mu;
+    std::vector<Buf> idle;
+    std::unordered_map<void *, size_t> out;              // buffers handed out: their true size
+    size_t idle_bytes = 0;
+};
+PinnedCache g_pinned;
+
 }  // namespace
+
+namespace nmres {
+
+hipError_t pinned_take(void **p, size_t bytes) {
+    *p = nullptr;
+    const size_t want = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);      // whole MB: the parsers' sizes differ by a few KB
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pinned.idle.size(); ++i)
+            if (g_pinned.idle[i].size >= want && g_pinned.idle[i].size <= 2 * want && (best < 0 || g_pinned.idle[i].size < g_pinned.idle[best].size)) best = i;
+        if (best >= 0) {
+            const PinnedCache::Buf b = g_pinned.idle[best];
+            g_pinned.idle.erase(g_pinned.idle.begin() + best);
+            g_pinned.idle_bytes -= b.size;
+            g_pinned.out[b.p] = b.size;
+            *p = b.p;
+            return hipSuccess;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+    if (e != hipSuccess) {                                // pinned memory is short: give the idle buffers back and try once more
+        (void)hipGetLastError();
+        pinned_trim();
+        e = hipHostMalloc(&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+    }
+    std::lock_guard<std::mutex> lk(g_pinned.mu);
+    g_pinned.out[q] = want;
+    *p = q;
+    return hipSuccess;
+}
+
+void pinned_give(void *p) {
+    if (!p) return;
+    static const bool keep = getenv("NM_NO_PINNED_CACHE") == nullptr;        // (A/B: every buffer is freed at once)
+    if (keep) {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        auto it = g_pinned.out.find(p);
+        if (it != g_pinned.out.end()) {
+            const size_t size = it->second;
+            g_pinned.out.erase(it);
+            if (g_pinned.idle_bytes + size <= PINNED_KEEP_BYTES) {
+                g_pinned.idle.push_back({p, size});
+                g_pinned.idle_bytes += size;
+                return;
+            }
+        }
+    } else {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        g_pinned.out.erase(p);
+    }
+    (void)hipHostFree(p);
+}
+
+void pinned_trim() {
+    std::vector<PinnedCache::Buf> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        drop.swap(g_pinned.idle);
+        g_pinned.idle_bytes = 0;
+    }
+    for (const PinnedCache::Buf &b : drop) (void)hipHostFree(b.p);
+}
+
+}  // namespace nmres
 
 extern "C" {
 
@@ -173,6 +253,7 @@ int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]) {
         g_installed = false;
     }
     g_cache.trim(0);
+    nmres::pinned_trim();
     return NM_OK;
 }
 
