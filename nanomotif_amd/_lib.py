@@ -40,6 +40,8 @@ POST_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint3
                             C.POINTER(C.c_int64))
 
 _lib = None
+early_engine_thread = None     # __main__.py: the thread that creates the engine context while the interpreter imports ...
+early_engine = None            # ... and what it made: (device, nm_ctx *, block cache installed); main.find_motifs_bin adopts it
 loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
 
 

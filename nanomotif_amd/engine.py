@@ -388,10 +388,15 @@ class ScanEngine:
     """One engine per GPU / process.  Mirrors what ``motif_model_bin`` needs (find_motifs_bin.py:1265-1283):
     the bin's contig sequences and the (bin, mod_type) pileup, but resident in HBM across calls."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, ctx=None):
+        """``ctx``: an ``nm_ctx *`` (ctypes.c_void_p) on ``device`` that somebody else created — the engine takes it over and destroys it
+        in ``close`` (the command line makes it on a thread while the interpreter still imports, __main__.py)."""
         self.lib = _lib.load()
-        self.ctx = C.c_void_p()
-        _lib.check(self.lib.nm_ctx_create(int(device), C.byref(self.ctx)))
+        if ctx is not None:
+            self.ctx = ctx
+        else:
+            self.ctx = C.c_void_p()
+            _lib.check(self.lib.nm_ctx_create(int(device), C.byref(self.ctx)))
         self.device = int(device)
         self.contig_index = {}
         self.contig_names = []

@@ -97,11 +97,19 @@ def find_motifs_bin(args):
             # large device blocks stay with the process when the library frees them (nm_block_cache: memory another process used is
             # scrubbed by the driver on its way back in — the pre-filters' state planes waited 0.19 s for that at 1 Gbp — and hipFree
             # synchronises the device); NANOMOTIF_BLOCK_CACHE_GB=0 turns it off
+            from . import _lib as _l
+            early = None
+            if _l.early_engine_thread is not None:       # (__main__.py: the context may exist already, made beside the imports)
+                _l.early_engine_thread.join()
+                _l.early_engine_thread, early, _l.early_engine = None, _l.early_engine, None
             cache_gb = float(os.environ.get("NANOMOTIF_BLOCK_CACHE_GB", "16"))
-            if cache_gb > 0:
-                from . import _lib as _l
+            if early is not None and early[0] != device:
+                _l.load().nm_ctx_destroy(early[1])       # (another --device than the command line showed at a glance)
+                early = None
+            if cache_gb > 0 and not (early is not None and early[2]):
                 _l.use_block_cache(int(cache_gb * (1 << 30)))
-            started["eng"] = ScanEngine(device)
+            started["eng"] = ScanEngine(device, ctx=early[1]) if early is not None else ScanEngine(device)
+            TIMINGS["engine_context_made_beside_the_imports"] = early is not None
         except BaseException as e:               # re-raised on the main thread below
             started["error"] = e
     starter = threading.Thread(target=start_engine, name="nm-engine-start")

@@ -61,6 +61,13 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     assert len(pssm) == 4 and all(len(row.split(" ")) == 41 and all(len(x.split(".")[1]) == 4 for x in row.split(" ")) for row in pssm)
     assert abs(sum(float(row.split(" ")[0]) for row in pssm) - 1.0) < 1e-3
     assert open(f"{tmp}/out/temp/{b0}/motif_graph_a.gml").read().startswith("graph [\n  directed 1\n")
+    # the engine context of a single-rank command is made on a thread while the interpreter imports (__main__.py) and adopted by the run;
+    # NANOMOTIF_NO_EARLY_INIT=1 makes it the regular way: same table
+    import json
+    assert json.load(open(tmp + "/out/logs/timings.motif_discovery.json"))["engine_context_made_beside_the_imports"] is True
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_regular_start", "-t", "1"], env_extra={"NANOMOTIF_NO_EARLY_INIT": "1"})
+    assert json.load(open(tmp + "/out_regular_start/logs/timings.motif_discovery.json"))["engine_context_made_beside_the_imports"] is False
+    assert open(tmp + "/out_regular_start/bin-motifs.tsv").read() == got
 
     # bgzip'd pileup (needs its .tbi to be present like the reference) and -f bin FASTA files
     with open(tmp + "/pileup.bed", "rb") as f, gzip.open(tmp + "/pileup.bed.gz", "wb") as g:
