@@ -362,15 +362,28 @@ __global__ __launch_bounds__(256) void bed_parse_kernel(const uint8_t *__restric
 // line starts of a slab are scratch).  prev_in / prev_out: the hash of the last row of the previous / of this slab.
 struct BedRun { unsigned long long row, off; };
 
+// A run's contig name goes along in a 64-byte slot (length, then up to 63 bytes; length 0xFF: longer than that — the host reads it from the
+// file): the host used to fetch every run's name from the file — for a bgzip pileup one inflated BGZF block per run, 0.09 s for the 10 000
+// contigs of a 1 Gbp metagenome (NM_BED_TIMING, round 6).
+constexpr uint32_t RUN_NAME_SLOT = 64;
 __global__ void bed_runs_kernel(const uint64_t *__restrict__ hash, const uint32_t *__restrict__ line_start, uint32_t n_lines, uint64_t row0,
                                 uint64_t slab_file_off, int first_slab, const unsigned long long *__restrict__ prev_in,
-                                unsigned long long *__restrict__ prev_out, unsigned int *n_runs, BedRun *runs, uint32_t cap) {
+                                unsigned long long *__restrict__ prev_out, unsigned int *n_runs, BedRun *runs, uint32_t cap,
+                                const uint8_t *__restrict__ text, uint64_t len, uint8_t *__restrict__ run_names, uint32_t name_cap) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_lines) return;
     const unsigned long long before = i ? hash[i - 1] : *prev_in;
     if ((i == 0 && first_slab) || hash[i] != before) {
         const unsigned int k = atomicAdd(n_runs, 1u);
         if (k < cap) runs[k] = BedRun{row0 + i, slab_file_off + line_start[i]};
+        if (k < name_cap) {
+            uint8_t *slot = run_names + (size_t)k * RUN_NAME_SLOT;
+            const uint8_t *p = text + line_start[i];
+            const uint64_t room = len - line_start[i];
+            uint32_t n = 0;
+            while (n < RUN_NAME_SLOT - 1 && n < room && p[n] != '\t' && p[n] != '\n') { slot[1 + n] = p[n]; ++n; }
+            slot[0] = (n < room && (p[n] == '\t' || p[n] == '\n')) ? (uint8_t)n : (uint8_t)0xFF;
+        }
     }
     if (i == n_lines - 1) *prev_out = hash[i];
 }
@@ -850,6 +863,9 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
     HIP_TRY(tmp_alloc((void **)&d_patch, (size_t)PATCH_CAP * sizeof(uint4)));
     if (line_have) HIP_TRY(tmp_alloc((void **)&d_hash, line_have * 8));
     HIP_TRY(tmp_alloc((void **)&d_runs, (size_t)RUN_CAP * sizeof(BedRun)));
+    constexpr uint32_t RUN_NAME_CAP = 1u << 20;           // runs whose names come back from the device (64 MB); further ones are read from the file
+    uint8_t *d_run_names = nullptr;
+    HIP_TRY(tmp_alloc((void **)&d_run_names, (size_t)RUN_NAME_CAP * RUN_NAME_SLOT));
     HIP_TRY(tmp_alloc((void **)&d_prev, 16));
     size_t scan_bytes = 0;
     HIP_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, d_block_cnt, d_block_off, 0u, (size_t)max_blocks + 1, rocprim::plus<unsigned int>(), c->stream));
@@ -940,7 +956,8 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             hipLaunchKernelGGL(bed_parse_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_text, len, d_line_start, n_lines, b->n_rows,
                                text_base, o);
             hipLaunchKernelGGL(bed_runs_kernel, dim3((n_lines + 255) / 256), dim3(256), 0, c->stream, d_hash, d_line_start, n_lines, b->n_rows, text_base,
-                               first_rows ? 1 : 0, d_prev + (n_parsed & 1), d_prev + ((n_parsed + 1) & 1), d_counters + 1, d_runs, RUN_CAP);
+                               first_rows ? 1 : 0, d_prev + (n_parsed & 1), d_prev + ((n_parsed + 1) & 1), d_counters + 1, d_runs, RUN_CAP,
+                               d_text, len, d_run_names, RUN_NAME_CAP);
             HIP_TRY(hipGetLastError());
             first_rows = false;
             n_parsed += 1;
@@ -1351,16 +1368,23 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (n_runs > RUN_CAP) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, RUN_CAP);
-        std::vector<BedRun> runs(n_runs);
-        HIP_TRY(hipMemcpy(runs.data(), d_runs, (size_t)n_runs * sizeof(BedRun), hipMemcpyDeviceToHost));
-        std::sort(runs.begin(), runs.end(), [](const BedRun &x, const BedRun &y) { return x.row < y.row; });
+        std::vector<BedRun> runs_found(n_runs);
+        HIP_TRY(hipMemcpy(runs_found.data(), d_runs, (size_t)n_runs * sizeof(BedRun), hipMemcpyDeviceToHost));
+        const unsigned int n_named = std::min<unsigned int>(n_runs, RUN_NAME_CAP);
+        std::vector<uint8_t> names_found((size_t)n_named * RUN_NAME_SLOT);
+        if (n_named) HIP_TRY(hipMemcpy(names_found.data(), d_run_names, names_found.size(), hipMemcpyDeviceToHost));
+        std::vector<unsigned int> order(n_runs);                  // the runs were recorded in the order the kernels' threads found them
+        for (unsigned int r = 0; r < n_runs; ++r) order[r] = r;
+        std::sort(order.begin(), order.end(), [&](unsigned int x, unsigned int y) { return runs_found[x].row < runs_found[y].row; });
         std::vector<unsigned long long> rows(n_runs), offs(n_runs);
-        for (unsigned int r = 0; r < n_runs; ++r) { rows[r] = runs[r].row; offs[r] = runs[r].off; }
+        for (unsigned int r = 0; r < n_runs; ++r) { rows[r] = runs_found[order[r]].row; offs[r] = runs_found[order[r]].off; }
         int rc = NM_OK;
         std::unordered_map<std::string, uint32_t> ids;
         b->run_row.assign(rows.begin(), rows.end());
         b->run_contig.resize(n_runs);
-        // the name of every run, read (and for bgzip: inflated) on several threads
+        // the name of every run: from its slot, or (longer than 63 bytes, beyond RUN_NAME_CAP, NM_BED_NAMES_FROM_FILE=1) read from the file —
+        // for bgzip: inflated — on several threads
+        const bool names_from_file = getenv("NM_BED_NAMES_FROM_FILE") != nullptr;          // (A/B and tests: every name read from the file)
         std::vector<std::string> run_names(n_runs);
         {
             const unsigned nt = n_runs >= 64 ? std::max(1u, threads) : 1u;
@@ -1369,6 +1393,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
                 pool.emplace_back([&, t] {
                     std::vector<char> buf;
                     for (unsigned int r = t; r < n_runs; r += nt) {
+                        const uint8_t *slot = order[r] < n_named && !names_from_file ? &names_found[(size_t)order[r] * RUN_NAME_SLOT] : nullptr;
+                        if (slot && slot[0] != 0xFF) {           // (the name came back with the run)
+                            run_names[r].assign(reinterpret_cast<const char *>(slot + 1), slot[0]);
+                            continue;
+                        }
                         const char *fb, *fe;
                         field_in(buf, offs[r], 0, &fb, &fe);
                         run_names[r].assign(fb, fe);

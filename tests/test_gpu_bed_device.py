@@ -128,6 +128,38 @@ def test_device_parser_equals_host_parser(tmp_path):
     eng.close()
 
 
+def test_contig_names_come_back_with_their_runs(tmp_path):
+    """A run's contig name travels from the parse kernels in a 64-byte slot (csrc/nmbedgpu.hip: bed_runs_kernel); names of 64 bytes and
+    more, and every name with NM_BED_NAMES_FROM_FILE=1, are read from the file (for bgzip: one inflated block per run) as before round 6.
+    Names of 1 / 62 / 63 / 64 / 65 / 300 bytes, non-ASCII UTF-8, a name that comes back later: both ways, text and bgzip, equal to the host reader."""
+    from helpers import write_bgzf_tabix
+    from nanomotif_amd.engine import ScanEngine
+    names = ["c", "n" * 62, "m" * 63, "k" * 64, "j" * 65, "contig_" + "x" * 293, "Ünï_cödé" * 7, "c"]
+    rest = "\ta\t9\t+\t0\t1\t255,0,0\t9\t80.00\t7\t2\t0\t0\t0\t0\t0"
+    lines = []
+    for k, nm in enumerate(names):
+        for pos in range(40 + 7 * k):
+            lines.append(f"{nm}\t{pos}\t{pos + 1}" + rest)
+    text = ("\n".join(lines) + "\n").encode()
+    path = str(tmp_path / "names.bed")
+    open(path, "wb").write(text)
+    write_bgzf_tabix(text, path + ".gz", block_size=3000)
+    eng = ScanEngine(0)
+    try:
+        for p in (path, path + ".gz"):
+            for env in (None, "1"):
+                if env:
+                    os.environ["NM_BED_NAMES_FROM_FILE"] = env
+                try:
+                    dev = _same_as_host(eng, p)
+                finally:
+                    os.environ.pop("NM_BED_NAMES_FROM_FILE", None)
+                assert dev.contig_names == names[:-1] and len(dev.run_contig) == len(names) and int(dev.run_contig[-1]) == 0
+                dev.close()
+    finally:
+        eng.close()
+
+
 def _columns(t, lut=None):
     if isinstance(t, pp.NativePileup):
         return {k: v.copy() for k, v in t.ingest_columns(np.arange(len(t.contig_names), dtype=np.uint32)).items()}
