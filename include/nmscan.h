@@ -73,6 +73,13 @@ int nm_set_device_allocator(nm_alloc_fn alloc, nm_free_fn free_fn, void *user);
  * back to the driver when a request of the cache fails; a block that came back is reused only behind a hipDeviceSynchronize — the
  * implicit synchronisation hipFree would have made — so the caller's contract is hipFree's: no work may still WRITE a block it frees. */
 int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]);
+/* The file parsers (nm_fasta_parse_device, nm_bed_parse_device*) move a file through pinned host buffers on the ctx's copy stream; the
+ * buffers are kept between calls (at most 160 MB idle; nm_block_cache(0, ...) releases them).  Pinning costs 0.17 ms per MB and the first
+ * transfer of a stream 7 - 17 ms (tools/alloc_costs_probe.hip): this call pays both ahead of time — `count` buffers of `bytes_each` pinned
+ * and parked in the cache, one small transfer each way on the copy stream — e.g. on the thread that created the ctx, while the caller is
+ * still busy elsewhere.  ctx NULL: the buffers only (any thread, any time after the library is loaded: the command line pins them on a
+ * second thread while the first one creates the ctx, beside the interpreter's imports).  Purely a warm-up: the parsers work without it. */
+int nm_warm_file_parsers(nm_ctx *ctx, uint64_t bytes_each, uint32_t count);
 
 /* Create / destroy an engine bound to HIP device `device`. */
 int nm_ctx_create(int device, nm_ctx **out);

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("NM_LIB", os.path.join(_HERE, "libnmscan.so"))   # NM_
 SYMBOLS = [
     "nm_abi_version", "nm_last_error", "nm_set_device_allocator", "nm_ctx_create", "nm_ctx_destroy", "nm_set_stream", "nm_set_score_lanes", "nm_sync", "nm_upload_contigs",
     "nm_upload_contigs_device", "nm_upload_pileup", "nm_upload_pileup_device", "nm_score_batch", "nm_score_batch_device", "nm_score_batch_wide", "nm_block_cache", "nm_hit_positions", "nm_stats",
-    "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_timing_intervals", "nm_parse_motifs",
+    "nm_last_kernel_ms", "nm_timing_reset", "nm_timing_total_ms", "nm_timing_intervals", "nm_warm_file_parsers", "nm_parse_motifs",
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
     "nm_comm_sync", "nm_comm_info", "nm_comm_destroy",
@@ -41,6 +41,7 @@ POST_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint3
 
 _lib = None
 early_engine_thread = None     # __main__.py: the thread that creates the engine context while the interpreter imports ...
+early_pin_thread = None        # ... the thread that pins the file parsers' host buffers meanwhile (nm_warm_file_parsers) ...
 early_engine = None            # ... and what it made: (device, nm_ctx *, block cache installed); main.find_motifs_bin adopts it
 loaded_with_torch = False      # torch's HIP runtime was in the process when the library was loaded (one runtime for both)
 
@@ -227,6 +228,7 @@ def _load_locked():
     lib.nm_comm_info.argtypes = [p, C.POINTER(C.c_int32)]
     lib.nm_comm_destroy.argtypes = [p]
     lib.nm_timing_total_ms.argtypes = [p, C.POINTER(C.c_double), u64p]
+    lib.nm_warm_file_parsers.argtypes = [p, C.c_uint64, C.c_uint32]
     lib.nm_timing_intervals.argtypes = [p, p, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double), u64p]
     for s in SYMBOLS:
         if s != "nm_last_error":

@@ -401,6 +401,12 @@ __global__ void bed_fill_contig_kernel(uint64_t n_rows, const unsigned long long
     contig[i] = run_id[lo];
 }
 
+// device -> pinned host memory by a kernel (16-byte words): the first copy-engine transfer in that direction on a stream costs ~7 ms
+__global__ void bed_copy_out_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
 __global__ void bed_patch_kernel(uint32_t n, const unsigned long long *__restrict__ row, const int8_t *__restrict__ mod, const double *__restrict__ frac,
                                  const uint8_t *__restrict__ what, int8_t *__restrict__ out_mod, double *__restrict__ out_frac) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1368,11 +1374,25 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (n_runs > RUN_CAP) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, RUN_CAP);
-        std::vector<BedRun> runs_found(n_runs);
-        HIP_TRY(hipMemcpy(runs_found.data(), d_runs, (size_t)n_runs * sizeof(BedRun), hipMemcpyDeviceToHost));
+        const double tt0 = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        // (both tables through ONE pinned buffer and the ctx stream: a blocking hipMemcpy into pageable memory was 8 ms each — the runtime
+        //  pins the destination on the fly)
         const unsigned int n_named = std::min<unsigned int>(n_runs, RUN_NAME_CAP);
-        std::vector<uint8_t> names_found((size_t)n_named * RUN_NAME_SLOT);
-        if (n_named) HIP_TRY(hipMemcpy(names_found.data(), d_run_names, names_found.size(), hipMemcpyDeviceToHost));
+        const size_t runs_bytes = (size_t)n_runs * sizeof(BedRun), names_bytes = (size_t)n_named * RUN_NAME_SLOT;
+        struct PinnedStage { void *p = nullptr; ~PinnedStage() { nmres::pinned_give(p); } } stage;
+        HIP_TRY(nmres::pinned_take(&stage.p, runs_bytes + names_bytes + 64));
+        const double tta = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        hipLaunchKernelGGL(bed_copy_out_kernel, dim3((unsigned)((runs_bytes / 16 + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(d_runs),
+                           static_cast<uint4 *>(stage.p), runs_bytes / 16);
+        if (n_named)
+            hipLaunchKernelGGL(bed_copy_out_kernel, dim3((unsigned)((names_bytes / 16 + 255) / 256)), dim3(256), 0, c->stream, reinterpret_cast<const uint4 *>(d_run_names),
+                               reinterpret_cast<uint4 *>(static_cast<uint8_t *>(stage.p) + runs_bytes), names_bytes / 16);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const double ttb = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
+        if (alloc_timing) fprintf(stderr, "[bed] runs: pinned buffer %.4f s, copies back %.4f s\n", tta - tt0, ttb - tta);
+        const BedRun *runs_found = static_cast<const BedRun *>(stage.p);
+        const uint8_t *names_found = static_cast<const uint8_t *>(stage.p) + runs_bytes;
         std::vector<unsigned int> order(n_runs);                  // the runs were recorded in the order the kernels' threads found them
         for (unsigned int r = 0; r < n_runs; ++r) order[r] = r;
         std::sort(order.begin(), order.end(), [&](unsigned int x, unsigned int y) { return runs_found[x].row < runs_found[y].row; });
@@ -1415,11 +1435,13 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             b->run_contig[r] = it->second;
         }
         b->run_row.push_back(b->n_rows);
+        const double tt1 = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
         uint32_t *d_run_id = nullptr;
         HIP_TRY(tmp_alloc((void **)&d_run_id, (size_t)n_runs * 4));
         HIP_TRY(dev_malloc(&b->d_file_contig, b->n_rows * 4));
         HIP_TRY(dev_malloc(&b->d_contig, b->n_rows * 4));
         HIP_TRY(tmp_alloc((void **)&d_run_row, (size_t)n_runs * 8));
+        const double tt2 = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
         HIP_TRY(hipMemcpyAsync(d_run_row, rows.data(), (size_t)n_runs * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_run_id, b->run_contig.data(), (size_t)n_runs * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(bed_fill_contig_kernel, dim3((unsigned)((b->n_rows + 255) / 256)), dim3(256), 0, c->stream, b->n_rows, d_run_row, d_run_id, n_runs,
@@ -1430,6 +1452,11 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         unsigned int np = 0;
         HIP_TRY(hipMemcpyAsync(&np, d_counters, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        if (alloc_timing) {
+            const double tt3 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            fprintf(stderr, "[bed] after the last slab: %u runs and their names %.3f s, the two contig columns allocated %.3f s, filled (kernel + wait) %.3f s, %u rows for the host's routines\n",
+                    n_runs, tt1 - tt0, tt2 - tt1, tt3 - tt2, np);
+        }
         if (np > PATCH_CAP) return fail(NM_ERANGE, "%s: more than %u rows need the host parser (unusual mod codes / number formats): use nm_bed_open", path, PATCH_CAP);
         if (np) {
             std::vector<uint4> patch(np);

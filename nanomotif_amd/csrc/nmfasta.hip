@@ -488,6 +488,27 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     return NM_OK;
 }
 
+int nm_warm_file_parsers(nm_ctx *c, uint64_t bytes_each, uint32_t count) {
+    if (count > 8 || bytes_each > (256ull << 20)) return fail(NM_ERANGE, "nm_warm_file_parsers: at most 8 buffers of 256 MB");
+    if (c) HIP_TRY(hipSetDevice(c->device));
+    void *bufs[8] = {nullptr};
+    int rc = NM_OK;
+    for (uint32_t i = 0; i < count && rc == NM_OK; ++i)
+        if (nmres::pinned_take(&bufs[i], (size_t)bytes_each) != hipSuccess) rc = fail(NM_ENOMEM, "cannot pin %llu bytes of host memory", (unsigned long long)bytes_each);
+    if (rc == NM_OK && count && bytes_each >= 64 && c && c->copy_stream) {       // one transfer each way: the copy engines' queues of the stream come up now
+        void *d = nullptr;
+        if (device_alloc(&d, 64) == hipSuccess) {
+            hipError_t e = hipMemcpyAsync(d, bufs[0], 64, hipMemcpyHostToDevice, c->copy_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(bufs[0], d, 64, hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+            (void)dev_free(d);
+            if (e != hipSuccess) rc = fail(NM_EHIP, "nm_warm_file_parsers: %s", hipGetErrorString(e));
+        }
+    }
+    for (uint32_t i = 0; i < count; ++i) nmres::pinned_give(bufs[i]);
+    return rc;
+}
+
 int nm_fastadev_shape(nm_fastadev *f, uint32_t *n_records, uint64_t *total_bp, double times[2]) {
     if (!f || !n_records || !total_bp) return fail(NM_EINVAL, "NULL argument");
     *n_records = (uint32_t)f->names.size();

@@ -102,6 +102,9 @@ def find_motifs_bin(args):
             if _l.early_engine_thread is not None:       # (__main__.py: the context may exist already, made beside the imports)
                 _l.early_engine_thread.join()
                 _l.early_engine_thread, early, _l.early_engine = None, _l.early_engine, None
+                if _l.early_pin_thread is not None:
+                    _l.early_pin_thread.join()
+                    _l.early_pin_thread = None
             cache_gb = float(os.environ.get("NANOMOTIF_BLOCK_CACHE_GB", "16"))
             if early is not None and early[0] != device:
                 _l.load().nm_ctx_destroy(early[1])       # (another --device than the command line showed at a glance)
