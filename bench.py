@@ -498,6 +498,8 @@ def run_cli1g_extra(device, log_fn, total_bp=1_000_000_000, parity_bins=16, gz_l
             # what search_s is made of (main.py: TIMINGS["search_" + key] of discover()'s laps): plan, background, the native search, post-processing
             # (with --out: + the precleanup tables, background PSSMs and search graphs of every task, written from Python)
             phases["search_parts_s"] = {k[len("search_"):]: round(v, 4) for k, v in t.items() if k.startswith("search_") and k != "search_s" and isinstance(v, float)}
+            # ... and filters_s (main.py: engine upload of the assembly, id tables, nm_ingest_pileup_part calls, window pipeline, closing the pileup table)
+            phases["filters_parts_s"] = {k[len("filters_"):]: round(v, 4) for k, v in t.items() if k.startswith("filters_") and isinstance(v, float)}
             legs[leg] = {"wall_s": wall, "in_find_motifs_bin_s": t.get("find_motifs_bin_s"), "phases": phases, "rates": rates,
                          "the_wall_is": max(timed, key=timed.get), "assembly_s_per_Gbp": (t.get("assembly_s") or 0.0) / (total_bp / 1e9),
                          "motif_rows": max(len(open(os.path.join(tmp, "out_" + leg, "bin-motifs.tsv")).read().splitlines()) - 1, 0)}

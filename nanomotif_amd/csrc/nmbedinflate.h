@@ -391,10 +391,11 @@ __device__ __forceinline__ unsigned int inf2_record(unsigned int lit, bool no_ma
     return lit | (no_match ? 256u : 0u) | ((len - 3u) << 9) | ((dist - 1u) << 17);
 }
 
-struct InfRing { unsigned int w[32][INF_LANES]; };                 // 32 dwords of compressed bytes per lane, [word][lane]
+constexpr unsigned int INF2_RING = 16;                             // dwords of compressed bytes per lane in the ring (a power of two, >= 16)
+struct InfRing { unsigned int w[INF2_RING][INF_LANES]; };          // [word][lane]
 
 // bit reader of phase 1: the stream arrives in pieces of 32 bytes — two 16-byte loads issued at EVERY service call (every eight turns of
-// the wave), written into the ring (32 dwords per lane) at the next one, when they have long arrived, provided the ring had room for them when they were asked
+// the wave), written into the ring (INF2_RING = 16 dwords per lane) at the next one, when they have long arrived, provided the ring had room for them when they were asked
 // for (otherwise the same bytes are asked for again: no state hangs on a condition, so the loads stay in flight across the turns instead
 // of being waited for on the spot) — and is consumed a dword at a time; the dword the next refill will take is read from the ring one
 // refill ahead, so that no turn waits for it either
@@ -409,13 +410,14 @@ struct InfBits2 {
     __device__ __forceinline__ void land(InfRing &r, int lane) {
         if (room) {
             const unsigned int f = fill;
-            r.w[(f + 0) & 31][lane] = q0.x; r.w[(f + 1) & 31][lane] = q0.y; r.w[(f + 2) & 31][lane] = q0.z; r.w[(f + 3) & 31][lane] = q0.w;
-            r.w[(f + 4) & 31][lane] = q1.x; r.w[(f + 5) & 31][lane] = q1.y; r.w[(f + 6) & 31][lane] = q1.z; r.w[(f + 7) & 31][lane] = q1.w;
+            constexpr unsigned int M = INF2_RING - 1;
+            r.w[(f + 0) & M][lane] = q0.x; r.w[(f + 1) & M][lane] = q0.y; r.w[(f + 2) & M][lane] = q0.z; r.w[(f + 3) & M][lane] = q0.w;
+            r.w[(f + 4) & M][lane] = q1.x; r.w[(f + 5) & M][lane] = q1.y; r.w[(f + 6) & M][lane] = q1.z; r.w[(f + 7) & M][lane] = q1.w;
             fill = f + 8;
         }
     }
     __device__ __forceinline__ void ask() {
-        room = fill - rd <= 24u;
+        room = fill - rd <= INF2_RING - 8u;
         const uint4 *p = src + (fill >> 2);
         q0 = p[0]; q1 = p[1];
     }
@@ -428,9 +430,9 @@ struct InfBits2 {
     __device__ __forceinline__ void start(InfRing &r, int lane, unsigned int skip) {
         fill = 0; rd = 0; buf = 0; cnt = 0;
         ask();
-        for (int k = 0; k < 3; ++k) service(r, lane);                // 24 dwords in the ring, 8 on their way
+        for (unsigned int k = 0; k < INF2_RING / 8; ++k) service(r, lane);      // the ring is full (a ring of 32: 24 dwords and 8 on their way)
         rd = skip >> 2;
-        ahead = r.w[rd & 31][lane];
+        ahead = r.w[rd & (INF2_RING - 1)][lane];
         if (skip & 3u) { refill(r, lane); buf >>= 8 * (skip & 3u); cnt -= 8 * (int)(skip & 3u); }
     }
     __device__ __forceinline__ void refill(InfRing &r, int lane) {
@@ -441,7 +443,7 @@ struct InfBits2 {
             service(r, lane);
             if (rd == fill) service(r, lane);
         }
-        ahead = r.w[rd & 31][lane];
+        ahead = r.w[rd & (INF2_RING - 1)][lane];
     }
     __device__ __forceinline__ unsigned int get(int n, InfRing &r, int lane) {       // n <= 16
         if (cnt < 32) refill(r, lane);
@@ -469,8 +471,11 @@ __device__ __forceinline__ unsigned int inf2_code_length(unsigned int x, const I
     return 1u + (unsigned int)__popc(signs & 0x7FFFu);
 }
 
-// Phase 1 keeps its LDS at 45 KB per workgroup (a ring of 32 dwords, not 64): three workgroups — a slab is 768 of them, three per CU —
-// leave 28 KB of a CU's LDS to six phase-2 waves of the slab before, so the two phases of neighbouring slabs run side by side.  The
+// Phase 1 keeps its LDS at 39 040 bytes per workgroup — a ring of 16 dwords, the codes per length counted in the rows of the table being
+// built — so that FOUR workgroups fit a CU's 160 KB, one per SIMD (with 45 KB — ring of 32, a count table of its own — three did: the
+// stand-alone harness decodes 65 536 blocks in the 9.7 ms it takes for 49 152).  A slab is 771 workgroups; the fourth slot of a CU takes
+// workgroups of the next slab, which the staging thread has queued on another stream; phase-2 waves (4.6 KB each) get their LDS as phase-1
+// workgroups retire.  The
 // literal / length table holds INF2_LSYM codes: all 288 (a table of 224 would make room for two more phase-2 waves, but every block
 // in the FIXED code — the short last block of most files — would then go through bed_inflate_kernel, ~40 ms for however few blocks;
 // the INF2_WIDE path below stays for whoever shrinks the table).
@@ -490,37 +495,41 @@ struct InfSymbols2 {
 };
 
 struct InfTables2 {
-    unsigned short count[16][INF_LANES];         // codes per length while a table is built
-    unsigned int ltab[16][INF_LANES], dtab[16][INF_LANES];
+    unsigned int ltab[16][INF_LANES], dtab[16][INF_LANES];      // (while a table is built its rows hold the number of codes per length)
     InfSymbols2 lsym;
     InfDistSymbols dsym;
 };
 
 // canonical code from code lengths; > 0: incomplete, < 0: over-subscribed (zlib contrib/puff: construct)
 // (*too_wide: more codes in use than the symbol table holds — nothing is written then)
+// (the codes per length are counted in the rows of `tab` itself: row len is read before row len - 1 is written — a count table of its own
+//  was 2 KB of the workgroup's LDS; *n_codes: how many symbols have a code)
 template <typename Symbols>
-__device__ int inf2_construct(unsigned short (*count)[INF_LANES], unsigned int (*tab)[INF_LANES], Symbols &symbol, InfCanon &canon, const unsigned char *length, int n, int lane,
-                              int capacity, bool *too_wide) {
+__device__ int inf2_construct(unsigned int (*tab)[INF_LANES], Symbols &symbol, InfCanon &canon, const unsigned char *length, int n, int lane,
+                              int capacity, bool *too_wide, int *n_codes) {
     symbol.clear(lane);
+    unsigned int (*count)[INF_LANES] = tab;
     for (int len = 0; len <= 15; ++len) count[len][lane] = 0;
     for (int s = 0; s < n; ++s) count[length[s]][lane] += 1;
-    if (n - (int)count[0][lane] > capacity) { *too_wide = true; return 0; }
+    *n_codes = n - (int)count[0][lane];
+    if (*n_codes > capacity) { *too_wide = true; return 0; }
     int left = 1;
-    if (count[0][lane] == n) left = 0;                                  // (no code at all: every decode fails, as in puff)
+    if (*n_codes == 0) left = 0;                                        // (no code at all: every decode fails, as in puff)
     else
         for (int len = 1; len <= 15; ++len) {
             left <<= 1;
-            left -= count[len][lane];
+            left -= (int)count[len][lane];
             if (left < 0) return left;
         }
     unsigned short offs[16];
     offs[1] = 0;
-    for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + count[len][lane];
+    for (int len = 1; len < 15; ++len) offs[len + 1] = offs[len] + (unsigned short)count[len][lane];
     unsigned int acc = 0;
 #pragma unroll
     for (int len = 1; len <= 15; ++len) {
+        const unsigned int c = count[len][lane];                       // (row len: still a count; row len - 1 becomes the table's entry)
         tab[len - 1][lane] = acc | ((unsigned int)offs[len] << 16);
-        acc += (unsigned int)count[len][lane] << (15 - len);
+        acc += c << (15 - len);
         canon.lim[len - 1] = acc;
     }
     for (int s = 0; s < n; ++s)
@@ -633,10 +642,11 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             for (; s < 256; ++s) lengths[s] = 9;
             for (; s < 280; ++s) lengths[s] = 7;
             for (; s < 288; ++s) lengths[s] = 8;
-            inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, 288, lane, INF2_LSYM, &wide);
+            int used = 0;
+            inf2_construct(T.ltab, T.lsym, kl, lengths, 288, lane, INF2_LSYM, &wide, &used);
             if (wide) { err = (int)INF2_WIDE; break; }                  // (never with a table of 288: the fixed code uses them all)
             for (s = 0; s < 30; ++s) lengths[s] = 5;
-            inf2_construct(T.count, T.dtab, T.dsym, kd, lengths, 30, lane, INF_MAXD, &wide);
+            inf2_construct(T.dtab, T.dsym, kd, lengths, 30, lane, INF_MAXD, &wide, &used);
         } else {                                                 // dynamic code
             const int nlen = (int)b.get(5, ring, lane) + 257, ndist = (int)b.get(5, ring, lane) + 1, ncode = (int)b.get(4, ring, lane) + 4;
             if (nlen > 286 || ndist > 30) { err = 4; break; }
@@ -644,7 +654,8 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             for (; idx < ncode; ++idx) lengths[INF_CLORDER[idx]] = (unsigned char)b.get(3, ring, lane);
             for (; idx < 19; ++idx) lengths[INF_CLORDER[idx]] = 0;
             InfCanon kc;
-            if (inf2_construct(T.count, T.ltab, T.lsym, kc, lengths, 19, lane, INF2_LSYM, &wide) != 0) { err = 5; break; }
+            int used = 0;
+            if (inf2_construct(T.ltab, T.lsym, kc, lengths, 19, lane, INF2_LSYM, &wide, &used) != 0) { err = 5; break; }
             idx = 0;
             unsigned int hs = 0;
             while (idx < nlen + ndist) {
@@ -666,11 +677,11 @@ __global__ __launch_bounds__(INF_LANES) void bed_tokens_kernel(const unsigned ch
             }
             if (err) break;
             if (lengths[256] == 0) { err = 9; break; }
-            int r = inf2_construct(T.count, T.ltab, T.lsym, kl, lengths, nlen, lane, INF2_LSYM, &wide);
+            int r = inf2_construct(T.ltab, T.lsym, kl, lengths, nlen, lane, INF2_LSYM, &wide, &used);
             if (wide) { err = (int)INF2_WIDE; break; }
-            if (r < 0 || (r > 0 && nlen - T.count[0][lane] != 1)) { err = 10; break; }
-            r = inf2_construct(T.count, T.dtab, T.dsym, kd, lengths + nlen, ndist, lane, INF_MAXD, &wide);
-            if (r < 0 || (r > 0 && ndist - T.count[0][lane] != 1)) { err = 11; break; }
+            if (r < 0 || (r > 0 && used != 1)) { err = 10; break; }
+            r = inf2_construct(T.dtab, T.dsym, kd, lengths + nlen, ndist, lane, INF_MAXD, &wide, &used);
+            if (r < 0 || (r > 0 && used != 1)) { err = 11; break; }
         }
         // The block's symbols, one per turn of the wave.  Straight-line code: a literal / length symbol, then — for every lane, whether its
         // symbol was a length or not — the extra bits, the distance symbol and its extra bits, consuming no bits where there is no match;

@@ -331,6 +331,14 @@ def find_motifs_bin(args):
             eng.upload_assembly_fasta(assembly, mine, [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
         else:
             eng.upload_assembly(mine, [assembly[c] for c in mine], [cfg.bin_contig[c] for c in mine], bin_names=all_bins)
+        t_part = t_phase[0]                      # (the end of the phase before: the pileup parse)
+
+        def part(name):                          # (what upload_filter_s is made of: TIMINGS["filters_<name>_s"])
+            nonlocal t_part
+            now = time.perf_counter()
+            TIMINGS["filters_" + name + "_s"] = TIMINGS.get("filters_" + name + "_s", 0.0) + now - t_part
+            t_part = now
+        part("upload_assembly")
         # raw rows -> device: the three pre-filters, classification, confident-row list (rows of contigs that are in no
         # bin or on another rank are ignored: the reference joins with contig -> bin after filtering, find_motifs_bin.py:416)
         local_id = {c: i for i, c in enumerate(mine)}
@@ -350,11 +358,13 @@ def find_motifs_bin(args):
         for fid, local in placements:
             sel = np.flatnonzero(file_contig == fid)
             extra.append(dict(contig=np.full(len(sel), local, np.uint32), **{k: cols[k][sel] for k in ("position", "mod_type", "strand", "fraction_mod", "nvalid_cov")}))
+        part("tables")
         if on_device:
             res = eng.ingest_device_pileup(table, lut, labels, low=low, high=high, max_part_rows=part_rows)
         else:
             res = eng.ingest_pileup(cols["contig"], cols["position"], cols["mod_type"], cols["strand"], cols["fraction_mod"],
                                     cols["nvalid_cov"], labels, low=low, high=high, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
+        part("ingest")
         if 2 * cfg.padding + 1 > MAX_DEVICE_WINDOW_WIDTH:
             # a search frame beyond the device's window planes (default 40; nobody runs such frames): windows are extracted and
             # filtered on the host (search.HostWindowStore), candidates scored on the device (far-reaching ones by the plain kernel)
@@ -376,9 +386,11 @@ def find_motifs_bin(args):
                               cols["nvalid_cov"], {i: ((mt, "merge"), MOD_TYPE_TO_CANONICAL[mt]) for i, mt in enumerate(pileup_mod.MOD_TYPES)},
                               low=0.3, high=0.7, want_rows=False, max_part_rows=part_rows, extra_parts=extra)
         log.info(f"pileup: {res['n_kept']:,} rows after the device-side filters ({time.perf_counter() - t0:.1f}s)")
-        lap("upload_filter_s")
+        part("window_pipeline")
         del cols
         table.close()
+        part("table_close")
+        lap("upload_filter_s")
         part = FilteredPileup(mine, *rows_part, res["kept"])
         if world > 1:
             gathered = [None] * world
