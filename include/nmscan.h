@@ -443,6 +443,14 @@ int nm_post_run_rows_custom(uint32_t n_tasks, uint32_t width, const uint64_t *ro
 int nm_post_sizes(const nm_post_result *post, uint64_t *n_rows, uint64_t *text_bytes, uint64_t stats[2]);
 int nm_post_export(const nm_post_result *post, uint32_t *row_task, uint8_t *row_stage, uint64_t *text_off, char *text,
                    int32_t *mod_position, int32_t *mod_position_iupac, int64_t *counts, double *score, int64_t *complement);
+/* The per-stage tables of every task as TEXT (the reference writes them with motifs.write_csv, motif.py:891-897 / find_motifs_bin.py:537-596:
+ * precleanup-motifs/<bin>-<mod>/motifs[-noise[-merge[-sub[-complement]]]].tsv): columns reference, motif, mod_type, mod_position, score,
+ * n_mod, n_nomod, motif_iupac, mod_position_iupac (+ the seven *_complement columns in the last stage), rows sorted by motif, floats as
+ * Python's repr — byte for byte what nanomotif_amd.postprocess.format_motifs makes of nm_post_export's rows.  task_reference / task_mod_type:
+ * the two constant columns of task t.  Table (t, s) = (*text)[(*off)[5 t + s], (*off)[5 t + s + 1]); a stage without rows is its header.
+ * *text and *off belong to `post` until nm_post_free. */
+int nm_post_tables(nm_post_result *post, const char *const *task_reference, const char *const *task_mod_type, const char **text,
+                   const uint64_t **off, uint64_t *n_off);
 int nm_post_free(nm_post_result *post);
 /* digamma of a positive integer, the value scipy.special.psi returns bit for bit (Cephes psi; model.py:82-83 only ever
  * evaluates it at alpha, beta, alpha + beta = 5 + counts) — what the native search uses, for hosts that score without SciPy. */

@@ -13,7 +13,10 @@
 // reference compare.  Maximal cliques come out in a fixed order (Bron-Kerbosch, pivot = most neighbours among the
 // candidates, ties to the smallest motif); the reference's networkx order depends on hash seeds and nothing downstream
 // depends on it.
+#include <algorithm>
+#include <charconv>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -500,6 +503,8 @@ void finish(PostTask &t, const int64_t *counts) {
 struct nm_post_result {
     std::vector<PostTask> tasks;
     uint64_t batches = 0, candidates = 0;
+    std::string tables;                   // nm_post_tables: the stage tables' text, back to back ...
+    std::vector<uint64_t> table_off;      // ... and where table (task, stage) begins: [task * 5 + stage], one more at the end
 };
 
 namespace {
@@ -734,6 +739,118 @@ int nm_post_export(const nm_post_result *pr, uint32_t *row_task, uint8_t *row_st
         }
     }
     text_off[2 * i] = at;
+    return NM_OK;
+}
+
+namespace {
+
+// repr(float) of CPython (float_repr_style "short"): the shortest digits that round-trip, fixed notation for decimal exponents -4 .. 15,
+// else d.ddde+XX with at least two exponent digits
+void append_py_repr(std::string &out, double x) {
+    if (std::isnan(x)) { out += "nan"; return; }
+    if (std::isinf(x)) { out += x < 0 ? "-inf" : "inf"; return; }
+    char buf[64];
+    const auto r = std::to_chars(buf, buf + sizeof buf - 1, x, std::chars_format::scientific);
+    *r.ptr = '\0';                                                      // (atoi below reads the exponent up to here)
+    const char *p = buf, *end = r.ptr;
+    if (*p == '-') { out += '-'; ++p; }
+    const char *epos = p;
+    while (epos < end && *epos != 'e') ++epos;
+    char digits[32];
+    size_t nd = 0;
+    for (const char *q = p; q < epos; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    const int e = atoi(epos + 1);
+    if (-4 <= e && e < 16) {
+        if (e >= 0) {
+            const size_t ip = (size_t)e + 1;
+            out.append(digits, std::min(nd, ip));
+            if (nd < ip) out.append(ip - nd, '0');
+            out += '.';
+            if (nd > ip) out.append(digits + ip, nd - ip);
+            else out += '0';
+        } else {
+            out += "0.";
+            out.append((size_t)(-e - 1), '0');
+            out.append(digits, nd);
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) { out += '.'; out.append(digits + 1, nd - 1); }
+        char eb[16];
+        snprintf(eb, sizeof eb, "e%c%02d", e < 0 ? '-' : '+', e < 0 ? -e : e);
+        out += eb;
+    }
+}
+
+}  // namespace
+
+// The per-stage tables of every task as the text nanomotif_amd.postprocess.format_motifs writes (motif.py:891-897: all non-object columns,
+// rows sorted by reference, mod type, motif): table (t, s) = text[off[t * 5 + s], off[t * 5 + s + 1]), the header alone for a stage without
+// rows.  task_reference / task_mod_type: the two constant columns of task t.  The text belongs to `post` (until nm_post_free).
+int nm_post_tables(nm_post_result *pr, const char *const *task_reference, const char *const *task_mod_type, const char **text, const uint64_t **off,
+                   uint64_t *n_off) {
+    if (!pr || !text || !off || !n_off || (!pr->tasks.empty() && (!task_reference || !task_mod_type))) return nm_set_error(NM_EINVAL, "NULL argument");
+    static const char *HEAD = "reference\tmotif\tmod_type\tmod_position\tscore\tn_mod\tn_nomod\tmotif_iupac\tmod_position_iupac";
+    static const char *HEAD_COMP = "\tmotif_complement\tmod_position_complement\tscore_complement\tn_mod_complement\tn_nomod_complement\tmotif_iupac_complement"
+                                   "\tmod_position_iupac_complement";
+    std::string &o = pr->tables;
+    o.clear();
+    pr->table_off.assign(pr->tasks.size() * N_STAGES + 1, 0);
+    auto put_int = [&](long long v) {
+        char b[24];
+        const auto r = std::to_chars(b, b + sizeof b, v);
+        o.append(b, r.ptr);
+    };
+    std::vector<uint32_t> order;
+    for (size_t t = 0; t < pr->tasks.size(); ++t) {
+        const PostTask &T = pr->tasks[t];
+        if (!task_reference[t] || !task_mod_type[t]) return nm_set_error(NM_EINVAL, "task %zu: NULL reference / mod type", t);
+        for (int s = 0; s < N_STAGES; ++s) {
+            pr->table_off[t * N_STAGES + s] = o.size();
+            const std::vector<PRow> &rows = s < T.n_stages ? T.stage[s] : T.stage[N_STAGES - 1];
+            const size_t n = s < T.n_stages ? rows.size() : 0;
+            const bool comp = n != 0 && s == 4;                          // (MotifRow.has_complement_columns: the rows of the last stage)
+            o += HEAD;
+            if (comp) o += HEAD_COMP;
+            o += '\n';
+            order.resize(n);
+            for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].m.str < rows[b].m.str; });
+            for (size_t k = 0; k < n; ++k) {
+                const PRow &r = rows[order[k]];
+                const PMotif st = stripped(r.m);
+                o += task_reference[t]; o += '\t';
+                o += r.m.str; o += '\t';
+                o += task_mod_type[t]; o += '\t';
+                put_int(r.m.modpos); o += '\t';
+                append_py_repr(o, r.score); o += '\t';
+                put_int(r.model.n_mod()); o += '\t';
+                put_int(r.model.n_nomod()); o += '\t';
+                o += iupac_of(st); o += '\t';
+                put_int(st.modpos);
+                if (comp) {
+                    if (r.complement < 0 || (size_t)r.complement >= T.stage[3].size()) o += "\t\t\t\t\t\t\t";
+                    else {
+                        const PRow &c = T.stage[3][(size_t)r.complement];
+                        const PMotif cst = stripped(c.m);
+                        o += '\t'; o += c.m.str;
+                        o += '\t'; put_int(c.m.modpos);
+                        o += '\t'; append_py_repr(o, c.score);
+                        o += '\t'; put_int(c.model.n_mod());
+                        o += '\t'; put_int(c.model.n_nomod());
+                        o += '\t'; o += iupac_of(cst);
+                        o += '\t'; put_int(cst.modpos);
+                    }
+                }
+                o += '\n';
+            }
+        }
+    }
+    pr->table_off.back() = o.size();
+    *text = o.data();
+    *off = pr->table_off.data();
+    *n_off = pr->table_off.size();
     return NM_OK;
 }
 

@@ -443,6 +443,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor,
                 pre = os.path.join(out_dir, "precleanup-motifs", f"{bin_name}-{mod_type}")
                 os.makedirs(pre, exist_ok=True)
                 stage_writer = (lambda pre: lambda name, rows: files.add(os.path.join(pre, name + ".tsv"), postprocess.format_motifs(rows)))(pre)
+                stage_writer.text = (lambda pre: lambda name, text: files.add(os.path.join(pre, name + ".tsv"), text))(pre)
                 temp_dir = os.path.join(out_dir, "temp", bin_name)
             if extractor is not None:
                 planned.append(((bin_name, mod_type), stage_writer, temp_dir))
@@ -462,6 +463,7 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor,
                     pre = os.path.join(out_dir, "precleanup-motifs", f"{key[0]}-{key[1]}")
                     os.makedirs(pre, exist_ok=True)
                     stage_writer = (lambda pre: lambda name, rows: files.add(os.path.join(pre, name + ".tsv"), postprocess.format_motifs(rows)))(pre)
+                    stage_writer.text = (lambda pre: lambda name, text: files.add(os.path.join(pre, name + ".tsv"), text))(pre)
                     temp_dir = os.path.join(out_dir, "temp", key[0])
                 planned.append((key, stage_writer, temp_dir))
         else:
@@ -488,8 +490,11 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor,
             else:
                 # post-processing of all tasks inside libnmscan as well (nm_post_run: noise -> clique merge in two scoring
                 # batches on the merge stage's 0.3 / 0.7 classification -> sub-motifs -> complements); postprocess.py is its twin
+                # (a run with --out: the five stage tables of every task come back as text, nm_post_tables — no row objects for them)
+                want_tables = any(sw is not None for _, sw, _ in planned) and os.environ.get("NANOMOTIF_PY_TABLES") != "1"
                 post = found.postprocess(engine, (engine.bin_index[key[0]] for key, _, _ in planned),
-                                         (engine.slot_of_mod[state_label(key[1], "merge")] for key, _, _ in planned), reduce=reduce)
+                                         (engine.slot_of_mod[state_label(key[1], "merge")] for key, _, _ in planned), reduce=reduce,
+                                         tables=want_tables)
                 scorer.rounds += post.batches
                 scorer.candidates += post.candidates
                 timings["post_native_call_s"] = time.perf_counter() - t_mark        # (part of postprocess_s: nm_post_run + the export of its rows)
@@ -498,7 +503,11 @@ def _discover(cfg, filtered, scorer, rank, bgzip_order, window_store, extractor,
                         write_search_artifacts(key[0], key[1], found.artifacts(t), temp_dir, files)
                     if stage_writer:
                         for s in range(post.n_stages(t)):
-                            stage_writer(post.STAGES[s], post.rows(t, s))
+                            text = post.table_text(t, s)
+                            if text is not None:
+                                stage_writer.text(post.STAGES[s], text)
+                            else:
+                                stage_writer(post.STAGES[s], post.rows(t, s))
                     native_rows[key] = post.final(t)
                 lap("postprocess_s")
             # (a thousand search graphs take 3 ms to free: off the critical path, on a thread of their own)

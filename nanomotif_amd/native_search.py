@@ -70,7 +70,7 @@ class SearchResults:
         except Exception:
             pass
 
-    def postprocess(self, engine, task_bins, merge_slots, reduce=None):
+    def postprocess(self, engine, task_bins, merge_slots, reduce=None, tables=False):
         """process_subpileup after the search for every task (nm_post_run): ``task_bins`` / ``merge_slots`` = engine bin
         index and the classification the merge stage is scored on, per task.  Returns PostResults."""
         n = len(self.keys)
@@ -84,9 +84,9 @@ class SearchResults:
         if err:
             raise err[0]
         _lib.check(rc)
-        return PostResults(self._lib, handle, self.keys)
+        return PostResults(self._lib, handle, self.keys, tables=tables)
 
-    def postprocess_custom(self, score_fn):
+    def postprocess_custom(self, score_fn, tables=False):
         """The same on a Python scorer (CPU tests): ``score_fn(list of (task index, Motif)) -> int64[n, 2]``, every request
         on the merge stage's 0.3 / 0.7 classification."""
         err = []
@@ -95,7 +95,7 @@ class SearchResults:
         if err:
             raise err[0]
         _lib.check(rc)
-        return PostResults(self._lib, handle, self.keys)
+        return PostResults(self._lib, handle, self.keys, tables=tables)
 
     def _node(self, t, k):
         i = int(self.node_off[t]) + k
@@ -185,7 +185,7 @@ def _post_score_callback(score_fn, err):
     return _lib.POST_SCORE_FN(_score)
 
 
-def postprocess_rows_custom(keys, rows_per_task, padding, score_fn):
+def postprocess_rows_custom(keys, rows_per_task, padding, score_fn, tables=False):
     """Native post-processing of explicit rows (tests): ``rows_per_task[t]`` = list of (motif string of 2 * padding + 1
     characters, n_mod, n_nomod, score) in graph node order.  Returns PostResults."""
     lib = _lib.load()
@@ -205,7 +205,7 @@ def postprocess_rows_custom(keys, rows_per_task, padding, score_fn):
     if err:
         raise err[0]
     _lib.check(rc)
-    return PostResults(lib, handle, keys)
+    return PostResults(lib, handle, keys, tables=tables)
 
 
 class PostResults:
@@ -213,8 +213,19 @@ class PostResults:
     records postprocess.postprocess_co produces; built on demand (a run without --out only reads the last stage)."""
     STAGES = ("motifs", "motifs-noise", "motifs-noise-merge", "motifs-noise-merge-sub", "motifs-noise-merge-sub-complement")
 
-    def __init__(self, lib, handle, keys):
+    def __init__(self, lib, handle, keys, tables=False):
+        """``tables``: also keep every (task, stage) table as the TEXT ``postprocess.format_motifs`` would write (nm_post_tables) — a run
+        with --out writes five of them per task and needs no row objects for the first four."""
         self.keys = list(keys)
+        self._tables = None
+        if tables and self.keys:
+            n_t = len(self.keys)
+            ref = (C.c_char_p * n_t)(*[str(k[0]).encode() for k in self.keys])
+            mod = (C.c_char_p * n_t)(*[str(k[1]).encode() for k in self.keys])
+            text, off, n_off = C.c_void_p(), C.POINTER(C.c_uint64)(), C.c_uint64(0)
+            _lib.check(lib.nm_post_tables(handle, ref, mod, C.byref(text), C.byref(off), C.byref(n_off)))
+            offs = np.ctypeslib.as_array(off, shape=(int(n_off.value),)).tolist()
+            self._tables = (C.string_at(text, offs[-1]), offs)                        # (bytes: the offsets count bytes, a bin name may not be ASCII)
         nr, nb = C.c_uint64(0), C.c_uint64(0)
         stats = (C.c_uint64 * 2)()
         _lib.check(lib.nm_post_sizes(handle, C.byref(nr), C.byref(nb), stats))
@@ -265,6 +276,13 @@ class PostResults:
                           "_cache": (text[o[2 * i + 1]:o[2 * i + 2]], modpos_iu[i], None)}       # (the reverse complement on first use)
             self._made[i] = r
         return r
+
+    def table_text(self, t, stage):
+        """The text of table (task ``t``, ``stage``) — ``format_motifs(self.rows(t, stage))`` — or None when the tables were not asked for."""
+        if self._tables is None:
+            return None
+        text, off = self._tables
+        return text[off[t * 5 + stage]:off[t * 5 + stage + 1]].decode("utf-8")
 
     def n_stages(self, t):
         """Stages of task ``t`` that hold rows (the reference stops a task at the first empty one)."""

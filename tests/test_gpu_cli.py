@@ -68,6 +68,16 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_regular_start", "-t", "1"], env_extra={"NANOMOTIF_NO_EARLY_INIT": "1"})
     assert json.load(open(tmp + "/out_regular_start/logs/timings.motif_discovery.json"))["engine_context_made_beside_the_imports"] is False
     assert open(tmp + "/out_regular_start/bin-motifs.tsv").read() == got
+    # the five precleanup tables of every task are formatted natively (nm_post_tables); NANOMOTIF_PY_TABLES=1: by postprocess.format_motifs
+    # from row objects, as before round 6 — the same files, byte for byte
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_py_tables", "-t", "1"], env_extra={"NANOMOTIF_PY_TABLES": "1"})
+    n_tables = 0
+    for task in sorted(os.listdir(tmp + "/out/precleanup-motifs")):
+        assert sorted(os.listdir(f"{tmp}/out/precleanup-motifs/{task}")) == sorted(os.listdir(f"{tmp}/out_py_tables/precleanup-motifs/{task}"))
+        for name in os.listdir(f"{tmp}/out/precleanup-motifs/{task}"):
+            assert open(f"{tmp}/out/precleanup-motifs/{task}/{name}").read() == open(f"{tmp}/out_py_tables/precleanup-motifs/{task}/{name}").read(), (task, name)
+            n_tables += 1
+    assert n_tables >= 10
 
     # bgzip'd pileup (needs its .tbi to be present like the reference) and -f bin FASTA files
     with open(tmp + "/pileup.bed", "rb") as f, gzip.open(tmp + "/pileup.bed.gz", "wb") as g:

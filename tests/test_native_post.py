@@ -57,10 +57,13 @@ def python_post(keys, rows_per_task, score_fn):
 
 def compare(keys, rows_per_task, score_fn):
     stages, final = python_post(keys, rows_per_task, score_fn)
-    post = ns.postprocess_rows_custom(keys, rows_per_task, PAD, score_fn)
+    post = ns.postprocess_rows_custom(keys, rows_per_task, PAD, score_fn, tables=True)
     n_rows = 0
     for t, key in enumerate(keys):
         assert post.n_stages(t) == len(stages[key]), (key, post.n_stages(t), list(stages[key]))
+        # the tables as text (nm_post_tables): what format_motifs writes of the same rows, byte for byte; a stage without rows: its header
+        for s in range(5):
+            assert post.table_text(t, s) == pp.format_motifs(post.rows(t, s)), (key, s)
         for s, name in enumerate(ns.PostResults.STAGES):
             want = [row_tuple(r) for r in stages[key].get(name, [])]
             got = [row_tuple(r) for r in post.rows(t, s)]
@@ -225,3 +228,33 @@ def test_native_post_on_threads_equals_one_thread_and_the_python_twin(monkeypatc
     monkeypatch.delenv("NM_POST_THREADS")
     total, post = compare(keys, rows, hash_scorer(77))  # default thread count against the Python twin, stage by stage
     assert total > 500
+
+
+def test_table_text_writes_floats_like_repr():
+    """nm_post_tables formats the score column like Python's repr(float): shortest digits that round-trip, fixed notation for decimal
+    exponents -4 .. 15, d.ddde+XX otherwise (csrc/nmpost.cpp: append_py_repr) — on scores of every magnitude, and a bin name that is not ASCII."""
+    rng = random.Random(5)
+    scores = [0.0, 1.0, 5.0, 0.1, 1e-5, 9.999999999999999e-5, 1e-4, 0.00012345, 1.5e-7, 1e15, 1e16, 123456789012345.6, 1234567890123456.7,
+              1.2345678901234568e+17, 2.5e22, 1e100, 5e-324, 1.7976931348623157e308, 1 / 3.0, 2 / 3.0, 12345.678, 100.0, 3.141592653589793]
+    scores += [rng.random() * 10 ** rng.randint(-12, 20) for _ in range(300)] + [float(np.float32(rng.random())) for _ in range(50)]
+    cores = ["GATC", "CCAGG", "GAAGA", "ACCCA", "GGCAT", "CTGAA", "TTAAC", "AGGCA"]
+    keys, rows = [], []
+    for t in range(0, len(scores), 8):
+        keys.append((f"bin_ü{t}", "a"))
+        task_rows = []
+        for k, sc in enumerate(scores[t:t + 8]):
+            core = cores[k]
+            at = core.index("A")
+            s = "." * (PAD - at) + core + "." * (W - (PAD - at) - len(core))
+            task_rows.append((s, 500 + k, 20 + k, sc))
+        rows.append(task_rows)
+    post = ns.postprocess_rows_custom(keys, rows, PAD, hash_scorer(3), tables=True)
+    seen = 0
+    for t in range(len(keys)):
+        text = post.table_text(t, 0)
+        assert text == pp.format_motifs(post.rows(t, 0))
+        for line, r in zip(text.splitlines()[1:], sorted(post.rows(t, 0), key=lambda r: r.motif)):
+            assert line.split("\t")[4] == repr(r.score) and line.startswith(f"bin_ü{t * 8}\t")
+            seen += 1
+    assert seen == len(scores)
+    assert ns.postprocess_rows_custom(keys, rows, PAD, hash_scorer(3)).table_text(0, 0) is None
