@@ -409,6 +409,11 @@ int nm_search_result_sizes(const nm_search_result *res, uint64_t *n_nodes, uint6
  * have cost anyway.  stats[3] = lock-step iterations of the run, children answered by the speculation, children asked for after
  * all. */
 int nm_search_result_speculation(const nm_search_result *res, uint64_t stats[3]);
+/* The search graph of every task as GML text — what the command line leaves as temp/<bin>/motif_graph_<mod>.gml (find_motifs_bin.py:521-535:
+ * nx.write_gml of the MotifTree): nodes in insertion order (id, label = the motif without its padding, score, priority, depth, visited),
+ * a node's edges in the order they were made, floats as Python's repr.  Task t = (*text)[(*off)[t], (*off)[t + 1]) — empty for a task
+ * without a result; *text and *off belong to `res` until nm_search_result_free. */
+int nm_search_result_gml(nm_search_result *res, const char **text, const uint64_t **off, uint64_t *n_off);
 /* offsets are [n_tasks + 1]; any of the column pointers may be NULL */
 int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uint64_t *edge_off, uint64_t *best_off, uint8_t *task_none,
                             char *node_motif, int64_t *node_counts, double *node_score, double *node_priority, int32_t *node_depth,

@@ -18,7 +18,7 @@ SYMBOLS = [
     "nm_win_clear", "nm_win_add_task", "nm_win_batch", "nm_win_batch_w", "nm_win_add_task_rows", "nm_win_add_task_contigs", "nm_plan_windows", "nm_methylated_row_counts", "nm_contig_base_counts", "nm_bg_counts", "nm_bg_counts_runs", "nm_assembly_other_letters", "nm_ingest_pileup", "nm_ingest_pileup_part", "nm_ingest_results", "nm_py_random_sample", "nm_py_random_sample_many", "nm_py_random_sample_groups", "nm_window_letter_counts", "nm_bed_open", "nm_bed_open_indexed", "nm_bed_shape", "nm_bed_contig_name", "nm_bed_mod_code", "nm_bed_columns", "nm_bed_ingest_columns", "nm_bed_close", "nm_fasta_open", "nm_fasta_shape", "nm_fasta_record", "nm_fasta_sequence", "nm_fasta_close",
     "nm_comm_unique_id", "nm_comm_init", "nm_allreduce_counts", "nm_allreduce_counts_async", "nm_comm_wait", "nm_allreduce_counts_host",
     "nm_comm_sync", "nm_comm_info", "nm_comm_destroy",
-    "nm_score_batch_per_contig", "nm_bin_contigs", "nm_readstats_upload", "nm_contig_methylation", "nm_bed_open_counts", "nm_bed_count_columns", "nm_bed_parse_device", "nm_bed_parse_device_indexed", "nm_bedcols_shape", "nm_bedcols_contig_name", "nm_bedcols_mod_code", "nm_bedcols_runs", "nm_bedcols_map_contigs", "nm_bedcols_device_columns", "nm_bedcols_close", "nm_device_read", "nm_score_batch_begin", "nm_score_batch_end", "nm_win_batch_w_begin", "nm_win_batch_w_end", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_speculation", "nm_search_result_export", "nm_search_result_free", "nm_post_run", "nm_post_run_custom", "nm_post_run_rows_custom", "nm_post_sizes", "nm_post_export", "nm_post_tables", "nm_post_free", "nm_psi_posint",
+    "nm_score_batch_per_contig", "nm_bin_contigs", "nm_readstats_upload", "nm_contig_methylation", "nm_bed_open_counts", "nm_bed_count_columns", "nm_bed_parse_device", "nm_bed_parse_device_indexed", "nm_bedcols_shape", "nm_bedcols_contig_name", "nm_bedcols_mod_code", "nm_bedcols_runs", "nm_bedcols_map_contigs", "nm_bedcols_device_columns", "nm_bedcols_close", "nm_device_read", "nm_score_batch_begin", "nm_score_batch_end", "nm_win_batch_w_begin", "nm_win_batch_w_end", "nm_search_run", "nm_search_run_custom", "nm_search_result_sizes", "nm_search_result_speculation", "nm_search_result_export", "nm_search_result_gml", "nm_search_result_free", "nm_post_run", "nm_post_run_custom", "nm_post_run_rows_custom", "nm_post_sizes", "nm_post_export", "nm_post_tables", "nm_post_free", "nm_psi_posint",
     "nm_bedcols_phase_seconds", "nm_bed_plan_indexed", "nm_bed_parse_device_planned", "nm_bedplan_close", "nm_fasta_parse_device", "nm_fastadev_shape", "nm_fastadev_record", "nm_fastadev_table", "nm_fastadev_sequence_device", "nm_upload_contigs_fasta", "nm_fastadev_close",
     "nm_tabix_regions",
 ]
@@ -215,6 +215,7 @@ def _load_locked():
     lib.nm_post_run_custom.argtypes = [p, POST_SCORE_FN, p, C.POINTER(p)]
     lib.nm_post_run_rows_custom.argtypes = [C.c_uint32, C.c_uint32, u64p, C.c_char_p, i64p, f64p, POST_SCORE_FN, p, C.POINTER(p)]
     lib.nm_post_sizes.argtypes = [p, u64p, u64p, u64p]
+    lib.nm_search_result_gml.argtypes = [p, C.POINTER(C.c_void_p), C.POINTER(u64p), u64p]
     lib.nm_post_tables.argtypes = [p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(u64p), u64p]
     lib.nm_post_export.argtypes = [p, u32p, u8p, u64p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64), f64p, C.POINTER(C.c_int64)]
     lib.nm_post_free.argtypes = [p]

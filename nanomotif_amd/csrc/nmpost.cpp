@@ -742,49 +742,6 @@ int nm_post_export(const nm_post_result *pr, uint32_t *row_task, uint8_t *row_st
     return NM_OK;
 }
 
-namespace {
-
-// repr(float) of CPython (float_repr_style "short"): the shortest digits that round-trip, fixed notation for decimal exponents -4 .. 15,
-// else d.ddde+XX with at least two exponent digits
-void append_py_repr(std::string &out, double x) {
-    if (std::isnan(x)) { out += "nan"; return; }
-    if (std::isinf(x)) { out += x < 0 ? "-inf" : "inf"; return; }
-    char buf[64];
-    const auto r = std::to_chars(buf, buf + sizeof buf - 1, x, std::chars_format::scientific);
-    *r.ptr = '\0';                                                      // (atoi below reads the exponent up to here)
-    const char *p = buf, *end = r.ptr;
-    if (*p == '-') { out += '-'; ++p; }
-    const char *epos = p;
-    while (epos < end && *epos != 'e') ++epos;
-    char digits[32];
-    size_t nd = 0;
-    for (const char *q = p; q < epos; ++q)
-        if (*q != '.') digits[nd++] = *q;
-    const int e = atoi(epos + 1);
-    if (-4 <= e && e < 16) {
-        if (e >= 0) {
-            const size_t ip = (size_t)e + 1;
-            out.append(digits, std::min(nd, ip));
-            if (nd < ip) out.append(ip - nd, '0');
-            out += '.';
-            if (nd > ip) out.append(digits + ip, nd - ip);
-            else out += '0';
-        } else {
-            out += "0.";
-            out.append((size_t)(-e - 1), '0');
-            out.append(digits, nd);
-        }
-    } else {
-        out += digits[0];
-        if (nd > 1) { out += '.'; out.append(digits + 1, nd - 1); }
-        char eb[16];
-        snprintf(eb, sizeof eb, "e%c%02d", e < 0 ? '-' : '+', e < 0 ? -e : e);
-        out += eb;
-    }
-}
-
-}  // namespace
-
 // The per-stage tables of every task as the text nanomotif_amd.postprocess.format_motifs writes (motif.py:891-897: all non-object columns,
 // rows sorted by reference, mod type, motif): table (t, s) = text[off[t * 5 + s], off[t * 5 + s + 1]), the header alone for a stage without
 // rows.  task_reference / task_mod_type: the two constant columns of task t.  The text belongs to `post` (until nm_post_free).
@@ -824,7 +781,7 @@ int nm_post_tables(nm_post_result *pr, const char *const *task_reference, const 
                 o += r.m.str; o += '\t';
                 o += task_mod_type[t]; o += '\t';
                 put_int(r.m.modpos); o += '\t';
-                append_py_repr(o, r.score); o += '\t';
+                nmsearch::append_py_repr(o, r.score); o += '\t';
                 put_int(r.model.n_mod()); o += '\t';
                 put_int(r.model.n_nomod()); o += '\t';
                 o += iupac_of(st); o += '\t';
@@ -836,7 +793,7 @@ int nm_post_tables(nm_post_result *pr, const char *const *task_reference, const 
                         const PMotif cst = stripped(c.m);
                         o += '\t'; o += c.m.str;
                         o += '\t'; put_int(c.m.modpos);
-                        o += '\t'; append_py_repr(o, c.score);
+                        o += '\t'; nmsearch::append_py_repr(o, c.score);
                         o += '\t'; put_int(c.model.n_mod());
                         o += '\t'; put_int(c.model.n_nomod());
                         o += '\t'; o += iupac_of(cst);

@@ -17,6 +17,7 @@
 // (nm_search_run) and, in the CPU tests, against the oracle's scan (nm_search_run_custom).
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <chrono>
 #include <condition_variable>
 #include <cmath>
@@ -700,6 +701,8 @@ struct nm_search_result {
     std::vector<Task> tasks;
     uint64_t rounds = 0, candidates = 0, window_requests = 0;
     uint64_t iterations = 0, spec_hits = 0, spec_misses = 0;     // lock-step iterations; children answered by / asked for despite the speculation
+    std::string gml;                      // nm_search_result_gml: the search graphs as GML text, task after task ...
+    std::vector<uint64_t> gml_off;        // ... [n_tasks + 1]
 };
 
 namespace {
@@ -1389,6 +1392,54 @@ int nm_search_result_export(const nm_search_result *res, uint64_t *node_off, uin
     node_off[res->tasks.size()] = nn;
     edge_off[res->tasks.size()] = ne;
     best_off[res->tasks.size()] = nb;
+    return NM_OK;
+}
+
+// The search graph of every task as the GML text the command line leaves under temp/<bin>/motif_graph_<mod>.gml (find_motifs_bin.py:521-535
+// writes the networkx graph): nodes in insertion order with id, label (the motif without its padding), score, priority, depth, visited; a
+// node's edges in the order they were made; floats as Python's repr.  Task t = (*text)[(*off)[t], (*off)[t + 1]), empty for a task
+// without a result.  Byte for byte what nanomotif_amd.native_search.SearchResults.artifacts builds from nm_search_result_export's arrays.
+int nm_search_result_gml(nm_search_result *res, const char **text, const uint64_t **off, uint64_t *n_off) {
+    if (!res || !text || !off || !n_off) return nm_set_error(NM_EINVAL, "NULL argument");
+    std::string &o = res->gml;
+    o.clear();
+    res->gml_off.assign(res->tasks.size() + 1, 0);
+    const uint32_t W = res->width;
+    auto put_int = [&](long long v) {
+        char b[24];
+        const auto r = std::to_chars(b, b + sizeof b, v);
+        o.append(b, r.ptr);
+    };
+    for (size_t i = 0; i < res->tasks.size(); ++i) {
+        const Task &t = res->tasks[i];
+        res->gml_off[i] = o.size();
+        if (t.result_none) continue;
+        o += "graph [\n  directed 1\n";
+        for (size_t k = 0; k < t.g.nodes.size(); ++k) {
+            const Node &n = t.g.nodes[k];
+            size_t a = 0, b = W;                                        // label: the motif's characters without the '.' at either end
+            while (a < b && n.motif[a] == '.') ++a;
+            while (b > a && n.motif[b - 1] == '.') --b;
+            o += "  node [\n    id "; put_int((long long)k);
+            o += "\n    label \""; o.append(n.motif.data() + a, b - a);
+            o += "\"\n    score "; nmsearch::append_py_repr(o, n.score);
+            o += "\n    priority "; nmsearch::append_py_repr(o, n.priority);
+            o += "\n    depth "; put_int(n.depth);
+            o += "\n    visited "; o += n.visited ? '1' : '0';
+            o += "\n  ]\n";
+        }
+        for (size_t k = 0; k < t.g.nodes.size(); ++k)
+            for (int v : t.g.nodes[k].succ) {
+                o += "  edge [\n    source "; put_int((long long)k);
+                o += "\n    target "; put_int(v);
+                o += "\n  ]\n";
+            }
+        o += "]\n";
+    }
+    res->gml_off.back() = o.size();
+    *text = o.data();
+    *off = res->gml_off.data();
+    *n_off = res->gml_off.size();
     return NM_OK;
 }
 

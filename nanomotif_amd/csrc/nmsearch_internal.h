@@ -3,6 +3,9 @@
 // view of a finished search that post-processing starts from.
 #pragma once
 #include <algorithm>
+#include <charconv>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -13,6 +16,47 @@
 int nm_set_error(int code, const char *fmt, ...);
 
 namespace nmsearch {
+
+// repr(float) of CPython (float_repr_style "short"): the shortest digits that round-trip, fixed notation for decimal exponents -4 .. 15,
+// else d.ddde+XX with at least two exponent digits
+inline void append_py_repr(std::string &out, double x) {
+    if (std::isnan(x)) { out += "nan"; return; }
+    if (std::isinf(x)) { out += x < 0 ? "-inf" : "inf"; return; }
+    char buf[64];
+    const auto r = std::to_chars(buf, buf + sizeof buf - 1, x, std::chars_format::scientific);
+    *r.ptr = '\0';                                                      // (atoi below reads the exponent up to here)
+    const char *p = buf, *end = r.ptr;
+    if (*p == '-') { out += '-'; ++p; }
+    const char *epos = p;
+    while (epos < end && *epos != 'e') ++epos;
+    char digits[32];
+    size_t nd = 0;
+    for (const char *q = p; q < epos; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    const int e = atoi(epos + 1);
+    if (-4 <= e && e < 16) {
+        if (e >= 0) {
+            const size_t ip = (size_t)e + 1;
+            out.append(digits, std::min(nd, ip));
+            if (nd < ip) out.append(ip - nd, '0');
+            out += '.';
+            if (nd > ip) out.append(digits + ip, nd - ip);
+            else out += '0';
+        } else {
+            out += "0.";
+            out.append((size_t)(-e - 1), '0');
+            out.append(digits, nd);
+        }
+    } else {
+        out += digits[0];
+        if (nd > 1) { out += '.'; out.append(digits + 1, nd - 1); }
+        char eb[16];
+        snprintf(eb, sizeof eb, "e%c%02d", e < 0 ? '-' : '+', e < 0 ? -e : e);
+        out += eb;
+    }
+}
+
+
 
 // scipy.special.psi for positive integers (Cephes psi: exact harmonic sum for x <= 10, asymptotic series beyond)
 inline double psi_int(double x) {

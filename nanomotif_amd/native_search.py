@@ -8,6 +8,7 @@ recorded traces)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -110,6 +111,18 @@ class SearchResults:
         ``result(t, full_graph=True)[0].gml_text()`` byte for byte (nodes in node order; a node's edges in the order they were made)."""
         if self.none[t]:
             return None
+        if os.environ.get("NANOMOTIF_PY_GML") != "1":
+            # the text comes from the library, all tasks in one call (nm_search_result_gml; NANOMOTIF_PY_GML=1: built here, as before round 6)
+            if getattr(self, "_gml_native", None) is None:
+                text, off, n_off = C.c_void_p(), C.POINTER(C.c_uint64)(), C.c_uint64(0)
+                with self._close_lock:
+                    if self._handle is None:
+                        raise RuntimeError("the search result has been freed")
+                    _lib.check(self._lib.nm_search_result_gml(self._handle, C.byref(text), C.byref(off), C.byref(n_off)))
+                    offs = np.ctypeslib.as_array(off, shape=(int(n_off.value),)).tolist()
+                    self._gml_native = (C.string_at(text, offs[-1]), offs)
+            blob, offs = self._gml_native
+            return _GmlText(blob[offs[t]:offs[t + 1]].decode("ascii")), None, self.pssms[t]
         if getattr(self, "_gml_cols", None) is None:
             self._gml_cols = (self.score.tolist(), self.priority.tolist(), self.depth.tolist(), self.visited.tolist())
         score, priority, depth, visited = self._gml_cols

@@ -70,7 +70,13 @@ def test_motif_discovery_cli_matches_oracle(tmp_path):
     assert open(tmp + "/out_regular_start/bin-motifs.tsv").read() == got
     # the five precleanup tables of every task are formatted natively (nm_post_tables); NANOMOTIF_PY_TABLES=1: by postprocess.format_motifs
     # from row objects, as before round 6 — the same files, byte for byte
-    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_py_tables", "-t", "1"], env_extra={"NANOMOTIF_PY_TABLES": "1"})
+    _run_cli(tmp, ["assembly.fasta", "pileup.bed", "-c", "contig_bin.tsv", "--out", "out_py_tables", "-t", "1"],
+             env_extra={"NANOMOTIF_PY_TABLES": "1", "NANOMOTIF_PY_GML": "1"})
+    for b in sorted(os.listdir(tmp + "/out/temp")):                      # (the search graphs: nm_search_result_gml against the Python text)
+        if os.path.isdir(f"{tmp}/out/temp/{b}"):
+            assert sorted(os.listdir(f"{tmp}/out/temp/{b}")) == sorted(os.listdir(f"{tmp}/out_py_tables/temp/{b}"))
+            for name in os.listdir(f"{tmp}/out/temp/{b}"):
+                assert open(f"{tmp}/out/temp/{b}/{name}").read() == open(f"{tmp}/out_py_tables/temp/{b}/{name}").read(), (b, name)
     n_tables = 0
     for task in sorted(os.listdir(tmp + "/out/precleanup-motifs")):
         assert sorted(os.listdir(f"{tmp}/out/precleanup-motifs/{task}")) == sorted(os.listdir(f"{tmp}/out_py_tables/precleanup-motifs/{task}"))

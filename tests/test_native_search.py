@@ -3,6 +3,8 @@ numpy window store must reproduce the reference-recorded search traces (tests/go
 agree with the Python coroutine search on several tasks advanced together, and its digamma must be scipy's bit for bit."""
 import random
 
+import os
+
 import numpy as np
 import pytest
 
@@ -126,8 +128,14 @@ def test_native_lockstep_equals_python_coroutines_bit_for_bit(memo, monkeypatch)
             assert a["depth"] == b["depth"] and a["visited"] == b["visited"]
         assert sorted(graph.edges()) == sorted(wg.edges())
         # the search graph's GML text made straight from the result arrays (what a run with --out writes) = the graph object's
+        # (round 6: the text comes from the library, nm_search_result_gml; NANOMOTIF_PY_GML=1: built in Python from the exported arrays)
         assert res.artifacts(t)[0].gml_text() == graph.gml_text() and graph.gml_text().count("node [") == len(graph.nodes)
         assert res.artifacts(t)[2] is res.pssms[t]
+        os.environ["NANOMOTIF_PY_GML"] = "1"
+        try:
+            assert res.artifacts(t)[0].gml_text() == graph.gml_text()
+        finally:
+            os.environ.pop("NANOMOTIF_PY_GML", None)
 
 
 def test_native_scores_are_scipy_exact():
