@@ -252,3 +252,29 @@ def test_cli_with_the_device_fasta_parser_writes_the_same_files(tmp_path):
         t = json.load(open(str(tmp_path / ("out_" + leg) / "logs" / "timings.motif_discovery.json")))
         assert t["assembly_parser"] == leg
     assert texts["device"] == texts["host"] and texts["device"].count("\n") > 2
+
+
+def test_parser_buffers_pinned_ahead_of_time(tmp_path):
+    """nm_warm_file_parsers pins the parsers' host buffers before they are needed (with or without a ctx; the command line does it on a thread
+    beside the engine's creation): a parse afterwards gives the same table, bad arguments are refused, nm_block_cache(0) releases what is idle."""
+    import ctypes as C
+    from nanomotif_amd import _lib, fasta
+    from nanomotif_amd.engine import ScanEngine
+    lib = _lib.load()
+    size = (32 << 20) + (1 << 16)
+    assert lib.nm_warm_file_parsers(None, size, 3) == 0                       # no ctx: the buffers only
+    eng = ScanEngine(0)
+    try:
+        assert lib.nm_warm_file_parsers(eng.ctx, size, 2) == 0                # with a ctx: + one transfer each way on its copy stream
+        assert lib.nm_warm_file_parsers(eng.ctx, size, 9) != 0 and b"at most 8" in lib.nm_last_error()
+        assert lib.nm_warm_file_parsers(eng.ctx, 1 << 30, 1) != 0
+        path = str(tmp_path / "a.fasta")
+        with open(path, "w") as f:
+            for k in range(20):
+                f.write(f">c{k} x\n" + "ACGTTGCAAC" * (50 + k) + "\n")
+        a = fasta.DeviceAssembly(eng, path)
+        assert list(a)[:3] == ["c0", "c1", "c2"] and a.length("c19") == 10 * 69 and bytes(a["c0"][:10]) == b"ACGTTGCAAC"
+        a.close()
+    finally:
+        eng.close()
+    assert lib.nm_block_cache(0, 0, None) == 0                                # (no cache installed: releases the idle pinned buffers, no error)
