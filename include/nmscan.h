@@ -78,7 +78,8 @@ int nm_block_cache(int enable, uint64_t max_idle_bytes, uint64_t stats[4]);
  * transfer of a stream 7 - 17 ms (tools/alloc_costs_probe.hip): this call pays both ahead of time — `count` buffers of `bytes_each` pinned
  * and parked in the cache, one small transfer each way on the copy stream — e.g. on the thread that created the ctx, while the caller is
  * still busy elsewhere.  ctx NULL: the buffers only (any thread, any time after the library is loaded: the command line pins them on a
- * second thread while the first one creates the ctx, beside the interpreter's imports).  Purely a warm-up: the parsers work without it. */
+ * second thread while the first one creates the ctx, beside the interpreter's imports — for device 0: the buffers are pinned for the calling
+ * thread's current device).  Purely a warm-up: the parsers work without it. */
 int nm_warm_file_parsers(nm_ctx *ctx, uint64_t bytes_each, uint32_t count);
 
 /* Create / destroy an engine bound to HIP device `device`. */

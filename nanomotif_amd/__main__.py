@@ -26,9 +26,11 @@ def _start_the_engine_early():
         try:
             lib = _lib.load()
             # the file parsers' three pinned buffers (32 MB + 64 KB each, 16 ms to pin) on a thread of their own, beside the streams of the ctx
-            pin = threading.Thread(target=lambda: lib.nm_warm_file_parsers(None, (32 << 20) + (1 << 16), 3), name="nm-pin-early", daemon=True)
-            pin.start()
-            _lib.early_pin_thread = pin
+            # (without a ctx the buffers are pinned for the thread's current device, which is device 0: another --device pins its own later)
+            if device == 0:
+                pin = threading.Thread(target=lambda: lib.nm_warm_file_parsers(None, (32 << 20) + (1 << 16), 3), name="nm-pin-early", daemon=True)
+                pin.start()
+                _lib.early_pin_thread = pin
             cache_gb = float(os.environ.get("NANOMOTIF_BLOCK_CACHE_GB", "16"))
             if cache_gb > 0 and lib.nm_block_cache(1, int(cache_gb * (1 << 30)), None) != 0:
                 return

@@ -140,10 +140,10 @@ int cache_free(void *, void *ptr) { return g_cache.release(ptr); }
 
 // ---- pinned host buffers of the file parsers (nmres.h)
 struct PinnedCache {
-    struct Buf { void *p; size_t size; };
+    struct Buf { void *p; size_t size; int device; };   // device: the current device of the thread that pinned it (the mapping is made for that one)
     std::mutex mu;
     std::vector<Buf> idle;
-    std::unordered_map<void *, size_t> out;              // buffers handed out: their true size
+    std::unordered_map<void *, Buf> out;                 // buffers handed out: their true size and device
     size_t idle_bytes = 0;
 };
 PinnedCache g_pinned;
@@ -155,16 +155,20 @@ namespace nmres {
 hipError_t pinned_take(void **p, size_t bytes) {
     *p = nullptr;
     const size_t want = (bytes + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);      // whole MB: the parsers' sizes differ by a few KB
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
     {
         std::lock_guard<std::mutex> lk(g_pinned.mu);
         int best = -1;
         for (int i = 0; i < (int)g_pinned.idle.size(); ++i)
-            if (g_pinned.idle[i].size >= want && g_pinned.idle[i].size <= 2 * want && (best < 0 || g_pinned.idle[i].size < g_pinned.idle[best].size)) best = i;
+            if (g_pinned.idle[i].device == device && g_pinned.idle[i].size >= want && g_pinned.idle[i].size <= 2 * want &&
+                (best < 0 || g_pinned.idle[i].size < g_pinned.idle[best].size))
+                best = i;
         if (best >= 0) {
             const PinnedCache::Buf b = g_pinned.idle[best];
             g_pinned.idle.erase(g_pinned.idle.begin() + best);
             g_pinned.idle_bytes -= b.size;
-            g_pinned.out[b.p] = b.size;
+            g_pinned.out[b.p] = b;
             *p = b.p;
             return hipSuccess;
         }
@@ -178,7 +182,7 @@ hipError_t pinned_take(void **p, size_t bytes) {
         if (e != hipSuccess) return e;
     }
     std::lock_guard<std::mutex> lk(g_pinned.mu);
-    g_pinned.out[q] = want;
+    g_pinned.out[q] = PinnedCache::Buf{q, want, device};
     *p = q;
     return hipSuccess;
 }
@@ -190,11 +194,11 @@ void pinned_give(void *p) {
         std::lock_guard<std::mutex> lk(g_pinned.mu);
         auto it = g_pinned.out.find(p);
         if (it != g_pinned.out.end()) {
-            const size_t size = it->second;
+            const PinnedCache::Buf b = it->second;
             g_pinned.out.erase(it);
-            if (g_pinned.idle_bytes + size <= PINNED_KEEP_BYTES) {
-                g_pinned.idle.push_back({p, size});
-                g_pinned.idle_bytes += size;
+            if (g_pinned.idle_bytes + b.size <= PINNED_KEEP_BYTES) {
+                g_pinned.idle.push_back(b);
+                g_pinned.idle_bytes += b.size;
                 return;
             }
         }

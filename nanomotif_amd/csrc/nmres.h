@@ -8,7 +8,7 @@
 #include <cstddef>
 
 namespace nmres {
-// a pinned buffer of at least `bytes`: an idle cached one (of at most twice the size) or a new hipHostMalloc
+// a pinned buffer of at least `bytes`: an idle cached one (of at most twice the size, pinned under the caller's current device) or a new hipHostMalloc
 hipError_t pinned_take(void **p, size_t bytes);
 // back to the cache; what does not fit (more than PINNED_KEEP_BYTES idle in all) is freed.  The caller has waited for every copy that
 // used the buffer.  nullptr is ignored.
