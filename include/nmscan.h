@@ -37,8 +37,11 @@ typedef enum nm_status {
     NM_ESTATE = -3,      /* call order (e.g. scoring before contigs / pileup were uploaded) */
     NM_ENOMEM = -4,
     NM_ERANGE = -5,      /* motif longer / offset wider than the engine supports (NM_MAX_MOTIF_LEN) */
-    NM_EINDEX = -6       /* nm_bed_*_indexed: the tabix index cannot be used with this pileup (not an index, stale):
+    NM_EINDEX = -6,      /* nm_bed_*_indexed: the tabix index cannot be used with this pileup (not an index, stale):
                             the caller reads the whole file instead; every other failure is final */
+    NM_EDECLINED = -7,   /* a DEVICE parser declines an input its host twin reads (gzip that is not bgzip, rows not grouped by contig, too many
+                            rows in unusual number formats): call nm_bed_open / nm_fasta_open instead — not an error of the file */
+    NM_ESEQUENCE = -8    /* a FASTA record is empty or holds a letter outside ATGCRYSWKMBDHVN: what DNAsequence asserts (seq.py:53-71) */
 } nm_status;
 
 #define NM_MAX_MOTIF_LEN 191  /* stripped motif length; every position within 95 of the modified base */
@@ -566,7 +569,7 @@ int nm_bed_close(nm_bed *bed);
  * does nm_bed_open).  nm_bed_parse_device_indexed reads only the
  * blocks a tabix index names for the wanted contigs (dataload.py:102-152, find_motifs_bin.py:192-312: the reference fetches a
  * bin's contigs through the .tbi) — arguments, stats and errors as nm_bed_open_indexed; rows equal to it bit for bit.
- * Any other gzip stream is refused (NM_EINVAL "compressed input ...": use nm_bed_open).
+ * Any other gzip stream is refused (NM_EDECLINED "compressed input ...": use nm_bed_open; so are a pileup whose rows are not grouped by contig and one with more than a million rows in unusual number formats).
  *   nm_bedcols_shape           rows, contigs, runs of equal contig names; times = {seconds in total, seconds copying the file}
  *   nm_bedcols_phase_seconds   {total, moving the file (pread / memcpy into pinned slabs, H2D issue), waiting for the device inflate of
  *                              a bgzip file's slabs (0 for plain text), the rest: line / field kernels, contig tables}; for a bgzip file
@@ -623,8 +626,8 @@ int nm_fasta_close(nm_fasta *fa);
  * record (bytes that are neither '\n' nor '\r' up to the next header: CRLF files, a last line without newline and lines of
  * any width are the same thing) and write the bases back to back in device memory — byte for byte the array nm_fasta_sequence
  * returns.  Only the header lines come back to the host (record name = first whitespace-delimited token).  Errors as
- * nm_fasta_open: the first record in file order that is empty or holds another letter (NM_EINVAL "DNA sequence must ...").
- * A gzip file is refused (NM_EINVAL "compressed input ...": use nm_fasta_open).
+ * nm_fasta_open: the first record in file order that is empty or holds another letter (NM_ESEQUENCE "DNA sequence must ...").
+ * A gzip file is refused (NM_EDECLINED "compressed input ...": use nm_fasta_open).
  *   nm_fastadev_shape            records, bases; times = {seconds in total, seconds a reader thread spent in pread}
  *   nm_fastadev_record           name, offset into the packed sequence, length
  *   nm_fastadev_table            all records at once: the names back to back, each followed by a NUL, and offsets[n_records + 1]

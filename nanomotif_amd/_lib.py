@@ -47,7 +47,8 @@ loaded_with_torch = False      # torch's HIP runtime was in the process when the
 
 
 class NmScanError(RuntimeError):
-    pass
+    """An error of libnmscan; ``code``: its nm_status (include/nmscan.h) when the library returned one."""
+    code = None
 
 
 def text_of(raw: bytes, what: str) -> str:
@@ -285,8 +286,12 @@ def use_torch_allocator(enable: bool = True):
 
 
 NM_EINDEX = -6          # include/nmscan.h: the tabix index cannot be used with this pileup (read the whole file)
+NM_EDECLINED = -7       # a device parser declines an input its host twin reads (use nm_bed_open / nm_fasta_open)
+NM_ESEQUENCE = -8       # a FASTA record is empty or holds a letter outside the IUPAC nucleotides
 
 
 def check(rc: int):
     if rc != 0:
-        raise NmScanError(f"libnmscan error {rc}: {load().nm_last_error().decode()}")
+        e = NmScanError(f"libnmscan error {rc}: {load().nm_last_error().decode()}")
+        e.code = int(rc)
+        raise e

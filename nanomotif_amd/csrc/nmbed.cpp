@@ -674,8 +674,8 @@ int nm_fasta_open(const char *path, uint32_t threads, nm_fasta **out) {
             const bool empty = recs[i].len == 0;
             delete f;
             release();
-            return empty ? nm_set_error(NM_EINVAL, "DNA sequence must not be empty (record '%s')", name.c_str())
-                         : nm_set_error(NM_EINVAL, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", name.c_str());
+            return empty ? nm_set_error(NM_ESEQUENCE, "DNA sequence must not be empty (record '%s')", name.c_str())
+                         : nm_set_error(NM_ESEQUENCE, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", name.c_str());
         }
     }
     release();

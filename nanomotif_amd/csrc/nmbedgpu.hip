@@ -626,7 +626,7 @@ int nm_bed_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_bedcol
         int rc = map_file(path, &src);
         if (rc) return rc;
         if (!nmbgzf::whole_file(src.z, src.zn, &src.pieces, &src.n))
-            return fail(NM_EINVAL, "%s: compressed input that is not bgzip: the device parser reads plain text and BGZF (use nm_bed_open)", path);
+            return fail(NM_EDECLINED, "%s: compressed input that is not bgzip: the device parser reads plain text and BGZF (use nm_bed_open)", path);
         src.bgzf = true;
     }
     return parse_device_impl(c, path, src, threads, out);
@@ -1373,7 +1373,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
         unsigned int n_runs = 0;
         HIP_TRY(hipMemcpyAsync(&n_runs, d_counters + 1, 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (n_runs > RUN_CAP) return fail(NM_ERANGE, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, RUN_CAP);
+        if (n_runs > RUN_CAP) return fail(NM_EDECLINED, "%s: more than %u runs of contig names (rows not grouped by contig): use nm_bed_open", path, RUN_CAP);
         const double tt0 = alloc_timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
         // (both tables through ONE pinned buffer and the ctx stream: a blocking hipMemcpy into pageable memory was 8 ms each — the runtime
         //  pins the destination on the fly)
@@ -1457,7 +1457,7 @@ int parse_device_impl(nm_ctx *c, const char *path, TextSource &src, uint32_t thr
             fprintf(stderr, "[bed] after the last slab: %u runs and their names %.3f s, the two contig columns allocated %.3f s, filled (kernel + wait) %.3f s, %u rows for the host's routines\n",
                     n_runs, tt1 - tt0, tt2 - tt1, tt3 - tt2, np);
         }
-        if (np > PATCH_CAP) return fail(NM_ERANGE, "%s: more than %u rows need the host parser (unusual mod codes / number formats): use nm_bed_open", path, PATCH_CAP);
+        if (np > PATCH_CAP) return fail(NM_EDECLINED, "%s: more than %u rows need the host parser (unusual mod codes / number formats): use nm_bed_open", path, PATCH_CAP);
         if (np) {
             std::vector<uint4> patch(np);
             HIP_TRY(hipMemcpy(patch.data(), d_patch, (size_t)np * sizeof(uint4), hipMemcpyDeviceToHost));

@@ -285,7 +285,7 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
     uint8_t magic[2] = {0, 0};
     if (n >= 2 && !pread_all(fd, magic, 0, 2)) return fail(NM_EINVAL, "cannot read assembly '%s'", path);
     if (magic[0] == 31 && magic[1] == 139)
-        return fail(NM_EINVAL, "%s: compressed input: the device parser reads plain-text FASTA (use nm_fasta_open)", path);
+        return fail(NM_EDECLINED, "%s: compressed input: the device parser reads plain-text FASTA (use nm_fasta_open)", path);
     nm_fastadev *f = new (std::nothrow) nm_fastadev();
     if (!f) return fail(NM_ENOMEM, "out of host memory");
     f->ctx = c;
@@ -475,8 +475,8 @@ int nm_fasta_parse_device(nm_ctx *c, const char *path, uint32_t threads, nm_fast
         f->names.emplace_back(h, (size_t)(t - h));
         const bool empty = f->offset[i + 1] == f->offset[i];
         if (empty || bad[i])
-            return empty ? fail(NM_EINVAL, "DNA sequence must not be empty (record '%s')", f->names.back().c_str())
-                         : fail(NM_EINVAL, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", f->names.back().c_str());
+            return empty ? fail(NM_ESEQUENCE, "DNA sequence must not be empty (record '%s')", f->names.back().c_str())
+                         : fail(NM_ESEQUENCE, "DNA sequence must be a nucleotide sequence of ATGCRYSWKMBDHVN (record '%s')", f->names.back().c_str());
     }
     f->seconds = now_s() - t_begin;
     if (timing)

@@ -72,7 +72,7 @@ def load_fasta(path, trim_names=False, trim_character=" ") -> dict:
     rc = lib.nm_fasta_open(os.fsencode(str(path)), 0, C.byref(h))
     if rc:
         msg = lib.nm_last_error().decode()
-        if "DNA sequence must" in msg:
+        if rc == _lib.NM_ESEQUENCE:
             raise AssertionError(msg)
         _lib.check(rc)
     try:
@@ -109,7 +109,7 @@ class DeviceAssembly:
         rc = self._lib.nm_fasta_parse_device(engine.ctx, os.fsencode(str(path)), int(threads), C.byref(self._h))
         if rc:
             msg = self._lib.nm_last_error().decode()
-            if "DNA sequence must" in msg:
+            if rc == _lib.NM_ESEQUENCE:
                 raise AssertionError(msg)                      # DNAsequence._check_sequence asserts (seq.py:68-71)
             self._check(rc)
         n, total = C.c_uint32(0), C.c_uint64(0)

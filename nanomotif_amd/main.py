@@ -85,6 +85,7 @@ def find_motifs_bin(args):
             else:
                 dist.init_process_group(backend)
     from ._lib import NmScanError
+    from . import _lib as _lib_codes
     from .engine import ScanEngine
     # The HIP runtime takes 0.1-0.3 s to come up in a fresh process: it does so on a side thread while this one reads the
     # contig-bin table and parses the assembly (native code, the interpreter lock is released).  Fails loudly without a
@@ -230,7 +231,7 @@ def find_motifs_bin(args):
             log.info(f"pileup: {len(table):,} rows parsed on the device ({time.perf_counter() - t0:.1f}s, {table.seconds_reading:.1f}s of it "
                      f"moving the file{how})")
         except NmScanError as e:
-            if "use nm_bed_open" not in str(e):
+            if e.code != _lib_codes.NM_EDECLINED:
                 raise
             log.info(f"pileup: the device parser declined ({e}); using the host parser")
     if table is None:

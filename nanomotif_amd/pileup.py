@@ -233,7 +233,9 @@ class DevicePileup:
                     import logging
                     logging.warning(f"{self.contigs_not_indexed} of {len(plan.contigs)} wanted contigs have no entry in {index_path} (no rows read for them)")
             elif rc != _lib.NM_EINDEX:
-                raise _lib.NmScanError(f"libnmscan error {rc}: {problem}")
+                err = _lib.NmScanError(f"libnmscan error {rc}: {problem}")
+                err.code = int(rc)
+                raise err
             else:
                 import logging
                 self.index_problem = problem
