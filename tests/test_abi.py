@@ -68,3 +68,16 @@ def test_console_entry_point_is_the_references():
     a = create_parser().parse_args(["motif_discovery", "a.fasta", "p.bed", "-c", "cb.tsv", "--out", "o", "-t", "3", "--seed", "7",
                                     "--search_frame_size", "40", "--min_motif_score", "0.2", "--minimum_kl_divergence", "0.05"])
     assert (a.command, a.assembly, a.pileup, a.contig_bin, a.out, a.threads, a.seed) == ("motif_discovery", "a.fasta", "p.bed", "cb.tsv", "o", 3, 7)
+
+
+def test_status_codes_of_the_python_host_are_the_headers():
+    """The nm_status values the Python host compares with (``_lib.NM_E*``; ``NmScanError.code``) are the header's."""
+    import re
+    from nanomotif_amd import _lib
+    text = open(os.path.join(ROOT, "include", "nmscan.h")).read()
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"\b(NM_(?:OK|E[A-Z]+))\s*=\s*(-?\d+)", text))
+    assert enum["NM_OK"] == 0 and len(set(enum.values())) == len(enum) >= 9
+    for name in ("NM_EINDEX", "NM_EDECLINED", "NM_ESEQUENCE"):
+        assert getattr(_lib, name) == enum[name], name
+    e = _lib.NmScanError("x")
+    assert e.code is None
